@@ -1,0 +1,281 @@
+"""ORACLE -- test infrastructure only.  NOT part of the product.
+
+CPU restatement of the LinkTeller influence-analysis hot path, written from the
+reference's behaviour (citations are ``file:line`` relative to the reference tree).
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module, and only as the checker / reported baseline -- never as the thing
+that is shipped or measured as the product.  ``linkteller_amd`` must never import it.
+
+Parity pin: the reference holds no tests / golden vectors for this path (SURVEY.md
+section 4), so this restatement is pinned against outputs of the *reference itself*,
+imported in the build container by ``tests/golden/generate_golden.py``; the resulting
+vectors are committed as ``tests/golden/*.npz`` and ``tests/test_oracle_golden.py``
+checks every function below against them (bit-exact for the integer work and for the
+fp32/fp64 op sequence, which uses the same ``torch.mm`` / ``torch.spmm`` calls).
+
+Third-party arithmetic under the path (unpinned by the reference, which has no
+requirements file): ``torch.mm`` / ``torch.spmm`` (PyTorch), ``sklearn.metrics``.
+
+The op sequence is kept *verbatim* (including the loop-invariant baseline forward that
+the reference recomputes per probe and the per-pair ``.norm().item()``) so that timing
+this module is a fair "reference CPU path" baseline.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+
+# --------------------------------------------------------------------------------------
+# a1: adjacency normaliser ``FirstOrderGCN``                    utils/load.py:572-578
+# --------------------------------------------------------------------------------------
+def first_order_gcn(adj):
+    """A_hat = I + D^-1/2 A D^-1/2, D = row sums, inf -> 0.  Returns scipy COO float64.
+
+    utils/load.py:572-578 (``gcn``), selected by ``fetch_normalization('FirstOrderGCN')``
+    at utils/load.py:617-627.
+    """
+    adj = sp.coo_matrix(adj)
+    row_sum = np.array(adj.sum(1))
+    with np.errstate(divide="ignore"):
+        d_inv_sqrt = np.power(row_sum, -0.5).flatten()
+    d_inv_sqrt[np.isinf(d_inv_sqrt)] = 0.0
+    d_mat = sp.diags(d_inv_sqrt)
+    return (sp.eye(adj.shape[0]) + d_mat.dot(adj).dot(d_mat)).tocoo()
+
+
+def aug_normalized_adjacency(adj):
+    """(D+I)^-1/2 (A+I) (D+I)^-1/2 -- the CLI default ``AugNormAdj``, utils/load.py:562-569."""
+    adj = adj + sp.eye(adj.shape[0])
+    adj = sp.coo_matrix(adj)
+    row_sum = np.array(adj.sum(1))
+    with np.errstate(divide="ignore"):
+        d_inv_sqrt = np.power(row_sum, -0.5).flatten()
+    d_inv_sqrt[np.isinf(d_inv_sqrt)] = 0.0
+    d_mat = sp.diags(d_inv_sqrt)
+    return d_mat.dot(adj).dot(d_mat).tocoo()
+
+
+NORMALIZERS = {"FirstOrderGCN": first_order_gcn, "AugNormAdj": aug_normalized_adjacency}
+
+
+# --------------------------------------------------------------------------------------
+# a2: scipy -> torch sparse COO (float32 values, int64 indices)  utils/load.py:552-559
+# --------------------------------------------------------------------------------------
+def to_torch_sparse(sparse_mx, dtype=torch.float32):
+    sparse_mx = sparse_mx.tocoo().astype(np.float32)  # the reference always rounds to f32 first
+    indices = torch.from_numpy(np.vstack((sparse_mx.row, sparse_mx.col)).astype(np.int64))
+    values = torch.from_numpy(sparse_mx.data).to(dtype)
+    return torch.sparse_coo_tensor(indices, values, torch.Size(sparse_mx.shape))
+
+
+# --------------------------------------------------------------------------------------
+# a3/a4: GraphConvolution / GCN forward            gcn/layers.py:30-36, gcn/models.py:19-24
+# --------------------------------------------------------------------------------------
+def graph_convolution(x, adj, weight, bias):
+    support = torch.mm(x, weight)            # layers.py:31
+    output = torch.spmm(adj, support)        # layers.py:32
+    return output + bias if bias is not None else output  # layers.py:33-36
+
+
+def gcn_forward(x, adj, params):
+    """2-layer GCN in eval mode (dropout is the identity, models.py:21): raw logits [N, C]."""
+    h = torch.relu(graph_convolution(x, adj, params["W1"], params["b1"]))   # models.py:20
+    return graph_convolution(h, adj, params["W2"], params["b2"])            # models.py:22
+
+
+def gcn3_forward(x, adj, params):
+    """3-layer variant, gcn/models.py:39-46 (eval mode)."""
+    h = torch.relu(graph_convolution(x, adj, params["W1"], params["b1"]))
+    h = torch.relu(graph_convolution(h, adj, params["W2"], params["b2"]))
+    return graph_convolution(h, adj, params["W3"], params["b3"])
+
+
+# --------------------------------------------------------------------------------------
+# a6: node / pair sampler                                       utils/load.py:304-381
+# --------------------------------------------------------------------------------------
+def degree_thresholds(dataset):
+    """(lo, hi) of utils/load.py:354-372."""
+    if dataset.startswith("twitch"):
+        return (5 if "PTBR" not in dataset else 10), 10
+    if dataset in ("flickr", "ppi") or dataset.startswith("deezer"):
+        return 15, 30
+    if dataset in ("cora"):          # sic: substring test in the reference
+        return 3, 4
+    if dataset in ("citeseer"):
+        return 3, 3
+    if dataset in ("pubmed"):
+        return 10, 10
+    raise NotImplementedError(f"lo and hi for dataset = {dataset} not set!")
+
+
+def sample_subgraph_pairs(dataset, sample_type, adj_csr, n_samples):
+    """``construct_edge_sets_from_random_subgraph`` utils/load.py:338-381.
+
+    Caller seeds ``np.random`` first (attacker.py:45).  Returns
+    ((exist_edges, nonexist_edges), nodes) with pairs as lists of (u, v) in the
+    reference's enumeration order (i < j over ``nodes``; utils/load.py:313-321).
+    """
+    indices, indptr, n_nodes = adj_csr.indices, adj_csr.indptr, adj_csr.shape[0]
+    if sample_type == "unbalanced":
+        indice_all = range(n_nodes)
+    else:
+        deg = np.zeros(n_nodes, dtype=np.int32)               # _get_degree, load.py:329-335
+        for i in range(n_nodes):
+            deg[i] = indptr[i + 1] - indptr[i]
+        lo, hi = degree_thresholds(dataset)
+        indice_all = np.where(deg <= lo)[0] if sample_type == "unbalanced-lo" else np.where(deg >= hi)[0]
+    nodes = np.random.choice(indice_all, n_samples, replace=False)      # load.py:379
+    nbrs = {u: indices[indptr[u]: indptr[u + 1]] for u in nodes}        # load.py:308-310
+    exist, nonexist = [], []
+    for i in range(len(nodes)):
+        for j in range(i + 1, len(nodes)):
+            u, v = nodes[i], nodes[j]
+            (exist if v in nbrs[u] else nonexist).append((u, v))
+    return (exist, nonexist), nodes
+
+
+# --------------------------------------------------------------------------------------
+# a7/a8: the probe primitive and the efficient loop              attacker.py:100-108, 209-245
+# --------------------------------------------------------------------------------------
+def get_gradient_eps_mat(features, adj, params, v, influence, forward=gcn_forward):
+    """attacker.py:100-108 -- verbatim op order, incl. the recomputed baseline forward."""
+    pert_1 = torch.zeros_like(features)
+    pert_1[v] = features[v] * influence
+    grad = (forward(features + pert_1, adj, params) - forward(features, adj, params)) / influence
+    return grad
+
+
+def influence_matrix(features, adj, params, test_nodes, influence, forward=gcn_forward,
+                     probe_range=None):
+    """attacker.py:216-229: influence_val[i][j] = || grad_mat(test_nodes[i])[test_nodes[j]] ||_2.
+
+    ``probe_range`` restricts the outer loop to a slice of probes (used by the bounded
+    cpu_baseline sample); rows outside it stay zero.
+    """
+    n_test = len(test_nodes)
+    influence_val = np.zeros((n_test, n_test))
+    rng = range(n_test) if probe_range is None else probe_range
+    with torch.no_grad():
+        for i in rng:
+            grad_mat = get_gradient_eps_mat(features, adj, params, int(test_nodes[i]), influence, forward)
+            for j in range(n_test):
+                influence_val[i][j] = grad_mat[int(test_nodes[j])].norm().item()
+    return influence_val
+
+
+def pair_scores(influence_val, test_nodes, exist_edges, nonexist_edges):
+    """attacker.py:233-245: score of (u, v) is influence_val[ind[v]][ind[u]] (perturb v, observe u)."""
+    node2ind = {node: i for i, node in enumerate(test_nodes)}
+    norm_exist = [influence_val[node2ind[v]][node2ind[u]] for u, v in exist_edges]
+    norm_nonexist = [influence_val[node2ind[v]][node2ind[u]] for u, v in nonexist_edges]
+    return norm_exist, norm_nonexist
+
+
+# --------------------------------------------------------------------------------------
+# a9: metrics                                                     attacker.py:378-386
+# --------------------------------------------------------------------------------------
+def attack_metrics(norm_exist, norm_nonexist):
+    from sklearn import metrics
+    y = [1] * len(norm_exist) + [0] * len(norm_nonexist)
+    pred = list(norm_exist) + list(norm_nonexist)
+    fpr, tpr, thresholds = metrics.roc_curve(y, pred)
+    precision, recall, thresholds_2 = metrics.precision_recall_curve(y, pred)
+    return dict(y=y, pred=pred, fpr=fpr, tpr=tpr, thresholds=thresholds,
+                precision=precision, recall=recall, thresholds_2=thresholds_2,
+                auc=metrics.auc(fpr, tpr), ap=metrics.average_precision_score(y, pred))
+
+
+def result_filename(dataset, mode, attack_mode, sample_type, n_test, sample_seed,
+                    perturb_type=None, epsilon=None, noise_seed=None):
+    """attacker.py:388-394."""
+    folder = f"eval_{dataset}"
+    if mode == "vanilla-clean":
+        return f"{folder}/{attack_mode}_{sample_type}_{n_test}_{sample_seed}.pt"
+    return (f"{folder}/{attack_mode}_{sample_type}_{perturb_type}_{n_test}_{sample_seed}"
+            f"_eps-{epsilon}_seed-{noise_seed}.pt")
+
+
+# --------------------------------------------------------------------------------------
+# Baseline attacks (LSA2-post / LSA2-attr)                        attacker.py:287-375
+# --------------------------------------------------------------------------------------
+def baseline_attack_scores(vectors, exist_edges, nonexist_edges):
+    """Correlation of mean-centred rows; ``vectors`` = posteriors (attack_mode 'baseline',
+    attacker.py:297-299) or features ('baseline-feat', :300-301).  Formula at :306-312."""
+    mean = torch.mean(vectors, dim=0)
+    dist = vectors - mean
+
+    def corr(u, v):
+        return (torch.dot(dist[u], dist[v]) / torch.norm(dist[u]) / torch.norm(dist[v])).item()
+
+    return [corr(u, v) for u, v in exist_edges], [corr(u, v) for u, v in nonexist_edges]
+
+
+# --------------------------------------------------------------------------------------
+# DP adjacency generation ("next" row f1)                          worker.py:178-335
+# --------------------------------------------------------------------------------------
+def get_noise(noise_type, size, seed, eps=10, delta=1e-5, sensitivity=2):
+    """utils/load.py:27-39."""
+    np.random.seed(seed)
+    if noise_type == "laplace":
+        return np.random.laplace(0, sensitivity / eps, size)
+    if noise_type == "gaussian":
+        c = np.sqrt(2 * np.log(1.25 / delta))
+        return np.random.normal(0, c * sensitivity / eps, size)
+    raise NotImplementedError("noise {} not implemented!".format(noise_type))
+
+
+def _upper_pairs_to_sym(indice, n):
+    """``construct_sparse_mat`` worker.py:178-203: keep (i, j) with i < j, symmetrise."""
+    indice = np.asarray(indice).reshape(-1, 2)
+    keep = indice[:, 0] < indice[:, 1]
+    i, j = indice[keep, 0], indice[keep, 1]
+    mat = sp.csr_matrix((np.ones(i.shape[0], dtype=np.int64), (i, j)), shape=(n, n))
+    return mat + mat.T
+
+
+def perturb_adj_discrete(adj, epsilon, noise_seed):
+    """EdgeRand, worker.py:213-278 (same ``np.random`` draw order)."""
+    s = 2 / (np.exp(epsilon) + 1)
+    n = adj.shape[0]
+    np.random.seed(noise_seed)
+    bernoulli = np.random.binomial(1, s, (n, n))
+    entry = np.asarray(list(zip(*np.where(bernoulli))))
+    dig_1 = np.random.binomial(1, 1 / 2, len(entry))
+    add_mat = _upper_pairs_to_sym(entry[np.where(dig_1 == 1)[0]], n)
+    minus_mat = _upper_pairs_to_sym(entry[np.where(dig_1 == 0)[0]], n)
+    adj_noisy = adj + add_mat - minus_mat
+    adj_noisy.data[np.where(adj_noisy.data == -1)[0]] = 0
+    adj_noisy.data[np.where(adj_noisy.data == 2)[0]] = 1
+    return adj_noisy
+
+
+def perturb_adj_continuous(adj, epsilon, noise_seed, noise_type="laplace", delta=1e-5):
+    """LapGraph, worker.py:281-335: Laplace noise on the strict lower triangle, keep the
+    top-(E + noise) cells, symmetrise.  The reference's 50-way split + argpartition is a
+    top-k selection; this restatement keeps the split so ties resolve identically."""
+    n = adj.shape[0]
+    n_edges = len(adj.data) // 2
+    a = sp.tril(adj, k=-1)
+    eps_1 = epsilon * 0.01
+    eps_2 = epsilon - eps_1
+    noise = get_noise(noise_type, (n, n), noise_seed, eps=eps_2, delta=delta, sensitivity=1)
+    noise *= np.tri(n, n, k=-1, dtype=bool)
+    a = a + noise                                   # dense np.matrix from here on
+    n_keep = n_edges + int(get_noise(noise_type, 1, noise_seed, eps=eps_1, delta=delta, sensitivity=1)[0])
+    a_r = np.asarray(a).ravel()
+    n_splits = 50
+    len_h = len(a_r) // n_splits
+    ind_list = []
+    for i in range(n_splits - 1):
+        ind = np.argpartition(a_r[len_h * i: len_h * (i + 1)], -n_keep)[-n_keep:]
+        ind_list.append(ind + len_h * i)
+    ind = np.argpartition(a_r[len_h * (n_splits - 1):], -n_keep)[-n_keep:]
+    ind_list.append(ind + len_h * (n_splits - 1))
+    ind_subset = np.hstack(ind_list)
+    ind = np.argpartition(a_r[ind_subset], -n_keep)[-n_keep:]
+    idx = ind_subset[ind]
+    row_idx, col_idx = idx // n, idx % n
+    mat = sp.csr_matrix((np.ones(n_keep, dtype=np.int32), (row_idx, col_idx)), shape=(n, n))
+    return mat + mat.T
