@@ -1,0 +1,127 @@
+/*
+ * linkteller_hip.h -- C ABI of the MI355X (gfx950) implementation of LinkTeller's
+ * influence-analysis hot path.
+ *
+ * The reference (AI-secure/LinkTeller) is pure Python/PyTorch and has no FFI/plugin layer
+ * (SURVEY.md section 8b): its "operator interface" for this path is four PyTorch call
+ * sites.  Each entry point below names the reference call site it stands in for
+ * (file:line relative to the reference tree); INTEGRATION.md shows the ctypes stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 (LT_OK) or a negative lt_status; nothing throws across the
+ *     boundary; lt_last_error() returns a thread-local description of the last failure.
+ *   - "device" pointers are borrowed HIP device pointers (e.g. torch tensor data_ptr());
+ *     the caller keeps them alive until the stream has drained.  All matrices are
+ *     row-major fp32 with an explicit leading dimension in elements.
+ *   - kernels are enqueued on the caller's stream (a hipStream_t passed as void*; NULL =
+ *     the default stream) and never synchronise; workspaces are caller-provided so that
+ *     the launch functions are hipGraph-capturable.
+ *   - handles are not thread-safe: one handle per host thread / per rank.
+ */
+#ifndef LINKTELLER_HIP_H
+#define LINKTELLER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LT_ABI_VERSION 1
+
+typedef enum lt_status {
+    LT_OK = 0,
+    LT_ERR_INVALID = -1,     /* bad argument / malformed CSR                          */
+    LT_ERR_HIP = -2,         /* a HIP runtime call failed (message has the HIP error) */
+    LT_ERR_UNSUPPORTED = -3, /* shape outside what the kernels are built for          */
+    LT_ERR_WORKSPACE = -4,   /* caller workspace too small / misaligned               */
+    LT_ERR_NOMEM = -5
+} lt_status;
+
+/* how lt_influence_rows evaluates a probe (all three give the reference's quantity
+ * || (f(X + d*e_v x_v^T) - f(X))[u] ||_2 / d, attacker.py:100-108,227-229)            */
+typedef enum lt_influence_mode {
+    LT_MODE_FULL = 0,   /* every probe: perturbed row GEMV + full SpMM over all N rows + ReLU + W2
+                           + layer-2 SpMM on the observed rows, then the fp32 finite difference */
+    LT_MODE_SPARSE = 1, /* bit-identical to FULL, but only rows whose value can differ from the
+                           baseline (the 1-/2-hop set of the probe) are recomputed             */
+    LT_MODE_DELTA = 2   /* propagates the perturbation itself (piecewise-linear through ReLU):
+                           no cancellation, agrees with an fp64 evaluation of the reference      */
+} lt_influence_mode;
+
+typedef struct lt_graph lt_graph;       /* device-resident normalised adjacency (CSR + CSC) */
+typedef struct lt_baseline lt_baseline; /* unperturbed forward state of a 2-layer GCN       */
+
+const char *lt_last_error(void);
+int lt_abi_version(void);
+/* number of visible HIP devices (0 on a CPU-only box; never initialises a context) */
+int lt_device_count(int *count);
+
+/* ---- graph ------------------------------------------------------------------------------
+ * Stands in for utils/load.py:552-559 (sparse_mx_to_torch_sparse_tensor) + the .cuda() at
+ * worker.py:665-678: takes the normalised adjacency A_hat as HOST CSR (int32 indices,
+ * fp32 values, columns strictly increasing inside each row), validates it, and uploads it
+ * to the current device together with its transpose (CSC) used by the sparse/delta modes. */
+int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, const int32_t *col,
+                    const float *val, lt_graph **out);
+int lt_graph_destroy(lt_graph *g);
+int lt_graph_info(const lt_graph *g, int32_t *n, int64_t *nnz, int32_t *max_row_nnz);
+
+/* ---- dense GEMM C[M,N] = A[M,K] * B[K,N]  (torch.mm at gcn/layers.py:31) ----------------
+ * exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): each output is a k-ordered fmaf chain. */
+int lt_gemm_f32(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                int32_t M, int32_t N, int32_t K, void *stream);
+
+/* ---- SpMM out[n,ncols] = A_hat * S (+ bias) (ReLU)  (torch.spmm + bias at
+ * gcn/layers.py:32-36, F.relu at gcn/models.py:20) ---------------------------------------
+ * ncols % 4 == 0 and ncols <= 256, or ncols <= 8; S/out 16-byte aligned when ncols % 4 == 0.
+ * Row-owned, fixed-order fmaf chains: deterministic and run-to-run reproducible. */
+int lt_spmm_csr_f32(const lt_graph *g, const float *S, int64_t lds, int32_t ncols,
+                    const float *bias_or_null, int32_t relu, float *out, int64_t ldo,
+                    void *stream);
+
+/* ---- 2-layer GCN forward (GCN.forward, gcn/models.py:19-24, eval mode) ------------------
+ * logits[n,C] = A_hat * (relu(A_hat * (X*W1) + b1) * W2) + b2.   H <= 256, C <= 8.
+ * lt_gcn2_workspace_bytes: size of the scratch the call needs (S1 and S2). */
+size_t lt_gcn2_workspace_bytes(int32_t n, int32_t H, int32_t C);
+int lt_gcn2_forward(const lt_graph *g, const float *X, int64_t ldx, int32_t F,
+                    const float *W1, const float *b1, int32_t H,
+                    const float *W2, const float *b2, int32_t C,
+                    float *logits, int64_t ldl, void *workspace, size_t workspace_bytes,
+                    void *stream);
+
+/* ---- baseline state for the probe loop --------------------------------------------------
+ * The reference recomputes model(features, adj) for every probe (attacker.py:106); it is
+ * loop-invariant, so it is computed once here: S1 = X*W1, Z1 = A_hat*S1 + b1,
+ * S2 = relu(Z1)*W2, OUT = A_hat*S2 + b2.  Owns those four device buffers; borrows
+ * X, W1, b1, W2, b2 (needed again by LT_MODE_FULL for the perturbed row X'[v]*W1). */
+int lt_baseline_create(const lt_graph *g, const float *X, int64_t ldx, int32_t F,
+                       const float *W1, const float *b1, int32_t H,
+                       const float *W2, const float *b2, int32_t C,
+                       void *stream, lt_baseline **out);
+/* recompute the four buffers in place (same pointers, e.g. once per benchmark step) */
+int lt_baseline_refresh(lt_baseline *b, void *stream);
+int lt_baseline_destroy(lt_baseline *b);
+/* copies the baseline logits OUT [n, C] (dense, ld = C) to a device buffer */
+int lt_baseline_logits(const lt_baseline *b, float *dst, void *stream);
+
+/* ---- the probe primitive: rows of the influence matrix ----------------------------------
+ * Stands in for Attacker.get_gradient_eps_mat + the inner j-loop of
+ * link_prediction_attack_efficient (attacker.py:100-108, 220-229):
+ *   out[i*ldo + j] = || (f(X + delta * e_v x_v^T) - f(X))[u_j] ||_2 / delta,
+ *   v = probe_nodes[i], u_j = observe_nodes[j]
+ * probe_nodes / observe_nodes / out are device pointers.  One call handles any n_probe
+ * (internally chunked so the workspace stays bounded); no host synchronisation. */
+size_t lt_influence_workspace_bytes(const lt_baseline *b, int32_t n_probe, int32_t n_obs,
+                                    int32_t mode);
+int lt_influence_rows(const lt_baseline *b, const int32_t *probe_nodes, int32_t n_probe,
+                      const int32_t *observe_nodes, int32_t n_obs, float delta, int32_t mode,
+                      float *out, int64_t ldo, void *workspace, size_t workspace_bytes,
+                      void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LINKTELLER_HIP_H */

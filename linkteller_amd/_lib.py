@@ -1,0 +1,90 @@
+"""ctypes binding of ``liblinkteller_hip.so`` (the C ABI declared in include/linkteller_hip.h).
+
+There is deliberately no CPU fallback: every compute entry point of this package goes through
+this library, and loading fails loudly if it has not been built (``python -c "import
+__graft_entry__ as g; g.build()"`` or ``make -C linkteller_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblinkteller_hip.so")
+
+LT_OK = 0
+MODE_FULL, MODE_SPARSE, MODE_DELTA = 0, 1, 2
+MODES = {"full": MODE_FULL, "sparse": MODE_SPARSE, "delta": MODE_DELTA}
+
+
+class LinkTellerHipError(RuntimeError):
+    """A negative lt_status came back across the C ABI (mapped to RuntimeError)."""
+
+
+_lib = None
+
+# name -> (restype, argtypes); must list every symbol include/linkteller_hip.h declares
+SIGNATURES = {
+    "lt_last_error": (C.c_char_p, []),
+    "lt_abi_version": (C.c_int, []),
+    "lt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "lt_graph_create": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.POINTER(C.c_void_p)]),
+    "lt_graph_destroy": (C.c_int, [C.c_void_p]),
+    "lt_graph_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                                C.POINTER(C.c_int32)]),
+    "lt_gemm_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                              C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "lt_spmm_csr_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32,
+                                  C.c_void_p, C.c_int64, C.c_void_p]),
+    "lt_gcn2_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "lt_gcn2_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
+                                  C.c_void_p, C.c_size_t, C.c_void_p]),
+    "lt_baseline_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                     C.POINTER(C.c_void_p)]),
+    "lt_baseline_refresh": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lt_baseline_destroy": (C.c_int, [C.c_void_p]),
+    "lt_baseline_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lt_influence_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "lt_influence_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
+                                    C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+}
+
+
+def lib():
+    """The loaded library (loads on first use; raises if the shared object is missing)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LinkTellerHipError(
+                f"{LIB_PATH} not found: the HIP extension is not built.  Build it with "
+                f"`make -C {os.path.join(_HERE, 'csrc')}` (needs hipcc); there is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status: int, what: str = ""):
+    if status != LT_OK:
+        msg = lib().lt_last_error().decode("utf-8", "replace")
+        raise LinkTellerHipError(f"{what or 'liblinkteller_hip'} failed with status {status}: {msg}")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(lib().lt_device_count(C.byref(n)), "lt_device_count")
+    return n.value
+
+
+def require_gpu():
+    """Fail loudly when there is nothing to run on (no silent eager/CPU path)."""
+    import torch
+    if not torch.cuda.is_available() or device_count() == 0:
+        raise LinkTellerHipError("no HIP device visible: linkteller_amd runs its hot path only on an "
+                                 "MI355X-class GPU through liblinkteller_hip.so (no CPU fallback)")

@@ -1,0 +1,140 @@
+// liblinkteller_hip: error plumbing + the device-resident graph handle.
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "lt_internal.h"
+
+static thread_local char g_err[512] = "";
+
+int lt_set_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char *lt_last_error(void) { return g_err; }
+extern "C" int lt_abi_version(void) { return LT_ABI_VERSION; }
+
+extern "C" int lt_device_count(int *count) {
+    LT_REQUIRE(count != nullptr, "lt_device_count: count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // clear the sticky "no device" state
+        n = 0;
+    }
+    *count = n;
+    return LT_OK;
+}
+
+static void free_graph(lt_graph *g) {
+    if (!g) return;
+    (void)hipFree(g->rowptr);
+    (void)hipFree(g->col);
+    (void)hipFree(g->val);
+    (void)hipFree(g->tptr);
+    (void)hipFree(g->trow);
+    (void)hipFree(g->tval);
+    delete g;
+}
+
+extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, const int32_t *col,
+                               const float *val, lt_graph **out) {
+    LT_REQUIRE(out != nullptr, "lt_graph_create: out is NULL");
+    *out = nullptr;
+    LT_REQUIRE(n >= 0 && nnz >= 0, "lt_graph_create: negative size (n=%d nnz=%lld)", n, (long long)nnz);
+    LT_REQUIRE(nnz < (int64_t)INT32_MAX, "lt_graph_create: nnz=%lld does not fit int32 row pointers", (long long)nnz);
+    LT_REQUIRE(rowptr != nullptr, "lt_graph_create: rowptr is NULL");
+    LT_REQUIRE(nnz == 0 || (col != nullptr && val != nullptr), "lt_graph_create: col/val is NULL");
+    LT_REQUIRE(rowptr[0] == 0, "lt_graph_create: rowptr[0]=%d, expected 0", rowptr[0]);
+    LT_REQUIRE((int64_t)rowptr[n] == nnz, "lt_graph_create: rowptr[n]=%d != nnz=%lld", rowptr[n], (long long)nnz);
+
+    // validate + build the transpose on the host (counting sort keeps rows ascending per column)
+    std::vector<int32_t> tptr((size_t)n + 1, 0), trow;
+    std::vector<float> tval;
+    int32_t max_row = 0;
+    for (int32_t r = 0; r < n; ++r) {
+        const int32_t b = rowptr[r], e = rowptr[r + 1];
+        LT_REQUIRE(b <= e, "lt_graph_create: rowptr not monotone at row %d", r);
+        if (e - b > max_row) max_row = e - b;
+        for (int32_t k = b; k < e; ++k) {
+            const int32_t c = col[k];
+            LT_REQUIRE(c >= 0 && c < n, "lt_graph_create: column %d out of range at row %d", c, r);
+            LT_REQUIRE(k == b || col[k - 1] < c,
+                       "lt_graph_create: columns of row %d are not strictly increasing", r);
+            tptr[(size_t)c + 1]++;
+        }
+    }
+    int32_t max_col = 0;
+    for (int32_t c = 0; c < n; ++c) {
+        if (tptr[(size_t)c + 1] > max_col) max_col = tptr[(size_t)c + 1];
+        tptr[(size_t)c + 1] += tptr[c];
+    }
+    try {
+        trow.resize((size_t)nnz);
+        tval.resize((size_t)nnz);
+    } catch (const std::bad_alloc &) {
+        return lt_set_error(LT_ERR_NOMEM, "lt_graph_create: host allocation of %lld entries failed", (long long)nnz);
+    }
+    {
+        std::vector<int32_t> cursor(tptr.begin(), tptr.end() - 1);
+        for (int32_t r = 0; r < n; ++r)
+            for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+                const int32_t p = cursor[col[k]]++;
+                trow[p] = r;
+                tval[p] = val[k];
+            }
+    }
+
+    lt_graph *g = new (std::nothrow) lt_graph();
+    if (!g) return lt_set_error(LT_ERR_NOMEM, "lt_graph_create: out of host memory");
+    g->n = n;
+    g->nnz = nnz;
+    g->max_row_nnz = max_row;
+    g->max_col_nnz = max_col;
+    const size_t pb = ((size_t)n + 1) * sizeof(int32_t);
+    const size_t ib = (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t);
+    const size_t fb = (size_t)(nnz > 0 ? nnz : 1) * sizeof(float);
+#define G_HIP(call)                                                                        \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            free_graph(g);                                                                 \
+            return lt_set_error(LT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+        }                                                                                  \
+    } while (0)
+    G_HIP(hipMalloc((void **)&g->rowptr, pb));
+    G_HIP(hipMalloc((void **)&g->col, ib));
+    G_HIP(hipMalloc((void **)&g->val, fb));
+    G_HIP(hipMalloc((void **)&g->tptr, pb));
+    G_HIP(hipMalloc((void **)&g->trow, ib));
+    G_HIP(hipMalloc((void **)&g->tval, fb));
+    G_HIP(hipMemcpy(g->rowptr, rowptr, pb, hipMemcpyHostToDevice));
+    G_HIP(hipMemcpy(g->tptr, tptr.data(), pb, hipMemcpyHostToDevice));
+    if (nnz > 0) {
+        G_HIP(hipMemcpy(g->col, col, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+        G_HIP(hipMemcpy(g->val, val, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice));
+        G_HIP(hipMemcpy(g->trow, trow.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+        G_HIP(hipMemcpy(g->tval, tval.data(), (size_t)nnz * sizeof(float), hipMemcpyHostToDevice));
+    }
+#undef G_HIP
+    *out = g;
+    return LT_OK;
+}
+
+extern "C" int lt_graph_destroy(lt_graph *g) {
+    free_graph(g);
+    return LT_OK;
+}
+
+extern "C" int lt_graph_info(const lt_graph *g, int32_t *n, int64_t *nnz, int32_t *max_row_nnz) {
+    LT_REQUIRE(g != nullptr, "lt_graph_info: graph is NULL");
+    if (n) *n = g->n;
+    if (nnz) *nnz = g->nnz;
+    if (max_row_nnz) *max_row_nnz = g->max_row_nnz;
+    return LT_OK;
+}

@@ -1,0 +1,345 @@
+// SpMM, fused GCN layers, the 2-layer forward and the baseline state.
+//   reference call sites: torch.spmm + bias (gcn/layers.py:32-36), F.relu (gcn/models.py:20),
+//   GCN.forward (gcn/models.py:19-24), the loop-invariant model(features, adj) of
+//   attacker.py:106.
+#include <new>
+
+#include "lt_rows.cuh"
+
+#define LT_BLOCK 256
+
+// --------------------------------------------------------------------------------------------
+// SpMM, wide right-hand side: out[r, 0:ncols) = A_hat[r,:] * S (+bias)(relu); 4 columns per lane,
+// LPR lanes per row, 64/LPR rows per wave.  HBM-bound on large graphs: the CSR entries of a row
+// are read once, each gathered S row is a contiguous 16*LPR-byte segment (1 KiB at 256 columns).
+// --------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(LT_BLOCK) void k_spmm_rows(
+    int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const float *__restrict__ S, int lds, int ncols,
+    const float *__restrict__ bias, int relu, float *__restrict__ out, int ldo) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
+    const int gl = lane & (LPR - 1);
+    int r = wave * RPW + lane / LPR;
+    if (LPR == 64) r = __builtin_amdgcn_readfirstlane(r);
+    if (r >= n) return;
+    const int coff = 4 * gl;
+    const bool active = coff < ncols;
+    const f32x4 acc = row_dot(col, val, rowptr[r], rowptr[r + 1], S, lds, coff, active, -1, nullptr);
+    if (!active) return;
+    f32x4 o = acc;
+    if (bias) {
+        const f32x4 b = ld4(bias + coff);
+        o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+    }
+    if (relu) {
+        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    }
+    *reinterpret_cast<f32x4 *>(out + (size_t)r * ldo + coff) = o;
+}
+
+// SpMM, narrow right-hand side (ncols <= 8), 8 lanes per row (the layer-2 shape).
+template <int CP>
+__global__ __launch_bounds__(LT_BLOCK) void k_spmm_narrow(
+    int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const float *__restrict__ T, int ldt, int C,
+    const float *__restrict__ bias, int relu, float *__restrict__ out, int ldo) {
+    const int gid = (blockIdx.x * LT_BLOCK + threadIdx.x) / LT_L2_LANES;
+    const int q = threadIdx.x & (LT_L2_LANES - 1);
+    if (gid >= n) return;  // whole 8-lane groups exit together
+    float acc[CP];
+    row2_dot<CP>(col, val, rowptr[gid], rowptr[gid + 1], q, C,
+                 [&](int c, int) { return T + (size_t)c * ldt; }, acc);
+    if (q == 0) {
+#pragma unroll
+        for (int c = 0; c < CP; ++c)
+            if (c < C) {
+                float o = acc[c];
+                if (bias) o += bias[c];
+                if (relu) o = fmaxf(o, 0.f);
+                out[(size_t)gid * ldo + c] = o;
+            }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Fused layer 1 for every row: acc = A_hat[r,:]*S1; Z1[r] = acc + b1 (optional store);
+// S2[r] = relu(Z1[r]) . W2.  H1 never exists in memory.
+// --------------------------------------------------------------------------------------------
+template <int LPR, int CP>
+__global__ __launch_bounds__(LT_BLOCK) void k_layer1(
+    int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const float *__restrict__ S1, int Hp,
+    const float *__restrict__ b1p, const float *__restrict__ W2p, int C,
+    float *__restrict__ Z1, float *__restrict__ S2) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
+    const int gl = lane & (LPR - 1);
+    int r = wave * RPW + lane / LPR;
+    if (LPR == 64) r = __builtin_amdgcn_readfirstlane(r);
+    if (r >= n) return;  // LPR-lane groups exit together; shuffles below stay inside a group
+    const int coff = 4 * gl;
+    const bool active = coff < Hp;
+    const f32x4 acc = row_dot(col, val, rowptr[r], rowptr[r + 1], S1, Hp, coff, active, -1, nullptr);
+    f32x4 b1v = {0.f, 0.f, 0.f, 0.f};
+    float part[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) part[c] = 0.f;
+    if (active) {
+        b1v = ld4(b1p + coff);
+        relu_w2_partial<CP>(acc, b1v, W2p + (size_t)coff * C, C, part);
+        if (Z1) {
+            f32x4 z = {acc.x + b1v.x, acc.y + b1v.y, acc.z + b1v.z, acc.w + b1v.w};
+            *reinterpret_cast<f32x4 *>(Z1 + (size_t)r * Hp + coff) = z;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CP; ++c) part[c] = group_sum<LPR>(part[c]);
+    if (gl == 0) {
+#pragma unroll
+        for (int c = 0; c < CP; ++c)
+            if (c < C) S2[(size_t)r * C + c] = part[c];
+    }
+}
+
+// Layer 2 for every row: OUT[r] = A_hat[r,:]*S2 + b2
+template <int CP>
+__global__ __launch_bounds__(LT_BLOCK) void k_layer2(
+    int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const float *__restrict__ S2, int C,
+    const float *__restrict__ b2, float *__restrict__ OUT) {
+    const int gid = (blockIdx.x * LT_BLOCK + threadIdx.x) / LT_L2_LANES;
+    const int q = threadIdx.x & (LT_L2_LANES - 1);
+    if (gid >= n) return;
+    float acc[CP];
+    row2_dot<CP>(col, val, rowptr[gid], rowptr[gid + 1], q, C,
+                 [&](int c, int) { return S2 + (size_t)c * C; }, acc);
+    if (q == 0) {
+#pragma unroll
+        for (int c = 0; c < CP; ++c)
+            if (c < C) OUT[(size_t)gid * C + c] = acc[c] + b2[c];
+    }
+}
+
+// pad helpers: dst[Hp] = src[H] then zeros; dst[Hp, C] = src[H, C] then zero rows
+__global__ void k_pad_rows(const float *__restrict__ src, int rows, int rows_p, int cols,
+                           float *__restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows_p * cols) return;
+    dst[i] = (i / cols) < rows ? src[i] : 0.f;
+}
+
+// --------------------------------------------------------------------------------------------
+// launch helpers
+// --------------------------------------------------------------------------------------------
+static inline unsigned blocks_for_rows(int n, int rows_per_block) {
+    return (unsigned)((n + rows_per_block - 1) / rows_per_block);
+}
+
+int lt_launch_layer1(const lt_graph *g, const float *S1, int Hp, const float *b1p,
+                     const float *W2p, int C, float *Z1, float *S2, hipStream_t st) {
+    if (g->n == 0) return LT_OK;
+    const int lpr = lt_lpr_for(Hp), cp = lt_cp_for(C);
+    const unsigned grid = blocks_for_rows(g->n, (LT_BLOCK / 64) * (64 / lpr));
+    LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
+        hipLaunchKernelGGL((k_layer1<LPR_, CP_>), dim3(grid), dim3(LT_BLOCK), 0, st, g->n,
+                           g->rowptr, g->col, g->val, S1, Hp, b1p, W2p, C, Z1, S2)));
+    LT_CHECK_LAUNCH();
+    return LT_OK;
+}
+
+int lt_launch_layer2(const lt_graph *g, const float *S2, int C, const float *b2, float *OUT,
+                     hipStream_t st) {
+    if (g->n == 0) return LT_OK;
+    const unsigned grid = blocks_for_rows(g->n, LT_BLOCK / LT_L2_LANES);
+    LT_DISPATCH_CP(lt_cp_for(C),
+        hipLaunchKernelGGL((k_layer2<CP_>), dim3(grid), dim3(LT_BLOCK), 0, st, g->n, g->rowptr,
+                           g->col, g->val, S2, C, b2, OUT));
+    LT_CHECK_LAUNCH();
+    return LT_OK;
+}
+
+extern "C" int lt_spmm_csr_f32(const lt_graph *g, const float *S, int64_t lds, int32_t ncols,
+                               const float *bias, int32_t relu, float *out, int64_t ldo,
+                               void *stream) {
+    LT_REQUIRE(g != nullptr, "lt_spmm_csr_f32: graph is NULL");
+    LT_REQUIRE(ncols > 0, "lt_spmm_csr_f32: ncols=%d", ncols);
+    LT_REQUIRE(S != nullptr && out != nullptr, "lt_spmm_csr_f32: S/out is NULL");
+    LT_REQUIRE(lds >= ncols && ldo >= ncols, "lt_spmm_csr_f32: leading dimension < ncols");
+    LT_REQUIRE(lds < INT32_MAX && ldo < INT32_MAX, "lt_spmm_csr_f32: leading dimension too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (g->n == 0) return LT_OK;
+    if (ncols <= LT_MAX_C && !(ncols % 4 == 0 && lds % 4 == 0 && ldo % 4 == 0)) {
+        const unsigned grid = blocks_for_rows(g->n, LT_BLOCK / LT_L2_LANES);
+        LT_DISPATCH_CP(lt_cp_for(ncols),
+            hipLaunchKernelGGL((k_spmm_narrow<CP_>), dim3(grid), dim3(LT_BLOCK), 0, st, g->n,
+                               g->rowptr, g->col, g->val, S, (int)lds, ncols, bias, relu, out,
+                               (int)ldo));
+        LT_CHECK_LAUNCH();
+        return LT_OK;
+    }
+    if (ncols % 4 != 0 || ncols > LT_MAX_H)
+        return lt_set_error(LT_ERR_UNSUPPORTED,
+                            "lt_spmm_csr_f32: ncols=%d (need ncols %% 4 == 0 and <= %d, or <= %d)",
+                            ncols, LT_MAX_H, LT_MAX_C);
+    LT_REQUIRE(lds % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)S % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+                   (!bias || (uintptr_t)bias % 16 == 0),
+               "lt_spmm_csr_f32: wide path needs 16-byte aligned S/out/bias and ld %% 4 == 0");
+    const int lpr = lt_lpr_for(ncols);
+    const unsigned grid = blocks_for_rows(g->n, (LT_BLOCK / 64) * (64 / lpr));
+    LT_DISPATCH_LPR(lpr,
+        hipLaunchKernelGGL((k_spmm_rows<LPR_>), dim3(grid), dim3(LT_BLOCK), 0, st, g->n, g->rowptr,
+                           g->col, g->val, S, (int)lds, ncols, bias, relu, out, (int)ldo));
+    LT_CHECK_LAUNCH();
+    return LT_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// 2-layer forward with caller workspace
+// --------------------------------------------------------------------------------------------
+static int check_dims(const char *who, const lt_graph *g, int F, int H, int C) {
+    LT_REQUIRE(g != nullptr, "%s: graph is NULL", who);
+    LT_REQUIRE(F > 0 && H > 0 && C > 0, "%s: F=%d H=%d C=%d must be positive", who, F, H, C);
+    if (H > LT_MAX_H || C > LT_MAX_C)
+        return lt_set_error(LT_ERR_UNSUPPORTED, "%s: H=%d C=%d (supported: H <= %d, C <= %d)", who, H,
+                            C, LT_MAX_H, LT_MAX_C);
+    return LT_OK;
+}
+
+struct gcn2_ws {
+    float *S1, *S2, *b1p, *W2p;
+    size_t bytes;
+};
+static gcn2_ws carve_gcn2(void *base, int n, int H, int C) {
+    const int Hp = lt_round_up(H, 4);
+    size_t off = 0;
+    gcn2_ws w;
+    char *p = (char *)base;
+    w.S1 = (float *)(p + off);  off += lt_align_up((size_t)n * Hp * sizeof(float), 256);
+    w.S2 = (float *)(p + off);  off += lt_align_up((size_t)n * C * sizeof(float), 256);
+    w.b1p = (float *)(p + off); off += lt_align_up((size_t)Hp * sizeof(float), 256);
+    w.W2p = (float *)(p + off); off += lt_align_up((size_t)Hp * C * sizeof(float), 256);
+    w.bytes = off;
+    return w;
+}
+
+extern "C" size_t lt_gcn2_workspace_bytes(int32_t n, int32_t H, int32_t C) {
+    if (n < 0 || H <= 0 || C <= 0) return 0;
+    return carve_gcn2(nullptr, n, H, C).bytes;
+}
+
+// S1 = X*W1 into an [n, Hp] buffer whose pad columns are zero; b1p / W2p zero-padded copies
+static int prepare_layer_inputs(int n, const float *X, int64_t ldx, int F, const float *W1,
+                                const float *b1, int H, const float *W2, int C, float *S1,
+                                float *b1p, float *W2p, hipStream_t st) {
+    const int Hp = lt_round_up(H, 4);
+    if (Hp != H) LT_HIP(hipMemsetAsync(S1, 0, (size_t)n * Hp * sizeof(float), st));
+    hipLaunchKernelGGL(k_pad_rows, dim3((Hp + 255) / 256), dim3(256), 0, st, b1, H, Hp, 1, b1p);
+    hipLaunchKernelGGL(k_pad_rows, dim3((Hp * C + 255) / 256), dim3(256), 0, st, W2, H, Hp, C, W2p);
+    LT_CHECK_LAUNCH();
+    return lt_launch_gemm(X, ldx, W1, H, S1, Hp, n, H, F, st);
+}
+
+extern "C" int lt_gcn2_forward(const lt_graph *g, const float *X, int64_t ldx, int32_t F,
+                               const float *W1, const float *b1, int32_t H, const float *W2,
+                               const float *b2, int32_t C, float *logits, int64_t ldl,
+                               void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = check_dims("lt_gcn2_forward", g, F, H, C);
+    if (rc) return rc;
+    LT_REQUIRE(X && W1 && b1 && W2 && b2 && logits, "lt_gcn2_forward: NULL tensor pointer");
+    LT_REQUIRE(ldx >= F, "lt_gcn2_forward: ldx=%lld < F=%d", (long long)ldx, F);
+    LT_REQUIRE(ldl == C, "lt_gcn2_forward: logits must be dense (ldl == C)");
+    if (g->n == 0) return LT_OK;
+    if (!workspace || workspace_bytes < lt_gcn2_workspace_bytes(g->n, H, C) || ((uintptr_t)workspace % 256))
+        return lt_set_error(LT_ERR_WORKSPACE, "lt_gcn2_forward: workspace needs %zu bytes, 256-byte aligned",
+                            lt_gcn2_workspace_bytes(g->n, H, C));
+    hipStream_t st = (hipStream_t)stream;
+    gcn2_ws w = carve_gcn2(workspace, g->n, H, C);
+    const int Hp = lt_round_up(H, 4);
+    rc = prepare_layer_inputs(g->n, X, ldx, F, W1, b1, H, W2, C, w.S1, w.b1p, w.W2p, st);
+    if (rc) return rc;
+    rc = lt_launch_layer1(g, w.S1, Hp, w.b1p, w.W2p, C, nullptr, w.S2, st);
+    if (rc) return rc;
+    return lt_launch_layer2(g, w.S2, C, b2, logits, st);
+}
+
+// --------------------------------------------------------------------------------------------
+// baseline state
+// --------------------------------------------------------------------------------------------
+static void free_baseline(lt_baseline *b) {
+    if (!b) return;
+    (void)hipFree(b->S1);
+    (void)hipFree(b->Z1);
+    (void)hipFree(b->S2);
+    (void)hipFree(b->OUT);
+    (void)hipFree(b->b1p);
+    (void)hipFree(b->W2p);
+    delete b;
+}
+
+extern "C" int lt_baseline_refresh(lt_baseline *b, void *stream) {
+    LT_REQUIRE(b != nullptr, "lt_baseline_refresh: baseline is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    if (b->n == 0) return LT_OK;
+    int rc = prepare_layer_inputs(b->n, b->X, b->ldx, b->F, b->W1, b->b1, b->H, b->W2, b->C, b->S1,
+                                  b->b1p, b->W2p, st);
+    if (rc) return rc;
+    rc = lt_launch_layer1(b->g, b->S1, b->Hp, b->b1p, b->W2p, b->C, b->Z1, b->S2, st);
+    if (rc) return rc;
+    return lt_launch_layer2(b->g, b->S2, b->C, b->b2, b->OUT, st);
+}
+
+extern "C" int lt_baseline_create(const lt_graph *g, const float *X, int64_t ldx, int32_t F,
+                                  const float *W1, const float *b1, int32_t H, const float *W2,
+                                  const float *b2, int32_t C, void *stream, lt_baseline **out) {
+    LT_REQUIRE(out != nullptr, "lt_baseline_create: out is NULL");
+    *out = nullptr;
+    int rc = check_dims("lt_baseline_create", g, F, H, C);
+    if (rc) return rc;
+    LT_REQUIRE(X && W1 && b1 && W2 && b2, "lt_baseline_create: NULL tensor pointer");
+    LT_REQUIRE(ldx >= F, "lt_baseline_create: ldx=%lld < F=%d", (long long)ldx, F);
+    lt_baseline *b = new (std::nothrow) lt_baseline();
+    if (!b) return lt_set_error(LT_ERR_NOMEM, "lt_baseline_create: out of host memory");
+    b->g = g; b->n = g->n; b->F = F; b->H = H; b->C = C; b->Hp = lt_round_up(H, 4);
+    b->X = X; b->ldx = ldx; b->W1 = W1; b->b1 = b1; b->W2 = W2; b->b2 = b2;
+    const size_t nh = (size_t)(b->n > 0 ? b->n : 1) * b->Hp * sizeof(float);
+    const size_t nc = (size_t)(b->n > 0 ? b->n : 1) * C * sizeof(float);
+#define B_HIP(call)                                                                         \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            free_baseline(b);                                                               \
+            return lt_set_error(LT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+        }                                                                                   \
+    } while (0)
+    B_HIP(hipMalloc((void **)&b->S1, nh));
+    B_HIP(hipMalloc((void **)&b->Z1, nh));
+    B_HIP(hipMalloc((void **)&b->S2, nc));
+    B_HIP(hipMalloc((void **)&b->OUT, nc));
+    B_HIP(hipMalloc((void **)&b->b1p, (size_t)b->Hp * sizeof(float)));
+    B_HIP(hipMalloc((void **)&b->W2p, (size_t)b->Hp * C * sizeof(float)));
+#undef B_HIP
+    rc = lt_baseline_refresh(b, stream);
+    if (rc) {
+        free_baseline(b);
+        return rc;
+    }
+    *out = b;
+    return LT_OK;
+}
+
+extern "C" int lt_baseline_destroy(lt_baseline *b) {
+    free_baseline(b);
+    return LT_OK;
+}
+
+extern "C" int lt_baseline_logits(const lt_baseline *b, float *dst, void *stream) {
+    LT_REQUIRE(b != nullptr && dst != nullptr, "lt_baseline_logits: NULL argument");
+    if (b->n == 0) return LT_OK;
+    LT_HIP(hipMemcpyAsync(dst, b->OUT, (size_t)b->n * b->C * sizeof(float), hipMemcpyDeviceToDevice,
+                          (hipStream_t)stream));
+    return LT_OK;
+}

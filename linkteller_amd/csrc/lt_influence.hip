@@ -1,0 +1,549 @@
+// The probe primitive: rows of the influence matrix.
+//   reference: Attacker.get_gradient_eps_mat (attacker.py:100-108) + the inner loop of
+//   link_prediction_attack_efficient (attacker.py:220-229):
+//       pert = 0; pert[v] = X[v] * d;  grad = (model(X + pert, A) - model(X, A)) / d
+//       influence_val[i][j] = || grad[test_nodes[j]] ||_2
+//
+// X + pert differs from X in row v only, so S1' = (X + pert) W1 differs from S1 = X W1 in row v
+// only (K1-K3 of SURVEY.md 2.1 vanish).  Three evaluations of the same quantity:
+//
+//   FULL   per probe: s'_v = x'_v W1 (batched MFMA GEMM over the chunk's probes); stage A runs the
+//          fused layer-1 (SpMM over ALL n rows with row v of S1 replaced, +b1, ReLU, .W2) for the
+//          probe; stage B runs layer 2 on the observed rows, subtracts the baseline logits,
+//          divides by d and takes the L2 norm.  P probes share each gathered S1 row in registers.
+//   SPARSE the same arithmetic, restricted to rows that can differ from the baseline: layer 1 on
+//          R_v = {r : A_hat[r,v] != 0}, layer 2 with those rows substituted.  Bit-identical to FULL.
+//   DELTA  propagates dS1[v] = d * S1[v] itself: dZ1[r] = A_hat[r,v] dS1[v]; the ReLU difference is
+//          evaluated piecewise-linearly (no subtraction of nearly equal numbers); layer 2 sums
+//          A_hat[u,r] * dS2[r] over r in R_v.  Free of the fp32 cancellation noise of the
+//          finite difference: agrees with an fp64 run of the reference.
+#include "lt_rows.cuh"
+
+#define LT_BLOCK 256
+#define LT_FULL_P 8                       // probes per wave in the wide FULL stage-A kernel
+#define LT_CHUNK_BUDGET ((size_t)1 << 30)  // bytes of per-probe scratch per chunk
+#define LT_ITEM_GRID 2048                  // blocks of the grid-stride item kernels
+
+// ------------------------------------------------------------------------------------------------
+// FULL: perturbed feature rows  xp = x + x*d  (two roundings, as attacker.py:103,105 do)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_perturb_rows(const float *__restrict__ X, long ldx, int F,
+                               const int32_t *__restrict__ probes, float delta,
+                               float *__restrict__ Xp) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (f >= F) return;
+    const float x = X[(long)probes[b] * ldx + f];
+    const float pert = __fmul_rn(x, delta);
+    Xp[(long)b * F + f] = __fadd_rn(x, pert);
+}
+
+// ------------------------------------------------------------------------------------------------
+// FULL stage A, narrow hidden widths (LPR < 64): one probe per grid.y, pointer-select substitution
+// ------------------------------------------------------------------------------------------------
+template <int LPR, int CP>
+__global__ __launch_bounds__(LT_BLOCK) void k_full_stageA(
+    int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const float *__restrict__ S1, int Hp,
+    const float *__restrict__ b1p, const float *__restrict__ W2p, int C,
+    const int32_t *__restrict__ probes, const float *__restrict__ Sp, float *__restrict__ S2p) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
+    const int gl = lane & (LPR - 1);
+    const int b = blockIdx.y;
+    int r = wave * RPW + lane / LPR;
+    if (LPR == 64) r = __builtin_amdgcn_readfirstlane(r);
+    if (r >= n) return;
+    const int coff = 4 * gl;
+    const bool active = coff < Hp;
+    const f32x4 acc = row_dot(col, val, rowptr[r], rowptr[r + 1], S1, Hp, coff, active, probes[b],
+                              Sp + (size_t)b * Hp);
+    float part[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) part[c] = 0.f;
+    if (active) relu_w2_partial<CP>(acc, ld4(b1p + coff), W2p + (size_t)coff * C, C, part);
+#pragma unroll
+    for (int c = 0; c < CP; ++c) part[c] = group_sum<LPR>(part[c]);
+    if (gl == 0) {
+        float *dst = S2p + ((size_t)b * n + r) * C;
+#pragma unroll
+        for (int c = 0; c < CP; ++c)
+            if (c < C) dst[c] = part[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FULL stage A, wide hidden width (LPR = 64, 128 < Hp <= 256): a wave owns one row and P probes.
+// The row's CSR entries are wave-uniform (scalar loads); each gathered S1 row (one coalesced
+// 16 B/lane load) feeds P independent fmaf chains.  Substitution of the probe's own row is rare,
+// so a 4-entry chunk first tests "does any column equal any of my P probes" with one vector
+// compare per entry and only then takes the per-probe select path.
+// ------------------------------------------------------------------------------------------------
+template <int CP, int P>
+__global__ __launch_bounds__(LT_BLOCK) void k_full_stageA_wide(
+    int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const float *__restrict__ S1, int Hp,
+    const float *__restrict__ b1p, const float *__restrict__ W2p, int C,
+    const int32_t *__restrict__ probes, int nb, const float *__restrict__ Sp,
+    float *__restrict__ S2p) {
+    const int lane = threadIdx.x & 63;
+    const int r = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (LT_BLOCK / 64) + (threadIdx.x >> 6)));
+    const int pb = blockIdx.y * P;
+    if (r >= n) return;
+    const int coff = 4 * lane;
+    const bool active = coff < Hp;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    int vp[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) vp[p] = (pb + p < nb) ? probes[pb + p] : -1;
+    const int vprobe = (lane < P && pb + lane < nb) ? probes[pb + lane] : -1;
+
+    f32x4 acc[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc[p] = zero;
+
+    const int e0 = rowptr[r], e1 = rowptr[r + 1];
+    int e = e0;
+    for (; e + 4 <= e1; e += 4) {
+        int c[4];
+        float a[4];
+        f32x4 s[4];
+        bool hit = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c[k] = col[e + k];
+            a[k] = val[e + k];
+            hit |= (vprobe == c[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = active ? ld4(S1 + (size_t)c[k] * Hp + coff) : zero;
+        if (__ballot(hit) == 0ull) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc[p] = fma4(a[k], s[k], acc[p]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    f32x4 sp = s[k];
+                    if (c[k] == vp[p]) sp = active ? ld4(Sp + (size_t)(pb + p) * Hp + coff) : zero;
+                    acc[p] = fma4(a[k], sp, acc[p]);
+                }
+        }
+    }
+    for (; e < e1; ++e) {
+        const int c = col[e];
+        const float a = val[e];
+        const f32x4 s = active ? ld4(S1 + (size_t)c * Hp + coff) : zero;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            f32x4 sp = s;
+            if (c == vp[p]) sp = active ? ld4(Sp + (size_t)(pb + p) * Hp + coff) : zero;
+            acc[p] = fma4(a, sp, acc[p]);
+        }
+    }
+
+    const f32x4 b1v = active ? ld4(b1p + coff) : zero;
+    float w2[4 * CP];
+#pragma unroll
+    for (int i = 0; i < 4 * CP; ++i) w2[i] = 0.f;
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int c = 0; c < CP; ++c)
+                if (c < C) w2[k * CP + c] = W2p[(size_t)(coff + k) * C + c];
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        // same operation order as relu_w2_partial
+        const float h0 = fmaxf(acc[p].x + b1v.x, 0.f);
+        const float h1 = fmaxf(acc[p].y + b1v.y, 0.f);
+        const float h2 = fmaxf(acc[p].z + b1v.z, 0.f);
+        const float h3 = fmaxf(acc[p].w + b1v.w, 0.f);
+        float part[CP];
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
+            float q = h0 * w2[c];
+            q = fmaf(h1, w2[CP + c], q);
+            q = fmaf(h2, w2[2 * CP + c], q);
+            q = fmaf(h3, w2[3 * CP + c], q);
+            part[c] = group_sum<64>(q);
+        }
+        if (lane == 0 && pb + p < nb) {
+            float *dst = S2p + ((size_t)(pb + p) * n + r) * C;
+#pragma unroll
+            for (int c = 0; c < CP; ++c)
+                if (c < C) dst[c] = part[c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// shared tail: finite difference + L2 norm of one observed row          attacker.py:105-106,227-229
+// ------------------------------------------------------------------------------------------------
+template <int CP>
+__device__ __forceinline__ float diff_norm(const float (&acc)[CP], const float *__restrict__ b2,
+                                           const float *__restrict__ base, int C, float delta) {
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < CP; ++c)
+        if (c < C) {
+            const float o = acc[c] + b2[c];           // layers.py:34
+            const float d = (o - base[c]) / delta;    // attacker.py:105-106
+            ss = fmaf(d, d, ss);
+        }
+    return sqrtf(ss);
+}
+
+// FULL stage B: 8 lanes per (probe, observed node)
+template <int CP>
+__global__ __launch_bounds__(LT_BLOCK) void k_full_stageB(
+    int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const float *__restrict__ S2p, int C,
+    const float *__restrict__ b2, const float *__restrict__ OUT,
+    const int32_t *__restrict__ observe, int n_obs, int nb, float delta, float *__restrict__ out,
+    long ldo) {
+    const long gid = ((long)blockIdx.x * LT_BLOCK + threadIdx.x) / LT_L2_LANES;
+    const int q = threadIdx.x & (LT_L2_LANES - 1);
+    if (gid >= (long)nb * n_obs) return;
+    const int b = (int)(gid / n_obs), j = (int)(gid % n_obs);
+    const int u = observe[j];
+    const float *T = S2p + (size_t)b * n * C;
+    float acc[CP];
+    row2_dot<CP>(col, val, rowptr[u], rowptr[u + 1], q, C,
+                 [&](int c, int) { return T + (size_t)c * C; }, acc);
+    if (q == 0) out[(long)b * ldo + j] = diff_norm<CP>(acc, b2, OUT + (size_t)u * C, C, delta);
+}
+
+// ------------------------------------------------------------------------------------------------
+// SPARSE / DELTA: item lists.  Probe b owns items [off[b], off[b+1]): one per r in R_v (CSC column v)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_probe_offsets(const int32_t *__restrict__ tptr,
+                                                        const int32_t *__restrict__ probes, int nb,
+                                                        int32_t *__restrict__ off) {
+    __shared__ int32_t buf[1024];
+    __shared__ int32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int b = base + threadIdx.x;
+        int d = 0;
+        if (b < nb) {
+            const int v = probes[b];
+            d = tptr[v + 1] - tptr[v];
+        }
+        buf[threadIdx.x] = d;
+        __syncthreads();
+        for (int s = 1; s < 1024; s <<= 1) {
+            const int add = threadIdx.x >= s ? buf[threadIdx.x - s] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (b < nb) off[b] = carry + buf[threadIdx.x] - d;  // exclusive
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += buf[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) off[nb] = carry;
+}
+
+__device__ __forceinline__ int find_probe(const int32_t *__restrict__ off, int nb, int item) {
+    int lo = 0, hi = nb;  // off[lo] <= item < off[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= item) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// position of `c` in the ascending list rows[0..cnt), or -1
+__device__ __forceinline__ int find_row(const int32_t *__restrict__ rows, int cnt, int c) {
+    int lo = 0, hi = cnt;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int v = rows[mid];
+        if (v == c) return mid;
+        if (v < c) lo = mid + 1; else hi = mid;
+    }
+    return -1;
+}
+
+// SPARSE stage A: for every item (b, r in R_v) the layer-1 row with S1[v] replaced -> S2x[item, :]
+// DELTA  stage A: for every item the layer-1 *change*                              -> S2x[item, :]
+template <int LPR, int CP, bool DELTA>
+__global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const int32_t *__restrict__ tptr,
+    const int32_t *__restrict__ trow, const float *__restrict__ tval,
+    const float *__restrict__ S1, const float *__restrict__ Z1, int Hp,
+    const float *__restrict__ b1p, const float *__restrict__ W2p, int C,
+    const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
+    const float *__restrict__ Sp, float delta, float *__restrict__ S2x) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & (LPR - 1);
+    const int coff = 4 * gl;
+    const bool active = coff < Hp;
+    const int total = off[nb];
+    const int wave0 = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
+    const int nwaves = gridDim.x * (LT_BLOCK / 64);
+    for (int base = wave0 * RPW; base < total; base += nwaves * RPW) {
+        const int item = base + lane / LPR;
+        const bool live = item < total;  // group-uniform; dead groups still join the shuffles
+        float part[CP];
+#pragma unroll
+        for (int c = 0; c < CP; ++c) part[c] = 0.f;
+        if (live) {
+            const int b = find_probe(off, nb, item);
+            const int v = probes[b];
+            const int t = tptr[v] + (item - off[b]);
+            const int r = trow[t];
+            if (active) {
+                const f32x4 b1v = ld4(b1p + coff);
+                if (DELTA) {
+                    const float arv = tval[t];
+                    const f32x4 s = ld4(S1 + (size_t)v * Hp + coff);
+                    const f32x4 z = ld4(Z1 + (size_t)r * Hp + coff);
+                    float dh[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float dz = arv * (delta * s[k]);
+                        const float z1 = z[k] + dz;
+                        dh[k] = z[k] > 0.f ? (z1 > 0.f ? dz : -z[k]) : (z1 > 0.f ? z1 : 0.f);
+                    }
+                    const float *w2 = W2p + (size_t)coff * C;
+#pragma unroll
+                    for (int c = 0; c < CP; ++c)
+                        if (c < C) {
+                            float p = dh[0] * w2[c];
+                            p = fmaf(dh[1], w2[C + c], p);
+                            p = fmaf(dh[2], w2[2 * C + c], p);
+                            p = fmaf(dh[3], w2[3 * C + c], p);
+                            part[c] = p;
+                        }
+                } else {
+                    const f32x4 acc = row_dot(col, val, rowptr[r], rowptr[r + 1], S1, Hp, coff, true, v,
+                                              Sp + (size_t)b * Hp);
+                    relu_w2_partial<CP>(acc, b1v, W2p + (size_t)coff * C, C, part);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CP; ++c) part[c] = group_sum<LPR>(part[c]);
+        if (live && gl == 0) {
+#pragma unroll
+            for (int c = 0; c < CP; ++c)
+                if (c < C) S2x[(size_t)item * C + c] = part[c];
+        }
+    }
+}
+
+// SPARSE / DELTA stage B: 8 lanes per (probe, observed node).
+template <int CP, bool DELTA>
+__global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const int32_t *__restrict__ tptr,
+    const int32_t *__restrict__ trow, const float *__restrict__ S2, int C,
+    const float *__restrict__ b2, const float *__restrict__ OUT,
+    const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
+    const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
+    float *__restrict__ out, long ldo) {
+    const long gid = ((long)blockIdx.x * LT_BLOCK + threadIdx.x) / LT_L2_LANES;
+    const int q = threadIdx.x & (LT_L2_LANES - 1);
+    if (gid >= (long)nb * n_obs) return;
+    const int b = (int)(gid / n_obs), j = (int)(gid % n_obs);
+    const int u = observe[j];
+    const int v = probes[b];
+    const int32_t *rv = trow + tptr[v];
+    const int cnt = tptr[v + 1] - tptr[v];
+    const float *items = S2x + (size_t)off[b] * C;
+    const int e0 = rowptr[u], e1 = rowptr[u + 1];
+
+    // does row u touch R_v at all?  (otherwise the perturbed logits ARE the baseline logits)
+    bool touch = false;
+    for (int e = e0 + q; e < e1; e += LT_L2_LANES) touch |= find_row(rv, cnt, col[e]) >= 0;
+    // 8-lane any(): xor butterfly on an int
+    int t = touch ? 1 : 0;
+#pragma unroll
+    for (int m = LT_L2_LANES / 2; m >= 1; m >>= 1) t |= __shfl_xor(t, m, 64);
+    float res = 0.f;
+    if (t) {  // group-uniform
+        float acc[CP];
+        if (DELTA) {
+            // d_out[c] = sum over e with col[e] in R_v of val[e] * dS2[item(col[e]), c]
+            row2_dot<CP>(col, val, e0, e1, q, C,
+                         [&](int c, int) {
+                             const int p = find_row(rv, cnt, c);
+                             return p >= 0 ? items + (size_t)p * C : (const float *)nullptr;
+                         },
+                         acc);
+            float ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < CP; ++c)
+                if (c < C) {
+                    const float d = acc[c] / delta;
+                    ss = fmaf(d, d, ss);
+                }
+            res = sqrtf(ss);
+        } else {
+            row2_dot<CP>(col, val, e0, e1, q, C,
+                         [&](int c, int) {
+                             const int p = find_row(rv, cnt, c);
+                             return p >= 0 ? items + (size_t)p * C : S2 + (size_t)c * C;
+                         },
+                         acc);
+            res = diff_norm<CP>(acc, b2, OUT + (size_t)u * C, C, delta);
+        }
+    }
+    if (q == 0) out[(long)b * ldo + j] = res;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct infl_ws {
+    float *Xp, *Sp, *S2p;  // FULL / SPARSE: perturbed feature rows, their S1 rows; FULL: per-probe S2
+    float *S2x;            // SPARSE / DELTA: per-item values
+    int32_t *off;          // SPARSE / DELTA: item offsets [chunk + 1]
+    size_t bytes;
+    int chunk;
+};
+
+static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mode) {
+    infl_ws w = {};
+    const size_t n = (size_t)b->n, C = (size_t)b->C, Hp = (size_t)b->Hp, F = (size_t)b->F;
+    const size_t maxc = (size_t)(b->g->max_col_nnz > 0 ? b->g->max_col_nnz : 1);
+    size_t per_probe = 0;
+    if (mode == LT_MODE_FULL) per_probe = (n * C + F + Hp) * sizeof(float);
+    else if (mode == LT_MODE_SPARSE) per_probe = (maxc * C + F + Hp) * sizeof(float) + sizeof(int32_t);
+    else per_probe = maxc * C * sizeof(float) + sizeof(int32_t);
+    size_t chunk = LT_CHUNK_BUDGET / (per_probe ? per_probe : 1);
+    if (chunk < 1) chunk = 1;
+    if (chunk > 65535) chunk = 65535;  // grid.y
+    if (chunk > (size_t)(n_probe > 0 ? n_probe : 1)) chunk = (size_t)(n_probe > 0 ? n_probe : 1);
+    w.chunk = (int)chunk;
+    size_t offb = 0;
+    char *p = (char *)base;
+    auto take = [&](size_t bytes) {
+        void *q = p ? (void *)(p + offb) : nullptr;
+        offb += lt_align_up(bytes ? bytes : 1, 256);
+        return q;
+    };
+    if (mode == LT_MODE_FULL || mode == LT_MODE_SPARSE) {
+        w.Xp = (float *)take(chunk * F * sizeof(float));
+        w.Sp = (float *)take(chunk * Hp * sizeof(float));
+    }
+    if (mode == LT_MODE_FULL) w.S2p = (float *)take(chunk * n * C * sizeof(float));
+    if (mode != LT_MODE_FULL) {
+        w.S2x = (float *)take(chunk * maxc * C * sizeof(float));
+        w.off = (int32_t *)take((chunk + 1) * sizeof(int32_t));
+    }
+    w.bytes = offb;
+    return w;
+}
+
+extern "C" size_t lt_influence_workspace_bytes(const lt_baseline *b, int32_t n_probe, int32_t n_obs,
+                                               int32_t mode) {
+    (void)n_obs;
+    if (!b || n_probe < 0 || mode < LT_MODE_FULL || mode > LT_MODE_DELTA) return 0;
+    return carve_infl(nullptr, b, n_probe, mode).bytes;
+}
+
+extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_nodes, int32_t n_probe,
+                                 const int32_t *observe_nodes, int32_t n_obs, float delta,
+                                 int32_t mode, float *out, int64_t ldo, void *workspace,
+                                 size_t workspace_bytes, void *stream) {
+    LT_REQUIRE(b != nullptr, "lt_influence_rows: baseline is NULL");
+    LT_REQUIRE(n_probe >= 0 && n_obs >= 0, "lt_influence_rows: negative count");
+    LT_REQUIRE(mode >= LT_MODE_FULL && mode <= LT_MODE_DELTA, "lt_influence_rows: unknown mode %d", mode);
+    LT_REQUIRE(delta != 0.f && delta == delta, "lt_influence_rows: delta must be a non-zero number");
+    if (n_probe == 0 || n_obs == 0) return LT_OK;
+    LT_REQUIRE(probe_nodes && observe_nodes && out, "lt_influence_rows: NULL pointer");
+    LT_REQUIRE(ldo >= n_obs, "lt_influence_rows: ldo=%lld < n_obs=%d", (long long)ldo, n_obs);
+    LT_REQUIRE(b->n > 0, "lt_influence_rows: empty graph");
+    const size_t need = lt_influence_workspace_bytes(b, n_probe, n_obs, mode);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace % 256))
+        return lt_set_error(LT_ERR_WORKSPACE, "lt_influence_rows: workspace needs %zu bytes, 256-byte aligned", need);
+
+    hipStream_t st = (hipStream_t)stream;
+    const lt_graph *g = b->g;
+    const infl_ws w = carve_infl(workspace, b, n_probe, mode);
+    const int lpr = lt_lpr_for(b->Hp), cp = lt_cp_for(b->C), C = b->C, Hp = b->Hp, n = b->n;
+
+    for (int p0 = 0; p0 < n_probe; p0 += w.chunk) {
+        const int nb = (n_probe - p0) < w.chunk ? (n_probe - p0) : w.chunk;
+        const int32_t *probes = probe_nodes + p0;
+        float *orow = out + (int64_t)p0 * ldo;
+        const long pairs = (long)nb * n_obs;
+        const unsigned gridB = (unsigned)((pairs * LT_L2_LANES + LT_BLOCK - 1) / LT_BLOCK);
+
+        if (mode != LT_MODE_DELTA) {
+            // perturbed rows and their S1 rows: Sp = (X[v] + X[v]*d) W1            attacker.py:101-105
+            hipLaunchKernelGGL(k_perturb_rows, dim3((b->F + 255) / 256, nb), dim3(256), 0, st, b->X,
+                               (long)b->ldx, b->F, probes, delta, w.Xp);
+            LT_CHECK_LAUNCH();
+            if (Hp != b->H) LT_HIP(hipMemsetAsync(w.Sp, 0, (size_t)nb * Hp * sizeof(float), st));
+            int rc = lt_launch_gemm(w.Xp, b->F, b->W1, b->H, w.Sp, Hp, nb, b->H, b->F, st);
+            if (rc) return rc;
+        }
+
+        if (mode == LT_MODE_FULL) {
+            if (lpr == 64) {
+                dim3 grid((n + LT_BLOCK / 64 - 1) / (LT_BLOCK / 64), (nb + LT_FULL_P - 1) / LT_FULL_P);
+                LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_wide<CP_, LT_FULL_P>), grid,
+                                                       dim3(LT_BLOCK), 0, st, n, g->rowptr, g->col,
+                                                       g->val, b->S1, Hp, b->b1p, b->W2p, C, probes, nb,
+                                                       w.Sp, w.S2p));
+            } else {
+                const int rpb = (LT_BLOCK / 64) * (64 / lpr);
+                dim3 grid((n + rpb - 1) / rpb, nb);
+                LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
+                    hipLaunchKernelGGL((k_full_stageA<LPR_, CP_>), grid, dim3(LT_BLOCK), 0, st, n,
+                                       g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p, C, probes,
+                                       w.Sp, w.S2p)));
+            }
+            LT_CHECK_LAUNCH();
+            LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageB<CP_>), dim3(gridB), dim3(LT_BLOCK), 0,
+                                                   st, n, g->rowptr, g->col, g->val, w.S2p, C, b->b2,
+                                                   b->OUT, observe_nodes, n_obs, nb, delta, orow,
+                                                   (long)ldo));
+            LT_CHECK_LAUNCH();
+        } else {
+            hipLaunchKernelGGL(k_probe_offsets, dim3(1), dim3(1024), 0, st, g->tptr, probes, nb, w.off);
+            LT_CHECK_LAUNCH();
+            if (mode == LT_MODE_SPARSE) {
+                LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
+                    hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, false>), dim3(LT_ITEM_GRID),
+                                       dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, g->tptr,
+                                       g->trow, g->tval, b->S1, b->Z1, Hp, b->b1p, b->W2p, C, probes, nb,
+                                       w.off, w.Sp, delta, w.S2x)));
+                LT_CHECK_LAUNCH();
+                LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, false>), dim3(gridB),
+                                                       dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
+                                                       g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
+                                                       nb, w.off, w.S2x, observe_nodes, n_obs, delta,
+                                                       orow, (long)ldo));
+            } else {
+                LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
+                    hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, true>), dim3(LT_ITEM_GRID),
+                                       dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, g->tptr,
+                                       g->trow, g->tval, b->S1, b->Z1, Hp, b->b1p, b->W2p, C, probes, nb,
+                                       w.off, (const float *)nullptr, delta, w.S2x)));
+                LT_CHECK_LAUNCH();
+                LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, true>), dim3(gridB),
+                                                       dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
+                                                       g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
+                                                       nb, w.off, w.S2x, observe_nodes, n_obs, delta,
+                                                       orow, (long)ldo));
+            }
+            LT_CHECK_LAUNCH();
+        }
+    }
+    return LT_OK;
+}

@@ -1,0 +1,79 @@
+// Internal declarations shared by the gfx950 translation units of liblinkteller_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "linkteller_hip.h"
+
+#define LT_MAX_H 256   // hidden width handled by one pass of the row kernels (64 lanes x float4)
+#define LT_MAX_C 8     // classes handled by the fused layer-2 epilogue
+
+struct lt_graph {
+    int32_t n = 0;
+    int64_t nnz = 0;
+    int32_t max_row_nnz = 0;
+    int32_t max_col_nnz = 0;
+    // CSR of A_hat (device)
+    int32_t *rowptr = nullptr;
+    int32_t *col = nullptr;
+    float *val = nullptr;
+    // CSC of A_hat = CSR of A_hat^T (device): for column v, the rows r with A_hat[r,v] != 0
+    int32_t *tptr = nullptr;
+    int32_t *trow = nullptr;
+    float *tval = nullptr;
+};
+
+struct lt_baseline {
+    const lt_graph *g = nullptr;
+    int32_t n = 0, F = 0, H = 0, C = 0;
+    int32_t Hp = 0;  // H rounded up to a multiple of 4: leading dimension of S1 / Z1 (pad columns are 0)
+    // borrowed
+    const float *X = nullptr;
+    int64_t ldx = 0;
+    const float *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
+    // owned (device)
+    float *S1 = nullptr;   // [n, Hp]  X * W1
+    float *Z1 = nullptr;   // [n, Hp]  A_hat * S1 + b1   (pre-activation)
+    float *S2 = nullptr;   // [n, C]   relu(Z1) * W2
+    float *OUT = nullptr;  // [n, C]   A_hat * S2 + b2   (baseline logits)
+    float *b1p = nullptr;  // [Hp]     b1 zero-padded
+    float *W2p = nullptr;  // [Hp, C]  W2 zero-padded rows
+};
+
+int lt_set_error(int code, const char *fmt, ...);
+
+#define LT_HIP(call)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return lt_set_error(LT_ERR_HIP, "%s failed: %s (%s:%d)", #call,                \
+                                hipGetErrorString(e_), __FILE__, __LINE__);                \
+    } while (0)
+
+#define LT_CHECK_LAUNCH()                                                                  \
+    do {                                                                                   \
+        hipError_t e_ = hipGetLastError();                                                 \
+        if (e_ != hipSuccess)                                                              \
+            return lt_set_error(LT_ERR_HIP, "kernel launch failed: %s (%s:%d)",            \
+                                hipGetErrorString(e_), __FILE__, __LINE__);                \
+    } while (0)
+
+#define LT_REQUIRE(cond, ...)                                                              \
+    do {                                                                                   \
+        if (!(cond)) return lt_set_error(LT_ERR_INVALID, __VA_ARGS__);                     \
+    } while (0)
+
+static inline int lt_round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline size_t lt_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- launchers implemented in the kernel translation units --------------------------------
+// layer 1 for all rows: Z1 = A_hat*S1 + b1 (optional store), S2 = relu(Z1)*W2
+int lt_launch_layer1(const lt_graph *g, const float *S1, int Hp, const float *b1p,
+                     const float *W2p, int C, float *Z1_or_null, float *S2, hipStream_t st);
+// layer 2 for all rows: OUT = A_hat*S2 + b2
+int lt_launch_layer2(const lt_graph *g, const float *S2, int C, const float *b2, float *OUT,
+                     hipStream_t st);
+int lt_launch_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
+                   int64_t ldc, int M, int N, int K, hipStream_t st);

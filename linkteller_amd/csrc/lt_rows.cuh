@@ -1,0 +1,143 @@
+// Row-owned CSR device primitives shared by the SpMM, the baseline forward and the probe
+// kernels.  Everything that has to be BIT-IDENTICAL between the baseline and a perturbed
+// forward (so that rows outside a probe's 2-hop set difference to exactly 0, as they do in
+// the reference: SURVEY.md section 7.2-1) goes through the functions in this header:
+//
+//   row_dot<LPR>        : acc = sum_e val[e] * S[col[e], :]  as one k-ordered fmaf chain per column
+//   relu_w2_partial     : this lane's share of relu(acc + b1) . W2
+//   group_sum<LPR>      : fixed butterfly (xor LPR/2 ... 1) -- fp add commutes, so every lane of
+//                         the group ends with the same bits
+//   row2_dot<C>         : layer-2 row (C <= 8 columns): 8 lanes per row, lane q owns entries
+//                         e0+q, e0+q+8, ... (fmaf chain), then the xor 4,2,1 butterfly
+//
+// Built with -ffp-contract=off: the only fused operations are the explicit fmaf calls.
+#pragma once
+#include "lt_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LT_L2_LANES 8  // lanes cooperating on one layer-2 row
+
+__device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+
+__device__ __forceinline__ f32x4 fma4(float a, f32x4 s, f32x4 acc) {
+    acc.x = fmaf(a, s.x, acc.x);
+    acc.y = fmaf(a, s.y, acc.y);
+    acc.z = fmaf(a, s.z, acc.z);
+    acc.w = fmaf(a, s.w, acc.w);
+    return acc;
+}
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float x) {
+#pragma unroll
+    for (int m = LPR / 2; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+    return x;
+}
+
+// Lane-local part of relu(acc + b1) . W2[:, c] for the 4 hidden columns this lane owns.
+// w2 points at W2p[(4*gl) * C]; rows beyond H are zero-padded so inactive columns add 0.
+template <int CP>
+__device__ __forceinline__ void relu_w2_partial(f32x4 acc, f32x4 b1v, const float *w2, int C,
+                                                float (&part)[CP]) {
+    const float h0 = fmaxf(acc.x + b1v.x, 0.f);
+    const float h1 = fmaxf(acc.y + b1v.y, 0.f);
+    const float h2 = fmaxf(acc.z + b1v.z, 0.f);
+    const float h3 = fmaxf(acc.w + b1v.w, 0.f);
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+        float p = 0.f;
+        if (c < C) {
+            p = h0 * w2[c];
+            p = fmaf(h1, w2[C + c], p);
+            p = fmaf(h2, w2[2 * C + c], p);
+            p = fmaf(h3, w2[3 * C + c], p);
+        }
+        part[c] = p;
+    }
+}
+
+// One CSR row against a dense [*, ld] matrix, 4 columns per lane.  `subst_col`/`subst_row`:
+// entries whose column equals subst_col read subst_row instead of S (the perturbed S1 row of a
+// probe); pass subst_col = -1 for none.  Pointer select, so the arithmetic is the same chain.
+__device__ __forceinline__ f32x4 row_dot(const int32_t *__restrict__ col,
+                                         const float *__restrict__ val, int e0, int e1,
+                                         const float *__restrict__ S, int ld, int coff,
+                                         bool active, int subst_col,
+                                         const float *__restrict__ subst_row) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int e = e0;
+    for (; e + 4 <= e1; e += 4) {
+        int c[4];
+        float a[4];
+        f32x4 s[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c[k] = col[e + k];
+            a[k] = val[e + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float *src = (c[k] == subst_col) ? subst_row : S + (size_t)c[k] * ld;
+            s[k] = active ? ld4(src + coff) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = fma4(a[k], s[k], acc);
+    }
+    for (; e < e1; ++e) {
+        const int c = col[e];
+        const float a = val[e];
+        const float *src = (c == subst_col) ? subst_row : S + (size_t)c * ld;
+        const f32x4 s = active ? ld4(src + coff) : f32x4{0.f, 0.f, 0.f, 0.f};
+        acc = fma4(a, s, acc);
+    }
+    return acc;
+}
+
+// Layer-2 row: out[c] = sum_e val[e] * T[col[e]*C + c] for c < C, cooperative over LT_L2_LANES
+// lanes (q = lane id inside the 8-lane group).  `lookup(col) -> const float*` returns the row of
+// T to read for that column, which lets the probe kernels substitute perturbed rows without
+// touching the arithmetic.  All 8 lanes return the full sums.
+template <int CP, typename Lookup>
+__device__ __forceinline__ void row2_dot(const int32_t *__restrict__ col,
+                                         const float *__restrict__ val, int e0, int e1, int q,
+                                         int C, Lookup lookup, float (&out)[CP]) {
+#pragma unroll
+    for (int c = 0; c < CP; ++c) out[c] = 0.f;
+    for (int e = e0 + q; e < e1; e += LT_L2_LANES) {
+        const float a = val[e];
+        const float *t = lookup(col[e], e);
+        if (t == nullptr) continue;  // DELTA mode: entries outside the probe's row set add nothing
+#pragma unroll
+        for (int c = 0; c < CP; ++c)
+            if (c < C) out[c] = fmaf(a, t[c], out[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < CP; ++c) out[c] = group_sum<LT_L2_LANES>(out[c]);
+}
+
+// compile-time dispatch over lanes-per-row / padded class count
+#define LT_DISPATCH_LPR(lpr, ...)                                         \
+    switch (lpr) {                                                        \
+        case 1: { constexpr int LPR_ = 1; __VA_ARGS__; } break;           \
+        case 2: { constexpr int LPR_ = 2; __VA_ARGS__; } break;           \
+        case 4: { constexpr int LPR_ = 4; __VA_ARGS__; } break;           \
+        case 8: { constexpr int LPR_ = 8; __VA_ARGS__; } break;           \
+        case 16: { constexpr int LPR_ = 16; __VA_ARGS__; } break;         \
+        case 32: { constexpr int LPR_ = 32; __VA_ARGS__; } break;         \
+        default: { constexpr int LPR_ = 64; __VA_ARGS__; } break;         \
+    }
+#define LT_DISPATCH_CP(cp, ...)                                           \
+    switch (cp) {                                                         \
+        case 2: { constexpr int CP_ = 2; __VA_ARGS__; } break;            \
+        case 4: { constexpr int CP_ = 4; __VA_ARGS__; } break;            \
+        default: { constexpr int CP_ = 8; __VA_ARGS__; } break;           \
+    }
+
+// lanes-per-row for a padded hidden width Hp (multiple of 4, <= 256): next pow2 >= Hp/4
+static inline int lt_lpr_for(int Hp) {
+    int need = Hp / 4, l = 1;
+    while (l < need) l <<= 1;
+    return l;
+}
+static inline int lt_cp_for(int C) { return C <= 2 ? 2 : (C <= 4 ? 4 : 8); }

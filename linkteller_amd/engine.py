@@ -1,0 +1,140 @@
+"""Thin torch-facing wrappers over the C ABI: torch owns device memory and streams, the kernels
+are liblinkteller_hip's.  Every function enqueues on torch's current stream and never syncs."""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+
+import torch
+
+from . import _lib
+from .graph import HipGraph, as_hip_graph
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise _lib.LinkTellerHipError(f"{name} must live on the GPU (got {t.device}); there is no CPU path")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    # torch's caching allocator returns >= 512-byte aligned blocks
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a @ b on the matrix cores in exact fp32 (reference gcn/layers.py:31 torch.mm)."""
+    a, b = _f32(a, "a"), _f32(b, "b")
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[0]:
+        raise ValueError(f"shape mismatch {tuple(a.shape)} @ {tuple(b.shape)}")
+    m, k = a.shape
+    n = b.shape[1]
+    out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().lt_gemm_f32(a.data_ptr(), k, b.data_ptr(), n, out.data_ptr(), n, m, n, k, _stream()),
+               "lt_gemm_f32")
+    return out
+
+
+def spmm(adj, dense: torch.Tensor, bias=None, relu: bool = False) -> torch.Tensor:
+    """adj @ dense (+ bias)(relu)  (reference gcn/layers.py:32-36 torch.spmm + bias)."""
+    g = as_hip_graph(adj)
+    s = _f32(dense, "dense")
+    if s.dim() != 2 or s.shape[0] != g.n:
+        raise ValueError(f"dense must be [{g.n}, k], got {tuple(s.shape)}")
+    k = s.shape[1]
+    out = torch.empty((g.n, k), dtype=torch.float32, device=s.device)
+    bptr = None
+    if bias is not None:
+        bias = _f32(bias, "bias")
+        bptr = bias.data_ptr()
+    _lib.check(_lib.lib().lt_spmm_csr_f32(g.handle, s.data_ptr(), k, k, bptr, int(bool(relu)),
+                                          out.data_ptr(), k, _stream()), "lt_spmm_csr_f32")
+    return out
+
+
+def gcn2_forward(adj, x, w1, b1, w2, b2) -> torch.Tensor:
+    """Logits of the 2-layer GCN in eval mode (reference gcn/models.py:19-24)."""
+    g = as_hip_graph(adj)
+    x, w1, b1, w2, b2 = (_f32(t, n) for t, n in ((x, "x"), (w1, "W1"), (b1, "b1"), (w2, "W2"), (b2, "b2")))
+    n, f = x.shape
+    h, c = w1.shape[1], w2.shape[1]
+    if n != g.n or w1.shape[0] != f or w2.shape[0] != h or b1.numel() != h or b2.numel() != c:
+        raise ValueError("inconsistent GCN shapes")
+    out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    nbytes = _lib.lib().lt_gcn2_workspace_bytes(n, h, c)
+    ws = _workspace(nbytes, x.device)
+    _lib.check(_lib.lib().lt_gcn2_forward(g.handle, x.data_ptr(), f, f, w1.data_ptr(), b1.data_ptr(), h,
+                                          w2.data_ptr(), b2.data_ptr(), c, out.data_ptr(), c,
+                                          ws.data_ptr(), ws.numel(), _stream()), "lt_gcn2_forward")
+    return out
+
+
+class Baseline:
+    """Unperturbed forward state (S1, Z1, S2, logits) for the probe loop; see lt_baseline_create."""
+
+    def __init__(self, adj, x, w1, b1, w2, b2):
+        self.graph: HipGraph = as_hip_graph(adj)
+        self.x, self.w1, self.b1, self.w2, self.b2 = (
+            _f32(t, n) for t, n in ((x, "x"), (w1, "W1"), (b1, "b1"), (w2, "W2"), (b2, "b2")))
+        n, f = self.x.shape
+        self.n, self.f, self.h, self.c = n, f, self.w1.shape[1], self.w2.shape[1]
+        if n != self.graph.n or self.w1.shape[0] != f or self.w2.shape[0] != self.h:
+            raise ValueError("inconsistent GCN shapes")
+        h = C.c_void_p()
+        _lib.check(_lib.lib().lt_baseline_create(self.graph.handle, self.x.data_ptr(), f, f, self.w1.data_ptr(),
+                                                 self.b1.data_ptr(), self.h, self.w2.data_ptr(),
+                                                 self.b2.data_ptr(), self.c, _stream(), C.byref(h)),
+                   "lt_baseline_create")
+        self._h = h
+        self._finalizer = weakref.finalize(self, _lib.lib().lt_baseline_destroy, h)
+        self._ws = {}
+
+    @property
+    def handle(self):
+        return self._h
+
+    def refresh(self):
+        _lib.check(_lib.lib().lt_baseline_refresh(self._h, _stream()), "lt_baseline_refresh")
+
+    def logits(self) -> torch.Tensor:
+        out = torch.empty((self.n, self.c), dtype=torch.float32, device=self.x.device)
+        _lib.check(_lib.lib().lt_baseline_logits(self._h, out.data_ptr(), _stream()), "lt_baseline_logits")
+        return out
+
+    def influence_rows(self, probe_nodes, observe_nodes, delta: float, mode="full", out=None) -> torch.Tensor:
+        """[n_probe, n_obs] fp32 on the device: ||(f(X + delta e_v x_v^T) - f(X))[u]||_2 / delta."""
+        dev = self.x.device
+        probes = _as_nodes(probe_nodes, self.n, dev, "probe_nodes")
+        obs = _as_nodes(observe_nodes, self.n, dev, "observe_nodes")
+        m = _lib.MODES[mode] if isinstance(mode, str) else int(mode)
+        npb, nob = probes.numel(), obs.numel()
+        if out is None:
+            out = torch.empty((npb, nob), dtype=torch.float32, device=dev)
+        elif out.shape != (npb, nob) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float32 [n_probe, n_obs] tensor")
+        key = (npb, nob, m)
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = _workspace(_lib.lib().lt_influence_workspace_bytes(self._h, npb, nob, m), dev)
+            self._ws = {key: ws}   # keep only the latest: sizes repeat across steps
+        _lib.check(_lib.lib().lt_influence_rows(self._h, probes.data_ptr(), npb, obs.data_ptr(), nob,
+                                                float(delta), m, out.data_ptr(), nob, ws.data_ptr(),
+                                                ws.numel(), _stream()), "lt_influence_rows")
+        return out
+
+
+def _as_nodes(nodes, n, device, name) -> torch.Tensor:
+    if isinstance(nodes, torch.Tensor) and nodes.is_cuda and nodes.dtype == torch.int32:
+        return nodes.contiguous()          # trusted fast path (already validated by the caller)
+    t = torch.as_tensor(nodes).to(torch.int64).reshape(-1).cpu()
+    if t.numel() and (int(t.min()) < 0 or int(t.max()) >= n):
+        raise IndexError(f"{name} out of range [0, {n})")
+    return t.to(torch.int32).to(device)
