@@ -121,6 +121,27 @@ int lt_influence_rows(const lt_baseline *b, const int32_t *probe_nodes, int32_t 
                       float *out, int64_t ldo, void *workspace, size_t workspace_bytes,
                       void *stream);
 
+/* ---- per-kernel timing (used by bench.py for the roofline object) --------------------------
+ * When enabled, every launcher brackets its kernel with a pair of hipEvents on the caller's
+ * stream.  lt_profile_summary synchronises on the recorded events and returns the summed
+ * duration and launch count of one kernel class.  No reference counterpart (the reference only
+ * has wall-clock prints, attacker.py:213,231). */
+typedef enum lt_kernel_id {
+    LT_K_GEMM = 0,        /* k_gemm_f32_mfma                           */
+    LT_K_LAYER1 = 1,      /* k_layer1 (baseline fused SpMM1+ReLU+W2)   */
+    LT_K_LAYER2 = 2,      /* k_layer2 (baseline SpMM2 + b2)            */
+    LT_K_PERTURB = 3,     /* k_perturb_rows                            */
+    LT_K_FULL_A = 4,      /* k_full_stageA[_wide]: batched perturbed SpMM1+ReLU+W2 */
+    LT_K_FULL_B = 5,      /* k_full_stageB: SpMM2 on observed rows + diff + norm    */
+    LT_K_ITEM_A = 6,      /* k_item_stageA (sparse / delta)            */
+    LT_K_ITEM_B = 7,      /* k_item_stageB (sparse / delta)            */
+    LT_K_SPMM = 8,        /* k_spmm_rows / k_spmm_narrow               */
+    LT_K_COUNT = 9
+} lt_kernel_id;
+int lt_profile_enable(int enable);
+int lt_profile_reset(void);
+int lt_profile_summary(int kernel_id, double *total_ms, int64_t *launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,7 +50,12 @@ SIGNATURES = {
     "lt_influence_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "lt_influence_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
                                     C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "lt_profile_enable": (C.c_int, [C.c_int]),
+    "lt_profile_reset": (C.c_int, []),
+    "lt_profile_summary": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
+KERNEL_IDS = {"gemm": 0, "layer1": 1, "layer2": 2, "perturb": 3, "full_stageA": 4, "full_stageB": 5,
+              "item_stageA": 6, "item_stageB": 7, "spmm": 8}
 
 
 def lib():

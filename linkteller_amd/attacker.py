@@ -1,0 +1,147 @@
+"""``Attacker`` -- the reference's attack driver (attacker.py:14-417) on the HIP probe primitive.
+
+Same constructor, method names, prints and result file as the reference, so
+``GCNTrainer.eval_output`` (gcn_trainer.py:320-339) can use it unchanged.  What differs is how
+``influence_val`` is produced: instead of ``n_test`` pairs of full forwards and ``n_test**2``
+``.norm().item()`` host syncs (attacker.py:220-229), one call to ``lt_influence_rows`` fills this
+rank's rows on the device and a single copy brings the matrix back.
+
+Extra, optional ``args`` fields (absent in the reference's namespace -> defaults):
+    influence_mode   'full' (default) | 'sparse' | 'delta'   (see include/linkteller_hip.h)
+"""
+from __future__ import annotations
+
+import os
+import os.path as osp
+import time
+
+import numpy as np
+import torch
+from sklearn import metrics
+
+from . import dist as lt_dist
+from . import engine
+from .sampling import construct_edge_sets_from_random_subgraph
+
+
+class Attacker:
+    def __init__(self, args, model, worker):
+        self.args = args
+        self.dataset = args.dataset
+        self.model = model
+        self.worker = worker
+
+        if args.sample_type == "balanced-full":
+            self.args.n_test = self.worker.n_nodes           # attacker.py:21-22
+
+        if self.dataset.startswith("twitch") or self.dataset.startswith("deezer"):
+            self.features = self.worker.features_2           # attacker.py:24-26
+            self.adj = self.worker.adj_2
+        else:
+            self.features = self.worker.features             # attacker.py:28-30
+            self.adj = self.worker.adj_full
+        self._baseline = None
+        self.influence_val = None
+
+    # ------------------------------------------------------------------------------------------
+    def prepare_test_data(self):
+        """attacker.py:33-48.  'balanced' and 'bfs' cannot run in the reference either (tuple
+        arity / signature mismatches at attacker.py:46-47)."""
+        st = self.args.sample_type
+        if st not in ("unbalanced", "unbalanced-lo", "unbalanced-hi"):
+            raise NotImplementedError(f"sample_type = {st} not implemented!")
+        np.random.seed(self.args.sample_seed)
+        (self.exist_edges, self.nonexist_edges), self.test_nodes = construct_edge_sets_from_random_subgraph(
+            self.dataset, st, self.worker.adj_ori, self.args.n_test)
+        print("generating testing (non-)edge set done!")
+
+    # ------------------------------------------------------------------------------------------
+    def _params(self):
+        sd = self.model.state_dict()
+        try:
+            return [sd[k].detach() for k in ("gc1.weight", "gc1.bias", "gc2.weight", "gc2.bias")]
+        except KeyError as e:
+            raise NotImplementedError(f"the probe kernels need a 2-layer GCN state_dict (missing {e})") from None
+
+    def baseline(self) -> engine.Baseline:
+        """Loop-invariant model(features, adj) of attacker.py:106, computed once."""
+        if self._baseline is None:
+            dev = self.features.device
+            self._baseline = engine.Baseline(self.adj, self.features, *[p.to(dev) for p in self._params()])
+        return self._baseline
+
+    def get_gradient_eps_mat(self, v):
+        """attacker.py:100-108: (model(X + pert_v, A) - model(X, A)) / influence as an [N, C] tensor.
+        Kept for API parity (one probe, all nodes observed); the attack itself uses the batched
+        primitive and never materialises this matrix."""
+        base = self.baseline()
+        delta = float(self.args.influence)
+        x = self.features
+        xp = x.clone()
+        xp[v] = x[v] + x[v] * delta
+        w1, b1, w2, b2 = (p.to(x.device) for p in self._params())
+        out_p = engine.gcn2_forward(base.graph, xp, w1, b1, w2, b2)
+        return (out_p - base.logits()) / delta
+
+    def influence_matrix(self, mode=None) -> np.ndarray:
+        """influence_val[i][j] = ||grad_mat(test_nodes[i])[test_nodes[j]]||_2 (attacker.py:216-229)
+        as float64 [n_test, n_test] on the host.  Probes are sharded over ranks when
+        torch.distributed is initialised (one all-gather of row slabs)."""
+        mode = mode or getattr(self.args, "influence_mode", None) or os.environ.get("LT_INFLUENCE_MODE", "full")
+        nodes = np.asarray(self.test_nodes, dtype=np.int64)
+        rank, ws = lt_dist.world()
+        b, e, _ = lt_dist.shard_bounds(len(nodes), rank, ws)
+        base = self.baseline()
+        local = base.influence_rows(nodes[b:e], nodes, float(self.args.influence), mode)
+        full = lt_dist.all_gather_rows(local, len(nodes))
+        return full.cpu().numpy().astype(np.float64)
+
+    def link_prediction_attack_efficient(self):
+        t = time.time()
+        self.influence_val = influence_val = self.influence_matrix()
+        print(f"time for predicting edges: {time.time() - t}")
+
+        node2ind = np.full(int(max(self.test_nodes)) + 1, -1, dtype=np.int64)
+        node2ind[np.asarray(self.test_nodes, dtype=np.int64)] = np.arange(len(self.test_nodes))
+
+        def scores(pairs):
+            pairs = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+            # perturb v, observe u: influence_val[ind[v]][ind[u]]   (attacker.py:236-245)
+            return influence_val[node2ind[pairs[:, 1]], node2ind[pairs[:, 0]]].tolist()
+
+        self.compute_and_save(scores(self.exist_edges), scores(self.nonexist_edges))
+
+    # ------------------------------------------------------------------------------------------
+    def result_filename(self):
+        a = self.args
+        folder = f"eval_{self.dataset}"
+        if a.mode == "vanilla-clean":                        # attacker.py:391-394
+            name = f"{a.attack_mode}_{a.sample_type}_{a.n_test}_{a.sample_seed}.pt"
+        else:
+            name = (f"{a.attack_mode}_{a.sample_type}_{a.perturb_type}_{a.n_test}_{a.sample_seed}"
+                    f"_eps-{a.epsilon}_seed-{a.noise_seed}.pt")
+        return osp.join(folder, name)
+
+    def compute_and_save(self, norm_exist, norm_nonexist):
+        """attacker.py:378-412: sklearn ROC / PR on the host, same prints, same ``.pt`` schema."""
+        y = [1] * len(norm_exist) + [0] * len(norm_nonexist)
+        pred = list(norm_exist) + list(norm_nonexist)
+
+        fpr, tpr, thresholds = metrics.roc_curve(y, pred)
+        self.auc = metrics.auc(fpr, tpr)
+        print("auc =", self.auc)
+        precision, recall, thresholds_2 = metrics.precision_recall_curve(y, pred)
+        self.ap = metrics.average_precision_score(y, pred)
+        print("ap =", self.ap)
+
+        rank, _ = lt_dist.world()
+        if rank != 0:
+            return
+        filename = self.result_filename()
+        os.makedirs(osp.dirname(filename), exist_ok=True)
+        torch.save({
+            "auc": {"fpr": fpr, "tpr": tpr, "thresholds": thresholds},
+            "pr": {"precision": precision, "recall": recall, "thresholds": thresholds_2},
+            "result": {"y": y, "pred": pred},
+        }, filename)
+        print(f"attack results saved to: {filename}")

@@ -138,3 +138,56 @@ extern "C" int lt_graph_info(const lt_graph *g, int32_t *n, int64_t *nnz, int32_
     if (max_row_nnz) *max_row_nnz = g->max_row_nnz;
     return LT_OK;
 }
+
+// ---- per-kernel event timing ------------------------------------------------------------------
+bool g_lt_profile_on = false;
+namespace {
+struct prof_rec { int id; hipEvent_t a, b; };
+std::vector<prof_rec> g_recs;
+std::vector<hipEvent_t> g_free;
+hipEvent_t g_open[LT_K_COUNT];
+hipEvent_t take_event() {
+    if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+void lt_profile_begin(int id, hipStream_t st) {
+    hipEvent_t e = take_event();
+    (void)hipEventRecord(e, st);
+    g_open[id] = e;
+}
+void lt_profile_end(int id, hipStream_t st) {
+    hipEvent_t e = take_event();
+    (void)hipEventRecord(e, st);
+    g_recs.push_back({id, g_open[id], e});
+}
+
+extern "C" int lt_profile_reset(void) {
+    for (auto &r : g_recs) { g_free.push_back(r.a); g_free.push_back(r.b); }
+    g_recs.clear();
+    return LT_OK;
+}
+extern "C" int lt_profile_enable(int enable) {
+    lt_profile_reset();
+    g_lt_profile_on = enable != 0;
+    return LT_OK;
+}
+extern "C" int lt_profile_summary(int kernel_id, double *total_ms, int64_t *launches) {
+    LT_REQUIRE(kernel_id >= 0 && kernel_id < LT_K_COUNT, "lt_profile_summary: kernel_id=%d", kernel_id);
+    double tot = 0.0;
+    int64_t cnt = 0;
+    for (auto &r : g_recs) {
+        if (r.id != kernel_id) continue;
+        LT_HIP(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        LT_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        tot += ms;
+        ++cnt;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = cnt;
+    return LT_OK;
+}

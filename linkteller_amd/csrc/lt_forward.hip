@@ -144,6 +144,7 @@ int lt_launch_layer1(const lt_graph *g, const float *S1, int Hp, const float *b1
     if (g->n == 0) return LT_OK;
     const int lpr = lt_lpr_for(Hp), cp = lt_cp_for(C);
     const unsigned grid = blocks_for_rows(g->n, (LT_BLOCK / 64) * (64 / lpr));
+    lt_prof_scope prof_(LT_K_LAYER1, st);
     LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
         hipLaunchKernelGGL((k_layer1<LPR_, CP_>), dim3(grid), dim3(LT_BLOCK), 0, st, g->n,
                            g->rowptr, g->col, g->val, S1, Hp, b1p, W2p, C, Z1, S2)));
@@ -155,6 +156,7 @@ int lt_launch_layer2(const lt_graph *g, const float *S2, int C, const float *b2,
                      hipStream_t st) {
     if (g->n == 0) return LT_OK;
     const unsigned grid = blocks_for_rows(g->n, LT_BLOCK / LT_L2_LANES);
+    lt_prof_scope prof_(LT_K_LAYER2, st);
     LT_DISPATCH_CP(lt_cp_for(C),
         hipLaunchKernelGGL((k_layer2<CP_>), dim3(grid), dim3(LT_BLOCK), 0, st, g->n, g->rowptr,
                            g->col, g->val, S2, C, b2, OUT));
@@ -172,6 +174,7 @@ extern "C" int lt_spmm_csr_f32(const lt_graph *g, const float *S, int64_t lds, i
     LT_REQUIRE(lds < INT32_MAX && ldo < INT32_MAX, "lt_spmm_csr_f32: leading dimension too large");
     hipStream_t st = (hipStream_t)stream;
     if (g->n == 0) return LT_OK;
+    lt_prof_scope prof_(LT_K_SPMM, st);
     if (ncols <= LT_MAX_C && !(ncols % 4 == 0 && lds % 4 == 0 && ldo % 4 == 0)) {
         const unsigned grid = blocks_for_rows(g->n, LT_BLOCK / LT_L2_LANES);
         LT_DISPATCH_CP(lt_cp_for(ncols),

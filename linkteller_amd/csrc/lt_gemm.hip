@@ -110,6 +110,7 @@ int lt_launch_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, flo
     if (M == 0 || N == 0) return LT_OK;
     dim3 grid((M + GM_BM - 1) / GM_BM, (N + GM_BN - 1) / GM_BN);
     LT_REQUIRE(grid.y <= 65535u, "lt_gemm_f32: N=%d too large", N);
+    lt_prof_scope prof_(LT_K_GEMM, st);
     hipLaunchKernelGGL(k_gemm_f32_mfma, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, C,
                        (long)ldc, M, N, K);
     LT_CHECK_LAUNCH();

@@ -485,8 +485,9 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
 
         if (mode != LT_MODE_DELTA) {
             // perturbed rows and their S1 rows: Sp = (X[v] + X[v]*d) W1            attacker.py:101-105
+            { lt_prof_scope prof_(LT_K_PERTURB, st);
             hipLaunchKernelGGL(k_perturb_rows, dim3((b->F + 255) / 256, nb), dim3(256), 0, st, b->X,
-                               (long)b->ldx, b->F, probes, delta, w.Xp);
+                               (long)b->ldx, b->F, probes, delta, w.Xp); }
             LT_CHECK_LAUNCH();
             if (Hp != b->H) LT_HIP(hipMemsetAsync(w.Sp, 0, (size_t)nb * Hp * sizeof(float), st));
             int rc = lt_launch_gemm(w.Xp, b->F, b->W1, b->H, w.Sp, Hp, nb, b->H, b->F, st);
@@ -494,6 +495,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
         }
 
         if (mode == LT_MODE_FULL) {
+            { lt_prof_scope prof_(LT_K_FULL_A, st);
             if (lpr == 64) {
                 dim3 grid((n + LT_BLOCK / 64 - 1) / (LT_BLOCK / 64), (nb + LT_FULL_P - 1) / LT_FULL_P);
                 LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_wide<CP_, LT_FULL_P>), grid,
@@ -507,35 +509,40 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                     hipLaunchKernelGGL((k_full_stageA<LPR_, CP_>), grid, dim3(LT_BLOCK), 0, st, n,
                                        g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p, C, probes,
                                        w.Sp, w.S2p)));
-            }
+            } }
             LT_CHECK_LAUNCH();
+            { lt_prof_scope prof_(LT_K_FULL_B, st);
             LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageB<CP_>), dim3(gridB), dim3(LT_BLOCK), 0,
                                                    st, n, g->rowptr, g->col, g->val, w.S2p, C, b->b2,
                                                    b->OUT, observe_nodes, n_obs, nb, delta, orow,
-                                                   (long)ldo));
+                                                   (long)ldo)); }
             LT_CHECK_LAUNCH();
         } else {
             hipLaunchKernelGGL(k_probe_offsets, dim3(1), dim3(1024), 0, st, g->tptr, probes, nb, w.off);
             LT_CHECK_LAUNCH();
             if (mode == LT_MODE_SPARSE) {
+                { lt_prof_scope prof_(LT_K_ITEM_A, st);
                 LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
                     hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, false>), dim3(LT_ITEM_GRID),
                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, g->tptr,
                                        g->trow, g->tval, b->S1, b->Z1, Hp, b->b1p, b->W2p, C, probes, nb,
-                                       w.off, w.Sp, delta, w.S2x)));
+                                       w.off, w.Sp, delta, w.S2x))); }
                 LT_CHECK_LAUNCH();
+                lt_prof_scope prof_(LT_K_ITEM_B, st);
                 LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, false>), dim3(gridB),
                                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
                                                        g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
                                                        nb, w.off, w.S2x, observe_nodes, n_obs, delta,
                                                        orow, (long)ldo));
             } else {
+                { lt_prof_scope prof_(LT_K_ITEM_A, st);
                 LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
                     hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, true>), dim3(LT_ITEM_GRID),
                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, g->tptr,
                                        g->trow, g->tval, b->S1, b->Z1, Hp, b->b1p, b->W2p, C, probes, nb,
-                                       w.off, (const float *)nullptr, delta, w.S2x)));
+                                       w.off, (const float *)nullptr, delta, w.S2x))); }
                 LT_CHECK_LAUNCH();
+                lt_prof_scope prof_(LT_K_ITEM_B, st);
                 LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, true>), dim3(gridB),
                                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
                                                        g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,

@@ -1,0 +1,37 @@
+"""Probe-dimension sharding: row i of the influence matrix depends on probe
+i only, so ranks take contiguous slices of the probe list and one all-gather of the row slabs
+(RCCL over xGMI when the backend is ``nccl``) rebuilds the matrix.  No other collective exists on
+the path.  Works on CPU tensors with ``gloo`` too (that is how the N>1 path is tested without GPUs).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_bounds(n_items: int, rank: int, world_size: int):
+    """[begin, end) of this rank's slice; every rank gets ceil(n/W) slots, the tail is padding."""
+    per = (n_items + world_size - 1) // world_size
+    b = min(rank * per, n_items)
+    return b, min(b + per, n_items), per
+
+
+def all_gather_rows(local_rows: torch.Tensor, n_total: int) -> torch.Tensor:
+    """local_rows: this rank's [end-begin, n_obs] slab (may be empty).  Returns [n_total, n_obs]
+    on every rank.  One ``all_gather_into_tensor`` on a padded contiguous slab."""
+    rank, ws = world()
+    if ws == 1:
+        return local_rows
+    _, _, per = shard_bounds(n_total, rank, ws)
+    n_obs = local_rows.shape[1]
+    slab = torch.zeros((per, n_obs), dtype=local_rows.dtype, device=local_rows.device)
+    slab[: local_rows.shape[0]] = local_rows
+    full = torch.empty((ws * per, n_obs), dtype=local_rows.dtype, device=local_rows.device)
+    dist.all_gather_into_tensor(full, slab)
+    return full[:n_total]
