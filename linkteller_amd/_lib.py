@@ -62,6 +62,10 @@ def lib():
     """The loaded library (loads on first use; raises if the shared object is missing)."""
     global _lib
     if _lib is None:
+        # torch ships its own libamdhip64.so.7 / libhsa-runtime64.so.1; whichever copy is loaded
+        # first serves the whole process.  Load torch's first so that this library, torch's
+        # allocator and torch's streams all talk to ONE HIP runtime.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise LinkTellerHipError(
                 f"{LIB_PATH} not found: the HIP extension is not built.  Build it with "
