@@ -107,7 +107,8 @@ class Attacker:
         def scores(pairs):
             pairs = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
             # perturb v, observe u: influence_val[ind[v]][ind[u]]   (attacker.py:236-245)
-            return influence_val[node2ind[pairs[:, 1]], node2ind[pairs[:, 0]]].tolist()
+            # list of numpy float64 scalars, exactly what the reference appends (attacker.py:239,245)
+            return list(influence_val[node2ind[pairs[:, 1]], node2ind[pairs[:, 0]]])
 
         self.compute_and_save(scores(self.exist_edges), scores(self.nonexist_edges))
 

@@ -4,9 +4,10 @@ Mirrors, for the hot path only, what the reference does between reading an adjac
 handing it to the model:
 
 * ``fetch_normalization(name)`` -- the six ``--norm`` choices of reference utils/load.py:562-627
-  (``FirstOrderGCN`` = ``I + D^-1/2 A D^-1/2`` is the one BASELINE.json uses).  Computed in
-  float64 on the CSR arrays in the reference's multiplication order ``(d_i * a_ij) * d_j`` so the
-  float32 values handed to the device are the reference's bit for bit.
+  (``FirstOrderGCN`` = ``I + D^-1/2 A D^-1/2`` is the one BASELINE.json uses).  Computed on the
+  CSR arrays in the reference's multiplication order ``(d_i * a_ij) * d_j`` and in the dtype numpy
+  promotion gives the reference (float32 for a float32 adjacency), so the float32 values handed
+  to the device are the reference's bit for bit.
 * ``sparse_mx_to_torch_sparse_tensor`` (reference utils/load.py:552-559) -- kept for API parity;
   the product path converts to int32 CSR instead (8 B/nnz rather than the reference's 20 B/nnz
   int64 COO) and uploads it once through ``lt_graph_create``.
@@ -23,17 +24,22 @@ from . import _lib
 
 
 # ----------------------------------------------------------------------------------------------
-# normalisers (host, float64)
+# normalisers (host; dtype follows numpy promotion from the input, as in the reference)
 # ----------------------------------------------------------------------------------------------
 def _canonical_csr(adj) -> sp.csr_matrix:
-    a = sp.csr_matrix(adj, dtype=np.float64, copy=True)
+    # dtype is deliberately NOT forced: the reference's arithmetic follows numpy promotion from
+    # the adjacency's dtype (float32 for the MUSAE readers, utils/load.py:456-460 -> the whole
+    # normalisation runs in float32; integer for the DP-perturbed graphs -> float64).
+    a = sp.csr_matrix(adj, copy=True)
+    if a.dtype == np.bool_:
+        a = a.astype(np.int64)
     a.sum_duplicates()
     a.sort_indices()
     return a
 
 
 def _with_identity(a: sp.csr_matrix) -> sp.csr_matrix:
-    out = _canonical_csr(a + sp.identity(a.shape[0], dtype=np.float64, format="csr"))
+    out = _canonical_csr(a + sp.identity(a.shape[0], dtype=np.float64, format="csr"))  # float64 from here
     return out
 
 

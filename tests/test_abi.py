@@ -1,0 +1,84 @@
+"""The C-ABI library loads on a CPU-only box and exports exactly what include/linkteller_hip.h
+declares; argument validation that happens before any device call is checked here too."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+
+@pytest.fixture(scope="module")
+def lt():
+    from linkteller_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib
+
+
+def declared_functions():
+    src = open(os.path.join(REPO, "include", "linkteller_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lt):
+    names = declared_functions()
+    assert len(names) >= 19
+    handle = lt.lib()
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in the header but not exported"
+        assert n in lt.SIGNATURES, f"{n} has no ctypes signature"
+    assert sorted(lt.SIGNATURES) == names
+    assert handle.lt_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure_not_fallback(lt):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert lt.device_count() == 0
+    from linkteller_amd import engine, graph
+    import scipy.sparse as sp
+    with pytest.raises(lt.LinkTellerHipError):
+        graph.HipGraph(sp.identity(4, format="csr"))
+    with pytest.raises(lt.LinkTellerHipError):
+        engine.gemm(torch.zeros(2, 2), torch.zeros(2, 2))
+
+
+def test_graph_create_validation(lt):
+    h = lt.lib()
+    out = C.c_void_p()
+
+    def create(n, rowptr, col, val):
+        rp = np.asarray(rowptr, dtype=np.int32)
+        ci = np.asarray(col, dtype=np.int32)
+        va = np.asarray(val, dtype=np.float32)
+        return h.lt_graph_create(n, len(ci), rp.ctypes.data, ci.ctypes.data if len(ci) else None,
+                                 va.ctypes.data if len(va) else None, C.byref(out))
+
+    assert create(2, [1, 1, 2], [0, 1], [1, 1]) == -1 and b"rowptr[0]" in h.lt_last_error()
+    assert create(2, [0, 2, 1], [0], [1]) == -1
+    assert create(2, [0, 1, 2], [0, 5], [1, 1]) == -1 and b"out of range" in h.lt_last_error()
+    assert create(2, [0, 2, 2], [1, 0], [1, 1]) == -1 and b"strictly increasing" in h.lt_last_error()
+    assert create(2, [0, 2, 2], [1, 1], [1, 1]) == -1     # duplicate column
+    assert h.lt_graph_create(2, 0, None, None, None, C.byref(out)) == -1
+    assert h.lt_graph_info(None, None, None, None) == -1
+    assert h.lt_graph_destroy(None) == 0
+
+
+def test_workspace_queries_and_argument_errors(lt):
+    h = lt.lib()
+    assert h.lt_gcn2_workspace_bytes(4385, 256, 2) >= 4385 * 256 * 4 + 4385 * 2 * 4
+    assert h.lt_gcn2_workspace_bytes(-1, 256, 2) == 0
+    assert h.lt_influence_workspace_bytes(None, 10, 10, 0) == 0
+    assert h.lt_spmm_csr_f32(None, None, 0, 4, None, 0, None, 0, None) == -1
+    assert h.lt_influence_rows(None, None, 1, None, 1, 1e-4, 0, None, 1, None, 0, None) == -1
+    assert h.lt_gemm_f32(None, 1, None, 1, None, 1, 1, 1, 1, None) == -1
+    tot, cnt = C.c_double(), C.c_int64()
+    assert h.lt_profile_summary(99, C.byref(tot), C.byref(cnt)) == -1
+    assert h.lt_profile_enable(0) == 0 and h.lt_profile_reset() == 0
+    assert h.lt_profile_summary(0, C.byref(tot), C.byref(cnt)) == 0 and cnt.value == 0

@@ -1,0 +1,57 @@
+"""world_size-2 gloo test of the probe sharding + all-gather (the only collective on the path)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from linkteller_amd import dist as lt_dist
+
+
+def test_shard_bounds_cover_and_pad():
+    for n in (0, 1, 7, 500, 2000, 4096):
+        for ws in (1, 2, 3, 8):
+            spans = [lt_dist.shard_bounds(n, r, ws) for r in range(ws)]
+            assert [s[2] for s in spans] == [spans[0][2]] * ws
+            covered = [i for b, e, _ in spans for i in range(b, e)]
+            assert covered == list(range(n))
+            assert all(e - b <= per for b, e, per in spans)
+
+
+def _worker(rank, ws, port, n, n_obs, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    full = torch.arange(n * n_obs, dtype=torch.float32).reshape(n, n_obs) * 0.5 + 1.0   # "influence rows"
+    b, e, _ = lt_dist.shard_bounds(n, rank, ws)
+    got = lt_dist.all_gather_rows(full[b:e].clone(), n)
+    q.put((rank, bool(torch.equal(got, full)), tuple(got.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,n_obs", [(500, 500), (7, 5), (1, 3)])
+def test_all_gather_rows_two_ranks(n, n_obs):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, n_obs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] for r in res) and all(r[2] == (n, n_obs) for r in res)
+
+
+def test_single_process_is_identity():
+    x = torch.ones(3, 4)
+    assert lt_dist.world() == (0, 1)
+    assert lt_dist.all_gather_rows(x, 3) is x

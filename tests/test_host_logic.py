@@ -1,0 +1,113 @@
+"""Host-side logic of the product (normalisers, CSR packing, sampler, pair scoring, metrics, result
+file) against the golden vectors.  The device compute is replaced by the golden influence matrix
+here -- the kernels themselves are checked in test_gpu_parity.py."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import csr_from, golden_args, load_golden
+from linkteller_amd import graph, sampling
+from linkteller_amd.attacker import Attacker
+
+
+def test_normalizers_match_reference_bits():
+    g = load_golden("normalizer.npz")
+    for key in g["keys"]:
+        a = csr_from(g, f"{key}.adj")
+        for norm in ("FirstOrderGCN", "AugNormAdj"):
+            res = graph.fetch_normalization(norm)(a)
+            ref = sp.csr_matrix((g[f"{key}.{norm}.data"], (g[f"{key}.{norm}.row"], g[f"{key}.{norm}.col"])),
+                                shape=a.shape)
+            ref.sort_indices()
+            assert np.array_equal(res.indptr, ref.indptr) and np.array_equal(res.indices, ref.indices)
+            assert np.array_equal(res.data, ref.data)                     # float64 bits
+            n, rowptr, col, val = graph.csr_arrays(res)
+            tref = sp.csr_matrix((g[f"{key}.{norm}.t_values"], (g[f"{key}.{norm}.t_indices"][0],
+                                                              g[f"{key}.{norm}.t_indices"][1])), shape=a.shape)
+            tref.sort_indices()
+            assert rowptr.dtype == np.int32 and col.dtype == np.int32 and val.dtype == np.float32
+            assert np.array_equal(val, tref.data) and np.array_equal(col, tref.indices)
+            t = graph.sparse_mx_to_torch_sparse_tensor(res)
+            assert t._values().dtype == torch.float32 and t._indices().dtype == torch.int64
+    with pytest.raises(NotImplementedError):
+        graph.fetch_normalization("nope")
+
+
+def test_all_six_normalizers_formulas():
+    a = csr_from(load_golden("normalizer.npz"), "er50.adj").astype(np.float64)   # float64 in -> float64 math
+    d = np.asarray(a.sum(1)).ravel()
+    dense = a.toarray().astype(np.float64)
+    n = a.shape[0]
+    eye = np.eye(n)
+    dm = np.diag(d ** -0.5)
+    d1 = np.diag((d + 1) ** -0.5)
+    want = {
+        "FirstOrderGCN": eye + dm @ dense @ dm,
+        "NormAdj": dm @ dense @ dm,
+        "AugNormAdj": d1 @ (dense + eye) @ d1,
+        "BingGeNormAdj": d1 @ (dense + eye) @ d1 + eye,
+        "RWalk": np.diag(1 / d) @ dense,
+        "AugRWalk": np.diag(1 / (d + 1)) @ (dense + eye),
+    }
+    for name, w in want.items():
+        assert np.allclose(graph.fetch_normalization(name)(a).toarray(), w, rtol=1e-13, atol=1e-15), name
+
+
+def test_sampler_matches_reference_stream_and_order():
+    g = load_golden("sampler.npz")
+    a = csr_from(g, "adj")
+    for tag in g["combos"]:
+        ds, st, seed = str(tag).split(".")
+        np.random.seed(int(seed))
+        (ex, nex), nodes = sampling.construct_edge_sets_from_random_subgraph(ds.replace("_", "/"), st, a, 24)
+        assert np.array_equal(nodes, g[f"{tag}.nodes"])
+        assert np.array_equal(ex, g[f"{tag}.exist"]) and np.array_equal(nex, g[f"{tag}.nonexist"])
+    with pytest.raises(NotImplementedError):
+        sampling.construct_edge_sets_from_random_subgraph("twitch/ES/RU", "bfs", a, 4)
+    with pytest.raises(NotImplementedError):
+        sampling.degree_bounds("unknown-dataset")
+
+
+@pytest.mark.parametrize("key", ["er300", "lap600"])
+def test_attacker_scoring_metrics_and_result_file(influence_golden, key, tmp_path, monkeypatch, capsys):
+    import argparse
+    import types
+    g = influence_golden
+    args = argparse.Namespace(**golden_args(g, key))
+    a = csr_from(g, f"{key}.adj")
+    worker = types.SimpleNamespace(features_2=None, adj_2=None, adj_ori=a, n_nodes=a.shape[0])
+    atk = Attacker(args, model=None, worker=worker)
+    atk.prepare_test_data()
+    assert np.array_equal(atk.test_nodes, g[f"{key}.ref32.test_nodes"])
+    assert np.array_equal(atk.exist_edges, g[f"{key}.ref32.exist"])
+    # device compute replaced by the golden matrix: everything downstream must reproduce the reference
+    monkeypatch.setattr(atk, "influence_matrix", lambda mode=None: g[f"{key}.ref32.influence_val"].copy())
+    monkeypatch.chdir(tmp_path)
+    atk.link_prediction_attack_efficient()
+    out = capsys.readouterr().out
+    assert "time for predicting edges:" in out and "attack results saved to:" in out
+    assert atk.auc == float(g[f"{key}.ref32.auc"]) and atk.ap == float(g[f"{key}.ref32.ap"])
+    fn = str(g[f"{key}.ref32.filename"])
+    assert os.path.exists(fn)
+    saved = torch.load(fn, weights_only=False)
+    assert repr({k: sorted(v.keys()) for k, v in saved.items()}) == str(g[f"{key}.ref32.schema"])
+    assert type(saved["result"]["y"]).__name__ == str(g[f"{key}.ref32.y_type"])
+    assert type(saved["result"]["pred"][0]).__name__ == str(g[f"{key}.ref32.pred_type"])
+    assert np.array_equal(np.asarray(saved["result"]["pred"]), g[f"{key}.ref32.pred"])
+    assert np.array_equal(np.asarray(saved["result"]["y"]), g[f"{key}.ref32.y"])
+    for k_, s_ in (("fpr", "auc"), ("tpr", "auc"), ("thresholds", "auc"), ("precision", "pr"), ("recall", "pr")):
+        assert np.array_equal(saved[s_][k_], g[f"{key}.ref32.{k_}"])
+    assert str(saved["auc"]["fpr"].dtype) == str(g[f"{key}.ref32.fpr_dtype"])
+
+
+def test_attacker_rejects_what_the_reference_cannot_run():
+    import argparse
+    import types
+    args = argparse.Namespace(dataset="cora", sample_type="bfs", n_test=4, sample_seed=1, influence=1e-4,
+                              mode="vanilla-clean", attack_mode="efficient")
+    w = types.SimpleNamespace(features=None, adj_full=None, adj_ori=sp.identity(8, format="csr"), n_nodes=8)
+    with pytest.raises(NotImplementedError):
+        Attacker(args, None, w).prepare_test_data()
