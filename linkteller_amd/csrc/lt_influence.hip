@@ -17,6 +17,8 @@
 //          evaluated piecewise-linearly (no subtraction of nearly equal numbers); layer 2 sums
 //          A_hat[u,r] * dS2[r] over r in R_v.  Free of the fp32 cancellation noise of the
 //          finite difference: agrees with an fp64 run of the reference.
+#include <stdlib.h>
+
 #include "lt_rows.cuh"
 
 #define LT_BLOCK 256
@@ -75,11 +77,44 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_stageA(
 
 // ------------------------------------------------------------------------------------------------
 // FULL stage A, wide hidden width (LPR = 64, 128 < Hp <= 256): a wave owns one row and P probes.
-// The row's CSR entries are wave-uniform (scalar loads); each gathered S1 row (one coalesced
-// 16 B/lane load) feeds P independent fmaf chains.  Substitution of the probe's own row is rare,
-// so a 4-entry chunk first tests "does any column equal any of my P probes" with one vector
-// compare per entry and only then takes the per-probe select path.
+//  * the row's CSR entries are wave-uniform (scalar loads); each gathered S1 row (one coalesced
+//    16 B/lane load) feeds P independent fmaf chains -> P x fewer L2 gather bytes per flop;
+//  * the 4 waves of a block work on the SAME row for 4 consecutive probe groups, so their gathers
+//    of that row's S1 lines meet in the CU's L1 instead of going to L2 four times;
+//  * substituting the probe's own row is rare: a 4-entry chunk first asks "does any column equal
+//    any of my P probes" with one vector compare per entry (probe ids sit one per lane) and only
+//    then takes the per-probe select path;
+//  * the 2P (probe, class) partial sums are reduced with v_permlane32_swap / v_permlane16_swap
+//    + DPP row rotations: same pairings as the xor 32,16,8,4,2,1 butterfly of group_sum<64>
+//    (fp add commutes), so the bits equal the baseline kernel's.
 // ------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
+// lanes l and l+32 of (a, b) -> one register: lanes 0-31 carry a's pair sums, lanes 32-63 b's.
+// Inline asm on purpose: with the __builtin_amdgcn_permlane32_swap result pair hipcc (ROCm 7.2)
+// folded "r.x + r.y" into "r.x + r.x" here.  v_permlane32_swap exchanges lanes 32-63 of %0 with
+// lanes 0-31 of %1; the two wait states after a VALU write of either operand are the s_nop.
+__device__ __forceinline__ float fold32(float a, float b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+// rows (16 lanes) 0+1 and 2+3 of (a, b) -> rows [a01 | b01 | a23 | b23]
+// (v_permlane16_swap exchanges the odd rows of %0 with the even rows of %1)
+__device__ __forceinline__ float fold16(float a, float b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+// finish inside each 16-lane row: xor 8, 4 (row rotations) then xor 2, 1 (quad permutes)
+__device__ __forceinline__ float fold_row(float z) {
+    z += dpp_mov<0x128>(z);  // row_ror:8
+    z += dpp_mov<0x124>(z);  // row_ror:4
+    z += dpp_mov<0x4E>(z);   // quad_perm [2,3,0,1]
+    z += dpp_mov<0xB1>(z);   // quad_perm [1,0,3,2]
+    return z;
+}
+
 template <int CP, int P>
 __global__ __launch_bounds__(LT_BLOCK) void k_full_stageA_wide(
     int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
@@ -87,13 +122,14 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_stageA_wide(
     const float *__restrict__ b1p, const float *__restrict__ W2p, int C,
     const int32_t *__restrict__ probes, int nb, const float *__restrict__ Sp,
     float *__restrict__ S2p) {
+    static_assert((P * CP) % 4 == 0, "P*CP must be a multiple of 4");
     const int lane = threadIdx.x & 63;
-    const int r = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (LT_BLOCK / 64) + (threadIdx.x >> 6)));
-    const int pb = blockIdx.y * P;
-    if (r >= n) return;
-    const int coff = 4 * lane;
-    const bool active = coff < Hp;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const int r = blockIdx.x;
+    const int pb = __builtin_amdgcn_readfirstlane((int)((blockIdx.y * (LT_BLOCK / 64) + (threadIdx.x >> 6)) * P));
+    if (pb >= nb) return;
+    // lanes past Hp re-read the last column group (always in bounds) and are zeroed through w2
+    const bool active = 4 * lane < Hp;
+    const int coff = active ? 4 * lane : Hp - 4;
 
     int vp[P];
 #pragma unroll
@@ -102,14 +138,32 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_stageA_wide(
 
     f32x4 acc[P];
 #pragma unroll
-    for (int p = 0; p < P; ++p) acc[p] = zero;
+    for (int p = 0; p < P; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const float *__restrict__ S1c = S1 + coff;
+    const float *__restrict__ Spc = Sp + coff;
     const int e0 = rowptr[r], e1 = rowptr[r + 1];
+    // one entry with the per-probe substitution test (rare path and row tail)
+    auto one_entry = [&](int ee) {
+        const int c = col[ee];
+        const float a = val[ee];
+        const f32x4 s = ld4(S1c + (size_t)c * Hp);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            f32x4 sp = s;
+            if (c == vp[p]) {
+                sp = ld4(Spc + (size_t)(pb + p) * Hp);
+                // retire the load here: keeps this rare path down to ONE temporary instead of P
+                // address/destination register sets (the common path's occupancy is what matters)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(sp));
+            }
+            acc[p] = fma4(a, sp, acc[p]);
+        }
+    };
     int e = e0;
     for (; e + 4 <= e1; e += 4) {
         int c[4];
         float a[4];
-        f32x4 s[4];
         bool hit = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -117,47 +171,30 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_stageA_wide(
             a[k] = val[e + k];
             hit |= (vprobe == c[k]);
         }
+        if (__builtin_expect(__ballot(hit) == 0ull, 1)) {
+            f32x4 s[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s[k] = active ? ld4(S1 + (size_t)c[k] * Hp + coff) : zero;
-        if (__ballot(hit) == 0ull) {
+            for (int k = 0; k < 4; ++k) s[k] = ld4(S1c + (size_t)c[k] * Hp);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int p = 0; p < P; ++p) acc[p] = fma4(a[k], s[k], acc[p]);
         } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    f32x4 sp = s[k];
-                    if (c[k] == vp[p]) sp = active ? ld4(Sp + (size_t)(pb + p) * Hp + coff) : zero;
-                    acc[p] = fma4(a[k], sp, acc[p]);
-                }
+#pragma nounroll
+            for (int k = 0; k < 4; ++k) one_entry(e + k);
         }
     }
-    for (; e < e1; ++e) {
-        const int c = col[e];
-        const float a = val[e];
-        const f32x4 s = active ? ld4(S1 + (size_t)c * Hp + coff) : zero;
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            f32x4 sp = s;
-            if (c == vp[p]) sp = active ? ld4(Sp + (size_t)(pb + p) * Hp + coff) : zero;
-            acc[p] = fma4(a, sp, acc[p]);
-        }
-    }
+#pragma nounroll
+    for (; e < e1; ++e) one_entry(e);
 
-    const f32x4 b1v = active ? ld4(b1p + coff) : zero;
+    const f32x4 b1v = ld4(b1p + coff);
     float w2[4 * CP];
 #pragma unroll
-    for (int i = 0; i < 4 * CP; ++i) w2[i] = 0.f;
-    if (active) {
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int c = 0; c < CP; ++c)
-                if (c < C) w2[k * CP + c] = W2p[(size_t)(coff + k) * C + c];
-    }
+        for (int c = 0; c < CP; ++c) w2[k * CP + c] = (active && c < C) ? W2p[(size_t)(coff + k) * C + c] : 0.f;
+
+    float part[P * CP];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         // same operation order as relu_w2_partial
@@ -165,22 +202,37 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_stageA_wide(
         const float h1 = fmaxf(acc[p].y + b1v.y, 0.f);
         const float h2 = fmaxf(acc[p].z + b1v.z, 0.f);
         const float h3 = fmaxf(acc[p].w + b1v.w, 0.f);
-        float part[CP];
 #pragma unroll
         for (int c = 0; c < CP; ++c) {
             float q = h0 * w2[c];
             q = fmaf(h1, w2[CP + c], q);
             q = fmaf(h2, w2[2 * CP + c], q);
             q = fmaf(h3, w2[3 * CP + c], q);
-            part[c] = group_sum<64>(q);
-        }
-        if (lane == 0 && pb + p < nb) {
-            float *dst = S2p + ((size_t)(pb + p) * n + r) * C;
-#pragma unroll
-            for (int c = 0; c < CP; ++c)
-                if (c < C) dst[c] = part[c];
+            part[p * CP + c] = q;
         }
     }
+    // 64-lane sums of all P*CP values; after the folds register i holds, in its four 16-lane rows,
+    // the totals of values 4i+0, 4i+2, 4i+1, 4i+3
+    const int row = lane >> 4;
+    const int sel = ((row & 1) << 1) | (row >> 1);  // row -> 0,2,1,3
+#ifdef LT_DBG_OLD_REDUCE
+#pragma unroll
+    for (int v = 0; v < P * CP; ++v) {
+        const float tot = group_sum<64>(part[v]);
+        const int p = v / CP, c = v % CP;
+        if (lane == 0 && c < C && pb + p < nb) S2p[((size_t)(pb + p) * n + r) * C + c] = tot;
+    }
+#else
+#pragma unroll
+    for (int i = 0; i < P * CP / 4; ++i) {
+        const float y0 = fold32(part[4 * i + 0], part[4 * i + 1]);
+        const float y1 = fold32(part[4 * i + 2], part[4 * i + 3]);
+        const float z = fold_row(fold16(y0, y1));
+        const int vidx = 4 * i + sel;       // index into part[]: probe = vidx / CP, class = vidx % CP
+        const int p = vidx / CP, c = vidx % CP;
+        if ((lane & 15) == 0 && c < C && pb + p < nb) S2p[((size_t)(pb + p) * n + r) * C + c] = z;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -407,6 +459,17 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// probes per wave of the wide FULL kernel: 16 (default) or 8 (LT_FULL_P=8), a tuning knob only --
+// results are bit-identical
+static int full_probes_per_wave() {
+    static int p = 0;
+    if (!p) {
+        const char *e = getenv("LT_FULL_P");
+        p = (e && atoi(e) == 8) ? 8 : 16;
+    }
+    return p;
+}
+
 struct infl_ws {
     float *Xp, *Sp, *S2p;  // FULL / SPARSE: perturbed feature rows, their S1 rows; FULL: per-probe S2
     float *S2x;            // SPARSE / DELTA: per-item values
@@ -497,11 +560,18 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
         if (mode == LT_MODE_FULL) {
             { lt_prof_scope prof_(LT_K_FULL_A, st);
             if (lpr == 64) {
-                dim3 grid((n + LT_BLOCK / 64 - 1) / (LT_BLOCK / 64), (nb + LT_FULL_P - 1) / LT_FULL_P);
-                LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_wide<CP_, LT_FULL_P>), grid,
-                                                       dim3(LT_BLOCK), 0, st, n, g->rowptr, g->col,
-                                                       g->val, b->S1, Hp, b->b1p, b->W2p, C, probes, nb,
-                                                       w.Sp, w.S2p));
+                const int P = full_probes_per_wave();
+                const int groups = (nb + P - 1) / P;
+                dim3 grid(n, (groups + LT_BLOCK / 64 - 1) / (LT_BLOCK / 64));
+                if (P == 16) {
+                    LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_wide<CP_, 16>), grid, dim3(LT_BLOCK), 0,
+                                                           st, n, g->rowptr, g->col, g->val, b->S1, Hp, b->b1p,
+                                                           b->W2p, C, probes, nb, w.Sp, w.S2p));
+                } else {
+                    LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_wide<CP_, 8>), grid, dim3(LT_BLOCK), 0,
+                                                           st, n, g->rowptr, g->col, g->val, b->S1, Hp, b->b1p,
+                                                           b->W2p, C, probes, nb, w.Sp, w.S2p));
+                }
             } else {
                 const int rpb = (LT_BLOCK / 64) * (64 / lpr);
                 dim3 grid((n + rpb - 1) / rpb, nb);
