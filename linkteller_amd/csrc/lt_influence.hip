@@ -143,49 +143,85 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_stageA_wide(
     const float *__restrict__ S1c = S1 + coff;
     const float *__restrict__ Spc = Sp + coff;
     const int e0 = rowptr[r], e1 = rowptr[r + 1];
-    // one entry with the per-probe substitution test (rare path and row tail)
+    // one entry with the per-probe substitution test (rare path only)
     auto one_entry = [&](int ee) {
         const int c = col[ee];
         const float a = val[ee];
         const f32x4 s = ld4(S1c + (size_t)c * Hp);
+        int pbq = pb;
+        asm volatile("" : "+s"(pbq));  // keep the P substitute-row addresses out of the hot loop's registers
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             f32x4 sp = s;
             if (c == vp[p]) {
-                sp = ld4(Spc + (size_t)(pb + p) * Hp);
-                // retire the load here: keeps this rare path down to ONE temporary instead of P
-                // address/destination register sets (the common path's occupancy is what matters)
+                sp = ld4(Spc + (size_t)(pbq + p) * Hp);
+                // retire the load here: ONE temporary instead of P destination register sets
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(sp));
             }
             acc[p] = fma4(a, sp, acc[p]);
         }
     };
-    int e = e0;
-    for (; e + 4 <= e1; e += 4) {
-        int c[4];
-        float a[4];
-        bool hit = false;
+    // The row is walked in chunks of 4 entries, software-pipelined: while chunk i is in the FMA
+    // pipe, the S1 rows of chunk i+1 are in flight (vector loads) and the (col, val) of chunk i+2
+    // are being fetched (scalar loads).  The last chunk may be partial: its loads are clamped to
+    // the row's last entry (always in bounds) and the surplus entries get coefficient 0 --
+    // fmaf(0, s, acc) == acc bit for bit for finite s (acc is never -0: it starts at +0).
+    const int deg = e1 - e0;
+    const int nchunks = (deg + 3) >> 2;
+    const int elast = e1 - 1;
+    auto load_scalars = [&](int i, int (&c)[4], float (&a)[4]) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            c[k] = col[e + k];
-            a[k] = val[e + k];
-            hit |= (vprobe == c[k]);
+            const int ee = e0 + 4 * i + k;
+            const int ec = min(ee, elast);
+            c[k] = col[ec];
+            const float v = val[ec];
+            a[k] = ee <= elast ? v : 0.f;
         }
-        if (__builtin_expect(__ballot(hit) == 0ull, 1)) {
-            f32x4 s[4];
+    };
+    auto gather = [&](const int (&c)[4], f32x4 (&s)[4]) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s[k] = ld4(S1c + (size_t)c[k] * Hp);
+        for (int k = 0; k < 4; ++k) s[k] = ld4(S1c + (size_t)c[k] * Hp);
+    };
+    // `anyhit` collects "some column of this row is one of my probes"; such a row (rare: about
+    // P*deg/n of them) is redone from scratch below with the per-probe substitution test, which
+    // keeps the select path -- and its registers -- out of this loop.
+    bool anyhit = false;
+    auto compute = [&](int i, const int (&c)[4], const float (&a)[4], const f32x4 (&s)[4]) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 4; ++k) anyhit |= (vprobe == c[k]);
 #pragma unroll
-                for (int p = 0; p < P; ++p) acc[p] = fma4(a[k], s[k], acc[p]);
-        } else {
-#pragma nounroll
-            for (int k = 0; k < 4; ++k) one_entry(e + k);
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc[p] = fma4(a[k], s[k], acc[p]);
+    };
+    if (nchunks > 0) {
+        int cA[4], cB[4], cC[4], cD[4];
+        float aA[4], aB[4], aC[4], aD[4];
+        f32x4 sA[4], sB[4];
+        load_scalars(0, cA, aA);
+        gather(cA, sA);
+        load_scalars(1, cB, aB);      // clamped: harmless when the row has a single chunk
+        for (int i = 0; i < nchunks; i += 2) {
+            if (i + 1 < nchunks) gather(cB, sB);
+            load_scalars(i + 2, cC, aC);
+            compute(i, cA, aA, sA);
+            if (i + 2 < nchunks) gather(cC, sA);
+            load_scalars(i + 3, cD, aD);
+            if (i + 1 < nchunks) compute(i + 1, cB, aB, sB);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                cA[k] = cC[k]; aA[k] = aC[k];
+                cB[k] = cD[k]; aB[k] = aD[k];
+            }
         }
     }
+    if (__builtin_expect(__ballot(anyhit) != 0ull, 0)) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma nounroll
-    for (; e < e1; ++e) one_entry(e);
+        for (int e = e0; e < e1; ++e) one_entry(e);
+    }
 
     const f32x4 b1v = ld4(b1p + coff);
     float w2[4 * CP];
