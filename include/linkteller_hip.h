@@ -84,8 +84,8 @@ int lt_spmm_csr_f32(const lt_graph *g, const float *S, int64_t lds, int32_t ncol
 
 /* ---- 2-layer GCN forward (GCN.forward, gcn/models.py:19-24, eval mode) ------------------
  * logits[n,C] = A_hat * (relu(A_hat * (X*W1) + b1) * W2) + b2.   H <= 256, C <= 8.
- * lt_gcn2_workspace_bytes: size of the scratch the call needs (S1 and S2). */
-size_t lt_gcn2_workspace_bytes(int32_t n, int32_t H, int32_t C);
+ * lt_gcn2_workspace_bytes: size of the scratch the call needs (S1, S2, split-K partials). */
+size_t lt_gcn2_workspace_bytes(int32_t n, int32_t F, int32_t H, int32_t C);
 int lt_gcn2_forward(const lt_graph *g, const float *X, int64_t ldx, int32_t F,
                     const float *W1, const float *b1, int32_t H,
                     const float *W2, const float *b2, int32_t C,

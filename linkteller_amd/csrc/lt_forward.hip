@@ -213,10 +213,10 @@ static int check_dims(const char *who, const lt_graph *g, int F, int H, int C) {
 }
 
 struct gcn2_ws {
-    float *S1, *S2, *b1p, *W2p;
+    float *S1, *S2, *b1p, *W2p, *slabs;
     size_t bytes;
 };
-static gcn2_ws carve_gcn2(void *base, int n, int H, int C) {
+static gcn2_ws carve_gcn2(void *base, int n, int H, int C, int F) {
     const int Hp = lt_round_up(H, 4);
     size_t off = 0;
     gcn2_ws w;
@@ -225,24 +225,27 @@ static gcn2_ws carve_gcn2(void *base, int n, int H, int C) {
     w.S2 = (float *)(p + off);  off += lt_align_up((size_t)n * C * sizeof(float), 256);
     w.b1p = (float *)(p + off); off += lt_align_up((size_t)Hp * sizeof(float), 256);
     w.W2p = (float *)(p + off); off += lt_align_up((size_t)Hp * C * sizeof(float), 256);
+    const size_t sb = lt_gemm_splitk_slab_bytes(n, H, F, LT_KSLICE_BASE);
+    w.slabs = sb ? (float *)(p + off) : nullptr; off += lt_align_up(sb, 256);
     w.bytes = off;
     return w;
 }
 
-extern "C" size_t lt_gcn2_workspace_bytes(int32_t n, int32_t H, int32_t C) {
-    if (n < 0 || H <= 0 || C <= 0) return 0;
-    return carve_gcn2(nullptr, n, H, C).bytes;
+extern "C" size_t lt_gcn2_workspace_bytes(int32_t n, int32_t F, int32_t H, int32_t C) {
+    if (n < 0 || F <= 0 || H <= 0 || C <= 0) return 0;
+    return carve_gcn2(nullptr, n, H, C, F).bytes;
 }
 
 // S1 = X*W1 into an [n, Hp] buffer whose pad columns are zero; b1p / W2p zero-padded copies
 static int prepare_layer_inputs(int n, const float *X, int64_t ldx, int F, const float *W1,
                                 const float *b1, int H, const float *W2, int C, float *S1,
-                                float *b1p, float *W2p, hipStream_t st) {
+                                float *b1p, float *W2p, float *slabs, hipStream_t st) {
     const int Hp = lt_round_up(H, 4);
     if (Hp != H) LT_HIP(hipMemsetAsync(S1, 0, (size_t)n * Hp * sizeof(float), st));
     hipLaunchKernelGGL(k_pad_rows, dim3((Hp + 255) / 256), dim3(256), 0, st, b1, H, Hp, 1, b1p);
     hipLaunchKernelGGL(k_pad_rows, dim3((Hp * C + 255) / 256), dim3(256), 0, st, W2, H, Hp, C, W2p);
     LT_CHECK_LAUNCH();
+    if (slabs) return lt_launch_gemm_splitk(X, ldx, W1, H, S1, Hp, n, H, F, LT_KSLICE_BASE, slabs, st);
     return lt_launch_gemm(X, ldx, W1, H, S1, Hp, n, H, F, st);
 }
 
@@ -256,13 +259,13 @@ extern "C" int lt_gcn2_forward(const lt_graph *g, const float *X, int64_t ldx, i
     LT_REQUIRE(ldx >= F, "lt_gcn2_forward: ldx=%lld < F=%d", (long long)ldx, F);
     LT_REQUIRE(ldl == C, "lt_gcn2_forward: logits must be dense (ldl == C)");
     if (g->n == 0) return LT_OK;
-    if (!workspace || workspace_bytes < lt_gcn2_workspace_bytes(g->n, H, C) || ((uintptr_t)workspace % 256))
+    if (!workspace || workspace_bytes < lt_gcn2_workspace_bytes(g->n, F, H, C) || ((uintptr_t)workspace % 256))
         return lt_set_error(LT_ERR_WORKSPACE, "lt_gcn2_forward: workspace needs %zu bytes, 256-byte aligned",
-                            lt_gcn2_workspace_bytes(g->n, H, C));
+                            lt_gcn2_workspace_bytes(g->n, F, H, C));
     hipStream_t st = (hipStream_t)stream;
-    gcn2_ws w = carve_gcn2(workspace, g->n, H, C);
+    gcn2_ws w = carve_gcn2(workspace, g->n, H, C, F);
     const int Hp = lt_round_up(H, 4);
-    rc = prepare_layer_inputs(g->n, X, ldx, F, W1, b1, H, W2, C, w.S1, w.b1p, w.W2p, st);
+    rc = prepare_layer_inputs(g->n, X, ldx, F, W1, b1, H, W2, C, w.S1, w.b1p, w.W2p, w.slabs, st);
     if (rc) return rc;
     rc = lt_launch_layer1(g, w.S1, Hp, w.b1p, w.W2p, C, nullptr, w.S2, st);
     if (rc) return rc;
@@ -280,6 +283,7 @@ static void free_baseline(lt_baseline *b) {
     (void)hipFree(b->OUT);
     (void)hipFree(b->b1p);
     (void)hipFree(b->W2p);
+    (void)hipFree(b->slabs);
     delete b;
 }
 
@@ -288,7 +292,7 @@ extern "C" int lt_baseline_refresh(lt_baseline *b, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     if (b->n == 0) return LT_OK;
     int rc = prepare_layer_inputs(b->n, b->X, b->ldx, b->F, b->W1, b->b1, b->H, b->W2, b->C, b->S1,
-                                  b->b1p, b->W2p, st);
+                                  b->b1p, b->W2p, b->slabs, st);
     if (rc) return rc;
     rc = lt_launch_layer1(b->g, b->S1, b->Hp, b->b1p, b->W2p, b->C, b->Z1, b->S2, st);
     if (rc) return rc;
@@ -324,6 +328,8 @@ extern "C" int lt_baseline_create(const lt_graph *g, const float *X, int64_t ldx
     B_HIP(hipMalloc((void **)&b->OUT, nc));
     B_HIP(hipMalloc((void **)&b->b1p, (size_t)b->Hp * sizeof(float)));
     B_HIP(hipMalloc((void **)&b->W2p, (size_t)b->Hp * C * sizeof(float)));
+    if (lt_gemm_splitk_slab_bytes(b->n, H, F, LT_KSLICE_BASE))
+        B_HIP(hipMalloc((void **)&b->slabs, lt_gemm_splitk_slab_bytes(b->n, H, F, LT_KSLICE_BASE)));
 #undef B_HIP
     rc = lt_baseline_refresh(b, stream);
     if (rc) {

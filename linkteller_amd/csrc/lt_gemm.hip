@@ -22,7 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_gemm_f32_mfma(const float *__restrict__ A, long lda,
                                                        const float *__restrict__ B, long ldb,
                                                        float *__restrict__ C, long ldc, int M, int N,
-                                                       int K) {
+                                                       int K, int kslice, long slab_stride) {
     __shared__ __attribute__((aligned(16))) float As[2][GM_BM * GM_LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][GM_BK * GM_BN];
 
@@ -41,20 +41,25 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma(const float *__restrict__
     const float *b_ptr = B + (long)b_row * ldb + n0 + b_col;
     const bool b_full = (n0 + b_col + 3) < N;
 
+    // split-K: blockIdx.z owns K range [kb, ke) and writes its partial tile to slab z
+    const int kb = blockIdx.z * kslice;
+    const int ke = min(K, kb + kslice);
+    C += (long)blockIdx.z * slab_stride;
+
     f32x4 ra, rb;
     auto load_tiles = [&](int k0) {
         ra = f32x4{0.f, 0.f, 0.f, 0.f};
         rb = f32x4{0.f, 0.f, 0.f, 0.f};
         if (a_row_ok) {
-            if (k0 + a_col + 3 < K) {
+            if (k0 + a_col + 3 < ke) {
                 ra = *reinterpret_cast<const f32x4u *>(a_ptr + k0);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (k0 + a_col + j < K) ra[j] = a_ptr[k0 + j];
+                    if (k0 + a_col + j < ke) ra[j] = a_ptr[k0 + j];
             }
         }
-        if (k0 + b_row < K) {
+        if (k0 + b_row < ke) {
             const float *p = b_ptr + (long)k0 * ldb;
             if (b_full) {
                 rb = *reinterpret_cast<const f32x4u *>(p);
@@ -75,8 +80,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma(const float *__restrict__
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-    const int nk = (K + GM_BK - 1) / GM_BK;
-    load_tiles(0);
+    const int nk = (ke - kb + GM_BK - 1) / GM_BK;
+    load_tiles(kb);
     store_tiles(0);
     __syncthreads();
 
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma(const float *__restrict__
     const int b_frag = (lane >> 5) * GM_BN + wc * 32 + (lane & 31);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles((kt + 1) * GM_BK);
+        if (kt + 1 < nk) load_tiles(kb + (kt + 1) * GM_BK);
         const float *as = &As[buf][a_frag];
         const float *bs = &Bs[buf][b_frag];
 #pragma unroll
@@ -112,8 +117,48 @@ int lt_launch_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, flo
     LT_REQUIRE(grid.y <= 65535u, "lt_gemm_f32: N=%d too large", N);
     lt_prof_scope prof_(LT_K_GEMM, st);
     hipLaunchKernelGGL(k_gemm_f32_mfma, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, C,
-                       (long)ldc, M, N, K);
+                       (long)ldc, M, N, K, K > 0 ? K : 1, 0L);
     LT_CHECK_LAUNCH();
+    return LT_OK;
+}
+
+// Sum of `splits` partial slabs in slab order (fixed order: deterministic, independent of M).
+__global__ void k_sum_slabs(const float *__restrict__ slabs, long slab_stride, int splits, int M, int N,
+                            long ld, float *__restrict__ C, long ldc) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)M * N) return;
+    const int r = (int)(i / N), c = (int)(i % N);
+    float acc = slabs[(long)r * ld + c];
+    for (int z = 1; z < splits; ++z) acc += slabs[(long)z * slab_stride + (long)r * ld + c];
+    C[(long)r * ldc + c] = acc;
+}
+
+size_t lt_gemm_splitk_slab_bytes(int M, int N, int K, int kslice) {
+    const int splits = (K + kslice - 1) / kslice;
+    return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
+}
+
+// Split-K GEMM: K is cut into fixed `kslice`-deep slices (a multiple of 16) so that
+// M/64 x N/64 x K/kslice blocks put several workgroups on every CU (one 64x64 workgroup per CU is
+// bound by the latency of its own tile loads); each output is the ordered sum of its slices, so
+// a row's result does not depend on how many rows the call carries.
+int lt_launch_gemm_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                          int M, int N, int K, int kslice, float *slabs, hipStream_t st) {
+    if (M == 0 || N == 0) return LT_OK;
+    const int splits = (K + kslice - 1) / kslice;
+    if (splits <= 1) return lt_launch_gemm(A, lda, B, ldb, C, ldc, M, N, K, st);
+    dim3 grid((M + GM_BM - 1) / GM_BM, (N + GM_BN - 1) / GM_BN, splits);
+    const long stride = (long)M * N;
+    {
+        lt_prof_scope prof_(LT_K_GEMM, st);
+        hipLaunchKernelGGL(k_gemm_f32_mfma, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, slabs,
+                           (long)N, M, N, K, kslice, stride);
+        LT_CHECK_LAUNCH();
+        const long tot = (long)M * N;
+        hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, slabs, stride,
+                           splits, M, N, (long)N, C, (long)ldc);
+        LT_CHECK_LAUNCH();
+    }
     return LT_OK;
 }
 

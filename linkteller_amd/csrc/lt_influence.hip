@@ -508,6 +508,7 @@ static int full_probes_per_wave() {
 
 struct infl_ws {
     float *Xp, *Sp, *S2p;  // FULL / SPARSE: perturbed feature rows, their S1 rows; FULL: per-probe S2
+    float *slabs;          // FULL / SPARSE: split-K partials of the perturbed-row GEMM
     float *S2x;            // SPARSE / DELTA: per-item values
     int32_t *off;          // SPARSE / DELTA: item offsets [chunk + 1]
     size_t bytes;
@@ -519,8 +520,9 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
     const size_t n = (size_t)b->n, C = (size_t)b->C, Hp = (size_t)b->Hp, F = (size_t)b->F;
     const size_t maxc = (size_t)(b->g->max_col_nnz > 0 ? b->g->max_col_nnz : 1);
     size_t per_probe = 0;
-    if (mode == LT_MODE_FULL) per_probe = (n * C + F + Hp) * sizeof(float);
-    else if (mode == LT_MODE_SPARSE) per_probe = (maxc * C + F + Hp) * sizeof(float) + sizeof(int32_t);
+    const size_t splitk = ((F + LT_KSLICE_PROBE - 1) / LT_KSLICE_PROBE) * (size_t)b->H;
+    if (mode == LT_MODE_FULL) per_probe = (n * C + F + Hp + splitk) * sizeof(float);
+    else if (mode == LT_MODE_SPARSE) per_probe = (maxc * C + F + Hp + splitk) * sizeof(float) + sizeof(int32_t);
     else per_probe = maxc * C * sizeof(float) + sizeof(int32_t);
     size_t chunk = LT_CHUNK_BUDGET / (per_probe ? per_probe : 1);
     if (chunk < 1) chunk = 1;
@@ -537,6 +539,7 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
     if (mode == LT_MODE_FULL || mode == LT_MODE_SPARSE) {
         w.Xp = (float *)take(chunk * F * sizeof(float));
         w.Sp = (float *)take(chunk * Hp * sizeof(float));
+        w.slabs = (float *)take(lt_gemm_splitk_slab_bytes((int)chunk, b->H, b->F, LT_KSLICE_PROBE));
     }
     if (mode == LT_MODE_FULL) w.S2p = (float *)take(chunk * n * C * sizeof(float));
     if (mode != LT_MODE_FULL) {
@@ -589,7 +592,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                (long)b->ldx, b->F, probes, delta, w.Xp); }
             LT_CHECK_LAUNCH();
             if (Hp != b->H) LT_HIP(hipMemsetAsync(w.Sp, 0, (size_t)nb * Hp * sizeof(float), st));
-            int rc = lt_launch_gemm(w.Xp, b->F, b->W1, b->H, w.Sp, Hp, nb, b->H, b->F, st);
+            int rc = lt_launch_gemm_splitk(w.Xp, b->F, b->W1, b->H, w.Sp, Hp, nb, b->H, b->F, LT_KSLICE_PROBE, w.slabs, st);
             if (rc) return rc;
         }
 

@@ -40,6 +40,7 @@ struct lt_baseline {
     float *OUT = nullptr;  // [n, C]   A_hat * S2 + b2   (baseline logits)
     float *b1p = nullptr;  // [Hp]     b1 zero-padded
     float *W2p = nullptr;  // [Hp, C]  W2 zero-padded rows
+    float *slabs = nullptr;  // split-K partials of X*W1 (only when F > LT_KSLICE_BASE)
 };
 
 int lt_set_error(int code, const char *fmt, ...);
@@ -87,3 +88,8 @@ int lt_launch_layer2(const lt_graph *g, const float *S2, int C, const float *b2,
                      hipStream_t st);
 int lt_launch_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
                    int64_t ldc, int M, int N, int K, hipStream_t st);
+#define LT_KSLICE_PROBE 256   // perturbed-row GEMM (M = probes of a chunk)
+#define LT_KSLICE_BASE 1024   // baseline X*W1 (M = n)
+size_t lt_gemm_splitk_slab_bytes(int M, int N, int K, int kslice);
+int lt_launch_gemm_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
+                          int64_t ldc, int M, int N, int K, int kslice, float *slabs, hipStream_t st);

@@ -69,7 +69,7 @@ def gcn2_forward(adj, x, w1, b1, w2, b2) -> torch.Tensor:
     if n != g.n or w1.shape[0] != f or w2.shape[0] != h or b1.numel() != h or b2.numel() != c:
         raise ValueError("inconsistent GCN shapes")
     out = torch.empty((n, c), dtype=torch.float32, device=x.device)
-    nbytes = _lib.lib().lt_gcn2_workspace_bytes(n, h, c)
+    nbytes = _lib.lib().lt_gcn2_workspace_bytes(n, f, h, c)
     ws = _workspace(nbytes, x.device)
     _lib.check(_lib.lib().lt_gcn2_forward(g.handle, x.data_ptr(), f, f, w1.data_ptr(), b1.data_ptr(), h,
                                           w2.data_ptr(), b2.data_ptr(), c, out.data_ptr(), c,

@@ -72,8 +72,8 @@ def test_graph_create_validation(lt):
 
 def test_workspace_queries_and_argument_errors(lt):
     h = lt.lib()
-    assert h.lt_gcn2_workspace_bytes(4385, 256, 2) >= 4385 * 256 * 4 + 4385 * 2 * 4
-    assert h.lt_gcn2_workspace_bytes(-1, 256, 2) == 0
+    assert h.lt_gcn2_workspace_bytes(4385, 3170, 256, 2) >= 4385 * 256 * 4 + 4385 * 2 * 4
+    assert h.lt_gcn2_workspace_bytes(-1, 8, 256, 2) == 0
     assert h.lt_influence_workspace_bytes(None, 10, 10, 0) == 0
     assert h.lt_spmm_csr_f32(None, None, 0, 4, None, 0, None, 0, None) == -1
     assert h.lt_influence_rows(None, None, 1, None, 1, 1e-4, 0, None, 1, None, 0, None) == -1
