@@ -39,6 +39,11 @@ static void free_graph(lt_graph *g) {
     (void)hipFree(g->tptr);
     (void)hipFree(g->trow);
     (void)hipFree(g->tval);
+    (void)hipFree(g->long_row);
+    (void)hipFree(g->long_segptr);
+    (void)hipFree(g->lseg_long);
+    (void)hipFree(g->lseg_begin);
+    (void)hipFree(g->seg_scratch);
     delete g;
 }
 
@@ -120,6 +125,34 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
         G_HIP(hipMemcpy(g->val, val, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice));
         G_HIP(hipMemcpy(g->trow, trow.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
         G_HIP(hipMemcpy(g->tval, tval.data(), (size_t)nnz * sizeof(float), hipMemcpyHostToDevice));
+    }
+    // segment table of the long rows
+    {
+        std::vector<int32_t> lrow, lptr(1, 0), slong, sbeg;
+        for (int32_t r = 0; r < n; ++r) {
+            const int32_t d = rowptr[r + 1] - rowptr[r];
+            if (d <= LT_SPMM_SEG) continue;
+            const int32_t li = (int32_t)lrow.size();
+            lrow.push_back(r);
+            for (int32_t b = rowptr[r]; b < rowptr[r + 1]; b += LT_SPMM_SEG) {
+                slong.push_back(li);
+                sbeg.push_back(b);
+            }
+            lptr.push_back((int32_t)sbeg.size());
+        }
+        g->n_long = (int32_t)lrow.size();
+        g->n_lseg = (int32_t)sbeg.size();
+        if (g->n_long > 0) {
+            G_HIP(hipMalloc((void **)&g->long_row, lrow.size() * sizeof(int32_t)));
+            G_HIP(hipMalloc((void **)&g->long_segptr, lptr.size() * sizeof(int32_t)));
+            G_HIP(hipMalloc((void **)&g->lseg_long, slong.size() * sizeof(int32_t)));
+            G_HIP(hipMalloc((void **)&g->lseg_begin, sbeg.size() * sizeof(int32_t)));
+            G_HIP(hipMemcpy(g->long_row, lrow.data(), lrow.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            G_HIP(hipMemcpy(g->long_segptr, lptr.data(), lptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            G_HIP(hipMemcpy(g->lseg_long, slong.data(), slong.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            G_HIP(hipMemcpy(g->lseg_begin, sbeg.data(), sbeg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            G_HIP(hipMalloc((void **)&g->seg_scratch, (size_t)g->n_lseg * LT_MAX_H * sizeof(float)));
+        }
     }
 #undef G_HIP
     *out = g;

@@ -27,7 +27,9 @@ __global__ __launch_bounds__(LT_BLOCK) void k_spmm_rows(
     if (r >= n) return;
     const int coff = 4 * gl;
     const bool active = coff < ncols;
-    const f32x4 acc = row_dot(col, val, rowptr[r], rowptr[r + 1], S, lds, coff, active, -1, nullptr);
+    const int e0 = rowptr[r], e1 = rowptr[r + 1];
+    if (e1 - e0 > LT_SPMM_SEG) return;  // long rows: k_spmm_long_segments + k_spmm_long_combine
+    const f32x4 acc = row_dot(col, val, e0, e1, S, lds, coff, active, -1, nullptr);
     if (!active) return;
     f32x4 o = acc;
     if (bias) {
@@ -38,6 +40,45 @@ __global__ __launch_bounds__(LT_BLOCK) void k_spmm_rows(
         o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
     }
     *reinterpret_cast<f32x4 *>(out + (size_t)r * ldo + coff) = o;
+}
+
+// Long rows of the wide SpMM: one wave per segment of LT_SPMM_SEG entries -> partial[seg, :]
+template <int LPR>
+__global__ __launch_bounds__(LT_BLOCK) void k_spmm_long_segments(
+    int n_lseg, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ long_row,
+    const int32_t *__restrict__ lseg_long, const int32_t *__restrict__ lseg_begin,
+    const int32_t *__restrict__ col, const float *__restrict__ val, const float *__restrict__ S,
+    int lds, int ncols, float *__restrict__ partial, int ldp) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
+    const int gl = lane & (LPR - 1);
+    int sg = wave * RPW + lane / LPR;
+    if (LPR == 64) sg = __builtin_amdgcn_readfirstlane(sg);
+    if (sg >= n_lseg) return;
+    const int coff = 4 * gl;
+    if (coff >= ncols) return;
+    const int r = long_row[lseg_long[sg]];
+    const int b = lseg_begin[sg];
+    const int e = min(b + LT_SPMM_SEG, rowptr[r + 1]);
+    const f32x4 acc = row_dot(col, val, b, e, S, lds, coff, true, -1, nullptr);
+    *reinterpret_cast<f32x4 *>(partial + (size_t)sg * ldp + coff) = acc;
+}
+
+// ... then one thread per (long row, column): partials added in segment order, epilogue, store
+__global__ void k_spmm_long_combine(int n_long, const int32_t *__restrict__ long_row,
+                                    const int32_t *__restrict__ long_segptr,
+                                    const float *__restrict__ partial, int ldp, int ncols,
+                                    const float *__restrict__ bias, int relu, float *__restrict__ out,
+                                    int ldo) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_long * ncols) return;
+    const int li = i / ncols, c = i % ncols;
+    float acc = partial[(size_t)long_segptr[li] * ldp + c];
+    for (int sg = long_segptr[li] + 1; sg < long_segptr[li + 1]; ++sg) acc += partial[(size_t)sg * ldp + c];
+    if (bias) acc += bias[c];
+    if (relu) acc = fmaxf(acc, 0.f);
+    out[(size_t)long_row[li] * ldo + c] = acc;
 }
 
 // SpMM, narrow right-hand side (ncols <= 8), 8 lanes per row (the layer-2 shape).
@@ -197,6 +238,19 @@ extern "C" int lt_spmm_csr_f32(const lt_graph *g, const float *S, int64_t lds, i
         hipLaunchKernelGGL((k_spmm_rows<LPR_>), dim3(grid), dim3(LT_BLOCK), 0, st, g->n, g->rowptr,
                            g->col, g->val, S, (int)lds, ncols, bias, relu, out, (int)ldo));
     LT_CHECK_LAUNCH();
+    if (g->n_long > 0) {
+        const unsigned gseg = blocks_for_rows(g->n_lseg, (LT_BLOCK / 64) * (64 / lpr));
+        LT_DISPATCH_LPR(lpr,
+            hipLaunchKernelGGL((k_spmm_long_segments<LPR_>), dim3(gseg), dim3(LT_BLOCK), 0, st, g->n_lseg,
+                               g->rowptr, g->long_row, g->lseg_long, g->lseg_begin, g->col, g->val, S,
+                               (int)lds, ncols, g->seg_scratch, LT_MAX_H));
+        LT_CHECK_LAUNCH();
+        const int tot = g->n_long * ncols;
+        hipLaunchKernelGGL(k_spmm_long_combine, dim3((tot + 255) / 256), dim3(256), 0, st, g->n_long,
+                           g->long_row, g->long_segptr, g->seg_scratch, LT_MAX_H, ncols, bias, relu, out,
+                           (int)ldo);
+        LT_CHECK_LAUNCH();
+    }
     return LT_OK;
 }
 

@@ -23,7 +23,17 @@ struct lt_graph {
     int32_t *tptr = nullptr;
     int32_t *trow = nullptr;
     float *tval = nullptr;
+    // Long rows (more than LT_SPMM_SEG entries) of the standalone SpMM are cut into segments that
+    // separate waves sum; partials land in `seg_scratch` and are added in segment order.
+    int32_t n_long = 0;          // number of long rows
+    int32_t n_lseg = 0;          // total segments over all long rows
+    int32_t *long_row = nullptr;   // [n_long]     row id
+    int32_t *long_segptr = nullptr;  // [n_long + 1] first segment of each long row
+    int32_t *lseg_long = nullptr;  // [n_lseg]     index into long_row
+    int32_t *lseg_begin = nullptr;  // [n_lseg]     first CSR entry of the segment
+    float *seg_scratch = nullptr;  // [n_lseg, LT_MAX_H] partial sums (one stream at a time: handle is not thread-safe)
 };
+#define LT_SPMM_SEG 512
 
 struct lt_baseline {
     const lt_graph *g = nullptr;

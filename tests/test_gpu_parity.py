@@ -69,3 +69,62 @@ def test_influence_matrix(influence_golden, gpu, key):
     zero64 = ref64 == 0
     for m, r in res.items():
         assert np.all(r[zero64] == 0), f"{m}: non-zero where the reference is exactly zero"
+
+
+def _hub_graph(n, e, hub_deg, seed):
+    """power-law graph plus one node wired to `hub_deg` others (exercises the long-row segments)."""
+    import scipy.sparse as sp
+    from linkteller_amd import synth
+    a = synth.powerlaw_graph(n, e, seed=seed).tolil()
+    rng = np.random.RandomState(seed)
+    nb = rng.choice(np.arange(1, n), hub_deg, replace=False)
+    a[0, nb] = 1.0
+    a[nb, 0] = 1.0
+    return sp.csr_matrix(a)
+
+
+@pytest.mark.parametrize("ncols,bias,relu", [(256, True, True), (256, False, False), (64, True, False),
+                                              (20, False, True), (2, True, False), (7, False, False), (8, True, True)])
+def test_spmm_matches_scipy(gpu, ncols, bias, relu):
+    from linkteller_amd import engine, graph
+    a_hat = graph.first_order_gcn(_hub_graph(2500, 12000, 1400, seed=5))
+    assert np.diff(a_hat.indptr).max() > 1024       # at least three 512-entry segments
+    rng = np.random.RandomState(1)
+    s = rng.standard_normal((a_hat.shape[0], ncols)).astype(np.float32)
+    b = rng.standard_normal(ncols).astype(np.float32) if bias else None
+    got = engine.spmm(graph.HipGraph(a_hat), torch.from_numpy(s).to(gpu),
+                      None if b is None else torch.from_numpy(b).to(gpu), relu=relu).cpu().numpy()
+    want = a_hat.astype(np.float64) @ s.astype(np.float64)
+    if b is not None:
+        want = want + b
+    if relu:
+        want = np.maximum(want, 0)
+    assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+
+
+def test_gemm_matches_numpy(gpu):
+    from linkteller_amd import engine
+    rng = np.random.RandomState(2)
+    for m, k, n in ((1, 1, 1), (65, 33, 17), (500, 3170, 256), (130, 1500, 70)):
+        a = rng.standard_normal((m, k)).astype(np.float32)
+        b = rng.standard_normal((k, n)).astype(np.float32)
+        got = engine.gemm(torch.from_numpy(a).to(gpu), torch.from_numpy(b).to(gpu)).cpu().numpy()
+        want = a.astype(np.float64) @ b.astype(np.float64)
+        assert np.abs(got - want).max() <= 2e-6 * np.sqrt(k) * max(1.0, np.abs(want).max())
+
+
+def test_hub_rows_in_the_probe_kernels(gpu):
+    """A hub node as probe AND as observed node: long rows through stage A / stage B / item kernels."""
+    from linkteller_amd import engine, graph, synth
+    adj = _hub_graph(1500, 6000, 700, seed=9)
+    x = synth.twitch_like_features(1500, 64, seed=3, density=0.05)
+    w = synth.gcn_weights(64, 256, 2, seed=42)
+    base = engine.Baseline(graph.HipGraph(graph.first_order_gcn(adj)), torch.from_numpy(x).to(gpu),
+                           *[torch.from_numpy(w[k]).to(gpu) for k in ("W1", "b1", "W2", "b2")])
+    nodes = np.concatenate([[0], np.random.RandomState(0).choice(np.arange(1, 1500), 40, replace=False)])
+    full = base.influence_rows(nodes, nodes, 1e-4, "full").cpu().numpy()
+    sparse = base.influence_rows(nodes, nodes, 1e-4, "sparse").cpu().numpy()
+    delta = base.influence_rows(nodes, nodes, 1e-4, "delta").cpu().numpy()
+    assert np.array_equal(full, sparse)
+    assert np.abs(full - delta).max() <= 0.02 * delta.max() + 0.05   # fp32 finite-difference noise only
+    assert np.array_equal(full == 0, delta == 0) or np.all(full[delta == 0] == 0)
