@@ -101,6 +101,11 @@ int lt_baseline_create(const lt_graph *g, const float *X, int64_t ldx, int32_t F
                        const float *W1, const float *b1, int32_t H,
                        const float *W2, const float *b2, int32_t C,
                        void *stream, lt_baseline **out);
+/* Adds an fp64-accumulated copy of the pre-activation Z1 (one more X*W1 on the f64 matrix cores +
+ * one fp64 SpMM; kept up to date by lt_baseline_refresh).  LT_MODE_DELTA then evaluates the ReLU kink
+ * test on it, which is what brings it within 1e-6 of an fp64 run of the reference; without it the
+ * delta mode still works but entries that cross a kink carry ~1e-4 relative error. */
+int lt_baseline_enable_fp64(lt_baseline *b, void *stream);
 /* recompute the four buffers in place (same pointers, e.g. once per benchmark step) */
 int lt_baseline_refresh(lt_baseline *b, void *stream);
 int lt_baseline_destroy(lt_baseline *b);

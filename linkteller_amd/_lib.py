@@ -45,6 +45,7 @@ SIGNATURES = {
                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                      C.POINTER(C.c_void_p)]),
     "lt_baseline_refresh": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lt_baseline_enable_fp64": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lt_baseline_destroy": (C.c_int, [C.c_void_p]),
     "lt_baseline_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "lt_influence_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),

@@ -338,6 +338,7 @@ static void free_baseline(lt_baseline *b) {
     (void)hipFree(b->b1p);
     (void)hipFree(b->W2p);
     (void)hipFree(b->slabs);
+    lt_baseline_free_fp64(b);
     delete b;
 }
 
@@ -350,7 +351,9 @@ extern "C" int lt_baseline_refresh(lt_baseline *b, void *stream) {
     if (rc) return rc;
     rc = lt_launch_layer1(b->g, b->S1, b->Hp, b->b1p, b->W2p, b->C, b->Z1, b->S2, st);
     if (rc) return rc;
-    return lt_launch_layer2(b->g, b->S2, b->C, b->b2, b->OUT, st);
+    rc = lt_launch_layer2(b->g, b->S2, b->C, b->b2, b->OUT, st);
+    if (rc) return rc;
+    return lt_baseline_refresh_fp64(b, st);
 }
 
 extern "C" int lt_baseline_create(const lt_graph *g, const float *X, int64_t ldx, int32_t F,

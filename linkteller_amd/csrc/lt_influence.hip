@@ -364,12 +364,12 @@ __device__ __forceinline__ int find_row(const int32_t *__restrict__ rows, int cn
 
 // SPARSE stage A: for every item (b, r in R_v) the layer-1 row with S1[v] replaced -> S2x[item, :]
 // DELTA  stage A: for every item the layer-1 *change*                              -> S2x[item, :]
-template <int LPR, int CP, bool DELTA>
+template <int LPR, int CP, int DELTA>  // 0: sparse recompute, 1: delta (fp32 Z1), 2: delta (fp64 Z1)
 __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const int32_t *__restrict__ tptr,
     const int32_t *__restrict__ trow, const float *__restrict__ tval,
-    const float *__restrict__ S1, const float *__restrict__ Z1, int Hp,
+    const float *__restrict__ S1, const float *__restrict__ Z1, const double *__restrict__ Z1d, int Hp,
     const float *__restrict__ b1p, const float *__restrict__ W2p, int C,
     const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
     const float *__restrict__ Sp, float delta, float *__restrict__ S2x) {
@@ -397,13 +397,24 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
                 if (DELTA) {
                     const float arv = tval[t];
                     const f32x4 s = ld4(S1 + (size_t)v * Hp + coff);
-                    const f32x4 z = ld4(Z1 + (size_t)r * Hp + coff);
                     float dh[4];
+                    if (DELTA == 2) {
+                        // kink test on the fp64-accumulated pre-activation (see lt_fp64.hip)
+                        const double *zp = Z1d + (size_t)r * Hp + coff;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float dz = arv * (delta * s[k]);
-                        const float z1 = z[k] + dz;
-                        dh[k] = z[k] > 0.f ? (z1 > 0.f ? dz : -z[k]) : (z1 > 0.f ? z1 : 0.f);
+                        for (int k = 0; k < 4; ++k) {
+                            const float dz = arv * (delta * s[k]);
+                            const double z = zp[k], z1 = z + (double)dz;
+                            dh[k] = z > 0.0 ? (z1 > 0.0 ? dz : (float)(-z)) : (z1 > 0.0 ? (float)z1 : 0.f);
+                        }
+                    } else {
+                        const f32x4 z = ld4(Z1 + (size_t)r * Hp + coff);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float dz = arv * (delta * s[k]);
+                            const float z1 = z[k] + dz;
+                            dh[k] = z[k] > 0.f ? (z1 > 0.f ? dz : -z[k]) : (z1 > 0.f ? z1 : 0.f);
+                        }
                     }
                     const float *w2 = W2p + (size_t)coff * C;
 #pragma unroll
@@ -632,9 +643,9 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
             if (mode == LT_MODE_SPARSE) {
                 { lt_prof_scope prof_(LT_K_ITEM_A, st);
                 LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
-                    hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, false>), dim3(LT_ITEM_GRID),
+                    hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, 0>), dim3(LT_ITEM_GRID),
                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, g->tptr,
-                                       g->trow, g->tval, b->S1, b->Z1, Hp, b->b1p, b->W2p, C, probes, nb,
+                                       g->trow, g->tval, b->S1, b->Z1, b->Z1d, Hp, b->b1p, b->W2p, C, probes, nb,
                                        w.off, w.Sp, delta, w.S2x))); }
                 LT_CHECK_LAUNCH();
                 lt_prof_scope prof_(LT_K_ITEM_B, st);
@@ -645,11 +656,19 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                        orow, (long)ldo));
             } else {
                 { lt_prof_scope prof_(LT_K_ITEM_A, st);
-                LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
-                    hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, true>), dim3(LT_ITEM_GRID),
-                                       dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, g->tptr,
-                                       g->trow, g->tval, b->S1, b->Z1, Hp, b->b1p, b->W2p, C, probes, nb,
-                                       w.off, (const float *)nullptr, delta, w.S2x))); }
+                if (b->Z1d) {
+                    LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
+                        hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, 2>), dim3(LT_ITEM_GRID), dim3(LT_BLOCK), 0,
+                                           st, g->rowptr, g->col, g->val, g->tptr, g->trow, g->tval, b->S1,
+                                           b->Z1, b->Z1d, Hp, b->b1p, b->W2p, C, probes, nb, w.off,
+                                           (const float *)nullptr, delta, w.S2x)));
+                } else {
+                    LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
+                        hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, 1>), dim3(LT_ITEM_GRID), dim3(LT_BLOCK), 0,
+                                           st, g->rowptr, g->col, g->val, g->tptr, g->trow, g->tval, b->S1,
+                                           b->Z1, b->Z1d, Hp, b->b1p, b->W2p, C, probes, nb, w.off,
+                                           (const float *)nullptr, delta, w.S2x)));
+                } }
                 LT_CHECK_LAUNCH();
                 lt_prof_scope prof_(LT_K_ITEM_B, st);
                 LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, true>), dim3(gridB),

@@ -51,6 +51,10 @@ struct lt_baseline {
     float *b1p = nullptr;  // [Hp]     b1 zero-padded
     float *W2p = nullptr;  // [Hp, C]  W2 zero-padded rows
     float *slabs = nullptr;  // split-K partials of X*W1 (only when F > LT_KSLICE_BASE)
+    // optional fp64-accumulated copies for the kink test of LT_MODE_DELTA (lt_baseline_enable_fp64)
+    double *S1d = nullptr;      // [n, Hp]
+    double *Z1d = nullptr;      // [n, Hp]
+    double *slabs_d = nullptr;  // split-K partials
 };
 
 int lt_set_error(int code, const char *fmt, ...);
@@ -88,6 +92,9 @@ struct lt_prof_scope {
     lt_prof_scope(int id_, hipStream_t st_) : id(id_), st(st_), on(g_lt_profile_on) { if (on) lt_profile_begin(id, st); }
     ~lt_prof_scope() { if (on) lt_profile_end(id, st); }
 };
+
+int lt_baseline_refresh_fp64(lt_baseline *b, hipStream_t st);
+void lt_baseline_free_fp64(lt_baseline *b);
 
 // ---- launchers implemented in the kernel translation units --------------------------------
 // layer 1 for all rows: Z1 = A_hat*S1 + b1 (optional store), S2 = relu(Z1)*W2

@@ -96,6 +96,7 @@ class Baseline:
         self._h = h
         self._finalizer = weakref.finalize(self, _lib.lib().lt_baseline_destroy, h)
         self._ws = {}
+        self._fp64 = False
 
     @property
     def handle(self):
@@ -115,6 +116,10 @@ class Baseline:
         probes = _as_nodes(probe_nodes, self.n, dev, "probe_nodes")
         obs = _as_nodes(observe_nodes, self.n, dev, "observe_nodes")
         m = _lib.MODES[mode] if isinstance(mode, str) else int(mode)
+        if m == _lib.MODE_DELTA and not self._fp64:
+            # kink test on an fp64-accumulated pre-activation (one-off cost, kept fresh by refresh())
+            _lib.check(_lib.lib().lt_baseline_enable_fp64(self._h, _stream()), "lt_baseline_enable_fp64")
+            self._fp64 = True
         npb, nob = probes.numel(), obs.numel()
         if out is None:
             out = torch.empty((npb, nob), dtype=torch.float32, device=dev)
