@@ -128,3 +128,47 @@ def test_hub_rows_in_the_probe_kernels(gpu):
     assert np.array_equal(full, sparse)
     assert np.abs(full - delta).max() <= 0.02 * delta.max() + 0.05   # fp32 finite-difference noise only
     assert np.array_equal(full == 0, delta == 0) or np.all(full[delta == 0] == 0)
+
+
+def test_cli_end_to_end_matches_oracle(gpu, tmp_path, monkeypatch, capsys):
+    """README-style command line on a synthetic MUSAE-format dataset: Worker -> GCNTrainer -> Attacker
+    -> HIP probe kernels -> result file, against the oracle run on the same files."""
+    import argparse
+    from test_cli_worker_dp import _write_musae
+    from linkteller_amd import main as lt_main, synth
+    from linkteller_amd.gcn import GCN
+    from oracle import linkteller_oracle as O
+    a1, a2 = synth.powerlaw_graph(260, 1200, seed=1), synth.powerlaw_graph(320, 1500, seed=2)
+    _write_musae(str(tmp_path), "ES", a1, 400, 1)
+    _write_musae(str(tmp_path), "RU", a2, 400, 2)
+    torch.manual_seed(0)
+    model = GCN(3170, 256, 2, 0.5)
+    torch.save(model.state_dict(), tmp_path / "model.pt")
+    monkeypatch.chdir(tmp_path)
+    for mode in ("delta", "full"):
+        lt_main.main(f"--mode vanilla-clean --dataset twitch/ES/RU --hidden 256 --norm FirstOrderGCN --test "
+                     f"--model-path {tmp_path}/model.pt --attack --attack-mode efficient --sample-type unbalanced "
+                     f"--n-test 60 --influence-mode {mode} --data-root {tmp_path}".split())
+        out = capsys.readouterr().out
+        assert "attack results saved to: eval_twitch/ES/RU/efficient_unbalanced_60_42.pt" in out
+        saved = torch.load("eval_twitch/ES/RU/efficient_unbalanced_60_42.pt", weights_only=False)
+        # oracle on the same inputs (fp64 evaluation of the reference algorithm)
+        from linkteller_amd.worker import Worker
+        args = argparse.Namespace(norm="FirstOrderGCN")
+        monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+        w = Worker(args, "twitch/ES/RU", "vanilla-clean", data_root=str(tmp_path))
+        monkeypatch.undo(); monkeypatch.chdir(tmp_path)
+        np.random.seed(42)
+        (ex, nex), nodes = O.sample_subgraph_pairs("twitch/ES/RU", "unbalanced", w.adj_ori, 60)
+        P = {k: v.double() for k, v in zip(("W1", "b1", "W2", "b2"), [model.state_dict()[n] for n in
+                                                                  ("gc1.weight", "gc1.bias", "gc2.weight", "gc2.bias")])}
+        infl = O.influence_matrix(w.features_2.double(), w.adj_2.double(), P, nodes, 1e-4)
+        ne, nn = O.pair_scores(infl, nodes, ex, nex)
+        m = O.attack_metrics(ne, nn)
+        assert saved["result"]["y"] == m["y"]
+        pred = np.asarray(saved["result"]["pred"])
+        tol = 1e-5 if mode == "delta" else 2e-2
+        assert np.abs(pred - np.asarray(m["pred"])).max() <= tol * max(1.0, np.max(m["pred"]))
+        if mode == "delta":
+            import sklearn.metrics as skm
+            assert abs(skm.auc(saved["auc"]["fpr"], saved["auc"]["tpr"]) - m["auc"]) <= 1e-4
