@@ -131,9 +131,6 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_stageA_wide(
     const bool active = 4 * lane < Hp;
     const int coff = active ? 4 * lane : Hp - 4;
 
-    int vp[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) vp[p] = (pb + p < nb) ? probes[pb + p] : -1;
     const int vprobe = (lane < P && pb + lane < nb) ? probes[pb + lane] : -1;
 
     f32x4 acc[P];
@@ -153,7 +150,8 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_stageA_wide(
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             f32x4 sp = s;
-            if (c == vp[p]) {
+            const int vpp = (pbq + p < nb) ? probes[pbq + p] : -1;   // fetched here: rare path, saves P SGPRs
+            if (c == vpp) {
                 sp = ld4(Spc + (size_t)(pbq + p) * Hp);
                 // retire the load here: ONE temporary instead of P destination register sets
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(sp));
@@ -231,34 +229,48 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_stageA_wide(
         for (int c = 0; c < CP; ++c) w2[k * CP + c] = (active && c < C) ? W2p[(size_t)(coff + k) * C + c] : 0.f;
 
     float part[P * CP];
+    if constexpr (CP == 2) {
+        // two classes: the (c = 0, c = 1) pair rides in one packed register (v_pk_mul/v_pk_fma with the
+        // hidden value broadcast through op_sel); per component the operations and their order are
+        // those of relu_w2_partial, so the bits are unchanged
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 w0 = {w2[0], w2[1]}, w1 = {w2[2], w2[3]}, w2v = {w2[4], w2[5]}, w3 = {w2[6], w2[7]};
+        const f32x2 blo = {b1v.x, b1v.y}, bhi = {b1v.z, b1v.w};
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-        // same operation order as relu_w2_partial
-        const float h0 = fmaxf(acc[p].x + b1v.x, 0.f);
-        const float h1 = fmaxf(acc[p].y + b1v.y, 0.f);
-        const float h2 = fmaxf(acc[p].z + b1v.z, 0.f);
-        const float h3 = fmaxf(acc[p].w + b1v.w, 0.f);
+        for (int p = 0; p < P; ++p) {
+            const f32x2 zlo = f32x2{acc[p].x, acc[p].y} + blo;
+            const f32x2 zhi = f32x2{acc[p].z, acc[p].w} + bhi;
+            const float h0 = fmaxf(zlo.x, 0.f), h1 = fmaxf(zlo.y, 0.f);
+            const float h2 = fmaxf(zhi.x, 0.f), h3 = fmaxf(zhi.y, 0.f);
+            f32x2 q = f32x2{h0, h0} * w0;
+            q = __builtin_elementwise_fma(f32x2{h1, h1}, w1, q);
+            q = __builtin_elementwise_fma(f32x2{h2, h2}, w2v, q);
+            q = __builtin_elementwise_fma(f32x2{h3, h3}, w3, q);
+            part[2 * p] = q.x;
+            part[2 * p + 1] = q.y;
+        }
+    } else {
 #pragma unroll
-        for (int c = 0; c < CP; ++c) {
-            float q = h0 * w2[c];
-            q = fmaf(h1, w2[CP + c], q);
-            q = fmaf(h2, w2[2 * CP + c], q);
-            q = fmaf(h3, w2[3 * CP + c], q);
-            part[p * CP + c] = q;
+        for (int p = 0; p < P; ++p) {
+            // same operation order as relu_w2_partial
+            const float h0 = fmaxf(acc[p].x + b1v.x, 0.f);
+            const float h1 = fmaxf(acc[p].y + b1v.y, 0.f);
+            const float h2 = fmaxf(acc[p].z + b1v.z, 0.f);
+            const float h3 = fmaxf(acc[p].w + b1v.w, 0.f);
+#pragma unroll
+            for (int c = 0; c < CP; ++c) {
+                float q = h0 * w2[c];
+                q = fmaf(h1, w2[CP + c], q);
+                q = fmaf(h2, w2[2 * CP + c], q);
+                q = fmaf(h3, w2[3 * CP + c], q);
+                part[p * CP + c] = q;
+            }
         }
     }
     // 64-lane sums of all P*CP values; after the folds register i holds, in its four 16-lane rows,
     // the totals of values 4i+0, 4i+2, 4i+1, 4i+3
     const int row = lane >> 4;
     const int sel = ((row & 1) << 1) | (row >> 1);  // row -> 0,2,1,3
-#ifdef LT_DBG_OLD_REDUCE
-#pragma unroll
-    for (int v = 0; v < P * CP; ++v) {
-        const float tot = group_sum<64>(part[v]);
-        const int p = v / CP, c = v % CP;
-        if (lane == 0 && c < C && pb + p < nb) S2p[((size_t)(pb + p) * n + r) * C + c] = tot;
-    }
-#else
 #pragma unroll
     for (int i = 0; i < P * CP / 4; ++i) {
         const float y0 = fold32(part[4 * i + 0], part[4 * i + 1]);
@@ -268,7 +280,6 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_stageA_wide(
         const int p = vidx / CP, c = vidx % CP;
         if ((lane & 15) == 0 && c < C && pb + p < nb) S2p[((size_t)(pb + p) * n + r) * C + c] = z;
     }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
