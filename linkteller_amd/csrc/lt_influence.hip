@@ -68,7 +68,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_stageA(
 #pragma unroll
     for (int c = 0; c < CP; ++c) part[c] = group_sum<LPR>(part[c]);
     if (gl == 0) {
-        float *dst = S2p + ((size_t)b * n + r) * C;
+        float *dst = S2p + ((size_t)r * gridDim.y + b) * C;   // [row][probe][class]
 #pragma unroll
         for (int c = 0; c < CP; ++c)
             if (c < C) dst[c] = part[c];
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64) void k_full_stageA_wide(
         const float z = fold_row(fold16(y0, y1));
         const int vidx = 4 * i + sel;       // index into part[]: probe = vidx / CP, class = vidx % CP
         const int p = vidx / CP, c = vidx % CP;
-        if ((lane & 15) == 0 && c < C && pb + p < nb) S2p[((size_t)(pb + p) * n + r) * C + c] = z;
+        if ((lane & 15) == 0 && c < C && pb + p < nb) S2p[((size_t)r * nb + pb + p) * C + c] = z;   // [row][probe][class]
     }
 }
 
@@ -302,24 +302,50 @@ __device__ __forceinline__ float diff_norm(const float (&acc)[CP], const float *
     return sqrtf(ss);
 }
 
-// FULL stage B: 8 lanes per (probe, observed node)
+// FULL stage B: a wave = one observed node x 64 probes (lane = probe).  S2p is [row][probe][class],
+// so every CSR entry of the observed row is one coalesced 64 x C x 4-byte load; (col, val) are
+// wave-uniform scalars.  The sum is formed exactly as row2_dot forms it -- 8 interleaved partial
+// chains (entry e goes to chain (e - e0) & 7) combined as ((p0+p4)+(p2+p6))+((p1+p5)+(p3+p7)), the
+// xor 4,2,1 butterfly -- so the bits equal the baseline's layer-2 kernel.
 template <int CP>
-__global__ __launch_bounds__(LT_BLOCK) void k_full_stageB(
+__global__ __launch_bounds__(64) void k_full_stageB(
     int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ S2p, int C,
     const float *__restrict__ b2, const float *__restrict__ OUT,
     const int32_t *__restrict__ observe, int n_obs, int nb, float delta, float *__restrict__ out,
     long ldo) {
-    const long gid = ((long)blockIdx.x * LT_BLOCK + threadIdx.x) / LT_L2_LANES;
-    const int q = threadIdx.x & (LT_L2_LANES - 1);
-    if (gid >= (long)nb * n_obs) return;
-    const int b = (int)(gid / n_obs), j = (int)(gid % n_obs);
+    const int pblocks = (nb + 63) >> 6;
+    const int j = blockIdx.x / pblocks;
+    const int b = (blockIdx.x % pblocks) * 64 + threadIdx.x;
     const int u = observe[j];
-    const float *T = S2p + (size_t)b * n * C;
+    const int e0 = rowptr[u], e1 = rowptr[u + 1];
+    const bool live = b < nb;
+    const float *T = S2p + (size_t)(live ? b : 0) * C;
+    const size_t rstride = (size_t)nb * C;
+    float part[LT_L2_LANES][CP];
+#pragma unroll
+    for (int q = 0; q < LT_L2_LANES; ++q)
+#pragma unroll
+        for (int c = 0; c < CP; ++c) part[q][c] = 0.f;
+    for (int e = e0; e < e1; e += LT_L2_LANES) {
+#pragma unroll
+        for (int q = 0; q < LT_L2_LANES; ++q)
+            if (e + q < e1) {
+                const float a = val[e + q];
+                const float *t = T + (size_t)col[e + q] * rstride;
+#pragma unroll
+                for (int c = 0; c < CP; ++c)
+                    if (c < C) part[q][c] = fmaf(a, t[c], part[q][c]);
+            }
+    }
     float acc[CP];
-    row2_dot<CP>(col, val, rowptr[u], rowptr[u + 1], q, C,
-                 [&](int c, int) { return T + (size_t)c * C; }, acc);
-    if (q == 0) out[(long)b * ldo + j] = diff_norm<CP>(acc, b2, OUT + (size_t)u * C, C, delta);
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+        const float t0 = part[0][c] + part[4][c], t1 = part[1][c] + part[5][c];
+        const float t2 = part[2][c] + part[6][c], t3 = part[3][c] + part[7][c];
+        acc[c] = (t0 + t2) + (t1 + t3);
+    }
+    if (live) out[(long)b * ldo + j] = diff_norm<CP>(acc, b2, OUT + (size_t)u * C, C, delta);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -651,10 +677,10 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
             } }
             LT_CHECK_LAUNCH();
             { lt_prof_scope prof_(LT_K_FULL_B, st);
-            LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageB<CP_>), dim3(gridB), dim3(LT_BLOCK), 0,
-                                                   st, n, g->rowptr, g->col, g->val, w.S2p, C, b->b2,
-                                                   b->OUT, observe_nodes, n_obs, nb, delta, orow,
-                                                   (long)ldo)); }
+            const unsigned gridB2 = (unsigned)(((nb + 63) / 64) * (long)n_obs);
+            LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageB<CP_>), dim3(gridB2), dim3(64), 0, st, n,
+                                                   g->rowptr, g->col, g->val, w.S2p, C, b->b2, b->OUT,
+                                                   observe_nodes, n_obs, nb, delta, orow, (long)ldo)); }
             LT_CHECK_LAUNCH();
         } else {
             hipLaunchKernelGGL(k_probe_offsets, dim3(1), dim3(1024), 0, st, g->tptr, probes, nb, w.off);
