@@ -1,0 +1,24 @@
+"""Sanity/perf on an R-MAT graph (BASELINE configs[4] shape, scaled): full == sparse bitwise, timings per mode."""
+import sys, time, numpy as np, torch
+sys.path.insert(0, '.')
+from linkteller_amd import engine, graph, synth
+scale = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+n_test = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+adj = synth.rmat_graph(scale, (1 << scale) * 16, seed=42)
+a_hat = graph.first_order_gcn(adj)
+n = adj.shape[0]
+print('n', n, 'nnz', a_hat.nnz, 'max deg', int(np.diff(a_hat.indptr).max()))
+x = torch.from_numpy(synth.gaussian_features(n, 256, seed=1)).cuda()
+w = synth.gcn_weights(256, 256, 2, seed=42)
+t0 = time.time()
+base = engine.Baseline(graph.HipGraph(a_hat), x, *[torch.from_numpy(w[k]).cuda() for k in ("W1", "b1", "W2", "b2")])
+torch.cuda.synchronize(); print('baseline create', round(time.time() - t0, 3), 's')
+np.random.seed(42)
+nodes = np.random.choice(np.arange(n), n_test, replace=False)
+res = {}
+for m in ('full', 'sparse', 'delta'):
+    base.influence_rows(nodes, nodes, 1e-4, m); torch.cuda.synchronize()
+    t0 = time.time(); res[m] = base.influence_rows(nodes, nodes, 1e-4, m); torch.cuda.synchronize()
+    print(m, round((time.time() - t0) * 1e3, 3), 'ms')
+print('full == sparse:', bool(torch.equal(res['full'], res['sparse'])), ' max', float(res['delta'].max()),
+      ' |full-delta| max', float((res['full'] - res['delta']).abs().max()))
