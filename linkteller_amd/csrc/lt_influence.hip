@@ -115,8 +115,14 @@ __device__ __forceinline__ float fold_row(float z) {
     return z;
 }
 
+#ifndef LT_STAGEA_PEEL
+#define LT_STAGEA_PEEL 0
+#endif
+#ifndef LT_STAGEA_WAVES
+#define LT_STAGEA_WAVES 1   // waves per block; the waves of a block take the same row
+#endif
 template <int CP, int P>
-__global__ __launch_bounds__(64) void k_full_stageA_wide(
+__global__ __launch_bounds__(64 * LT_STAGEA_WAVES) void k_full_stageA_wide(
     int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ S1, int Hp,
     const float *__restrict__ b1p, const float *__restrict__ W2p, int C,
@@ -127,8 +133,9 @@ __global__ __launch_bounds__(64) void k_full_stageA_wide(
     // one wave per block (finer scheduling granularity than 4-wave blocks: -15 % measured); linear
     // block id = row * groups + group, so the probe groups of one row run together and meet in L2
     const int groups = (nb + P - 1) / P;
-    const int r = blockIdx.x / groups;
-    const int pb = (blockIdx.x % groups) * P;
+    const int gblocks = (groups + LT_STAGEA_WAVES - 1) / LT_STAGEA_WAVES;
+    const int r = blockIdx.x / gblocks;
+    const int pb = __builtin_amdgcn_readfirstlane((int)(((blockIdx.x % gblocks) * LT_STAGEA_WAVES + (threadIdx.x >> 6)) * P));
     if (pb >= nb) return;
     // lanes past Hp re-read the last column group (always in bounds) and are zeroed through w2
     const bool active = 4 * lane < Hp;
@@ -203,6 +210,29 @@ __global__ __launch_bounds__(64) void k_full_stageA_wide(
         load_scalars(0, cA, aA);
         gather(cA, sA);
         load_scalars(1, cB, aB);      // clamped: harmless when the row has a single chunk
+#if LT_STAGEA_PEEL
+        int i = 0;
+        for (; i + 2 < nchunks; i += 2) {   // steady state: every load unconditional
+            gather(cB, sB);
+            load_scalars(i + 2, cC, aC);
+            compute(i, cA, aA, sA);
+            gather(cC, sA);
+            load_scalars(i + 3, cD, aD);
+            compute(i + 1, cB, aB, sB);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                cA[k] = cC[k]; aA[k] = aC[k];
+                cB[k] = cD[k]; aB[k] = aD[k];
+            }
+        }
+        if (i + 1 < nchunks) {
+            gather(cB, sB);
+            compute(i, cA, aA, sA);
+            compute(i + 1, cB, aB, sB);
+        } else {
+            compute(i, cA, aA, sA);
+        }
+#else
         for (int i = 0; i < nchunks; i += 2) {
             if (i + 1 < nchunks) gather(cB, sB);
             load_scalars(i + 2, cC, aC);
@@ -216,6 +246,7 @@ __global__ __launch_bounds__(64) void k_full_stageA_wide(
                 cB[k] = cD[k]; aB[k] = aD[k];
             }
         }
+#endif
     }
     if (__builtin_expect(__ballot(anyhit) != 0ull, 0)) {
 #pragma unroll
@@ -652,18 +683,19 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
             if (lpr == 64) {
                 const int P = full_probes_per_wave();
                 const int groups = (nb + P - 1) / P;
-                LT_REQUIRE((long)n * groups < 2147483647L, "lt_influence_rows: n * probe groups exceeds the grid limit");
-                dim3 grid((unsigned)((long)n * groups));
+                const int gblocks = (groups + LT_STAGEA_WAVES - 1) / LT_STAGEA_WAVES;
+                LT_REQUIRE((long)n * gblocks < 2147483647L, "lt_influence_rows: n * probe groups exceeds the grid limit");
+                dim3 grid((unsigned)((long)n * gblocks));
                 if (P == 32) {
-                    LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_wide<CP_, 32>), grid, dim3(64), 0,
+                    LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_wide<CP_, 32>), grid, dim3(64 * LT_STAGEA_WAVES), 0,
                                                            st, n, g->rowptr, g->col, g->val, b->S1, Hp, b->b1p,
                                                            b->W2p, C, probes, nb, w.Sp, w.S2p));
                 } else if (P == 16) {
-                    LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_wide<CP_, 16>), grid, dim3(64), 0,
+                    LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_wide<CP_, 16>), grid, dim3(64 * LT_STAGEA_WAVES), 0,
                                                            st, n, g->rowptr, g->col, g->val, b->S1, Hp, b->b1p,
                                                            b->W2p, C, probes, nb, w.Sp, w.S2p));
                 } else {
-                    LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_wide<CP_, 8>), grid, dim3(64), 0,
+                    LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_wide<CP_, 8>), grid, dim3(64 * LT_STAGEA_WAVES), 0,
                                                            st, n, g->rowptr, g->col, g->val, b->S1, Hp, b->b1p,
                                                            b->W2p, C, probes, nb, w.Sp, w.S2p));
                 }
