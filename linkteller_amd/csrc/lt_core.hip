@@ -102,8 +102,10 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
     g->max_row_nnz = max_row;
     g->max_col_nnz = max_col;
     const size_t pb = ((size_t)n + 1) * sizeof(int32_t);
-    const size_t ib = (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t);
-    const size_t fb = (size_t)(nnz > 0 ? nnz : 1) * sizeof(float);
+    // +LT_CSR_PAD zero entries: the LDS-ring probe kernel reads (col, val) in 4-entry scalar bursts that
+    // may run past a row's (and so the array's) end; padded columns are 0 (a valid node), values 0
+    const size_t ib = ((size_t)nnz + LT_CSR_PAD) * sizeof(int32_t);
+    const size_t fb = ((size_t)nnz + LT_CSR_PAD) * sizeof(float);
 #define G_HIP(call)                                                                        \
     do {                                                                                   \
         hipError_t e_ = (call);                                                            \
@@ -115,6 +117,8 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
     G_HIP(hipMalloc((void **)&g->rowptr, pb));
     G_HIP(hipMalloc((void **)&g->col, ib));
     G_HIP(hipMalloc((void **)&g->val, fb));
+    G_HIP(hipMemset(g->col, 0, ib));
+    G_HIP(hipMemset(g->val, 0, fb));
     G_HIP(hipMalloc((void **)&g->tptr, pb));
     G_HIP(hipMalloc((void **)&g->trow, ib));
     G_HIP(hipMalloc((void **)&g->tval, fb));

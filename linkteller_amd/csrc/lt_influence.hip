@@ -19,6 +19,8 @@
 //          finite difference: agrees with an fp64 run of the reference.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "lt_rows.cuh"
 
 #define LT_BLOCK 256
@@ -113,6 +115,74 @@ __device__ __forceinline__ float fold_row(float z) {
     z += dpp_mov<0x4E>(z);   // quad_perm [2,3,0,1]
     z += dpp_mov<0xB1>(z);   // quad_perm [1,0,3,2]
     return z;
+}
+
+// Shared epilogue of the wide stage-A kernels: h = relu(acc + b1), the lane's share of h . W2 for all
+// P probes, the permlane/DPP folds, and the [row][probe][class] store.
+template <int CP, int P>
+__device__ __forceinline__ void stageA_epilogue(f32x4 (&acc)[P], int lane, bool active, int coff,
+                                                const float *__restrict__ b1p,
+                                                const float *__restrict__ W2p, int C, int n, int nb,
+                                                int r, int pb, float *__restrict__ S2p) {
+    const f32x4 b1v = ld4(b1p + coff);
+    float w2[4 * CP];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < CP; ++c) w2[k * CP + c] = (active && c < C) ? W2p[(size_t)(coff + k) * C + c] : 0.f;
+
+    float part[P * CP];
+    if constexpr (CP == 2) {
+        // two classes: the (c = 0, c = 1) pair rides in one packed register (v_pk_mul/v_pk_fma with the
+        // hidden value broadcast through op_sel); per component the operations and their order are
+        // those of relu_w2_partial, so the bits are unchanged
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 w0 = {w2[0], w2[1]}, w1 = {w2[2], w2[3]}, w2v = {w2[4], w2[5]}, w3 = {w2[6], w2[7]};
+        const f32x2 blo = {b1v.x, b1v.y}, bhi = {b1v.z, b1v.w};
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const f32x2 zlo = f32x2{acc[p].x, acc[p].y} + blo;
+            const f32x2 zhi = f32x2{acc[p].z, acc[p].w} + bhi;
+            const float h0 = fmaxf(zlo.x, 0.f), h1 = fmaxf(zlo.y, 0.f);
+            const float h2 = fmaxf(zhi.x, 0.f), h3 = fmaxf(zhi.y, 0.f);
+            f32x2 q = f32x2{h0, h0} * w0;
+            q = __builtin_elementwise_fma(f32x2{h1, h1}, w1, q);
+            q = __builtin_elementwise_fma(f32x2{h2, h2}, w2v, q);
+            q = __builtin_elementwise_fma(f32x2{h3, h3}, w3, q);
+            part[2 * p] = q.x;
+            part[2 * p + 1] = q.y;
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            // same operation order as relu_w2_partial
+            const float h0 = fmaxf(acc[p].x + b1v.x, 0.f);
+            const float h1 = fmaxf(acc[p].y + b1v.y, 0.f);
+            const float h2 = fmaxf(acc[p].z + b1v.z, 0.f);
+            const float h3 = fmaxf(acc[p].w + b1v.w, 0.f);
+#pragma unroll
+            for (int c = 0; c < CP; ++c) {
+                float q = h0 * w2[c];
+                q = fmaf(h1, w2[CP + c], q);
+                q = fmaf(h2, w2[2 * CP + c], q);
+                q = fmaf(h3, w2[3 * CP + c], q);
+                part[p * CP + c] = q;
+            }
+        }
+    }
+    // 64-lane sums of all P*CP values; after the folds register i holds, in its four 16-lane rows,
+    // the totals of values 4i+0, 4i+2, 4i+1, 4i+3
+    const int row = lane >> 4;
+    const int sel = ((row & 1) << 1) | (row >> 1);  // row -> 0,2,1,3
+#pragma unroll
+    for (int i = 0; i < P * CP / 4; ++i) {
+        const float y0 = fold32(part[4 * i + 0], part[4 * i + 1]);
+        const float y1 = fold32(part[4 * i + 2], part[4 * i + 3]);
+        const float z = fold_row(fold16(y0, y1));
+        const int vidx = 4 * i + sel;       // index into part[]: probe = vidx / CP, class = vidx % CP
+        const int p = vidx / CP, c = vidx % CP;
+        if ((lane & 15) == 0 && c < C && pb + p < nb) S2p[((size_t)r * nb + pb + p) * C + c] = z;   // [row][probe][class]
+    }
 }
 
 #ifndef LT_STAGEA_PEEL
@@ -255,64 +325,205 @@ __global__ __launch_bounds__(64 * LT_STAGEA_WAVES) void k_full_stageA_wide(
         for (int e = e0; e < e1; ++e) one_entry(e);
     }
 
-    const f32x4 b1v = ld4(b1p + coff);
-    float w2[4 * CP];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int c = 0; c < CP; ++c) w2[k * CP + c] = (active && c < C) ? W2p[(size_t)(coff + k) * C + c] : 0.f;
+    stageA_epilogue<CP, P>(acc, lane, active, coff, b1p, W2p, C, n, nb, r, pb, S2p);
+}
 
-    float part[P * CP];
-    if constexpr (CP == 2) {
-        // two classes: the (c = 0, c = 1) pair rides in one packed register (v_pk_mul/v_pk_fma with the
-        // hidden value broadcast through op_sel); per component the operations and their order are
-        // those of relu_w2_partial, so the bits are unchanged
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const f32x2 w0 = {w2[0], w2[1]}, w1 = {w2[2], w2[3]}, w2v = {w2[4], w2[5]}, w3 = {w2[6], w2[7]};
-        const f32x2 blo = {b1v.x, b1v.y}, bhi = {b1v.z, b1v.w};
+// ------------------------------------------------------------------------------------------------
+// FULL stage A, LDS-ring variant (wide hidden width, one wave per block).  The S1 rows of a row's
+// entries are fetched by LDS-DMA (global_load_lds_dwordx4: one 1 KiB row per instruction, no VGPR
+// destination) into a wave-private ring NB half-blocks (4 entries each) ahead of the FMAs, so
+//   * loads in flight cost LDS, not registers (acc[P] + 4 staged rows = ~90 VGPRs),
+//   * the wait before each entry is a COUNTED s_waitcnt vmcnt(4*NB + 3 - k) -- never a drain,
+//   * the (col, val) of a half-block arrive as one 4-dword scalar load each, a half-block early.
+// Arithmetic is the same fmaf chain as every other layer-1 kernel (entries past the row end carry
+// coefficient 0), the epilogue is shared with the register-staged kernel.
+// ------------------------------------------------------------------------------------------------
+#ifndef LT_RING_NB
+#define LT_RING_NB 1   // half-blocks in flight behind the one being consumed (ring = 4*(NB+1) KiB per wave)
+#endif
+#define LT_RING_SLOTS (4 * (LT_RING_NB + 1))
+#ifndef LT_RING_ROWS
+#define LT_RING_ROWS 1   // consecutive rows a wave walks (amortises wave launch)
+#endif
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int CP, int P>
+__global__ __launch_bounds__(64) void k_full_stageA_lds(
+    int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const float *__restrict__ S1, int Hp,
+    const float *__restrict__ b1p, const float *__restrict__ W2p, int C,
+    const int32_t *__restrict__ probes, int nb, const float *__restrict__ Sp,
+    float *__restrict__ S2p, int32_t *__restrict__ redo) {
+    static_assert((P * CP) % 4 == 0, "P*CP must be a multiple of 4");
+    __shared__ __attribute__((aligned(16))) float ring[LT_RING_SLOTS * 256];
+    const int lane = threadIdx.x;
+    const int groups = (nb + P - 1) / P;
+    const int pb = (blockIdx.x % groups) * P;
+    const int rbase = (blockIdx.x / groups) * LT_RING_ROWS;
+  for (int rr = 0; rr < LT_RING_ROWS; ++rr) {
+    const int r = rbase + rr;
+    if (r >= n) break;
+    const bool active = 4 * lane < Hp;
+    const int coff = active ? 4 * lane : Hp - 4;
+    int vprobe = (lane < P && pb + lane < nb) ? probes[pb + lane] : -1;
+    asm volatile("" : "+v"(vprobe));   // retire this ordinary load before any LDS-DMA is in flight (hipcc would drain vmcnt(0) at its first use)
+
+    f32x4 acc[P];
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const f32x2 zlo = f32x2{acc[p].x, acc[p].y} + blo;
-            const f32x2 zhi = f32x2{acc[p].z, acc[p].w} + bhi;
-            const float h0 = fmaxf(zlo.x, 0.f), h1 = fmaxf(zlo.y, 0.f);
-            const float h2 = fmaxf(zhi.x, 0.f), h3 = fmaxf(zhi.y, 0.f);
-            f32x2 q = f32x2{h0, h0} * w0;
-            q = __builtin_elementwise_fma(f32x2{h1, h1}, w1, q);
-            q = __builtin_elementwise_fma(f32x2{h2, h2}, w2v, q);
-            q = __builtin_elementwise_fma(f32x2{h3, h3}, w3, q);
-            part[2 * p] = q.x;
-            part[2 * p + 1] = q.y;
+    for (int p = 0; p < P; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const float *__restrict__ S1c = S1 + coff;
+    const int e0 = rowptr[r], e1 = rowptr[r + 1];
+    const int deg = e1 - e0;
+    const int nh = (deg + 3) >> 2;
+    bool anyhit = false;
+
+    auto load_cols = [&](int h, int (&c)[4]) {
+        const int32_t *cp = col + e0 + 4 * h;     // may run past the row: stays inside the padded array
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[k] = cp[k];
+    };
+    auto load_vals = [&](int h, float (&a)[4]) {
+        const float *vp_ = val + e0 + 4 * h;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float v = vp_[k];
+            a[k] = (4 * h + k < deg) ? v : 0.f;
         }
-    } else {
+    };
+    auto issue = [&](int h, const int (&c)[4]) {
+        const int base = (h % (LT_RING_NB + 1)) * 4;
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            // same operation order as relu_w2_partial
-            const float h0 = fmaxf(acc[p].x + b1v.x, 0.f);
-            const float h1 = fmaxf(acc[p].y + b1v.y, 0.f);
-            const float h2 = fmaxf(acc[p].z + b1v.z, 0.f);
-            const float h3 = fmaxf(acc[p].w + b1v.w, 0.f);
-#pragma unroll
-            for (int c = 0; c < CP; ++c) {
-                float q = h0 * w2[c];
-                q = fmaf(h1, w2[CP + c], q);
-                q = fmaf(h2, w2[2 * CP + c], q);
-                q = fmaf(h3, w2[3 * CP + c], q);
-                part[p * CP + c] = q;
-            }
+        for (int k = 0; k < 4; ++k) {
+            anyhit |= (vprobe == c[k]) & (4 * h + k < deg);
+            __builtin_amdgcn_global_load_lds(S1c + (size_t)c[k] * Hp, (lds_ptr_t)(ring + (base + k) * 256), 16, 0, 0);
         }
+    };
+    // consume half-block h; AFTER = number of half-blocks issued after it
+    auto consume = [&](int h, const float (&a)[4], auto after_tag) {
+        constexpr int AFTER = decltype(after_tag)::value;
+        const float *slot = ring + (h % (LT_RING_NB + 1)) * 4 * 256 + 4 * lane;
+        f32x4 s[4];
+        wait_vmcnt<4 * AFTER + 3>(); s[0] = *reinterpret_cast<const f32x4 *>(slot);
+        wait_vmcnt<4 * AFTER + 2>(); s[1] = *reinterpret_cast<const f32x4 *>(slot + 256);
+        wait_vmcnt<4 * AFTER + 1>(); s[2] = *reinterpret_cast<const f32x4 *>(slot + 512);
+        wait_vmcnt<4 * AFTER + 0>(); s[3] = *reinterpret_cast<const f32x4 *>(slot + 768);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc[p] = fma4(a[k], s[k], acc[p]);
+    };
+
+    if (nh > 0) {
+        int cI[4];
+        float aC[4], aN[4];
+        // prologue: half-blocks 0 .. min(NB, nh) - 1 in flight
+        load_cols(0, cI);
+        load_vals(0, aC);
+        issue(0, cI);
+#pragma unroll
+        for (int j = 1; j < LT_RING_NB; ++j)
+            if (j < nh) { load_cols(j, cI); issue(j, cI); }
+        int h = 0;
+        // steady state: LT_RING_NB half-blocks are in flight behind h after the issue below
+        for (; h + LT_RING_NB < nh; ++h) {
+            load_cols(h + LT_RING_NB, cI);
+            load_vals(h + 1, aN);
+            issue(h + LT_RING_NB, cI);
+            consume(h, aC, std::integral_constant<int, LT_RING_NB>{});
+#pragma unroll
+            for (int k = 0; k < 4; ++k) aC[k] = aN[k];
+        }
+        // drain: nothing left to issue; fewer half-blocks behind h each time
+#if LT_RING_NB >= 2
+        if (h + 1 < nh) {
+            load_vals(h + 1, aN);
+            consume(h, aC, std::integral_constant<int, 1>{});
+#pragma unroll
+            for (int k = 0; k < 4; ++k) aC[k] = aN[k];
+            ++h;
+        }
+#endif
+        consume(h, aC, std::integral_constant<int, 0>{});
     }
-    // 64-lane sums of all P*CP values; after the folds register i holds, in its four 16-lane rows,
-    // the totals of values 4i+0, 4i+2, 4i+1, 4i+3
-    const int row = lane >> 4;
-    const int sel = ((row & 1) << 1) | (row >> 1);  // row -> 0,2,1,3
+
+    if (__builtin_expect(__ballot(anyhit) != 0ull, 0)) {
+        // a column of this row is one of my probes (about P*deg/n of the waves): hand the (row, group)
+        // to k_full_stageA_redo, which applies the per-probe substitution; keeping that select path out
+        // of this kernel is worth 50 VGPRs (152 -> 102)
+        if (lane == 0) redo[1 + atomicAdd(redo, 1)] = blockIdx.x;
+        return;
+    }
+    stageA_epilogue<CP, P>(acc, lane, active, coff, b1p, W2p, C, n, nb, r, pb, S2p);
+  }
+}
+
+// Redo kernel of the ring variant: (row, probe group) pairs whose row contains one of the group's probes.
+// Same fmaf chains, with the probe's own perturbed S1 row substituted on its column; grid-stride over
+// the list the ring kernel appended (order does not matter: each pair owns its outputs).
+template <int CP, int P>
+__global__ __launch_bounds__(64) void k_full_stageA_redo(
+    int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const float *__restrict__ S1, int Hp,
+    const float *__restrict__ b1p, const float *__restrict__ W2p, int C,
+    const int32_t *__restrict__ probes, int nb, const float *__restrict__ Sp,
+    float *__restrict__ S2p, const int32_t *__restrict__ redo) {
+    const int lane = threadIdx.x;
+    const int groups = (nb + P - 1) / P;
+    const int count = redo[0];
+    const bool active = 4 * lane < Hp;
+    const int coff = active ? 4 * lane : Hp - 4;
+    const float *__restrict__ S1c = S1 + coff;
+    const float *__restrict__ Spc = Sp + coff;
+    for (int it = blockIdx.x; it < count; it += gridDim.x) {
+        const int bid = redo[1 + it];
+        const int r = bid / groups;
+        const int pb = (bid % groups) * P;
+        const int vprobe = (lane < P && pb + lane < nb) ? probes[pb + lane] : -1;
+        f32x4 acc[P];
 #pragma unroll
-    for (int i = 0; i < P * CP / 4; ++i) {
-        const float y0 = fold32(part[4 * i + 0], part[4 * i + 1]);
-        const float y1 = fold32(part[4 * i + 2], part[4 * i + 3]);
-        const float z = fold_row(fold16(y0, y1));
-        const int vidx = 4 * i + sel;       // index into part[]: probe = vidx / CP, class = vidx % CP
-        const int p = vidx / CP, c = vidx % CP;
-        if ((lane & 15) == 0 && c < C && pb + p < nb) S2p[((size_t)r * nb + pb + p) * C + c] = z;   // [row][probe][class]
+        for (int p = 0; p < P; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int e0 = rowptr[r], e1 = rowptr[r + 1];
+        auto entry = [&](int c, float a, f32x4 s) {
+            // bit p of m: probe pb+p sits on column c (probe ids live one per lane in vprobe)
+            const unsigned m = (unsigned)__ballot(vprobe == c);
+            if (m == 0u) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc[p] = fma4(a, s, acc[p]);
+            } else {
+                int pbq = pb;
+                asm volatile("" : "+s"(pbq));
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    f32x4 sp = s;
+                    if ((m >> p) & 1u) {
+                        sp = ld4(Spc + (size_t)(pbq + p) * Hp);
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sp));
+                    }
+                    acc[p] = fma4(a, sp, acc[p]);
+                }
+            }
+        };
+        int e = e0;
+        for (; e + 4 <= e1; e += 4) {
+            int c[4];
+            float a[4];
+            f32x4 s[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { c[k] = col[e + k]; a[k] = val[e + k]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] = ld4(S1c + (size_t)c[k] * Hp);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) entry(c[k], a[k], s[k]);
+        }
+        for (; e < e1; ++e) entry(col[e], val[e], ld4(S1c + (size_t)col[e] * Hp));
+        stageA_epilogue<CP, P>(acc, lane, active, coff, b1p, W2p, C, n, nb, r, pb, S2p);
     }
 }
 
@@ -588,11 +799,21 @@ static int full_probes_per_wave() {
     return p;
 }
 
+static bool full_use_lds_ring() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("LT_STAGEA_LDS");   // default on; LT_STAGEA_LDS=0 selects the register-staged kernel
+        v = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return v == 1;
+}
+
 struct infl_ws {
     float *Xp, *Sp, *S2p;  // FULL / SPARSE: perturbed feature rows, their S1 rows; FULL: per-probe S2
     float *slabs;          // FULL / SPARSE: split-K partials of the perturbed-row GEMM
     float *S2x;            // SPARSE / DELTA: per-item values
     int32_t *off;          // SPARSE / DELTA: item offsets [chunk + 1]
+    int32_t *redo;         // FULL (ring kernel): [0] = count, then (row * groups + group) entries
     size_t bytes;
     int chunk;
 };
@@ -603,7 +824,7 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
     const size_t maxc = (size_t)(b->g->max_col_nnz > 0 ? b->g->max_col_nnz : 1);
     size_t per_probe = 0;
     const size_t splitk = ((F + LT_KSLICE_PROBE - 1) / LT_KSLICE_PROBE) * (size_t)b->H;
-    if (mode == LT_MODE_FULL) per_probe = (n * C + F + Hp + splitk) * sizeof(float);
+    if (mode == LT_MODE_FULL) per_probe = (n * C + F + Hp + splitk) * sizeof(float) + n / 4;
     else if (mode == LT_MODE_SPARSE) per_probe = (maxc * C + F + Hp + splitk) * sizeof(float) + sizeof(int32_t);
     else per_probe = maxc * C * sizeof(float) + sizeof(int32_t);
     size_t chunk = LT_CHUNK_BUDGET / (per_probe ? per_probe : 1);
@@ -623,7 +844,10 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
         w.Sp = (float *)take(chunk * Hp * sizeof(float));
         w.slabs = (float *)take(lt_gemm_splitk_slab_bytes((int)chunk, b->H, b->F, LT_KSLICE_PROBE));
     }
-    if (mode == LT_MODE_FULL) w.S2p = (float *)take(chunk * n * C * sizeof(float));
+    if (mode == LT_MODE_FULL) {
+        w.S2p = (float *)take(chunk * n * C * sizeof(float));
+        w.redo = (int32_t *)take((1 + n * ((chunk + 7) / 8)) * sizeof(int32_t));
+    }
     if (mode != LT_MODE_FULL) {
         w.S2x = (float *)take(chunk * maxc * C * sizeof(float));
         w.off = (int32_t *)take((chunk + 1) * sizeof(int32_t));
@@ -686,7 +910,39 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                 const int gblocks = (groups + LT_STAGEA_WAVES - 1) / LT_STAGEA_WAVES;
                 LT_REQUIRE((long)n * gblocks < 2147483647L, "lt_influence_rows: n * probe groups exceeds the grid limit");
                 dim3 grid((unsigned)((long)n * gblocks));
-                if (P == 32) {
+                if (full_use_lds_ring()) {
+                    const int Pr = (P == 8) ? 8 : (P == 32 ? 32 : 16);
+                    const long rblocks = (n + LT_RING_ROWS - 1) / LT_RING_ROWS;
+                    const int rgroups = (nb + Pr - 1) / Pr;
+                    LT_REQUIRE(rblocks * rgroups < 2147483647L, "lt_influence_rows: grid limit");
+                    dim3 gridr((unsigned)(rblocks * rgroups));
+                    LT_HIP(hipMemsetAsync(w.redo, 0, sizeof(int32_t), st));
+                    if (Pr == 8) {
+                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, 8>), gridr, dim3(64), 0, st, n,
+                                                               g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p,
+                                                               C, probes, nb, w.Sp, w.S2p, w.redo));
+                        LT_CHECK_LAUNCH();
+                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_redo<CP_, 8>), dim3(4096), dim3(64), 0, st,
+                                                               n, g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p,
+                                                               C, probes, nb, w.Sp, w.S2p, w.redo));
+                    } else if (Pr == 32) {
+                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, 32>), gridr, dim3(64), 0, st, n,
+                                                               g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p,
+                                                               C, probes, nb, w.Sp, w.S2p, w.redo));
+                        LT_CHECK_LAUNCH();
+                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_redo<CP_, 32>), dim3(4096), dim3(64), 0, st,
+                                                               n, g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p,
+                                                               C, probes, nb, w.Sp, w.S2p, w.redo));
+                    } else {
+                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, 16>), gridr, dim3(64), 0, st, n,
+                                                               g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p,
+                                                               C, probes, nb, w.Sp, w.S2p, w.redo));
+                        LT_CHECK_LAUNCH();
+                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_redo<CP_, 16>), dim3(4096), dim3(64), 0, st,
+                                                               n, g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p,
+                                                               C, probes, nb, w.Sp, w.S2p, w.redo));
+                    }
+                } else if (P == 32) {
                     LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_wide<CP_, 32>), grid, dim3(64 * LT_STAGEA_WAVES), 0,
                                                            st, n, g->rowptr, g->col, g->val, b->S1, Hp, b->b1p,
                                                            b->W2p, C, probes, nb, w.Sp, w.S2p));

@@ -34,6 +34,7 @@ struct lt_graph {
     float *seg_scratch = nullptr;  // [n_lseg, LT_MAX_H] partial sums (one stream at a time: handle is not thread-safe)
 };
 #define LT_SPMM_SEG 512
+#define LT_CSR_PAD 16   // zero entries appended to col/val
 
 struct lt_baseline {
     const lt_graph *g = nullptr;
