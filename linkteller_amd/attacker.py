@@ -21,7 +21,7 @@ from sklearn import metrics
 
 from . import dist as lt_dist
 from . import engine
-from .sampling import construct_edge_sets_from_random_subgraph
+from .sampling import construct_balanced_edge_sets, construct_edge_sets_from_random_subgraph
 
 
 class Attacker:
@@ -46,12 +46,16 @@ class Attacker:
     # ------------------------------------------------------------------------------------------
     def prepare_test_data(self):
         """attacker.py:33-48.  'balanced' and 'bfs' cannot run in the reference either (tuple
-        arity / signature mismatches at attacker.py:46-47)."""
+        arity / signature mismatches at attacker.py:46-47); 'balanced-full' can."""
         st = self.args.sample_type
-        if st not in ("unbalanced", "unbalanced-lo", "unbalanced-hi"):
+        func = {"unbalanced": construct_edge_sets_from_random_subgraph,
+                "unbalanced-lo": construct_edge_sets_from_random_subgraph,
+                "unbalanced-hi": construct_edge_sets_from_random_subgraph,
+                "balanced-full": construct_balanced_edge_sets}.get(st)
+        if not func:
             raise NotImplementedError(f"sample_type = {st} not implemented!")
         np.random.seed(self.args.sample_seed)
-        (self.exist_edges, self.nonexist_edges), self.test_nodes = construct_edge_sets_from_random_subgraph(
+        (self.exist_edges, self.nonexist_edges), self.test_nodes = func(
             self.dataset, st, self.worker.adj_ori, self.args.n_test)
         print("generating testing (non-)edge set done!")
 
@@ -62,6 +66,53 @@ class Attacker:
             return [sd[k].detach() for k in ("gc1.weight", "gc1.bias", "gc2.weight", "gc2.bias")]
         except KeyError as e:
             raise NotImplementedError(f"the probe kernels need a 2-layer GCN state_dict (missing {e})") from None
+
+    def _is_two_layer(self):
+        keys = set(self.model.state_dict().keys())
+        return keys == {"gc1.weight", "gc1.bias", "gc2.weight", "gc2.bias"}
+
+    def _layers(self):
+        """[(W, b), ...] of a GraphConvolution stack (gc1, gc2, gc3, ...), on the features' device."""
+        sd, out, i = self.model.state_dict(), [], 1
+        while f"gc{i}.weight" in sd:
+            out.append((sd[f"gc{i}.weight"].detach().to(self.features.device),
+                        sd[f"gc{i}.bias"].detach().to(self.features.device)))
+            i += 1
+        if not out:
+            raise NotImplementedError("model has no gc<i>.weight layers")
+        return out
+
+    def _rows_generic(self, probe_nodes, observe_nodes):
+        """Probe rows for models the fused kernels do not cover (GCN3, --n-layer 3): per probe, row v of
+        S1 = X W1 is replaced by (x_v + x_v*d) W1 and the remaining layers run through lt_spmm_csr_f32 /
+        lt_gemm_f32.  Same quantity, ~2 launches per layer per probe; not a benchmarked path."""
+        layers = self._layers()
+        x, delta = self.features, float(self.args.influence)
+        g = engine.as_hip_graph(self.adj)
+
+        def rest(s1):
+            h = engine.spmm(g, s1, layers[0][1], relu=len(layers) > 1)
+            for li, (w, b) in enumerate(layers[1:], start=1):
+                h = engine.spmm(g, engine.gemm(h, w), b, relu=li < len(layers) - 1)
+            return h
+
+        s1 = engine.gemm(x, layers[0][0])
+        obs = torch.as_tensor(np.asarray(observe_nodes, dtype=np.int64), device=x.device)
+        base = rest(s1)[obs]
+        rows = torch.empty((len(probe_nodes), obs.numel()), dtype=torch.float32, device=x.device)
+        for i, v in enumerate(np.asarray(probe_nodes, dtype=np.int64)):
+            xv = x[v]
+            s1p = s1.clone()
+            s1p[v] = engine.gemm((xv + xv * delta)[None, :].contiguous(), layers[0][0])[0]
+            rows[i] = ((rest(s1p)[obs] - base) / delta).norm(dim=1)
+        return rows
+
+    def _rows(self, probe_nodes, observe_nodes, mode=None):
+        """[len(probe_nodes), len(observe_nodes)] influence rows on the device."""
+        if self._is_two_layer():
+            mode = mode or getattr(self.args, "influence_mode", None) or os.environ.get("LT_INFLUENCE_MODE", "full")
+            return self.baseline().influence_rows(probe_nodes, observe_nodes, float(self.args.influence), mode)
+        return self._rows_generic(probe_nodes, observe_nodes)
 
     def baseline(self) -> engine.Baseline:
         """Loop-invariant model(features, adj) of attacker.py:106, computed once."""
@@ -87,12 +138,10 @@ class Attacker:
         """influence_val[i][j] = ||grad_mat(test_nodes[i])[test_nodes[j]]||_2 (attacker.py:216-229)
         as float64 [n_test, n_test] on the host.  Probes are sharded over ranks when
         torch.distributed is initialised (one all-gather of row slabs)."""
-        mode = mode or getattr(self.args, "influence_mode", None) or os.environ.get("LT_INFLUENCE_MODE", "full")
         nodes = np.asarray(self.test_nodes, dtype=np.int64)
         rank, ws = lt_dist.world()
         b, e, _ = lt_dist.shard_bounds(len(nodes), rank, ws)
-        base = self.baseline()
-        local = base.influence_rows(nodes[b:e], nodes, float(self.args.influence), mode)
+        local = self._rows(nodes[b:e], nodes, mode)
         full = lt_dist.all_gather_rows(local, len(nodes))
         return full.cpu().numpy().astype(np.float64)
 
@@ -111,6 +160,80 @@ class Attacker:
             return list(influence_val[node2ind[pairs[:, 1]], node2ind[pairs[:, 0]]])
 
         self.compute_and_save(scores(self.exist_edges), scores(self.nonexist_edges))
+
+    def link_prediction_attack_efficient_balanced(self, chunk=1024):
+        """attacker.py:250-284 (``balanced-full``): for every node u that starts a pair, perturb u and
+        read ||grad[v]|| for its partners v.  Scores are emitted grouped by u ascending -- edges of u,
+        then non-edges of u, each in list order -- exactly as the reference appends them."""
+        t = time.time()
+        ex = np.asarray(self.exist_edges, dtype=np.int64).reshape(-1, 2)
+        nex = np.asarray(self.nonexist_edges, dtype=np.int64).reshape(-1, 2)
+        n = self.worker.n_nodes
+        all_nodes = np.arange(n, dtype=np.int64)
+        starts = np.union1d(ex[:, 0], nex[:, 0])
+        pos = np.full(n, -1, dtype=np.int64)
+        s_ex = np.empty(len(ex)); s_nex = np.empty(len(nex))
+        for c0 in range(0, len(starts), chunk):
+            probes = starts[c0:c0 + chunk]
+            rows = self._rows(probes, all_nodes).cpu().numpy().astype(np.float64)
+            pos[:] = -1
+            pos[probes] = np.arange(len(probes))
+            for pairs, dst in ((ex, s_ex), (nex, s_nex)):
+                sel = pos[pairs[:, 0]] >= 0
+                dst[sel] = rows[pos[pairs[sel, 0]], pairs[sel, 1]]
+        print(f"time for predicting edges: {time.time() - t}")
+        # stable sort by the first node reproduces the reference's grouped emission order
+        oe, on = np.argsort(ex[:, 0], kind="stable"), np.argsort(nex[:, 0], kind="stable")
+        self.compute_and_save(list(s_ex[oe]), list(s_nex[on]))
+
+    # ------------------------------------------------------------------------------------------
+    def _baseline_vectors(self):
+        """attacker.py:295-303: softmax posteriors (sigmoid for ppi) or the raw features, float32 on host."""
+        am = self.args.attack_mode
+        if am == "baseline":
+            with torch.no_grad():
+                out = self.model(self.features, self.adj)
+                post = torch.softmax(out, dim=1) if self.dataset != "ppi" else torch.sigmoid(out)
+            return post.float().cpu()
+        if am == "baseline-feat":
+            return self.features.float().cpu()
+        raise NotImplementedError(f"attack_mode={am} not implemented!")
+
+    def baseline_attack(self):
+        """LSA2-post / LSA2-attr, attacker.py:287-334: correlation of mean-centred vectors, the mean taken
+        over the sampled nodes; fp32 arithmetic, scores widened to float64 like the reference's matrix."""
+        t = time.time()
+        vec = self._baseline_vectors()
+        nodes = torch.as_tensor(np.asarray(self.test_nodes, dtype=np.int64))
+        d = vec[nodes] - torch.mean(vec[nodes], dim=0)
+        nrm = torch.norm(d, dim=1)
+        corr = ((d @ d.T) / nrm[:, None] / nrm[None, :]).numpy().astype(np.float64)
+        print(f"time for computing correlation value: {time.time() - t}")
+        node2ind = np.full(int(nodes.max()) + 1, -1, dtype=np.int64)
+        node2ind[nodes.numpy()] = np.arange(len(nodes))
+
+        def scores(pairs):
+            pairs = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+            i, j = node2ind[pairs[:, 0]], node2ind[pairs[:, 1]]
+            return list(corr[np.minimum(i, j), np.maximum(i, j)])
+
+        self.compute_and_save(scores(self.exist_edges), scores(self.nonexist_edges))
+
+    def baseline_attack_balanced(self):
+        """attacker.py:337-375: same correlation with the mean over all nodes, one value per listed pair."""
+        t = time.time()
+        vec = self._baseline_vectors()
+        d = vec - torch.mean(vec, dim=0)
+        nrm = torch.norm(d, dim=1)
+
+        def scores(pairs):
+            pairs = torch.as_tensor(np.asarray(pairs, dtype=np.int64).reshape(-1, 2))
+            u, v = pairs[:, 0], pairs[:, 1]
+            return list(((d[u] * d[v]).sum(dim=1) / nrm[u] / nrm[v]).numpy().astype(np.float64))
+
+        se, sn = scores(self.exist_edges), scores(self.nonexist_edges)
+        print(f"time for computing correlation value: {time.time() - t}")
+        self.compute_and_save(se, sn)
 
     # ------------------------------------------------------------------------------------------
     def result_filename(self):

@@ -62,3 +62,27 @@ def construct_edge_sets_from_random_subgraph(dataset, sample_type, adj, n_sample
     print("#edges_set =", len(edges))
     print("#nonedge_set =", len(non_edges))
     return (edges, non_edges), nodes
+
+
+def construct_balanced_edge_sets(dataset, sample_type, adj, n_samples):
+    """``balanced-full`` (reference utils/load.py:219-249): every u < v edge of the graph, plus as many
+    random pairs that are adjacent in neither direction.  The non-edge draws are two scalar
+    ``np.random.choice(n_nodes)`` calls per candidate, in the reference's order (u == v and repeated
+    pairs can occur, as they do there).  Returns ((edges, non_edges), all nodes)."""
+    adj = sp.csr_matrix(adj)
+    n_nodes = adj.shape[0]
+    indptr, indices = adj.indptr, adj.indices
+    rows = np.repeat(np.arange(n_nodes, dtype=np.int64), np.diff(indptr))
+    upper = indices > rows
+    edges = np.stack([rows[upper], indices[upper].astype(np.int64)], axis=1)
+    nbr_sets = [set(indices[indptr[u]: indptr[u + 1]].tolist()) for u in range(n_nodes)]
+    non_edges = np.empty((edges.shape[0], 2), dtype=np.int64)
+    k = 0
+    while k < edges.shape[0]:
+        u = np.random.choice(n_nodes)
+        v = np.random.choice(n_nodes)
+        if v not in nbr_sets[u] and u not in nbr_sets[v]:
+            non_edges[k] = (u, v)
+            k += 1
+    print(f"sampling done! len(edge_set) = {len(edges)}, len(nonedge_set) = {len(non_edges)}")
+    return (edges, non_edges), list(range(n_nodes))

@@ -68,11 +68,19 @@ class GCNTrainer:
             self.attacker = Attacker(args=a, model=self.model, worker=self.worker)
             self.attacker.prepare_test_data()
             t = time.time()
-            if a.attack_mode == "efficient" and a.sample_type != "balanced-full":
-                self.attacker.link_prediction_attack_efficient()
+            if a.attack_mode == "efficient":                      # gcn_trainer.py:326-337
+                if a.sample_type == "balanced-full":
+                    self.attacker.link_prediction_attack_efficient_balanced()
+                else:
+                    self.attacker.link_prediction_attack_efficient()
+            elif a.attack_mode in ("baseline", "baseline-feat"):
+                if a.sample_type == "balanced-full":
+                    self.attacker.baseline_attack_balanced()
+                else:
+                    self.attacker.baseline_attack()
             else:
-                raise NotImplementedError(f"attack_mode = {a.attack_mode} / sample_type = {a.sample_type} is outside "
-                                          "the hot path (SURVEY.md section 2)")
+                raise NotImplementedError(f"attack_mode = {a.attack_mode}: the per-pair naive attack is superseded by "
+                                          "the efficient one (SURVEY.md section 2)")
             print(f"attacks done using {time.time() - t} seconds!")
         labels = self.worker.labels_2
         loss_test = F.cross_entropy(output, labels.squeeze())

@@ -200,16 +200,84 @@ def result_filename(dataset, mode, attack_mode, sample_type, n_test, sample_seed
 # --------------------------------------------------------------------------------------
 # Baseline attacks (LSA2-post / LSA2-attr)                        attacker.py:287-375
 # --------------------------------------------------------------------------------------
-def baseline_attack_scores(vectors, exist_edges, nonexist_edges):
-    """Correlation of mean-centred rows; ``vectors`` = posteriors (attack_mode 'baseline',
-    attacker.py:297-299) or features ('baseline-feat', :300-301).  Formula at :306-312."""
+def baseline_vectors(attack_mode, features, adj, params, dataset, forward=gcn_forward):
+    """attacker.py:295-303: softmax posteriors ('baseline'; sigmoid for ppi) or raw features."""
+    if attack_mode == "baseline":
+        out = forward(features, adj, params)
+        return torch.softmax(out, dim=1) if dataset != "ppi" else torch.sigmoid(out)
+    if attack_mode == "baseline-feat":
+        return features
+    raise NotImplementedError(f"attack_mode={attack_mode} not implemented!")
+
+
+def _corr(vectors, mean, u, v):
+    du, dv = vectors[u] - mean, vectors[v] - mean
+    return torch.dot(du, dv) / torch.norm(du) / torch.norm(dv)
+
+
+def baseline_attack(vectors, test_nodes, exist_edges, nonexist_edges):
+    """attacker.py:305-334: mean over the SAMPLED nodes, correlation of every i < j pair stored in a
+    float64 matrix (so scores are fp32 values widened), looked up as dist[min][max]."""
+    n = len(test_nodes)
+    mean = torch.mean(vectors[torch.as_tensor(np.asarray(test_nodes))], dim=0)
+    dist = np.zeros((n, n))
+    for i in range(n):
+        for j in range(i + 1, n):
+            dist[i][j] = _corr(vectors, mean, int(test_nodes[i]), int(test_nodes[j]))
+    node2ind = {node: i for i, node in enumerate(test_nodes)}
+
+    def look(u, v):
+        i, j = node2ind[u], node2ind[v]
+        return dist[i][j] if i < j else dist[j][i]
+
+    return [look(u, v) for u, v in exist_edges], [look(u, v) for u, v in nonexist_edges]
+
+
+def baseline_attack_balanced(vectors, exist_edges, nonexist_edges):
+    """attacker.py:337-375: mean over ALL nodes, one correlation per listed pair (.item())."""
     mean = torch.mean(vectors, dim=0)
-    dist = vectors - mean
+    return ([_corr(vectors, mean, int(u), int(v)).item() for u, v in exist_edges],
+            [_corr(vectors, mean, int(u), int(v)).item() for u, v in nonexist_edges])
 
-    def corr(u, v):
-        return (torch.dot(dist[u], dist[v]) / torch.norm(dist[u]) / torch.norm(dist[v])).item()
 
-    return [corr(u, v) for u, v in exist_edges], [corr(u, v) for u, v in nonexist_edges]
+# --------------------------------------------------------------------------------------
+# balanced-full sampling + its efficient loop            utils/load.py:219-249, attacker.py:250-284
+# --------------------------------------------------------------------------------------
+def sample_balanced_full(adj_csr):
+    """``construct_balanced_edge_sets``: every u < v edge, and as many random pairs (u, v) that are
+    adjacent in neither direction (u == v and repeats are possible, as in the reference).
+    Caller seeds ``np.random`` first."""
+    indices, indptr, n_nodes = adj_csr.indices, adj_csr.indptr, adj_csr.shape[0]
+    nbrs = [indices[indptr[u]: indptr[u + 1]] for u in range(n_nodes)]
+    edge_set = [(u, v) for u in range(n_nodes) for v in nbrs[u] if v > u]
+    nonedge_set = []
+    while len(nonedge_set) < len(edge_set):
+        u = np.random.choice(n_nodes)
+        v = np.random.choice(n_nodes)
+        if v not in nbrs[u] and u not in nbrs[v]:
+            nonedge_set.append((u, v))
+    return (edge_set, nonedge_set), list(range(n_nodes))
+
+
+def efficient_balanced_scores(features, adj, params, n_nodes, exist_edges, nonexist_edges, influence,
+                              forward=gcn_forward):
+    """attacker.py:250-284: for every node u that starts a pair, perturb u and read ||grad[v]||;
+    scores come out grouped by u ascending (edges of u, then non-edges of u)."""
+    from collections import defaultdict
+    edges, nonedges = defaultdict(list), defaultdict(list)
+    for u, v in exist_edges:
+        edges[u].append(v)
+    for u, v in nonexist_edges:
+        nonedges[u].append(v)
+    norm_exist, norm_nonexist = [], []
+    with torch.no_grad():
+        for u in range(n_nodes):
+            if u not in edges and u not in nonedges:
+                continue
+            grad_mat = get_gradient_eps_mat(features, adj, params, u, influence, forward)
+            norm_exist += [grad_mat[int(v)].norm().item() for v in edges.get(u, [])]
+            norm_nonexist += [grad_mat[int(v)].norm().item() for v in nonedges.get(u, [])]
+    return norm_exist, norm_nonexist
 
 
 # --------------------------------------------------------------------------------------

@@ -336,9 +336,105 @@ def gen_dp():
     save("dp_adjacency.npz", **out)
 
 
+# ----------------------------------------------------------------------------------------
+# (7) "next" rows: baseline attacks, balanced-full, GCN3        attacker.py:250-375, models.py:28-46
+# ----------------------------------------------------------------------------------------
+def _run_and_capture(atk, method):
+    captured = {}
+    orig = atk.compute_and_save
+
+    def spy(norm_exist, norm_nonexist):
+        captured["norm_exist"] = np.asarray(norm_exist, dtype=np.float64)
+        captured["norm_nonexist"] = np.asarray(norm_nonexist, dtype=np.float64)
+        orig(norm_exist, norm_nonexist)
+
+    atk.compute_and_save = spy
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as td:
+        os.chdir(td)
+        try:
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+                getattr(atk, method)()
+            files = []
+            for root, _, fs in os.walk(td):
+                files += [os.path.relpath(os.path.join(root, f), td) for f in fs]
+        finally:
+            os.chdir(cwd)
+    lines = [ln for ln in buf.getvalue().splitlines() if ln.startswith(("auc =", "ap ="))]
+    captured["auc"] = np.float64(lines[0].split("=")[1])
+    captured["ap"] = np.float64(lines[1].split("=")[1])
+    captured["filename"] = np.array(files[0])
+    return captured
+
+
+def gen_next_rows():
+    out = {}
+    n, e, f, h, c = 300, 1400, 64, 32, 2
+    a = synth.powerlaw_graph(n, e, seed=51)
+    x = synth.twitch_like_features(n, f, seed=52, density=0.05)
+    for k, v in csr_parts(a).items():
+        out[f"adj.{k}"] = v
+    out["x"] = x
+    m32 = ref_model(f, h, c, seed=42)
+    for k, v in state_np(m32).items():
+        out[f"sd.{k}"] = v
+    # baseline / baseline-feat on an unbalanced sample (attacker.py:287-334)
+    for mode in ("baseline", "baseline-feat"):
+        args = make_args(n_test=40, sample_type="unbalanced", attack_mode=mode)
+        atk = ref_attacker.Attacker(args, m32, fake_worker(a, a, x, args.norm))
+        quiet(atk.prepare_test_data)
+        cap = _run_and_capture(atk, "baseline_attack")
+        for k, v in cap.items():
+            out[f"{mode}.{k}"] = v
+        out[f"{mode}.test_nodes"] = np.asarray(atk.test_nodes, dtype=np.int64)
+    # balanced-full: sampler + efficient_balanced + baseline_balanced (attacker.py:250-284, 337-375)
+    nb_, eb_ = 120, 420
+    ab = synth.powerlaw_graph(nb_, eb_, seed=53)
+    xb = synth.twitch_like_features(nb_, f, seed=54, density=0.05)
+    for k, v in csr_parts(ab).items():
+        out[f"bf.adj.{k}"] = v
+    out["bf.x"] = xb
+    args = make_args(n_test=7, sample_type="balanced-full", attack_mode="efficient", sample_seed=82)
+    for dt, tag in ((torch.float32, "ref32"), (torch.float64, "ref64")):
+        md = ref_model(f, h, c, seed=42, dtype=dt)
+        atk = ref_attacker.Attacker(args, md, fake_worker(ab, ab, xb, args.norm, dtype=dt))
+        quiet(atk.prepare_test_data)
+        assert args.n_test == nb_
+        cap = _run_and_capture(atk, "link_prediction_attack_efficient_balanced")
+        for k, v in cap.items():
+            out[f"bf.{tag}.{k}"] = v
+        if tag == "ref32":
+            out["bf.exist"] = np.asarray(atk.exist_edges, dtype=np.int64).reshape(-1, 2)
+            out["bf.nonexist"] = np.asarray(atk.nonexist_edges, dtype=np.int64).reshape(-1, 2)
+            args_b = make_args(n_test=nb_, sample_type="balanced-full", attack_mode="baseline", sample_seed=82)
+            atk_b = ref_attacker.Attacker(args_b, md, fake_worker(ab, ab, xb, args.norm))
+            atk_b.exist_edges, atk_b.nonexist_edges, atk_b.test_nodes = atk.exist_edges, atk.nonexist_edges, atk.test_nodes
+            capb = _run_and_capture(atk_b, "baseline_attack_balanced")
+            for k, v in capb.items():
+                out[f"bf.baseline.{k}"] = v
+        args.n_test = 7
+    # GCN3 served model under the efficient attack (--n-layer 3)
+    torch.manual_seed(42)
+    m3 = quiet(GCN3, nfeat=f, nhid1=32, nhid2=16, nclass=c, dropout=0.5)
+    m3.eval()
+    for k, v in state_np(m3).items():
+        out[f"gcn3.sd.{k}"] = v
+    args3 = make_args(n_test=32, sample_type="unbalanced")
+    r32 = run_attack(args3, m3, fake_worker(a, a, x, args3.norm))
+    m3d = quiet(GCN3, nfeat=f, nhid1=32, nhid2=16, nclass=c, dropout=0.5)
+    m3d.load_state_dict(m3.state_dict())
+    m3d.eval()
+    r64 = run_attack(args3, m3d.double(), fake_worker(a, a, x, args3.norm, dtype=torch.float64))
+    for k in ("influence_val", "test_nodes", "norm_exist", "norm_nonexist", "auc", "ap"):
+        out[f"gcn3.ref32.{k}"] = r32[k]
+        out[f"gcn3.ref64.{k}"] = r64[k]
+    save("next_rows.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["normalizer", "forward", "sampler", "influence", "dp"]
+    which = sys.argv[1:] or ["normalizer", "forward", "sampler", "influence", "dp", "next"]
     for w in which:
         print(f"[{w}]")
         {"normalizer": gen_normalizer, "forward": gen_forward, "sampler": gen_sampler,
-         "influence": gen_influence, "dp": gen_dp}[w]()
+         "influence": gen_influence, "dp": gen_dp, "next": gen_next_rows}[w]()

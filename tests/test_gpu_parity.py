@@ -172,3 +172,72 @@ def test_cli_end_to_end_matches_oracle(gpu, tmp_path, monkeypatch, capsys):
         if mode == "delta":
             import sklearn.metrics as skm
             assert abs(skm.auc(saved["auc"]["fpr"], saved["auc"]["tpr"]) - m["auc"]) <= 1e-4
+
+
+def _next_rows_setup(gpu, prefix_adj, xkey):
+    import argparse
+    import types
+    from linkteller_amd import graph
+    g = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "next_rows.npz"), allow_pickle=False)
+    a = csr_from(g, prefix_adj)
+    x = torch.from_numpy(g[xkey]).to(gpu)
+    adj_t = graph.sparse_mx_to_torch_sparse_tensor(graph.first_order_gcn(a)).to(gpu)
+    w = types.SimpleNamespace(features_2=x, adj_2=adj_t, adj_ori=a, n_nodes=a.shape[0])
+    return g, a, w, argparse
+
+
+def test_balanced_full_and_baselines_on_device(gpu, tmp_path, monkeypatch):
+    from linkteller_amd.attacker import Attacker
+    from linkteller_amd.gcn import GCN
+    g, ab, w, argparse = _next_rows_setup(gpu, "bf.adj", "bf.x")
+    model = GCN(64, 32, 2, 0.5)
+    model.load_state_dict({k: torch.from_numpy(g[f"sd.{k}"]) for k in ("gc1.weight", "gc1.bias", "gc2.weight", "gc2.bias")})
+    model.to(gpu).eval()
+    monkeypatch.chdir(tmp_path)
+    for mode, tol in (("delta", 1e-5), ("full", 3e-2)):
+        args = argparse.Namespace(dataset="twitch/ES/RU", sample_type="balanced-full", n_test=7, sample_seed=82,
+                                  influence=1e-4, mode="vanilla-clean", attack_mode="efficient", influence_mode=mode)
+        atk = Attacker(args, model, w)
+        atk.prepare_test_data()
+        assert np.array_equal(atk.exist_edges, g["bf.exist"])
+        atk.link_prediction_attack_efficient_balanced(chunk=50)      # several probe chunks
+        saved = torch.load(str(g["bf.ref32.filename"]), weights_only=False)
+        ref = np.concatenate([g["bf.ref64.norm_exist"], g["bf.ref64.norm_nonexist"]])
+        got = np.asarray(saved["result"]["pred"])
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= tol * ref.max()
+    args = argparse.Namespace(dataset="twitch/ES/RU", sample_type="balanced-full", n_test=7, sample_seed=82,
+                              influence=1e-4, mode="vanilla-clean", attack_mode="baseline")
+    atk = Attacker(args, model, w)
+    atk.prepare_test_data()
+    atk.baseline_attack_balanced()
+    got = np.asarray(torch.load(str(g["bf.baseline.filename"]), weights_only=False)["result"]["pred"])
+    ref = np.concatenate([g["bf.baseline.norm_exist"], g["bf.baseline.norm_nonexist"]])
+    assert np.abs(got - ref).max() <= 2e-5
+
+
+def test_gcn3_efficient_attack_on_device(gpu, tmp_path, monkeypatch):
+    from linkteller_amd.attacker import Attacker
+    from linkteller_amd.gcn import GCN3
+    g, a, w, argparse = _next_rows_setup(gpu, "adj", "x")
+    model = GCN3(64, 32, 16, 2, 0.5)
+    model.load_state_dict({k: torch.from_numpy(g[f"gcn3.sd.{k}"]) for k in
+                           ("gc1.weight", "gc1.bias", "gc2.weight", "gc2.bias", "gc3.weight", "gc3.bias")})
+    model.to(gpu).eval()
+    args = argparse.Namespace(dataset="twitch/ES/RU", sample_type="unbalanced", n_test=32, sample_seed=42,
+                              influence=1e-4, mode="vanilla-clean", attack_mode="efficient")
+    atk = Attacker(args, model, w)
+    atk.prepare_test_data()
+    assert np.array_equal(atk.test_nodes, g["gcn3.ref32.test_nodes"])
+    infl = atk.influence_matrix()
+    ref64, ref32 = g["gcn3.ref64.influence_val"], g["gcn3.ref32.influence_val"]
+    e32 = np.abs(ref32 - ref64).max()
+    assert np.abs(infl - ref64).max() <= 3.0 * e32            # fp32 finite difference: the reference's noise class
+    assert np.all(infl[ref64 == 0] == 0)
+    # logits of the 3-layer model through the unfused HIP layers
+    with torch.no_grad():
+        out = model(w.features_2, w.adj_2).cpu().numpy().astype(np.float64)
+    from oracle import linkteller_oracle as O
+    P3 = {k: torch.from_numpy(g[f"gcn3.sd.{n}"]).double() for k, n in (("W1", "gc1.weight"), ("b1", "gc1.bias"),
+          ("W2", "gc2.weight"), ("b2", "gc2.bias"), ("W3", "gc3.weight"), ("b3", "gc3.bias"))}
+    ref = O.gcn3_forward(torch.from_numpy(g["x"]).double(), O.to_torch_sparse(O.first_order_gcn(a)).double(), P3).numpy()
+    assert np.abs(out - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6

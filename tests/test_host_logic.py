@@ -111,3 +111,53 @@ def test_attacker_rejects_what_the_reference_cannot_run():
     w = types.SimpleNamespace(features=None, adj_full=None, adj_ori=sp.identity(8, format="csr"), n_nodes=8)
     with pytest.raises(NotImplementedError):
         Attacker(args, None, w).prepare_test_data()
+
+
+def test_balanced_full_sampler_matches_reference():
+    g = load_golden("next_rows.npz")
+    ab = csr_from(g, "bf.adj")
+    np.random.seed(82)
+    (ex, nex), nodes = sampling.construct_balanced_edge_sets("twitch/ES/RU", "balanced-full", ab, 7)
+    assert nodes == list(range(ab.shape[0]))
+    assert np.array_equal(ex, g["bf.exist"]) and np.array_equal(nex, g["bf.nonexist"])
+
+
+def test_baseline_attacks_host_math(monkeypatch, tmp_path):
+    """LSA2 baselines: the correlation math against the reference's scores, with the model forward
+    (the only device step) replaced by the oracle's posteriors."""
+    import argparse
+    import types
+    from oracle import linkteller_oracle as O
+    g = load_golden("next_rows.npz")
+    a = csr_from(g, "adj")
+    x = torch.from_numpy(g["x"])
+    P = {k: torch.from_numpy(g[f"sd.{n}"]) for k, n in (("W1", "gc1.weight"), ("b1", "gc1.bias"), ("W2", "gc2.weight"), ("b2", "gc2.bias"))}
+    adj = O.to_torch_sparse(O.first_order_gcn(a))
+    monkeypatch.chdir(tmp_path)
+    for mode in ("baseline", "baseline-feat"):
+        args = argparse.Namespace(dataset="twitch/ES/RU", sample_type="unbalanced", n_test=40, sample_seed=42,
+                                  influence=1e-4, mode="vanilla-clean", attack_mode=mode)
+        w = types.SimpleNamespace(features_2=x, adj_2=adj, adj_ori=a, n_nodes=a.shape[0])
+        atk = Attacker(args, model=lambda f, ad: O.gcn_forward(f, ad, P), worker=w)
+        atk.prepare_test_data()
+        atk.baseline_attack()
+        ref = np.concatenate([g[f"{mode}.norm_exist"], g[f"{mode}.norm_nonexist"]])
+        got = np.asarray(torch.load(str(g[f"{mode}.filename"]), weights_only=False)["result"]["pred"])
+        assert np.abs(got - ref).max() <= 2e-6                  # fp32 dot-product order only
+        if mode == "baseline-feat":
+            # with C = 2 the centred softmax posteriors are collinear, every correlation is +-1 up to
+            # rounding and the reference's own AUC is decided by that rounding: scores, not AUC, are the check
+            assert abs(atk.auc - float(g[f"{mode}.auc"])) <= 1e-4
+    ab = csr_from(g, "bf.adj")
+    xb = torch.from_numpy(g["bf.x"])
+    adjb = O.to_torch_sparse(O.first_order_gcn(ab))
+    args = argparse.Namespace(dataset="twitch/ES/RU", sample_type="balanced-full", n_test=7, sample_seed=82,
+                              influence=1e-4, mode="vanilla-clean", attack_mode="baseline")
+    w = types.SimpleNamespace(features_2=xb, adj_2=adjb, adj_ori=ab, n_nodes=ab.shape[0])
+    atk = Attacker(args, model=lambda f, ad: O.gcn_forward(f, ad, P), worker=w)
+    assert args.n_test == ab.shape[0]
+    atk.prepare_test_data()
+    atk.baseline_attack_balanced()
+    ref = np.concatenate([g["bf.baseline.norm_exist"], g["bf.baseline.norm_nonexist"]])
+    got = np.asarray(torch.load(str(g["bf.baseline.filename"]), weights_only=False)["result"]["pred"])
+    assert np.abs(got - ref).max() <= 2e-6

@@ -117,3 +117,52 @@ def test_dp_adjacency_generators():
         assert np.array_equal(res.indptr, g[f"{tag}.indptr"])
         assert np.array_equal(res.indices, g[f"{tag}.indices"])
         assert np.array_equal(np.asarray(res.data, dtype=np.float64), g[f"{tag}.data"])
+
+
+def test_next_rows_baseline_balanced_gcn3():
+    g = load_golden("next_rows.npz")
+    a = csr_from(g, "adj")
+    x = torch.from_numpy(g["x"])
+    adj = O.to_torch_sparse(O.first_order_gcn(a))
+    P = {k: torch.from_numpy(g[f"sd.{n}"]) for k, n in (("W1", "gc1.weight"), ("b1", "gc1.bias"), ("W2", "gc2.weight"), ("b2", "gc2.bias"))}
+    for mode in ("baseline", "baseline-feat"):
+        np.random.seed(42)
+        (ex, nex), nodes = O.sample_subgraph_pairs("twitch/ES/RU", "unbalanced", a, 40)
+        assert np.array_equal(nodes, g[f"{mode}.test_nodes"])
+        vec = O.baseline_vectors(mode, x, adj, P, "twitch/ES/RU")
+        ne, nn = O.baseline_attack(vec, nodes, ex, nex)
+        assert np.array_equal(np.asarray(ne), g[f"{mode}.norm_exist"])
+        assert np.array_equal(np.asarray(nn), g[f"{mode}.norm_nonexist"])
+        m = O.attack_metrics(ne, nn)
+        assert m["auc"] == float(g[f"{mode}.auc"]) and m["ap"] == float(g[f"{mode}.ap"])
+        assert O.result_filename("twitch/ES/RU", "vanilla-clean", mode, "unbalanced", 40, 42) == str(g[f"{mode}.filename"])
+    # balanced-full
+    ab = csr_from(g, "bf.adj")
+    xb = torch.from_numpy(g["bf.x"])
+    adjb = O.to_torch_sparse(O.first_order_gcn(ab))
+    np.random.seed(82)
+    (ex, nex), nodes = O.sample_balanced_full(ab)
+    assert nodes == list(range(ab.shape[0]))
+    assert np.array_equal(np.asarray(ex, dtype=np.int64).reshape(-1, 2), g["bf.exist"])
+    assert np.array_equal(np.asarray(nex, dtype=np.int64).reshape(-1, 2), g["bf.nonexist"])
+    for dt, tag in ((torch.float32, "ref32"), (torch.float64, "ref64")):
+        Pd = {k: v.to(dt) for k, v in P.items()}
+        ne, nn = O.efficient_balanced_scores(xb.to(dt), adjb.to(dt), Pd, ab.shape[0], ex, nex, 1e-4)
+        assert np.array_equal(np.asarray(ne), g[f"bf.{tag}.norm_exist"])
+        assert np.array_equal(np.asarray(nn), g[f"bf.{tag}.norm_nonexist"])
+    m = O.attack_metrics(g["bf.ref32.norm_exist"].tolist(), g["bf.ref32.norm_nonexist"].tolist())
+    assert m["auc"] == float(g["bf.ref32.auc"])
+    assert O.result_filename("twitch/ES/RU", "vanilla-clean", "efficient", "balanced-full", ab.shape[0], 82) == str(g["bf.ref32.filename"])
+    vec = O.baseline_vectors("baseline", xb, adjb, P, "twitch/ES/RU")
+    ne, nn = O.baseline_attack_balanced(vec, ex, nex)
+    assert np.array_equal(np.asarray(ne), g["bf.baseline.norm_exist"])
+    assert np.array_equal(np.asarray(nn), g["bf.baseline.norm_nonexist"])
+    # GCN3 under the efficient attack
+    names = (("W1", "gc1.weight"), ("b1", "gc1.bias"), ("W2", "gc2.weight"), ("b2", "gc2.bias"), ("W3", "gc3.weight"), ("b3", "gc3.bias"))
+    P3 = {k: torch.from_numpy(g[f"gcn3.sd.{n}"]) for k, n in names}
+    nodes3 = g["gcn3.ref32.test_nodes"]
+    infl = O.influence_matrix(x, adj, P3, nodes3, 1e-4, forward=O.gcn3_forward)
+    assert np.array_equal(infl, g["gcn3.ref32.influence_val"])
+    infl64 = O.influence_matrix(x.double(), adj.double(), {k: v.double() for k, v in P3.items()}, nodes3, 1e-4,
+                                forward=O.gcn3_forward)
+    assert np.array_equal(infl64, g["gcn3.ref64.influence_val"])
