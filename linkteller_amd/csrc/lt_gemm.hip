@@ -110,6 +110,119 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma(const float *__restrict__
     }
 }
 
+
+// ---- 128x128 block tile: each of the 4 waves owns a 64x64 quadrant = 2x2 MFMA tiles, so one A and
+// one B fragment feed two MFMAs each (half the LDS reads per flop of the 64x64 kernel) and a k-tile
+// carries 32 MFMAs per wave (2048 cycles) -- enough to cover the next tile's global loads with one
+// workgroup per CU.  Used for the big X*W1 product; same k-ordered fmaf chains per output.
+#define GL_BM 128
+#define GL_BN 128
+#define GL_LDA (GM_BK + 1)
+__global__ __launch_bounds__(256) void k_gemm_f32_mfma_128(const float *__restrict__ A, long lda,
+                                                           const float *__restrict__ B, long ldb,
+                                                           float *__restrict__ C, long ldc, int M, int N,
+                                                           int K, int kslice, long slab_stride) {
+    __shared__ __attribute__((aligned(16))) float As[2][GL_BM * GL_LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GM_BK * GL_BN];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int m0 = blockIdx.x * GL_BM, n0 = blockIdx.y * GL_BN;
+    const int kb = blockIdx.z * kslice, ke = min(K, kb + kslice);
+    C += (long)blockIdx.z * slab_stride;
+
+    // staging: A tile 128 x 16 -> thread owns rows (tid>>2) and (tid>>2)+64, 4 floats each;
+    //          B tile 16 x 128 -> thread owns rows (tid>>5) and (tid>>5)+8, 4 floats each
+    const int a_row = tid >> 2, a_col = (tid & 3) * 4;
+    const int b_row = tid >> 5, b_col = (tid & 31) * 4;
+    const float *a_ptr0 = A + (long)(m0 + a_row) * lda + a_col;
+    const float *a_ptr1 = a_ptr0 + 64 * lda;
+    const bool a_ok0 = (m0 + a_row) < M, a_ok1 = (m0 + a_row + 64) < M;
+    const float *b_ptr = B + (long)b_row * ldb + n0 + b_col;
+    const bool b_full = (n0 + b_col + 3) < N;
+    f32x4 ra0, ra1, rb0, rb1;
+    auto load_a = [&](const float *p, bool ok, int k0) {
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            if (k0 + a_col + 3 < ke) r = *reinterpret_cast<const f32x4u *>(p + k0);
+            else
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k0 + a_col + j < ke) r[j] = p[k0 + j];
+        }
+        return r;
+    };
+    auto load_b = [&](int krow) {
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (krow < ke) {
+            const float *p = b_ptr + (long)(krow - b_row) * ldb;
+            if (b_full) r = *reinterpret_cast<const f32x4u *>(p);
+            else
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (n0 + b_col + j < N) r[j] = p[j];
+        }
+        return r;
+    };
+    auto load_tiles = [&](int k0) {
+        ra0 = load_a(a_ptr0, a_ok0, k0);
+        ra1 = load_a(a_ptr1, a_ok1, k0);
+        rb0 = load_b(k0 + b_row);
+        rb1 = load_b(k0 + b_row + 8);
+    };
+    auto store_tiles = [&](int buf) {
+        float *as = &As[buf][a_row * GL_LDA + a_col];
+        as[0] = ra0.x; as[1] = ra0.y; as[2] = ra0.z; as[3] = ra0.w;
+        as += 64 * GL_LDA;
+        as[0] = ra1.x; as[1] = ra1.y; as[2] = ra1.z; as[3] = ra1.w;
+        *reinterpret_cast<f32x4 *>(&Bs[buf][b_row * GL_BN + b_col]) = rb0;
+        *reinterpret_cast<f32x4 *>(&Bs[buf][(b_row + 8) * GL_BN + b_col]) = rb1;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = (ke - kb + GM_BK - 1) / GM_BK;
+    load_tiles(kb);
+    store_tiles(0);
+    __syncthreads();
+    const int a_frag = (wr * 64 + (lane & 31)) * GL_LDA + (lane >> 5);
+    const int b_frag = (lane >> 5) * GL_BN + wc * 64 + (lane & 31);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles(kb + (kt + 1) * GM_BK);
+        const float *as = &As[buf][a_frag];
+        const float *bs = &Bs[buf][b_frag];
+#pragma unroll
+        for (int kk = 0; kk < GM_BK; kk += 2) {
+            const float a0 = as[kk], a1 = as[32 * GL_LDA + kk];
+            const float b0 = bs[kk * GL_BN], b1 = bs[kk * GL_BN + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int cn = n0 + wc * 64 + j * 32 + (lane & 31);
+            if (cn >= N) continue;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int cm = m0 + wr * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                if (cm < M) C[(long)cm * ldc + cn] = acc[i][j][reg];
+            }
+        }
+}
+
 int lt_launch_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
                    int M, int N, int K, hipStream_t st) {
     if (M == 0 || N == 0) return LT_OK;
@@ -147,12 +260,18 @@ int lt_launch_gemm_splitk(const float *A, int64_t lda, const float *B, int64_t l
     if (M == 0 || N == 0) return LT_OK;
     const int splits = (K + kslice - 1) / kslice;
     if (splits <= 1) return lt_launch_gemm(A, lda, B, ldb, C, ldc, M, N, K, st);
-    dim3 grid((M + GM_BM - 1) / GM_BM, (N + GM_BN - 1) / GM_BN, splits);
+    const bool big = M >= 1024 && N >= 128;
+    dim3 grid(big ? (M + GL_BM - 1) / GL_BM : (M + GM_BM - 1) / GM_BM,
+              big ? (N + GL_BN - 1) / GL_BN : (N + GM_BN - 1) / GM_BN, splits);
     const long stride = (long)M * N;
     {
         lt_prof_scope prof_(LT_K_GEMM, st);
-        hipLaunchKernelGGL(k_gemm_f32_mfma, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, slabs,
-                           (long)N, M, N, K, kslice, stride);
+        if (big)
+            hipLaunchKernelGGL(k_gemm_f32_mfma_128, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, slabs,
+                               (long)N, M, N, K, kslice, stride);
+        else
+            hipLaunchKernelGGL(k_gemm_f32_mfma, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, slabs,
+                               (long)N, M, N, K, kslice, stride);
         LT_CHECK_LAUNCH();
         const long tot = (long)M * N;
         hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, slabs, stride,

@@ -453,77 +453,62 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
         consume(h, aC, std::integral_constant<int, 0>{});
     }
 
-    if (__builtin_expect(__ballot(anyhit) != 0ull, 0)) {
-        // a column of this row is one of my probes (about P*deg/n of the waves): hand the (row, group)
-        // to k_full_stageA_redo, which applies the per-probe substitution; keeping that select path out
-        // of this kernel is worth 50 VGPRs (152 -> 102)
-        if (lane == 0) redo[1 + atomicAdd(redo, 1)] = blockIdx.x;
-        return;
+    const unsigned hitmask = (unsigned)__ballot(anyhit);   // bit p: probe pb+p sits on one of this row's columns
+    if (__builtin_expect(hitmask != 0u, 0)) {
+        // a column of this row is one of my probes (about P*deg/n of the waves).  This wave still
+        // finishes the row with the UNSUBSTITUTED S1 row for all P probes -- right for every probe but
+        // the one(s) sitting on that column -- and hands (row, group) to k_full_stageA_fix, which
+        // recomputes just those probes with their own perturbed row and overwrites their S2' entries.
+        // Keeping the select path out of this kernel is worth 50 VGPRs (152 -> 102).
+        if (lane == 0) {
+            const int slot = atomicAdd(redo, 1);
+            redo[1 + 2 * slot] = blockIdx.x;
+            redo[2 + 2 * slot] = (int)hitmask;
+        }
     }
     stageA_epilogue<CP, P>(acc, lane, active, coff, b1p, W2p, C, n, nb, r, pb, S2p);
   }
 }
 
-// Redo kernel of the ring variant: (row, probe group) pairs whose row contains one of the group's probes.
-// Same fmaf chains, with the probe's own perturbed S1 row substituted on its column; grid-stride over
-// the list the ring kernel appended (order does not matter: each pair owns its outputs).
-template <int CP, int P>
-__global__ __launch_bounds__(64) void k_full_stageA_redo(
+// Fix-up kernel of the ring variant: for every listed (row, probe group) and every probe of the group that
+// sits on one of the row's columns, the row's layer-1 value with that probe's perturbed S1 row substituted
+// (row_dot + relu_w2_partial + group_sum: the single-probe chain every other kernel uses), written over
+// the unsubstituted value the ring kernel stored.  ~|R_v| single-probe rows per probe: tiny.
+template <int CP, int PM>
+__global__ __launch_bounds__(64) void k_full_stageA_fix(
     int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ S1, int Hp,
     const float *__restrict__ b1p, const float *__restrict__ W2p, int C,
     const int32_t *__restrict__ probes, int nb, const float *__restrict__ Sp,
     float *__restrict__ S2p, const int32_t *__restrict__ redo) {
     const int lane = threadIdx.x;
-    const int groups = (nb + P - 1) / P;
+    const int groups = (nb + PM - 1) / PM;
     const int count = redo[0];
     const bool active = 4 * lane < Hp;
     const int coff = active ? 4 * lane : Hp - 4;
-    const float *__restrict__ S1c = S1 + coff;
-    const float *__restrict__ Spc = Sp + coff;
     for (int it = blockIdx.x; it < count; it += gridDim.x) {
-        const int bid = redo[1 + it];
+        const int bid = redo[1 + 2 * it];
+        unsigned mask = (unsigned)redo[2 + 2 * it];
         const int r = bid / groups;
-        const int pb = (bid % groups) * P;
-        const int vprobe = (lane < P && pb + lane < nb) ? probes[pb + lane] : -1;
-        f32x4 acc[P];
-#pragma unroll
-        for (int p = 0; p < P; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int pb = (bid % groups) * PM;
         const int e0 = rowptr[r], e1 = rowptr[r + 1];
-        auto entry = [&](int c, float a, f32x4 s) {
-            // bit p of m: probe pb+p sits on column c (probe ids live one per lane in vprobe)
-            const unsigned m = (unsigned)__ballot(vprobe == c);
-            if (m == 0u) {
+        while (mask) {
+            const int p = __builtin_ctz(mask);
+            mask &= mask - 1;
+            const int v = probes[pb + p];
+            const f32x4 acc = row_dot(col, val, e0, e1, S1, Hp, coff, true, v, Sp + (size_t)(pb + p) * Hp);
+            float part[CP];
 #pragma unroll
-                for (int p = 0; p < P; ++p) acc[p] = fma4(a, s, acc[p]);
-            } else {
-                int pbq = pb;
-                asm volatile("" : "+s"(pbq));
+            for (int c = 0; c < CP; ++c) part[c] = 0.f;
+            if (active) relu_w2_partial<CP>(acc, ld4(b1p + coff), W2p + (size_t)coff * C, C, part);
 #pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    f32x4 sp = s;
-                    if ((m >> p) & 1u) {
-                        sp = ld4(Spc + (size_t)(pbq + p) * Hp);
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sp));
-                    }
-                    acc[p] = fma4(a, sp, acc[p]);
-                }
+            for (int c = 0; c < CP; ++c) part[c] = group_sum<64>(part[c]);
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < CP; ++c)
+                    if (c < C) S2p[((size_t)r * nb + pb + p) * C + c] = part[c];
             }
-        };
-        int e = e0;
-        for (; e + 4 <= e1; e += 4) {
-            int c[4];
-            float a[4];
-            f32x4 s[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { c[k] = col[e + k]; a[k] = val[e + k]; }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) s[k] = ld4(S1c + (size_t)c[k] * Hp);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) entry(c[k], a[k], s[k]);
         }
-        for (; e < e1; ++e) entry(col[e], val[e], ld4(S1c + (size_t)col[e] * Hp));
-        stageA_epilogue<CP, P>(acc, lane, active, coff, b1p, W2p, C, n, nb, r, pb, S2p);
     }
 }
 
@@ -824,7 +809,7 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
     const size_t maxc = (size_t)(b->g->max_col_nnz > 0 ? b->g->max_col_nnz : 1);
     size_t per_probe = 0;
     const size_t splitk = ((F + LT_KSLICE_PROBE - 1) / LT_KSLICE_PROBE) * (size_t)b->H;
-    if (mode == LT_MODE_FULL) per_probe = (n * C + F + Hp + splitk) * sizeof(float) + n / 4;
+    if (mode == LT_MODE_FULL) per_probe = (n * C + F + Hp + splitk) * sizeof(float) + n;
     else if (mode == LT_MODE_SPARSE) per_probe = (maxc * C + F + Hp + splitk) * sizeof(float) + sizeof(int32_t);
     else per_probe = maxc * C * sizeof(float) + sizeof(int32_t);
     size_t chunk = LT_CHUNK_BUDGET / (per_probe ? per_probe : 1);
@@ -846,7 +831,7 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
     }
     if (mode == LT_MODE_FULL) {
         w.S2p = (float *)take(chunk * n * C * sizeof(float));
-        w.redo = (int32_t *)take((1 + n * ((chunk + 7) / 8)) * sizeof(int32_t));
+        w.redo = (int32_t *)take((1 + 2 * n * ((chunk + 7) / 8)) * sizeof(int32_t));
     }
     if (mode != LT_MODE_FULL) {
         w.S2x = (float *)take(chunk * maxc * C * sizeof(float));
@@ -922,7 +907,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                                g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p,
                                                                C, probes, nb, w.Sp, w.S2p, w.redo));
                         LT_CHECK_LAUNCH();
-                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_redo<CP_, 8>), dim3(4096), dim3(64), 0, st,
+                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_fix<CP_, 8>), dim3(2048), dim3(64), 0, st,
                                                                n, g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p,
                                                                C, probes, nb, w.Sp, w.S2p, w.redo));
                     } else if (Pr == 32) {
@@ -930,7 +915,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                                g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p,
                                                                C, probes, nb, w.Sp, w.S2p, w.redo));
                         LT_CHECK_LAUNCH();
-                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_redo<CP_, 32>), dim3(4096), dim3(64), 0, st,
+                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_fix<CP_, 32>), dim3(2048), dim3(64), 0, st,
                                                                n, g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p,
                                                                C, probes, nb, w.Sp, w.S2p, w.redo));
                     } else {
@@ -938,7 +923,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                                g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p,
                                                                C, probes, nb, w.Sp, w.S2p, w.redo));
                         LT_CHECK_LAUNCH();
-                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_redo<CP_, 16>), dim3(4096), dim3(64), 0, st,
+                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_fix<CP_, 16>), dim3(2048), dim3(64), 0, st,
                                                                n, g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p,
                                                                C, probes, nb, w.Sp, w.S2p, w.redo));
                     }
