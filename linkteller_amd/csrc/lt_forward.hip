@@ -279,7 +279,7 @@ static gcn2_ws carve_gcn2(void *base, int n, int H, int C, int F) {
     w.S2 = (float *)(p + off);  off += lt_align_up((size_t)n * C * sizeof(float), 256);
     w.b1p = (float *)(p + off); off += lt_align_up((size_t)Hp * sizeof(float), 256);
     w.W2p = (float *)(p + off); off += lt_align_up((size_t)Hp * C * sizeof(float), 256);
-    const size_t sb = lt_gemm_splitk_slab_bytes(n, H, F, LT_KSLICE_BASE);
+    const size_t sb = lt_gemm_splitk_slab_bytes(n, H, F, lt_gemm_pick_kslice(n, H, F));
     w.slabs = sb ? (float *)(p + off) : nullptr; off += lt_align_up(sb, 256);
     w.bytes = off;
     return w;
@@ -299,7 +299,7 @@ static int prepare_layer_inputs(int n, const float *X, int64_t ldx, int F, const
     hipLaunchKernelGGL(k_pad_rows, dim3((Hp + 255) / 256), dim3(256), 0, st, b1, H, Hp, 1, b1p);
     hipLaunchKernelGGL(k_pad_rows, dim3((Hp * C + 255) / 256), dim3(256), 0, st, W2, H, Hp, C, W2p);
     LT_CHECK_LAUNCH();
-    if (slabs) return lt_launch_gemm_splitk(X, ldx, W1, H, S1, Hp, n, H, F, LT_KSLICE_BASE, slabs, st);
+    if (slabs) return lt_launch_gemm_splitk(X, ldx, W1, H, S1, Hp, n, H, F, lt_gemm_pick_kslice(n, H, F), slabs, st);
     return lt_launch_gemm(X, ldx, W1, H, S1, Hp, n, H, F, st);
 }
 
@@ -385,8 +385,8 @@ extern "C" int lt_baseline_create(const lt_graph *g, const float *X, int64_t ldx
     B_HIP(hipMalloc((void **)&b->OUT, nc));
     B_HIP(hipMalloc((void **)&b->b1p, (size_t)b->Hp * sizeof(float)));
     B_HIP(hipMalloc((void **)&b->W2p, (size_t)b->Hp * C * sizeof(float)));
-    if (lt_gemm_splitk_slab_bytes(b->n, H, F, LT_KSLICE_BASE))
-        B_HIP(hipMalloc((void **)&b->slabs, lt_gemm_splitk_slab_bytes(b->n, H, F, LT_KSLICE_BASE)));
+    if (lt_gemm_splitk_slab_bytes(b->n, H, F, lt_gemm_pick_kslice(b->n, H, F)))
+        B_HIP(hipMalloc((void **)&b->slabs, lt_gemm_splitk_slab_bytes(b->n, H, F, lt_gemm_pick_kslice(b->n, H, F))));
 #undef B_HIP
     rc = lt_baseline_refresh(b, stream);
     if (rc) {

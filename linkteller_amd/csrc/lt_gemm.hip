@@ -246,6 +246,25 @@ __global__ void k_sum_slabs(const float *__restrict__ slabs, long slab_stride, i
     C[(long)r * ldc + c] = acc;
 }
 
+// Slice length for the big (128x128-tile) split-K product: pick the slice count whose workgroups fill the
+// 256 CUs in whole rounds (a 2.2-blocks-per-CU grid runs as long as a 3-per-CU one), charging each extra
+// slab ~2 tile-steps of write + re-read.  Deterministic in (M, N, K); multiples of 16.
+int lt_gemm_pick_kslice(int M, int N, int K) {
+    const long tiles = (long)((M + GL_BM - 1) / GL_BM) * ((N + GL_BN - 1) / GL_BN);
+    int best_s = 1;
+    double best = 1e30;
+    for (int s = 1; s <= 16; ++s) {
+        const int ks = ((K + s - 1) / s + GM_BK - 1) / GM_BK * GM_BK;
+        if (ks <= 0) break;
+        const int slices = (K + ks - 1) / ks;
+        const long rounds = (tiles * slices + 255) / 256;
+        const double cost = (double)rounds * (ks / GM_BK) + 2.2 * (slices - 1);
+        if (cost < best - 1e-9) { best = cost; best_s = s; }
+    }
+    const int ks = ((K + best_s - 1) / best_s + GM_BK - 1) / GM_BK * GM_BK;
+    return ks > 0 ? ks : GM_BK;
+}
+
 size_t lt_gemm_splitk_slab_bytes(int M, int N, int K, int kslice) {
     const int splits = (K + kslice - 1) / kslice;
     return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;

@@ -107,7 +107,8 @@ int lt_launch_layer2(const lt_graph *g, const float *S2, int C, const float *b2,
 int lt_launch_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
                    int64_t ldc, int M, int N, int K, hipStream_t st);
 #define LT_KSLICE_PROBE 256   // perturbed-row GEMM (M = probes of a chunk)
-#define LT_KSLICE_BASE 400    // baseline X*W1 (M = n): 8 slices at F = 3170 -> 560 workgroups of 128x128
+#define LT_KSLICE_BASE 400    // fp64 X*W1 of the delta mode (64x64 tiles)
 size_t lt_gemm_splitk_slab_bytes(int M, int N, int K, int kslice);
+int lt_gemm_pick_kslice(int M, int N, int K);   // baseline X*W1: slice length that fills the CUs in whole rounds
 int lt_launch_gemm_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
                           int64_t ldc, int M, int N, int K, int kslice, float *slabs, hipStream_t st);
