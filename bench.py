@@ -70,11 +70,19 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # test hooks (used to exercise the N > 1 flow on a 1-GPU box): LT_BENCH_DEVICE pins every rank to one
+    # device, LT_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU)
+    if os.environ.get("LT_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["LT_BENCH_DEVICE"])
+    backend = os.environ.get("LT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from linkteller_amd import _lib, engine, graph, synth
     from linkteller_amd import dist as lt_dist
@@ -156,8 +164,8 @@ def main():
             unit = "one SpMM"
         traffic = None
         tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile):
-            try:
+        if os.path.exists(tfile) and world == 1 and a.n_test == 500 and a.workload == "twitch-RU" and not a.powerlaw:
+            try:   # PMC counters were collected for exactly this launch shape (profiles/README.md)
                 traffic = json.load(open(tfile)).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
