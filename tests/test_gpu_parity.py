@@ -241,3 +241,87 @@ def test_gcn3_efficient_attack_on_device(gpu, tmp_path, monkeypatch):
           ("W2", "gc2.weight"), ("b2", "gc2.bias"), ("W3", "gc3.weight"), ("b3", "gc3.bias"))}
     ref = O.gcn3_forward(torch.from_numpy(g["x"]).double(), O.to_torch_sparse(O.first_order_gcn(a)).double(), P3).numpy()
     assert np.abs(out - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
+
+
+def _oracle_matrix(adj_hat_csr, x, w, probes, observe, delta, dtype):
+    """Reference algorithm (oracle) for arbitrary probe / observe node lists."""
+    from oracle import linkteller_oracle as O
+    adj_t = O.to_torch_sparse(adj_hat_csr).to(dtype)
+    P = {k: torch.from_numpy(w[k]).to(dtype) for k in ("W1", "b1", "W2", "b2")}
+    xt = torch.from_numpy(x).to(dtype)
+    out = np.zeros((len(probes), len(observe)))
+    with torch.no_grad():
+        for i, v in enumerate(probes):
+            g = O.get_gradient_eps_mat(xt, adj_t, P, int(v), delta)
+            out[i] = g[torch.as_tensor(np.asarray(observe))].norm(dim=1).numpy()
+    return out
+
+
+@pytest.mark.parametrize("h,c,norm", [(10, 2, "FirstOrderGCN"), (100, 3, "FirstOrderGCN"), (16, 1, "AugNormAdj"),
+                                      (256, 8, "FirstOrderGCN"), (64, 7, "NormAdj"), (132, 2, "FirstOrderGCN")])
+def test_shapes_and_edge_cases(gpu, h, c, norm):
+    """Hidden widths that need padding / several lane groupings, 1..8 classes, graphs with isolated nodes
+    and (NormAdj) empty rows, duplicate probes, observe list != probe list, a single probe."""
+    import scipy.sparse as sp
+    from linkteller_amd import engine, graph, synth
+    n, f = 180, 40
+    a = synth.powerlaw_graph(n, 500, seed=h + c).tolil()
+    for k in (5, 17, 99):                # isolated nodes
+        a[k, :] = 0
+        a[:, k] = 0
+    a = sp.csr_matrix(a)
+    a.eliminate_zeros()
+    a_hat = graph.fetch_normalization(norm)(a)
+    x = synth.gaussian_features(n, f, seed=3)
+    w = synth.gcn_weights(f, h, c, seed=h)
+    base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu),
+                           *[torch.from_numpy(w[k]).to(gpu) for k in ("W1", "b1", "W2", "b2")])
+    rng = np.random.RandomState(1)
+    probes = np.concatenate([rng.choice(n, 21, replace=False), [5, 17], [3, 3]])     # isolated + duplicate probes
+    observe = np.concatenate([rng.choice(n, 30, replace=False), [99, 5]])
+    ref64 = _oracle_matrix(a_hat, x, w, probes, observe, 1e-4, torch.float64)
+    ref32 = _oracle_matrix(a_hat, x, w, probes, observe, 1e-4, torch.float32)
+    scale = max(ref64.max(), 1e-6)
+    e32 = np.abs(ref32 - ref64).max()
+    res = {m: base.influence_rows(probes, observe, 1e-4, m).cpu().numpy().astype(np.float64) for m in ("full", "sparse", "delta")}
+    assert np.array_equal(res["full"], res["sparse"])
+    assert np.abs(res["delta"] - ref64).max() <= 1e-5 * scale
+    assert np.abs(res["full"] - ref64).max() <= 3.0 * e32 + 1e-4 * scale
+    for r in res.values():
+        assert np.all(r[ref64 == 0] == 0)
+    assert np.array_equal(res["full"][-1], res["full"][-2])          # duplicate probe -> identical rows
+    one = base.influence_rows(probes[:1], observe, 1e-4, "full").cpu().numpy()
+    assert np.array_equal(one[0], res["full"][0].astype(np.float32))
+    logits = base.logits().cpu().numpy().astype(np.float64)
+    from oracle import linkteller_oracle as O
+    ref_logits = O.gcn_forward(torch.from_numpy(x).double(), O.to_torch_sparse(a_hat).double(),
+                               {k: torch.from_numpy(w[k]).double() for k in w}).numpy()
+    assert np.abs(logits - ref_logits).max() <= 2e-5 * max(1.0, np.abs(ref_logits).max())
+
+
+def test_empty_and_degenerate_calls(gpu):
+    import scipy.sparse as sp
+    from linkteller_amd import _lib, engine, graph, synth
+    a_hat = graph.first_order_gcn(synth.erdos_renyi_graph(50, 100, seed=1))
+    x = synth.gaussian_features(50, 12, seed=2)
+    w = synth.gcn_weights(12, 32, 2, seed=1)
+    base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu),
+                           *[torch.from_numpy(w[k]).to(gpu) for k in ("W1", "b1", "W2", "b2")])
+    assert base.influence_rows([], [1, 2], 1e-4, "full").shape == (0, 2)
+    assert base.influence_rows([1, 2], [], 1e-4, "delta").shape == (2, 0)
+    with pytest.raises(IndexError):
+        base.influence_rows([50], [0], 1e-4, "full")
+    with pytest.raises(IndexError):
+        base.influence_rows([0], [-1], 1e-4, "full")
+    with pytest.raises(_lib.LinkTellerHipError):        # unsupported shapes fail loudly, no fallback
+        engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), torch.zeros(12, 300, device=gpu),
+                        torch.zeros(300, device=gpu), torch.zeros(300, 2, device=gpu), torch.zeros(2, device=gpu))
+    with pytest.raises(_lib.LinkTellerHipError):
+        engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), torch.zeros(12, 16, device=gpu),
+                        torch.zeros(16, device=gpu), torch.zeros(16, 9, device=gpu), torch.zeros(9, device=gpu))
+    # graph with no edges at all: A_hat = I, influence is purely the self term
+    eye = graph.first_order_gcn(sp.csr_matrix((50, 50), dtype=np.float32))
+    b2 = engine.Baseline(graph.HipGraph(eye), torch.from_numpy(x).to(gpu),
+                         *[torch.from_numpy(w[k]).to(gpu) for k in ("W1", "b1", "W2", "b2")])
+    r = b2.influence_rows([0, 1, 2], [0, 1, 2], 1e-4, "delta").cpu().numpy()
+    assert np.all(r[~np.eye(3, dtype=bool)] == 0) and np.all(np.diag(r) > 0)
