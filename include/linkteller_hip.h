@@ -127,9 +127,11 @@ int lt_influence_rows(const lt_baseline *b, const int32_t *probe_nodes, int32_t 
                       void *stream);
 
 /* ---- per-kernel timing (used by bench.py for the roofline object) --------------------------
- * When enabled, every launcher brackets its kernel with a pair of hipEvents on the caller's
- * stream.  lt_profile_summary synchronises on the recorded events and returns the summed
- * duration and launch count of one kernel class.  No reference counterpart (the reference only
+ * lt_profile_enable(mask): bit k of mask set = launches of kernel class k are bracketed by a pair of
+ * hipEvents on the caller's stream (mask 0 = off, -1 = every class; an event pair costs a few
+ * microseconds of stream time, so a timed region should enable only what it reports).
+ * lt_profile_summary synchronises on the recorded events and returns the summed duration and
+ * launch count of one kernel class.  No reference counterpart (the reference only
  * has wall-clock prints, attacker.py:213,231). */
 typedef enum lt_kernel_id {
     LT_K_GEMM = 0,        /* k_gemm_f32_mfma                           */
@@ -143,7 +145,7 @@ typedef enum lt_kernel_id {
     LT_K_SPMM = 8,        /* k_spmm_rows / k_spmm_narrow               */
     LT_K_COUNT = 9
 } lt_kernel_id;
-int lt_profile_enable(int enable);
+int lt_profile_enable(int mask);
 int lt_profile_reset(void);
 int lt_profile_summary(int kernel_id, double *total_ms, int64_t *launches);
 

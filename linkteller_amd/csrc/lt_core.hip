@@ -177,7 +177,7 @@ extern "C" int lt_graph_info(const lt_graph *g, int32_t *n, int64_t *nnz, int32_
 }
 
 // ---- per-kernel event timing ------------------------------------------------------------------
-bool g_lt_profile_on = false;
+unsigned g_lt_profile_mask = 0;   // bit k set: kernel class k is bracketed by events
 namespace {
 struct prof_rec { int id; hipEvent_t a, b; };
 std::vector<prof_rec> g_recs;
@@ -207,9 +207,9 @@ extern "C" int lt_profile_reset(void) {
     g_recs.clear();
     return LT_OK;
 }
-extern "C" int lt_profile_enable(int enable) {
+extern "C" int lt_profile_enable(int mask) {
     lt_profile_reset();
-    g_lt_profile_on = enable != 0;
+    g_lt_profile_mask = (unsigned)mask;
     return LT_OK;
 }
 extern "C" int lt_profile_summary(int kernel_id, double *total_ms, int64_t *launches) {

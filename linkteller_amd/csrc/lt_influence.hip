@@ -348,6 +348,8 @@ __global__ __launch_bounds__(64 * LT_STAGEA_WAVES) void k_full_stageA_wide(
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 
+__global__ void k_zero_counter(int32_t *p) { *p = 0; }
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -901,7 +903,8 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                     const int rgroups = (nb + Pr - 1) / Pr;
                     LT_REQUIRE(rblocks * rgroups < 2147483647L, "lt_influence_rows: grid limit");
                     dim3 gridr((unsigned)(rblocks * rgroups));
-                    LT_HIP(hipMemsetAsync(w.redo, 0, sizeof(int32_t), st));
+                    hipLaunchKernelGGL(k_zero_counter, dim3(1), dim3(1), 0, st, w.redo);   // (a memset node here faults under hipGraph replay)
+                    LT_CHECK_LAUNCH();
                     if (Pr == 8) {
                         LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, 8>), gridr, dim3(64), 0, st, n,
                                                                g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p,

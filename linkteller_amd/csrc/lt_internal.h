@@ -85,12 +85,12 @@ static inline int lt_round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline size_t lt_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- optional per-kernel event timing (lt_core.hip) ------------------------------------------
-extern bool g_lt_profile_on;
+extern unsigned g_lt_profile_mask;
 void lt_profile_begin(int kernel_id, hipStream_t st);
 void lt_profile_end(int kernel_id, hipStream_t st);
 struct lt_prof_scope {
     int id; hipStream_t st; bool on;
-    lt_prof_scope(int id_, hipStream_t st_) : id(id_), st(st_), on(g_lt_profile_on) { if (on) lt_profile_begin(id, st); }
+    lt_prof_scope(int id_, hipStream_t st_) : id(id_), st(st_), on((g_lt_profile_mask >> id_) & 1u) { if (on) lt_profile_begin(id, st); }
     ~lt_prof_scope() { if (on) lt_profile_end(id, st); }
 };
 
