@@ -347,6 +347,7 @@ __global__ __launch_bounds__(64 * LT_STAGEA_WAVES) void k_full_stageA_wide(
 #endif
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 __global__ void k_zero_counter(int32_t *p) { *p = 0; }
 
@@ -378,9 +379,14 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
 
     f32x4 acc[P];
 #pragma unroll
-    for (int p = 0; p < P; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < P; ++p) {   // v_mov_b64 pairs: half the instructions of 4 x v_mov_b32 (this kernel is VALU-issue bound)
+        double lo, hi;
+        asm("v_mov_b64 %0, 0" : "=v"(lo));
+        asm("v_mov_b64 %0, 0" : "=v"(hi));
+        const f32x2_t l2 = __builtin_bit_cast(f32x2_t, lo), h2 = __builtin_bit_cast(f32x2_t, hi);
+        acc[p] = f32x4{l2.x, l2.y, h2.x, h2.y};
+    }
 
-    const float *__restrict__ S1c = S1 + coff;
     const int e0 = rowptr[r], e1 = rowptr[r + 1];
     const int deg = e1 - e0;
     const int nh = (deg + 3) >> 2;
@@ -404,12 +410,13 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             anyhit |= (vprobe == c[k]) & (4 * h + k < deg);
-            __builtin_amdgcn_global_load_lds(S1c + (size_t)c[k] * Hp, (lds_ptr_t)(ring + (base + k) * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((S1 + (size_t)c[k] * Hp) + coff, (lds_ptr_t)(ring + (base + k) * 256), 16, 0, 0);
         }
     };
     // consume half-block h; AFTER = number of half-blocks issued after it
     auto consume = [&](int h, const float (&a)[4], auto after_tag) {
         constexpr int AFTER = decltype(after_tag)::value;
+        const int cnt = (AFTER == 0) ? deg - 4 * h : 4;   // only the last half-block can be partial
         const float *slot = ring + (h % (LT_RING_NB + 1)) * 4 * 256 + 4 * lane;
         f32x4 s[4];
         wait_vmcnt<4 * AFTER + 3>(); s[0] = *reinterpret_cast<const f32x4 *>(slot);
@@ -417,9 +424,11 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
         wait_vmcnt<4 * AFTER + 1>(); s[2] = *reinterpret_cast<const f32x4 *>(slot + 512);
         wait_vmcnt<4 * AFTER + 0>(); s[3] = *reinterpret_cast<const f32x4 *>(slot + 768);
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 4; ++k) {
+            if (AFTER == 0 && k >= cnt) break;   // wave-uniform: entries past the row end are skipped
 #pragma unroll
             for (int p = 0; p < P; ++p) acc[p] = fma4(a[k], s[k], acc[p]);
+        }
     };
 
     if (nh > 0) {
