@@ -165,7 +165,16 @@ __global__ __launch_bounds__(LT_BLOCK) void k_layer2(
     }
 }
 
-// pad helpers: dst[Hp] = src[H] then zeros; dst[Hp, C] = src[H, C] then zero rows
+// b1p[Hp] = b1[H] then zeros and W2p[Hp, C] = W2[H, C] then zero rows, in one launch
+__global__ void k_pad_b1_w2(const float *__restrict__ b1, const float *__restrict__ W2, int H, int Hp, int C,
+                            float *__restrict__ b1p, float *__restrict__ W2p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Hp) b1p[i] = i < H ? b1[i] : 0.f;
+    const int j = i - Hp;
+    if (j >= 0 && j < Hp * C) W2p[j] = (j / C) < H ? W2[j] : 0.f;
+}
+
+// pad helper (kept for callers that pad a single array)
 __global__ void k_pad_rows(const float *__restrict__ src, int rows, int rows_p, int cols,
                            float *__restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -296,8 +305,7 @@ static int prepare_layer_inputs(int n, const float *X, int64_t ldx, int F, const
                                 float *b1p, float *W2p, float *slabs, hipStream_t st) {
     const int Hp = lt_round_up(H, 4);
     if (Hp != H) LT_HIP(hipMemsetAsync(S1, 0, (size_t)n * Hp * sizeof(float), st));
-    hipLaunchKernelGGL(k_pad_rows, dim3((Hp + 255) / 256), dim3(256), 0, st, b1, H, Hp, 1, b1p);
-    hipLaunchKernelGGL(k_pad_rows, dim3((Hp * C + 255) / 256), dim3(256), 0, st, W2, H, Hp, C, W2p);
+    hipLaunchKernelGGL(k_pad_b1_w2, dim3((Hp * (C + 1) + 255) / 256), dim3(256), 0, st, b1, W2, H, Hp, C, b1p, W2p);
     LT_CHECK_LAUNCH();
     if (slabs) return lt_launch_gemm_splitk(X, ldx, W1, H, S1, Hp, n, H, F, lt_gemm_pick_kslice(n, H, F), slabs, st);
     return lt_launch_gemm(X, ldx, W1, H, S1, Hp, n, H, F, st);

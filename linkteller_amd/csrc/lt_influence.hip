@@ -33,9 +33,12 @@
 // ------------------------------------------------------------------------------------------------
 __global__ void k_perturb_rows(const float *__restrict__ X, long ldx, int F,
                                const int32_t *__restrict__ probes, float delta,
-                               float *__restrict__ Xp) {
+                               float *__restrict__ Xp, int32_t *__restrict__ counter_or_null) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
+    // also resets the ring kernel's hit-list counter (saves a launch; a 4-byte memset node faults under
+    // hipGraph replay on ROCm 7.2, a kernel store does not)
+    if (counter_or_null && f == 0 && b == 0) *counter_or_null = 0;
     if (f >= F) return;
     const float x = X[(long)probes[b] * ldx + f];
     const float pert = __fmul_rn(x, delta);
@@ -348,8 +351,6 @@ __global__ __launch_bounds__(64 * LT_STAGEA_WAVES) void k_full_stageA_wide(
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-
-__global__ void k_zero_counter(int32_t *p) { *p = 0; }
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -891,7 +892,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
             // perturbed rows and their S1 rows: Sp = (X[v] + X[v]*d) W1            attacker.py:101-105
             { lt_prof_scope prof_(LT_K_PERTURB, st);
             hipLaunchKernelGGL(k_perturb_rows, dim3((b->F + 255) / 256, nb), dim3(256), 0, st, b->X,
-                               (long)b->ldx, b->F, probes, delta, w.Xp); }
+                               (long)b->ldx, b->F, probes, delta, w.Xp, mode == LT_MODE_FULL ? w.redo : (int32_t *)nullptr); }
             LT_CHECK_LAUNCH();
             if (Hp != b->H) LT_HIP(hipMemsetAsync(w.Sp, 0, (size_t)nb * Hp * sizeof(float), st));
             int rc = lt_launch_gemm_splitk(w.Xp, b->F, b->W1, b->H, w.Sp, Hp, nb, b->H, b->F, LT_KSLICE_PROBE, w.slabs, st);
@@ -912,8 +913,6 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                     const int rgroups = (nb + Pr - 1) / Pr;
                     LT_REQUIRE(rblocks * rgroups < 2147483647L, "lt_influence_rows: grid limit");
                     dim3 gridr((unsigned)(rblocks * rgroups));
-                    hipLaunchKernelGGL(k_zero_counter, dim3(1), dim3(1), 0, st, w.redo);   // (a memset node here faults under hipGraph replay)
-                    LT_CHECK_LAUNCH();
                     if (Pr == 8) {
                         LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, 8>), gridr, dim3(64), 0, st, n,
                                                                g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p,
