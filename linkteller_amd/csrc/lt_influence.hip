@@ -796,6 +796,13 @@ static int full_probes_per_wave() {
     return p;
 }
 
+// bytes of per-probe scratch per chunk; LT_CHUNK_BUDGET_BYTES overrides it (tests force multi-chunk calls)
+static size_t chunk_budget() {
+    const char *e = getenv("LT_CHUNK_BUDGET_BYTES");
+    if (e && atoll(e) > 0) return (size_t)atoll(e);
+    return LT_CHUNK_BUDGET;
+}
+
 static bool full_use_lds_ring() {
     static int v = -1;
     if (v < 0) {
@@ -824,7 +831,7 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
     if (mode == LT_MODE_FULL) per_probe = (n * C + F + Hp + splitk) * sizeof(float) + n;
     else if (mode == LT_MODE_SPARSE) per_probe = (maxc * C + F + Hp + splitk) * sizeof(float) + sizeof(int32_t);
     else per_probe = maxc * C * sizeof(float) + sizeof(int32_t);
-    size_t chunk = LT_CHUNK_BUDGET / (per_probe ? per_probe : 1);
+    size_t chunk = chunk_budget() / (per_probe ? per_probe : 1);
     if (chunk < 1) chunk = 1;
     if (chunk > 65535) chunk = 65535;  // grid.y
     if (chunk > (size_t)(n_probe > 0 ? n_probe : 1)) chunk = (size_t)(n_probe > 0 ? n_probe : 1);

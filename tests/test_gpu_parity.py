@@ -325,3 +325,16 @@ def test_empty_and_degenerate_calls(gpu):
                          *[torch.from_numpy(w[k]).to(gpu) for k in ("W1", "b1", "W2", "b2")])
     r = b2.influence_rows([0, 1, 2], [0, 1, 2], 1e-4, "delta").cpu().numpy()
     assert np.all(r[~np.eye(3, dtype=bool)] == 0) and np.all(np.diag(r) > 0)
+
+
+def test_probe_chunking_is_transparent(gpu, influence_golden, monkeypatch):
+    """A workspace budget small enough to split the probe list into many chunks gives the same bits."""
+    g = influence_golden
+    args, base = _setup(g, "pl600", gpu)
+    nodes = g["pl600.ref32.test_nodes"]
+    ref = {m: base.influence_rows(nodes, nodes, args["influence"], m).cpu().numpy() for m in ("full", "sparse", "delta")}
+    monkeypatch.setenv("LT_CHUNK_BUDGET_BYTES", str(120 * 1024))     # ~10 probes per chunk at n=600, H=256
+    args2, base2 = _setup(g, "pl600", gpu)
+    for m in ("full", "sparse", "delta"):
+        got = base2.influence_rows(nodes, nodes, args["influence"], m).cpu().numpy()
+        assert np.array_equal(got, ref[m]), m
