@@ -338,3 +338,28 @@ def test_probe_chunking_is_transparent(gpu, influence_golden, monkeypatch):
     for m in ("full", "sparse", "delta"):
         got = base2.influence_rows(nodes, nodes, args["influence"], m).cpu().numpy()
         assert np.array_equal(got, ref[m]), m
+
+
+def test_rmat_shape_scaled_config5(gpu):
+    """BASELINE configs[4] shape (R-MAT, F = H = 256, C = 2) at a scale the oracle finishes in seconds:
+    heavy-tailed degrees (hub rows of thousands of entries) through every mode."""
+    from linkteller_amd import engine, graph, synth
+    adj = synth.rmat_graph(13, (1 << 13) * 12, seed=42)
+    a_hat = graph.first_order_gcn(adj)
+    assert np.diff(a_hat.indptr).max() > 1000
+    n = adj.shape[0]
+    x = synth.gaussian_features(n, 256, seed=1)
+    w = synth.gcn_weights(256, 256, 2, seed=42)
+    base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu),
+                           *[torch.from_numpy(w[k]).to(gpu) for k in ("W1", "b1", "W2", "b2")])
+    rng = np.random.RandomState(3)
+    hub = int(np.argmax(np.diff(a_hat.indptr)))
+    probes = np.concatenate([[hub], rng.choice(n, 11, replace=False)])
+    observe = np.concatenate([[hub], rng.choice(n, 200, replace=False)])
+    ref64 = _oracle_matrix(a_hat, x, w, probes, observe, 1e-4, torch.float64)
+    ref32 = _oracle_matrix(a_hat, x, w, probes, observe, 1e-4, torch.float32)
+    res = {m: base.influence_rows(probes, observe, 1e-4, m).cpu().numpy().astype(np.float64) for m in ("full", "sparse", "delta")}
+    assert np.array_equal(res["full"], res["sparse"])
+    assert np.abs(res["delta"] - ref64).max() <= 1e-5 * ref64.max()
+    assert np.abs(res["full"] - ref64).max() <= 3.0 * np.abs(ref32 - ref64).max() + 1e-4 * ref64.max()
+    assert np.all(res["full"][ref64 == 0] == 0) and np.all(res["delta"][ref64 == 0] == 0)
