@@ -117,65 +117,66 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma(const float *__restrict__
 // workgroup per CU.  Used for the big X*W1 product; same k-ordered fmaf chains per output.
 #define GL_BM 128
 #define GL_BN 128
-#define GL_LDA (GM_BK + 1)
+#ifndef GL_BK
+#define GL_BK 16        // k-depth of a tile (32 measured 10 % slower: two workgroups per CU no longer overlap as well)
+#endif
+#define GL_LDA (GL_BK + 1)
+#define GL_PASS (GL_BK / 8)   // staging passes: 256 threads x float4 cover 128 x 8 (A) or 8 x 128 (B) floats
 __global__ __launch_bounds__(256) void k_gemm_f32_mfma_128(const float *__restrict__ A, long lda,
                                                            const float *__restrict__ B, long ldb,
                                                            float *__restrict__ C, long ldc, int M, int N,
                                                            int K, int kslice, long slab_stride) {
     __shared__ __attribute__((aligned(16))) float As[2][GL_BM * GL_LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][GM_BK * GL_BN];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GL_BK * GL_BN];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     const int m0 = blockIdx.x * GL_BM, n0 = blockIdx.y * GL_BN;
     const int kb = blockIdx.z * kslice, ke = min(K, kb + kslice);
     C += (long)blockIdx.z * slab_stride;
 
-    // staging: A tile 128 x 16 -> thread owns rows (tid>>2) and (tid>>2)+64, 4 floats each;
-    //          B tile 16 x 128 -> thread owns rows (tid>>5) and (tid>>5)+8, 4 floats each
-    const int a_row = tid >> 2, a_col = (tid & 3) * 4;
+    // staging: A tile 128 x BK -> thread owns row a_row (+ 128/PASS per pass), 4 floats at a_col;
+    //          B tile BK x 128 -> thread owns row b_row (+ 8 per pass), 4 floats at b_col
+    constexpr int A_TPR = GL_BK / 4;            // threads per A row
+    constexpr int A_RPP = 256 / A_TPR;          // A rows per pass
+    const int a_row = tid / A_TPR, a_col = (tid % A_TPR) * 4;
     const int b_row = tid >> 5, b_col = (tid & 31) * 4;
-    const float *a_ptr0 = A + (long)(m0 + a_row) * lda + a_col;
-    const float *a_ptr1 = a_ptr0 + 64 * lda;
-    const bool a_ok0 = (m0 + a_row) < M, a_ok1 = (m0 + a_row + 64) < M;
+    const float *a_ptr = A + (long)(m0 + a_row) * lda + a_col;
     const float *b_ptr = B + (long)b_row * ldb + n0 + b_col;
     const bool b_full = (n0 + b_col + 3) < N;
-    f32x4 ra0, ra1, rb0, rb1;
-    auto load_a = [&](const float *p, bool ok, int k0) {
-        f32x4 r = {0.f, 0.f, 0.f, 0.f};
-        if (ok) {
-            if (k0 + a_col + 3 < ke) r = *reinterpret_cast<const f32x4u *>(p + k0);
-            else
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (k0 + a_col + j < ke) r[j] = p[k0 + j];
-        }
-        return r;
-    };
-    auto load_b = [&](int krow) {
-        f32x4 r = {0.f, 0.f, 0.f, 0.f};
-        if (krow < ke) {
-            const float *p = b_ptr + (long)(krow - b_row) * ldb;
-            if (b_full) r = *reinterpret_cast<const f32x4u *>(p);
-            else
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (n0 + b_col + j < N) r[j] = p[j];
-        }
-        return r;
-    };
+    f32x4 ra[GL_PASS], rb[GL_PASS];
     auto load_tiles = [&](int k0) {
-        ra0 = load_a(a_ptr0, a_ok0, k0);
-        ra1 = load_a(a_ptr1, a_ok1, k0);
-        rb0 = load_b(k0 + b_row);
-        rb1 = load_b(k0 + b_row + 8);
+#pragma unroll
+        for (int p = 0; p < GL_PASS; ++p) {
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+            if (m0 + a_row + p * A_RPP < M) {
+                const float *q = a_ptr + (long)p * A_RPP * lda + k0;
+                if (k0 + a_col + 3 < ke) r = *reinterpret_cast<const f32x4u *>(q);
+                else
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (k0 + a_col + j < ke) r[j] = q[j];
+            }
+            ra[p] = r;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            const int krow = k0 + b_row + 8 * p;
+            if (krow < ke) {
+                const float *q = b_ptr + (long)(krow - b_row) * ldb;
+                if (b_full) t = *reinterpret_cast<const f32x4u *>(q);
+                else
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (n0 + b_col + j < N) t[j] = q[j];
+            }
+            rb[p] = t;
+        }
     };
     auto store_tiles = [&](int buf) {
-        float *as = &As[buf][a_row * GL_LDA + a_col];
-        as[0] = ra0.x; as[1] = ra0.y; as[2] = ra0.z; as[3] = ra0.w;
-        as += 64 * GL_LDA;
-        as[0] = ra1.x; as[1] = ra1.y; as[2] = ra1.z; as[3] = ra1.w;
-        *reinterpret_cast<f32x4 *>(&Bs[buf][b_row * GL_BN + b_col]) = rb0;
-        *reinterpret_cast<f32x4 *>(&Bs[buf][(b_row + 8) * GL_BN + b_col]) = rb1;
+#pragma unroll
+        for (int p = 0; p < GL_PASS; ++p) {
+            float *as = &As[buf][(a_row + p * A_RPP) * GL_LDA + a_col];
+            as[0] = ra[p].x; as[1] = ra[p].y; as[2] = ra[p].z; as[3] = ra[p].w;
+            *reinterpret_cast<f32x4 *>(&Bs[buf][(b_row + 8 * p) * GL_BN + b_col]) = rb[p];
+        }
     };
 
     f32x16 acc[2][2];
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma_128(const float *__restri
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = (ke - kb + GM_BK - 1) / GM_BK;
+    const int nk = (ke - kb + GL_BK - 1) / GL_BK;
     load_tiles(kb);
     store_tiles(0);
     __syncthreads();
@@ -194,11 +195,11 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma_128(const float *__restri
     const int b_frag = (lane >> 5) * GL_BN + wc * 64 + (lane & 31);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles(kb + (kt + 1) * GM_BK);
+        if (kt + 1 < nk) load_tiles(kb + (kt + 1) * GL_BK);
         const float *as = &As[buf][a_frag];
         const float *bs = &Bs[buf][b_frag];
 #pragma unroll
-        for (int kk = 0; kk < GM_BK; kk += 2) {
+        for (int kk = 0; kk < GL_BK; kk += 2) {
             const float a0 = as[kk], a1 = as[32 * GL_LDA + kk];
             const float b0 = bs[kk * GL_BN], b1 = bs[kk * GL_BN + 32];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
@@ -254,15 +255,15 @@ int lt_gemm_pick_kslice(int M, int N, int K) {
     int best_s = 1;
     double best = 1e30;
     for (int s = 1; s <= 16; ++s) {
-        const int ks = ((K + s - 1) / s + GM_BK - 1) / GM_BK * GM_BK;
+        const int ks = ((K + s - 1) / s + GL_BK - 1) / GL_BK * GL_BK;
         if (ks <= 0) break;
         const int slices = (K + ks - 1) / ks;
         const long rounds = (tiles * slices + 255) / 256;
-        const double cost = (double)rounds * (ks / GM_BK) + 2.2 * (slices - 1);
+        const double cost = (double)rounds * (ks / 16) + 2.2 * (slices - 1);   // in 16-deep tile-steps
         if (cost < best - 1e-9) { best = cost; best_s = s; }
     }
-    const int ks = ((K + best_s - 1) / best_s + GM_BK - 1) / GM_BK * GM_BK;
-    return ks > 0 ? ks : GM_BK;
+    const int ks = ((K + best_s - 1) / best_s + GL_BK - 1) / GL_BK * GL_BK;
+    return ks > 0 ? ks : GL_BK;
 }
 
 size_t lt_gemm_splitk_slab_bytes(int M, int N, int K, int kslice) {
