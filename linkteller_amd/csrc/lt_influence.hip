@@ -787,13 +787,24 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
 // ------------------------------------------------------------------------------------------------
 // probes per wave of the wide FULL kernel: 16 (default) or 8 (LT_FULL_P=8), a tuning knob only --
 // results are bit-identical
-static int full_probes_per_wave() {
-    static int p = 0;
-    if (!p) {
+// Probes per wave of the wide FULL kernels (8, 16 or 32): a tuning knob only -- results are bit-identical.
+// Measured cost of a (row, group) wave ~ 3.4 + 0.63 * P (arbitrary units; twitch-RU, 500 probes: P = 8 /
+// 16 / 32 -> 528 / 396 / 376 us), so the choice minimises ceil(nb / P) * (3.4 + 0.63 P); LT_FULL_P pins it.
+static int full_probes_per_wave(int nb) {
+    static int pinned = -1;
+    if (pinned < 0) {
         const char *e = getenv("LT_FULL_P");
-        p = (e && atoi(e) == 8) ? 8 : ((e && atoi(e) == 32) ? 32 : 16);
+        const int v = e ? atoi(e) : 0;
+        pinned = (v == 8 || v == 16 || v == 32) ? v : 0;
     }
-    return p;
+    if (pinned) return pinned;
+    int best = 16;
+    double best_cost = 1e30;
+    for (int P = 8; P <= 32; P *= 2) {
+        const double cost = (double)((nb + P - 1) / P) * (3.4 + 0.63 * P);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = P; }
+    }
+    return best;
 }
 
 // bytes of per-probe scratch per chunk; LT_CHUNK_BUDGET_BYTES overrides it (tests force multi-chunk calls)
@@ -909,7 +920,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
         if (mode == LT_MODE_FULL) {
             { lt_prof_scope prof_(LT_K_FULL_A, st);
             if (lpr == 64) {
-                const int P = full_probes_per_wave();
+                const int P = full_probes_per_wave(nb);
                 const int groups = (nb + P - 1) / P;
                 const int gblocks = (groups + LT_STAGEA_WAVES - 1) / LT_STAGEA_WAVES;
                 LT_REQUIRE((long)n * gblocks < 2147483647L, "lt_influence_rows: n * probe groups exceeds the grid limit");
