@@ -107,12 +107,25 @@ def main():
     local = torch.empty((b1_ - b0, a.n_test), dtype=torch.float32, device=dev)
     delta = 1e-4
 
+    pending = []
+
     def step(mode):
+        """One influence-matrix build.  For N > 1 the all-gather of step k is left in flight on the
+        communicator's stream while step k+1 computes (steps are independent; every step's matrix is
+        complete before the closing barrier + synchronize)."""
         base.refresh()
         base.influence_rows(probes, obs, delta, mode, out=local)
-        return lt_dist.all_gather_rows(local, a.n_test)
+        full, work = lt_dist.all_gather_rows(local, a.n_test, async_op=True)
+        if work is not None:
+            pending.append(work)
+        return full
+
+    def drain():
+        while pending:
+            pending.pop().wait()
 
     def barrier():
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

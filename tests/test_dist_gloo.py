@@ -28,7 +28,9 @@ def _worker(rank, ws, port, n, n_obs, q):
     full = torch.arange(n * n_obs, dtype=torch.float32).reshape(n, n_obs) * 0.5 + 1.0   # "influence rows"
     b, e, _ = lt_dist.shard_bounds(n, rank, ws)
     got = lt_dist.all_gather_rows(full[b:e].clone(), n)
-    q.put((rank, bool(torch.equal(got, full)), tuple(got.shape)))
+    got2, work = lt_dist.all_gather_rows(full[b:e].clone() * 2, n, async_op=True)     # pipelined form used by bench.py
+    work.wait()
+    q.put((rank, bool(torch.equal(got, full)) and bool(torch.equal(got2, full * 2)), tuple(got.shape)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -55,3 +57,5 @@ def test_single_process_is_identity():
     x = torch.ones(3, 4)
     assert lt_dist.world() == (0, 1)
     assert lt_dist.all_gather_rows(x, 3) is x
+    y, work = lt_dist.all_gather_rows(x, 3, async_op=True)
+    assert y is x and work is None
