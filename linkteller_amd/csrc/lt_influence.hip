@@ -785,8 +785,6 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-// probes per wave of the wide FULL kernel: 16 (default) or 8 (LT_FULL_P=8), a tuning knob only --
-// results are bit-identical
 // Probes per wave of the wide FULL kernels (8, 16 or 32): a tuning knob only -- results are bit-identical.
 // Measured cost of a (row, group) wave ~ 3.4 + 0.63 * P (arbitrary units; twitch-RU, 500 probes: P = 8 /
 // 16 / 32 -> 528 / 396 / 376 us), so the choice minimises ceil(nb / P) * (3.4 + 0.63 P); LT_FULL_P pins it.
@@ -931,31 +929,20 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                     const int rgroups = (nb + Pr - 1) / Pr;
                     LT_REQUIRE(rblocks * rgroups < 2147483647L, "lt_influence_rows: grid limit");
                     dim3 gridr((unsigned)(rblocks * rgroups));
-                    if (Pr == 8) {
-                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, 8>), gridr, dim3(64), 0, st, n,
-                                                               g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p,
-                                                               C, probes, nb, w.Sp, w.S2p, w.redo));
-                        LT_CHECK_LAUNCH();
-                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_fix<CP_, 8>), dim3(2048), dim3(64), 0, st,
-                                                               n, g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p,
-                                                               C, probes, nb, w.Sp, w.S2p, w.redo));
-                    } else if (Pr == 32) {
-                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, 32>), gridr, dim3(64), 0, st, n,
-                                                               g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p,
-                                                               C, probes, nb, w.Sp, w.S2p, w.redo));
-                        LT_CHECK_LAUNCH();
-                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_fix<CP_, 32>), dim3(2048), dim3(64), 0, st,
-                                                               n, g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p,
-                                                               C, probes, nb, w.Sp, w.S2p, w.redo));
-                    } else {
-                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, 16>), gridr, dim3(64), 0, st, n,
-                                                               g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p,
-                                                               C, probes, nb, w.Sp, w.S2p, w.redo));
-                        LT_CHECK_LAUNCH();
-                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_fix<CP_, 16>), dim3(2048), dim3(64), 0, st,
-                                                               n, g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p,
-                                                               C, probes, nb, w.Sp, w.S2p, w.redo));
-                    }
+#define LT_RING_PAIR(P_)                                                                                      \
+    do {                                                                                                      \
+        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, P_>), gridr, dim3(64), 0, st, n,        \
+                                               g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p, C,       \
+                                               probes, nb, w.Sp, w.S2p, w.redo));                             \
+        LT_CHECK_LAUNCH();                                                                                    \
+        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_fix<CP_, P_>), dim3(2048), dim3(64), 0, st, n,   \
+                                               g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p, C,       \
+                                               probes, nb, w.Sp, w.S2p, w.redo));                             \
+    } while (0)
+                    if (Pr == 8) LT_RING_PAIR(8);
+                    else if (Pr == 32) LT_RING_PAIR(32);
+                    else LT_RING_PAIR(16);
+#undef LT_RING_PAIR
                 } else if (P == 32) {
                     LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_wide<CP_, 32>), grid, dim3(64 * LT_STAGEA_WAVES), 0,
                                                            st, n, g->rowptr, g->col, g->val, b->S1, Hp, b->b1p,

@@ -363,3 +363,50 @@ def test_rmat_shape_scaled_config5(gpu):
     assert np.abs(res["delta"] - ref64).max() <= 1e-5 * ref64.max()
     assert np.abs(res["full"] - ref64).max() <= 3.0 * np.abs(ref32 - ref64).max() + 1e-4 * ref64.max()
     assert np.all(res["full"][ref64 == 0] == 0) and np.all(res["delta"][ref64 == 0] == 0)
+
+
+def _two_hop_mask(a_hat, probes, observe):
+    """mask[i, j] = observe[j] is within two hops of probes[i] in the pattern of a_hat (self loops included)."""
+    import scipy.sparse as sp
+    pat = sp.csr_matrix((np.ones(a_hat.nnz, np.float32), a_hat.indices, a_hat.indptr), shape=a_hat.shape)
+    sel = sp.csr_matrix((np.ones(len(probes), np.float32), (np.arange(len(probes)), probes)),
+                        shape=(len(probes), a_hat.shape[0]))
+    reach = (sel @ pat.T @ pat.T).toarray() > 0            # column v of pat = rows reading S1[v]
+    return reach[:, observe]
+
+
+@pytest.mark.parametrize("n_test,served", [(500, "clean"), (2000, "clean"), (500, "lapgraph")])
+def test_full_size_twitch_ru(gpu, n_test, served):
+    """BASELINE configs[1], [2] (on one GPU) and [3] at their full sizes: twitch-RU shape (N=4385, F=3170,
+    H=256), n_test probes.  The oracle checks a sample of probe rows; the whole matrix is checked through
+    size-independent properties: 'sparse' == 'full' bit for bit, exact zeros outside the 2-hop set, non-zero
+    inside it (up to ReLU-dead paths), 'delta' close to 'full', symmetry of the support."""
+    from linkteller_amd import dp, engine, graph, synth
+    adj, x, w = synth.twitch_like_problem("twitch-RU", hidden=256, n_classes=2, seed=0)
+    if served == "lapgraph":
+        adj = dp.perturb_adj(adj, "continuous", 5.0, noise_seed=42)       # worker.py:206-335 (config 4)
+    a_hat = graph.first_order_gcn(adj)
+    n = adj.shape[0]
+    base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu),
+                           *[torch.from_numpy(w[k]).to(gpu) for k in ("W1", "b1", "W2", "b2")])
+    nodes = np.sort(np.random.RandomState(7).choice(n, n_test, replace=False))
+    res = {m: base.influence_rows(nodes, nodes, 1e-4, m).cpu().numpy() for m in ("full", "sparse", "delta")}
+    assert np.array_equal(res["full"], res["sparse"])
+    mask = _two_hop_mask(a_hat, nodes, nodes)
+    for m, r in res.items():
+        assert np.all(np.isfinite(r)), m
+        assert np.all(r[~mask] == 0), m
+    assert np.array_equal(mask, mask.T)
+    assert (res["delta"][mask] > 0).mean() > 0.9
+    scale = float(res["delta"].max())
+    # the fp32 finite difference (full) sits within its own noise class of the exact perturbation (delta)
+    gap = np.abs(res["full"].astype(np.float64) - res["delta"]).max()
+    print(f"n_test={n_test} served={served}: max score {scale:.4g}, |full - delta| max {gap:.4g}, nnz(A_hat) {a_hat.nnz}")
+    assert gap <= 0.05 * scale
+    sample = np.random.RandomState(11).choice(n_test, 6, replace=False)
+    ref64 = _oracle_matrix(a_hat, x, w, nodes[sample], nodes, 1e-4, torch.float64)
+    ref32 = _oracle_matrix(a_hat, x, w, nodes[sample], nodes, 1e-4, torch.float32)
+    e32 = np.abs(ref32 - ref64).max()
+    assert np.abs(res["delta"][sample] - ref64).max() <= 1e-5 * ref64.max()
+    assert np.abs(res["full"][sample] - ref64).max() <= 3.0 * e32 + 1e-4 * ref64.max()
+    assert np.all(res["full"][sample][ref64 == 0] == 0)
