@@ -101,7 +101,7 @@ def main():
     x = torch.from_numpy(x_np).to(dev)
     params = [torch.from_numpy(w[k]).to(dev) for k in ("W1", "b1", "W2", "b2")]
     base = engine.Baseline(hg, x, *params)
-    b0, b1_, _ = lt_dist.shard_bounds(a.n_test, rank, world)
+    b0, b1_, per = lt_dist.shard_bounds(a.n_test, rank, world)
     probes = torch.from_numpy(test_nodes[b0:b1_].astype(np.int32)).to(dev)
     obs = torch.from_numpy(test_nodes.astype(np.int32)).to(dev)
     local = torch.empty((b1_ - b0, a.n_test), dtype=torch.float32, device=dev)
@@ -113,9 +113,18 @@ def main():
         """One influence-matrix build.  For N > 1 the all-gather of step k is left in flight on the
         communicator's stream while step k+1 computes (steps are independent; every step's matrix is
         complete before the closing barrier + synchronize)."""
+        if world > 1:
+            # a fresh padded slab per step: the collective of step k may still be reading its slab
+            # while step k+1 computes
+            slab = torch.empty((per, a.n_test), dtype=torch.float32, device=dev)
+            if b1_ - b0 < per:
+                slab[b1_ - b0:].zero_()
+            out = slab[: b1_ - b0]
+        else:
+            slab = out = local
         base.refresh()
-        base.influence_rows(probes, obs, delta, mode, out=local)
-        full, work = lt_dist.all_gather_rows(local, a.n_test, async_op=True)
+        base.influence_rows(probes, obs, delta, mode, out=out)
+        full, work = lt_dist.all_gather_rows(slab, a.n_test, async_op=True)
         if work is not None:
             pending.append(work)
         return full

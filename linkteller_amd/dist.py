@@ -23,8 +23,9 @@ def shard_bounds(n_items: int, rank: int, world_size: int):
 
 
 def all_gather_rows(local_rows: torch.Tensor, n_total: int, async_op: bool = False):
-    """local_rows: this rank's [end-begin, n_obs] slab (may be empty).  Returns [n_total, n_obs]
-    on every rank.  One ``all_gather_into_tensor`` on a padded contiguous slab.
+    """local_rows: this rank's [end-begin, n_obs] slab (may be empty), or the full padded
+    [ceil(n/W), n_obs] slab (then it is sent as is and must not be overwritten before the collective
+    has completed).  Returns [n_total, n_obs] on every rank.  One ``all_gather_into_tensor`` on a padded contiguous slab.
     ``async_op=True`` returns ``(tensor, work)``: the collective runs on the communicator's stream and
     the caller's stream is not made to wait (``work.wait()`` before reading the tensor)."""
     rank, ws = world()
@@ -32,8 +33,11 @@ def all_gather_rows(local_rows: torch.Tensor, n_total: int, async_op: bool = Fal
         return (local_rows, None) if async_op else local_rows
     _, _, per = shard_bounds(n_total, rank, ws)
     n_obs = local_rows.shape[1]
-    slab = torch.zeros((per, n_obs), dtype=local_rows.dtype, device=local_rows.device)
-    slab[: local_rows.shape[0]] = local_rows
+    if local_rows.shape[0] == per and local_rows.is_contiguous():
+        slab = local_rows                  # already the padded slab: no staging copy
+    else:
+        slab = torch.zeros((per, n_obs), dtype=local_rows.dtype, device=local_rows.device)
+        slab[: local_rows.shape[0]] = local_rows
     full = torch.empty((ws * per, n_obs), dtype=local_rows.dtype, device=local_rows.device)
     if async_op:
         work = dist.all_gather_into_tensor(full, slab, async_op=True)
