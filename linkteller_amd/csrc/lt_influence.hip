@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "lt_rows.cuh"
+#include "lt_lanes.cuh"
 
 #define LT_BLOCK 256
 #define LT_FULL_P 8                       // probes per wave in the wide FULL stage-A kernel
@@ -89,37 +90,10 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_stageA(
 //  * substituting the probe's own row is rare: a 4-entry chunk first asks "does any column equal
 //    any of my P probes" with one vector compare per entry (probe ids sit one per lane) and only
 //    then takes the per-probe select path;
-//  * the 2P (probe, class) partial sums are reduced with v_permlane32_swap / v_permlane16_swap
-//    + DPP row rotations: same pairings as the xor 32,16,8,4,2,1 butterfly of group_sum<64>
-//    (fp add commutes), so the bits equal the baseline kernel's.
+//  * the P*C (probe, class) partial sums are reduced together (lt_lanes.cuh): the xor 32,16,8,4,2,1
+//    butterfly of group_sum<64> with the live registers halving at every stage -- same pairings,
+//    fp add commutes, so the bits equal the baseline kernel's -- and leave in one coalesced store.
 // ------------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
-}
-// lanes l and l+32 of (a, b) -> one register: lanes 0-31 carry a's pair sums, lanes 32-63 b's.
-// Inline asm on purpose: with the __builtin_amdgcn_permlane32_swap result pair hipcc (ROCm 7.2)
-// folded "r.x + r.y" into "r.x + r.x" here.  v_permlane32_swap exchanges lanes 32-63 of %0 with
-// lanes 0-31 of %1; the two wait states after a VALU write of either operand are the s_nop.
-__device__ __forceinline__ float fold32(float a, float b) {
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return a + b;
-}
-// rows (16 lanes) 0+1 and 2+3 of (a, b) -> rows [a01 | b01 | a23 | b23]
-// (v_permlane16_swap exchanges the odd rows of %0 with the even rows of %1)
-__device__ __forceinline__ float fold16(float a, float b) {
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return a + b;
-}
-// finish inside each 16-lane row: xor 8, 4 (row rotations) then xor 2, 1 (quad permutes)
-__device__ __forceinline__ float fold_row(float z) {
-    z += dpp_mov<0x128>(z);  // row_ror:8
-    z += dpp_mov<0x124>(z);  // row_ror:4
-    z += dpp_mov<0x4E>(z);   // quad_perm [2,3,0,1]
-    z += dpp_mov<0xB1>(z);   // quad_perm [1,0,3,2]
-    return z;
-}
-
 // Shared epilogue of the wide stage-A kernels: h = relu(acc + b1), the lane's share of h . W2 for all
 // P probes, the permlane/DPP folds, and the [row][probe][class] store.
 template <int CP, int P>
@@ -173,18 +147,17 @@ __device__ __forceinline__ void stageA_epilogue(f32x4 (&acc)[P], int lane, bool 
             }
         }
     }
-    // 64-lane sums of all P*CP values; after the folds register i holds, in its four 16-lane rows,
-    // the totals of values 4i+0, 4i+2, 4i+1, 4i+3
-    const int row = lane >> 4;
-    const int sel = ((row & 1) << 1) | (row >> 1);  // row -> 0,2,1,3
+    // 64-lane totals of all P*CP values (lt_lanes.cuh): in batches of up to 64 values, lane l ends with
+    // the total of value q = batch * VB + (l >> log2(64 / VB)) = (probe q / CP, class q % CP), so one
+    // batch leaves in one coalesced store of S2p[row][pb + p][c]
+    constexpr int V = P * CP, VB = V < 64 ? V : 64;
 #pragma unroll
-    for (int i = 0; i < P * CP / 4; ++i) {
-        const float y0 = fold32(part[4 * i + 0], part[4 * i + 1]);
-        const float y1 = fold32(part[4 * i + 2], part[4 * i + 3]);
-        const float z = fold_row(fold16(y0, y1));
-        const int vidx = 4 * i + sel;       // index into part[]: probe = vidx / CP, class = vidx % CP
-        const int p = vidx / CP, c = vidx % CP;
-        if ((lane & 15) == 0 && c < C && pb + p < nb) S2p[((size_t)r * nb + pb + p) * C + c] = z;   // [row][probe][class]
+    for (int j = 0; j < V / VB; ++j) {
+        const float z = lane_totals<VB>(part + j * VB, lane);
+        const int q = j * VB + lane_totals_owner<VB>(lane);
+        const int p = q / CP, c = q % CP;
+        const bool owner = (lane & (64 / VB - 1)) == 0;
+        if (owner && c < C && pb + p < nb) S2p[((size_t)r * nb + pb + p) * C + c] = z;   // [row][probe][class]
     }
 }
 
