@@ -124,18 +124,14 @@ __global__ __launch_bounds__(LT_BLOCK) void k_layer1(
     if (r >= n) return;  // LPR-lane groups exit together; shuffles below stay inside a group
     const int coff = 4 * gl;
     const bool active = coff < Hp;
-    const f32x4 acc = row_dot(col, val, rowptr[r], rowptr[r + 1], S1, Hp, coff, active, -1, nullptr);
-    f32x4 b1v = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 b1v = active ? ld4(b1p + coff) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 z = row_dot(col, val, rowptr[r], rowptr[r + 1], S1, Hp, coff, active, -1, nullptr, b1v);
     float part[CP];
 #pragma unroll
     for (int c = 0; c < CP; ++c) part[c] = 0.f;
     if (active) {
-        b1v = ld4(b1p + coff);
-        relu_w2_partial<CP>(acc, b1v, W2p + (size_t)coff * C, C, part);
-        if (Z1) {
-            f32x4 z = {acc.x + b1v.x, acc.y + b1v.y, acc.z + b1v.z, acc.w + b1v.w};
-            *reinterpret_cast<f32x4 *>(Z1 + (size_t)r * Hp + coff) = z;
-        }
+        relu_w2_partial<CP>(z, W2p + (size_t)coff * C, C, part);
+        if (Z1) *reinterpret_cast<f32x4 *>(Z1 + (size_t)r * Hp + coff) = z;
     }
 #pragma unroll
     for (int c = 0; c < CP; ++c) part[c] = group_sum<LPR>(part[c]);

@@ -65,12 +65,13 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_stageA(
     if (r >= n) return;
     const int coff = 4 * gl;
     const bool active = coff < Hp;
+    const f32x4 b1v = active ? ld4(b1p + coff) : f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4 acc = row_dot(col, val, rowptr[r], rowptr[r + 1], S1, Hp, coff, active, probes[b],
-                              Sp + (size_t)b * Hp);
+                              Sp + (size_t)b * Hp, b1v);
     float part[CP];
 #pragma unroll
     for (int c = 0; c < CP; ++c) part[c] = 0.f;
-    if (active) relu_w2_partial<CP>(acc, ld4(b1p + coff), W2p + (size_t)coff * C, C, part);
+    if (active) relu_w2_partial<CP>(acc, W2p + (size_t)coff * C, C, part);
 #pragma unroll
     for (int c = 0; c < CP; ++c) part[c] = group_sum<LPR>(part[c]);
     if (gl == 0) {
@@ -94,6 +95,14 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_stageA(
 //    butterfly of group_sum<64> with the live registers halving at every stage -- same pairings,
 //    fp add commutes, so the bits equal the baseline kernel's -- and leave in one coalesced store.
 // ------------------------------------------------------------------------------------------------
+// fmaxf(x, 0) as exactly one v_max_f32: the accumulators pass through inline asm, so hipcc cannot prove
+// them canonical and would put a v_max_f32 x, x, x in front of every fmaxf (same bits for every non-NaN x)
+__device__ __forceinline__ float relu1(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // Shared epilogue of the wide stage-A kernels: h = relu(acc + b1), the lane's share of h . W2 for all
 // P probes, the permlane/DPP folds, and the [row][probe][class] store.
 template <int CP, int P>
@@ -101,7 +110,6 @@ __device__ __forceinline__ void stageA_epilogue(f32x4 (&acc)[P], int lane, bool 
                                                 const float *__restrict__ b1p,
                                                 const float *__restrict__ W2p, int C, int n, int nb,
                                                 int r, int pb, float *__restrict__ S2p) {
-    const f32x4 b1v = ld4(b1p + coff);
     float w2[4 * CP];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -115,13 +123,10 @@ __device__ __forceinline__ void stageA_epilogue(f32x4 (&acc)[P], int lane, bool 
         // those of relu_w2_partial, so the bits are unchanged
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         const f32x2 w0 = {w2[0], w2[1]}, w1 = {w2[2], w2[3]}, w2v = {w2[4], w2[5]}, w3 = {w2[6], w2[7]};
-        const f32x2 blo = {b1v.x, b1v.y}, bhi = {b1v.z, b1v.w};
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            const f32x2 zlo = f32x2{acc[p].x, acc[p].y} + blo;
-            const f32x2 zhi = f32x2{acc[p].z, acc[p].w} + bhi;
-            const float h0 = fmaxf(zlo.x, 0.f), h1 = fmaxf(zlo.y, 0.f);
-            const float h2 = fmaxf(zhi.x, 0.f), h3 = fmaxf(zhi.y, 0.f);
+            const float h0 = relu1(acc[p].x), h1 = relu1(acc[p].y);
+            const float h2 = relu1(acc[p].z), h3 = relu1(acc[p].w);
             f32x2 q = f32x2{h0, h0} * w0;
             q = __builtin_elementwise_fma(f32x2{h1, h1}, w1, q);
             q = __builtin_elementwise_fma(f32x2{h2, h2}, w2v, q);
@@ -133,10 +138,10 @@ __device__ __forceinline__ void stageA_epilogue(f32x4 (&acc)[P], int lane, bool 
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             // same operation order as relu_w2_partial
-            const float h0 = fmaxf(acc[p].x + b1v.x, 0.f);
-            const float h1 = fmaxf(acc[p].y + b1v.y, 0.f);
-            const float h2 = fmaxf(acc[p].z + b1v.z, 0.f);
-            const float h3 = fmaxf(acc[p].w + b1v.w, 0.f);
+            const float h0 = fmaxf(acc[p].x, 0.f);
+            const float h1 = fmaxf(acc[p].y, 0.f);
+            const float h2 = fmaxf(acc[p].z, 0.f);
+            const float h3 = fmaxf(acc[p].w, 0.f);
 #pragma unroll
             for (int c = 0; c < CP; ++c) {
                 float q = h0 * w2[c];
@@ -189,9 +194,10 @@ __global__ __launch_bounds__(64 * LT_STAGEA_WAVES) void k_full_stageA_wide(
 
     const int vprobe = (lane < P && pb + lane < nb) ? probes[pb + lane] : -1;
 
+    const f32x4 b1v = ld4(b1p + coff);   // every chain starts from the bias (row_dot's `init`)
     f32x4 acc[P];
 #pragma unroll
-    for (int p = 0; p < P; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < P; ++p) acc[p] = b1v;
 
     const float *__restrict__ S1c = S1 + coff;
     const float *__restrict__ Spc = Sp + coff;
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(64 * LT_STAGEA_WAVES) void k_full_stageA_wide(
     }
     if (__builtin_expect(__ballot(anyhit) != 0ull, 0)) {
 #pragma unroll
-        for (int p = 0; p < P; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < P; ++p) acc[p] = b1v;
 #pragma nounroll
         for (int e = e0; e < e1; ++e) one_entry(e);
     }
@@ -351,12 +357,16 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
     int vprobe = (lane < P && pb + lane < nb) ? probes[pb + lane] : -1;
     asm volatile("" : "+v"(vprobe));   // retire this ordinary load before any LDS-DMA is in flight (hipcc would drain vmcnt(0) at its first use)
 
+    // every chain starts from the bias (row_dot's `init`); retired before the DMAs for the same reason
+    const f32x4 b1v = ld4(b1p + coff);
+    double blo = __builtin_bit_cast(double, f32x2_t{b1v.x, b1v.y}), bhi = __builtin_bit_cast(double, f32x2_t{b1v.z, b1v.w});
+    asm volatile("" : "+v"(blo), "+v"(bhi));
     f32x4 acc[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {   // v_mov_b64 pairs: half the instructions of 4 x v_mov_b32 (this kernel is VALU-issue bound)
         double lo, hi;
-        asm("v_mov_b64 %0, 0" : "=v"(lo));
-        asm("v_mov_b64 %0, 0" : "=v"(hi));
+        asm("v_mov_b64 %0, %1" : "=v"(lo) : "v"(blo));
+        asm("v_mov_b64 %0, %1" : "=v"(hi) : "v"(bhi));
         const f32x2_t l2 = __builtin_bit_cast(f32x2_t, lo), h2 = __builtin_bit_cast(f32x2_t, hi);
         acc[p] = f32x4{l2.x, l2.y, h2.x, h2.y};
     }
@@ -366,13 +376,13 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
     const int nh = (deg + 3) >> 2;
     bool anyhit = false;
 
-    auto load_cols = [&](int h, int (&c)[4]) {
-        const int32_t *cp = col + e0 + 4 * h;     // may run past the row: stays inside the padded array
+    auto load_cols = [&](int h, int (&c)[4], int eb) {
+        const int32_t *cp = col + eb + 4 * h;     // may run past the row: stays inside the padded array
 #pragma unroll
         for (int k = 0; k < 4; ++k) c[k] = cp[k];
     };
-    auto load_vals = [&](int h, float (&a)[4]) {
-        const float *vp_ = val + e0 + 4 * h;
+    auto load_vals = [&](int h, float (&a)[4], int eb) {
+        const float *vp_ = val + eb + 4 * h;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float v = vp_[k];
@@ -387,55 +397,68 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
             __builtin_amdgcn_global_load_lds((S1 + (size_t)c[k] * Hp) + coff, (lds_ptr_t)(ring + (base + k) * 256), 16, 0, 0);
         }
     };
-    // consume half-block h; AFTER = number of half-blocks issued after it
-    auto consume = [&](int h, const float (&a)[4], auto after_tag) {
+    // half-block h out of the ring into registers; AFTER = number of half-blocks issued after it
+    auto fetch = [&](int h, f32x4 (&s)[4], auto after_tag) {
         constexpr int AFTER = decltype(after_tag)::value;
-        const int cnt = (AFTER == 0) ? deg - 4 * h : 4;   // only the last half-block can be partial
         const float *slot = ring + (h % (LT_RING_NB + 1)) * 4 * 256 + 4 * lane;
-        f32x4 s[4];
         wait_vmcnt<4 * AFTER + 3>(); s[0] = *reinterpret_cast<const f32x4 *>(slot);
         wait_vmcnt<4 * AFTER + 2>(); s[1] = *reinterpret_cast<const f32x4 *>(slot + 256);
         wait_vmcnt<4 * AFTER + 1>(); s[2] = *reinterpret_cast<const f32x4 *>(slot + 512);
         wait_vmcnt<4 * AFTER + 0>(); s[3] = *reinterpret_cast<const f32x4 *>(slot + 768);
+    };
+    // the first `cnt` entries of a fetched half-block into all P chains
+    auto fmas = [&](const float (&a)[4], const f32x4 (&s)[4], int cnt) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (AFTER == 0 && k >= cnt) break;   // wave-uniform: entries past the row end are skipped
+            if (k >= cnt) break;   // wave-uniform: entries past the row end are skipped (last half-block only)
 #pragma unroll
             for (int p = 0; p < P; ++p) acc[p] = fma4(a[k], s[k], acc[p]);
         }
     };
-
     if (nh > 0) {
-        int cI[4];
+        int cI[4], cN[4], cF[4];
         float aC[4], aN[4];
+        f32x4 s[4];
         // prologue: half-blocks 0 .. min(NB, nh) - 1 in flight
-        load_cols(0, cI);
-        load_vals(0, aC);
+        load_cols(0, cI, e0);
+        load_vals(0, aC, e0);
         issue(0, cI);
 #pragma unroll
         for (int j = 1; j < LT_RING_NB; ++j)
-            if (j < nh) { load_cols(j, cI); issue(j, cI); }
+            if (j < nh) { load_cols(j, cI, e0); issue(j, cI); }
+        load_cols(LT_RING_NB, cN, e0);   // one half-block of look-ahead (past a short row: inside the padding, unused)
         int h = 0;
-        // steady state: LT_RING_NB half-blocks are in flight behind h after the issue below
+        // steady state: LT_RING_NB half-blocks are in flight behind h after the issue below.  The (col, val)
+        // scalar loads of the NEXT iteration are issued once the first ring read of this one has landed
+        // (the empty asm ties their address to it), i.e. in front of a block of FMAs that covers their
+        // latency; issued any earlier they would share the lgkmcnt(0) that guards the ring reads.
         for (; h + LT_RING_NB < nh; ++h) {
-            load_cols(h + LT_RING_NB, cI);
-            load_vals(h + 1, aN);
-            issue(h + LT_RING_NB, cI);
-            consume(h, aC, std::integral_constant<int, LT_RING_NB>{});
+            issue(h + LT_RING_NB, cN);
+            fetch(h, s, std::integral_constant<int, LT_RING_NB>{});
+            int eb = e0;
+            asm volatile("" : "+s"(eb) : "v"(s[0].x));
+            load_cols(h + LT_RING_NB + 1, cF, eb);
+            load_vals(h + 1, aN, eb);
+            fmas(aC, s, 4);
+            // pin the look-ahead columns in SGPRs here (hipcc otherwise sinks the loads to the top of the
+            // next iteration, right in front of their use)
+            asm volatile("" : "+s"(cF[0]), "+s"(cF[1]), "+s"(cF[2]), "+s"(cF[3]));
 #pragma unroll
-            for (int k = 0; k < 4; ++k) aC[k] = aN[k];
+            for (int k = 0; k < 4; ++k) { aC[k] = aN[k]; cN[k] = cF[k]; }
         }
         // drain: nothing left to issue; fewer half-blocks behind h each time
 #if LT_RING_NB >= 2
         if (h + 1 < nh) {
-            load_vals(h + 1, aN);
-            consume(h, aC, std::integral_constant<int, 1>{});
+            load_vals(h + 1, aN, e0);
+            fetch(h, s, std::integral_constant<int, 1>{});
+            fmas(aC, s, 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k) aC[k] = aN[k];
             ++h;
         }
 #endif
-        consume(h, aC, std::integral_constant<int, 0>{});
+        fetch(h, s, std::integral_constant<int, 0>{});
+        fmas(aC, s, deg - 4 * h);
     }
 
     const unsigned hitmask = (unsigned)__ballot(anyhit);   // bit p: probe pb+p sits on one of this row's columns
@@ -471,6 +494,7 @@ __global__ __launch_bounds__(64) void k_full_stageA_fix(
     const int count = redo[0];
     const bool active = 4 * lane < Hp;
     const int coff = active ? 4 * lane : Hp - 4;
+    const f32x4 b1v = ld4(b1p + coff);
     for (int it = blockIdx.x; it < count; it += gridDim.x) {
         const int bid = redo[1 + 2 * it];
         unsigned mask = (unsigned)redo[2 + 2 * it];
@@ -481,11 +505,11 @@ __global__ __launch_bounds__(64) void k_full_stageA_fix(
             const int p = __builtin_ctz(mask);
             mask &= mask - 1;
             const int v = probes[pb + p];
-            const f32x4 acc = row_dot(col, val, e0, e1, S1, Hp, coff, true, v, Sp + (size_t)(pb + p) * Hp);
+            const f32x4 acc = row_dot(col, val, e0, e1, S1, Hp, coff, true, v, Sp + (size_t)(pb + p) * Hp, b1v);
             float part[CP];
 #pragma unroll
             for (int c = 0; c < CP; ++c) part[c] = 0.f;
-            if (active) relu_w2_partial<CP>(acc, ld4(b1p + coff), W2p + (size_t)coff * C, C, part);
+            if (active) relu_w2_partial<CP>(acc, W2p + (size_t)coff * C, C, part);
 #pragma unroll
             for (int c = 0; c < CP; ++c) part[c] = group_sum<64>(part[c]);
             if (lane == 0) {
@@ -680,8 +704,8 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
                         }
                 } else {
                     const f32x4 acc = row_dot(col, val, rowptr[r], rowptr[r + 1], S1, Hp, coff, true, v,
-                                              Sp + (size_t)b * Hp);
-                    relu_w2_partial<CP>(acc, b1v, W2p + (size_t)coff * C, C, part);
+                                              Sp + (size_t)b * Hp, b1v);
+                    relu_w2_partial<CP>(acc, W2p + (size_t)coff * C, C, part);
                 }
             }
         }

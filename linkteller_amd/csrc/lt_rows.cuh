@@ -3,8 +3,10 @@
 // forward (so that rows outside a probe's 2-hop set difference to exactly 0, as they do in
 // the reference: SURVEY.md section 7.2-1) goes through the functions in this header:
 //
-//   row_dot<LPR>        : acc = sum_e val[e] * S[col[e], :]  as one k-ordered fmaf chain per column
-//   relu_w2_partial     : this lane's share of relu(acc + b1) . W2
+//   row_dot             : acc = init + sum_e val[e] * S[col[e], :]  as one k-ordered fmaf chain per column
+//                         that STARTS from `init` (layer 1 passes the bias: z = fma(a_k, s_k, ... fma(a_0, s_0, b1)),
+//                         which costs no instruction, where "+ b1" at the end costs one per column)
+//   relu_w2_partial     : this lane's share of relu(z) . W2
 //   group_sum<LPR>      : fixed butterfly (xor LPR/2 ... 1) -- fp add commutes, so every lane of
 //                         the group ends with the same bits
 //   row2_dot<C>         : layer-2 row (C <= 8 columns): 8 lanes per row, lane q owns entries
@@ -35,15 +37,14 @@ __device__ __forceinline__ float group_sum(float x) {
     return x;
 }
 
-// Lane-local part of relu(acc + b1) . W2[:, c] for the 4 hidden columns this lane owns.
-// w2 points at W2p[(4*gl) * C]; rows beyond H are zero-padded so inactive columns add 0.
+// Lane-local part of relu(z) . W2[:, c] for the 4 hidden columns this lane owns (z = pre-activation, bias
+// included).  w2 points at W2p[(4*gl) * C]; rows beyond H are zero-padded so inactive columns add 0.
 template <int CP>
-__device__ __forceinline__ void relu_w2_partial(f32x4 acc, f32x4 b1v, const float *w2, int C,
-                                                float (&part)[CP]) {
-    const float h0 = fmaxf(acc.x + b1v.x, 0.f);
-    const float h1 = fmaxf(acc.y + b1v.y, 0.f);
-    const float h2 = fmaxf(acc.z + b1v.z, 0.f);
-    const float h3 = fmaxf(acc.w + b1v.w, 0.f);
+__device__ __forceinline__ void relu_w2_partial(f32x4 z, const float *w2, int C, float (&part)[CP]) {
+    const float h0 = fmaxf(z.x, 0.f);
+    const float h1 = fmaxf(z.y, 0.f);
+    const float h2 = fmaxf(z.z, 0.f);
+    const float h3 = fmaxf(z.w, 0.f);
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
         float p = 0.f;
@@ -57,15 +58,16 @@ __device__ __forceinline__ void relu_w2_partial(f32x4 acc, f32x4 b1v, const floa
     }
 }
 
-// One CSR row against a dense [*, ld] matrix, 4 columns per lane.  `subst_col`/`subst_row`:
+// One CSR row against a dense [*, ld] matrix, 4 columns per lane, accumulated onto `init`.  `subst_col`/`subst_row`:
 // entries whose column equals subst_col read subst_row instead of S (the perturbed S1 row of a
 // probe); pass subst_col = -1 for none.  Pointer select, so the arithmetic is the same chain.
 __device__ __forceinline__ f32x4 row_dot(const int32_t *__restrict__ col,
                                          const float *__restrict__ val, int e0, int e1,
                                          const float *__restrict__ S, int ld, int coff,
                                          bool active, int subst_col,
-                                         const float *__restrict__ subst_row) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                                         const float *__restrict__ subst_row,
+                                         f32x4 init = f32x4{0.f, 0.f, 0.f, 0.f}) {
+    f32x4 acc = init;
     int e = e0;
     for (; e + 4 <= e1; e += 4) {
         int c[4];
