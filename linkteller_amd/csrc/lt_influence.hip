@@ -358,19 +358,9 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
     asm volatile("" : "+v"(vprobe));   // retire this ordinary load before any LDS-DMA is in flight (hipcc would drain vmcnt(0) at its first use)
 
     // every chain starts from the bias (row_dot's `init`); retired before the DMAs for the same reason
-    const f32x4 b1v = ld4(b1p + coff);
-    double blo = __builtin_bit_cast(double, f32x2_t{b1v.x, b1v.y}), bhi = __builtin_bit_cast(double, f32x2_t{b1v.z, b1v.w});
-    asm volatile("" : "+v"(blo), "+v"(bhi));
-    f32x4 acc[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {   // v_mov_b64 pairs: half the instructions of 4 x v_mov_b32 (this kernel is VALU-issue bound)
-        double lo, hi;
-        asm("v_mov_b64 %0, %1" : "=v"(lo) : "v"(blo));
-        asm("v_mov_b64 %0, %1" : "=v"(hi) : "v"(bhi));
-        const f32x2_t l2 = __builtin_bit_cast(f32x2_t, lo), h2 = __builtin_bit_cast(f32x2_t, hi);
-        acc[p] = f32x4{l2.x, l2.y, h2.x, h2.y};
-    }
-
+    f32x4 b1v = ld4(b1p + coff);
+    asm volatile("" : "+v"(b1v));
+    f32x4 acc[P];   // set by the first entry of the row: acc = fma(a_0, s_0, b1) -- no initialisation pass
     const int e0 = rowptr[r], e1 = rowptr[r + 1];
     const int deg = e1 - e0;
     const int nh = (deg + 3) >> 2;
@@ -406,59 +396,87 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
         wait_vmcnt<4 * AFTER + 1>(); s[2] = *reinterpret_cast<const f32x4 *>(slot + 512);
         wait_vmcnt<4 * AFTER + 0>(); s[3] = *reinterpret_cast<const f32x4 *>(slot + 768);
     };
-    // the first `cnt` entries of a fetched half-block into all P chains
-    auto fmas = [&](const float (&a)[4], const f32x4 (&s)[4], int cnt) {
+    // the first `cnt` (>= 1) entries of a fetched half-block into all P chains; FIRST: the row's first
+    // half-block, whose entry 0 starts every chain from the bias
+    auto fmas = [&](const float (&a)[4], const f32x4 (&s)[4], int cnt, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        if constexpr (FIRST) {
+            // acc[p] = fma(a_0, s_0, b1) for every probe.  The P results are equal by construction (FULL mode
+            // is P independent recomputations of the same row), and hipcc would compute one and copy it P
+            // times; volatile asm keeps them P separate FMAs -- and P opaque values, so the chains that
+            // continue from them stay separate too.
+            const double ap = __builtin_bit_cast(double, f32x2_t{a[0], a[0]});
+            const double slo = __builtin_bit_cast(double, f32x2_t{s[0].x, s[0].y});
+            const double shi = __builtin_bit_cast(double, f32x2_t{s[0].z, s[0].w});
+            const double blo = __builtin_bit_cast(double, f32x2_t{b1v.x, b1v.y});
+            const double bhi = __builtin_bit_cast(double, f32x2_t{b1v.z, b1v.w});
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+            for (int p = 0; p < P; ++p) {
+                double lo, hi;
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(ap), "v"(slo), "v"(blo));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(ap), "v"(shi), "v"(bhi));
+                const f32x2_t l2 = __builtin_bit_cast(f32x2_t, lo), h2 = __builtin_bit_cast(f32x2_t, hi);
+                acc[p] = f32x4{l2.x, l2.y, h2.x, h2.y};
+            }
+        }
+#pragma unroll
+        for (int k = FIRST ? 1 : 0; k < 4; ++k) {
             if (k >= cnt) break;   // wave-uniform: entries past the row end are skipped (last half-block only)
 #pragma unroll
             for (int p = 0; p < P; ++p) acc[p] = fma4(a[k], s[k], acc[p]);
         }
     };
-    if (nh > 0) {
+    static_assert(LT_RING_NB == 1, "the loop below is written for one half-block in flight behind the consumed one");
+    if (nh == 0) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {   // empty row: z = b1 (opaque copies, see fmas)
+            f32x4 t = b1v;
+            asm volatile("" : "+v"(t));
+            acc[p] = t;
+        }
+    } else {
         int cI[4], cN[4], cF[4];
         float aC[4], aN[4];
         f32x4 s[4];
-        // prologue: half-blocks 0 .. min(NB, nh) - 1 in flight
         load_cols(0, cI, e0);
         load_vals(0, aC, e0);
         issue(0, cI);
-#pragma unroll
-        for (int j = 1; j < LT_RING_NB; ++j)
-            if (j < nh) { load_cols(j, cI, e0); issue(j, cI); }
-        load_cols(LT_RING_NB, cN, e0);   // one half-block of look-ahead (past a short row: inside the padding, unused)
-        int h = 0;
-        // steady state: LT_RING_NB half-blocks are in flight behind h after the issue below.  The (col, val)
-        // scalar loads of the NEXT iteration are issued once the first ring read of this one has landed
-        // (the empty asm ties their address to it), i.e. in front of a block of FMAs that covers their
-        // latency; issued any earlier they would share the lgkmcnt(0) that guards the ring reads.
-        for (; h + LT_RING_NB < nh; ++h) {
-            issue(h + LT_RING_NB, cN);
-            fetch(h, s, std::integral_constant<int, LT_RING_NB>{});
+        load_cols(1, cN, e0);   // one half-block of look-ahead (past a short row: inside the padding, unused)
+        // Half-block h+1 goes in flight, half-block h is consumed.  The (col, val) scalar loads of the NEXT
+        // iteration are issued once the first ring read of this one has landed (the empty asm ties their
+        // address to it), i.e. in front of a block of FMAs that covers their latency; issued any earlier
+        // they would share the lgkmcnt(0) that guards the ring reads.
+        auto front = [&](int h) {
+            issue(h + 1, cN);
+            fetch(h, s, std::integral_constant<int, 1>{});
             int eb = e0;
             asm volatile("" : "+s"(eb) : "v"(s[0].x));
-            load_cols(h + LT_RING_NB + 1, cF, eb);
+            load_cols(h + 2, cF, eb);
             load_vals(h + 1, aN, eb);
-            fmas(aC, s, 4);
+        };
+        auto back = [&]() {
             // pin the look-ahead columns in SGPRs here (hipcc otherwise sinks the loads to the top of the
             // next iteration, right in front of their use)
             asm volatile("" : "+s"(cF[0]), "+s"(cF[1]), "+s"(cF[2]), "+s"(cF[3]));
 #pragma unroll
             for (int k = 0; k < 4; ++k) { aC[k] = aN[k]; cN[k] = cF[k]; }
+        };
+        // the row's first half-block starts the chains (one copy of that code for long and short rows)
+        const bool more = nh > 1;
+        if (more) front(0);
+        else fetch(0, s, std::integral_constant<int, 0>{});
+        fmas(aC, s, more ? 4 : deg, std::true_type{});
+        if (more) {
+            back();
+            int h = 1;
+            for (; h + 1 < nh; ++h) {
+                front(h);
+                fmas(aC, s, 4, std::false_type{});
+                back();
+            }
+            fetch(h, s, std::integral_constant<int, 0>{});
+            fmas(aC, s, deg - 4 * h, std::false_type{});
         }
-        // drain: nothing left to issue; fewer half-blocks behind h each time
-#if LT_RING_NB >= 2
-        if (h + 1 < nh) {
-            load_vals(h + 1, aN, e0);
-            fetch(h, s, std::integral_constant<int, 1>{});
-            fmas(aC, s, 4);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) aC[k] = aN[k];
-            ++h;
-        }
-#endif
-        fetch(h, s, std::integral_constant<int, 0>{});
-        fmas(aC, s, deg - 4 * h);
     }
 
     const unsigned hitmask = (unsigned)__ballot(anyhit);   // bit p: probe pb+p sits on one of this row's columns
