@@ -364,7 +364,8 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
     const int e0 = rowptr[r], e1 = rowptr[r + 1];
     const int deg = e1 - e0;
     const int nh = (deg + 3) >> 2;
-    bool anyhit = false;
+    unsigned long long hit = 0ull;
+    const unsigned lane_off = 4u * (unsigned)coff;
 
     auto load_cols = [&](int h, int (&c)[4], int eb) {
         const int32_t *cp = col + eb + 4 * h;     // may run past the row: stays inside the padded array
@@ -374,17 +375,19 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
     auto load_vals = [&](int h, float (&a)[4], int eb) {
         const float *vp_ = val + eb + 4 * h;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float v = vp_[k];
-            a[k] = (4 * h + k < deg) ? v : 0.f;
-        }
+        for (int k = 0; k < 4; ++k) a[k] = vp_[k];   // entries past the row end are never used (fmas stops at cnt)
     };
     auto issue = [&](int h, const int (&c)[4]) {
         const int base = (h % (LT_RING_NB + 1)) * 4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            anyhit |= (vprobe == c[k]) & (4 * h + k < deg);
-            __builtin_amdgcn_global_load_lds((S1 + (size_t)c[k] * Hp) + coff, (lds_ptr_t)(ring + (base + k) * 256), 16, 0, 0);
+            // wave-level hit mask in SGPRs (v_cmp + s_or): bit l = lane l's probe sits on this column
+            hit |= (4 * h + k < deg) ? __ballot(vprobe == c[k]) : 0ull;
+            // uniform row base + 32-bit unsigned lane offset -> the saddr form of global_load_lds (no VALU)
+            const char *rowp = reinterpret_cast<const char *>(S1 + (size_t)c[k] * Hp);
+            asm("" : "+s"(rowp));   // keeps hipcc from re-associating it into (S1 + lane_off) + row, a 64-bit VALU add
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(rowp + lane_off),
+                                             (lds_ptr_t)(ring + (base + k) * 256), 16, 0, 0);
         }
     };
     // half-block h out of the ring into registers; AFTER = number of half-blocks issued after it
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
         }
     }
 
-    const unsigned hitmask = (unsigned)__ballot(anyhit);   // bit p: probe pb+p sits on one of this row's columns
+    const unsigned hitmask = (unsigned)hit;   // bit p: probe pb+p sits on one of this row's columns (probe ids sit in lanes < P <= 32)
     if (__builtin_expect(hitmask != 0u, 0)) {
         // a column of this row is one of my probes (about P*deg/n of the waves).  This wave still
         // finishes the row with the UNSUBSTITUTED S1 row for all P probes -- right for every probe but
