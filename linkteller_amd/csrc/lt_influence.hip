@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
     const int deg = e1 - e0;
     const int nh = (deg + 3) >> 2;
     unsigned long long hit = 0ull;
-    const unsigned lane_off = 4u * (unsigned)coff;
+    unsigned lane_off = 4u * (unsigned)coff;
 
     auto load_cols = [&](int h, int (&c)[4], int eb) {
         const int32_t *cp = col + eb + 4 * h;     // may run past the row: stays inside the padded array
@@ -385,7 +385,11 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
             hit |= (4 * h + k < deg) ? __ballot(vprobe == c[k]) : 0ull;
             // uniform row base + 32-bit unsigned lane offset -> the saddr form of global_load_lds (no VALU)
             const char *rowp = reinterpret_cast<const char *>(S1 + (size_t)c[k] * Hp);
-            asm("" : "+s"(rowp));   // keeps hipcc from re-associating it into (S1 + lane_off) + row, a 64-bit VALU add
+            // two empty asm fences: the first keeps hipcc from re-associating the address into
+            // (S1 + lane_off) + row, the second re-defines lane_off in this basic block so that instruction
+            // selection sees base + zext(32-bit offset); without them the add is a 64-bit VALU op per entry
+            asm("" : "+s"(rowp));
+            asm("" : "+v"(lane_off));
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(rowp + lane_off),
                                              (lds_ptr_t)(ring + (base + k) * 256), 16, 0, 0);
         }
