@@ -25,7 +25,6 @@
 #include "lt_lanes.cuh"
 
 #define LT_BLOCK 256
-#define LT_FULL_P 8                       // probes per wave in the wide FULL stage-A kernel
 #define LT_CHUNK_BUDGET ((size_t)1 << 30)  // bytes of per-probe scratch per chunk
 #define LT_ITEM_GRID 2048                  // blocks of the grid-stride item kernels
 
@@ -34,12 +33,9 @@
 // ------------------------------------------------------------------------------------------------
 __global__ void k_perturb_rows(const float *__restrict__ X, long ldx, int F,
                                const int32_t *__restrict__ probes, float delta,
-                               float *__restrict__ Xp, int32_t *__restrict__ counter_or_null) {
+                               float *__restrict__ Xp) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
-    // also resets the ring kernel's hit-list counter (saves a launch; a 4-byte memset node faults under
-    // hipGraph replay on ROCm 7.2, a kernel store does not)
-    if (counter_or_null && f == 0 && b == 0) *counter_or_null = 0;
     if (f >= F) return;
     const float x = X[(long)probes[b] * ldx + f];
     const float pert = __fmul_rn(x, delta);
@@ -84,13 +80,13 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_stageA(
 
 // ------------------------------------------------------------------------------------------------
 // FULL stage A, wide hidden width (LPR = 64, 128 < Hp <= 256): a wave owns one row and P probes.
-//  * the row's CSR entries are wave-uniform (scalar loads); each gathered S1 row (one coalesced
-//    16 B/lane load) feeds P independent fmaf chains -> P x fewer L2 gather bytes per flop;
-//  * the 4 waves of a block work on the SAME row for 4 consecutive probe groups, so their gathers
-//    of that row's S1 lines meet in the CU's L1 instead of going to L2 four times;
-//  * substituting the probe's own row is rare: a 4-entry chunk first asks "does any column equal
-//    any of my P probes" with one vector compare per entry (probe ids sit one per lane) and only
-//    then takes the per-probe select path;
+//  * the row's CSR entries are wave-uniform (scalar loads); each gathered S1 row feeds P independent
+//    fmaf chains -> P x fewer L2 gather bytes per flop;
+//  * blocks are one wave; the probe groups of a row are adjacent in the grid, so their gathers of that
+//    row's S1 lines meet in L2;
+//  * substituting the probe's own row is rare: the hot loop only asks "does this column equal one of my
+//    P probes" (one vector compare per entry, probe ids sit one per lane, the answer is a wave mask in
+//    SGPRs); the probes that were hit are recomputed after the epilogue, one single-probe chain each;
 //  * the P*C (probe, class) partial sums are reduced together (lt_lanes.cuh): the xor 32,16,8,4,2,1
 //    butterfly of group_sum<64> with the live registers halving at every stage -- same pairings,
 //    fp add commutes, so the bits equal the baseline kernel's -- and leave in one coalesced store.
@@ -103,13 +99,12 @@ __device__ __forceinline__ float relu1(float x) {
     return r;
 }
 
-// Shared epilogue of the wide stage-A kernels: h = relu(acc + b1), the lane's share of h . W2 for all
-// P probes, the permlane/DPP folds, and the [row][probe][class] store.
+// Epilogue of the wide stage-A kernel: h = relu(z) (the chains already hold z = A_hat S1' + b1), the lane's
+// share of h . W2 for all P probes, the multi-value lane reduction, and the [row][probe][class] store.
 template <int CP, int P>
 __device__ __forceinline__ void stageA_epilogue(f32x4 (&acc)[P], int lane, bool active, int coff,
-                                                const float *__restrict__ b1p,
                                                 const float *__restrict__ W2p, int C, int n, int nb,
-                                                int r, int pb, float *__restrict__ S2p) {
+                                                int r, int pb, float *__restrict__ S2p, unsigned skip) {
     float w2[4 * CP];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -162,163 +157,19 @@ __device__ __forceinline__ void stageA_epilogue(f32x4 (&acc)[P], int lane, bool 
         const int q = j * VB + lane_totals_owner<VB>(lane);
         const int p = q / CP, c = q % CP;
         const bool owner = (lane & (64 / VB - 1)) == 0;
-        if (owner && c < C && pb + p < nb) S2p[((size_t)r * nb + pb + p) * C + c] = z;   // [row][probe][class]
+        // `skip`: probes (bits) whose entries someone else writes (the ring kernel's substituted recomputation)
+        if (owner && c < C && pb + p < nb && !((skip >> (p & 31)) & 1u)) S2p[((size_t)r * nb + pb + p) * C + c] = z;   // [row][probe][class]
     }
-}
-
-#ifndef LT_STAGEA_PEEL
-#define LT_STAGEA_PEEL 0
-#endif
-#ifndef LT_STAGEA_WAVES
-#define LT_STAGEA_WAVES 1   // waves per block; the waves of a block take the same row
-#endif
-template <int CP, int P>
-__global__ __launch_bounds__(64 * LT_STAGEA_WAVES) void k_full_stageA_wide(
-    int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-    const float *__restrict__ val, const float *__restrict__ S1, int Hp,
-    const float *__restrict__ b1p, const float *__restrict__ W2p, int C,
-    const int32_t *__restrict__ probes, int nb, const float *__restrict__ Sp,
-    float *__restrict__ S2p) {
-    static_assert((P * CP) % 4 == 0, "P*CP must be a multiple of 4");
-    const int lane = threadIdx.x & 63;
-    // one wave per block (finer scheduling granularity than 4-wave blocks: -15 % measured); linear
-    // block id = row * groups + group, so the probe groups of one row run together and meet in L2
-    const int groups = (nb + P - 1) / P;
-    const int gblocks = (groups + LT_STAGEA_WAVES - 1) / LT_STAGEA_WAVES;
-    const int r = blockIdx.x / gblocks;
-    const int pb = __builtin_amdgcn_readfirstlane((int)(((blockIdx.x % gblocks) * LT_STAGEA_WAVES + (threadIdx.x >> 6)) * P));
-    if (pb >= nb) return;
-    // lanes past Hp re-read the last column group (always in bounds) and are zeroed through w2
-    const bool active = 4 * lane < Hp;
-    const int coff = active ? 4 * lane : Hp - 4;
-
-    const int vprobe = (lane < P && pb + lane < nb) ? probes[pb + lane] : -1;
-
-    const f32x4 b1v = ld4(b1p + coff);   // every chain starts from the bias (row_dot's `init`)
-    f32x4 acc[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) acc[p] = b1v;
-
-    const float *__restrict__ S1c = S1 + coff;
-    const float *__restrict__ Spc = Sp + coff;
-    const int e0 = rowptr[r], e1 = rowptr[r + 1];
-    // one entry with the per-probe substitution test (rare path only)
-    auto one_entry = [&](int ee) {
-        const int c = col[ee];
-        const float a = val[ee];
-        const f32x4 s = ld4(S1c + (size_t)c * Hp);
-        int pbq = pb;
-        asm volatile("" : "+s"(pbq));  // keep the P substitute-row addresses out of the hot loop's registers
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            f32x4 sp = s;
-            const int vpp = (pbq + p < nb) ? probes[pbq + p] : -1;   // fetched here: rare path, saves P SGPRs
-            if (c == vpp) {
-                sp = ld4(Spc + (size_t)(pbq + p) * Hp);
-                // retire the load here: ONE temporary instead of P destination register sets
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(sp));
-            }
-            acc[p] = fma4(a, sp, acc[p]);
-        }
-    };
-    // The row is walked in chunks of 4 entries, software-pipelined: while chunk i is in the FMA
-    // pipe, the S1 rows of chunk i+1 are in flight (vector loads) and the (col, val) of chunk i+2
-    // are being fetched (scalar loads).  The last chunk may be partial: its loads are clamped to
-    // the row's last entry (always in bounds) and the surplus entries get coefficient 0 --
-    // fmaf(0, s, acc) == acc bit for bit for finite s (acc is never -0: it starts at +0).
-    const int deg = e1 - e0;
-    const int nchunks = (deg + 3) >> 2;
-    const int elast = e1 - 1;
-    auto load_scalars = [&](int i, int (&c)[4], float (&a)[4]) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int ee = e0 + 4 * i + k;
-            const int ec = min(ee, elast);
-            c[k] = col[ec];
-            const float v = val[ec];
-            a[k] = ee <= elast ? v : 0.f;
-        }
-    };
-    auto gather = [&](const int (&c)[4], f32x4 (&s)[4]) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) s[k] = ld4(S1c + (size_t)c[k] * Hp);
-    };
-    // `anyhit` collects "some column of this row is one of my probes"; such a row (rare: about
-    // P*deg/n of them) is redone from scratch below with the per-probe substitution test, which
-    // keeps the select path -- and its registers -- out of this loop.
-    bool anyhit = false;
-    auto compute = [&](int i, const int (&c)[4], const float (&a)[4], const f32x4 (&s)[4]) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) anyhit |= (vprobe == c[k]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int p = 0; p < P; ++p) acc[p] = fma4(a[k], s[k], acc[p]);
-    };
-    if (nchunks > 0) {
-        int cA[4], cB[4], cC[4], cD[4];
-        float aA[4], aB[4], aC[4], aD[4];
-        f32x4 sA[4], sB[4];
-        load_scalars(0, cA, aA);
-        gather(cA, sA);
-        load_scalars(1, cB, aB);      // clamped: harmless when the row has a single chunk
-#if LT_STAGEA_PEEL
-        int i = 0;
-        for (; i + 2 < nchunks; i += 2) {   // steady state: every load unconditional
-            gather(cB, sB);
-            load_scalars(i + 2, cC, aC);
-            compute(i, cA, aA, sA);
-            gather(cC, sA);
-            load_scalars(i + 3, cD, aD);
-            compute(i + 1, cB, aB, sB);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                cA[k] = cC[k]; aA[k] = aC[k];
-                cB[k] = cD[k]; aB[k] = aD[k];
-            }
-        }
-        if (i + 1 < nchunks) {
-            gather(cB, sB);
-            compute(i, cA, aA, sA);
-            compute(i + 1, cB, aB, sB);
-        } else {
-            compute(i, cA, aA, sA);
-        }
-#else
-        for (int i = 0; i < nchunks; i += 2) {
-            if (i + 1 < nchunks) gather(cB, sB);
-            load_scalars(i + 2, cC, aC);
-            compute(i, cA, aA, sA);
-            if (i + 2 < nchunks) gather(cC, sA);
-            load_scalars(i + 3, cD, aD);
-            if (i + 1 < nchunks) compute(i + 1, cB, aB, sB);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                cA[k] = cC[k]; aA[k] = aC[k];
-                cB[k] = cD[k]; aB[k] = aD[k];
-            }
-        }
-#endif
-    }
-    if (__builtin_expect(__ballot(anyhit) != 0ull, 0)) {
-#pragma unroll
-        for (int p = 0; p < P; ++p) acc[p] = b1v;
-#pragma nounroll
-        for (int e = e0; e < e1; ++e) one_entry(e);
-    }
-
-    stageA_epilogue<CP, P>(acc, lane, active, coff, b1p, W2p, C, n, nb, r, pb, S2p);
 }
 
 // ------------------------------------------------------------------------------------------------
-// FULL stage A, LDS-ring variant (wide hidden width, one wave per block).  The S1 rows of a row's
+// The kernel (LDS ring, one wave per block).  The S1 rows of a row's
 // entries are fetched by LDS-DMA (global_load_lds_dwordx4: one 1 KiB row per instruction, no VGPR
 // destination) into a wave-private ring NB half-blocks (4 entries each) ahead of the FMAs, so
-//   * loads in flight cost LDS, not registers (acc[P] + 4 staged rows = ~90 VGPRs),
+//   * loads in flight cost LDS, not registers (acc[P] + 4 staged rows: 92 VGPRs at P = 16, 156 at P = 32),
 //   * the wait before each entry is a COUNTED s_waitcnt vmcnt(4*NB + 3 - k) -- never a drain,
 //   * the (col, val) of a half-block arrive as one 4-dword scalar load each, a half-block early.
-// Arithmetic is the same fmaf chain as every other layer-1 kernel (entries past the row end carry
-// coefficient 0), the epilogue is shared with the register-staged kernel.
+// Arithmetic is the same fmaf chain as every other layer-1 kernel (entries past the row end are skipped).
 // ------------------------------------------------------------------------------------------------
 #ifndef LT_RING_NB
 #define LT_RING_NB 1   // half-blocks in flight behind the one being consumed (ring = 4*(NB+1) KiB per wave)
@@ -342,7 +193,7 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
     const float *__restrict__ val, const float *__restrict__ S1, int Hp,
     const float *__restrict__ b1p, const float *__restrict__ W2p, int C,
     const int32_t *__restrict__ probes, int nb, const float *__restrict__ Sp,
-    float *__restrict__ S2p, int32_t *__restrict__ redo) {
+    float *__restrict__ S2p) {
     static_assert((P * CP) % 4 == 0, "P*CP must be a multiple of 4");
     __shared__ __attribute__((aligned(16))) float ring[LT_RING_SLOTS * 256];
     const int lane = threadIdx.x;
@@ -487,54 +338,24 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
     }
 
     const unsigned hitmask = (unsigned)hit;   // bit p: probe pb+p sits on one of this row's columns (probe ids sit in lanes < P <= 32)
+    // A column of this row is one of my probes (about P*deg/n of the waves): the chains above used the
+    // UNSUBSTITUTED S1 row for all P probes -- right for every probe but the one(s) sitting on that column.
+    // The epilogue leaves those out, and the wave recomputes them here, one single-probe chain each (row_dot
+    // + relu_w2_partial + group_sum, the chain every other kernel uses), with its accumulators dead and the
+    // row's S1 lines still warm in L1/L2.  Keeping the select path out of the hot loop is worth 50 VGPRs.
+    stageA_epilogue<CP, P>(acc, lane, active, coff, W2p, C, n, nb, r, pb, S2p, hitmask);
     if (__builtin_expect(hitmask != 0u, 0)) {
-        // a column of this row is one of my probes (about P*deg/n of the waves).  This wave still
-        // finishes the row with the UNSUBSTITUTED S1 row for all P probes -- right for every probe but
-        // the one(s) sitting on that column -- and hands (row, group) to k_full_stageA_fix, which
-        // recomputes just those probes with their own perturbed row and overwrites their S2' entries.
-        // Keeping the select path out of this kernel is worth 50 VGPRs (152 -> 102).
-        if (lane == 0) {
-            const int slot = atomicAdd(redo, 1);
-            redo[1 + 2 * slot] = blockIdx.x;
-            redo[2 + 2 * slot] = (int)hitmask;
-        }
-    }
-    stageA_epilogue<CP, P>(acc, lane, active, coff, b1p, W2p, C, n, nb, r, pb, S2p);
-  }
-}
-
-// Fix-up kernel of the ring variant: for every listed (row, probe group) and every probe of the group that
-// sits on one of the row's columns, the row's layer-1 value with that probe's perturbed S1 row substituted
-// (row_dot + relu_w2_partial + group_sum: the single-probe chain every other kernel uses), written over
-// the unsubstituted value the ring kernel stored.  ~|R_v| single-probe rows per probe: tiny.
-template <int CP, int PM>
-__global__ __launch_bounds__(64) void k_full_stageA_fix(
-    int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-    const float *__restrict__ val, const float *__restrict__ S1, int Hp,
-    const float *__restrict__ b1p, const float *__restrict__ W2p, int C,
-    const int32_t *__restrict__ probes, int nb, const float *__restrict__ Sp,
-    float *__restrict__ S2p, const int32_t *__restrict__ redo) {
-    const int lane = threadIdx.x;
-    const int groups = (nb + PM - 1) / PM;
-    const int count = redo[0];
-    const bool active = 4 * lane < Hp;
-    const int coff = active ? 4 * lane : Hp - 4;
-    const f32x4 b1v = ld4(b1p + coff);
-    for (int it = blockIdx.x; it < count; it += gridDim.x) {
-        const int bid = redo[1 + 2 * it];
-        unsigned mask = (unsigned)redo[2 + 2 * it];
-        const int r = bid / groups;
-        const int pb = (bid % groups) * PM;
-        const int e0 = rowptr[r], e1 = rowptr[r + 1];
-        while (mask) {
-            const int p = __builtin_ctz(mask);
-            mask &= mask - 1;
+        const f32x4 b1r = ld4(b1p + coff);
+        unsigned m = hitmask;
+        while (m) {
+            const int p = __builtin_ctz(m);
+            m &= m - 1;
             const int v = probes[pb + p];
-            const f32x4 acc = row_dot(col, val, e0, e1, S1, Hp, coff, true, v, Sp + (size_t)(pb + p) * Hp, b1v);
+            const f32x4 z = row_dot(col, val, e0, e1, S1, Hp, coff, true, v, Sp + (size_t)(pb + p) * Hp, b1r);
             float part[CP];
 #pragma unroll
             for (int c = 0; c < CP; ++c) part[c] = 0.f;
-            if (active) relu_w2_partial<CP>(acc, W2p + (size_t)coff * C, C, part);
+            if (active) relu_w2_partial<CP>(z, W2p + (size_t)coff * C, C, part);
 #pragma unroll
             for (int c = 0; c < CP; ++c) part[c] = group_sum<64>(part[c]);
             if (lane == 0) {
@@ -544,6 +365,7 @@ __global__ __launch_bounds__(64) void k_full_stageA_fix(
             }
         }
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -807,7 +629,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-// Probes per wave of the wide FULL kernels (8, 16 or 32): a tuning knob only -- results are bit-identical.
+// Probes per wave of the wide FULL kernel (8, 16 or 32): a tuning knob only -- results are bit-identical.
 // Measured cost of a (row, group) wave ~ 3.4 + 0.63 * P (arbitrary units; twitch-RU, 500 probes: P = 8 /
 // 16 / 32 -> 528 / 396 / 376 us), so the choice minimises ceil(nb / P) * (3.4 + 0.63 P); LT_FULL_P pins it.
 static int full_probes_per_wave(int nb) {
@@ -834,21 +656,11 @@ static size_t chunk_budget() {
     return LT_CHUNK_BUDGET;
 }
 
-static bool full_use_lds_ring() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("LT_STAGEA_LDS");   // default on; LT_STAGEA_LDS=0 selects the register-staged kernel
-        v = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return v == 1;
-}
-
 struct infl_ws {
     float *Xp, *Sp, *S2p;  // FULL / SPARSE: perturbed feature rows, their S1 rows; FULL: per-probe S2
     float *slabs;          // FULL / SPARSE: split-K partials of the perturbed-row GEMM
     float *S2x;            // SPARSE / DELTA: per-item values
     int32_t *off;          // SPARSE / DELTA: item offsets [chunk + 1]
-    int32_t *redo;         // FULL (ring kernel): [0] = count, then (row * groups + group) entries
     size_t bytes;
     int chunk;
 };
@@ -881,7 +693,6 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
     }
     if (mode == LT_MODE_FULL) {
         w.S2p = (float *)take(chunk * n * C * sizeof(float));
-        w.redo = (int32_t *)take((1 + 2 * n * ((chunk + 7) / 8)) * sizeof(int32_t));
     }
     if (mode != LT_MODE_FULL) {
         w.S2x = (float *)take(chunk * maxc * C * sizeof(float));
@@ -930,7 +741,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
             // perturbed rows and their S1 rows: Sp = (X[v] + X[v]*d) W1            attacker.py:101-105
             { lt_prof_scope prof_(LT_K_PERTURB, st);
             hipLaunchKernelGGL(k_perturb_rows, dim3((b->F + 255) / 256, nb), dim3(256), 0, st, b->X,
-                               (long)b->ldx, b->F, probes, delta, w.Xp, mode == LT_MODE_FULL ? w.redo : (int32_t *)nullptr); }
+                               (long)b->ldx, b->F, probes, delta, w.Xp); }
             LT_CHECK_LAUNCH();
             if (Hp != b->H) LT_HIP(hipMemsetAsync(w.Sp, 0, (size_t)nb * Hp * sizeof(float), st));
             int rc = lt_launch_gemm_splitk(w.Xp, b->F, b->W1, b->H, w.Sp, Hp, nb, b->H, b->F, LT_KSLICE_PROBE, w.slabs, st);
@@ -941,43 +752,20 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
             { lt_prof_scope prof_(LT_K_FULL_A, st);
             if (lpr == 64) {
                 const int P = full_probes_per_wave(nb);
-                const int groups = (nb + P - 1) / P;
-                const int gblocks = (groups + LT_STAGEA_WAVES - 1) / LT_STAGEA_WAVES;
-                LT_REQUIRE((long)n * gblocks < 2147483647L, "lt_influence_rows: n * probe groups exceeds the grid limit");
-                dim3 grid((unsigned)((long)n * gblocks));
-                if (full_use_lds_ring()) {
-                    const int Pr = (P == 8) ? 8 : (P == 32 ? 32 : 16);
-                    const long rblocks = (n + LT_RING_ROWS - 1) / LT_RING_ROWS;
-                    const int rgroups = (nb + Pr - 1) / Pr;
-                    LT_REQUIRE(rblocks * rgroups < 2147483647L, "lt_influence_rows: grid limit");
-                    dim3 gridr((unsigned)(rblocks * rgroups));
-#define LT_RING_PAIR(P_)                                                                                      \
+                const long rblocks = (n + LT_RING_ROWS - 1) / LT_RING_ROWS;
+                const int rgroups = (nb + P - 1) / P;
+                LT_REQUIRE(rblocks * rgroups < 2147483647L, "lt_influence_rows: n * probe groups exceeds the grid limit");
+                dim3 gridr((unsigned)(rblocks * rgroups));
+#define LT_RING_LAUNCH(P_)                                                                                    \
     do {                                                                                                      \
         LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, P_>), gridr, dim3(64), 0, st, n,        \
                                                g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p, C,       \
-                                               probes, nb, w.Sp, w.S2p, w.redo));                             \
-        LT_CHECK_LAUNCH();                                                                                    \
-        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_fix<CP_, P_>), dim3(2048), dim3(64), 0, st, n,   \
-                                               g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p, C,       \
-                                               probes, nb, w.Sp, w.S2p, w.redo));                             \
+                                               probes, nb, w.Sp, w.S2p));                                     \
     } while (0)
-                    if (Pr == 8) LT_RING_PAIR(8);
-                    else if (Pr == 32) LT_RING_PAIR(32);
-                    else LT_RING_PAIR(16);
-#undef LT_RING_PAIR
-                } else if (P == 32) {
-                    LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_wide<CP_, 32>), grid, dim3(64 * LT_STAGEA_WAVES), 0,
-                                                           st, n, g->rowptr, g->col, g->val, b->S1, Hp, b->b1p,
-                                                           b->W2p, C, probes, nb, w.Sp, w.S2p));
-                } else if (P == 16) {
-                    LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_wide<CP_, 16>), grid, dim3(64 * LT_STAGEA_WAVES), 0,
-                                                           st, n, g->rowptr, g->col, g->val, b->S1, Hp, b->b1p,
-                                                           b->W2p, C, probes, nb, w.Sp, w.S2p));
-                } else {
-                    LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_wide<CP_, 8>), grid, dim3(64 * LT_STAGEA_WAVES), 0,
-                                                           st, n, g->rowptr, g->col, g->val, b->S1, Hp, b->b1p,
-                                                           b->W2p, C, probes, nb, w.Sp, w.S2p));
-                }
+                if (P == 8) LT_RING_LAUNCH(8);
+                else if (P == 32) LT_RING_LAUNCH(32);
+                else LT_RING_LAUNCH(16);
+#undef LT_RING_LAUNCH
             } else {
                 const int rpb = (LT_BLOCK / 64) * (64 / lpr);
                 dim3 grid((n + rpb - 1) / rpb, nb);
