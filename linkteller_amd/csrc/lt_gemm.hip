@@ -10,6 +10,8 @@
 // "column-wise" (lane -> row) and 17 is odd, so the 32 lanes of a half hit 32 distinct banks.
 #include "lt_internal.h"
 
+#include <type_traits>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -113,12 +115,16 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma(const float *__restrict__
 
 // ---- 128x128 block tile: each of the 4 waves owns a 64x64 quadrant = 2x2 MFMA tiles, so one A and
 // one B fragment feed two MFMAs each (half the LDS reads per flop of the 64x64 kernel) and a k-tile
-// carries 32 MFMAs per wave (2048 cycles) -- enough to cover the next tile's global loads with one
-// workgroup per CU.  Used for the big X*W1 product; same k-ordered fmaf chains per output.
+// carries 32 MFMAs per wave (2048 cycles).  Global loads run two k-tiles ahead of the LDS stores in two
+// register stages, LDS fragment reads one k-step ahead of the MFMAs; the steady-state loop is branch-free
+// so that hipcc's s_waitcnt are counted (vmcnt(7..4), lgkmcnt(3)) instead of drains.  Used for the big
+// X*W1 product (N a multiple of 128); same k-ordered fmaf chains per output.  Measured on twitch-RU
+// (4385 x 3170 x 256, 7 K-slices): 71 us = 100 TFLOP/s, 2/3 of the 150 TFLOP/s a pure MFMA stream reaches
+// on this part (tools/fold_test/mfma_peak.hip); the LDS store + barrier per k-tile is the largest rest.
 #define GL_BM 128
 #define GL_BN 128
 #ifndef GL_BK
-#define GL_BK 16        // k-depth of a tile (32 measured 10 % slower: two workgroups per CU no longer overlap as well)
+#define GL_BK 16        // k-depth of a tile (32 measured 8 % slower, also with the two-stage prefetch)
 #endif
 #define GL_LDA (GL_BK + 1)
 #define GL_PASS (GL_BK / 8)   // staging passes: 256 threads x float4 cover 128 x 8 (A) or 8 x 128 (B) floats
@@ -126,6 +132,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma_128(const float *__restri
                                                            const float *__restrict__ B, long ldb,
                                                            float *__restrict__ C, long ldc, int M, int N,
                                                            int K, int kslice, long slab_stride) {
+    // requires N % 128 == 0 (every B tile is full; the launcher falls back to the 64x64 kernel otherwise)
     __shared__ __attribute__((aligned(16))) float As[2][GL_BM * GL_LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][GL_BK * GL_BN];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -135,47 +142,58 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma_128(const float *__restri
     C += (long)blockIdx.z * slab_stride;
 
     // staging: A tile 128 x BK -> thread owns row a_row (+ 128/PASS per pass), 4 floats at a_col;
-    //          B tile BK x 128 -> thread owns row b_row (+ 8 per pass), 4 floats at b_col
+    //          B tile BK x 128 -> thread owns row b_row (+ 8 per pass), 4 floats at b_col.
+    // Rows past M are clamped to the last row: they only feed output rows that are never stored, and the
+    // loads of a full k-tile stay unconditional -- straight-line code whose outstanding loads the compiler
+    // can COUNT (vmcnt(n)); any branch in there and it drains vmcnt(0), i.e. kills the prefetch.
     constexpr int A_TPR = GL_BK / 4;            // threads per A row
     constexpr int A_RPP = 256 / A_TPR;          // A rows per pass
     const int a_row = tid / A_TPR, a_col = (tid % A_TPR) * 4;
     const int b_row = tid >> 5, b_col = (tid & 31) * 4;
-    const float *a_ptr = A + (long)(m0 + a_row) * lda + a_col;
-    const float *b_ptr = B + (long)b_row * ldb + n0 + b_col;
-    const bool b_full = (n0 + b_col + 3) < N;
-    f32x4 ra[GL_PASS], rb[GL_PASS];
-    auto load_tiles = [&](int k0) {
+    // The tile pointers walk along K (tiles are loaded strictly in order): no per-load address temporaries,
+    // which hipcc would alias with the load destinations and then guard with s_waitcnt vmcnt(0).
+    const float *a_ptr[GL_PASS], *b_ptr[GL_PASS];
+#pragma unroll
+    for (int p = 0; p < GL_PASS; ++p) {
+        a_ptr[p] = A + (long)min(m0 + a_row + p * A_RPP, M - 1) * lda + a_col + kb;
+        b_ptr[p] = B + (long)(kb + b_row + 8 * p) * ldb + n0 + b_col;
+    }
+    const long b_step = (long)GL_BK * ldb;
+
+    // two register stages: tile t is loaded into stage t & 1 TWO iterations before it is stored to LDS.  One
+    // k-tile of MFMAs is 2048 cycles (0.85 us), less than the latency of a loaded HBM system.
+    f32x4 ra[2][GL_PASS], rb[2][GL_PASS];
+    auto load_full = [&](auto stage_tag) {      // the next k-tile, all of it inside [kb, ke)
+        constexpr int S = decltype(stage_tag)::value;
+#pragma unroll
+        for (int p = 0; p < GL_PASS; ++p) {
+            ra[S][p] = *reinterpret_cast<const f32x4u *>(a_ptr[p]);
+            rb[S][p] = *reinterpret_cast<const f32x4u *>(b_ptr[p]);
+            a_ptr[p] += GL_BK;
+            b_ptr[p] += b_step;
+        }
+    };
+    auto load_tail = [&](int k0, auto stage_tag) {      // the slice's last, partial k-tile: zero-filled past ke
+        constexpr int S = decltype(stage_tag)::value;
 #pragma unroll
         for (int p = 0; p < GL_PASS; ++p) {
             f32x4 r = {0.f, 0.f, 0.f, 0.f};
-            if (m0 + a_row + p * A_RPP < M) {
-                const float *q = a_ptr + (long)p * A_RPP * lda + k0;
-                if (k0 + a_col + 3 < ke) r = *reinterpret_cast<const f32x4u *>(q);
-                else
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (k0 + a_col + j < ke) r[j] = q[j];
-            }
-            ra[p] = r;
+            for (int j = 0; j < 4; ++j)
+                if (k0 + a_col + j < ke) r[j] = a_ptr[p][j];
+            ra[S][p] = r;
             f32x4 t = {0.f, 0.f, 0.f, 0.f};
-            const int krow = k0 + b_row + 8 * p;
-            if (krow < ke) {
-                const float *q = b_ptr + (long)(krow - b_row) * ldb;
-                if (b_full) t = *reinterpret_cast<const f32x4u *>(q);
-                else
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (n0 + b_col + j < N) t[j] = q[j];
-            }
-            rb[p] = t;
+            if (k0 + b_row + 8 * p < ke) t = *reinterpret_cast<const f32x4u *>(b_ptr[p]);
+            rb[S][p] = t;
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, auto stage_tag) {
+        constexpr int S = decltype(stage_tag)::value;
 #pragma unroll
         for (int p = 0; p < GL_PASS; ++p) {
             float *as = &As[buf][(a_row + p * A_RPP) * GL_LDA + a_col];
-            as[0] = ra[p].x; as[1] = ra[p].y; as[2] = ra[p].z; as[3] = ra[p].w;
-            *reinterpret_cast<f32x4 *>(&Bs[buf][(b_row + 8 * p) * GL_BN + b_col]) = rb[p];
+            as[0] = ra[S][p].x; as[1] = ra[S][p].y; as[2] = ra[S][p].z; as[3] = ra[S][p].w;
+            *reinterpret_cast<f32x4 *>(&Bs[buf][(b_row + 8 * p) * GL_BN + b_col]) = rb[S][p];
         }
     };
 
@@ -187,35 +205,80 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma_128(const float *__restri
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = (ke - kb + GL_BK - 1) / GL_BK;
-    load_tiles(kb);
-    store_tiles(0);
-    __syncthreads();
     const int a_frag = (wr * 64 + (lane & 31)) * GL_LDA + (lane >> 5);
     const int b_frag = (lane >> 5) * GL_BN + wc * 64 + (lane & 31);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles(kb + (kt + 1) * GL_BK);
+    // one k-tile out of LDS buffer `buf`; the fragments of step kk+2 are read while step kk multiplies
+    auto multiply = [&](int buf) {
         const float *as = &As[buf][a_frag];
         const float *bs = &Bs[buf][b_frag];
+        float a0 = as[0], a1 = as[32 * GL_LDA], b0 = bs[0], b1 = bs[32];
 #pragma unroll
         for (int kk = 0; kk < GL_BK; kk += 2) {
-            const float a0 = as[kk], a1 = as[32 * GL_LDA + kk];
-            const float b0 = bs[kk * GL_BN], b1 = bs[kk * GL_BN + 32];
+            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+            if (kk + 2 < GL_BK) {
+                na0 = as[kk + 2]; na1 = as[32 * GL_LDA + kk + 2];
+                nb0 = bs[(kk + 2) * GL_BN]; nb1 = bs[(kk + 2) * GL_BN + 32];
+            }
+            // keep the reads above in front of the MFMAs below (hipcc sinks them to just before their use,
+            // which puts an LDS round trip in front of every group of four MFMAs)
+            __builtin_amdgcn_sched_barrier(0);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         }
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
+    };
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    const int nfull = (ke - kb) / GL_BK;               // full k-tiles; a partial one may follow
+    const bool partial = (ke - kb) % GL_BK != 0;
+    if (nfull > 0) {
+        load_full(S0{});
+        store_tiles(0, S0{});
+        if (nfull > 1) load_full(S1{});
         __syncthreads();
+        // iteration kt: tile kt+2 starts loading into stage kt & 1, tile kt is multiplied out of LDS buffer
+        // kt & 1, tile kt+1 (stage (kt+1) & 1, loaded an iteration ago) goes to the other LDS buffer
+        auto step = [&](int kt, auto even_tag) {
+            constexpr int E = decltype(even_tag)::value;   // kt & 1
+            if (kt + 2 < nfull) load_full(std::integral_constant<int, E>{});
+            multiply(E);
+            if (kt + 1 < nfull) store_tiles(E ^ 1, std::integral_constant<int, E ^ 1>{});
+            __syncthreads();
+        };
+        // steady state, two tiles per trip, everything unconditional: with a branch around the loads hipcc no
+        // longer knows how many loads are younger than the stage it stores, and waits for all of them
+        int kt = 0;
+        for (; kt + 3 < nfull; kt += 2) {
+            load_full(S0{});
+            multiply(0);
+            store_tiles(1, S1{});
+            __syncthreads();
+            load_full(S1{});
+            multiply(1);
+            store_tiles(0, S0{});
+            __syncthreads();
+        }
+        // the last one to three full tiles
+        for (; kt + 1 < nfull; kt += 2) {
+            step(kt, S0{});
+            step(kt + 1, S1{});
+        }
+        if (kt < nfull) step(kt, S0{});
+    }
+    if (partial) {
+        load_tail(kb + nfull * GL_BK, S0{});
+        store_tiles(0, S0{});
+        __syncthreads();
+        multiply(0);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int cn = n0 + wc * 64 + j * 32 + (lane & 31);
-            if (cn >= N) continue;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int cm = m0 + wr * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
@@ -280,7 +343,7 @@ int lt_launch_gemm_splitk(const float *A, int64_t lda, const float *B, int64_t l
     if (M == 0 || N == 0) return LT_OK;
     const int splits = (K + kslice - 1) / kslice;
     if (splits <= 1) return lt_launch_gemm(A, lda, B, ldb, C, ldc, M, N, K, st);
-    const bool big = M >= 1024 && N >= 128;
+    const bool big = M >= 1024 && N % GL_BN == 0;
     dim3 grid(big ? (M + GL_BM - 1) / GL_BM : (M + GM_BM - 1) / GM_BM,
               big ? (N + GL_BN - 1) / GL_BN : (N + GM_BN - 1) / GM_BN, splits);
     const long stride = (long)M * N;
