@@ -137,8 +137,8 @@ typedef enum lt_kernel_id {
     LT_K_GEMM = 0,        /* k_gemm_f32_mfma                           */
     LT_K_LAYER1 = 1,      /* k_layer1 (baseline fused SpMM1+ReLU+W2)   */
     LT_K_LAYER2 = 2,      /* k_layer2 (baseline SpMM2 + b2)            */
-    LT_K_PERTURB = 3,     /* k_perturb_rows                            */
-    LT_K_FULL_A = 4,      /* k_full_stageA[_wide]: batched perturbed SpMM1+ReLU+W2 */
+    LT_K_PERTURB = 3,     /* (unused since the perturbation moved into the probe-row GEMM's loads; id kept) */
+    LT_K_FULL_A = 4,      /* k_full_stageA / k_full_stageA_lds: batched perturbed SpMM1+ReLU+W2 */
     LT_K_FULL_B = 5,      /* k_full_stageB: SpMM2 on observed rows + diff + norm    */
     LT_K_ITEM_A = 6,      /* k_item_stageA (sparse / delta)            */
     LT_K_ITEM_B = 7,      /* k_item_stageB (sparse / delta)            */

@@ -295,14 +295,25 @@ extern "C" size_t lt_gcn2_workspace_bytes(int32_t n, int32_t F, int32_t H, int32
     return carve_gcn2(nullptr, n, H, C, F).bytes;
 }
 
-// S1 = X*W1 into an [n, Hp] buffer whose pad columns are zero; b1p / W2p zero-padded copies
+// S1 = X*W1 into an [n, Hp] buffer whose pad columns are zero; *b1_eff / *W2_eff = b1 / W2 zero-padded to Hp
+// rows: the caller's tensors themselves when nothing needs padding (H % 4 == 0, b1 16-byte aligned for the
+// float4 reads), else copies made here into b1p_buf / W2p_buf.
 static int prepare_layer_inputs(int n, const float *X, int64_t ldx, int F, const float *W1,
                                 const float *b1, int H, const float *W2, int C, float *S1,
-                                float *b1p, float *W2p, float *slabs, hipStream_t st) {
+                                float *b1p_buf, float *W2p_buf, const float **b1_eff, const float **W2_eff,
+                                float *slabs, hipStream_t st) {
     const int Hp = lt_round_up(H, 4);
     if (Hp != H) LT_HIP(hipMemsetAsync(S1, 0, (size_t)n * Hp * sizeof(float), st));
-    hipLaunchKernelGGL(k_pad_b1_w2, dim3((Hp * (C + 1) + 255) / 256), dim3(256), 0, st, b1, W2, H, Hp, C, b1p, W2p);
-    LT_CHECK_LAUNCH();
+    if (Hp == H && ((uintptr_t)b1 % 16) == 0) {
+        *b1_eff = b1;
+        *W2_eff = W2;
+    } else {
+        hipLaunchKernelGGL(k_pad_b1_w2, dim3((Hp * (C + 1) + 255) / 256), dim3(256), 0, st, b1, W2, H, Hp, C,
+                           b1p_buf, W2p_buf);
+        LT_CHECK_LAUNCH();
+        *b1_eff = b1p_buf;
+        *W2_eff = W2p_buf;
+    }
     if (slabs) return lt_launch_gemm_splitk(X, ldx, W1, H, S1, Hp, n, H, F, lt_gemm_pick_kslice(n, H, F), slabs, st);
     return lt_launch_gemm(X, ldx, W1, H, S1, Hp, n, H, F, st);
 }
@@ -323,9 +334,10 @@ extern "C" int lt_gcn2_forward(const lt_graph *g, const float *X, int64_t ldx, i
     hipStream_t st = (hipStream_t)stream;
     gcn2_ws w = carve_gcn2(workspace, g->n, H, C, F);
     const int Hp = lt_round_up(H, 4);
-    rc = prepare_layer_inputs(g->n, X, ldx, F, W1, b1, H, W2, C, w.S1, w.b1p, w.W2p, w.slabs, st);
+    const float *b1e = nullptr, *W2e = nullptr;
+    rc = prepare_layer_inputs(g->n, X, ldx, F, W1, b1, H, W2, C, w.S1, w.b1p, w.W2p, &b1e, &W2e, w.slabs, st);
     if (rc) return rc;
-    rc = lt_launch_layer1(g, w.S1, Hp, w.b1p, w.W2p, C, nullptr, w.S2, st);
+    rc = lt_launch_layer1(g, w.S1, Hp, b1e, W2e, C, nullptr, w.S2, st);
     if (rc) return rc;
     return lt_launch_layer2(g, w.S2, C, b2, logits, st);
 }
@@ -339,8 +351,8 @@ static void free_baseline(lt_baseline *b) {
     (void)hipFree(b->Z1);
     (void)hipFree(b->S2);
     (void)hipFree(b->OUT);
-    (void)hipFree(b->b1p);
-    (void)hipFree(b->W2p);
+    (void)hipFree(b->b1p_buf);
+    (void)hipFree(b->W2p_buf);
     (void)hipFree(b->slabs);
     lt_baseline_free_fp64(b);
     delete b;
@@ -351,7 +363,7 @@ extern "C" int lt_baseline_refresh(lt_baseline *b, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     if (b->n == 0) return LT_OK;
     int rc = prepare_layer_inputs(b->n, b->X, b->ldx, b->F, b->W1, b->b1, b->H, b->W2, b->C, b->S1,
-                                  b->b1p, b->W2p, b->slabs, st);
+                                  b->b1p_buf, b->W2p_buf, &b->b1p, &b->W2p, b->slabs, st);
     if (rc) return rc;
     rc = lt_launch_layer1(b->g, b->S1, b->Hp, b->b1p, b->W2p, b->C, b->Z1, b->S2, st);
     if (rc) return rc;
@@ -387,8 +399,8 @@ extern "C" int lt_baseline_create(const lt_graph *g, const float *X, int64_t ldx
     B_HIP(hipMalloc((void **)&b->Z1, nh));
     B_HIP(hipMalloc((void **)&b->S2, nc));
     B_HIP(hipMalloc((void **)&b->OUT, nc));
-    B_HIP(hipMalloc((void **)&b->b1p, (size_t)b->Hp * sizeof(float)));
-    B_HIP(hipMalloc((void **)&b->W2p, (size_t)b->Hp * C * sizeof(float)));
+    B_HIP(hipMalloc((void **)&b->b1p_buf, (size_t)b->Hp * sizeof(float)));
+    B_HIP(hipMalloc((void **)&b->W2p_buf, (size_t)b->Hp * C * sizeof(float)));
     if (lt_gemm_splitk_slab_bytes(b->n, H, F, lt_gemm_pick_kslice(b->n, H, F)))
         B_HIP(hipMalloc((void **)&b->slabs, lt_gemm_splitk_slab_bytes(b->n, H, F, lt_gemm_pick_kslice(b->n, H, F))));
 #undef B_HIP

@@ -21,10 +21,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GM_BK 16
 #define GM_LDA (GM_BK + 1)
 
+// GATHER: row m of the A operand is  x + x * delta  of row rows[m] of A, rounded as the reference rounds it
+// (perturbed features of probe m: attacker.py:101-105) -- the perturbed rows never exist in memory.
+template <bool GATHER>
 __global__ __launch_bounds__(256) void k_gemm_f32_mfma(const float *__restrict__ A, long lda,
                                                        const float *__restrict__ B, long ldb,
                                                        float *__restrict__ C, long ldc, int M, int N,
-                                                       int K, int kslice, long slab_stride) {
+                                                       int K, int kslice, long slab_stride,
+                                                       const int32_t *__restrict__ rows, float delta) {
     __shared__ __attribute__((aligned(16))) float As[2][GM_BM * GM_LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][GM_BK * GM_BN];
 
@@ -39,7 +43,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma(const float *__restrict__
     const int a_row = tid >> 2, a_col = (tid & 3) * 4;
     const int b_row = tid >> 4, b_col = (tid & 15) * 4;
     const bool a_row_ok = (m0 + a_row) < M;
-    const float *a_ptr = A + (long)(m0 + a_row) * lda + a_col;
+    const long a_src = GATHER ? (a_row_ok ? (long)rows[m0 + a_row] : 0L) : (long)(m0 + a_row);
+    const float *a_ptr = A + a_src * lda + a_col;
     const float *b_ptr = B + (long)b_row * ldb + n0 + b_col;
     const bool b_full = (n0 + b_col + 3) < N;
 
@@ -59,6 +64,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma(const float *__restrict__
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (k0 + a_col + j < ke) ra[j] = a_ptr[k0 + j];
+            }
+            if (GATHER) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ra[j] = __fadd_rn(ra[j], __fmul_rn(ra[j], delta));   // two roundings, no fma
             }
         }
         if (k0 + b_row < ke) {
@@ -293,8 +302,8 @@ int lt_launch_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, flo
     dim3 grid((M + GM_BM - 1) / GM_BM, (N + GM_BN - 1) / GM_BN);
     LT_REQUIRE(grid.y <= 65535u, "lt_gemm_f32: N=%d too large", N);
     lt_prof_scope prof_(LT_K_GEMM, st);
-    hipLaunchKernelGGL(k_gemm_f32_mfma, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, C,
-                       (long)ldc, M, N, K, K > 0 ? K : 1, 0L);
+    hipLaunchKernelGGL(k_gemm_f32_mfma<false>, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, C,
+                       (long)ldc, M, N, K, K > 0 ? K : 1, 0L, (const int32_t *)nullptr, 0.f);
     LT_CHECK_LAUNCH();
     return LT_OK;
 }
@@ -339,27 +348,37 @@ size_t lt_gemm_splitk_slab_bytes(int M, int N, int K, int kslice) {
 // bound by the latency of its own tile loads); each output is the ordered sum of its slices, so
 // a row's result does not depend on how many rows the call carries.
 int lt_launch_gemm_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
-                          int M, int N, int K, int kslice, float *slabs, hipStream_t st) {
+                          int M, int N, int K, int kslice, float *slabs, hipStream_t st,
+                          const int32_t *gather_rows, float delta) {
     if (M == 0 || N == 0) return LT_OK;
     const int splits = (K + kslice - 1) / kslice;
-    if (splits <= 1) return lt_launch_gemm(A, lda, B, ldb, C, ldc, M, N, K, st);
-    const bool big = M >= 1024 && N % GL_BN == 0;
+    if (splits <= 1 && !gather_rows) return lt_launch_gemm(A, lda, B, ldb, C, ldc, M, N, K, st);
+    const bool big = !gather_rows && M >= 1024 && N % GL_BN == 0;
     dim3 grid(big ? (M + GL_BM - 1) / GL_BM : (M + GM_BM - 1) / GM_BM,
               big ? (N + GL_BN - 1) / GL_BN : (N + GM_BN - 1) / GM_BN, splits);
+    LT_REQUIRE(grid.y <= 65535u && grid.z <= 65535u, "split-K GEMM: N=%d or K=%d too large", N, K);
     const long stride = (long)M * N;
+    // a single slice writes C directly (no slab, no sum)
+    float *dst = splits > 1 ? slabs : C;
+    const long ldd = splits > 1 ? (long)N : (long)ldc;
     {
         lt_prof_scope prof_(LT_K_GEMM, st);
         if (big)
-            hipLaunchKernelGGL(k_gemm_f32_mfma_128, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, slabs,
-                               (long)N, M, N, K, kslice, stride);
+            hipLaunchKernelGGL(k_gemm_f32_mfma_128, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, dst, ldd,
+                               M, N, K, kslice, stride);
+        else if (gather_rows)
+            hipLaunchKernelGGL(k_gemm_f32_mfma<true>, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, dst, ldd,
+                               M, N, K, kslice, stride, gather_rows, delta);
         else
-            hipLaunchKernelGGL(k_gemm_f32_mfma, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, slabs,
-                               (long)N, M, N, K, kslice, stride);
+            hipLaunchKernelGGL(k_gemm_f32_mfma<false>, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, dst, ldd,
+                               M, N, K, kslice, stride, (const int32_t *)nullptr, 0.f);
         LT_CHECK_LAUNCH();
-        const long tot = (long)M * N;
-        hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, slabs, stride,
-                           splits, M, N, (long)N, C, (long)ldc);
-        LT_CHECK_LAUNCH();
+        if (splits > 1) {
+            const long tot = (long)M * N;
+            hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, slabs, stride,
+                               splits, M, N, (long)N, C, (long)ldc);
+            LT_CHECK_LAUNCH();
+        }
     }
     return LT_OK;
 }

@@ -29,20 +29,6 @@
 #define LT_ITEM_GRID 2048                  // blocks of the grid-stride item kernels
 
 // ------------------------------------------------------------------------------------------------
-// FULL: perturbed feature rows  xp = x + x*d  (two roundings, as attacker.py:103,105 do)
-// ------------------------------------------------------------------------------------------------
-__global__ void k_perturb_rows(const float *__restrict__ X, long ldx, int F,
-                               const int32_t *__restrict__ probes, float delta,
-                               float *__restrict__ Xp) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = blockIdx.y;
-    if (f >= F) return;
-    const float x = X[(long)probes[b] * ldx + f];
-    const float pert = __fmul_rn(x, delta);
-    Xp[(long)b * F + f] = __fadd_rn(x, pert);
-}
-
-// ------------------------------------------------------------------------------------------------
 // FULL stage A, narrow hidden widths (LPR < 64): one probe per grid.y, pointer-select substitution
 // ------------------------------------------------------------------------------------------------
 template <int LPR, int CP>
@@ -657,7 +643,7 @@ static size_t chunk_budget() {
 }
 
 struct infl_ws {
-    float *Xp, *Sp, *S2p;  // FULL / SPARSE: perturbed feature rows, their S1 rows; FULL: per-probe S2
+    float *Sp, *S2p;       // FULL / SPARSE: S1 rows of the perturbed probes; FULL: per-probe S2
     float *slabs;          // FULL / SPARSE: split-K partials of the perturbed-row GEMM
     float *S2x;            // SPARSE / DELTA: per-item values
     int32_t *off;          // SPARSE / DELTA: item offsets [chunk + 1]
@@ -671,8 +657,8 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
     const size_t maxc = (size_t)(b->g->max_col_nnz > 0 ? b->g->max_col_nnz : 1);
     size_t per_probe = 0;
     const size_t splitk = ((F + LT_KSLICE_PROBE - 1) / LT_KSLICE_PROBE) * (size_t)b->H;
-    if (mode == LT_MODE_FULL) per_probe = (n * C + F + Hp + splitk) * sizeof(float) + n;
-    else if (mode == LT_MODE_SPARSE) per_probe = (maxc * C + F + Hp + splitk) * sizeof(float) + sizeof(int32_t);
+    if (mode == LT_MODE_FULL) per_probe = (n * C + Hp + splitk) * sizeof(float);
+    else if (mode == LT_MODE_SPARSE) per_probe = (maxc * C + Hp + splitk) * sizeof(float) + sizeof(int32_t);
     else per_probe = maxc * C * sizeof(float) + sizeof(int32_t);
     size_t chunk = chunk_budget() / (per_probe ? per_probe : 1);
     if (chunk < 1) chunk = 1;
@@ -687,7 +673,6 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
         return q;
     };
     if (mode == LT_MODE_FULL || mode == LT_MODE_SPARSE) {
-        w.Xp = (float *)take(chunk * F * sizeof(float));
         w.Sp = (float *)take(chunk * Hp * sizeof(float));
         w.slabs = (float *)take(lt_gemm_splitk_slab_bytes((int)chunk, b->H, b->F, LT_KSLICE_PROBE));
     }
@@ -739,12 +724,10 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
 
         if (mode != LT_MODE_DELTA) {
             // perturbed rows and their S1 rows: Sp = (X[v] + X[v]*d) W1            attacker.py:101-105
-            { lt_prof_scope prof_(LT_K_PERTURB, st);
-            hipLaunchKernelGGL(k_perturb_rows, dim3((b->F + 255) / 256, nb), dim3(256), 0, st, b->X,
-                               (long)b->ldx, b->F, probes, delta, w.Xp); }
-            LT_CHECK_LAUNCH();
             if (Hp != b->H) LT_HIP(hipMemsetAsync(w.Sp, 0, (size_t)nb * Hp * sizeof(float), st));
-            int rc = lt_launch_gemm_splitk(w.Xp, b->F, b->W1, b->H, w.Sp, Hp, nb, b->H, b->F, LT_KSLICE_PROBE, w.slabs, st);
+            // (the GEMM gathers row probes[i] of X and perturbs it while loading: no Xp buffer, no extra kernel)
+            int rc = lt_launch_gemm_splitk(b->X, b->ldx, b->W1, b->H, w.Sp, Hp, nb, b->H, b->F, LT_KSLICE_PROBE, w.slabs, st,
+                                           probes, delta);
             if (rc) return rc;
         }
 

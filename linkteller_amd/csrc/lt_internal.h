@@ -49,8 +49,12 @@ struct lt_baseline {
     float *Z1 = nullptr;   // [n, Hp]  A_hat * S1 + b1   (pre-activation)
     float *S2 = nullptr;   // [n, C]   relu(Z1) * W2
     float *OUT = nullptr;  // [n, C]   A_hat * S2 + b2   (baseline logits)
-    float *b1p = nullptr;  // [Hp]     b1 zero-padded
-    float *W2p = nullptr;  // [Hp, C]  W2 zero-padded rows
+    // b1 [Hp] / W2 [Hp, C] with zero padding up to Hp: the caller's own tensors when H is a multiple of 4 and
+    // b1 is 16-byte aligned (no copy), else the zero-padded copies below (refreshed with the baseline)
+    const float *b1p = nullptr;
+    const float *W2p = nullptr;
+    float *b1p_buf = nullptr;  // [Hp]
+    float *W2p_buf = nullptr;  // [Hp, C]
     float *slabs = nullptr;  // split-K partials of X*W1 (only when F > LT_KSLICE_BASE)
     // optional fp64-accumulated copies for the kink test of LT_MODE_DELTA (lt_baseline_enable_fp64)
     double *S1d = nullptr;      // [n, Hp]
@@ -110,5 +114,7 @@ int lt_launch_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, flo
 #define LT_KSLICE_BASE 400    // fp64 X*W1 of the delta mode (64x64 tiles)
 size_t lt_gemm_splitk_slab_bytes(int M, int N, int K, int kslice);
 int lt_gemm_pick_kslice(int M, int N, int K);   // baseline X*W1: slice length that fills the CUs in whole rounds
+// gather_rows != NULL: row m of the A operand is row gather_rows[m] of A, perturbed by x + x * delta
 int lt_launch_gemm_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
-                          int64_t ldc, int M, int N, int K, int kslice, float *slabs, hipStream_t st);
+                          int64_t ldc, int M, int N, int K, int kslice, float *slabs, hipStream_t st,
+                          const int32_t *gather_rows = nullptr, float delta = 0.f);
