@@ -4,10 +4,12 @@ sys.path.insert(0, '.')
 from linkteller_amd import engine, graph, synth
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 n_test = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+modes = sys.argv[3].split(',') if len(sys.argv) > 3 else ['full', 'sparse', 'delta']
+t0 = time.time()
 adj = synth.rmat_graph(scale, (1 << scale) * 16, seed=42)
 a_hat = graph.first_order_gcn(adj)
 n = adj.shape[0]
-print('n', n, 'nnz', a_hat.nnz, 'max deg', int(np.diff(a_hat.indptr).max()))
+print('n', n, 'nnz', a_hat.nnz, 'max deg', int(np.diff(a_hat.indptr).max()), ' host graph build', round(time.time() - t0, 1), 's')
 x = torch.from_numpy(synth.gaussian_features(n, 256, seed=1)).cuda()
 w = synth.gcn_weights(256, 256, 2, seed=42)
 t0 = time.time()
@@ -16,9 +18,12 @@ torch.cuda.synchronize(); print('baseline create', round(time.time() - t0, 3), '
 np.random.seed(42)
 nodes = np.random.choice(np.arange(n), n_test, replace=False)
 res = {}
-for m in ('full', 'sparse', 'delta'):
+for m in modes:
     base.influence_rows(nodes, nodes, 1e-4, m); torch.cuda.synchronize()
     t0 = time.time(); res[m] = base.influence_rows(nodes, nodes, 1e-4, m); torch.cuda.synchronize()
     print(m, round((time.time() - t0) * 1e3, 3), 'ms')
-print('full == sparse:', bool(torch.equal(res['full'], res['sparse'])), ' max', float(res['delta'].max()),
-      ' |full-delta| max', float((res['full'] - res['delta']).abs().max()))
+if 'full' in res and 'sparse' in res:
+    print('full == sparse:', bool(torch.equal(res['full'], res['sparse'])))
+if 'sparse' in res and 'delta' in res:
+    print('max', float(res['delta'].max()), ' |sparse-delta| max', float((res['sparse'] - res['delta']).abs().max()),
+          ' nonzero pairs', int((res['delta'] > 0).sum()), 'of', res['delta'].numel())
