@@ -122,6 +122,118 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma(const float *__restrict__
 }
 
 
+// ---- 64x64 block tile, 64-deep k-tiles: the probe-row product X'[probes] * W1 (M = probes of a chunk, a
+// few hundred rows) split into 256-deep K slices.  With 16-deep tiles a slice was 16 load -> 8 MFMA -> barrier
+// round trips, each bound by the latency of its own loads (0.2 us of MFMAs against > 1 us of latency: 16-20 us
+// per call); a 64-deep tile carries 32 MFMAs per wave (0.85 us) behind one round of loads, the next tile's
+// loads are in flight meanwhile, and a slice is 4 trips.  Requires N % 64 == 0 (full B tiles); rows past M
+// are clamped (they feed output rows that are never stored).  Same k-ordered chains, same bits.
+#define GD_BK 64
+#define GD_LDA (GD_BK + 1)
+#define GD_PASS 4   // 256 threads x float4 cover 16 rows x 64 floats per pass
+template <bool GATHER>
+__global__ __launch_bounds__(256) void k_gemm_f32_mfma_deep(const float *__restrict__ A, long lda,
+                                                            const float *__restrict__ B, long ldb,
+                                                            float *__restrict__ C, long ldc, int M, int N,
+                                                            int K, int kslice, long slab_stride,
+                                                            const int32_t *__restrict__ rows, float delta) {
+    __shared__ __attribute__((aligned(16))) float As[2][GM_BM * GD_LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GD_BK * GM_BN];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int m0 = blockIdx.x * GM_BM, n0 = blockIdx.y * GM_BN;
+    const int kb = blockIdx.z * kslice, ke = min(K, kb + kslice);
+    C += (long)blockIdx.z * slab_stride;
+
+    // staging: thread -> row t_row (+16 per pass), 4 floats at t_col, for both the A tile (64 x 64) and the
+    // B tile (64 x 64)
+    const int t_row = tid >> 4, t_col = (tid & 15) * 4;
+    const float *a_ptr[GD_PASS], *b_ptr[GD_PASS];
+#pragma unroll
+    for (int p = 0; p < GD_PASS; ++p) {
+        const int m = min(m0 + t_row + 16 * p, M - 1);
+        const long src = GATHER ? (long)rows[m] : (long)m;
+        a_ptr[p] = A + src * lda + t_col + kb;
+        b_ptr[p] = B + (long)(kb + t_row + 16 * p) * ldb + n0 + t_col;
+    }
+    const long b_step = (long)GD_BK * ldb;
+    auto perturb = [&](f32x4 v) {
+        if (GATHER) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = __fadd_rn(v[j], __fmul_rn(v[j], delta));   // two roundings, no fma
+        }
+        return v;
+    };
+    f32x4 ra[GD_PASS], rb[GD_PASS];
+    auto load_full = [&]() {      // the next k-tile, all of it inside [kb, ke)
+#pragma unroll
+        for (int p = 0; p < GD_PASS; ++p) {
+            ra[p] = *reinterpret_cast<const f32x4u *>(a_ptr[p]);
+            rb[p] = *reinterpret_cast<const f32x4u *>(b_ptr[p]);
+            a_ptr[p] += GD_BK;
+            b_ptr[p] += b_step;
+        }
+    };
+    auto load_tail = [&](int k0) {      // the slice's last, partial k-tile: zero-filled past ke
+#pragma unroll
+        for (int p = 0; p < GD_PASS; ++p) {
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k0 + t_col + j < ke) r[j] = a_ptr[p][j];
+            ra[p] = r;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (k0 + t_row + 16 * p < ke) t = *reinterpret_cast<const f32x4u *>(b_ptr[p]);
+            rb[p] = t;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < GD_PASS; ++p) {
+            const f32x4 v = perturb(ra[p]);
+            float *as = &As[buf][(t_row + 16 * p) * GD_LDA + t_col];
+            as[0] = v.x; as[1] = v.y; as[2] = v.z; as[3] = v.w;
+            *reinterpret_cast<f32x4 *>(&Bs[buf][(t_row + 16 * p) * GM_BN + t_col]) = rb[p];
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int a_frag = (wr * 32 + (lane & 31)) * GD_LDA + (lane >> 5);
+    const int b_frag = (lane >> 5) * GM_BN + wc * 32 + (lane & 31);
+    auto multiply = [&](int buf) {
+        const float *as = &As[buf][a_frag];
+        const float *bs = &Bs[buf][b_frag];
+#pragma unroll
+        for (int kk = 0; kk < GD_BK; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[kk], bs[kk * GM_BN], acc, 0, 0, 0);
+    };
+    const int nfull = (ke - kb) / GD_BK;
+    const bool partial = (ke - kb) % GD_BK != 0;
+    const int nk = nfull + (partial ? 1 : 0);
+    auto load_any = [&](int t) { if (t < nfull) load_full(); else load_tail(kb + t * GD_BK); };
+    if (nk > 0) {
+        load_any(0);
+        store_tiles(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) load_any(kt + 1);
+            multiply(buf);
+            if (kt + 1 < nk) store_tiles(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int cn = n0 + wc * 32 + (lane & 31);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int cm = m0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (cm < M) C[(long)cm * ldc + cn] = acc[reg];
+    }
+}
+
+
 // ---- 128x128 block tile: each of the 4 waves owns a 64x64 quadrant = 2x2 MFMA tiles, so one A and
 // one B fragment feed two MFMAs each (half the LDS reads per flop of the 64x64 kernel) and a k-tile
 // carries 32 MFMAs per wave (2048 cycles).  Global loads run two k-tiles ahead of the LDS stores in two
@@ -366,6 +478,12 @@ int lt_launch_gemm_splitk(const float *A, int64_t lda, const float *B, int64_t l
         if (big)
             hipLaunchKernelGGL(k_gemm_f32_mfma_128, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, dst, ldd,
                                M, N, K, kslice, stride);
+        else if (N % GM_BN == 0 && gather_rows)
+            hipLaunchKernelGGL(k_gemm_f32_mfma_deep<true>, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, dst,
+                               ldd, M, N, K, kslice, stride, gather_rows, delta);
+        else if (N % GM_BN == 0)
+            hipLaunchKernelGGL(k_gemm_f32_mfma_deep<false>, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, dst,
+                               ldd, M, N, K, kslice, stride, (const int32_t *)nullptr, 0.f);
         else if (gather_rows)
             hipLaunchKernelGGL(k_gemm_f32_mfma<true>, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, dst, ldd,
                                M, N, K, kslice, stride, gather_rows, delta);
