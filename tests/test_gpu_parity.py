@@ -410,3 +410,35 @@ def test_full_size_twitch_ru(gpu, n_test, served):
     assert np.abs(res["delta"][sample] - ref64).max() <= 1e-5 * ref64.max()
     assert np.abs(res["full"][sample] - ref64).max() <= 3.0 * e32 + 1e-4 * ref64.max()
     assert np.all(res["full"][sample][ref64 == 0] == 0)
+
+
+@pytest.mark.parametrize("p", [8, 16, 32])
+def test_every_probes_per_wave_variant(gpu, p, tmp_path):
+    """The wide stage-A kernel exists for 8, 16 and 32 probes per wave (picked from the probe count); each,
+    pinned through LT_FULL_P in a fresh process, must give the bits of `sparse` on a graph with hub rows, for
+    probe counts that leave partial groups."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import numpy as np, torch
+        from linkteller_amd import engine, graph, synth
+        adj = synth.powerlaw_graph(700, 4000, seed=5)
+        a_hat = graph.first_order_gcn(adj)
+        n = adj.shape[0]
+        x = synth.gaussian_features(n, 96, seed=2)
+        w = synth.gcn_weights(96, 256, 2, seed=3)
+        dev = torch.device("cuda", 0)
+        base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(dev),
+                               *[torch.from_numpy(w[k]).to(dev) for k in ("W1", "b1", "W2", "b2")])
+        rng = np.random.RandomState(1)
+        for n_probe in (1, 7, 33, 77):
+            probes = rng.choice(n, n_probe, replace=False)
+            obs = rng.choice(n, 150, replace=False)
+            f = base.influence_rows(probes, obs, 1e-4, "full").cpu().numpy()
+            s = base.influence_rows(probes, obs, 1e-4, "sparse").cpu().numpy()
+            assert np.array_equal(f, s), n_probe
+            assert np.isfinite(f).all() and f.max() > 0
+        print("ok")
+    ''')
+    env = dict(os.environ, LT_FULL_P=str(p), PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
