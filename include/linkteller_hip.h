@@ -102,11 +102,15 @@ int lt_baseline_create(const lt_graph *g, const float *X, int64_t ldx, int32_t F
                        const float *W2, const float *b2, int32_t C,
                        void *stream, lt_baseline **out);
 /* Adds an fp64-accumulated copy of the pre-activation Z1 (one more X*W1 on the f64 matrix cores +
- * one fp64 SpMM; kept up to date by lt_baseline_refresh).  LT_MODE_DELTA then evaluates the ReLU kink
+ * one fp64 SpMM; redone after every lt_baseline_refresh when next needed).  LT_MODE_DELTA then evaluates the ReLU kink
  * test on it, which is what brings it within 1e-6 of an fp64 run of the reference; without it the
  * delta mode still works but entries that cross a kink carry ~1e-4 relative error. */
 int lt_baseline_enable_fp64(lt_baseline *b, void *stream);
-/* recompute the four buffers in place (same pointers, e.g. once per benchmark step) */
+/* Re-reads X and the weights (same pointers; e.g. once per benchmark step): S1 = X*W1 is recomputed on
+ * `stream` now; Z1 / S2 / OUT (and the fp64 Z1) are marked stale and recomputed by the first call that reads
+ * them -- lt_baseline_logits, LT_MODE_SPARSE / LT_MODE_DELTA rows -- on THAT call's stream, so a caller that
+ * uses several streams orders them itself.  LT_MODE_FULL rows never need them: their stage A yields the
+ * unperturbed layer as a by-product and stage B forms the baseline logits of the observed nodes itself. */
 int lt_baseline_refresh(lt_baseline *b, void *stream);
 int lt_baseline_destroy(lt_baseline *b);
 /* copies the baseline logits OUT [n, C] (dense, ld = C) to a device buffer */

@@ -362,14 +362,29 @@ extern "C" int lt_baseline_refresh(lt_baseline *b, void *stream) {
     LT_REQUIRE(b != nullptr, "lt_baseline_refresh: baseline is NULL");
     hipStream_t st = (hipStream_t)stream;
     if (b->n == 0) return LT_OK;
-    int rc = prepare_layer_inputs(b->n, b->X, b->ldx, b->F, b->W1, b->b1, b->H, b->W2, b->C, b->S1,
-                                  b->b1p_buf, b->W2p_buf, &b->b1p, &b->W2p, b->slabs, st);
-    if (rc) return rc;
-    rc = lt_launch_layer1(b->g, b->S1, b->Hp, b->b1p, b->W2p, b->C, b->Z1, b->S2, st);
-    if (rc) return rc;
-    rc = lt_launch_layer2(b->g, b->S2, b->C, b->b2, b->OUT, st);
-    if (rc) return rc;
-    return lt_baseline_refresh_fp64(b, st);
+    b->layers_fresh = false;
+    b->fp64_fresh = false;
+    return prepare_layer_inputs(b->n, b->X, b->ldx, b->F, b->W1, b->b1, b->H, b->W2, b->C, b->S1,
+                                b->b1p_buf, b->W2p_buf, &b->b1p, &b->W2p, b->slabs, st);
+}
+
+// Z1 / S2 / OUT (and the fp64 pre-activation when enabled and asked for) from the current S1, if stale
+int lt_baseline_ensure_layers(const lt_baseline *cb, bool need_fp64, hipStream_t st) {
+    lt_baseline *b = const_cast<lt_baseline *>(cb);   // cache state only: logically const for the caller
+    if (b->n == 0) return LT_OK;
+    if (!b->layers_fresh) {
+        int rc = lt_launch_layer1(b->g, b->S1, b->Hp, b->b1p, b->W2p, b->C, b->Z1, b->S2, st);
+        if (rc) return rc;
+        rc = lt_launch_layer2(b->g, b->S2, b->C, b->b2, b->OUT, st);
+        if (rc) return rc;
+        b->layers_fresh = true;
+    }
+    if (need_fp64 && b->Z1d && !b->fp64_fresh) {
+        const int rc = lt_baseline_refresh_fp64(b, st);
+        if (rc) return rc;
+        b->fp64_fresh = true;
+    }
+    return LT_OK;
 }
 
 extern "C" int lt_baseline_create(const lt_graph *g, const float *X, int64_t ldx, int32_t F,
@@ -421,6 +436,8 @@ extern "C" int lt_baseline_destroy(lt_baseline *b) {
 extern "C" int lt_baseline_logits(const lt_baseline *b, float *dst, void *stream) {
     LT_REQUIRE(b != nullptr && dst != nullptr, "lt_baseline_logits: NULL argument");
     if (b->n == 0) return LT_OK;
+    const int rc = lt_baseline_ensure_layers(b, false, (hipStream_t)stream);
+    if (rc) return rc;
     LT_HIP(hipMemcpyAsync(dst, b->OUT, (size_t)b->n * b->C * sizeof(float), hipMemcpyDeviceToDevice,
                           (hipStream_t)stream));
     return LT_OK;

@@ -189,7 +189,9 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     LT_HIP(hipMalloc((void **)&b->S1d, nh));
     LT_HIP(hipMalloc((void **)&b->Z1d, nh));
     if (splits > 1) LT_HIP(hipMalloc((void **)&b->slabs_d, (size_t)splits * (b->n > 0 ? b->n : 1) * b->H * sizeof(double)));
-    return compute_z1d(b, (hipStream_t)stream);
+    const int rc = compute_z1d(b, (hipStream_t)stream);
+    b->fp64_fresh = rc == LT_OK;
+    return rc;
 }
 
 void lt_baseline_free_fp64(lt_baseline *b) {

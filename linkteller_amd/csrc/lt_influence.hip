@@ -48,8 +48,10 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_stageA(
     const int coff = 4 * gl;
     const bool active = coff < Hp;
     const f32x4 b1v = active ? ld4(b1p + coff) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 acc = row_dot(col, val, rowptr[r], rowptr[r + 1], S1, Hp, coff, active, probes[b],
-                              Sp + (size_t)b * Hp, b1v);
+    // grid.y = probes + 1: the last column is the unperturbed layer (the baseline S2 stage B differences against)
+    const int nbq = (int)gridDim.y - 1;
+    const f32x4 acc = row_dot(col, val, rowptr[r], rowptr[r + 1], S1, Hp, coff, active, b < nbq ? probes[b] : -1,
+                              Sp + (size_t)(b < nbq ? b : 0) * Hp, b1v);
     float part[CP];
 #pragma unroll
     for (int c = 0; c < CP; ++c) part[c] = 0.f;
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_stageA(
 #pragma unroll
     for (int c = 0; c < CP; ++c) part[c] = group_sum<LPR>(part[c]);
     if (gl == 0) {
-        float *dst = S2p + ((size_t)r * gridDim.y + b) * C;   // [row][probe][class]
+        float *dst = S2p + ((size_t)r * gridDim.y + b) * C;   // [row][probe | baseline][class]
 #pragma unroll
         for (int c = 0; c < CP; ++c)
             if (c < C) dst[c] = part[c];
@@ -90,7 +92,8 @@ __device__ __forceinline__ float relu1(float x) {
 template <int CP, int P>
 __device__ __forceinline__ void stageA_epilogue(f32x4 (&acc)[P], int lane, bool active, int coff,
                                                 const float *__restrict__ W2p, int C, int n, int nb,
-                                                int r, int pb, float *__restrict__ S2p, unsigned skip) {
+                                                int r, int pb, float *__restrict__ S2p, unsigned skip,
+                                                int base_p) {
     float w2[4 * CP];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -143,8 +146,12 @@ __device__ __forceinline__ void stageA_epilogue(f32x4 (&acc)[P], int lane, bool 
         const int q = j * VB + lane_totals_owner<VB>(lane);
         const int p = q / CP, c = q % CP;
         const bool owner = (lane & (64 / VB - 1)) == 0;
-        // `skip`: probes (bits) whose entries someone else writes (the ring kernel's substituted recomputation)
-        if (owner && c < C && pb + p < nb && !((skip >> (p & 31)) & 1u)) S2p[((size_t)r * nb + pb + p) * C + c] = z;   // [row][probe][class]
+        // S2p is [row][nb probes | baseline][class].  `skip`: probes (bits) whose entries the wave rewrites itself
+        // (substituted recomputation); `base_p`: a probe of this wave whose chain met no substitution, i.e. IS the
+        // unperturbed layer -- its totals also go to the baseline column (or -1)
+        float *rowp = S2p + (size_t)r * (nb + 1) * C;
+        if (owner && c < C && pb + p < nb && !((skip >> (p & 31)) & 1u)) rowp[(size_t)(pb + p) * C + c] = z;
+        if (owner && c < C && p == base_p) rowp[(size_t)nb * C + c] = z;
     }
 }
 
@@ -329,15 +336,27 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
     // The epilogue leaves those out, and the wave recomputes them here, one single-probe chain each (row_dot
     // + relu_w2_partial + group_sum, the chain every other kernel uses), with its accumulators dead and the
     // row's S1 lines still warm in L1/L2.  Keeping the select path out of the hot loop is worth 50 VGPRs.
-    stageA_epilogue<CP, P>(acc, lane, active, coff, W2p, C, n, nb, r, pb, S2p, hitmask);
-    if (__builtin_expect(hitmask != 0u, 0)) {
+    // group 0 also delivers the baseline column: any of its probes that met no substitution
+    const int nvalid = min(nb - pb, P);
+    const unsigned valid = nvalid >= 32 ? 0xffffffffu : ((1u << nvalid) - 1u);
+    const unsigned clean = ~hitmask & valid;
+    const int base_p = (pb == 0 && clean != 0u) ? __builtin_ctz(clean) : -1;
+    stageA_epilogue<CP, P>(acc, lane, active, coff, W2p, C, n, nb, r, pb, S2p, hitmask, base_p);
+    const bool base_redo = pb == 0 && clean == 0u;   // every probe of group 0 sits on this row: recompute it plainly
+    if (__builtin_expect(hitmask != 0u || base_redo, 0)) {
         const f32x4 b1r = ld4(b1p + coff);
         unsigned m = hitmask;
-        while (m) {
-            const int p = __builtin_ctz(m);
-            m &= m - 1;
-            const int v = probes[pb + p];
-            const f32x4 z = row_dot(col, val, e0, e1, S1, Hp, coff, true, v, Sp + (size_t)(pb + p) * Hp, b1r);
+        bool do_base = base_redo;
+        while (m || do_base) {
+            int p = -1, v = -1;
+            if (m) {
+                p = __builtin_ctz(m);
+                m &= m - 1;
+                v = probes[pb + p];
+            } else {
+                do_base = false;
+            }
+            const f32x4 z = row_dot(col, val, e0, e1, S1, Hp, coff, true, v, Sp + (size_t)(pb + (p < 0 ? 0 : p)) * Hp, b1r);
             float part[CP];
 #pragma unroll
             for (int c = 0; c < CP; ++c) part[c] = 0.f;
@@ -345,9 +364,10 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
 #pragma unroll
             for (int c = 0; c < CP; ++c) part[c] = group_sum<64>(part[c]);
             if (lane == 0) {
+                float *dst = S2p + ((size_t)r * (nb + 1) + (p < 0 ? nb : pb + p)) * C;
 #pragma unroll
                 for (int c = 0; c < CP; ++c)
-                    if (c < C) S2p[((size_t)r * nb + pb + p) * C + c] = part[c];
+                    if (c < C) dst[c] = part[c];
             }
         }
     }
@@ -371,16 +391,18 @@ __device__ __forceinline__ float diff_norm(const float (&acc)[CP], const float *
     return sqrtf(ss);
 }
 
-// FULL stage B: a wave = one observed node x 64 probes (lane = probe).  S2p is [row][probe][class],
+// FULL stage B: a wave = one observed node x 64 probes (lane = probe).  S2p is [row][probe | baseline][class],
 // so every CSR entry of the observed row is one coalesced 64 x C x 4-byte load; (col, val) are
 // wave-uniform scalars.  The sum is formed exactly as row2_dot forms it -- 8 interleaved partial
 // chains (entry e goes to chain (e - e0) & 7) combined as ((p0+p4)+(p2+p6))+((p1+p5)+(p3+p7)), the
-// xor 4,2,1 butterfly -- so the bits equal the baseline's layer-2 kernel.
+// xor 4,2,1 butterfly -- so the bits equal the baseline's layer-2 kernel.  The baseline logits of the
+// observed node come from the same walk over the baseline column (wave-uniform loads): FULL mode needs
+// neither k_layer1 nor k_layer2.
 template <int CP>
 __global__ __launch_bounds__(64) void k_full_stageB(
     int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ S2p, int C,
-    const float *__restrict__ b2, const float *__restrict__ OUT,
+    const float *__restrict__ b2,
     const int32_t *__restrict__ observe, int n_obs, int nb, float delta, float *__restrict__ out,
     long ldo) {
     const int pblocks = (nb + 63) >> 6;
@@ -389,32 +411,40 @@ __global__ __launch_bounds__(64) void k_full_stageB(
     const int u = observe[j];
     const int e0 = rowptr[u], e1 = rowptr[u + 1];
     const bool live = b < nb;
+    const size_t rstride = (size_t)(nb + 1) * C;
     const float *T = S2p + (size_t)(live ? b : 0) * C;
-    const size_t rstride = (size_t)nb * C;
-    float part[LT_L2_LANES][CP];
+    const float *Tb = S2p + (size_t)nb * C;
+    float part[LT_L2_LANES][CP], pbase[LT_L2_LANES][CP];
 #pragma unroll
     for (int q = 0; q < LT_L2_LANES; ++q)
 #pragma unroll
-        for (int c = 0; c < CP; ++c) part[q][c] = 0.f;
+        for (int c = 0; c < CP; ++c) part[q][c] = pbase[q][c] = 0.f;
     for (int e = e0; e < e1; e += LT_L2_LANES) {
 #pragma unroll
         for (int q = 0; q < LT_L2_LANES; ++q)
             if (e + q < e1) {
                 const float a = val[e + q];
-                const float *t = T + (size_t)col[e + q] * rstride;
+                const size_t ro = (size_t)col[e + q] * rstride;
+                const float *t = T + ro, *tb = Tb + ro;
 #pragma unroll
                 for (int c = 0; c < CP; ++c)
-                    if (c < C) part[q][c] = fmaf(a, t[c], part[q][c]);
+                    if (c < C) {
+                        part[q][c] = fmaf(a, t[c], part[q][c]);
+                        pbase[q][c] = fmaf(a, tb[c], pbase[q][c]);
+                    }
             }
     }
-    float acc[CP];
+    float acc[CP], base[CP];
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
         const float t0 = part[0][c] + part[4][c], t1 = part[1][c] + part[5][c];
         const float t2 = part[2][c] + part[6][c], t3 = part[3][c] + part[7][c];
         acc[c] = (t0 + t2) + (t1 + t3);
+        const float u0 = pbase[0][c] + pbase[4][c], u1 = pbase[1][c] + pbase[5][c];
+        const float u2 = pbase[2][c] + pbase[6][c], u3 = pbase[3][c] + pbase[7][c];
+        base[c] = c < C ? ((u0 + u2) + (u1 + u3)) + b2[c] : 0.f;   // = OUT[u] of k_layer2, bit for bit
     }
-    if (live) out[(long)b * ldo + j] = diff_norm<CP>(acc, b2, OUT + (size_t)u * C, C, delta);
+    if (live) out[(long)b * ldo + j] = diff_norm<CP>(acc, b2, base, C, delta);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -662,7 +692,7 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
     else per_probe = maxc * C * sizeof(float) + sizeof(int32_t);
     size_t chunk = chunk_budget() / (per_probe ? per_probe : 1);
     if (chunk < 1) chunk = 1;
-    if (chunk > 65535) chunk = 65535;  // grid.y
+    if (chunk > 65534) chunk = 65534;  // grid.y (FULL, narrow kernel: probes + 1)
     if (chunk > (size_t)(n_probe > 0 ? n_probe : 1)) chunk = (size_t)(n_probe > 0 ? n_probe : 1);
     w.chunk = (int)chunk;
     size_t offb = 0;
@@ -677,7 +707,7 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
         w.slabs = (float *)take(lt_gemm_splitk_slab_bytes((int)chunk, b->H, b->F, LT_KSLICE_PROBE));
     }
     if (mode == LT_MODE_FULL) {
-        w.S2p = (float *)take(chunk * n * C * sizeof(float));
+        w.S2p = (float *)take((chunk + 1) * n * C * sizeof(float));   // + the baseline column
     }
     if (mode != LT_MODE_FULL) {
         w.S2x = (float *)take(chunk * maxc * C * sizeof(float));
@@ -714,6 +744,12 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
     const lt_graph *g = b->g;
     const infl_ws w = carve_infl(workspace, b, n_probe, mode);
     const int lpr = lt_lpr_for(b->Hp), cp = lt_cp_for(b->C), C = b->C, Hp = b->Hp, n = b->n;
+    // SPARSE / DELTA read the baseline activations (Z1, S2, OUT; DELTA the fp64 Z1 when enabled); FULL forms
+    // what it needs of them itself
+    if (mode != LT_MODE_FULL) {
+        const int rc = lt_baseline_ensure_layers(b, mode == LT_MODE_DELTA, st);
+        if (rc) return rc;
+    }
 
     for (int p0 = 0; p0 < n_probe; p0 += w.chunk) {
         const int nb = (n_probe - p0) < w.chunk ? (n_probe - p0) : w.chunk;
@@ -751,7 +787,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
 #undef LT_RING_LAUNCH
             } else {
                 const int rpb = (LT_BLOCK / 64) * (64 / lpr);
-                dim3 grid((n + rpb - 1) / rpb, nb);
+                dim3 grid((n + rpb - 1) / rpb, nb + 1);   // + the baseline column
                 LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
                     hipLaunchKernelGGL((k_full_stageA<LPR_, CP_>), grid, dim3(LT_BLOCK), 0, st, n,
                                        g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p, C, probes,
@@ -761,7 +797,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
             { lt_prof_scope prof_(LT_K_FULL_B, st);
             const unsigned gridB2 = (unsigned)(((nb + 63) / 64) * (long)n_obs);
             LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageB<CP_>), dim3(gridB2), dim3(64), 0, st, n,
-                                                   g->rowptr, g->col, g->val, w.S2p, C, b->b2, b->OUT,
+                                                   g->rowptr, g->col, g->val, w.S2p, C, b->b2,
                                                    observe_nodes, n_obs, nb, delta, orow, (long)ldo)); }
             LT_CHECK_LAUNCH();
         } else {

@@ -60,6 +60,11 @@ struct lt_baseline {
     double *S1d = nullptr;      // [n, Hp]
     double *Z1d = nullptr;      // [n, Hp]
     double *slabs_d = nullptr;  // split-K partials
+    // lt_baseline_refresh recomputes S1 and marks what depends on it stale; Z1 / S2 / OUT (and Z1d) are
+    // recomputed by the first call that reads them (logits, SPARSE / DELTA rows) -- FULL rows never do: their
+    // stage A yields the baseline S2 as a by-product and stage B forms the baseline logits itself.
+    mutable bool layers_fresh = false;
+    mutable bool fp64_fresh = false;
 };
 
 int lt_set_error(int code, const char *fmt, ...);
@@ -99,6 +104,7 @@ struct lt_prof_scope {
 };
 
 int lt_baseline_refresh_fp64(lt_baseline *b, hipStream_t st);
+int lt_baseline_ensure_layers(const lt_baseline *b, bool need_fp64, hipStream_t st);
 void lt_baseline_free_fp64(lt_baseline *b);
 
 // ---- launchers implemented in the kernel translation units --------------------------------

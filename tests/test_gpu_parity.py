@@ -442,3 +442,35 @@ def test_every_probes_per_wave_variant(gpu, p, tmp_path):
     env = dict(os.environ, LT_FULL_P=str(p), PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_row_that_contains_every_probe(gpu):
+    """A hub row adjacent to every probe of the first probe group: in FULL mode no chain of that wave is the
+    unperturbed one, so the baseline value of the row takes the explicit recomputation path.  Star + ring graph,
+    probes = leaves only, observed = everything (the hub included)."""
+    import scipy.sparse as sp
+    from linkteller_amd import engine, graph, synth
+    n = 90
+    rows = np.concatenate([np.zeros(n - 1, int), np.arange(1, n)])
+    cols = np.concatenate([np.arange(1, n), np.roll(np.arange(1, n), 1)])
+    a = sp.coo_matrix((np.ones(len(rows), np.float32), (rows, cols)), shape=(n, n)).tocsr()
+    a = ((a + a.T) > 0).astype(np.float32).tocsr()
+    a_hat = graph.first_order_gcn(a)
+    x = synth.gaussian_features(n, 24, seed=4)
+    w = synth.gcn_weights(24, 256, 2, seed=6)
+    base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu),
+                           *[torch.from_numpy(w[k]).to(gpu) for k in ("W1", "b1", "W2", "b2")])
+    observe = np.arange(n)
+    for probes in (np.arange(1, 6), np.arange(1, 41), np.array([3]), np.arange(0, 33)):
+        res = {m: base.influence_rows(probes, observe, 1e-4, m).cpu().numpy().astype(np.float64)
+               for m in ("full", "sparse", "delta")}
+        assert np.array_equal(res["full"], res["sparse"])
+        ref64 = _oracle_matrix(a_hat, x, w, probes, observe, 1e-4, torch.float64)
+        ref32 = _oracle_matrix(a_hat, x, w, probes, observe, 1e-4, torch.float32)
+        assert np.abs(res["delta"] - ref64).max() <= 1e-5 * ref64.max()
+        assert np.abs(res["full"] - ref64).max() <= 3.0 * np.abs(ref32 - ref64).max() + 1e-4 * ref64.max()
+    logits = base.logits().cpu().numpy()
+    from oracle import linkteller_oracle as O
+    ref_logits = O.gcn_forward(torch.from_numpy(x).double(), O.to_torch_sparse(a_hat).double(),
+                               {k: torch.from_numpy(w[k]).double() for k in ("W1", "b1", "W2", "b2")}).numpy()
+    assert np.abs(logits - ref_logits).max() <= 2e-5 * np.abs(ref_logits).max() + 1e-6
