@@ -44,6 +44,10 @@ static void free_graph(lt_graph *g) {
     (void)hipFree(g->lseg_long);
     (void)hipFree(g->lseg_begin);
     (void)hipFree(g->seg_scratch);
+    (void)hipFree(g->p_long_row);
+    (void)hipFree(g->p_long_segptr);
+    (void)hipFree(g->p_seg_long);
+    (void)hipFree(g->p_seg_begin);
     delete g;
 }
 
@@ -156,6 +160,32 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
             G_HIP(hipMemcpy(g->lseg_long, slong.data(), slong.size() * sizeof(int32_t), hipMemcpyHostToDevice));
             G_HIP(hipMemcpy(g->lseg_begin, sbeg.data(), sbeg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
             G_HIP(hipMalloc((void **)&g->seg_scratch, (size_t)g->n_lseg * LT_MAX_H * sizeof(float)));
+        }
+    }
+    // the same table at LT_ROW_SEG for the layer-1 / probe kernels
+    {
+        std::vector<int32_t> lrow, lptr(1, 0), slong, sbeg;
+        for (int32_t r = 0; r < n; ++r) {
+            if (rowptr[r + 1] - rowptr[r] <= LT_ROW_SEG) continue;
+            const int32_t li = (int32_t)lrow.size();
+            lrow.push_back(r);
+            for (int32_t b = rowptr[r]; b < rowptr[r + 1]; b += LT_ROW_SEG) {
+                slong.push_back(li);
+                sbeg.push_back(b);
+            }
+            lptr.push_back((int32_t)sbeg.size());
+        }
+        g->p_n_long = (int32_t)lrow.size();
+        g->p_n_seg = (int32_t)sbeg.size();
+        if (g->p_n_long > 0) {
+            G_HIP(hipMalloc((void **)&g->p_long_row, lrow.size() * sizeof(int32_t)));
+            G_HIP(hipMalloc((void **)&g->p_long_segptr, lptr.size() * sizeof(int32_t)));
+            G_HIP(hipMalloc((void **)&g->p_seg_long, slong.size() * sizeof(int32_t)));
+            G_HIP(hipMalloc((void **)&g->p_seg_begin, sbeg.size() * sizeof(int32_t)));
+            G_HIP(hipMemcpy(g->p_long_row, lrow.data(), lrow.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            G_HIP(hipMemcpy(g->p_long_segptr, lptr.data(), lptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            G_HIP(hipMemcpy(g->p_seg_long, slong.data(), slong.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            G_HIP(hipMemcpy(g->p_seg_begin, sbeg.data(), sbeg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         }
     }
 #undef G_HIP

@@ -180,32 +180,54 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int CP, int P>
+// Long rows (more than LT_ROW_SEG entries: hubs) do not run as one wave per probe group: the SEG instantiation
+// takes one SEGMENT of a long row per block (same walk, over LT_ROW_SEG entries, the chains of a non-first
+// segment starting from +0) and leaves the P (+1 baseline) segment sums in `lpart`; k_full_long_combine adds
+// them in segment order -- row_dot's canonical order -- and runs the epilogue.  The plain instantiation skips
+// the long rows.
+template <int CP, int P, bool SEG>
 __global__ __launch_bounds__(64) void k_full_stageA_lds(
     int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ S1, int Hp,
     const float *__restrict__ b1p, const float *__restrict__ W2p, int C,
     const int32_t *__restrict__ probes, int nb, const float *__restrict__ Sp,
-    float *__restrict__ S2p) {
+    float *__restrict__ S2p, int n_segblocks, const int32_t *__restrict__ seg_long,
+    const int32_t *__restrict__ seg_begin, const int32_t *__restrict__ long_row,
+    float *__restrict__ lpart) {
     static_assert((P * CP) % 4 == 0, "P*CP must be a multiple of 4");
     __shared__ __attribute__((aligned(16))) float ring[LT_RING_SLOTS * 256];
     const int lane = threadIdx.x;
     const int groups = (nb + P - 1) / P;
-    const int pb = (blockIdx.x % groups) * P;
-    const int rbase = (blockIdx.x / groups) * LT_RING_ROWS;
-  for (int rr = 0; rr < LT_RING_ROWS; ++rr) {
-    const int r = rbase + rr;
-    if (r >= n) break;
+    constexpr bool segmode = SEG;   // two instantiations: in one kernel the two tails cost 50-100 VGPRs of copies
+    int r, pb, e0, e1, sg = 0;
+    bool first_seg = true;
+    if (segmode) {
+        sg = blockIdx.x / groups;
+        pb = (blockIdx.x % groups) * P;
+        r = long_row[seg_long[sg]];
+        e0 = seg_begin[sg];
+        e1 = min(rowptr[r + 1], e0 + LT_ROW_SEG);
+        first_seg = e0 == rowptr[r];
+    } else {
+        const int bid = blockIdx.x;
+        pb = (bid % groups) * P;
+        r = bid / groups;
+        if (r >= n) return;
+        e0 = rowptr[r];
+        e1 = rowptr[r + 1];
+        if (e1 - e0 > LT_ROW_SEG) return;   // a long row: its segments are the blocks above
+    }
+  {
     const bool active = 4 * lane < Hp;
     const int coff = active ? 4 * lane : Hp - 4;
     int vprobe = (lane < P && pb + lane < nb) ? probes[pb + lane] : -1;
     asm volatile("" : "+v"(vprobe));   // retire this ordinary load before any LDS-DMA is in flight (hipcc would drain vmcnt(0) at its first use)
 
-    // every chain starts from the bias (row_dot's `init`); retired before the DMAs for the same reason
-    f32x4 b1v = ld4(b1p + coff);
+    // every chain starts from the bias (row_dot's `init`; +0 for the later segments of a long row); retired
+    // before the DMAs for the same reason
+    f32x4 b1v = first_seg ? ld4(b1p + coff) : f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("" : "+v"(b1v));
     f32x4 acc[P];   // set by the first entry of the row: acc = fma(a_0, s_0, b1) -- no initialisation pass
-    const int e0 = rowptr[r], e1 = rowptr[r + 1];
     const int deg = e1 - e0;
     const int nh = (deg + 3) >> 2;
     unsigned long long hit = 0ull;
@@ -341,10 +363,31 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
     const unsigned valid = nvalid >= 32 ? 0xffffffffu : ((1u << nvalid) - 1u);
     const unsigned clean = ~hitmask & valid;
     const int base_p = (pb == 0 && clean != 0u) ? __builtin_ctz(clean) : -1;
-    stageA_epilogue<CP, P>(acc, lane, active, coff, W2p, C, n, nb, r, pb, S2p, hitmask, base_p);
     const bool base_redo = pb == 0 && clean == 0u;   // every probe of group 0 sits on this row: recompute it plainly
+    // segment sums go to lpart: slot p < P = probe pb + p, slot P = the unperturbed segment (group 0 only);
+    // uniform slot base + 32-bit lane offset = the saddr store form
+    float *slot_base = segmode ? lpart + ((size_t)(sg * groups + pb / P) * (P + 1)) * Hp : nullptr;
+    if constexpr (!SEG) {
+        stageA_epilogue<CP, P>(acc, lane, active, coff, W2p, C, n, nb, r, pb, S2p, hitmask, base_p);
+    } else {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            if (!((hitmask >> p) & 1u)) {
+                char *sp = reinterpret_cast<char *>(slot_base + (size_t)p * Hp);
+                asm("" : "+s"(sp));
+                *reinterpret_cast<f32x4 *>(sp + lane_off) = acc[p];
+            }
+            if (p == base_p) {
+                char *sp = reinterpret_cast<char *>(slot_base + (size_t)P * Hp);
+                asm("" : "+s"(sp));
+                *reinterpret_cast<f32x4 *>(sp + lane_off) = acc[p];
+            }
+        }
+    }
     if (__builtin_expect(hitmask != 0u || base_redo, 0)) {
-        const f32x4 b1r = ld4(b1p + coff);
+        // the probes that sit on one of the columns walked (and, if no chain of group 0 was clean, the
+        // unperturbed one) get their own single chain: over the row, or over this segment of it
+        const f32x4 b1r = first_seg ? ld4(b1p + coff) : f32x4{0.f, 0.f, 0.f, 0.f};
         unsigned m = hitmask;
         bool do_base = base_redo;
         while (m || do_base) {
@@ -356,18 +399,24 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
             } else {
                 do_base = false;
             }
-            const f32x4 z = row_dot(col, val, e0, e1, S1, Hp, coff, true, v, Sp + (size_t)(pb + (p < 0 ? 0 : p)) * Hp, b1r);
-            float part[CP];
+            // e1 - e0 <= LT_ROW_SEG here, so this is one segment chain (row_dot of a short row is the same thing)
+            const f32x4 z = seg_chain(col, val, e0, e1, S1, Hp, coff, true, v, Sp + (size_t)(pb + (p < 0 ? 0 : p)) * Hp, b1r);
+            if (segmode) {
+                char *sp = reinterpret_cast<char *>(slot_base + (size_t)(p < 0 ? P : p) * Hp);
+                *reinterpret_cast<f32x4 *>(sp + lane_off) = z;
+            } else {
+                float part[CP];
 #pragma unroll
-            for (int c = 0; c < CP; ++c) part[c] = 0.f;
-            if (active) relu_w2_partial<CP>(z, W2p + (size_t)coff * C, C, part);
+                for (int c = 0; c < CP; ++c) part[c] = 0.f;
+                if (active) relu_w2_partial<CP>(z, W2p + (size_t)coff * C, C, part);
 #pragma unroll
-            for (int c = 0; c < CP; ++c) part[c] = group_sum<64>(part[c]);
-            if (lane == 0) {
-                float *dst = S2p + ((size_t)r * (nb + 1) + (p < 0 ? nb : pb + p)) * C;
+                for (int c = 0; c < CP; ++c) part[c] = group_sum<64>(part[c]);
+                if (lane == 0) {
+                    float *dst = S2p + ((size_t)r * (nb + 1) + (p < 0 ? nb : pb + p)) * C;
 #pragma unroll
-                for (int c = 0; c < CP; ++c)
-                    if (c < C) dst[c] = part[c];
+                    for (int c = 0; c < CP; ++c)
+                        if (c < C) dst[c] = part[c];
+                }
             }
         }
     }
@@ -376,6 +425,56 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
 
 // ------------------------------------------------------------------------------------------------
 // shared tail: finite difference + L2 norm of one observed row          attacker.py:105-106,227-229
+// ------------------------------------------------------------------------------------------------
+// FULL stage A, long rows: a wave = (long row, probe group).  Adds the segment sums the segment-mode blocks of
+// k_full_stageA_lds left in `lpart`, in segment order (row_dot's canonical order), then the ordinary epilogue.
+// ------------------------------------------------------------------------------------------------
+template <int CP, int P>
+__global__ __launch_bounds__(64) void k_full_long_combine(
+    int Hp, const float *__restrict__ W2p, int C, int n, int nb, const int32_t *__restrict__ long_row,
+    const int32_t *__restrict__ long_segptr, const float *__restrict__ lpart, float *__restrict__ S2p) {
+    const int lane = threadIdx.x;
+    const int groups = (nb + P - 1) / P;
+    const int li = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int pb = g * P;
+    const int r = long_row[li];
+    const int s0 = long_segptr[li], s1 = long_segptr[li + 1];
+    const bool active = 4 * lane < Hp;
+    const int coff = active ? 4 * lane : Hp - 4;
+    auto slot = [&](int s, int p) {
+        return *reinterpret_cast<const f32x4 *>(lpart + ((size_t)(s * groups + g) * (P + 1) + p) * Hp + coff);
+    };
+    f32x4 acc[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc[p] = slot(s0, p);
+    for (int s = s0 + 1; s < s1; ++s) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const f32x4 t = slot(s, p);
+            acc[p].x += t.x; acc[p].y += t.y; acc[p].z += t.z; acc[p].w += t.w;
+        }
+    }
+    if (g == 0) {   // the unperturbed row: slot P of every segment -> the baseline column
+        f32x4 zb = slot(s0, P);
+        for (int s = s0 + 1; s < s1; ++s) {
+            const f32x4 t = slot(s, P);
+            zb.x += t.x; zb.y += t.y; zb.z += t.z; zb.w += t.w;
+        }
+        float part[CP];
+#pragma unroll
+        for (int c = 0; c < CP; ++c) part[c] = 0.f;
+        if (active) relu_w2_partial<CP>(zb, W2p + (size_t)coff * C, C, part);
+#pragma unroll
+        for (int c = 0; c < CP; ++c) part[c] = group_sum<64>(part[c]);
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < CP; ++c)
+                if (c < C) S2p[((size_t)r * (nb + 1) + nb) * C + c] = part[c];
+        }
+    }
+    stageA_epilogue<CP, P>(acc, lane, active, coff, W2p, C, n, nb, r, pb, S2p, 0u, -1);
+}
+
 // ------------------------------------------------------------------------------------------------
 template <int CP>
 __device__ __forceinline__ float diff_norm(const float (&acc)[CP], const float *__restrict__ b2,
@@ -674,6 +773,7 @@ static size_t chunk_budget() {
 
 struct infl_ws {
     float *Sp, *S2p;       // FULL / SPARSE: S1 rows of the perturbed probes; FULL: per-probe S2
+    float *lpart;          // FULL: segment sums of the long rows [segment][group][P + 1][Hp]
     float *slabs;          // FULL / SPARSE: split-K partials of the perturbed-row GEMM
     float *S2x;            // SPARSE / DELTA: per-item values
     int32_t *off;          // SPARSE / DELTA: item offsets [chunk + 1]
@@ -687,7 +787,8 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
     const size_t maxc = (size_t)(b->g->max_col_nnz > 0 ? b->g->max_col_nnz : 1);
     size_t per_probe = 0;
     const size_t splitk = ((F + LT_KSLICE_PROBE - 1) / LT_KSLICE_PROBE) * (size_t)b->H;
-    if (mode == LT_MODE_FULL) per_probe = (n * C + Hp + splitk) * sizeof(float);
+    const size_t nseg = (size_t)b->g->p_n_seg;
+    if (mode == LT_MODE_FULL) per_probe = (n * C + Hp + splitk) * sizeof(float) + nseg * Hp * sizeof(float) * 9 / 8;
     else if (mode == LT_MODE_SPARSE) per_probe = (maxc * C + Hp + splitk) * sizeof(float) + sizeof(int32_t);
     else per_probe = maxc * C * sizeof(float) + sizeof(int32_t);
     size_t chunk = chunk_budget() / (per_probe ? per_probe : 1);
@@ -708,6 +809,8 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
     }
     if (mode == LT_MODE_FULL) {
         w.S2p = (float *)take((chunk + 1) * n * C * sizeof(float));   // + the baseline column
+        // groups * (P + 1) slots per segment: at most ceil(chunk / 8) * 9 (P = 8), or chunk / 32 * 33 + 33
+        w.lpart = (float *)take(nseg * (((chunk + 7) / 8) * 9 + 33) * Hp * sizeof(float));
     }
     if (mode != LT_MODE_FULL) {
         w.S2x = (float *)take(chunk * maxc * C * sizeof(float));
@@ -773,13 +876,28 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                 const int P = full_probes_per_wave(nb);
                 const long rblocks = (n + LT_RING_ROWS - 1) / LT_RING_ROWS;
                 const int rgroups = (nb + P - 1) / P;
-                LT_REQUIRE(rblocks * rgroups < 2147483647L, "lt_influence_rows: n * probe groups exceeds the grid limit");
+                LT_REQUIRE((rblocks + g->p_n_seg) * rgroups < 2147483647L, "lt_influence_rows: n * probe groups exceeds the grid limit");
                 dim3 gridr((unsigned)(rblocks * rgroups));
+                const int n_segblocks = g->p_n_seg * rgroups;
 #define LT_RING_LAUNCH(P_)                                                                                    \
     do {                                                                                                      \
-        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, P_>), gridr, dim3(64), 0, st, n,        \
+        if (n_segblocks > 0) {   /* hub rows: their segments first, then the sum over segments */            \
+            LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, P_, true>), dim3(n_segblocks),      \
+                                                   dim3(64), 0, st, n, g->rowptr, g->col, g->val, b->S1, Hp,  \
+                                                   b->b1p, b->W2p, C, probes, nb, w.Sp, w.S2p, n_segblocks,   \
+                                                   g->p_seg_long, g->p_seg_begin, g->p_long_row, w.lpart));   \
+            LT_CHECK_LAUNCH();                                                                                \
+            LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_long_combine<CP_, P_>),                             \
+                                                   dim3((unsigned)(g->p_n_long * rgroups)), dim3(64), 0, st,  \
+                                                   Hp, b->W2p, C, n, nb, g->p_long_row, g->p_long_segptr,     \
+                                                   w.lpart, w.S2p));                                          \
+            LT_CHECK_LAUNCH();                                                                                \
+        }                                                                                                     \
+        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, P_, false>), gridr, dim3(64), 0, st, n, \
                                                g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p, C,       \
-                                               probes, nb, w.Sp, w.S2p));                                     \
+                                               probes, nb, w.Sp, w.S2p, 0, (const int32_t *)nullptr,          \
+                                               (const int32_t *)nullptr, (const int32_t *)nullptr,            \
+                                               (float *)nullptr));                                            \
     } while (0)
                 if (P == 8) LT_RING_LAUNCH(8);
                 else if (P == 32) LT_RING_LAUNCH(32);

@@ -32,8 +32,17 @@ struct lt_graph {
     int32_t *lseg_long = nullptr;  // [n_lseg]     index into long_row
     int32_t *lseg_begin = nullptr;  // [n_lseg]     first CSR entry of the segment
     float *seg_scratch = nullptr;  // [n_lseg, LT_MAX_H] partial sums (one stream at a time: handle is not thread-safe)
+    // The same cut at LT_ROW_SEG entries for the layer-1 chains (lt_rows.cuh row_dot): a row longer than that
+    // is summed segment by segment in EVERY kernel, which lets FULL stage A hand the segments of a hub row to
+    // separate waves (k_full_stageA_lds segment mode + k_full_long_combine).
+    int32_t p_n_long = 0, p_n_seg = 0;
+    int32_t *p_long_row = nullptr;     // [p_n_long]     row id
+    int32_t *p_long_segptr = nullptr;  // [p_n_long + 1] first segment of each long row
+    int32_t *p_seg_long = nullptr;     // [p_n_seg]      index into p_long_row
+    int32_t *p_seg_begin = nullptr;    // [p_n_seg]      first CSR entry of the segment
 };
 #define LT_SPMM_SEG 512
+#define LT_ROW_SEG 128   // layer-1 chains: entries per segment (rows up to this length are one plain chain)
 #define LT_CSR_PAD 16   // zero entries appended to col/val
 
 struct lt_baseline {

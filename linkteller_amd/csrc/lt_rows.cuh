@@ -61,12 +61,15 @@ __device__ __forceinline__ void relu_w2_partial(f32x4 z, const float *w2, int C,
 // One CSR row against a dense [*, ld] matrix, 4 columns per lane, accumulated onto `init`.  `subst_col`/`subst_row`:
 // entries whose column equals subst_col read subst_row instead of S (the perturbed S1 row of a
 // probe); pass subst_col = -1 for none.  Pointer select, so the arithmetic is the same chain.
-__device__ __forceinline__ f32x4 row_dot(const int32_t *__restrict__ col,
-                                         const float *__restrict__ val, int e0, int e1,
-                                         const float *__restrict__ S, int ld, int coff,
-                                         bool active, int subst_col,
-                                         const float *__restrict__ subst_row,
-                                         f32x4 init = f32x4{0.f, 0.f, 0.f, 0.f}) {
+//
+// Canonical order: the row is cut into segments of LT_ROW_SEG entries; a segment is one k-ordered fmaf chain
+// (the first starts from `init`, the others from +0) and the segment sums are added in segment order,
+// z = ((seg0 + seg1) + seg2) + ...  A row of up to LT_ROW_SEG entries is therefore one plain chain.  The cut is
+// what lets FULL stage A give the segments of a hub row to different waves and still produce these bits.
+__device__ __forceinline__ f32x4 seg_chain(const int32_t *__restrict__ col, const float *__restrict__ val,
+                                           int e0, int e1, const float *__restrict__ S, int ld, int coff,
+                                           bool active, int subst_col, const float *__restrict__ subst_row,
+                                           f32x4 init) {
     f32x4 acc = init;
     int e = e0;
     for (; e + 4 <= e1; e += 4) {
@@ -94,6 +97,20 @@ __device__ __forceinline__ f32x4 row_dot(const int32_t *__restrict__ col,
         acc = fma4(a, s, acc);
     }
     return acc;
+}
+__device__ __forceinline__ f32x4 row_dot(const int32_t *__restrict__ col,
+                                         const float *__restrict__ val, int e0, int e1,
+                                         const float *__restrict__ S, int ld, int coff,
+                                         bool active, int subst_col,
+                                         const float *__restrict__ subst_row,
+                                         f32x4 init = f32x4{0.f, 0.f, 0.f, 0.f}) {
+    f32x4 total = seg_chain(col, val, e0, min(e1, e0 + LT_ROW_SEG), S, ld, coff, active, subst_col, subst_row, init);
+    for (int s0 = e0 + LT_ROW_SEG; s0 < e1; s0 += LT_ROW_SEG) {   // long rows only
+        const f32x4 t = seg_chain(col, val, s0, min(e1, s0 + LT_ROW_SEG), S, ld, coff, active, subst_col, subst_row,
+                                  f32x4{0.f, 0.f, 0.f, 0.f});
+        total.x += t.x; total.y += t.y; total.z += t.z; total.w += t.w;
+    }
+    return total;
 }
 
 // Layer-2 row: out[c] = sum_e val[e] * T[col[e]*C + c] for c < C, cooperative over LT_L2_LANES
