@@ -355,6 +355,9 @@ static void free_baseline(lt_baseline *b) {
     (void)hipFree(b->W2p_buf);
     (void)hipFree(b->slabs);
     lt_baseline_free_fp64(b);
+    if (b->side) { (void)hipStreamSynchronize(b->side); (void)hipStreamDestroy(b->side); }
+    if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+    if (b->ev_join) (void)hipEventDestroy(b->ev_join);
     delete b;
 }
 

@@ -27,6 +27,7 @@
 #define LT_BLOCK 256
 #define LT_CHUNK_BUDGET ((size_t)1 << 30)  // bytes of per-probe scratch per chunk
 #define LT_ITEM_GRID 2048                  // blocks of the grid-stride item kernels
+#define LT_SB_AHEAD 24                     // FULL stage B: entries in flight per wave (a multiple of LT_L2_LANES)
 
 // ------------------------------------------------------------------------------------------------
 // FULL stage A, narrow hidden widths (LPR < 64): one probe per grid.y, pointer-select substitution
@@ -426,53 +427,45 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
 // ------------------------------------------------------------------------------------------------
 // shared tail: finite difference + L2 norm of one observed row          attacker.py:105-106,227-229
 // ------------------------------------------------------------------------------------------------
-// FULL stage A, long rows: a wave = (long row, probe group).  Adds the segment sums the segment-mode blocks of
-// k_full_stageA_lds left in `lpart`, in segment order (row_dot's canonical order), then the ordinary epilogue.
+// FULL stage A, long rows: a wave = (long row, probe) -- or (long row, baseline) for probe index nb.  Adds the
+// segment sums the SEG instantiation of k_full_stageA_lds left in `lpart`, in segment order (row_dot's
+// canonical order), then the single-probe tail every other kernel uses (relu_w2_partial + group_sum<64>).
+// One wave per probe rather than per probe group: a hub row has a dozen segments to read one after the other,
+// and n_long * nb short waves hide that latency where n_long * groups long ones did not (114 -> 15 us).
 // ------------------------------------------------------------------------------------------------
 template <int CP, int P>
-__global__ __launch_bounds__(64) void k_full_long_combine(
-    int Hp, const float *__restrict__ W2p, int C, int n, int nb, const int32_t *__restrict__ long_row,
+__global__ __launch_bounds__(LT_BLOCK) void k_full_long_combine(
+    int Hp, const float *__restrict__ W2p, int C, int nb, int n_long, const int32_t *__restrict__ long_row,
     const int32_t *__restrict__ long_segptr, const float *__restrict__ lpart, float *__restrict__ S2p) {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const long wid = ((long)blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
+    const int li = (int)(wid / (nb + 1)), b = (int)(wid % (nb + 1));
+    if (li >= n_long) return;
     const int groups = (nb + P - 1) / P;
-    const int li = blockIdx.x / groups, g = blockIdx.x % groups;
-    const int pb = g * P;
+    const int g = b < nb ? b / P : 0, sl = b < nb ? b % P : P;
     const int r = long_row[li];
     const int s0 = long_segptr[li], s1 = long_segptr[li + 1];
     const bool active = 4 * lane < Hp;
     const int coff = active ? 4 * lane : Hp - 4;
-    auto slot = [&](int s, int p) {
-        return *reinterpret_cast<const f32x4 *>(lpart + ((size_t)(s * groups + g) * (P + 1) + p) * Hp + coff);
+    auto slot = [&](int s) {
+        return *reinterpret_cast<const f32x4 *>(lpart + ((size_t)(s * groups + g) * (P + 1) + sl) * Hp + coff);
     };
-    f32x4 acc[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) acc[p] = slot(s0, p);
+    f32x4 z = slot(s0);
     for (int s = s0 + 1; s < s1; ++s) {
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const f32x4 t = slot(s, p);
-            acc[p].x += t.x; acc[p].y += t.y; acc[p].z += t.z; acc[p].w += t.w;
-        }
+        const f32x4 t = slot(s);
+        z.x += t.x; z.y += t.y; z.z += t.z; z.w += t.w;
     }
-    if (g == 0) {   // the unperturbed row: slot P of every segment -> the baseline column
-        f32x4 zb = slot(s0, P);
-        for (int s = s0 + 1; s < s1; ++s) {
-            const f32x4 t = slot(s, P);
-            zb.x += t.x; zb.y += t.y; zb.z += t.z; zb.w += t.w;
-        }
-        float part[CP];
+    float part[CP];
 #pragma unroll
-        for (int c = 0; c < CP; ++c) part[c] = 0.f;
-        if (active) relu_w2_partial<CP>(zb, W2p + (size_t)coff * C, C, part);
+    for (int c = 0; c < CP; ++c) part[c] = 0.f;
+    if (active) relu_w2_partial<CP>(z, W2p + (size_t)coff * C, C, part);
 #pragma unroll
-        for (int c = 0; c < CP; ++c) part[c] = group_sum<64>(part[c]);
-        if (lane == 0) {
+    for (int c = 0; c < CP; ++c) part[c] = group_sum<64>(part[c]);
+    if (lane == 0) {
 #pragma unroll
-            for (int c = 0; c < CP; ++c)
-                if (c < C) S2p[((size_t)r * (nb + 1) + nb) * C + c] = part[c];
-        }
+        for (int c = 0; c < CP; ++c)
+            if (c < C) S2p[((size_t)r * (nb + 1) + b) * C + c] = part[c];
     }
-    stageA_epilogue<CP, P>(acc, lane, active, coff, W2p, C, n, nb, r, pb, S2p, 0u, -1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -518,18 +511,30 @@ __global__ __launch_bounds__(64) void k_full_stageB(
     for (int q = 0; q < LT_L2_LANES; ++q)
 #pragma unroll
         for (int c = 0; c < CP; ++c) part[q][c] = pbase[q][c] = 0.f;
-    for (int e = e0; e < e1; e += LT_L2_LANES) {
+    // LT_SB_AHEAD entries are loaded before their FMAs run (in entry order, so every chain keeps its order): an
+    // observed hub with 10^3 entries is 10^3 / 8 dependent round trips otherwise
+    constexpr int AHEAD = LT_SB_AHEAD;
+    for (int e = e0; e < e1; e += AHEAD) {
+        float a[AHEAD], tv[AHEAD][CP], tbv[AHEAD][CP];
 #pragma unroll
-        for (int q = 0; q < LT_L2_LANES; ++q)
+        for (int q = 0; q < AHEAD; ++q) {
+            const bool in = e + q < e1;
+            a[q] = in ? val[e + q] : 0.f;
+            const size_t ro = (size_t)(in ? col[e + q] : 0) * rstride;
+#pragma unroll
+            for (int c = 0; c < CP; ++c) {
+                tv[q][c] = (in && c < C) ? T[ro + c] : 0.f;
+                tbv[q][c] = (in && c < C) ? Tb[ro + c] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < AHEAD; ++q)
             if (e + q < e1) {
-                const float a = val[e + q];
-                const size_t ro = (size_t)col[e + q] * rstride;
-                const float *t = T + ro, *tb = Tb + ro;
 #pragma unroll
                 for (int c = 0; c < CP; ++c)
                     if (c < C) {
-                        part[q][c] = fmaf(a, t[c], part[q][c]);
-                        pbase[q][c] = fmaf(a, tb[c], pbase[q][c]);
+                        part[q % LT_L2_LANES][c] = fmaf(a[q], tv[q][c], part[q % LT_L2_LANES][c]);
+                        pbase[q % LT_L2_LANES][c] = fmaf(a[q], tbv[q][c], pbase[q % LT_L2_LANES][c]);
                     }
             }
     }
@@ -764,6 +769,16 @@ static int full_probes_per_wave(int nb) {
     return best;
 }
 
+// LT_OVERLAP=0 keeps the hub-row kernels on the caller's stream (A/B knob)
+static bool overlap_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("LT_OVERLAP");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return v == 1;
+}
+
 // bytes of per-probe scratch per chunk; LT_CHUNK_BUDGET_BYTES overrides it (tests force multi-chunk calls)
 static size_t chunk_budget() {
     const char *e = getenv("LT_CHUNK_BUDGET_BYTES");
@@ -879,18 +894,31 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                 LT_REQUIRE((rblocks + g->p_n_seg) * rgroups < 2147483647L, "lt_influence_rows: n * probe groups exceeds the grid limit");
                 dim3 gridr((unsigned)(rblocks * rgroups));
                 const int n_segblocks = g->p_n_seg * rgroups;
+                // hub rows: their segments and the sum over segments run on a side stream next to the plain rows
+                // (they are a few hundred long waves: alone they would leave most of the chip idle)
+                hipStream_t ls = st;
+                if (n_segblocks > 0 && overlap_enabled()) {
+                    if (!b->side) {
+                        LT_HIP(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+                        LT_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+                        LT_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+                    }
+                    ls = b->side;
+                    LT_HIP(hipEventRecord(b->ev_fork, st));
+                    LT_HIP(hipStreamWaitEvent(ls, b->ev_fork, 0));
+                }
 #define LT_RING_LAUNCH(P_)                                                                                    \
     do {                                                                                                      \
-        if (n_segblocks > 0) {   /* hub rows: their segments first, then the sum over segments */            \
+        if (n_segblocks > 0) {                                                                                \
             LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, P_, true>), dim3(n_segblocks),      \
-                                                   dim3(64), 0, st, n, g->rowptr, g->col, g->val, b->S1, Hp,  \
+                                                   dim3(64), 0, ls, n, g->rowptr, g->col, g->val, b->S1, Hp,  \
                                                    b->b1p, b->W2p, C, probes, nb, w.Sp, w.S2p, n_segblocks,   \
                                                    g->p_seg_long, g->p_seg_begin, g->p_long_row, w.lpart));   \
             LT_CHECK_LAUNCH();                                                                                \
             LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_long_combine<CP_, P_>),                             \
-                                                   dim3((unsigned)(g->p_n_long * rgroups)), dim3(64), 0, st,  \
-                                                   Hp, b->W2p, C, n, nb, g->p_long_row, g->p_long_segptr,     \
-                                                   w.lpart, w.S2p));                                          \
+                                                   dim3((unsigned)(((long)g->p_n_long * (nb + 1) + 3) / 4)),  \
+                                                   dim3(LT_BLOCK), 0, ls, Hp, b->W2p, C, nb, g->p_n_long,     \
+                                                   g->p_long_row, g->p_long_segptr, w.lpart, w.S2p));         \
             LT_CHECK_LAUNCH();                                                                                \
         }                                                                                                     \
         LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, P_, false>), gridr, dim3(64), 0, st, n, \
@@ -903,6 +931,10 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                 else if (P == 32) LT_RING_LAUNCH(32);
                 else LT_RING_LAUNCH(16);
 #undef LT_RING_LAUNCH
+                if (ls != st) {
+                    LT_HIP(hipEventRecord(b->ev_join, ls));
+                    LT_HIP(hipStreamWaitEvent(st, b->ev_join, 0));
+                }
             } else {
                 const int rpb = (LT_BLOCK / 64) * (64 / lpr);
                 dim3 grid((n + rpb - 1) / rpb, nb + 1);   // + the baseline column

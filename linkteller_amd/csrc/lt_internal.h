@@ -74,6 +74,10 @@ struct lt_baseline {
     // stage A yields the baseline S2 as a by-product and stage B forms the baseline logits itself.
     mutable bool layers_fresh = false;
     mutable bool fp64_fresh = false;
+    // FULL rows on a graph with hub rows: the segment kernel + combine run on `side` next to the plain-row
+    // kernel (fork after the probe-row GEMM, join before stage B).  Created on first use.
+    mutable hipStream_t side = nullptr;
+    mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 int lt_set_error(int code, const char *fmt, ...);
