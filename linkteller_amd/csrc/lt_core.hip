@@ -48,6 +48,7 @@ static void free_graph(lt_graph *g) {
     (void)hipFree(g->p_long_segptr);
     (void)hipFree(g->p_seg_long);
     (void)hipFree(g->p_seg_begin);
+    (void)hipFree(g->p_seg_scratch);
     delete g;
 }
 
@@ -186,6 +187,7 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
             G_HIP(hipMemcpy(g->p_long_segptr, lptr.data(), lptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
             G_HIP(hipMemcpy(g->p_seg_long, slong.data(), slong.size() * sizeof(int32_t), hipMemcpyHostToDevice));
             G_HIP(hipMemcpy(g->p_seg_begin, sbeg.data(), sbeg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            G_HIP(hipMalloc((void **)&g->p_seg_scratch, (size_t)g->p_n_seg * LT_MAX_H * sizeof(float)));
         }
     }
 #undef G_HIP

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_layer1(
     int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ S1, int Hp,
     const float *__restrict__ b1p, const float *__restrict__ W2p, int C,
-    float *__restrict__ Z1, float *__restrict__ S2) {
+    float *__restrict__ Z1, float *__restrict__ S2, int skip_long) {
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
@@ -122,6 +122,8 @@ __global__ __launch_bounds__(LT_BLOCK) void k_layer1(
     int r = wave * RPW + lane / LPR;
     if (LPR == 64) r = __builtin_amdgcn_readfirstlane(r);
     if (r >= n) return;  // LPR-lane groups exit together; shuffles below stay inside a group
+    // rows of more than LT_ROW_SEG entries are summed segment by segment by k_layer1_seg / k_layer1_long
+    if (skip_long && rowptr[r + 1] - rowptr[r] > LT_ROW_SEG) return;
     const int coff = 4 * gl;
     const bool active = coff < Hp;
     const f32x4 b1v = active ? ld4(b1p + coff) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -139,6 +141,70 @@ __global__ __launch_bounds__(LT_BLOCK) void k_layer1(
 #pragma unroll
         for (int c = 0; c < CP; ++c)
             if (c < C) S2[(size_t)r * C + c] = part[c];
+    }
+}
+
+// Long rows of layer 1 (hubs): one LPR-lane group per SEGMENT writes the segment's chain sum (the first
+// segment's chain starts from the bias, row_dot's canonical order) ...
+template <int LPR>
+__global__ __launch_bounds__(LT_BLOCK) void k_layer1_seg(
+    int n_seg, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const int32_t *__restrict__ seg_long,
+    const int32_t *__restrict__ seg_begin, const int32_t *__restrict__ long_row,
+    const float *__restrict__ S1, int Hp, const float *__restrict__ b1p, float *__restrict__ part) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
+    const int gl = lane & (LPR - 1);
+    int sg = wave * RPW + lane / LPR;
+    if (LPR == 64) sg = __builtin_amdgcn_readfirstlane(sg);
+    if (sg >= n_seg) return;
+    const int r = long_row[seg_long[sg]];
+    const int e0 = seg_begin[sg], e1 = min(rowptr[r + 1], e0 + LT_ROW_SEG);
+    const int coff = 4 * gl;
+    const bool active = coff < Hp;
+    const f32x4 init = (active && e0 == rowptr[r]) ? ld4(b1p + coff) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 z = seg_chain(col, val, e0, e1, S1, Hp, coff, active, -1, nullptr, init);
+    if (active) *reinterpret_cast<f32x4 *>(part + (size_t)sg * Hp + coff) = z;
+}
+// ... and one group per long ROW adds them in segment order and finishes like k_layer1.
+template <int LPR, int CP>
+__global__ __launch_bounds__(LT_BLOCK) void k_layer1_long(
+    int n_long, const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_segptr,
+    const float *__restrict__ part, int Hp, const float *__restrict__ W2p, int C,
+    float *__restrict__ Z1, float *__restrict__ S2) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
+    const int gl = lane & (LPR - 1);
+    int li = wave * RPW + lane / LPR;
+    if (LPR == 64) li = __builtin_amdgcn_readfirstlane(li);
+    if (li >= n_long) return;
+    const int r = long_row[li];
+    const int s0 = long_segptr[li], s1 = long_segptr[li + 1];
+    const int coff = 4 * gl;
+    const bool active = coff < Hp;
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        z = *reinterpret_cast<const f32x4 *>(part + (size_t)s0 * Hp + coff);
+        for (int s = s0 + 1; s < s1; ++s) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(part + (size_t)s * Hp + coff);
+            z.x += t.x; z.y += t.y; z.z += t.z; z.w += t.w;
+        }
+    }
+    float p2[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) p2[c] = 0.f;
+    if (active) {
+        relu_w2_partial<CP>(z, W2p + (size_t)coff * C, C, p2);
+        if (Z1) *reinterpret_cast<f32x4 *>(Z1 + (size_t)r * Hp + coff) = z;
+    }
+#pragma unroll
+    for (int c = 0; c < CP; ++c) p2[c] = group_sum<LPR>(p2[c]);
+    if (gl == 0) {
+#pragma unroll
+        for (int c = 0; c < CP; ++c)
+            if (c < C) S2[(size_t)r * C + c] = p2[c];
     }
 }
 
@@ -189,11 +255,25 @@ int lt_launch_layer1(const lt_graph *g, const float *S1, int Hp, const float *b1
                      const float *W2p, int C, float *Z1, float *S2, hipStream_t st) {
     if (g->n == 0) return LT_OK;
     const int lpr = lt_lpr_for(Hp), cp = lt_cp_for(C);
-    const unsigned grid = blocks_for_rows(g->n, (LT_BLOCK / 64) * (64 / lpr));
+    const int rpb = (LT_BLOCK / 64) * (64 / lpr);
+    const unsigned grid = blocks_for_rows(g->n, rpb);
+    const int have_long = g->p_n_long > 0 ? 1 : 0;
     lt_prof_scope prof_(LT_K_LAYER1, st);
+    if (have_long) {   // hub rows first: segment sums, then their ordered sum (uses the graph's scratch)
+        LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_layer1_seg<LPR_>), dim3(blocks_for_rows(g->p_n_seg, rpb)),
+                                                 dim3(LT_BLOCK), 0, st, g->p_n_seg, g->rowptr, g->col, g->val,
+                                                 g->p_seg_long, g->p_seg_begin, g->p_long_row, S1, Hp, b1p,
+                                                 g->p_seg_scratch));
+        LT_CHECK_LAUNCH();
+        LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
+            hipLaunchKernelGGL((k_layer1_long<LPR_, CP_>), dim3(blocks_for_rows(g->p_n_long, rpb)), dim3(LT_BLOCK), 0,
+                               st, g->p_n_long, g->p_long_row, g->p_long_segptr, g->p_seg_scratch, Hp, W2p, C,
+                               Z1, S2)));
+        LT_CHECK_LAUNCH();
+    }
     LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
         hipLaunchKernelGGL((k_layer1<LPR_, CP_>), dim3(grid), dim3(LT_BLOCK), 0, st, g->n,
-                           g->rowptr, g->col, g->val, S1, Hp, b1p, W2p, C, Z1, S2)));
+                           g->rowptr, g->col, g->val, S1, Hp, b1p, W2p, C, Z1, S2, have_long)));
     LT_CHECK_LAUNCH();
     return LT_OK;
 }

@@ -40,6 +40,7 @@ struct lt_graph {
     int32_t *p_long_segptr = nullptr;  // [p_n_long + 1] first segment of each long row
     int32_t *p_seg_long = nullptr;     // [p_n_seg]      index into p_long_row
     int32_t *p_seg_begin = nullptr;    // [p_n_seg]      first CSR entry of the segment
+    float *p_seg_scratch = nullptr;    // [p_n_seg, LT_MAX_H] segment sums of the baseline layer 1 (one stream at a time)
 };
 #define LT_SPMM_SEG 512
 #define LT_ROW_SEG 128   // layer-1 chains: entries per segment (rows up to this length are one plain chain)

@@ -123,10 +123,33 @@ __device__ __forceinline__ void row2_dot(const int32_t *__restrict__ col,
                                          int C, Lookup lookup, float (&out)[CP]) {
 #pragma unroll
     for (int c = 0; c < CP; ++c) out[c] = 0.f;
-    for (int e = e0 + q; e < e1; e += LT_L2_LANES) {
+    int e = e0 + q;
+    // four entries of the lane's chain in flight (a hub row is hundreds of entries per lane); the FMAs stay in
+    // entry order, so the chain -- and its bits -- are unchanged
+    for (; e + 3 * LT_L2_LANES < e1; e += 4 * LT_L2_LANES) {
+        float a[4], tv[4][CP];
+        const float *t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a[k] = val[e + k * LT_L2_LANES];
+            t[k] = lookup(col[e + k * LT_L2_LANES], e + k * LT_L2_LANES);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int c = 0; c < CP; ++c) tv[k][c] = (t[k] != nullptr && c < C) ? t[k][c] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (t[k] == nullptr) continue;  // DELTA mode: entries outside the probe's row set add nothing
+#pragma unroll
+            for (int c = 0; c < CP; ++c)
+                if (c < C) out[c] = fmaf(a[k], tv[k][c], out[c]);
+        }
+    }
+    for (; e < e1; e += LT_L2_LANES) {
         const float a = val[e];
         const float *t = lookup(col[e], e);
-        if (t == nullptr) continue;  // DELTA mode: entries outside the probe's row set add nothing
+        if (t == nullptr) continue;
 #pragma unroll
         for (int c = 0; c < CP; ++c)
             if (c < C) out[c] = fmaf(a, t[c], out[c]);
