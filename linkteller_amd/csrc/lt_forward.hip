@@ -252,8 +252,9 @@ static inline unsigned blocks_for_rows(int n, int rows_per_block) {
 }
 
 int lt_launch_layer1(const lt_graph *g, const float *S1, int Hp, const float *b1p,
-                     const float *W2p, int C, float *Z1, float *S2, hipStream_t st) {
+                     const float *W2p, int C, float *Z1, float *S2, hipStream_t st, float *seg_part) {
     if (g->n == 0) return LT_OK;
+    if (!seg_part) seg_part = g->p_seg_scratch;
     const int lpr = lt_lpr_for(Hp), cp = lt_cp_for(C);
     const int rpb = (LT_BLOCK / 64) * (64 / lpr);
     const unsigned grid = blocks_for_rows(g->n, rpb);
@@ -263,11 +264,11 @@ int lt_launch_layer1(const lt_graph *g, const float *S1, int Hp, const float *b1
         LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_layer1_seg<LPR_>), dim3(blocks_for_rows(g->p_n_seg, rpb)),
                                                  dim3(LT_BLOCK), 0, st, g->p_n_seg, g->rowptr, g->col, g->val,
                                                  g->p_seg_long, g->p_seg_begin, g->p_long_row, S1, Hp, b1p,
-                                                 g->p_seg_scratch));
+                                                 seg_part));
         LT_CHECK_LAUNCH();
         LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
             hipLaunchKernelGGL((k_layer1_long<LPR_, CP_>), dim3(blocks_for_rows(g->p_n_long, rpb)), dim3(LT_BLOCK), 0,
-                               st, g->p_n_long, g->p_long_row, g->p_long_segptr, g->p_seg_scratch, Hp, W2p, C,
+                               st, g->p_n_long, g->p_long_row, g->p_long_segptr, seg_part, Hp, W2p, C,
                                Z1, S2)));
         LT_CHECK_LAUNCH();
     }
@@ -434,6 +435,7 @@ static void free_baseline(lt_baseline *b) {
     (void)hipFree(b->b1p_buf);
     (void)hipFree(b->W2p_buf);
     (void)hipFree(b->slabs);
+    (void)hipFree(b->seg_part);
     lt_baseline_free_fp64(b);
     if (b->side) { (void)hipStreamSynchronize(b->side); (void)hipStreamDestroy(b->side); }
     if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
@@ -456,7 +458,7 @@ int lt_baseline_ensure_layers(const lt_baseline *cb, bool need_fp64, hipStream_t
     lt_baseline *b = const_cast<lt_baseline *>(cb);   // cache state only: logically const for the caller
     if (b->n == 0) return LT_OK;
     if (!b->layers_fresh) {
-        int rc = lt_launch_layer1(b->g, b->S1, b->Hp, b->b1p, b->W2p, b->C, b->Z1, b->S2, st);
+        int rc = lt_launch_layer1(b->g, b->S1, b->Hp, b->b1p, b->W2p, b->C, b->Z1, b->S2, st, b->seg_part);
         if (rc) return rc;
         rc = lt_launch_layer2(b->g, b->S2, b->C, b->b2, b->OUT, st);
         if (rc) return rc;
@@ -499,6 +501,7 @@ extern "C" int lt_baseline_create(const lt_graph *g, const float *X, int64_t ldx
     B_HIP(hipMalloc((void **)&b->OUT, nc));
     B_HIP(hipMalloc((void **)&b->b1p_buf, (size_t)b->Hp * sizeof(float)));
     B_HIP(hipMalloc((void **)&b->W2p_buf, (size_t)b->Hp * C * sizeof(float)));
+    if (g->p_n_seg > 0) B_HIP(hipMalloc((void **)&b->seg_part, (size_t)g->p_n_seg * b->Hp * sizeof(float)));
     if (lt_gemm_splitk_slab_bytes(b->n, H, F, lt_gemm_pick_kslice(b->n, H, F)))
         B_HIP(hipMalloc((void **)&b->slabs, lt_gemm_splitk_slab_bytes(b->n, H, F, lt_gemm_pick_kslice(b->n, H, F))));
 #undef B_HIP

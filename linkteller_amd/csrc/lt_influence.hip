@@ -615,7 +615,9 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
     const float *__restrict__ S1, const float *__restrict__ Z1, const double *__restrict__ Z1d, int Hp,
     const float *__restrict__ b1p, const float *__restrict__ W2p, int C,
     const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
-    const float *__restrict__ Sp, float delta, float *__restrict__ S2x) {
+    const float *__restrict__ Sp, float delta, float *__restrict__ S2x, int n_long,
+    const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_segptr,
+    const float *__restrict__ seg_part) {
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int gl = lane & (LPR - 1);
@@ -670,8 +672,33 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
                             part[c] = p;
                         }
                 } else {
-                    const f32x4 acc = row_dot(col, val, rowptr[r], rowptr[r + 1], S1, Hp, coff, true, v,
-                                              Sp + (size_t)b * Hp, b1v);
+                    const int e0 = rowptr[r], e1 = rowptr[r + 1];
+                    f32x4 acc;
+                    if (e1 - e0 > LT_ROW_SEG && seg_part != nullptr) {
+                        // a hub row: only the segment that holds column v differs from the baseline, whose
+                        // segment sums k_layer1_seg left in seg_part -- recompute that one, re-add in order
+                        int lo = 0, hi = n_long - 1;                 // r's index among the long rows
+                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (long_row[mid] < r) lo = mid + 1; else hi = mid; }
+                        const int sb = long_segptr[lo], ns = long_segptr[lo + 1] - sb;
+                        int pl = e0, ph = e1 - 1;                   // position of v in the (ascending) columns of r
+                        while (pl < ph) { const int mid = (pl + ph) >> 1; if (col[mid] < v) pl = mid + 1; else ph = mid; }
+                        const int sstar = (pl - e0) / LT_ROW_SEG;
+                        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                        for (int s = 0; s < ns; ++s) {
+                            f32x4 t;
+                            if (s == sstar) {
+                                const int es = e0 + s * LT_ROW_SEG;
+                                t = seg_chain(col, val, es, min(e1, es + LT_ROW_SEG), S1, Hp, coff, true, v,
+                                              Sp + (size_t)b * Hp, s == 0 ? b1v : f32x4{0.f, 0.f, 0.f, 0.f});
+                            } else {
+                                t = ld4(seg_part + (size_t)(sb + s) * Hp + coff);
+                            }
+                            if (s == 0) acc = t;
+                            else { acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
+                        }
+                    } else {
+                        acc = row_dot(col, val, e0, e1, S1, Hp, coff, true, v, Sp + (size_t)b * Hp, b1v);
+                    }
                     relu_w2_partial<CP>(acc, W2p + (size_t)coff * C, C, part);
                 }
             }
@@ -959,7 +986,8 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                     hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, 0>), dim3(LT_ITEM_GRID),
                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, g->tptr,
                                        g->trow, g->tval, b->S1, b->Z1, b->Z1d, Hp, b->b1p, b->W2p, C, probes, nb,
-                                       w.off, w.Sp, delta, w.S2x))); }
+                                       w.off, w.Sp, delta, w.S2x, g->p_n_long, g->p_long_row, g->p_long_segptr,
+                                       b->seg_part))); }
                 LT_CHECK_LAUNCH();
                 lt_prof_scope prof_(LT_K_ITEM_B, st);
                 LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, false>), dim3(gridB),
@@ -974,13 +1002,15 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                         hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, 2>), dim3(LT_ITEM_GRID), dim3(LT_BLOCK), 0,
                                            st, g->rowptr, g->col, g->val, g->tptr, g->trow, g->tval, b->S1,
                                            b->Z1, b->Z1d, Hp, b->b1p, b->W2p, C, probes, nb, w.off,
-                                           (const float *)nullptr, delta, w.S2x)));
+                                           (const float *)nullptr, delta, w.S2x, 0, (const int32_t *)nullptr,
+                                           (const int32_t *)nullptr, (const float *)nullptr)));
                 } else {
                     LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
                         hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, 1>), dim3(LT_ITEM_GRID), dim3(LT_BLOCK), 0,
                                            st, g->rowptr, g->col, g->val, g->tptr, g->trow, g->tval, b->S1,
                                            b->Z1, b->Z1d, Hp, b->b1p, b->W2p, C, probes, nb, w.off,
-                                           (const float *)nullptr, delta, w.S2x)));
+                                           (const float *)nullptr, delta, w.S2x, 0, (const int32_t *)nullptr,
+                                           (const int32_t *)nullptr, (const float *)nullptr)));
                 } }
                 LT_CHECK_LAUNCH();
                 lt_prof_scope prof_(LT_K_ITEM_B, st);

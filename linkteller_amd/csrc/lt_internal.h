@@ -66,6 +66,7 @@ struct lt_baseline {
     float *b1p_buf = nullptr;  // [Hp]
     float *W2p_buf = nullptr;  // [Hp, C]
     float *slabs = nullptr;  // split-K partials of X*W1 (only when F > LT_KSLICE_BASE)
+    float *seg_part = nullptr;  // [g->p_n_seg, Hp] segment sums of the long rows of Z1 (SPARSE recomputes one segment of a hub row)
     // optional fp64-accumulated copies for the kink test of LT_MODE_DELTA (lt_baseline_enable_fp64)
     double *S1d = nullptr;      // [n, Hp]
     double *Z1d = nullptr;      // [n, Hp]
@@ -123,8 +124,10 @@ void lt_baseline_free_fp64(lt_baseline *b);
 
 // ---- launchers implemented in the kernel translation units --------------------------------
 // layer 1 for all rows: Z1 = A_hat*S1 + b1 (optional store), S2 = relu(Z1)*W2
+// seg_part: [g->p_n_seg, Hp] scratch for the segment sums of the long rows (NULL: the graph's own scratch)
 int lt_launch_layer1(const lt_graph *g, const float *S1, int Hp, const float *b1p,
-                     const float *W2p, int C, float *Z1_or_null, float *S2, hipStream_t st);
+                     const float *W2p, int C, float *Z1_or_null, float *S2, hipStream_t st,
+                     float *seg_part = nullptr);
 // layer 2 for all rows: OUT = A_hat*S2 + b2
 int lt_launch_layer2(const lt_graph *g, const float *S2, int C, const float *b2, float *OUT,
                      hipStream_t st);
