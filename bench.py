@@ -225,6 +225,28 @@ def main():
             extras.setdefault("other_modes", {})[m] = {
                 "pairs_per_s": round(a.n_test ** 2 * a.steps / el, 1), "ms_per_step": round(el / a.steps * 1e3, 4),
                 "max_abs_diff_vs_value_mode": float((res - ref_full).abs().max().item())}
+        # the same build on a hub-heavy graph of the same size (the real MUSAE graphs are heavy-tailed; the
+        # headline graph is Erdos-Renyi as in SURVEY 8(d)): reported next to `value`, never instead of it
+        if not a.powerlaw:
+            adj_h, _, _ = synth.twitch_like_problem(a.workload, hidden=a.hidden, n_classes=2, seed=0, powerlaw=True)
+            ah = graph.first_order_gcn(adj_h)
+            base_h = engine.Baseline(graph.HipGraph(ah), x, *params)
+            out_h = torch.empty((a.n_test, a.n_test), dtype=torch.float32, device=dev)
+            res_h = {}
+            for m in ("full", "sparse"):
+                for _ in range(2):
+                    base_h.refresh(); base_h.influence_rows(obs, obs, delta, m, out=out_h)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    base_h.refresh(); base_h.influence_rows(obs, obs, delta, m, out=out_h)
+                torch.cuda.synchronize()
+                res_h[m] = (time.perf_counter() - t0) / 10
+            extras["hub_graph"] = {"graph": "power-law, same N and E", "max_degree": int(np.diff(ah.indptr).max()),
+                                   "full_ms_per_step": round(res_h["full"] * 1e3, 4),
+                                   "sparse_ms_per_step": round(res_h["sparse"] * 1e3, 4),
+                                   "full_pairs_per_s": round(a.n_test ** 2 / res_h["full"], 1)}
+            del base_h, out_h
         # standalone SpMM (lt_spmm_csr_f32) on this graph and on an HBM-resident R-MAT graph
         def time_spmm(g_, s_, reps=20):
             for _ in range(3):
