@@ -490,37 +490,46 @@ __device__ __forceinline__ float diff_norm(const float (&acc)[CP], const float *
 // xor 4,2,1 butterfly -- so the bits equal the baseline's layer-2 kernel.  The baseline logits of the
 // observed node come from the same walk over the baseline column (wave-uniform loads): FULL mode needs
 // neither k_layer1 nor k_layer2.
-template <int CP>
-__global__ __launch_bounds__(64) void k_full_stageB(
+// WPB waves per block share one (observed node, 64 probes): wave w walks the entries e0 + w, e0 + w + WPB, ...
+// i.e. the chains w, w + WPB, ... (WPB divides 8) and the chain sums meet in LDS.  WPB = 4 when the graph has
+// hub rows (an observed hub is 10^3 entries), 1 otherwise.
+template <int CP, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_full_stageB(
     int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ S2p, int C,
     const float *__restrict__ b2,
     const int32_t *__restrict__ observe, int n_obs, int nb, float delta, float *__restrict__ out,
     long ldo) {
+    constexpr int NCH = LT_L2_LANES / WPB;   // chains per wave
+    const int lane = threadIdx.x & 63;
+    // wave index as a scalar: the (col, val) and baseline-column loads below stay scalar loads
+    const int w = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int pblocks = (nb + 63) >> 6;
     const int j = blockIdx.x / pblocks;
-    const int b = (blockIdx.x % pblocks) * 64 + threadIdx.x;
+    const int b = (blockIdx.x % pblocks) * 64 + lane;
     const int u = observe[j];
     const int e0 = rowptr[u], e1 = rowptr[u + 1];
     const bool live = b < nb;
     const size_t rstride = (size_t)(nb + 1) * C;
     const float *T = S2p + (size_t)(live ? b : 0) * C;
     const float *Tb = S2p + (size_t)nb * C;
-    float part[LT_L2_LANES][CP], pbase[LT_L2_LANES][CP];
+    float part[NCH][CP], pbase[NCH][CP];
 #pragma unroll
-    for (int q = 0; q < LT_L2_LANES; ++q)
+    for (int q = 0; q < NCH; ++q)
 #pragma unroll
         for (int c = 0; c < CP; ++c) part[q][c] = pbase[q][c] = 0.f;
     // LT_SB_AHEAD entries are loaded before their FMAs run (in entry order, so every chain keeps its order): an
     // observed hub with 10^3 entries is 10^3 / 8 dependent round trips otherwise
-    constexpr int AHEAD = LT_SB_AHEAD;
-    for (int e = e0; e < e1; e += AHEAD) {
+    constexpr int AHEAD = LT_SB_AHEAD / WPB < NCH ? NCH : LT_SB_AHEAD / WPB;   // a multiple of NCH
+    static_assert(AHEAD % NCH == 0, "entries in flight per wave must cover whole rounds of its chains");
+    for (int e = e0 + w; e < e1; e += AHEAD * WPB) {
         float a[AHEAD], tv[AHEAD][CP], tbv[AHEAD][CP];
 #pragma unroll
         for (int q = 0; q < AHEAD; ++q) {
-            const bool in = e + q < e1;
-            a[q] = in ? val[e + q] : 0.f;
-            const size_t ro = (size_t)(in ? col[e + q] : 0) * rstride;
+            const int ee = e + q * WPB;
+            const bool in = ee < e1;
+            a[q] = in ? val[ee] : 0.f;
+            const size_t ro = (size_t)(in ? col[ee] : 0) * rstride;
 #pragma unroll
             for (int c = 0; c < CP; ++c) {
                 tv[q][c] = (in && c < C) ? T[ro + c] : 0.f;
@@ -529,23 +538,46 @@ __global__ __launch_bounds__(64) void k_full_stageB(
         }
 #pragma unroll
         for (int q = 0; q < AHEAD; ++q)
-            if (e + q < e1) {
+            if (e + q * WPB < e1) {
 #pragma unroll
                 for (int c = 0; c < CP; ++c)
                     if (c < C) {
-                        part[q % LT_L2_LANES][c] = fmaf(a[q], tv[q][c], part[q % LT_L2_LANES][c]);
-                        pbase[q % LT_L2_LANES][c] = fmaf(a[q], tbv[q][c], pbase[q % LT_L2_LANES][c]);
+                        part[q % NCH][c] = fmaf(a[q], tv[q][c], part[q % NCH][c]);
+                        pbase[q % NCH][c] = fmaf(a[q], tbv[q][c], pbase[q % NCH][c]);
                     }
             }
+    }
+    // chain k of the row = local chain k / WPB of wave k % WPB
+    float ch[LT_L2_LANES][CP], chb[LT_L2_LANES][CP];
+    if constexpr (WPB == 1) {
+#pragma unroll
+        for (int k = 0; k < LT_L2_LANES; ++k)
+#pragma unroll
+            for (int c = 0; c < CP; ++c) { ch[k][c] = part[k][c]; chb[k][c] = pbase[k][c]; }
+    } else {
+        __shared__ float xch[2][LT_L2_LANES][CP][64];
+#pragma unroll
+        for (int q = 0; q < NCH; ++q)
+#pragma unroll
+            for (int c = 0; c < CP; ++c) {
+                xch[0][w + q * WPB][c][lane] = part[q][c];
+                xch[1][w + q * WPB][c][lane] = pbase[q][c];
+            }
+        __syncthreads();
+        if (w != 0) return;
+#pragma unroll
+        for (int k = 0; k < LT_L2_LANES; ++k)
+#pragma unroll
+            for (int c = 0; c < CP; ++c) { ch[k][c] = xch[0][k][c][lane]; chb[k][c] = xch[1][k][c][lane]; }
     }
     float acc[CP], base[CP];
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
-        const float t0 = part[0][c] + part[4][c], t1 = part[1][c] + part[5][c];
-        const float t2 = part[2][c] + part[6][c], t3 = part[3][c] + part[7][c];
+        const float t0 = ch[0][c] + ch[4][c], t1 = ch[1][c] + ch[5][c];
+        const float t2 = ch[2][c] + ch[6][c], t3 = ch[3][c] + ch[7][c];
         acc[c] = (t0 + t2) + (t1 + t3);
-        const float u0 = pbase[0][c] + pbase[4][c], u1 = pbase[1][c] + pbase[5][c];
-        const float u2 = pbase[2][c] + pbase[6][c], u3 = pbase[3][c] + pbase[7][c];
+        const float u0 = chb[0][c] + chb[4][c], u1 = chb[1][c] + chb[5][c];
+        const float u2 = chb[2][c] + chb[6][c], u3 = chb[3][c] + chb[7][c];
         base[c] = c < C ? ((u0 + u2) + (u1 + u3)) + b2[c] : 0.f;   // = OUT[u] of k_layer2, bit for bit
     }
     if (live) out[(long)b * ldo + j] = diff_norm<CP>(acc, b2, base, C, delta);
@@ -973,9 +1005,15 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
             LT_CHECK_LAUNCH();
             { lt_prof_scope prof_(LT_K_FULL_B, st);
             const unsigned gridB2 = (unsigned)(((nb + 63) / 64) * (long)n_obs);
-            LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageB<CP_>), dim3(gridB2), dim3(64), 0, st, n,
-                                                   g->rowptr, g->col, g->val, w.S2p, C, b->b2,
-                                                   observe_nodes, n_obs, nb, delta, orow, (long)ldo)); }
+            if (g->p_n_long > 0) {
+                LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageB<CP_, 4>), dim3(gridB2), dim3(256), 0, st, n,
+                                                       g->rowptr, g->col, g->val, w.S2p, C, b->b2,
+                                                       observe_nodes, n_obs, nb, delta, orow, (long)ldo));
+            } else {
+                LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageB<CP_, 1>), dim3(gridB2), dim3(64), 0, st, n,
+                                                       g->rowptr, g->col, g->val, w.S2p, C, b->b2,
+                                                       observe_nodes, n_obs, nb, delta, orow, (long)ldo));
+            } }
             LT_CHECK_LAUNCH();
         } else {
             hipLaunchKernelGGL(k_probe_offsets, dim3(1), dim3(1024), 0, st, g->tptr, probes, nb, w.off);
