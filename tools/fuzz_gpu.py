@@ -1,0 +1,86 @@
+"""Randomised cross-check on the GPU (run by hand: python tools/fuzz_gpu.py [cases] [seed]): graph families x
+hidden widths x class counts x probe/observe lists, asserting
+  full == sparse bit for bit, delta within 1e-5 of the fp64 oracle, full within 3x the oracle's own fp32 noise,
+  exact zeros preserved, logits within 2e-5."""
+import sys
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+sys.path.insert(0, ".")
+from linkteller_amd import engine, graph, synth          # noqa: E402
+from oracle import linkteller_oracle as O                # noqa: E402
+
+
+def oracle_matrix(a_hat, x, w, probes, observe, delta, dtype):
+    adj_t = O.to_torch_sparse(a_hat).to(dtype)
+    P = {k: torch.from_numpy(w[k]).to(dtype) for k in ("W1", "b1", "W2", "b2")}
+    xt = torch.from_numpy(x).to(dtype)
+    out = np.zeros((len(probes), len(observe)))
+    with torch.no_grad():
+        for i, v in enumerate(probes):
+            g = O.get_gradient_eps_mat(xt, adj_t, P, int(v), delta)
+            out[i] = g[torch.as_tensor(np.asarray(observe))].norm(dim=1).numpy()
+    return out
+
+
+def make_graph(kind, n, rng):
+    if kind == "er":
+        return synth.erdos_renyi_graph(n, int(n * rng.uniform(1.5, 8)), seed=int(rng.randint(1 << 30)))
+    if kind == "pl":
+        return synth.powerlaw_graph(n, int(n * rng.uniform(2, 8)), seed=int(rng.randint(1 << 30)), exponent=rng.uniform(1.8, 2.6))
+    if kind == "star":
+        rows = np.concatenate([np.zeros(n - 1, int), np.arange(1, n)])
+        cols = np.concatenate([np.arange(1, n), np.roll(np.arange(1, n), 1)])
+        a = sp.coo_matrix((np.ones(len(rows), np.float32), (rows, cols)), shape=(n, n)).tocsr()
+        return ((a + a.T) > 0).astype(np.float32).tocsr()
+    if kind == "sparse_iso":      # many isolated nodes
+        a = synth.erdos_renyi_graph(n, max(4, n // 4), seed=int(rng.randint(1 << 30)))
+        return a
+    raise ValueError(kind)
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    dev = torch.device("cuda", 0)
+    worst = 0.0
+    for it in range(cases):
+        kind = rng.choice(["er", "pl", "pl", "star", "sparse_iso"])
+        n = int(rng.choice([40, 130, 300, 700]))
+        h = int(rng.choice([4, 10, 32, 100, 128, 132, 200, 256]))
+        c = int(rng.choice([1, 2, 2, 3, 7, 8]))
+        f = int(rng.choice([8, 33, 64]))
+        norm = rng.choice(["FirstOrderGCN", "FirstOrderGCN", "AugNormAdj", "NormAdj"])
+        adj = make_graph(kind, n, rng)
+        a_hat = graph.fetch_normalization(norm)(adj).tocsr().astype(np.float32)
+        a_hat.sort_indices()
+        x = synth.gaussian_features(n, f, seed=it)
+        w = synth.gcn_weights(f, h, c, seed=it + 1)
+        base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(dev),
+                               *[torch.from_numpy(w[k]).to(dev) for k in ("W1", "b1", "W2", "b2")])
+        n_probe = int(rng.choice([1, 5, 17, 40, 70]))
+        probes = rng.choice(n, min(n_probe, n), replace=bool(rng.randint(2)))
+        observe = rng.choice(n, min(n, int(rng.choice([1, 30, 150]))), replace=False)
+        ref64 = oracle_matrix(a_hat, x, w, probes, observe, 1e-4, torch.float64)
+        ref32 = oracle_matrix(a_hat, x, w, probes, observe, 1e-4, torch.float32)
+        scale = max(ref64.max(), 1e-6)
+        res = {m: base.influence_rows(probes, observe, 1e-4, m).cpu().numpy().astype(np.float64) for m in ("full", "sparse", "delta")}
+        tag = f"case {it}: {kind} n={n} H={h} C={c} F={f} {norm} probes={len(probes)} obs={len(observe)} maxdeg={int(np.diff(a_hat.indptr).max())}"
+        assert np.array_equal(res["full"], res["sparse"]), tag
+        ed = np.abs(res["delta"] - ref64).max() / scale
+        assert ed <= 1e-5, (tag, ed)
+        assert np.abs(res["full"] - ref64).max() <= 3.0 * np.abs(ref32 - ref64).max() + 1e-4 * scale, tag
+        for r in res.values():
+            assert np.all(r[ref64 == 0] == 0), tag
+        logits = base.logits().cpu().numpy().astype(np.float64)
+        rl = O.gcn_forward(torch.from_numpy(x).double(), O.to_torch_sparse(a_hat).double(),
+                           {k: torch.from_numpy(w[k]).double() for k in ("W1", "b1", "W2", "b2")}).numpy()
+        assert np.abs(logits - rl).max() <= 2e-5 * max(1.0, np.abs(rl).max()), tag
+        worst = max(worst, ed)
+        print("ok", tag, f"delta err {ed:.1e}")
+    print("all", cases, "cases ok; worst delta error", worst)
+
+
+if __name__ == "__main__":
+    main()
