@@ -474,3 +474,29 @@ def test_row_that_contains_every_probe(gpu):
     ref_logits = O.gcn_forward(torch.from_numpy(x).double(), O.to_torch_sparse(a_hat).double(),
                                {k: torch.from_numpy(w[k]).double() for k in ("W1", "b1", "W2", "b2")}).numpy()
     assert np.abs(logits - ref_logits).max() <= 2e-5 * np.abs(ref_logits).max() + 1e-6
+
+
+def test_refresh_picks_up_new_weights_in_every_mode(gpu, influence_golden):
+    """lt_baseline_refresh recomputes S1 only and leaves the layer activations stale until something reads
+    them; after an in-place change of the (borrowed) weights every consumer -- full rows (which never read
+    them), sparse / delta rows, logits -- must equal a baseline created from scratch on the new weights, in any
+    order of calls."""
+    g = influence_golden
+    args, base = _setup(g, "pl600", gpu)
+    nodes = g["pl600.ref32.test_nodes"]
+    base.influence_rows(nodes, nodes, args["influence"], "delta")        # enables the fp64 copy too
+    for order in (("full", "logits", "sparse", "delta"), ("delta", "full", "sparse", "logits"), ("logits", "sparse", "full", "delta")):
+        base.w1.mul_(1.01)
+        base.b1.add_(0.003)
+        base.refresh()
+        got = {}
+        for what in order:
+            got[what] = (base.logits() if what == "logits"
+                         else base.influence_rows(nodes, nodes, args["influence"], what)).cpu().numpy()
+        from linkteller_amd import engine
+        fresh = engine.Baseline(base.graph, base.x, base.w1, base.b1, base.w2, base.b2)
+        for what in order:
+            ref = (fresh.logits() if what == "logits"
+                   else fresh.influence_rows(nodes, nodes, args["influence"], what)).cpu().numpy()
+            assert np.array_equal(got[what], ref), (order, what)
+        assert np.array_equal(got["full"], got["sparse"])
