@@ -181,12 +181,14 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// Long rows (more than LT_ROW_SEG entries: hubs) do not run as one wave per probe group: the SEG instantiation
+// Long rows (more than LT_ROW_SEG entries: hubs) are not walked by the plain instantiation (MODE 0).  MODE 1
 // takes one SEGMENT of a long row per block (same walk, over LT_ROW_SEG entries, the chains of a non-first
 // segment starting from +0) and leaves the P (+1 baseline) segment sums in `lpart`; k_full_long_combine adds
-// them in segment order -- row_dot's canonical order -- and runs the epilogue.  The plain instantiation skips
-// the long rows.
-template <int CP, int P, bool SEG>
+// them in segment order -- row_dot's canonical order -- and runs the epilogue.  That costs P KiB of scratch per
+// segment and probe group, fine for a graph with a few hubs; a graph with 10^5 long rows (R-MAT) uses MODE 2
+// instead: one wave walks all the segments of its row one after the other and keeps the running sum in a
+// second set of registers (so P <= 16 there).
+template <int CP, int P, int MODE>   // 0: rows of up to LT_ROW_SEG entries; 1: one segment of a long row; 2: a whole long row
 __global__ __launch_bounds__(64) void k_full_stageA_lds(
     int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ S1, int Hp,
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
     __shared__ __attribute__((aligned(16))) float ring[LT_RING_SLOTS * 256];
     const int lane = threadIdx.x;
     const int groups = (nb + P - 1) / P;
-    constexpr bool segmode = SEG;   // two instantiations: in one kernel the two tails cost 50-100 VGPRs of copies
+    constexpr bool segmode = MODE == 1;   // separate instantiations: in one kernel the different tails cost 50-100 VGPRs of copies
     int r, pb, e0, e1, sg = 0;
     bool first_seg = true;
     if (segmode) {
@@ -209,6 +211,11 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
         e0 = seg_begin[sg];
         e1 = min(rowptr[r + 1], e0 + LT_ROW_SEG);
         first_seg = e0 == rowptr[r];
+    } else if (MODE == 2) {
+        pb = (blockIdx.x % groups) * P;
+        r = long_row[blockIdx.x / groups];
+        e0 = rowptr[r];
+        e1 = rowptr[r + 1];
     } else {
         const int bid = blockIdx.x;
         pb = (bid % groups) * P;
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
         if (r >= n) return;
         e0 = rowptr[r];
         e1 = rowptr[r + 1];
-        if (e1 - e0 > LT_ROW_SEG) return;   // a long row: its segments are the blocks above
+        if (e1 - e0 > LT_ROW_SEG) return;   // a long row: MODE 1 / MODE 2 blocks take it
     }
   {
     const bool active = 4 * lane < Hp;
@@ -228,128 +235,151 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
     // before the DMAs for the same reason
     f32x4 b1v = first_seg ? ld4(b1p + coff) : f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("" : "+v"(b1v));
-    f32x4 acc[P];   // set by the first entry of the row: acc = fma(a_0, s_0, b1) -- no initialisation pass
-    const int deg = e1 - e0;
-    const int nh = (deg + 3) >> 2;
+    f32x4 acc[P];   // set by the first entry walked: acc = fma(a_0, s_0, init) -- no initialisation pass
     unsigned long long hit = 0ull;
     unsigned lane_off = 4u * (unsigned)coff;
+    // the chains of the entries [ws, we) (at most LT_ROW_SEG of them), started from `winit`, into acc[]
+    auto walk = [&](const int ws, const int we, const f32x4 winit) {
+        const int deg = we - ws;
+        const int nh = (deg + 3) >> 2;
 
-    auto load_cols = [&](int h, int (&c)[4], int eb) {
-        const int32_t *cp = col + eb + 4 * h;     // may run past the row: stays inside the padded array
-#pragma unroll
-        for (int k = 0; k < 4; ++k) c[k] = cp[k];
-    };
-    auto load_vals = [&](int h, float (&a)[4], int eb) {
-        const float *vp_ = val + eb + 4 * h;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) a[k] = vp_[k];   // entries past the row end are never used (fmas stops at cnt)
-    };
-    auto issue = [&](int h, const int (&c)[4]) {
-        const int base = (h % (LT_RING_NB + 1)) * 4;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            // wave-level hit mask in SGPRs (v_cmp + s_or): bit l = lane l's probe sits on this column
-            hit |= (4 * h + k < deg) ? __ballot(vprobe == c[k]) : 0ull;
-            // uniform row base + 32-bit unsigned lane offset -> the saddr form of global_load_lds (no VALU)
-            const char *rowp = reinterpret_cast<const char *>(S1 + (size_t)c[k] * Hp);
-            // two empty asm fences: the first keeps hipcc from re-associating the address into
-            // (S1 + lane_off) + row, the second re-defines lane_off in this basic block so that instruction
-            // selection sees base + zext(32-bit offset); without them the add is a 64-bit VALU op per entry
-            asm("" : "+s"(rowp));
-            asm("" : "+v"(lane_off));
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(rowp + lane_off),
-                                             (lds_ptr_t)(ring + (base + k) * 256), 16, 0, 0);
-        }
-    };
-    // half-block h out of the ring into registers; AFTER = number of half-blocks issued after it
-    auto fetch = [&](int h, f32x4 (&s)[4], auto after_tag) {
-        constexpr int AFTER = decltype(after_tag)::value;
-        const float *slot = ring + (h % (LT_RING_NB + 1)) * 4 * 256 + 4 * lane;
-        wait_vmcnt<4 * AFTER + 3>(); s[0] = *reinterpret_cast<const f32x4 *>(slot);
-        wait_vmcnt<4 * AFTER + 2>(); s[1] = *reinterpret_cast<const f32x4 *>(slot + 256);
-        wait_vmcnt<4 * AFTER + 1>(); s[2] = *reinterpret_cast<const f32x4 *>(slot + 512);
-        wait_vmcnt<4 * AFTER + 0>(); s[3] = *reinterpret_cast<const f32x4 *>(slot + 768);
-    };
-    // the first `cnt` (>= 1) entries of a fetched half-block into all P chains; FIRST: the row's first
-    // half-block, whose entry 0 starts every chain from the bias
-    auto fmas = [&](const float (&a)[4], const f32x4 (&s)[4], int cnt, auto first_tag) {
-        constexpr bool FIRST = decltype(first_tag)::value;
-        if constexpr (FIRST) {
-            // acc[p] = fma(a_0, s_0, b1) for every probe.  The P results are equal by construction (FULL mode
-            // is P independent recomputations of the same row), and hipcc would compute one and copy it P
-            // times; volatile asm keeps them P separate FMAs -- and P opaque values, so the chains that
-            // continue from them stay separate too.
-            const double ap = __builtin_bit_cast(double, f32x2_t{a[0], a[0]});
-            const double slo = __builtin_bit_cast(double, f32x2_t{s[0].x, s[0].y});
-            const double shi = __builtin_bit_cast(double, f32x2_t{s[0].z, s[0].w});
-            const double blo = __builtin_bit_cast(double, f32x2_t{b1v.x, b1v.y});
-            const double bhi = __builtin_bit_cast(double, f32x2_t{b1v.z, b1v.w});
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                double lo, hi;
-                asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(ap), "v"(slo), "v"(blo));
-                asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(ap), "v"(shi), "v"(bhi));
-                const f32x2_t l2 = __builtin_bit_cast(f32x2_t, lo), h2 = __builtin_bit_cast(f32x2_t, hi);
-                acc[p] = f32x4{l2.x, l2.y, h2.x, h2.y};
+        auto load_cols = [&](int h, int (&c)[4], int eb) {
+            const int32_t *cp = col + eb + 4 * h;     // may run past the row: stays inside the padded array
+    #pragma unroll
+            for (int k = 0; k < 4; ++k) c[k] = cp[k];
+        };
+        auto load_vals = [&](int h, float (&a)[4], int eb) {
+            const float *vp_ = val + eb + 4 * h;
+    #pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = vp_[k];   // entries past the row end are never used (fmas stops at cnt)
+        };
+        auto issue = [&](int h, const int (&c)[4]) {
+            const int base = (h % (LT_RING_NB + 1)) * 4;
+    #pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // wave-level hit mask in SGPRs (v_cmp + s_or): bit l = lane l's probe sits on this column
+                hit |= (4 * h + k < deg) ? __ballot(vprobe == c[k]) : 0ull;
+                // uniform row base + 32-bit unsigned lane offset -> the saddr form of global_load_lds (no VALU)
+                const char *rowp = reinterpret_cast<const char *>(S1 + (size_t)c[k] * Hp);
+                // two empty asm fences: the first keeps hipcc from re-associating the address into
+                // (S1 + lane_off) + row, the second re-defines lane_off in this basic block so that instruction
+                // selection sees base + zext(32-bit offset); without them the add is a 64-bit VALU op per entry
+                asm("" : "+s"(rowp));
+                asm("" : "+v"(lane_off));
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(rowp + lane_off),
+                                                 (lds_ptr_t)(ring + (base + k) * 256), 16, 0, 0);
             }
-        }
-#pragma unroll
-        for (int k = FIRST ? 1 : 0; k < 4; ++k) {
-            if (k >= cnt) break;   // wave-uniform: entries past the row end are skipped (last half-block only)
-#pragma unroll
-            for (int p = 0; p < P; ++p) acc[p] = fma4(a[k], s[k], acc[p]);
-        }
-    };
-    static_assert(LT_RING_NB == 1, "the loop below is written for one half-block in flight behind the consumed one");
-    if (nh == 0) {
-#pragma unroll
-        for (int p = 0; p < P; ++p) {   // empty row: z = b1 (opaque copies, see fmas)
-            f32x4 t = b1v;
-            asm volatile("" : "+v"(t));
-            acc[p] = t;
-        }
-    } else {
-        int cI[4], cN[4], cF[4];
-        float aC[4], aN[4];
-        f32x4 s[4];
-        load_cols(0, cI, e0);
-        load_vals(0, aC, e0);
-        issue(0, cI);
-        load_cols(1, cN, e0);   // one half-block of look-ahead (past a short row: inside the padding, unused)
-        // Half-block h+1 goes in flight, half-block h is consumed.  The (col, val) scalar loads of the NEXT
-        // iteration are issued once the first ring read of this one has landed (the empty asm ties their
-        // address to it), i.e. in front of a block of FMAs that covers their latency; issued any earlier
-        // they would share the lgkmcnt(0) that guards the ring reads.
-        auto front = [&](int h) {
-            issue(h + 1, cN);
-            fetch(h, s, std::integral_constant<int, 1>{});
-            int eb = e0;
-            asm volatile("" : "+s"(eb) : "v"(s[0].x));
-            load_cols(h + 2, cF, eb);
-            load_vals(h + 1, aN, eb);
         };
-        auto back = [&]() {
-            // pin the look-ahead columns in SGPRs here (hipcc otherwise sinks the loads to the top of the
-            // next iteration, right in front of their use)
-            asm volatile("" : "+s"(cF[0]), "+s"(cF[1]), "+s"(cF[2]), "+s"(cF[3]));
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { aC[k] = aN[k]; cN[k] = cF[k]; }
+        // half-block h out of the ring into registers; AFTER = number of half-blocks issued after it
+        auto fetch = [&](int h, f32x4 (&s)[4], auto after_tag) {
+            constexpr int AFTER = decltype(after_tag)::value;
+            const float *slot = ring + (h % (LT_RING_NB + 1)) * 4 * 256 + 4 * lane;
+            wait_vmcnt<4 * AFTER + 3>(); s[0] = *reinterpret_cast<const f32x4 *>(slot);
+            wait_vmcnt<4 * AFTER + 2>(); s[1] = *reinterpret_cast<const f32x4 *>(slot + 256);
+            wait_vmcnt<4 * AFTER + 1>(); s[2] = *reinterpret_cast<const f32x4 *>(slot + 512);
+            wait_vmcnt<4 * AFTER + 0>(); s[3] = *reinterpret_cast<const f32x4 *>(slot + 768);
         };
-        // the row's first half-block starts the chains (one copy of that code for long and short rows)
-        const bool more = nh > 1;
-        if (more) front(0);
-        else fetch(0, s, std::integral_constant<int, 0>{});
-        fmas(aC, s, more ? 4 : deg, std::true_type{});
-        if (more) {
-            back();
-            int h = 1;
-            for (; h + 1 < nh; ++h) {
-                front(h);
-                fmas(aC, s, 4, std::false_type{});
+        // the first `cnt` (>= 1) entries of a fetched half-block into all P chains; FIRST: the row's first
+        // half-block, whose entry 0 starts every chain from the bias
+        auto fmas = [&](const float (&a)[4], const f32x4 (&s)[4], int cnt, auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            if constexpr (FIRST) {
+                // acc[p] = fma(a_0, s_0, b1) for every probe.  The P results are equal by construction (FULL mode
+                // is P independent recomputations of the same row), and hipcc would compute one and copy it P
+                // times; volatile asm keeps them P separate FMAs -- and P opaque values, so the chains that
+                // continue from them stay separate too.
+                const double ap = __builtin_bit_cast(double, f32x2_t{a[0], a[0]});
+                const double slo = __builtin_bit_cast(double, f32x2_t{s[0].x, s[0].y});
+                const double shi = __builtin_bit_cast(double, f32x2_t{s[0].z, s[0].w});
+                const double blo = __builtin_bit_cast(double, f32x2_t{winit.x, winit.y});
+                const double bhi = __builtin_bit_cast(double, f32x2_t{winit.z, winit.w});
+    #pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    double lo, hi;
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(ap), "v"(slo), "v"(blo));
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(ap), "v"(shi), "v"(bhi));
+                    const f32x2_t l2 = __builtin_bit_cast(f32x2_t, lo), h2 = __builtin_bit_cast(f32x2_t, hi);
+                    acc[p] = f32x4{l2.x, l2.y, h2.x, h2.y};
+                }
+            }
+    #pragma unroll
+            for (int k = FIRST ? 1 : 0; k < 4; ++k) {
+                if (k >= cnt) break;   // wave-uniform: entries past the row end are skipped (last half-block only)
+    #pragma unroll
+                for (int p = 0; p < P; ++p) acc[p] = fma4(a[k], s[k], acc[p]);
+            }
+        };
+        static_assert(LT_RING_NB == 1, "the loop below is written for one half-block in flight behind the consumed one");
+        if (nh == 0) {
+    #pragma unroll
+            for (int p = 0; p < P; ++p) {   // empty row: z = b1 (opaque copies, see fmas)
+                f32x4 t = winit;
+                asm volatile("" : "+v"(t));
+                acc[p] = t;
+            }
+        } else {
+            int cI[4], cN[4], cF[4];
+            float aC[4], aN[4];
+            f32x4 s[4];
+            load_cols(0, cI, ws);
+            load_vals(0, aC, ws);
+            issue(0, cI);
+            load_cols(1, cN, ws);   // one half-block of look-ahead (past a short row: inside the padding, unused)
+            // Half-block h+1 goes in flight, half-block h is consumed.  The (col, val) scalar loads of the NEXT
+            // iteration are issued once the first ring read of this one has landed (the empty asm ties their
+            // address to it), i.e. in front of a block of FMAs that covers their latency; issued any earlier
+            // they would share the lgkmcnt(0) that guards the ring reads.
+            auto front = [&](int h) {
+                issue(h + 1, cN);
+                fetch(h, s, std::integral_constant<int, 1>{});
+                int eb = ws;
+                asm volatile("" : "+s"(eb) : "v"(s[0].x));
+                load_cols(h + 2, cF, eb);
+                load_vals(h + 1, aN, eb);
+            };
+            auto back = [&]() {
+                // pin the look-ahead columns in SGPRs here (hipcc otherwise sinks the loads to the top of the
+                // next iteration, right in front of their use)
+                asm volatile("" : "+s"(cF[0]), "+s"(cF[1]), "+s"(cF[2]), "+s"(cF[3]));
+    #pragma unroll
+                for (int k = 0; k < 4; ++k) { aC[k] = aN[k]; cN[k] = cF[k]; }
+            };
+            // the row's first half-block starts the chains (one copy of that code for long and short rows)
+            const bool more = nh > 1;
+            if (more) front(0);
+            else fetch(0, s, std::integral_constant<int, 0>{});
+            fmas(aC, s, more ? 4 : deg, std::true_type{});
+            if (more) {
                 back();
+                int h = 1;
+                for (; h + 1 < nh; ++h) {
+                    front(h);
+                    fmas(aC, s, 4, std::false_type{});
+                    back();
+                }
+                fetch(h, s, std::integral_constant<int, 0>{});
+                fmas(aC, s, deg - 4 * h, std::false_type{});
             }
-            fetch(h, s, std::integral_constant<int, 0>{});
-            fmas(aC, s, deg - 4 * h, std::false_type{});
+        }
+
+    };
+    f32x4 tot[MODE == 2 ? P : 1];   // MODE 2: sum of the segment sums so far
+    if constexpr (MODE != 2) {
+        walk(e0, e1, b1v);
+    } else {
+        for (int ws = e0;; ws += LT_ROW_SEG) {
+            const int we = min(e1, ws + LT_ROW_SEG);
+            walk(ws, we, ws == e0 ? b1v : f32x4{0.f, 0.f, 0.f, 0.f});
+            if (ws == e0) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) tot[p] = acc[p];
+            } else {
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    tot[p].x += acc[p].x; tot[p].y += acc[p].y; tot[p].z += acc[p].z; tot[p].w += acc[p].w;
+                }
+            }
+            if (we >= e1) break;
         }
     }
 
@@ -368,8 +398,10 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
     // segment sums go to lpart: slot p < P = probe pb + p, slot P = the unperturbed segment (group 0 only);
     // uniform slot base + 32-bit lane offset = the saddr store form
     float *slot_base = segmode ? lpart + ((size_t)(sg * groups + pb / P) * (P + 1)) * Hp : nullptr;
-    if constexpr (!SEG) {
+    if constexpr (MODE == 0) {
         stageA_epilogue<CP, P>(acc, lane, active, coff, W2p, C, n, nb, r, pb, S2p, hitmask, base_p);
+    } else if constexpr (MODE == 2) {
+        stageA_epilogue<CP, P>(tot, lane, active, coff, W2p, C, n, nb, r, pb, S2p, hitmask, base_p);
     } else {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
@@ -400,8 +432,11 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
             } else {
                 do_base = false;
             }
-            // e1 - e0 <= LT_ROW_SEG here, so this is one segment chain (row_dot of a short row is the same thing)
-            const f32x4 z = seg_chain(col, val, e0, e1, S1, Hp, coff, true, v, Sp + (size_t)(pb + (p < 0 ? 0 : p)) * Hp, b1r);
+            // MODE 0 / 1: e1 - e0 <= LT_ROW_SEG, one segment chain (row_dot of a short row is the same thing);
+            // MODE 2: the whole long row, segment by segment
+            const f32x4 z = MODE == 2
+                ? row_dot(col, val, e0, e1, S1, Hp, coff, true, v, Sp + (size_t)(pb + (p < 0 ? 0 : p)) * Hp, b1r)
+                : seg_chain(col, val, e0, e1, S1, Hp, coff, true, v, Sp + (size_t)(pb + (p < 0 ? 0 : p)) * Hp, b1r);
             if (segmode) {
                 char *sp = reinterpret_cast<char *>(slot_base + (size_t)(p < 0 ? P : p) * Hp);
                 *reinterpret_cast<f32x4 *>(sp + lane_off) = z;
@@ -845,6 +880,19 @@ static size_t chunk_budget() {
     return LT_CHUNK_BUDGET;
 }
 
+// Long rows go segment-parallel when the segment sums of ONE probe fit LT_LONG_PAR_BYTES (a graph with a few
+// hubs); a graph where they do not (10^5 long rows) walks each long row in one wave per <= 16 probes.
+#define LT_LONG_PAR_BYTES ((size_t)4 << 20)
+static bool long_rows_parallel(const lt_graph *g, int Hp) {
+    static int forced = -2;   // LT_LONG_PAR=0 / 1 pins the choice (tests run both paths on small graphs)
+    if (forced == -2) {
+        const char *e = getenv("LT_LONG_PAR");
+        forced = e ? (atoi(e) != 0 ? 1 : 0) : -1;
+    }
+    if (forced >= 0) return forced == 1;
+    return (size_t)g->p_n_seg * Hp * sizeof(float) * 9 / 8 <= LT_LONG_PAR_BYTES;
+}
+
 struct infl_ws {
     float *Sp, *S2p;       // FULL / SPARSE: S1 rows of the perturbed probes; FULL: per-probe S2
     float *lpart;          // FULL: segment sums of the long rows [segment][group][P + 1][Hp]
@@ -861,7 +909,7 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
     const size_t maxc = (size_t)(b->g->max_col_nnz > 0 ? b->g->max_col_nnz : 1);
     size_t per_probe = 0;
     const size_t splitk = ((F + LT_KSLICE_PROBE - 1) / LT_KSLICE_PROBE) * (size_t)b->H;
-    const size_t nseg = (size_t)b->g->p_n_seg;
+    const size_t nseg = long_rows_parallel(b->g, b->Hp) ? (size_t)b->g->p_n_seg : 0;
     if (mode == LT_MODE_FULL) per_probe = (n * C + Hp + splitk) * sizeof(float) + nseg * Hp * sizeof(float) * 9 / 8;
     else if (mode == LT_MODE_SPARSE) per_probe = (maxc * C + Hp + splitk) * sizeof(float) + sizeof(int32_t);
     else per_probe = maxc * C * sizeof(float) + sizeof(int32_t);
@@ -952,11 +1000,14 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                 const int rgroups = (nb + P - 1) / P;
                 LT_REQUIRE((rblocks + g->p_n_seg) * rgroups < 2147483647L, "lt_influence_rows: n * probe groups exceeds the grid limit");
                 dim3 gridr((unsigned)(rblocks * rgroups));
-                const int n_segblocks = g->p_n_seg * rgroups;
-                // hub rows: their segments and the sum over segments run on a side stream next to the plain rows
-                // (they are a few hundred long waves: alone they would leave most of the chip idle)
+                // hub rows: segment-parallel (MODE 1 + combine) when their segment sums fit a modest scratch, else
+                // one wave per (row, <= 16 probes) walking the segments in turn (MODE 2).  Either way on a side
+                // stream next to the plain rows: alone those few long waves would leave most of the chip idle.
+                const bool par = g->p_n_seg > 0 && long_rows_parallel(g, Hp);
+                const int n_segblocks = par ? g->p_n_seg * rgroups : 0;
+                const int PL = P == 8 ? 8 : 16, lgroups = (nb + PL - 1) / PL;
                 hipStream_t ls = st;
-                if (n_segblocks > 0 && overlap_enabled()) {
+                if (g->p_n_long > 0 && overlap_enabled()) {
                     if (!b->side) {
                         LT_HIP(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
                         LT_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
@@ -966,12 +1017,12 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                     LT_HIP(hipEventRecord(b->ev_fork, st));
                     LT_HIP(hipStreamWaitEvent(ls, b->ev_fork, 0));
                 }
+#define LT_RING_ARGS n, g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p, C, probes, nb, w.Sp, w.S2p
 #define LT_RING_LAUNCH(P_)                                                                                    \
     do {                                                                                                      \
         if (n_segblocks > 0) {                                                                                \
-            LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, P_, true>), dim3(n_segblocks),      \
-                                                   dim3(64), 0, ls, n, g->rowptr, g->col, g->val, b->S1, Hp,  \
-                                                   b->b1p, b->W2p, C, probes, nb, w.Sp, w.S2p, n_segblocks,   \
+            LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, P_, 1>), dim3(n_segblocks),         \
+                                                   dim3(64), 0, ls, LT_RING_ARGS, n_segblocks,                \
                                                    g->p_seg_long, g->p_seg_begin, g->p_long_row, w.lpart));   \
             LT_CHECK_LAUNCH();                                                                                \
             LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_long_combine<CP_, P_>),                             \
@@ -980,16 +1031,30 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                    g->p_long_row, g->p_long_segptr, w.lpart, w.S2p));         \
             LT_CHECK_LAUNCH();                                                                                \
         }                                                                                                     \
-        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, P_, false>), gridr, dim3(64), 0, st, n, \
-                                               g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p, C,       \
-                                               probes, nb, w.Sp, w.S2p, 0, (const int32_t *)nullptr,          \
+        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, P_, 0>), gridr, dim3(64), 0, st,        \
+                                               LT_RING_ARGS, 0, (const int32_t *)nullptr,                     \
                                                (const int32_t *)nullptr, (const int32_t *)nullptr,            \
                                                (float *)nullptr));                                            \
     } while (0)
+#define LT_LONG_LAUNCH(P_)                                                                                    \
+    do {                                                                                                      \
+        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, P_, 2>),                                \
+                                               dim3((unsigned)((long)g->p_n_long * lgroups)), dim3(64), 0,    \
+                                               ls, LT_RING_ARGS, 0, (const int32_t *)nullptr,                 \
+                                               (const int32_t *)nullptr, g->p_long_row, (float *)nullptr));   \
+        LT_CHECK_LAUNCH();                                                                                    \
+    } while (0)
+                if (g->p_n_long > 0 && !par) {
+                    LT_REQUIRE((long)g->p_n_long * lgroups < 2147483647L, "lt_influence_rows: grid limit (long rows)");
+                    if (PL == 8) LT_LONG_LAUNCH(8);
+                    else LT_LONG_LAUNCH(16);
+                }
                 if (P == 8) LT_RING_LAUNCH(8);
                 else if (P == 32) LT_RING_LAUNCH(32);
                 else LT_RING_LAUNCH(16);
 #undef LT_RING_LAUNCH
+#undef LT_LONG_LAUNCH
+#undef LT_RING_ARGS
                 if (ls != st) {
                     LT_HIP(hipEventRecord(b->ev_join, ls));
                     LT_HIP(hipStreamWaitEvent(st, b->ev_join, 0));

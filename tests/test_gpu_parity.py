@@ -412,11 +412,12 @@ def test_full_size_twitch_ru(gpu, n_test, served):
     assert np.all(res["full"][sample][ref64 == 0] == 0)
 
 
-@pytest.mark.parametrize("p", [8, 16, 32])
-def test_every_probes_per_wave_variant(gpu, p, tmp_path):
-    """The wide stage-A kernel exists for 8, 16 and 32 probes per wave (picked from the probe count); each,
-    pinned through LT_FULL_P in a fresh process, must give the bits of `sparse` on a graph with hub rows, for
-    probe counts that leave partial groups."""
+@pytest.mark.parametrize("p,long_par", [(8, 1), (16, 1), (32, 1), (8, 0), (16, 0), (32, 0)])
+def test_every_probes_per_wave_variant(gpu, p, long_par, tmp_path):
+    """The wide stage-A kernel exists for 8, 16 and 32 probes per wave (picked from the probe count), and hub
+    rows take one of two routes (segments in separate waves, LT_LONG_PAR=1, or one wave per row walking its
+    segments, LT_LONG_PAR=0: picked from the size of the graph); each combination, pinned in a fresh process,
+    must give the bits of `sparse` on a graph with hub rows, for probe counts that leave partial groups."""
     import os, subprocess, sys, textwrap
     code = textwrap.dedent('''
         import numpy as np, torch
@@ -424,6 +425,7 @@ def test_every_probes_per_wave_variant(gpu, p, tmp_path):
         adj = synth.powerlaw_graph(700, 4000, seed=5)
         a_hat = graph.first_order_gcn(adj)
         n = adj.shape[0]
+        assert np.diff(a_hat.indptr).max() > 300          # rows of several 128-entry segments
         x = synth.gaussian_features(n, 96, seed=2)
         w = synth.gcn_weights(96, 256, 2, seed=3)
         dev = torch.device("cuda", 0)
@@ -439,7 +441,8 @@ def test_every_probes_per_wave_variant(gpu, p, tmp_path):
             assert np.isfinite(f).all() and f.max() > 0
         print("ok")
     ''')
-    env = dict(os.environ, LT_FULL_P=str(p), PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, LT_FULL_P=str(p), LT_LONG_PAR=str(long_par),
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
