@@ -30,27 +30,28 @@
 #define LT_SB_AHEAD 24                     // FULL stage B: entries in flight per wave (a multiple of LT_L2_LANES)
 
 // ------------------------------------------------------------------------------------------------
-// FULL stage A, narrow hidden widths (LPR < 64): one probe per grid.y, pointer-select substitution
+// FULL stage A, narrow hidden widths (LPR < 64): a lane group per (row, probe), pointer-select substitution
 // ------------------------------------------------------------------------------------------------
 template <int LPR, int CP>
 __global__ __launch_bounds__(LT_BLOCK) void k_full_stageA(
     int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ S1, int Hp,
     const float *__restrict__ b1p, const float *__restrict__ W2p, int C,
-    const int32_t *__restrict__ probes, const float *__restrict__ Sp, float *__restrict__ S2p) {
+    const int32_t *__restrict__ probes, int nbq, const float *__restrict__ Sp, float *__restrict__ S2p) {
+    // One LPR-lane group per (row, column) pair, the column (probe, or nbq = the unperturbed layer) running
+    // fastest: the 64 / LPR groups of a wave mostly share their row, so its S1 gathers are one request for the
+    // whole wave instead of one per probe, and the groups' results are adjacent in S2p.
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
+    const long wave = ((long)blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
     const int gl = lane & (LPR - 1);
-    const int b = blockIdx.y;
-    int r = wave * RPW + lane / LPR;
-    if (LPR == 64) r = __builtin_amdgcn_readfirstlane(r);
+    const int ncol = nbq + 1;
+    const long gid = wave * RPW + lane / LPR;
+    const int r = (int)(gid / ncol), b = (int)(gid % ncol);
     if (r >= n) return;
     const int coff = 4 * gl;
     const bool active = coff < Hp;
     const f32x4 b1v = active ? ld4(b1p + coff) : f32x4{0.f, 0.f, 0.f, 0.f};
-    // grid.y = probes + 1: the last column is the unperturbed layer (the baseline S2 stage B differences against)
-    const int nbq = (int)gridDim.y - 1;
     const f32x4 acc = row_dot(col, val, rowptr[r], rowptr[r + 1], S1, Hp, coff, active, b < nbq ? probes[b] : -1,
                               Sp + (size_t)(b < nbq ? b : 0) * Hp, b1v);
     float part[CP];
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_stageA(
 #pragma unroll
     for (int c = 0; c < CP; ++c) part[c] = group_sum<LPR>(part[c]);
     if (gl == 0) {
-        float *dst = S2p + ((size_t)r * gridDim.y + b) * C;   // [row][probe | baseline][class]
+        float *dst = S2p + ((size_t)r * ncol + b) * C;   // [row][probe | baseline][class]
 #pragma unroll
         for (int c = 0; c < CP; ++c)
             if (c < C) dst[c] = part[c];
@@ -880,6 +881,15 @@ static size_t chunk_budget() {
     return LT_CHUNK_BUDGET;
 }
 
+static int wide_min_hp() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("LT_WIDE_MIN_HP");
+        v = (e && atoi(e) > 0) ? atoi(e) : 24;   // measured on twitch-RU, 500 probes: H = 16: 158 us (narrow) vs 257; H = 32: 359 vs 264
+    }
+    return v;
+}
+
 // Long rows go segment-parallel when the segment sums of ONE probe fit LT_LONG_PAR_BYTES (a graph with a few
 // hubs); a graph where they do not (10^5 long rows) walks each long row in one wave per <= 16 probes.
 #define LT_LONG_PAR_BYTES ((size_t)4 << 20)
@@ -994,7 +1004,9 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
 
         if (mode == LT_MODE_FULL) {
             { lt_prof_scope prof_(LT_K_FULL_A, st);
-            if (lpr == 64) {
+            // the batched (P probes per wave) kernel also serves narrower layers with part of its lanes idle: it
+            // still beats one chain per (row, probe) as soon as the layer has a few dozen columns
+            if (Hp >= wide_min_hp()) {
                 const int P = full_probes_per_wave(nb);
                 const long rblocks = (n + LT_RING_ROWS - 1) / LT_RING_ROWS;
                 const int rgroups = (nb + P - 1) / P;
@@ -1060,11 +1072,12 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                     LT_HIP(hipStreamWaitEvent(st, b->ev_join, 0));
                 }
             } else {
-                const int rpb = (LT_BLOCK / 64) * (64 / lpr);
-                dim3 grid((n + rpb - 1) / rpb, nb + 1);   // + the baseline column
+                const long gpb = (LT_BLOCK / 64) * (64 / lpr);               // (row, column) groups per block
+                const long blocks = ((long)n * (nb + 1) + gpb - 1) / gpb;    // columns = probes + the baseline
+                LT_REQUIRE(blocks < 2147483647L, "lt_influence_rows: n * probes exceeds the grid limit");
                 LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
-                    hipLaunchKernelGGL((k_full_stageA<LPR_, CP_>), grid, dim3(LT_BLOCK), 0, st, n,
-                                       g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p, C, probes,
+                    hipLaunchKernelGGL((k_full_stageA<LPR_, CP_>), dim3((unsigned)blocks), dim3(LT_BLOCK), 0, st, n,
+                                       g->rowptr, g->col, g->val, b->S1, Hp, b->b1p, b->W2p, C, probes, nb,
                                        w.Sp, w.S2p)));
             } }
             LT_CHECK_LAUNCH();
