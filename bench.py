@@ -38,6 +38,7 @@ def parse():
     p.add_argument("--workload", default="twitch-RU", choices=["twitch-RU", "twitch-ES"])
     p.add_argument("--n-test", type=int, default=500)
     p.add_argument("--hidden", type=int, default=256)
+    p.add_argument("--classes", type=int, default=2, help="output classes (twitch: 2)")
     p.add_argument("--mode", default="full", choices=["full", "sparse", "delta"])
     p.add_argument("--powerlaw", action="store_true", help="hub-heavy graph instead of Erdos-Renyi")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -88,11 +89,11 @@ def main():
     from linkteller_amd import dist as lt_dist
 
     # ---------------- workload (identical on every rank: seeded) ----------------
-    adj, x_np, w = synth.twitch_like_problem(a.workload, hidden=a.hidden, n_classes=2, seed=0,
+    adj, x_np, w = synth.twitch_like_problem(a.workload, hidden=a.hidden, n_classes=a.classes, seed=0,
                                              powerlaw=a.powerlaw)
     a_hat = graph.first_order_gcn(adj)
     n, f = x_np.shape
-    h, c = a.hidden, 2
+    h, c = a.hidden, a.classes
     nnz = a_hat.nnz
     np.random.seed(42)
     test_nodes = np.random.choice(np.arange(n), a.n_test, replace=False)
@@ -228,7 +229,7 @@ def main():
         # the same build on a hub-heavy graph of the same size (the real MUSAE graphs are heavy-tailed; the
         # headline graph is Erdos-Renyi as in SURVEY 8(d)): reported next to `value`, never instead of it
         if not a.powerlaw:
-            adj_h, _, _ = synth.twitch_like_problem(a.workload, hidden=a.hidden, n_classes=2, seed=0, powerlaw=True)
+            adj_h, _, _ = synth.twitch_like_problem(a.workload, hidden=a.hidden, n_classes=a.classes, seed=0, powerlaw=True)
             ah = graph.first_order_gcn(adj_h)
             base_h = engine.Baseline(graph.HipGraph(ah), x, *params)
             out_h = torch.empty((a.n_test, a.n_test), dtype=torch.float32, device=dev)
