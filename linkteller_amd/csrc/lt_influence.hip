@@ -27,6 +27,7 @@
 #define LT_BLOCK 256
 #define LT_CHUNK_BUDGET ((size_t)1 << 30)  // bytes of per-probe scratch per chunk
 #define LT_ITEM_GRID 2048                  // blocks of the grid-stride item kernels
+#define LT_BITS_MAX_BYTES ((size_t)64 << 20)  // stage B of the item modes tests membership in R_v through a bitmap up to this size
 #define LT_SB_AHEAD 24                     // FULL stage B: entries in flight per wave (a multiple of LT_L2_LANES)
 
 // ------------------------------------------------------------------------------------------------
@@ -781,6 +782,21 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
     }
 }
 
+// bits[b][r >> 5] bit (r & 31) = 1  <=>  r in R_v of probe b: one load tells stage B whether an entry of an
+// observed row can be affected by the probe (a binary search in R_v otherwise); one block per probe
+__global__ __launch_bounds__(256) void k_item_bits(const int32_t *__restrict__ tptr, const int32_t *__restrict__ trow,
+                                                   const int32_t *__restrict__ probes, int words,
+                                                   uint32_t *__restrict__ bits) {
+    uint32_t *mine = bits + (size_t)blockIdx.x * words;
+    for (int i = threadIdx.x; i < words; i += blockDim.x) mine[i] = 0u;
+    __syncthreads();
+    const int v = probes[blockIdx.x];
+    for (int t = tptr[v] + threadIdx.x; t < tptr[v + 1]; t += blockDim.x) {
+        const int r = trow[t];
+        atomicOr(&mine[r >> 5], 1u << (r & 31));
+    }
+}
+
 // SPARSE / DELTA stage B: 8 lanes per (probe, observed node).
 template <int CP, bool DELTA>
 __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
@@ -790,7 +806,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
     const float *__restrict__ b2, const float *__restrict__ OUT,
     const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
     const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
-    float *__restrict__ out, long ldo) {
+    float *__restrict__ out, long ldo, const uint32_t *__restrict__ bits, int words) {
     const long gid = ((long)blockIdx.x * LT_BLOCK + threadIdx.x) / LT_L2_LANES;
     const int q = threadIdx.x & (LT_L2_LANES - 1);
     if (gid >= (long)nb * n_obs) return;
@@ -803,8 +819,11 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
     const int e0 = rowptr[u], e1 = rowptr[u + 1];
 
     // does row u touch R_v at all?  (otherwise the perturbed logits ARE the baseline logits)
+    const uint32_t *mb = bits ? bits + (size_t)b * words : nullptr;
+    // membership of column c in R_v: the bitmap when there is one, the search otherwise
+    auto member = [&](int c) { return mb ? ((mb[c >> 5] >> (c & 31)) & 1u) != 0u : find_row(rv, cnt, c) >= 0; };
     bool touch = false;
-    for (int e = e0 + q; e < e1; e += LT_L2_LANES) touch |= find_row(rv, cnt, col[e]) >= 0;
+    for (int e = e0 + q; e < e1; e += LT_L2_LANES) touch |= member(col[e]);
     // 8-lane any(): xor butterfly on an int
     int t = touch ? 1 : 0;
 #pragma unroll
@@ -816,7 +835,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
             // d_out[c] = sum over e with col[e] in R_v of val[e] * dS2[item(col[e]), c]
             row2_dot<CP>(col, val, e0, e1, q, C,
                          [&](int c, int) {
-                             const int p = find_row(rv, cnt, c);
+                             const int p = (!mb || member(c)) ? find_row(rv, cnt, c) : -1;
                              return p >= 0 ? items + (size_t)p * C : (const float *)nullptr;
                          },
                          acc);
@@ -831,7 +850,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
         } else {
             row2_dot<CP>(col, val, e0, e1, q, C,
                          [&](int c, int) {
-                             const int p = find_row(rv, cnt, c);
+                             const int p = (!mb || member(c)) ? find_row(rv, cnt, c) : -1;
                              return p >= 0 ? items + (size_t)p * C : S2 + (size_t)c * C;
                          },
                          acc);
@@ -909,6 +928,7 @@ struct infl_ws {
     float *slabs;          // FULL / SPARSE: split-K partials of the perturbed-row GEMM
     float *S2x;            // SPARSE / DELTA: per-item values
     int32_t *off;          // SPARSE / DELTA: item offsets [chunk + 1]
+    uint32_t *bits;        // SPARSE / DELTA: membership bitmap of R_v per probe [chunk][ceil(n / 32)], or NULL (huge graphs)
     size_t bytes;
     int chunk;
 };
@@ -947,6 +967,10 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
     if (mode != LT_MODE_FULL) {
         w.S2x = (float *)take(chunk * maxc * C * sizeof(float));
         w.off = (int32_t *)take((chunk + 1) * sizeof(int32_t));
+        const size_t bw = (n + 31) / 32;
+        // (LT_ITEM_BITS=0 forces the search path a huge graph takes: tests)
+        static const bool no_bits = getenv("LT_ITEM_BITS") && atoi(getenv("LT_ITEM_BITS")) == 0;
+        w.bits = (!no_bits && chunk * bw * sizeof(uint32_t) <= LT_BITS_MAX_BYTES) ? (uint32_t *)take(chunk * bw * sizeof(uint32_t)) : nullptr;
     }
     w.bytes = offb;
     return w;
@@ -1096,6 +1120,11 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
         } else {
             hipLaunchKernelGGL(k_probe_offsets, dim3(1), dim3(1024), 0, st, g->tptr, probes, nb, w.off);
             LT_CHECK_LAUNCH();
+            const int words = (n + 31) / 32;
+            if (w.bits) {
+                hipLaunchKernelGGL(k_item_bits, dim3(nb), dim3(256), 0, st, g->tptr, g->trow, probes, words, w.bits);
+                LT_CHECK_LAUNCH();
+            }
             if (mode == LT_MODE_SPARSE) {
                 { lt_prof_scope prof_(LT_K_ITEM_A, st);
                 LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
@@ -1110,7 +1139,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
                                                        g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
                                                        nb, w.off, w.S2x, observe_nodes, n_obs, delta,
-                                                       orow, (long)ldo));
+                                                       orow, (long)ldo, w.bits, words));
             } else {
                 { lt_prof_scope prof_(LT_K_ITEM_A, st);
                 if (b->Z1d) {
@@ -1134,7 +1163,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
                                                        g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
                                                        nb, w.off, w.S2x, observe_nodes, n_obs, delta,
-                                                       orow, (long)ldo));
+                                                       orow, (long)ldo, w.bits, words));
             }
             LT_CHECK_LAUNCH();
         }

@@ -441,7 +441,7 @@ def test_every_probes_per_wave_variant(gpu, p, long_par, tmp_path):
             assert np.isfinite(f).all() and f.max() > 0
         print("ok")
     ''')
-    env = dict(os.environ, LT_FULL_P=str(p), LT_LONG_PAR=str(long_par),
+    env = dict(os.environ, LT_FULL_P=str(p), LT_LONG_PAR=str(long_par), LT_ITEM_BITS=str(long_par),   # 0: no bitmap either
                PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
