@@ -66,6 +66,8 @@ def main():
         ref32 = oracle_matrix(a_hat, x, w, probes, observe, 1e-4, torch.float32)
         scale = max(ref64.max(), 1e-6)
         res = {m: base.influence_rows(probes, observe, 1e-4, m).cpu().numpy().astype(np.float64) for m in ("full", "sparse", "delta")}
+        logits_ref = O.gcn_forward(torch.from_numpy(x).double(), O.to_torch_sparse(a_hat).double(),
+                                   {k: torch.from_numpy(w[k]).double() for k in ("W1", "b1", "W2", "b2")}).numpy()
         tag = f"case {it}: {kind} n={n} H={h} C={c} F={f} {norm} probes={len(probes)} obs={len(observe)} maxdeg={int(np.diff(a_hat.indptr).max())}"
         assert np.array_equal(res["full"], res["sparse"]), tag
         ed = np.abs(res["delta"] - ref64).max() / scale
@@ -73,7 +75,12 @@ def main():
         ef, e32 = np.abs(res["full"] - ref64).max(), np.abs(ref32 - ref64).max()
         if ef > 3.0 * e32 + 1e-4 * scale:
             print("NOISE?", tag, f"|full-ref64| {ef:.3e}  |ref32-ref64| {e32:.3e}  scale {scale:.3e}  nonzeros {(ref64 > 0).sum()}")
-        assert ef <= 10.0 * e32 + 1e-3 * scale, tag
+        # absolute floor: an fp32 finite difference carries ~ eps * |logit| / delta = 6e-4 * |logit| of noise whatever
+        # the score is; a one-entry sample of the oracle's own noise can be anything
+        floor = 6e-4 * max(1.0, float(np.abs(logits_ref).max()))
+        if ef > 10.0 * e32 + 1e-3 * scale + 3.0 * floor:
+            print("FAIL", tag, f"|full-ref64| {ef:.3e}  |ref32-ref64| {e32:.3e}  scale {scale:.3e}  floor {floor:.3e}")
+            raise SystemExit(1)
         for r in res.values():
             assert np.all(r[ref64 == 0] == 0), tag
         logits = base.logits().cpu().numpy().astype(np.float64)
