@@ -213,7 +213,7 @@ def main():
                                 "traffic is ~30x lower and frac may exceed 1: the binding resource is fp32 FMA issue")
             roofline["fp32_fma"] = {"achieved_tflops": round(fma / avg_s / 1e12, 1), "peak_tflops": 157.3,
                                     "frac": round(fma / avg_s / 1e12 / 157.3, 3)}
-        if "gemm" in per_kernel:
+        if "gemm" in per_kernel and a.mode != "delta":   # (delta also times its fp64 product in this class)
             # the two f32 MFMA products of a step (X*W1 and the probe rows), split-K slab sums included in the time
             gflop = 2.0 * (n + n_probe_local) * f * h
             gsec = per_kernel["gemm"]["avg_us"] * per_kernel["gemm"]["launches"] / a.steps * 1e-6
