@@ -139,3 +139,27 @@ def twitch_like_problem(name: str = "twitch-RU", hidden: int = 256, n_classes: i
     x = twitch_like_features(shp["n"], n_features, seed=seed + 1)
     w = gcn_weights(n_features, hidden, n_classes, seed=42)
     return adj, x, w
+
+
+def write_musae_dataset(root: str, code: str, adj, n_feat_ids: int, seed: int):
+    """Writes ``<root>/twitch/<code>/musae_<code>_{features.json,edges.csv,target.csv}`` in the MUSAE layout
+    the reference reads (utils/load.py:47, 63, 455): a JSON dict node -> list of feature ids, an edge list with
+    one line per undirected edge, and a target table whose rows are in shuffled order (``new_id`` is the node).
+    Synthetic content, seeded; returns the feature dict."""
+    import json
+    import os
+    rng = np.random.RandomState(seed)
+    d = os.path.join(root, "twitch", code)
+    os.makedirs(d)
+    n = adj.shape[0]
+    feats = {str(i): sorted(rng.choice(n_feat_ids, rng.randint(1, 6), replace=False).tolist()) for i in range(n)}
+    with open(os.path.join(d, f"musae_{code}_features.json"), "w") as fh:
+        json.dump(feats, fh)
+    coo = sp.triu(adj, k=1).tocoo()
+    with open(os.path.join(d, f"musae_{code}_edges.csv"), "w") as fh:
+        fh.write("from,to\n" + "".join(f"{i},{j}\n" for i, j in zip(coo.row, coo.col)))
+    perm = rng.permutation(n)
+    with open(os.path.join(d, f"musae_{code}_target.csv"), "w") as fh:
+        fh.write("id,days,mature,views,partner,new_id\n" +
+                 "".join(f"{1000 + i},1,{bool(i % 3 == 0)},5,False,{i}\n" for i in perm))
+    return feats

@@ -432,9 +432,58 @@ def gen_next_rows():
     save("next_rows.npz", **out)
 
 
+# ----------------------------------------------------------------------------------------
+# (7) the twitch transfer loader: feature_reader / graph_reader / Worker twitch branch
+#     utils/load.py:42-93, 452-460; worker.py:470-496, 549-552, 631-645
+# ----------------------------------------------------------------------------------------
+def gen_loader():
+    """The reference's own ``Worker`` reads a tiny synthetic MUSAE tree (written by
+    ``synth.write_musae_dataset``, whose file texts are stored so the test rebuilds exactly these files)
+    from ``./data`` of a temporary working directory; everything it exposes to the attack is stored."""
+    out = {}
+    a1, a2 = synth.powerlaw_graph(220, 500, seed=61), synth.erdos_renyi_graph(200, 450, seed=62)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as td:
+        synth.write_musae_dataset(os.path.join(td, "data"), "ES", a1, 60, 1)
+        synth.write_musae_dataset(os.path.join(td, "data"), "RU", a2, 60, 2)
+        for code in ("ES", "RU"):
+            for kind in ("features.json", "edges.csv", "target.csv"):
+                with open(os.path.join(td, "data", "twitch", code, f"musae_{code}_{kind}")) as fh:
+                    out[f"file.{code}.{kind}"] = np.array(fh.read())
+        os.chdir(td)
+        cuda_was = torch.cuda.is_available
+        torch.cuda.is_available = lambda: False
+        try:
+            for mode, tag in (("vanilla-clean", "clean"), ("vanilla", "lap5")):
+                args = argparse.Namespace(mode=mode, norm="FirstOrderGCN", perturb_type="continuous", epsilon=5.0,
+                                          noise_seed=42, noise_type="laplace", delta=1e-5)
+                w = quiet(ref_worker.Worker, args, dataset="twitch/ES/RU", mode=mode)
+                if tag == "clean":
+                    out["features_1"] = w.features_1.numpy()
+                    out["features_2"] = w.features_2.numpy()
+                    out["labels_1"] = w.labels_1.numpy()
+                    out["labels_2"] = w.labels_2.numpy()
+                    out["sizes"] = np.array([w.n_nodes_1, w.n_nodes_2, w.n_features, w.n_classes, w.multi_label],
+                                            dtype=np.int64)
+                    for k, v in csr_parts(w.adj_ori).items():
+                        out[f"adj_ori.{k}"] = v
+                    out["adj_ori.dtype"] = np.array(str(w.adj_ori.dtype))
+                for name in ("adj_1", "adj_2"):
+                    t = getattr(w, name).coalesce()
+                    out[f"{tag}.{name}.indices"] = t.indices().numpy()
+                    out[f"{tag}.{name}.values"] = t.values().numpy()
+                    out[f"{tag}.{name}.shape"] = np.array(t.shape, dtype=np.int64)
+                # the clean graph stays the ground truth for the pairs (worker.py:552)
+                assert (w.adj_ori != (a2 + 0)).nnz == 0
+        finally:
+            torch.cuda.is_available = cuda_was
+            os.chdir(cwd)
+    save("twitch_loader.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["normalizer", "forward", "sampler", "influence", "dp", "next"]
+    which = sys.argv[1:] or ["normalizer", "forward", "sampler", "influence", "dp", "next", "loader"]
     for w in which:
         print(f"[{w}]")
         {"normalizer": gen_normalizer, "forward": gen_forward, "sampler": gen_sampler,
-         "influence": gen_influence, "dp": gen_dp, "next": gen_next_rows}[w]()
+         "influence": gen_influence, "dp": gen_dp, "next": gen_next_rows, "loader": gen_loader}[w]()

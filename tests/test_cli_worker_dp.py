@@ -50,20 +50,7 @@ def test_dp_generators_match_reference():
 
 
 def _write_musae(root, code, adj, n_feat_ids, seed):
-    rng = np.random.RandomState(seed)
-    d = os.path.join(root, "twitch", code)
-    os.makedirs(d)
-    n = adj.shape[0]
-    feats = {str(i): sorted(rng.choice(n_feat_ids, rng.randint(1, 6), replace=False).tolist()) for i in range(n)}
-    json.dump(feats, open(os.path.join(d, f"musae_{code}_features.json"), "w"))
-    coo = sp.triu(adj, k=1).tocoo()
-    with open(os.path.join(d, f"musae_{code}_edges.csv"), "w") as fh:
-        fh.write("from,to\n" + "".join(f"{i},{j}\n" for i, j in zip(coo.row, coo.col)))
-    perm = rng.permutation(n)
-    with open(os.path.join(d, f"musae_{code}_target.csv"), "w") as fh:
-        fh.write("id,days,mature,views,partner,new_id\n" +
-                 "".join(f"{1000 + i},1,{bool(i % 3 == 0)},5,False,{i}\n" for i in perm))
-    return feats
+    return synth.write_musae_dataset(root, code, adj, n_feat_ids, seed)
 
 
 def test_twitch_worker_reads_musae_layout(tmp_path, monkeypatch):
@@ -79,8 +66,16 @@ def test_twitch_worker_reads_musae_layout(tmp_path, monkeypatch):
     assert (w.adj_ori != a2).nnz == 0 and w.adj_ori.dtype == np.float32
     assert w.features_2.shape == (30, 3170) and w.features_2.dtype == torch.float32
     assert w.labels_2.tolist() == [int(i % 3 == 0) for i in range(30)]
-    # standardised with graph-1 statistics: a feature id never used in ES keeps mean 0 / scale 1
-    raw = np.zeros((30, 3170)); [raw.__setitem__((int(i), v), 1) for i, v in f2.items()]
+    # standardised with graph-1 statistics (worker.py:486-490): recompute from the raw indicator matrices
+    raw1 = np.zeros((40, 3170)); raw2 = np.zeros((30, 3170))
+    for i, v in json.load(open(tmp_path / "twitch" / "ES" / "musae_ES_features.json")).items():
+        raw1[int(i), v] = 1
+    for i, v in f2.items():
+        raw2[int(i), v] = 1
+    mu, sd = raw1.mean(0), raw1.std(0)
+    sd[sd == 0] = 1.0
+    assert np.allclose(w.features_2.numpy(), ((raw2 - mu) / sd).astype(np.float32), atol=1e-6)
+    assert np.allclose(w.features_1.numpy(), ((raw1 - mu) / sd).astype(np.float32), atol=1e-6)
     assert w.adj_2.is_sparse and w.adj_2.shape == (30, 30)
     dense = w.adj_2.to_dense().numpy()
     deg = np.asarray(a2.sum(1)).ravel()
@@ -91,3 +86,38 @@ def test_twitch_worker_reads_musae_layout(tmp_path, monkeypatch):
     assert not np.allclose(w2.adj_2.to_dense().numpy(), dense)
     with pytest.raises(NotImplementedError):
         Worker(args, dataset="cora", mode="vanilla-clean", data_root=str(tmp_path))
+
+
+def test_twitch_worker_matches_reference_loader(tmp_path, monkeypatch):
+    """tests/golden/twitch_loader.npz holds what the REFERENCE's Worker (feature_reader + graph_reader +
+    StandardScaler + normaliser, worker.py:470-496, 549-552, 631-645; utils/load.py:42-93, 452-460) produced
+    from the MUSAE files stored in the same fixture; our Worker must reproduce every array bit for bit, for
+    the clean and for the LapGraph-served (mode 'vanilla', eps = 5) setting."""
+    from linkteller_amd.worker import Worker
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    g = load_golden("twitch_loader.npz")
+    for code in ("ES", "RU"):
+        d = tmp_path / "twitch" / code
+        d.mkdir(parents=True)
+        for kind in ("features.json", "edges.csv", "target.csv"):
+            (d / f"musae_{code}_{kind}").write_text(str(g[f"file.{code}.{kind}"]))
+    for mode, tag in (("vanilla-clean", "clean"), ("vanilla", "lap5")):
+        args = argparse.Namespace(mode=mode, norm="FirstOrderGCN", perturb_type="continuous", epsilon=5.0,
+                                  noise_seed=42, noise_type="laplace", delta=1e-5)
+        w = Worker(args, dataset="twitch/ES/RU", mode=mode, data_root=str(tmp_path))
+        assert w.features_1.dtype == torch.float32 and w.features_2.dtype == torch.float32
+        assert np.array_equal(w.features_1.numpy(), g["features_1"])
+        assert np.array_equal(w.features_2.numpy(), g["features_2"])
+        assert np.array_equal(w.labels_1.numpy(), g["labels_1"]) and np.array_equal(w.labels_2.numpy(), g["labels_2"])
+        assert [w.n_nodes_1, w.n_nodes_2, w.n_features, w.n_classes, w.multi_label] == g["sizes"].tolist()
+        assert w.n_nodes == w.n_nodes_2
+        ori = sp.csr_matrix(w.adj_ori); ori.sort_indices()
+        assert str(ori.dtype) == str(g["adj_ori.dtype"])
+        assert np.array_equal(ori.indptr, g["adj_ori.indptr"]) and np.array_equal(ori.indices, g["adj_ori.indices"])
+        assert np.array_equal(ori.data, g["adj_ori.data"])
+        for name in ("adj_1", "adj_2"):
+            t = getattr(w, name).coalesce()
+            assert t.dtype == torch.float32
+            assert list(t.shape) == g[f"{tag}.{name}.shape"].tolist()
+            assert np.array_equal(t.indices().numpy(), g[f"{tag}.{name}.indices"]), (tag, name)
+            assert np.array_equal(t.values().numpy(), g[f"{tag}.{name}.values"]), (tag, name)

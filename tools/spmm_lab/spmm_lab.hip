@@ -1,0 +1,439 @@
+// spmm_lab -- development harness for the CSR SpMM  out[n,H] = A_hat * S  on R-MAT graphs (BASELINE configs[4]
+// shape).  Not part of the product: it times candidate kernels against the library's lt_spmm_csr_f32 on the same
+// device arrays and checks them bit for bit against it (every variant keeps the k-ordered fmaf chain per output
+// column).  Build: make -C tools/spmm_lab ; run: tools/spmm_lab/spmm_lab <scale> [edge_factor] [H] [reps] [variants]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <math.h>
+#include <algorithm>
+#include <functional>
+#include <type_traits>
+#include <chrono>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "linkteller_hip.h"
+
+#define CK(call)                                                                                   \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            fprintf(stderr, "%s failed: %s (%s:%d)\n", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                                               \
+        }                                                                                          \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 fma4(float a, f32x4 s, f32x4 acc) {
+    acc.x = fmaf(a, s.x, acc.x); acc.y = fmaf(a, s.y, acc.y);
+    acc.z = fmaf(a, s.z, acc.z); acc.w = fmaf(a, s.w, acc.w);
+    return acc;
+}
+
+// lane k of the GL-lane group this lane belongs to
+template <int GL>
+__device__ __forceinline__ int bcast_i(int x, int k) {
+    if constexpr (GL == 64) return __builtin_amdgcn_readlane(x, k);
+    else return __shfl(x, k, GL);
+}
+template <int GL, int K>
+__device__ __forceinline__ int bcast_c(int x) {
+    if constexpr (GL == 16) return __builtin_amdgcn_update_dpp(0, x, 0x150 + K, 0xf, 0xf, false);   // row_newbcast:K
+    else return bcast_i<GL>(x, K);
+}
+
+template <int N, typename F, int I = 0>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, F, I + 1>(static_cast<F &&>(f));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// work items: (first entry, entry count, destination row in `out` -- or n + segment id in `partial`)
+// sorted by length class, longest first; a row of more than SEG entries is cut into segments
+// ------------------------------------------------------------------------------------------------
+struct Work {
+    int n_items = 0;
+    int32_t *e0 = nullptr, *cnt = nullptr, *dst = nullptr;   // device
+    int n_long = 0, n_seg = 0;
+    int32_t *long_row = nullptr, *long_segptr = nullptr;       // device
+    float *partial = nullptr;                                  // [n_seg, H]
+};
+
+// Sliced SpMM.  A GL-lane group owns one work item (row / segment) x one slice of 4*GL columns; the slice is
+// chosen from the XCD the block lands on (blocks are dealt round-robin over the 8 XCDs), so an XCD's L2 only
+// ever sees 1/NS of S.
+// cache policy of a gather.  POL 0: plain; 1: nt; 2: sc1; 3: sc0 sc1; 4: sc1 nt
+template <int POL>
+__device__ __forceinline__ void gload(f32x4 &d, unsigned off, const char *base) {
+    if constexpr (POL == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(off), "s"(base) : "memory");
+    else if constexpr (POL == 1) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(d) : "v"(off), "s"(base) : "memory");
+    else if constexpr (POL == 2) asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(d) : "v"(off), "s"(base) : "memory");
+    else if constexpr (POL == 3) asm volatile("global_load_dwordx4 %0, %1, %2 sc0 sc1" : "=v"(d) : "v"(off), "s"(base) : "memory");
+    else if constexpr (POL == 4) asm volatile("global_load_dwordx4 %0, %1, %2 sc1 nt" : "=v"(d) : "v"(off), "s"(base) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(off), "s"(base) : "memory");
+}
+
+// HINT 0: compiler-managed plain gathers.  HINT > 0: bit 31 of a column index marks a COLD column (few readers): its
+// gather uses cache policy HINT, hot columns use plain loads; all gathers are inline asm with one explicit wait.
+// SEQ: blocks walk the slices one after the other (all XCDs on one slice at a time) instead of slice = f(XCD).
+template <int GL, int U, bool NT, bool SORTED, int HINT = 0, bool SEQ = false>
+__global__ __launch_bounds__(256) void k_spmm_sliced(
+    int n_items, const int32_t *__restrict__ w_e0, const int32_t *__restrict__ w_cnt,
+    const int32_t *__restrict__ w_dst, const int32_t *__restrict__ rowptr, int n,
+    const int32_t *__restrict__ col, const float *__restrict__ val,
+    const float *__restrict__ S, int lds, int ncols, float *__restrict__ out, int ldo,
+    float *__restrict__ partial, int ldp, int ns /* slices */) {
+    constexpr int GPW = 64 / GL;            // groups per wave
+    constexpr int IPB = 4 * GPW;            // items per block
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int j = lane & (GL - 1);
+    int slice, chunk;
+    if (SEQ) {
+        const int bps = gridDim.x / ns;     // blocks per slice
+        slice = blockIdx.x / bps;
+        chunk = blockIdx.x % bps;
+    } else {
+        const int xcd = blockIdx.x & 7;
+        const int q = blockIdx.x >> 3;
+        const int xps = 8 / ns;             // XCDs per slice
+        slice = xcd % ns;
+        chunk = q * xps + xcd / ns;
+    }
+    int it = chunk * IPB + wv * GPW + lane / GL;
+    if (GL == 64) it = __builtin_amdgcn_readfirstlane(it);
+    if (it >= n_items) return;
+    int e0, cnt, dst;
+    if (SORTED) { e0 = w_e0[it]; cnt = w_cnt[it]; dst = w_dst[it]; }
+    else { e0 = rowptr[it]; cnt = rowptr[it + 1] - e0; dst = it; }
+    const int coff = slice * 4 * GL + 4 * j;
+    const bool active = coff < ncols;
+    const unsigned rowbytes = (unsigned)lds * 4u;
+    const unsigned loff = (unsigned)coff * 4u;
+    const char *Sb = reinterpret_cast<const char *>(S);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int e1 = e0 + cnt;
+    for (int eb = e0; eb < e1; eb += GL) {
+        const int me = eb + j;
+        int myc = 0;
+        float mya = 0.f;
+        if (me < e1) {
+            if (NT) { myc = __builtin_nontemporal_load(col + me); mya = __builtin_nontemporal_load(val + me); }
+            else { myc = col[me]; mya = val[me]; }
+        }
+        const int left = e1 - eb;
+        static_for<GL / U>([&](auto kbt) {
+            constexpr int kb = decltype(kbt)::value * U;
+            if (kb < left) {
+                f32x4 s[U];
+                float a[U];
+                static_for<U>([&](auto ut) {
+                    constexpr int u = decltype(ut)::value;
+                    constexpr int k = kb + u;
+                    const int ch = bcast_c<GL, k>(myc);
+                    const int c = HINT ? (ch & 0x7fffffff) : ch;
+                    a[u] = __builtin_bit_cast(float, bcast_c<GL, k>(__builtin_bit_cast(int, mya)));
+                    s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (k < left && active) {
+                        if constexpr (HINT == 0) {
+                            s[u] = *reinterpret_cast<const f32x4 *>(Sb + (size_t)((unsigned)c * rowbytes + loff));
+                        } else {
+                            const unsigned off = (unsigned)c * rowbytes + loff;
+                            if (ch < 0) gload<HINT>(s[u], off, Sb);
+                            else gload<0>(s[u], off, Sb);
+                        }
+                    }
+                });
+                if constexpr (HINT != 0) {
+                    static_assert(U == 8 || U == 4, "explicit wait written for 4 or 8 gathers");
+                    if constexpr (U == 8)
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]));
+                    else
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]));
+                }
+                static_for<U>([&](auto ut) {
+                    constexpr int u = decltype(ut)::value;
+                    if (kb + u < left) acc = fma4(a[u], s[u], acc);
+                });
+            }
+        });
+    }
+    if (!active) return;
+    float *d = dst < n ? out + (size_t)dst * ldo + coff : partial + (size_t)(dst - n) * ldp + coff;
+    if (NT) __builtin_nontemporal_store(acc, reinterpret_cast<f32x4 *>(d));
+    else *reinterpret_cast<f32x4 *>(d) = acc;
+}
+
+// long rows: partials added in segment order
+__global__ void k_combine(int n_long, const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_segptr,
+                          const float *__restrict__ partial, int ldp, int ncols, float *__restrict__ out, int ldo) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_long * ncols) return;
+    const int li = i / ncols, c = i % ncols;
+    float acc = partial[(size_t)long_segptr[li] * ldp + c];
+    for (int sg = long_segptr[li] + 1; sg < long_segptr[li + 1]; ++sg) acc += partial[(size_t)sg * ldp + c];
+    out[(size_t)long_row[li] * ldo + c] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host: R-MAT graph -> symmetric, deduplicated, + I, FirstOrderGCN-like values
+// ------------------------------------------------------------------------------------------------
+struct HostCsr {
+    int n = 0;
+    std::vector<int32_t> rowptr, col;
+    std::vector<float> val;
+};
+
+static HostCsr make_rmat(int scale, long draws, uint64_t seed) {
+    const int n = 1 << scale;
+    std::mt19937_64 rng(seed);
+    std::vector<uint64_t> keys;
+    keys.reserve((size_t)draws * 2 + n);
+    std::uniform_real_distribution<double> U(0.0, 1.0);
+    for (long i = 0; i < draws; ++i) {
+        uint64_t r = 0, c = 0;
+        for (int b = 0; b < scale; ++b) {
+            const double x = U(rng);
+            // a 0.57 -> (0,0), b 0.19 -> (0,1), c 0.19 -> (1,0), d 0.05 -> (1,1)
+            const int down = x >= 0.76, right = (x >= 0.57 && x < 0.76) || x >= 0.95;
+            r |= (uint64_t)down << b;
+            c |= (uint64_t)right << b;
+        }
+        if (r == c) continue;
+        keys.push_back(r << 32 | c);
+        keys.push_back(c << 32 | r);
+    }
+    for (int i = 0; i < n; ++i) keys.push_back((uint64_t)i << 32 | (uint64_t)i);
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    HostCsr g;
+    g.n = n;
+    g.rowptr.assign((size_t)n + 1, 0);
+    g.col.resize(keys.size());
+    g.val.resize(keys.size());
+    for (size_t i = 0; i < keys.size(); ++i) {
+        g.rowptr[(keys[i] >> 32) + 1]++;
+        g.col[i] = (int32_t)(keys[i] & 0xffffffffu);
+    }
+    for (int i = 0; i < n; ++i) g.rowptr[i + 1] += g.rowptr[i];
+    std::vector<float> dinv((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const int d = g.rowptr[i + 1] - g.rowptr[i] - 1;
+        dinv[i] = d > 0 ? 1.0f / sqrtf((float)d) : 0.f;
+    }
+    for (int r = 0; r < n; ++r)
+        for (int e = g.rowptr[r]; e < g.rowptr[r + 1]; ++e)
+            g.val[e] = g.col[e] == r ? 1.0f : dinv[r] * dinv[g.col[e]];
+    return g;
+}
+
+template <typename T>
+static T *upload(const std::vector<T> &v, size_t pad = 0) {
+    T *d = nullptr;
+    CK(hipMalloc((void **)&d, (v.size() + pad) * sizeof(T) + 16));
+    CK(hipMemset(d, 0, (v.size() + pad) * sizeof(T) + 16));
+    if (!v.empty()) CK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+}
+
+static Work build_work(const HostCsr &g, int H, int SEG) {
+    Work w;
+    struct Item { int32_t e0, cnt, dst; };
+    std::vector<Item> items;
+    std::vector<int32_t> lrow, lptr(1, 0);
+    int nseg = 0;
+    for (int r = 0; r < g.n; ++r) {
+        const int d = g.rowptr[r + 1] - g.rowptr[r];
+        if (d <= SEG) { items.push_back({g.rowptr[r], d, r}); continue; }
+        lrow.push_back(r);
+        for (int b = g.rowptr[r]; b < g.rowptr[r + 1]; b += SEG) {
+            items.push_back({b, std::min(SEG, g.rowptr[r + 1] - b), g.n + nseg});
+            ++nseg;
+        }
+        lptr.push_back(nseg);
+    }
+    // length classes (ceil(cnt / 16) blocks), longest first, natural order inside a class
+    std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return (a.cnt + 15) / 16 > (b.cnt + 15) / 16; });
+    std::vector<int32_t> e0(items.size()), cnt(items.size()), dst(items.size());
+    for (size_t i = 0; i < items.size(); ++i) { e0[i] = items[i].e0; cnt[i] = items[i].cnt; dst[i] = items[i].dst; }
+    w.n_items = (int)items.size();
+    w.e0 = upload(e0); w.cnt = upload(cnt); w.dst = upload(dst);
+    w.n_long = (int)lrow.size(); w.n_seg = nseg;
+    w.long_row = upload(lrow); w.long_segptr = upload(lptr);
+    CK(hipMalloc((void **)&w.partial, (size_t)std::max(nseg, 1) * H * sizeof(float)));
+    return w;
+}
+
+struct Ctx {
+    HostCsr *g; int H;
+    int32_t *rowptr, *col; float *val, *S, *out, *ref;
+    int32_t *colh[4];   // col with bit 31 set on cold columns, for hot sets of 8K / 12K / 16K / 24K columns
+    Work work;
+    lt_graph *lg;
+};
+
+template <int GL, int U, bool NT, bool SORTED, int HINT = 0, bool SEQ = false, int HOTSET = 0>
+static void run_sliced(Ctx &c, hipStream_t st) {
+    const int ns = c.H / (4 * GL) > 0 ? (c.H + 4 * GL - 1) / (4 * GL) : 1;
+    const int xps = 8 / ns;
+    constexpr int IPB = 4 * (64 / GL);
+    const int n_items = SORTED ? c.work.n_items : c.g->n;
+    const int chunks = (n_items + IPB - 1) / IPB;
+    const int grid = SEQ ? chunks * ns : 8 * ((chunks + xps - 1) / xps);
+    const int32_t *colp = HINT ? c.colh[HOTSET] : c.col;
+    hipLaunchKernelGGL((k_spmm_sliced<GL, U, NT, SORTED, HINT, SEQ>), dim3(grid), dim3(256), 0, st, n_items, c.work.e0, c.work.cnt,
+                       c.work.dst, c.rowptr, c.g->n, colp, c.val, c.S, c.H, c.H, c.out, c.H, c.work.partial, c.H, ns);
+    if (SORTED && c.work.n_long > 0) {
+        const int tot = c.work.n_long * c.H;
+        hipLaunchKernelGGL(k_combine, dim3((tot + 255) / 256), dim3(256), 0, st, c.work.n_long, c.work.long_row,
+                           c.work.long_segptr, c.work.partial, c.H, c.H, c.out, c.H);
+    }
+}
+
+static void run_lib(Ctx &c, hipStream_t st) {
+    if (lt_spmm_csr_f32(c.lg, c.S, c.H, c.H, nullptr, 0, c.out, c.H, st) != LT_OK) {
+        fprintf(stderr, "lt_spmm_csr_f32: %s\n", lt_last_error());
+        exit(1);
+    }
+}
+
+struct Variant { const char *name; void (*fn)(Ctx &, hipStream_t); };
+
+int main(int argc, char **argv) {
+    const int scale = argc > 1 ? atoi(argv[1]) : 16;
+    const int ef = argc > 2 ? atoi(argv[2]) : 16;
+    const int H = argc > 3 ? atoi(argv[3]) : 256;
+    const int reps = argc > 4 ? atoi(argv[4]) : 10;
+    const char *only = argc > 5 ? argv[5] : "";
+    auto t0 = std::chrono::steady_clock::now();
+    HostCsr g = make_rmat(scale, (long)ef << scale, 42);
+    const long nnz = (long)g.col.size();
+    int maxd = 0;
+    for (int r = 0; r < g.n; ++r) maxd = std::max(maxd, g.rowptr[r + 1] - g.rowptr[r]);
+    printf("rmat scale %d: n %d nnz %ld max row %d (host build %.1f s)\n", scale, g.n, nnz, maxd,
+           std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    Ctx c;
+    c.g = &g; c.H = H;
+    c.rowptr = upload(g.rowptr); c.col = upload(g.col, 64); c.val = upload(g.val, 64);
+    {
+        std::vector<float> s((size_t)g.n * H);
+        std::mt19937 r2(7);
+        std::normal_distribution<float> N(0.f, 1.f);
+        for (auto &x : s) x = N(r2);
+        c.S = upload(s);
+    }
+    CK(hipMalloc((void **)&c.out, (size_t)g.n * H * sizeof(float)));
+    CK(hipMalloc((void **)&c.ref, (size_t)g.n * H * sizeof(float)));
+    c.work = build_work(g, H, 128);   // the library's canonical order: 128-entry segments added in order (lt_rows.cuh row_dot)
+    {
+        // hot sets by in-degree (= row length: the matrix is symmetric)
+        std::vector<int> deg((size_t)g.n);
+        for (int r = 0; r < g.n; ++r) deg[r] = g.rowptr[r + 1] - g.rowptr[r];
+        std::vector<int> sorted(deg);
+        std::sort(sorted.begin(), sorted.end(), std::greater<int>());
+        const int hs[4] = {8192, 12288, 16384, 24576};
+        for (int h = 0; h < 4; ++h) {
+            const int thr = sorted[std::min(hs[h], g.n) - 1];   // columns with deg > thr are hot (at most hs[h] of them)
+            std::vector<int32_t> ch(g.col.size());
+            long hot = 0;
+            for (size_t e = 0; e < ch.size(); ++e) {
+                const bool cold = deg[g.col[e]] <= thr;
+                hot += !cold;
+                ch[e] = g.col[e] | (cold ? (int32_t)0x80000000 : 0);
+            }
+            c.colh[h] = upload(ch, 64);
+            printf("hot set %d: degree > %d, %.1f%% of the entries\n", hs[h], thr, 100.0 * hot / ch.size());
+        }
+    }
+    if (lt_graph_create(g.n, nnz, g.rowptr.data(), g.col.data(), g.val.data(), &c.lg) != LT_OK) {
+        fprintf(stderr, "lt_graph_create: %s\n", lt_last_error());
+        return 1;
+    }
+    printf("work items %d (long rows %d, segments %d)\n", c.work.n_items, c.work.n_long, c.work.n_seg);
+    const double alg = (double)nnz * 8 + ((double)g.n + 1) * 4 + 2.0 * g.n * H * 4;
+    const double gather = (double)nnz * H * 4;
+
+    std::vector<Variant> vs = {
+        {"lib", run_lib},
+        {"g64_u8_srt_nt", run_sliced<64, 8, true, true>},
+        {"g16_u8_srt_nt", run_sliced<16, 8, true, true>},
+        {"g8_u8_srt_nt", run_sliced<8, 8, true, true>},
+        {"g16_seq", run_sliced<16, 8, true, true, 0, true>},
+        {"g8_seq", run_sliced<8, 8, true, true, 0, true>},
+        {"g16_asm0", run_sliced<16, 8, true, true, 0 + 5, false, 1>},   // HINT 5 = plain policy for cold too (asm path cost)
+        {"g16_nt_h8k", run_sliced<16, 8, true, true, 1, false, 0>},
+        {"g16_nt_h12k", run_sliced<16, 8, true, true, 1, false, 1>},
+        {"g16_nt_h16k", run_sliced<16, 8, true, true, 1, false, 2>},
+        {"g16_sc1_h12k", run_sliced<16, 8, true, true, 2, false, 1>},
+        {"g16_sc01_h12k", run_sliced<16, 8, true, true, 3, false, 1>},
+        {"g16_sc1nt_h12k", run_sliced<16, 8, true, true, 4, false, 1>},
+        {"g8_nt_h16k", run_sliced<8, 8, true, true, 1, false, 2>},
+        {"g8_nt_h24k", run_sliced<8, 8, true, true, 1, false, 3>},
+        {"g8_sc1nt_h24k", run_sliced<8, 8, true, true, 4, false, 3>},
+        {"g16_seq_nt_h12k", run_sliced<16, 8, true, true, 1, true, 1>},
+    };
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    hipEvent_t ea, eb;
+    CK(hipEventCreate(&ea)); CK(hipEventCreate(&eb));
+    bool have_ref = false;
+    std::vector<float> h_ref, h_out;
+    for (auto &v : vs) {
+        if (only[0] && !strstr(only, v.name) && strcmp(v.name, "lib") != 0) continue;
+        CK(hipMemsetAsync(c.out, 0xff, (size_t)g.n * H * sizeof(float), st));
+        v.fn(c, st);
+        CK(hipStreamSynchronize(st));
+        CK(hipGetLastError());
+        // correctness: bit-equal to the library kernel
+        const char *verdict = "ref";
+        if (!have_ref) {
+            CK(hipMemcpy(c.ref, c.out, (size_t)g.n * H * sizeof(float), hipMemcpyDeviceToDevice));
+            have_ref = true;
+        } else {
+            h_ref.resize((size_t)g.n * H); h_out.resize((size_t)g.n * H);
+            CK(hipMemcpy(h_ref.data(), c.ref, h_ref.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(h_out.data(), c.out, h_out.size() * 4, hipMemcpyDeviceToHost));
+            // rows of up to 512 entries: the library sums them in the same order -> bit-equal; longer rows: the
+            // library nests 512-entry segments around the 128-entry ones, so only closeness is checked there
+            size_t bad = 0, loose = 0;
+            double worst = 0.0;
+            for (int r = 0; r < g.n; ++r) {
+                const bool exact = g.rowptr[r + 1] - g.rowptr[r] <= 512;
+                for (int k = 0; k < H; ++k) {
+                    const size_t i = (size_t)r * H + k;
+                    if (exact) bad += memcmp(&h_ref[i], &h_out[i], 4) != 0;
+                    else {
+                        const double d = fabs((double)h_ref[i] - h_out[i]) / (1.0 + fabs((double)h_ref[i]));
+                        if (!(d <= 1e-4)) ++loose;
+                        worst = std::max(worst, d);
+                    }
+                }
+            }
+            static char buf[96];
+            snprintf(buf, sizeof buf, "%s (short rows: %zu words differ; long rows: worst rel %.1e)",
+                     bad || loose ? "MISMATCH" : "ok", bad, worst);
+            verdict = buf;
+        }
+        v.fn(c, st);
+        CK(hipEventRecord(ea, st));
+        for (int i = 0; i < reps; ++i) v.fn(c, st);
+        CK(hipEventRecord(eb, st));
+        CK(hipEventSynchronize(eb));
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, ea, eb));
+        ms /= reps;
+        printf("%-18s %9.4f ms   algorithmic %8.1f GB/s (%.1f%% of 8 TB/s)   gather %6.2f TB/s   %s\n", v.name, ms,
+               alg / ms / 1e6, alg / ms / 1e6 / 80.0, gather / ms / 1e9, verdict);
+        fflush(stdout);
+    }
+    return 0;
+}
