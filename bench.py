@@ -28,6 +28,42 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 matrix peak
+
+
+def source_signature():
+    """sha256 over the kernel sources: PMC traffic figures in profiles/ are stamped with it and ignored when stale."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(REPO, "linkteller_amd", "csrc", "*.hip")) +
+                     glob.glob(os.path.join(REPO, "linkteller_amd", "csrc", "*.cuh")) +
+                     glob.glob(os.path.join(REPO, "linkteller_amd", "csrc", "*.h"))):
+        h.update(open(fn, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(kernel_key):
+    """HBM bytes per launch of `kernel_key` from the PMC passes kept in profiles/pmc_traffic.json (FETCH_SIZE x 2 +
+    WRITE_SIZE, collected by tools/pmc_traffic.sh in separate rocprofv3 --pmc runs of THIS command); None when the
+    file was collected for other kernel sources than the ones in the tree."""
+    try:
+        d = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+        if d.get("source_signature") != source_signature():
+            return None
+        return d.get("kernels", {}).get(kernel_key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def parse():
@@ -44,7 +80,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU reference sample")
     p.add_argument("--no-extras", action="store_true", help="skip other_modes / standalone SpMM legs")
-    p.add_argument("--spmm-scale", type=int, default=18, help="R-MAT scale of the HBM-resident SpMM leg (0 = skip)")
+    p.add_argument("--spmm-scale", type=int, default=21,
+                   help="R-MAT scale of the HBM-resident SpMM leg (BASELINE configs[4]: 21; 0 = skip)")
+    p.add_argument("--only-spmm", action="store_true", help="run only the R-MAT SpMM leg (for the PMC passes)")
     return p.parse_args()
 
 
@@ -88,6 +126,40 @@ def main():
     from linkteller_amd import _lib, engine, graph, synth
     from linkteller_amd import dist as lt_dist
 
+    def spmm_rmat_leg(scale, hcols, reps=10):
+        """Standalone SpMM (lt_spmm_csr_f32) on an R-MAT graph whose S exceeds every cache: the 'SpMM HBM GB/s' half of
+        the metric, at BASELINE configs[4] size by default.  Kernel time from HIP events on the launch stream."""
+        t0 = time.perf_counter()
+        big = graph.first_order_gcn(synth.rmat_graph(scale, (1 << scale) * 16, seed=42))
+        gb = graph.HipGraph(big)
+        host_s = time.perf_counter() - t0
+        sb = torch.randn((big.shape[0], hcols), device=dev)
+        for _ in range(2):
+            engine.spmm(gb, sb)
+        _lib.lib().lt_profile_enable(1 << _lib.KERNEL_IDS["spmm"])
+        for _ in range(reps):
+            engine.spmm(gb, sb)
+        torch.cuda.synchronize()
+        tot, cnt = kernel_ms("spmm")
+        _lib.lib().lt_profile_enable(0)
+        sec = tot / cnt * 1e-3
+        byts = spmm_bytes(big.shape[0], big.nnz, hcols)
+        key = f"spmm_rmat{scale}"
+        return {"kernel": "k_rows_tiled (+ k_spmm_long_combine for the hub rows)", "bound": "hbm",
+                "achieved": round(byts / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(byts / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": measured_traffic(key),
+                "algorithmic_bytes_per_launch": int(byts), "avg_launch_us": round(sec * 1e6, 1),
+                "units_per_launch": f"one SpMM A_hat[{big.shape[0]}^2, nnz={big.nnz}] x S[{big.shape[0]}x{hcols}] fp32 "
+                                    f"(R-MAT scale {scale}, max row {int(np.diff(big.indptr).max())})",
+                "gathered_bytes_per_launch": int(big.nnz) * hcols * 4, "host_graph_build_s": round(host_s, 1),
+                "note": "algorithmic bytes = SURVEY 8(d) (CSR once, S once, result once); a row-gather SpMM moves nnz*H*4 "
+                        "bytes of gathered rows through L2, and what it cannot hold comes over the fabric: `traffic` "
+                        "(FETCH_SIZE*2 + WRITE_SIZE, PMC) over avg_launch_us is the real HBM-side rate"}
+
+    if a.only_spmm:
+        print(json.dumps({"roofline_spmm": spmm_rmat_leg(a.spmm_scale, a.hidden, reps=4)}))
+        return
+
     # ---------------- workload (identical on every rank: seeded) ----------------
     adj, x_np, w = synth.twitch_like_problem(a.workload, hidden=a.hidden, n_classes=a.classes, seed=0,
                                              powerlaw=a.powerlaw)
@@ -102,6 +174,7 @@ def main():
     x = torch.from_numpy(x_np).to(dev)
     params = [torch.from_numpy(w[k]).to(dev) for k in ("W1", "b1", "W2", "b2")]
     base = engine.Baseline(hg, x, *params)
+    baseline_sharded = lt_dist.choose_baseline_sharding(base)      # N > 1: X*W1 sharded + all-gather(S1), or replicated
     b0, b1_, per = lt_dist.shard_bounds(a.n_test, rank, world)
     probes = torch.from_numpy(test_nodes[b0:b1_].astype(np.int32)).to(dev)
     obs = torch.from_numpy(test_nodes.astype(np.int32)).to(dev)
@@ -183,42 +256,45 @@ def main():
     roofline = None
     if dom is not None:
         avg_s = per_kernel[dom]["avg_us"] * 1e-6
+        traffic = measured_traffic(dom) if (world == 1 and a.n_test == 500 and a.workload == "twitch-RU" and not a.powerlaw) else None
         if dom == "full_stageA":
-            # SURVEY 8(d), batched faithful mode: CSR once + per probe (read S1' + write Z1') -- the
-            # traffic an unfused per-probe SpMM moves; the fused kernel keeps Z1' in registers.
-            alg = nnz * 8 + (n + 1) * 4 + n_probe_local * 2 * n * h * 4
-            unit = f"{n_probe_local} probe SpMMs (A_hat[{n}x{n}, nnz={nnz}] x S1'[{n}x{h}]) per launch"
+            # The binding resource of the fused batched probe kernel is fp32 FMA issue: B*nnz*H fused multiply-adds
+            # (every probe recomputes every row: the faithful mode), operands cache-resident at this size.
+            flop = 2.0 * n_probe_local * nnz * h
+            ach = flop / avg_s / 1e12
+            # SURVEY 8(d)'s batched byte figure (CSR once + per probe read S1' + write Z1') is what an UNFUSED per-probe
+            # SpMM would move; kept as a sub-key, it is not what this kernel moves (Z1' lives in registers)
+            unfused = nnz * 8 + (n + 1) * 4 + n_probe_local * 2 * n * h * 4
+            roofline = {"kernel": "k_full_stageA_lds", "bound": "fp32_fma", "achieved": round(ach, 2),
+                        "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4),
+                        "traffic": traffic, "avg_launch_us": per_kernel[dom]["avg_us"],
+                        "units_per_launch": f"{n_probe_local} perturbed layer-1 passes over A_hat[{n}x{n}, nnz={nnz}] x S1'[{n}x{h}] "
+                                            f"= {n_probe_local}*nnz*H FMAs",
+                        "algorithmic_flop_per_launch": flop,
+                        "unfused_hbm_figure": {"bytes_per_launch": int(unfused),
+                                               "GBps_at_this_duration": round(unfused / avg_s / 1e9, 1),
+                                               "note": "SURVEY 8(d) batched formula; exceeds the HBM peak because the fused "
+                                                       "kernel never moves these bytes"}}
         elif dom == "gemm":
-            alg = (n * f + f * h + n * h) * 4
-            unit = "X*W1"
+            flop = 2.0 * n * f * h
+            ach = flop / avg_s / 1e12
+            roofline = {"kernel": "k_gemm_f32_mfma_128", "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
+                        "avg_launch_us": per_kernel[dom]["avg_us"], "units_per_launch": f"X[{n}x{f}] * W1[{f}x{h}] fp32"}
         else:
             alg = spmm_bytes(n, nnz, h)
-            unit = "one SpMM"
-        traffic = None
-        tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile) and world == 1 and a.n_test == 500 and a.workload == "twitch-RU" and not a.powerlaw:
-            try:   # PMC counters were collected for exactly this launch shape (profiles/README.md)
-                traffic = json.load(open(tfile)).get(dom, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        ach = alg / avg_s / 1e9
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": int(alg), "avg_launch_us": per_kernel[dom]["avg_us"],
-                    "units_per_launch": unit}
-        if dom == "full_stageA":
-            fma = 2.0 * n_probe_local * nnz * h
-            roofline["note"] = ("algorithmic bytes = SURVEY 8(d) batched figure, i.e. what an UNFUSED per-probe SpMM moves; the "
-                                "kernel is fused (Z1' stays in registers) and cache-resident at this size, so measured HBM "
-                                "traffic is ~30x lower and frac may exceed 1: the binding resource is fp32 FMA issue")
-            roofline["fp32_fma"] = {"achieved_tflops": round(fma / avg_s / 1e12, 1), "peak_tflops": 157.3,
-                                    "frac": round(fma / avg_s / 1e12 / 157.3, 3)}
+            ach = alg / avg_s / 1e9
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "algorithmic_bytes_per_launch": int(alg), "avg_launch_us": per_kernel[dom]["avg_us"],
+                        "units_per_launch": "one SpMM"}
         if "gemm" in per_kernel and a.mode != "delta":   # (delta also times its fp64 product in this class)
             # the two f32 MFMA products of a step (X*W1 and the probe rows), split-K slab sums included in the time
-            gflop = 2.0 * (n + n_probe_local) * f * h
+            rows_x = (lt_dist.shard_bounds(n, rank, world)[1] - lt_dist.shard_bounds(n, rank, world)[0]) if baseline_sharded else n
+            gflop = 2.0 * (rows_x + n_probe_local) * f * h
             gsec = per_kernel["gemm"]["avg_us"] * per_kernel["gemm"]["launches"] / a.steps * 1e-6
-            roofline["gemm_mfma_f32"] = {"achieved_tflops": round(gflop / gsec / 1e12, 1), "peak_tflops": 157.3,
-                                         "frac": round(gflop / gsec / 1e12 / 157.3, 3)}
+            roofline["gemm_mfma_f32"] = {"achieved_tflops": round(gflop / gsec / 1e12, 1), "peak_tflops": FP32_PEAK_TFLOPS,
+                                         "frac": round(gflop / gsec / 1e12 / FP32_PEAK_TFLOPS, 3)}
 
     extras = {}
     if rank == 0 and not a.no_extras and world == 1:
@@ -249,12 +325,14 @@ def main():
                     base_h.refresh(); base_h.influence_rows(obs, obs, delta, m, out=out_h)
                 torch.cuda.synchronize()
                 res_h[m] = (time.perf_counter() - t0) / 10
-            extras["hub_graph"] = {"graph": "power-law, same N and E", "max_degree": int(np.diff(ah.indptr).max()),
-                                   "full_ms_per_step": round(res_h["full"] * 1e3, 4),
-                                   "sparse_ms_per_step": round(res_h["sparse"] * 1e3, 4),
-                                   "full_pairs_per_s": round(a.n_test ** 2 / res_h["full"], 1)}
+            extras["workload_2"] = {"workload": f"{a.workload}-shaped POWER-LAW graph (same N, E; what real MUSAE graphs look "
+                                                f"like), n_test={a.n_test}", "max_degree": int(np.diff(ah.indptr).max()),
+                                    "value": round(a.n_test ** 2 / res_h["full"], 1), "unit": "node-pairs/s", "mode": "full",
+                                    "ms_per_step": round(res_h["full"] * 1e3, 4),
+                                    "sparse_ms_per_step": round(res_h["sparse"] * 1e3, 4),
+                                    "sparse_pairs_per_s": round(a.n_test ** 2 / res_h["sparse"], 1)}
             del base_h, out_h
-        # standalone SpMM (lt_spmm_csr_f32) on this graph and on an HBM-resident R-MAT graph
+        # standalone SpMM (lt_spmm_csr_f32) on this graph (cache-resident) and on the R-MAT graph of configs[4]
         def time_spmm(g_, s_, reps=20):
             for _ in range(3):
                 engine.spmm(g_, s_)
@@ -269,15 +347,7 @@ def main():
         extras["spmm_twitch"] = {"us": round(t * 1e6, 2), "algorithmic_GBps": round(spmm_bytes(n, nnz, h) / t / 1e9, 1),
                                  "note": "operands (9.6 MB) are L2/Infinity-Cache resident; wall time incl. launch"}
         if a.spmm_scale:
-            big = graph.first_order_gcn(synth.rmat_graph(a.spmm_scale, (1 << a.spmm_scale) * 16, seed=42))
-            gb = graph.HipGraph(big)
-            sb = torch.randn((big.shape[0], h), device=dev)
-            t = time_spmm(gb, sb, 10)
-            byts = spmm_bytes(big.shape[0], big.nnz, h)
-            extras["spmm_rmat"] = {"scale": a.spmm_scale, "n": int(big.shape[0]), "nnz": int(big.nnz),
-                                   "ms": round(t * 1e3, 4), "algorithmic_GBps": round(byts / t / 1e9, 1),
-                                   "frac_of_hbm_peak": round(byts / t / 1e9 / HBM_PEAK_GBS, 4)}
-            del gb, sb
+            extras["roofline_spmm"] = spmm_rmat_leg(a.spmm_scale, h)
 
     # ---------------- CPU reference path (oracle), bounded sample, rank 0 / N=1 only -----------
     cpu = None
@@ -290,11 +360,13 @@ def main():
         # scale to hundreds of host cores, so "all cores" would understate the CPU path
         ncpu = os.cpu_count() or 1
         best = (None, 1e30)
+        calib = {}
         for th in sorted({t for t in (1, 8, 16, 32, 64) if t <= ncpu}):
             torch.set_num_threads(th)
             tc = time.perf_counter()
             O.influence_matrix(xt, adj_t, P, test_nodes, delta, probe_range=range(0, 1))
             tc = time.perf_counter() - tc
+            calib[th] = tc
             if tc < best[1]:
                 best = (th, tc)
         torch.set_num_threads(best[0])
@@ -311,7 +383,10 @@ def main():
                "kind": "port",
                "sample": f"first {done} of {a.n_test} probes (x {a.n_test} observed nodes) of the same workload, "
                          f"reference op sequence incl. per-probe baseline forward and per-pair .item(), {el:.1f} s",
-               "host_cores": ncpu, "max_abs_diff_vs_gpu_rows": float(chk)}
+               "host_cores": ncpu, "cpu_model": cpu_model(),
+               "single_thread": {"value": round(a.n_test / calib[1], 1), "unit": "node-pairs/s", "cores": 1,
+                                 "sample": f"1 probe x {a.n_test} observed nodes, {calib[1]:.2f} s"},
+               "max_abs_diff_vs_gpu_rows": float(chk)}
 
     if rank == 0:
         out = {
@@ -323,6 +398,10 @@ def main():
                                    f"N={n} E={adj.nnz // 2} nnz(A_hat)={nnz}, F={f} H={h} C={c}, 2-layer GCN "
                                    f"FirstOrderGCN, n_test={a.n_test}, influence=1e-4 (BASELINE configs[1])",
                        "mode": a.mode, "probes_per_rank": n_probe_local,
+                       "baseline_XW1": ("sharded over ranks + all-gather of S1" if baseline_sharded else
+                                        ("replicated on every rank" if world > 1 else "single GPU")),
+                       "collective_bytes_per_step": (world * per * a.n_test * 4 + (world * lt_dist.shard_bounds(n, rank, world)[2] * ((h + 3) // 4 * 4) * 4
+                                                                                   if baseline_sharded else 0)) if world > 1 else 0,
                        "step": "baseline forward + all probes + norms" + (" + all-gather" if world > 1 else "")},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": per_kernel,
             "kernels_note": f"dominant kernel timed by HIP events inside the timed region; the other rows from an "

@@ -59,6 +59,20 @@ int lt_abi_version(void);
 /* number of visible HIP devices (0 on a CPU-only box; never initialises a context) */
 int lt_device_count(int *count);
 
+/* ---- tuning knobs (no reference counterpart) ---------------------------------------------------
+ * Every setting gives bit-identical results; the knobs choose between kernel routes and are what the
+ * tests use to run each route on small inputs.  Defaults come from LT_* environment variables read once.
+ *   "tiled_min_bytes"     S of at least this many bytes takes the tiled SpMM / layer-1 route (default 32 MiB)
+ *   "chunk_budget_bytes"  per-call scratch budget that decides the probe chunking (default 1 GiB)
+ *   "full_p"              probes per wave of FULL stage A: 8 / 16 / 32, 0 = from the probe count
+ *   "long_par"            hub rows in FULL stage A: 1 = segments in separate waves, 0 = one wave per row
+ *   "overlap"             hub-row kernels on the baseline's side stream (1) or on the caller's (0)
+ *   "item_bits"           SPARSE / DELTA stage B membership bitmap on (1) / off (0)
+ *   "wide_min_hp"         smallest padded hidden width served by the batched stage-A kernel
+ * value = LT_TUNING_DEFAULT restores the default. */
+#define LT_TUNING_DEFAULT (-0x7fffffffffffffffLL - 1)
+int lt_set_tuning(const char *key, long long value);
+
 /* ---- graph ------------------------------------------------------------------------------
  * Stands in for utils/load.py:552-559 (sparse_mx_to_torch_sparse_tensor) + the .cuda() at
  * worker.py:665-678: takes the normalised adjacency A_hat as HOST CSR (int32 indices,
@@ -112,6 +126,15 @@ int lt_baseline_enable_fp64(lt_baseline *b, void *stream);
  * uses several streams orders them itself.  LT_MODE_FULL rows never need them: their stage A yields the
  * unperturbed layer as a by-product and stage B forms the baseline logits of the observed nodes itself. */
 int lt_baseline_refresh(lt_baseline *b, void *stream);
+/* Multi-GPU: the loop-invariant X*W1 sharded over ranks instead of replicated.
+ * lt_baseline_attach_s1: the baseline reads S1 = X*W1 from caller-owned storage from now on ([>= n, Hp] fp32 with
+ *   Hp = H rounded up to 4, ld == Hp; e.g. the torch tensor the ranks' all-gather writes); the current S1 is copied in.
+ * lt_baseline_refresh_rows: like lt_baseline_refresh, but computes only rows [row_begin, row_end) of X*W1, into
+ *   dst[row_end - row_begin, Hp] (typically the rank's send buffer of the all-gather).  Rows carry the same bits
+ *   whichever rank computed them (the split-K slicing is that of the full product).  The rest of S1 is the caller's
+ *   job; Z1 / S2 / OUT are marked stale exactly as by lt_baseline_refresh. */
+int lt_baseline_attach_s1(lt_baseline *b, float *S1, int64_t ld, void *stream);
+int lt_baseline_refresh_rows(lt_baseline *b, int32_t row_begin, int32_t row_end, float *dst, void *stream);
 int lt_baseline_destroy(lt_baseline *b);
 /* copies the baseline logits OUT [n, C] (dense, ld = C) to a device buffer */
 int lt_baseline_logits(const lt_baseline *b, float *dst, void *stream);

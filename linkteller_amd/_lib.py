@@ -28,6 +28,7 @@ SIGNATURES = {
     "lt_last_error": (C.c_char_p, []),
     "lt_abi_version": (C.c_int, []),
     "lt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "lt_set_tuning": (C.c_int, [C.c_char_p, C.c_longlong]),
     "lt_graph_create": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.POINTER(C.c_void_p)]),
     "lt_graph_destroy": (C.c_int, [C.c_void_p]),
@@ -45,6 +46,8 @@ SIGNATURES = {
                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                      C.POINTER(C.c_void_p)]),
     "lt_baseline_refresh": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lt_baseline_attach_s1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "lt_baseline_refresh_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "lt_baseline_enable_fp64": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lt_baseline_destroy": (C.c_int, [C.c_void_p]),
     "lt_baseline_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -84,6 +87,14 @@ def check(status: int, what: str = ""):
     if status != LT_OK:
         msg = lib().lt_last_error().decode("utf-8", "replace")
         raise LinkTellerHipError(f"{what or 'liblinkteller_hip'} failed with status {status}: {msg}")
+
+
+TUNING_DEFAULT = -(1 << 63)
+
+
+def set_tuning(key: str, value=None):
+    """Route-selection knob of the library (include/linkteller_hip.h); ``None`` restores the default."""
+    check(lib().lt_set_tuning(key.encode(), TUNING_DEFAULT if value is None else int(value)), "lt_set_tuning")
 
 
 def device_count() -> int:

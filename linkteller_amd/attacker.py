@@ -7,7 +7,7 @@ Same constructor, method names, prints and result file as the reference, so
 rank's rows on the device and a single copy brings the matrix back.
 
 Extra, optional ``args`` fields (absent in the reference's namespace -> defaults):
-    influence_mode   'full' (default) | 'sparse' | 'delta'   (see include/linkteller_hip.h)
+    influence_mode   'sparse' (default; bit-identical to 'full') | 'full' | 'delta'   (see include/linkteller_hip.h)
 """
 from __future__ import annotations
 
@@ -41,6 +41,7 @@ class Attacker:
             self.features = self.worker.features             # attacker.py:28-30
             self.adj = self.worker.adj_full
         self._baseline = None
+        self._baseline_key = None
         self.influence_val = None
 
     # ------------------------------------------------------------------------------------------
@@ -110,15 +111,26 @@ class Attacker:
     def _rows(self, probe_nodes, observe_nodes, mode=None):
         """[len(probe_nodes), len(observe_nodes)] influence rows on the device."""
         if self._is_two_layer():
-            mode = mode or getattr(self.args, "influence_mode", None) or os.environ.get("LT_INFLUENCE_MODE", "full")
+            mode = mode or getattr(self.args, "influence_mode", None) or os.environ.get("LT_INFLUENCE_MODE", "sparse")
             return self.baseline().influence_rows(probe_nodes, observe_nodes, float(self.args.influence), mode)
         return self._rows_generic(probe_nodes, observe_nodes)
 
     def baseline(self) -> engine.Baseline:
-        """Loop-invariant model(features, adj) of attacker.py:106, computed once."""
-        if self._baseline is None:
-            dev = self.features.device
-            self._baseline = engine.Baseline(self.adj, self.features, *[p.to(dev) for p in self._params()])
+        """Loop-invariant model(features, adj) of attacker.py:106: built once per (features, adj, parameters) --
+        rebuilt when any of them was replaced, refreshed (X W1 recomputed from the borrowed tensors) on every attack
+        so that in-place weight updates are seen.  With several ranks X W1 is sharded or replicated per
+        ``dist.choose_baseline_sharding``."""
+        dev = self.features.device
+        src = self._params()
+        off_device = any(p.device != dev for p in src)
+        # parameters held on another device are copied: then an in-place update (p._version) means a rebuild too
+        key = (id(self.adj), self.features.data_ptr(), tuple((p.data_ptr(), p._version if off_device else 0) for p in src))
+        if self._baseline is None or self._baseline_key != key:
+            self._baseline = engine.Baseline(self.adj, self.features, *[p.to(dev) for p in src])
+            self._baseline_key = key
+            lt_dist.choose_baseline_sharding(self._baseline)
+        else:
+            self._baseline.refresh()
         return self._baseline
 
     def get_gradient_eps_mat(self, v):

@@ -1,6 +1,9 @@
 // liblinkteller_hip: error plumbing + the device-resident graph handle.
 #include <string.h>
 
+#include <stdlib.h>
+
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -17,6 +20,53 @@ int lt_set_error(int code, const char *fmt, ...) {
 }
 
 extern "C" const char *lt_last_error(void) { return g_err; }
+
+// ---- tuning knobs -------------------------------------------------------------------------------
+static long long env_ll(const char *name, long long dflt) {
+    const char *e = getenv(name);
+    return (e && *e) ? atoll(e) : dflt;
+}
+static lt_tuning tuning_defaults() {
+    lt_tuning t;
+    t.tiled_min_bytes = env_ll("LT_SPMM_TILED_MIN_BYTES", (long long)32 << 20);
+    t.chunk_budget = env_ll("LT_CHUNK_BUDGET_BYTES", (long long)1 << 30);
+    if (t.chunk_budget <= 0) t.chunk_budget = (long long)1 << 30;
+    const long long p = env_ll("LT_FULL_P", 0);
+    t.full_p = (p == 8 || p == 16 || p == 32) ? (int)p : 0;
+    t.long_par = getenv("LT_LONG_PAR") ? (env_ll("LT_LONG_PAR", 0) != 0 ? 1 : 0) : -1;
+    t.overlap = env_ll("LT_OVERLAP", 1) != 0 ? 1 : 0;
+    t.item_bits = env_ll("LT_ITEM_BITS", 1) != 0 ? 1 : 0;
+    const long long w = env_ll("LT_WIDE_MIN_HP", 24);
+    t.wide_min_hp = w > 0 ? (int)w : 24;
+    return t;
+}
+lt_tuning &lt_tune() {
+    static lt_tuning t = tuning_defaults();
+    return t;
+}
+extern "C" int lt_set_tuning(const char *key, long long value) {
+    LT_REQUIRE(key != nullptr, "lt_set_tuning: key is NULL");
+    lt_tuning &t = lt_tune();
+    const lt_tuning d = tuning_defaults();
+    const bool reset = value == LT_TUNING_DEFAULT;
+    if (!strcmp(key, "tiled_min_bytes")) t.tiled_min_bytes = reset ? d.tiled_min_bytes : value;
+    else if (!strcmp(key, "chunk_budget_bytes")) {
+        LT_REQUIRE(reset || value > 0, "lt_set_tuning: chunk_budget_bytes must be positive");
+        t.chunk_budget = reset ? d.chunk_budget : value;
+    } else if (!strcmp(key, "full_p")) {
+        LT_REQUIRE(reset || value == 0 || value == 8 || value == 16 || value == 32, "lt_set_tuning: full_p must be 0, 8, 16 or 32");
+        t.full_p = reset ? d.full_p : (int)value;
+    } else if (!strcmp(key, "long_par")) {
+        LT_REQUIRE(reset || value == 0 || value == 1, "lt_set_tuning: long_par must be 0 or 1");
+        t.long_par = reset ? d.long_par : (int)value;
+    } else if (!strcmp(key, "overlap")) t.overlap = reset ? d.overlap : (value != 0);
+    else if (!strcmp(key, "item_bits")) t.item_bits = reset ? d.item_bits : (value != 0);
+    else if (!strcmp(key, "wide_min_hp")) {
+        LT_REQUIRE(reset || value > 0, "lt_set_tuning: wide_min_hp must be positive");
+        t.wide_min_hp = reset ? d.wide_min_hp : (int)value;
+    } else return lt_set_error(LT_ERR_INVALID, "lt_set_tuning: unknown key '%s'", key);
+    return LT_OK;
+}
 extern "C" int lt_abi_version(void) { return LT_ABI_VERSION; }
 
 extern "C" int lt_device_count(int *count) {
@@ -39,11 +89,9 @@ static void free_graph(lt_graph *g) {
     (void)hipFree(g->tptr);
     (void)hipFree(g->trow);
     (void)hipFree(g->tval);
-    (void)hipFree(g->long_row);
-    (void)hipFree(g->long_segptr);
-    (void)hipFree(g->lseg_long);
-    (void)hipFree(g->lseg_begin);
-    (void)hipFree(g->seg_scratch);
+    (void)hipFree(g->w_e0);
+    (void)hipFree(g->w_cnt);
+    (void)hipFree(g->w_dst);
     (void)hipFree(g->p_long_row);
     (void)hipFree(g->p_long_segptr);
     (void)hipFree(g->p_seg_long);
@@ -135,35 +183,7 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
         G_HIP(hipMemcpy(g->trow, trow.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
         G_HIP(hipMemcpy(g->tval, tval.data(), (size_t)nnz * sizeof(float), hipMemcpyHostToDevice));
     }
-    // segment table of the long rows
-    {
-        std::vector<int32_t> lrow, lptr(1, 0), slong, sbeg;
-        for (int32_t r = 0; r < n; ++r) {
-            const int32_t d = rowptr[r + 1] - rowptr[r];
-            if (d <= LT_SPMM_SEG) continue;
-            const int32_t li = (int32_t)lrow.size();
-            lrow.push_back(r);
-            for (int32_t b = rowptr[r]; b < rowptr[r + 1]; b += LT_SPMM_SEG) {
-                slong.push_back(li);
-                sbeg.push_back(b);
-            }
-            lptr.push_back((int32_t)sbeg.size());
-        }
-        g->n_long = (int32_t)lrow.size();
-        g->n_lseg = (int32_t)sbeg.size();
-        if (g->n_long > 0) {
-            G_HIP(hipMalloc((void **)&g->long_row, lrow.size() * sizeof(int32_t)));
-            G_HIP(hipMalloc((void **)&g->long_segptr, lptr.size() * sizeof(int32_t)));
-            G_HIP(hipMalloc((void **)&g->lseg_long, slong.size() * sizeof(int32_t)));
-            G_HIP(hipMalloc((void **)&g->lseg_begin, sbeg.size() * sizeof(int32_t)));
-            G_HIP(hipMemcpy(g->long_row, lrow.data(), lrow.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-            G_HIP(hipMemcpy(g->long_segptr, lptr.data(), lptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-            G_HIP(hipMemcpy(g->lseg_long, slong.data(), slong.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-            G_HIP(hipMemcpy(g->lseg_begin, sbeg.data(), sbeg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-            G_HIP(hipMalloc((void **)&g->seg_scratch, (size_t)g->n_lseg * LT_MAX_H * sizeof(float)));
-        }
-    }
-    // the same table at LT_ROW_SEG for the layer-1 / probe kernels
+    // segment table of the long rows (LT_ROW_SEG entries per segment)
     {
         std::vector<int32_t> lrow, lptr(1, 0), slong, sbeg;
         for (int32_t r = 0; r < n; ++r) {
@@ -188,6 +208,42 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
             G_HIP(hipMemcpy(g->p_seg_long, slong.data(), slong.size() * sizeof(int32_t), hipMemcpyHostToDevice));
             G_HIP(hipMemcpy(g->p_seg_begin, sbeg.data(), sbeg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
             G_HIP(hipMalloc((void **)&g->p_seg_scratch, (size_t)g->p_n_seg * LT_MAX_H * sizeof(float)));
+        }
+        // work items of the tiled SpMM: segments by first column, then short rows by length class (16 entries)
+        struct item { int32_t e0, cnt, dst; };
+        std::vector<item> items;
+        try {
+            items.reserve((size_t)n + sbeg.size());
+            for (size_t sg = 0; sg < sbeg.size(); ++sg) {
+                const int32_t r = lrow[slong[sg]];
+                const int32_t left = rowptr[r + 1] - sbeg[sg];
+                items.push_back({sbeg[sg], left < LT_ROW_SEG ? left : LT_ROW_SEG, n + (int32_t)sg});
+            }
+            std::stable_sort(items.begin(), items.end(), [col](const item &a, const item &b) { return col[a.e0] < col[b.e0]; });
+            const size_t nseg_items = items.size();
+            for (int32_t r = 0; r < n; ++r) {
+                const int32_t d = rowptr[r + 1] - rowptr[r];
+                if (d <= LT_ROW_SEG) items.push_back({rowptr[r], d, r});
+            }
+            std::stable_sort(items.begin() + nseg_items, items.end(),
+                             [](const item &a, const item &b) { return (a.cnt + 15) / 16 > (b.cnt + 15) / 16; });
+        } catch (const std::bad_alloc &) {
+            free_graph(g);
+            return lt_set_error(LT_ERR_NOMEM, "lt_graph_create: host allocation of the work list failed");
+        }
+        g->w_n = (int32_t)items.size();
+        if (g->w_n > 0) {
+            std::vector<int32_t> tmp(items.size());
+            const size_t wb = items.size() * sizeof(int32_t);
+            G_HIP(hipMalloc((void **)&g->w_e0, wb));
+            G_HIP(hipMalloc((void **)&g->w_cnt, wb));
+            G_HIP(hipMalloc((void **)&g->w_dst, wb));
+            for (size_t i = 0; i < items.size(); ++i) tmp[i] = items[i].e0;
+            G_HIP(hipMemcpy(g->w_e0, tmp.data(), wb, hipMemcpyHostToDevice));
+            for (size_t i = 0; i < items.size(); ++i) tmp[i] = items[i].cnt;
+            G_HIP(hipMemcpy(g->w_cnt, tmp.data(), wb, hipMemcpyHostToDevice));
+            for (size_t i = 0; i < items.size(); ++i) tmp[i] = items[i].dst;
+            G_HIP(hipMemcpy(g->w_dst, tmp.data(), wb, hipMemcpyHostToDevice));
         }
     }
 #undef G_HIP

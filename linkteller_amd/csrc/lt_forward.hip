@@ -1,4 +1,4 @@
-// SpMM, fused GCN layers, the 2-layer forward and the baseline state.
+// Fused GCN layers, the 2-layer forward and the baseline state (the standalone SpMM lives in lt_spmm.hip).
 //   reference call sites: torch.spmm + bias (gcn/layers.py:32-36), F.relu (gcn/models.py:20),
 //   GCN.forward (gcn/models.py:19-24), the loop-invariant model(features, adj) of
 //   attacker.py:106.
@@ -7,103 +7,6 @@
 #include "lt_rows.cuh"
 
 #define LT_BLOCK 256
-
-// --------------------------------------------------------------------------------------------
-// SpMM, wide right-hand side: out[r, 0:ncols) = A_hat[r,:] * S (+bias)(relu); 4 columns per lane,
-// LPR lanes per row, 64/LPR rows per wave.  HBM-bound on large graphs: the CSR entries of a row
-// are read once, each gathered S row is a contiguous 16*LPR-byte segment (1 KiB at 256 columns).
-// --------------------------------------------------------------------------------------------
-template <int LPR>
-__global__ __launch_bounds__(LT_BLOCK) void k_spmm_rows(
-    int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-    const float *__restrict__ val, const float *__restrict__ S, int lds, int ncols,
-    const float *__restrict__ bias, int relu, float *__restrict__ out, int ldo) {
-    constexpr int RPW = 64 / LPR;
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
-    const int gl = lane & (LPR - 1);
-    int r = wave * RPW + lane / LPR;
-    if (LPR == 64) r = __builtin_amdgcn_readfirstlane(r);
-    if (r >= n) return;
-    const int coff = 4 * gl;
-    const bool active = coff < ncols;
-    const int e0 = rowptr[r], e1 = rowptr[r + 1];
-    if (e1 - e0 > LT_SPMM_SEG) return;  // long rows: k_spmm_long_segments + k_spmm_long_combine
-    const f32x4 acc = row_dot(col, val, e0, e1, S, lds, coff, active, -1, nullptr);
-    if (!active) return;
-    f32x4 o = acc;
-    if (bias) {
-        const f32x4 b = ld4(bias + coff);
-        o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
-    }
-    if (relu) {
-        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-    }
-    *reinterpret_cast<f32x4 *>(out + (size_t)r * ldo + coff) = o;
-}
-
-// Long rows of the wide SpMM: one wave per segment of LT_SPMM_SEG entries -> partial[seg, :]
-template <int LPR>
-__global__ __launch_bounds__(LT_BLOCK) void k_spmm_long_segments(
-    int n_lseg, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ long_row,
-    const int32_t *__restrict__ lseg_long, const int32_t *__restrict__ lseg_begin,
-    const int32_t *__restrict__ col, const float *__restrict__ val, const float *__restrict__ S,
-    int lds, int ncols, float *__restrict__ partial, int ldp) {
-    constexpr int RPW = 64 / LPR;
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
-    const int gl = lane & (LPR - 1);
-    int sg = wave * RPW + lane / LPR;
-    if (LPR == 64) sg = __builtin_amdgcn_readfirstlane(sg);
-    if (sg >= n_lseg) return;
-    const int coff = 4 * gl;
-    if (coff >= ncols) return;
-    const int r = long_row[lseg_long[sg]];
-    const int b = lseg_begin[sg];
-    const int e = min(b + LT_SPMM_SEG, rowptr[r + 1]);
-    const f32x4 acc = row_dot(col, val, b, e, S, lds, coff, true, -1, nullptr);
-    *reinterpret_cast<f32x4 *>(partial + (size_t)sg * ldp + coff) = acc;
-}
-
-// ... then one thread per (long row, column): partials added in segment order, epilogue, store
-__global__ void k_spmm_long_combine(int n_long, const int32_t *__restrict__ long_row,
-                                    const int32_t *__restrict__ long_segptr,
-                                    const float *__restrict__ partial, int ldp, int ncols,
-                                    const float *__restrict__ bias, int relu, float *__restrict__ out,
-                                    int ldo) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_long * ncols) return;
-    const int li = i / ncols, c = i % ncols;
-    float acc = partial[(size_t)long_segptr[li] * ldp + c];
-    for (int sg = long_segptr[li] + 1; sg < long_segptr[li + 1]; ++sg) acc += partial[(size_t)sg * ldp + c];
-    if (bias) acc += bias[c];
-    if (relu) acc = fmaxf(acc, 0.f);
-    out[(size_t)long_row[li] * ldo + c] = acc;
-}
-
-// SpMM, narrow right-hand side (ncols <= 8), 8 lanes per row (the layer-2 shape).
-template <int CP>
-__global__ __launch_bounds__(LT_BLOCK) void k_spmm_narrow(
-    int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-    const float *__restrict__ val, const float *__restrict__ T, int ldt, int C,
-    const float *__restrict__ bias, int relu, float *__restrict__ out, int ldo) {
-    const int gid = (blockIdx.x * LT_BLOCK + threadIdx.x) / LT_L2_LANES;
-    const int q = threadIdx.x & (LT_L2_LANES - 1);
-    if (gid >= n) return;  // whole 8-lane groups exit together
-    float acc[CP];
-    row2_dot<CP>(col, val, rowptr[gid], rowptr[gid + 1], q, C,
-                 [&](int c, int) { return T + (size_t)c * ldt; }, acc);
-    if (q == 0) {
-#pragma unroll
-        for (int c = 0; c < CP; ++c)
-            if (c < C) {
-                float o = acc[c];
-                if (bias) o += bias[c];
-                if (relu) o = fmaxf(o, 0.f);
-                out[(size_t)gid * ldo + c] = o;
-            }
-    }
-}
 
 // --------------------------------------------------------------------------------------------
 // Fused layer 1 for every row: acc = A_hat[r,:]*S1; Z1[r] = acc + b1 (optional store);
@@ -208,6 +111,39 @@ __global__ __launch_bounds__(LT_BLOCK) void k_layer1_long(
     }
 }
 
+// Large graphs: Z1 comes from the tiled SpMM (lt_spmm.hip; chains started from the bias, so Z1 is the pre-activation
+// itself) and this pass finishes the rows of up to LT_ROW_SEG entries: S2[r] = relu(Z1[r]) . W2 with the lane
+// reduction of k_layer1 (the long rows are finished by k_layer1_long from their segment sums).
+template <int LPR, int CP>
+__global__ __launch_bounds__(LT_BLOCK) void k_layer1_tail(
+    int n, const int32_t *__restrict__ rowptr, const float *__restrict__ Z1, int Hp,
+    const float *__restrict__ W2p, int C, float *__restrict__ S2) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
+    const int gl = lane & (LPR - 1);
+    int r = wave * RPW + lane / LPR;
+    if (LPR == 64) r = __builtin_amdgcn_readfirstlane(r);
+    if (r >= n) return;
+    if (rowptr[r + 1] - rowptr[r] > LT_ROW_SEG) return;
+    const int coff = 4 * gl;
+    const bool active = coff < Hp;
+    float part[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) part[c] = 0.f;
+    if (active) {
+        const f32x4 z = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Z1 + (size_t)r * Hp + coff));
+        relu_w2_partial<CP>(z, W2p + (size_t)coff * C, C, part);
+    }
+#pragma unroll
+    for (int c = 0; c < CP; ++c) part[c] = group_sum<LPR>(part[c]);
+    if (gl == 0) {
+#pragma unroll
+        for (int c = 0; c < CP; ++c)
+            if (c < C) S2[(size_t)r * C + c] = part[c];
+    }
+}
+
 // Layer 2 for every row: OUT[r] = A_hat[r,:]*S2 + b2
 template <int CP>
 __global__ __launch_bounds__(LT_BLOCK) void k_layer2(
@@ -236,14 +172,6 @@ __global__ void k_pad_b1_w2(const float *__restrict__ b1, const float *__restric
     if (j >= 0 && j < Hp * C) W2p[j] = (j / C) < H ? W2[j] : 0.f;
 }
 
-// pad helper (kept for callers that pad a single array)
-__global__ void k_pad_rows(const float *__restrict__ src, int rows, int rows_p, int cols,
-                           float *__restrict__ dst) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows_p * cols) return;
-    dst[i] = (i / cols) < rows ? src[i] : 0.f;
-}
-
 // --------------------------------------------------------------------------------------------
 // launch helpers
 // --------------------------------------------------------------------------------------------
@@ -260,6 +188,23 @@ int lt_launch_layer1(const lt_graph *g, const float *S1, int Hp, const float *b1
     const unsigned grid = blocks_for_rows(g->n, rpb);
     const int have_long = g->p_n_long > 0 ? 1 : 0;
     lt_prof_scope prof_(LT_K_LAYER1, st);
+    if (Z1 != nullptr && lt_tiled_wanted(g, Hp)) {
+        // S1 is far larger than the L2s: column-sliced work-item kernel for the chains (same chains, so the same
+        // bits), then the two finishing passes
+        int rc = lt_launch_rows_tiled(g, S1, Hp, Hp, b1p, nullptr, 0, Z1, Hp, seg_part, Hp, st);
+        if (rc) return rc;
+        if (have_long) {
+            LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
+                hipLaunchKernelGGL((k_layer1_long<LPR_, CP_>), dim3(blocks_for_rows(g->p_n_long, rpb)), dim3(LT_BLOCK), 0,
+                                   st, g->p_n_long, g->p_long_row, g->p_long_segptr, seg_part, Hp, W2p, C, Z1, S2)));
+            LT_CHECK_LAUNCH();
+        }
+        LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
+            hipLaunchKernelGGL((k_layer1_tail<LPR_, CP_>), dim3(grid), dim3(LT_BLOCK), 0, st, g->n, g->rowptr, Z1, Hp,
+                               W2p, C, S2)));
+        LT_CHECK_LAUNCH();
+        return LT_OK;
+    }
     if (have_long) {   // hub rows first: segment sums, then their ordered sum (uses the graph's scratch)
         LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_layer1_seg<LPR_>), dim3(blocks_for_rows(g->p_n_seg, rpb)),
                                                  dim3(LT_BLOCK), 0, st, g->p_n_seg, g->rowptr, g->col, g->val,
@@ -291,55 +236,6 @@ int lt_launch_layer2(const lt_graph *g, const float *S2, int C, const float *b2,
     return LT_OK;
 }
 
-extern "C" int lt_spmm_csr_f32(const lt_graph *g, const float *S, int64_t lds, int32_t ncols,
-                               const float *bias, int32_t relu, float *out, int64_t ldo,
-                               void *stream) {
-    LT_REQUIRE(g != nullptr, "lt_spmm_csr_f32: graph is NULL");
-    LT_REQUIRE(ncols > 0, "lt_spmm_csr_f32: ncols=%d", ncols);
-    LT_REQUIRE(S != nullptr && out != nullptr, "lt_spmm_csr_f32: S/out is NULL");
-    LT_REQUIRE(lds >= ncols && ldo >= ncols, "lt_spmm_csr_f32: leading dimension < ncols");
-    LT_REQUIRE(lds < INT32_MAX && ldo < INT32_MAX, "lt_spmm_csr_f32: leading dimension too large");
-    hipStream_t st = (hipStream_t)stream;
-    if (g->n == 0) return LT_OK;
-    lt_prof_scope prof_(LT_K_SPMM, st);
-    if (ncols <= LT_MAX_C && !(ncols % 4 == 0 && lds % 4 == 0 && ldo % 4 == 0)) {
-        const unsigned grid = blocks_for_rows(g->n, LT_BLOCK / LT_L2_LANES);
-        LT_DISPATCH_CP(lt_cp_for(ncols),
-            hipLaunchKernelGGL((k_spmm_narrow<CP_>), dim3(grid), dim3(LT_BLOCK), 0, st, g->n,
-                               g->rowptr, g->col, g->val, S, (int)lds, ncols, bias, relu, out,
-                               (int)ldo));
-        LT_CHECK_LAUNCH();
-        return LT_OK;
-    }
-    if (ncols % 4 != 0 || ncols > LT_MAX_H)
-        return lt_set_error(LT_ERR_UNSUPPORTED,
-                            "lt_spmm_csr_f32: ncols=%d (need ncols %% 4 == 0 and <= %d, or <= %d)",
-                            ncols, LT_MAX_H, LT_MAX_C);
-    LT_REQUIRE(lds % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)S % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
-                   (!bias || (uintptr_t)bias % 16 == 0),
-               "lt_spmm_csr_f32: wide path needs 16-byte aligned S/out/bias and ld %% 4 == 0");
-    const int lpr = lt_lpr_for(ncols);
-    const unsigned grid = blocks_for_rows(g->n, (LT_BLOCK / 64) * (64 / lpr));
-    LT_DISPATCH_LPR(lpr,
-        hipLaunchKernelGGL((k_spmm_rows<LPR_>), dim3(grid), dim3(LT_BLOCK), 0, st, g->n, g->rowptr,
-                           g->col, g->val, S, (int)lds, ncols, bias, relu, out, (int)ldo));
-    LT_CHECK_LAUNCH();
-    if (g->n_long > 0) {
-        const unsigned gseg = blocks_for_rows(g->n_lseg, (LT_BLOCK / 64) * (64 / lpr));
-        LT_DISPATCH_LPR(lpr,
-            hipLaunchKernelGGL((k_spmm_long_segments<LPR_>), dim3(gseg), dim3(LT_BLOCK), 0, st, g->n_lseg,
-                               g->rowptr, g->long_row, g->lseg_long, g->lseg_begin, g->col, g->val, S,
-                               (int)lds, ncols, g->seg_scratch, LT_MAX_H));
-        LT_CHECK_LAUNCH();
-        const int tot = g->n_long * ncols;
-        hipLaunchKernelGGL(k_spmm_long_combine, dim3((tot + 255) / 256), dim3(256), 0, st, g->n_long,
-                           g->long_row, g->long_segptr, g->seg_scratch, LT_MAX_H, ncols, bias, relu, out,
-                           (int)ldo);
-        LT_CHECK_LAUNCH();
-    }
-    return LT_OK;
-}
-
 // --------------------------------------------------------------------------------------------
 // 2-layer forward with caller workspace
 // --------------------------------------------------------------------------------------------
@@ -353,7 +249,7 @@ static int check_dims(const char *who, const lt_graph *g, int F, int H, int C) {
 }
 
 struct gcn2_ws {
-    float *S1, *S2, *b1p, *W2p, *slabs;
+    float *S1, *S2, *b1p, *W2p, *slabs, *Z1;
     size_t bytes;
 };
 static gcn2_ws carve_gcn2(void *base, int n, int H, int C, int F) {
@@ -367,6 +263,9 @@ static gcn2_ws carve_gcn2(void *base, int n, int H, int C, int F) {
     w.W2p = (float *)(p + off); off += lt_align_up((size_t)Hp * C * sizeof(float), 256);
     const size_t sb = lt_gemm_splitk_slab_bytes(n, H, F, lt_gemm_pick_kslice(n, H, F));
     w.slabs = sb ? (float *)(p + off) : nullptr; off += lt_align_up(sb, 256);
+    // a graph large enough for the tiled layer-1 route materialises the pre-activation
+    const bool tiled = (long long)n * Hp * (long long)sizeof(float) >= lt_tune().tiled_min_bytes;
+    w.Z1 = tiled ? (float *)(p + off) : nullptr; off += tiled ? lt_align_up((size_t)n * Hp * sizeof(float), 256) : 0;
     w.bytes = off;
     return w;
 }
@@ -418,7 +317,7 @@ extern "C" int lt_gcn2_forward(const lt_graph *g, const float *X, int64_t ldx, i
     const float *b1e = nullptr, *W2e = nullptr;
     rc = prepare_layer_inputs(g->n, X, ldx, F, W1, b1, H, W2, C, w.S1, w.b1p, w.W2p, &b1e, &W2e, w.slabs, st);
     if (rc) return rc;
-    rc = lt_launch_layer1(g, w.S1, Hp, b1e, W2e, C, nullptr, w.S2, st);
+    rc = lt_launch_layer1(g, w.S1, Hp, b1e, W2e, C, w.Z1, w.S2, st);
     if (rc) return rc;
     return lt_launch_layer2(g, w.S2, C, b2, logits, st);
 }
@@ -428,7 +327,7 @@ extern "C" int lt_gcn2_forward(const lt_graph *g, const float *X, int64_t ldx, i
 // --------------------------------------------------------------------------------------------
 static void free_baseline(lt_baseline *b) {
     if (!b) return;
-    (void)hipFree(b->S1);
+    if (b->S1_owned) (void)hipFree(b->S1);
     (void)hipFree(b->Z1);
     (void)hipFree(b->S2);
     (void)hipFree(b->OUT);
@@ -451,6 +350,57 @@ extern "C" int lt_baseline_refresh(lt_baseline *b, void *stream) {
     b->fp64_fresh = false;
     return prepare_layer_inputs(b->n, b->X, b->ldx, b->F, b->W1, b->b1, b->H, b->W2, b->C, b->S1,
                                 b->b1p_buf, b->W2p_buf, &b->b1p, &b->W2p, b->slabs, st);
+}
+
+// Rows [row_begin, row_end) of X*W1 into dst[(row_end - row_begin), Hp] -- the sharded baseline of a multi-GPU run:
+// every rank computes its slice, one all-gather rebuilds S1 (the caller's collective, into the storage attached
+// with lt_baseline_attach_s1).  The split-K slicing is the one of the FULL product, so a row has the same bits
+// whichever rank, and however many ranks, computed it.
+extern "C" int lt_baseline_refresh_rows(lt_baseline *b, int32_t row_begin, int32_t row_end, float *dst, void *stream) {
+    LT_REQUIRE(b != nullptr, "lt_baseline_refresh_rows: baseline is NULL");
+    LT_REQUIRE(row_begin >= 0 && row_begin <= row_end && row_end <= b->n,
+               "lt_baseline_refresh_rows: rows [%d, %d) outside [0, %d]", row_begin, row_end, b->n);
+    LT_REQUIRE(dst != nullptr && ((uintptr_t)dst % 16) == 0, "lt_baseline_refresh_rows: dst is NULL or not 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    b->layers_fresh = false;
+    b->fp64_fresh = false;
+    // b1 / W2 padding follows the weights exactly as in lt_baseline_refresh
+    if (b->Hp == b->H && ((uintptr_t)b->b1 % 16) == 0) {
+        b->b1p = b->b1;
+        b->W2p = b->W2;
+    } else {
+        hipLaunchKernelGGL(k_pad_b1_w2, dim3((b->Hp * (b->C + 1) + 255) / 256), dim3(256), 0, st, b->b1, b->W2, b->H,
+                           b->Hp, b->C, b->b1p_buf, b->W2p_buf);
+        LT_CHECK_LAUNCH();
+        b->b1p = b->b1p_buf;
+        b->W2p = b->W2p_buf;
+    }
+    const int m = row_end - row_begin;
+    if (m == 0) return LT_OK;
+    if (b->Hp != b->H) LT_HIP(hipMemsetAsync(dst, 0, (size_t)m * b->Hp * sizeof(float), st));
+    const float *A = b->X + (size_t)row_begin * b->ldx;
+    if (b->slabs)
+        return lt_launch_gemm_splitk(A, b->ldx, b->W1, b->H, dst, b->Hp, m, b->H, b->F, lt_gemm_pick_kslice(b->n, b->H, b->F),
+                                     b->slabs, st);
+    return lt_launch_gemm(A, b->ldx, b->W1, b->H, dst, b->Hp, m, b->H, b->F, st);
+}
+
+// The baseline reads S1 = X*W1 from caller-owned storage from now on ([>= n, Hp] fp32, ld == Hp, 16-byte aligned;
+// e.g. a torch tensor that is the output of the ranks' all-gather).  The current S1 is copied over.
+extern "C" int lt_baseline_attach_s1(lt_baseline *b, float *S1, int64_t ld, void *stream) {
+    LT_REQUIRE(b != nullptr && S1 != nullptr, "lt_baseline_attach_s1: NULL argument");
+    LT_REQUIRE(ld == b->Hp, "lt_baseline_attach_s1: ld=%lld, must equal the padded hidden width %d", (long long)ld, b->Hp);
+    LT_REQUIRE(((uintptr_t)S1 % 16) == 0, "lt_baseline_attach_s1: storage must be 16-byte aligned");
+    if (S1 == b->S1) return LT_OK;
+    if (b->n > 0)
+        LT_HIP(hipMemcpyAsync(S1, b->S1, (size_t)b->n * b->Hp * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (b->S1_owned) {
+        LT_HIP(hipStreamSynchronize((hipStream_t)stream));   // the copy reads the buffer freed below
+        (void)hipFree(b->S1);
+    }
+    b->S1 = S1;
+    b->S1_owned = false;
+    return LT_OK;
 }
 
 // Z1 / S2 / OUT (and the fp64 pre-activation when enabled and asked for) from the current S1, if stale
@@ -501,7 +451,14 @@ extern "C" int lt_baseline_create(const lt_graph *g, const float *X, int64_t ldx
     B_HIP(hipMalloc((void **)&b->OUT, nc));
     B_HIP(hipMalloc((void **)&b->b1p_buf, (size_t)b->Hp * sizeof(float)));
     B_HIP(hipMalloc((void **)&b->W2p_buf, (size_t)b->Hp * C * sizeof(float)));
-    if (g->p_n_seg > 0) B_HIP(hipMalloc((void **)&b->seg_part, (size_t)g->p_n_seg * b->Hp * sizeof(float)));
+    if (g->p_n_seg > 0) {
+        B_HIP(hipMalloc((void **)&b->seg_part, (size_t)g->p_n_seg * b->Hp * sizeof(float)));
+        // hub rows of FULL stage A run on a side stream next to the plain rows (fork / join by events inside
+        // lt_influence_rows): created here so that the launch functions create nothing and stay capturable
+        B_HIP(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+        B_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+        B_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+    }
     if (lt_gemm_splitk_slab_bytes(b->n, H, F, lt_gemm_pick_kslice(b->n, H, F)))
         B_HIP(hipMalloc((void **)&b->slabs, lt_gemm_splitk_slab_bytes(b->n, H, F, lt_gemm_pick_kslice(b->n, H, F))));
 #undef B_HIP

@@ -198,12 +198,19 @@ int lt_baseline_refresh_fp64(lt_baseline *b, hipStream_t st) {
 
 extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     LT_REQUIRE(b != nullptr, "lt_baseline_enable_fp64: baseline is NULL");
-    if (b->Z1d) return LT_OK;
+    if (b->Z1d) return LT_OK;   // Z1d is set only once all three buffers exist (see below)
     const size_t nh = (size_t)(b->n > 0 ? b->n : 1) * b->Hp * sizeof(double);
     const int splits = (b->F + LT_KSLICE_BASE - 1) / LT_KSLICE_BASE;
-    LT_HIP(hipMalloc((void **)&b->S1d, nh));
-    LT_HIP(hipMalloc((void **)&b->Z1d, nh));
-    if (splits > 1) LT_HIP(hipMalloc((void **)&b->slabs_d, (size_t)splits * (b->n > 0 ? b->n : 1) * b->H * sizeof(double)));
+    double *s1d = nullptr, *z1d = nullptr, *slabs = nullptr;
+    hipError_t e = hipMalloc((void **)&s1d, nh);
+    if (e == hipSuccess) e = hipMalloc((void **)&z1d, nh);
+    if (e == hipSuccess && splits > 1)
+        e = hipMalloc((void **)&slabs, (size_t)splits * (b->n > 0 ? b->n : 1) * b->H * sizeof(double));
+    if (e != hipSuccess) {   // all or nothing: a retry starts from a clean state, nothing leaks
+        (void)hipFree(s1d); (void)hipFree(z1d); (void)hipFree(slabs);
+        return lt_set_error(LT_ERR_HIP, "lt_baseline_enable_fp64: hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    b->S1d = s1d; b->Z1d = z1d; b->slabs_d = slabs;
     const int rc = compute_z1d(b, (hipStream_t)stream);
     b->fp64_fresh = rc == LT_OK;
     return rc;
@@ -213,4 +220,6 @@ void lt_baseline_free_fp64(lt_baseline *b) {
     (void)hipFree(b->S1d);
     (void)hipFree(b->Z1d);
     (void)hipFree(b->slabs_d);
+    b->S1d = b->Z1d = b->slabs_d = nullptr;
+    b->fp64_fresh = false;
 }

@@ -865,15 +865,9 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
 // ------------------------------------------------------------------------------------------------
 // Probes per wave of the wide FULL kernel (8, 16 or 32): a tuning knob only -- results are bit-identical.
 // Measured cost of a (row, group) wave ~ 3.4 + 0.63 * P (arbitrary units; twitch-RU, 500 probes: P = 8 /
-// 16 / 32 -> 528 / 396 / 376 us), so the choice minimises ceil(nb / P) * (3.4 + 0.63 P); LT_FULL_P pins it.
+// 16 / 32 -> 528 / 396 / 376 us), so the choice minimises ceil(nb / P) * (3.4 + 0.63 P); lt_set_tuning("full_p") pins it.
 static int full_probes_per_wave(int nb) {
-    static int pinned = -1;
-    if (pinned < 0) {
-        const char *e = getenv("LT_FULL_P");
-        const int v = e ? atoi(e) : 0;
-        pinned = (v == 8 || v == 16 || v == 32) ? v : 0;
-    }
-    if (pinned) return pinned;
+    if (lt_tune().full_p) return lt_tune().full_p;
     int best = 16;
     double best_cost = 1e30;
     for (int P = 8; P <= 32; P *= 2) {
@@ -883,42 +877,21 @@ static int full_probes_per_wave(int nb) {
     return best;
 }
 
-// LT_OVERLAP=0 keeps the hub-row kernels on the caller's stream (A/B knob)
-static bool overlap_enabled() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("LT_OVERLAP");
-        v = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return v == 1;
-}
+// "overlap" = 0 keeps the hub-row kernels on the caller's stream (A/B knob)
+static bool overlap_enabled() { return lt_tune().overlap != 0; }
 
-// bytes of per-probe scratch per chunk; LT_CHUNK_BUDGET_BYTES overrides it (tests force multi-chunk calls)
-static size_t chunk_budget() {
-    const char *e = getenv("LT_CHUNK_BUDGET_BYTES");
-    if (e && atoll(e) > 0) return (size_t)atoll(e);
-    return LT_CHUNK_BUDGET;
-}
+// bytes of per-probe scratch per chunk ("chunk_budget_bytes": tests force multi-chunk calls)
+static size_t chunk_budget() { return (size_t)lt_tune().chunk_budget; }
 
-static int wide_min_hp() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("LT_WIDE_MIN_HP");
-        v = (e && atoi(e) > 0) ? atoi(e) : 24;   // measured on twitch-RU, 500 probes: H = 16: 158 us (narrow) vs 257; H = 32: 359 vs 264
-    }
-    return v;
-}
+// measured on twitch-RU, 500 probes: H = 16: 158 us (narrow) vs 257; H = 32: 359 vs 264
+static int wide_min_hp() { return lt_tune().wide_min_hp; }
 
 // Long rows go segment-parallel when the segment sums of ONE probe fit LT_LONG_PAR_BYTES (a graph with a few
 // hubs); a graph where they do not (10^5 long rows) walks each long row in one wave per <= 16 probes.
+// "long_par" pins the choice (tests run both paths on small graphs).
 #define LT_LONG_PAR_BYTES ((size_t)4 << 20)
 static bool long_rows_parallel(const lt_graph *g, int Hp) {
-    static int forced = -2;   // LT_LONG_PAR=0 / 1 pins the choice (tests run both paths on small graphs)
-    if (forced == -2) {
-        const char *e = getenv("LT_LONG_PAR");
-        forced = e ? (atoi(e) != 0 ? 1 : 0) : -1;
-    }
-    if (forced >= 0) return forced == 1;
+    if (lt_tune().long_par >= 0) return lt_tune().long_par == 1;
     return (size_t)g->p_n_seg * Hp * sizeof(float) * 9 / 8 <= LT_LONG_PAR_BYTES;
 }
 
@@ -968,8 +941,8 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
         w.S2x = (float *)take(chunk * maxc * C * sizeof(float));
         w.off = (int32_t *)take((chunk + 1) * sizeof(int32_t));
         const size_t bw = (n + 31) / 32;
-        // (LT_ITEM_BITS=0 forces the search path a huge graph takes: tests)
-        static const bool no_bits = getenv("LT_ITEM_BITS") && atoi(getenv("LT_ITEM_BITS")) == 0;
+        // ("item_bits" = 0 forces the search path a huge graph takes: tests)
+        const bool no_bits = lt_tune().item_bits == 0;
         w.bits = (!no_bits && chunk * bw * sizeof(uint32_t) <= LT_BITS_MAX_BYTES) ? (uint32_t *)take(chunk * bw * sizeof(uint32_t)) : nullptr;
     }
     w.bytes = offb;
@@ -1015,6 +988,9 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
         const int32_t *probes = probe_nodes + p0;
         float *orow = out + (int64_t)p0 * ldo;
         const long pairs = (long)nb * n_obs;
+        LT_REQUIRE(mode == LT_MODE_FULL || (pairs * LT_L2_LANES + LT_BLOCK - 1) / LT_BLOCK < 2147483647L,
+                   "lt_influence_rows: %d probes x %d observed nodes per chunk exceed the grid limit (lower chunk_budget_bytes)",
+                   nb, n_obs);
         const unsigned gridB = (unsigned)((pairs * LT_L2_LANES + LT_BLOCK - 1) / LT_BLOCK);
 
         if (mode != LT_MODE_DELTA) {
@@ -1043,12 +1019,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                 const int n_segblocks = par ? g->p_n_seg * rgroups : 0;
                 const int PL = P == 8 ? 8 : 16, lgroups = (nb + PL - 1) / PL;
                 hipStream_t ls = st;
-                if (g->p_n_long > 0 && overlap_enabled()) {
-                    if (!b->side) {
-                        LT_HIP(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
-                        LT_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
-                        LT_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
-                    }
+                if (g->p_n_long > 0 && overlap_enabled() && b->side) {   // stream + events made by lt_baseline_create
                     ls = b->side;
                     LT_HIP(hipEventRecord(b->ev_fork, st));
                     LT_HIP(hipStreamWaitEvent(ls, b->ev_fork, 0));

@@ -23,26 +23,24 @@ struct lt_graph {
     int32_t *tptr = nullptr;
     int32_t *trow = nullptr;
     float *tval = nullptr;
-    // Long rows (more than LT_SPMM_SEG entries) of the standalone SpMM are cut into segments that
-    // separate waves sum; partials land in `seg_scratch` and are added in segment order.
-    int32_t n_long = 0;          // number of long rows
-    int32_t n_lseg = 0;          // total segments over all long rows
-    int32_t *long_row = nullptr;   // [n_long]     row id
-    int32_t *long_segptr = nullptr;  // [n_long + 1] first segment of each long row
-    int32_t *lseg_long = nullptr;  // [n_lseg]     index into long_row
-    int32_t *lseg_begin = nullptr;  // [n_lseg]     first CSR entry of the segment
-    float *seg_scratch = nullptr;  // [n_lseg, LT_MAX_H] partial sums (one stream at a time: handle is not thread-safe)
-    // The same cut at LT_ROW_SEG entries for the layer-1 chains (lt_rows.cuh row_dot): a row longer than that
-    // is summed segment by segment in EVERY kernel, which lets FULL stage A hand the segments of a hub row to
-    // separate waves (k_full_stageA_lds segment mode + k_full_long_combine).
+    // Long rows (hubs).  A row of more than LT_ROW_SEG entries is summed segment by segment in EVERY kernel
+    // (lt_rows.cuh row_dot: 128-entry fmaf chains, their sums added in segment order), which lets any kernel hand
+    // the segments of a hub row to separate waves and still produce the same bits: the SpMM / layer-1 segment
+    // kernels, FULL stage A (k_full_stageA_lds segment mode + k_full_long_combine).
     int32_t p_n_long = 0, p_n_seg = 0;
     int32_t *p_long_row = nullptr;     // [p_n_long]     row id
     int32_t *p_long_segptr = nullptr;  // [p_n_long + 1] first segment of each long row
     int32_t *p_seg_long = nullptr;     // [p_n_seg]      index into p_long_row
     int32_t *p_seg_begin = nullptr;    // [p_n_seg]      first CSR entry of the segment
-    float *p_seg_scratch = nullptr;    // [p_n_seg, LT_MAX_H] segment sums of the baseline layer 1 (one stream at a time)
+    float *p_seg_scratch = nullptr;    // [p_n_seg, LT_MAX_H] segment sums (standalone SpMM, lt_gcn2_forward; one stream at a time)
+    // Work items of the tiled SpMM (lt_spmm.hip), built for every graph: one item per row of up to LT_ROW_SEG entries
+    // and one per segment of a long row.  Order: the segments first, by the column their first entry reads (waves
+    // that run at the same time then gather from one sliding window of S), then the short rows, longest first.
+    int32_t w_n = 0;
+    int32_t *w_e0 = nullptr;    // [w_n] first CSR entry
+    int32_t *w_cnt = nullptr;   // [w_n] entries (<= LT_ROW_SEG)
+    int32_t *w_dst = nullptr;   // [w_n] row id, or n + segment id (index into the p_seg_* tables)
 };
-#define LT_SPMM_SEG 512
 #define LT_ROW_SEG 128   // layer-1 chains: entries per segment (rows up to this length are one plain chain)
 #define LT_CSR_PAD 16   // zero entries appended to col/val
 
@@ -55,7 +53,8 @@ struct lt_baseline {
     int64_t ldx = 0;
     const float *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
     // owned (device)
-    float *S1 = nullptr;   // [n, Hp]  X * W1
+    float *S1 = nullptr;   // [n, Hp]  X * W1 (caller-owned after lt_baseline_attach_s1)
+    bool S1_owned = true;
     float *Z1 = nullptr;   // [n, Hp]  A_hat * S1 + b1   (pre-activation)
     float *S2 = nullptr;   // [n, C]   relu(Z1) * W2
     float *OUT = nullptr;  // [n, C]   A_hat * S2 + b2   (baseline logits)
@@ -83,6 +82,19 @@ struct lt_baseline {
 };
 
 int lt_set_error(int code, const char *fmt, ...);
+
+// Tuning knobs (lt_core.hip): defaults come from the environment (LT_* variables, read once), lt_set_tuning
+// overrides them at run time.  Every setting gives bit-identical results; they select between kernel routes.
+struct lt_tuning {
+    long long tiled_min_bytes;   // S of at least this many bytes -> tiled SpMM / layer 1 (LT_SPMM_TILED_MIN_BYTES)
+    long long chunk_budget;      // bytes of per-probe scratch per probe chunk (LT_CHUNK_BUDGET_BYTES)
+    int full_p;                  // probes per wave of FULL stage A: 8 / 16 / 32, 0 = from the probe count (LT_FULL_P)
+    int long_par;                // hub rows of FULL stage A: 1 segment-parallel, 0 one wave per row, -1 by size (LT_LONG_PAR)
+    int overlap;                 // hub-row kernels on the baseline's side stream (LT_OVERLAP)
+    int item_bits;               // SPARSE / DELTA stage B membership bitmap (LT_ITEM_BITS)
+    int wide_min_hp;             // smallest padded hidden width served by the batched stage-A kernel (LT_WIDE_MIN_HP)
+};
+lt_tuning &lt_tune();
 
 #define LT_HIP(call)                                                                       \
     do {                                                                                   \
@@ -129,6 +141,13 @@ int lt_launch_layer1(const lt_graph *g, const float *S1, int Hp, const float *b1
                      const float *W2p, int C, float *Z1_or_null, float *S2, hipStream_t st,
                      float *seg_part = nullptr);
 // layer 2 for all rows: OUT = A_hat*S2 + b2
+// Tiled SpMM over the graph's work items (lt_spmm.hip): chains start from `init` (NULL = 0) for short rows and for
+// the first segment of a long row; short rows get `+ bias_after` (NULL = none) and the optional ReLU and go to
+// out[row]; segment sums go raw to seg_out[segment] for the caller's ordered combine.
+bool lt_tiled_wanted(const lt_graph *g, int ncols);
+int lt_launch_rows_tiled(const lt_graph *g, const float *S, int64_t lds, int ncols, const float *init,
+                         const float *bias_after, int relu, float *out, int64_t ldo, float *seg_out,
+                         int64_t ld_seg, hipStream_t st);
 int lt_launch_layer2(const lt_graph *g, const float *S2, int C, const float *b2, float *OUT,
                      hipStream_t st);
 int lt_launch_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, float *C,

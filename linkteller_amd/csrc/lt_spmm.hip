@@ -1,0 +1,310 @@
+// SpMM  out = A_hat * S (+ bias)(ReLU)                       torch.spmm + bias, gcn/layers.py:32-36
+//
+// Two routes, same arithmetic (a row is a k-ordered fmaf chain per output column; a row of more than
+// LT_ROW_SEG entries is the ordered sum of its 128-entry segment chains -- lt_rows.cuh):
+//
+//  * small graphs (S fits the caches: twitch): k_spmm_rows, one lane group per row, the whole row of S per gather;
+//    launch-bound, nothing to tile.
+//  * large graphs (S beyond the L2s): k_rows_tiled.  What bounds a row-gather SpMM there is not HBM streaming but
+//    the L2 capacity misses of the gathers (R-MAT scale 21: 67 GB of gathered rows against 5 GB of algorithmic
+//    traffic), served by the fabric at ~5 TB/s.  Three things cut those misses (profiles/r02_spmm_lab_*.txt):
+//      - column slices: a 16-lane group owns one work item x 64 columns (256 B of a gathered row) and the slice is
+//        a function of the XCD a block lands on (blocks are dealt round-robin over the 8 XCDs), so one XCD's
+//        4 MiB L2 only ever sees a quarter of S: four times the rows per byte of cache;
+//      - work items instead of rows: rows of up to 128 entries and the 128-entry segments of the long rows are
+//        the same kind of item, sorted so that a wave's four items are equally long (no idle lane groups) and the
+//        hub rows are spread over the chip instead of serialising their waves;
+//      - the segment items are ordered by the column their first entry reads.  Entries of a row are sorted by
+//        column, so waves that run at the same time gather from one sliding window of S and the segments of
+//        different hub rows that cross the same columns meet in L2.
+//    (col, val) stream in with non-temporal loads, one coalesced 16-entry block per lane group, and are handed
+//    round by DPP row broadcasts; results leave with non-temporal stores.
+#include <type_traits>
+
+#include "lt_rows.cuh"
+
+#define LT_BLOCK 256
+#define LT_TILE_GL 16    // lanes per item: 16 lanes x float4 = 64 columns
+#define LT_TILE_U 8      // gathers in flight per lane
+
+template <int N, typename F, int I = 0>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, F, I + 1>(static_cast<F &&>(f));
+    }
+}
+// lane K of this lane's 16-lane row (DPP row_newbcast)
+template <int K>
+__device__ __forceinline__ int row_bcast(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, 0x150 + K, 0xf, 0xf, false);
+}
+
+// BIG: S spans 4 GiB or more (byte offsets of a gathered row no longer fit 32 bits)
+template <bool BIG>
+__global__ __launch_bounds__(LT_BLOCK) void k_rows_tiled(
+    int n_items, const int32_t *__restrict__ w_e0, const int32_t *__restrict__ w_cnt,
+    const int32_t *__restrict__ w_dst, int n, const int32_t *__restrict__ col, const float *__restrict__ val,
+    const float *__restrict__ S, long lds, int ncols, const float *__restrict__ init,
+    const float *__restrict__ bias_after, int relu, float *__restrict__ out, long ldo,
+    float *__restrict__ seg_out, long ld_seg, const int32_t *__restrict__ seg_begin,
+    const int32_t *__restrict__ seg_long, const int32_t *__restrict__ long_row,
+    const int32_t *__restrict__ rowptr, int ns) {
+    constexpr int GL = LT_TILE_GL, U = LT_TILE_U;
+    constexpr int GPW = 64 / GL, IPB = (LT_BLOCK / 64) * GPW;
+    const int lane = threadIdx.x & 63;
+    const int j = lane & (GL - 1);
+    // slice from the XCD: blocks b and b + 8 share an XCD (observed dispatch order; only speed depends on it)
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int xps = 8 / ns;
+    const int slice = xcd % ns;
+    const int it = (q * xps + xcd / ns) * IPB + (threadIdx.x >> 6) * GPW + lane / GL;
+    if (it >= n_items) return;
+    const int e0 = __builtin_nontemporal_load(w_e0 + it);
+    const int cnt = __builtin_nontemporal_load(w_cnt + it);
+    const int dst = __builtin_nontemporal_load(w_dst + it);
+    const int coff = slice * 4 * GL + 4 * j;
+    const bool active = coff < ncols;
+    // a chain starts from `init` (the layer-1 bias) on a short row and on the FIRST segment of a long row
+    bool first = true;
+    if (dst >= n) {
+        const int sg = dst - n;
+        first = seg_begin[sg] == rowptr[long_row[seg_long[sg]]];
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (init != nullptr && first && active) acc = ld4(init + coff);
+    const char *Sb = reinterpret_cast<const char *>(S);
+    const size_t rowbytes = (size_t)lds * 4u;
+    const unsigned loff = (unsigned)coff * 4u;
+    const int e1 = e0 + cnt;
+    for (int eb = e0; eb < e1; eb += GL) {
+        const int me = eb + j;
+        int myc = 0;
+        float mya = 0.f;
+        if (me < e1) {
+            myc = __builtin_nontemporal_load(col + me);
+            mya = __builtin_nontemporal_load(val + me);
+        }
+        const int left = e1 - eb;
+        static_for<GL / U>([&](auto kbt) {
+            constexpr int kb = decltype(kbt)::value * U;
+            if (kb < left) {
+                f32x4 s[U];
+                float a[U];
+                static_for<U>([&](auto ut) {
+                    constexpr int u = decltype(ut)::value;
+                    constexpr int k = kb + u;
+                    const int c = row_bcast<k>(myc);
+                    a[u] = __builtin_bit_cast(float, row_bcast<k>(__builtin_bit_cast(int, mya)));
+                    s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (k < left && active) {
+                        if (BIG) s[u] = *reinterpret_cast<const f32x4 *>(Sb + ((size_t)c * rowbytes + loff));
+                        else s[u] = *reinterpret_cast<const f32x4 *>(Sb + (size_t)((unsigned)c * (unsigned)rowbytes + loff));
+                    }
+                });
+                // entries past the end of the item are skipped, not multiplied by zero: the chain is exactly row_dot's
+                static_for<U>([&](auto ut) {
+                    constexpr int u = decltype(ut)::value;
+                    if (kb + u < left) acc = fma4(a[u], s[u], acc);
+                });
+            }
+        });
+    }
+    if (!active) return;
+    float *d;
+    if (dst < n) {
+        if (bias_after) {
+            const f32x4 b = ld4(bias_after + coff);
+            acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+        }
+        if (relu) {
+            acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+        }
+        d = out + (size_t)dst * ldo + coff;
+    } else {
+        d = seg_out + (size_t)(dst - n) * ld_seg + coff;
+    }
+    __builtin_nontemporal_store(acc, reinterpret_cast<f32x4 *>(d));
+}
+
+bool lt_tiled_wanted(const lt_graph *g, int ncols) {
+    return g->w_n > 0 && ncols % 4 == 0 && (long long)g->n * ncols * (long long)sizeof(float) >= lt_tune().tiled_min_bytes;
+}
+
+int lt_launch_rows_tiled(const lt_graph *g, const float *S, int64_t lds, int ncols, const float *init,
+                         const float *bias_after, int relu, float *out, int64_t ldo, float *seg_out,
+                         int64_t ld_seg, hipStream_t st) {
+    if (g->w_n == 0) return LT_OK;
+    int ns = (ncols + 4 * LT_TILE_GL - 1) / (4 * LT_TILE_GL);   // 64-column slices: 1, 2, 4 (3 -> 4, one idle)
+    ns = ns <= 1 ? 1 : (ns == 2 ? 2 : 4);
+    LT_REQUIRE(ncols <= 4 * LT_TILE_GL * 4, "tiled SpMM: ncols=%d > %d", ncols, 16 * LT_TILE_GL);
+    const int xps = 8 / ns;
+    constexpr int IPB = (LT_BLOCK / 64) * (64 / LT_TILE_GL);
+    const long chunks = ((long)g->w_n + IPB - 1) / IPB;
+    const long grid = 8 * ((chunks + xps - 1) / xps);
+    LT_REQUIRE(grid < 2147483647L, "tiled SpMM: grid limit");
+    const bool big = (unsigned long long)g->n * (unsigned long long)lds * 4ull >= (1ull << 32);
+    if (big)
+        hipLaunchKernelGGL(k_rows_tiled<true>, dim3((unsigned)grid), dim3(LT_BLOCK), 0, st, g->w_n, g->w_e0, g->w_cnt, g->w_dst,
+                           g->n, g->col, g->val, S, (long)lds, ncols, init, bias_after, relu, out, (long)ldo, seg_out,
+                           (long)ld_seg, g->p_seg_begin, g->p_seg_long, g->p_long_row, g->rowptr, ns);
+    else
+        hipLaunchKernelGGL(k_rows_tiled<false>, dim3((unsigned)grid), dim3(LT_BLOCK), 0, st, g->w_n, g->w_e0, g->w_cnt, g->w_dst,
+                           g->n, g->col, g->val, S, (long)lds, ncols, init, bias_after, relu, out, (long)ldo, seg_out,
+                           (long)ld_seg, g->p_seg_begin, g->p_seg_long, g->p_long_row, g->rowptr, ns);
+    LT_CHECK_LAUNCH();
+    return LT_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// small graphs: one LPR-lane group per row (4 columns per lane), rows of up to LT_ROW_SEG entries
+// --------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(LT_BLOCK) void k_spmm_rows(
+    int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const float *__restrict__ S, int lds, int ncols,
+    const float *__restrict__ bias, int relu, float *__restrict__ out, int ldo) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
+    const int gl = lane & (LPR - 1);
+    int r = wave * RPW + lane / LPR;
+    if (LPR == 64) r = __builtin_amdgcn_readfirstlane(r);
+    if (r >= n) return;
+    const int coff = 4 * gl;
+    const bool active = coff < ncols;
+    const int e0 = rowptr[r], e1 = rowptr[r + 1];
+    if (e1 - e0 > LT_ROW_SEG) return;  // long rows: k_spmm_segments + k_spmm_long_combine
+    const f32x4 acc = seg_chain(col, val, e0, e1, S, lds, coff, active, -1, nullptr, f32x4{0.f, 0.f, 0.f, 0.f});
+    if (!active) return;
+    f32x4 o = acc;
+    if (bias) {
+        const f32x4 b = ld4(bias + coff);
+        o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+    }
+    if (relu) {
+        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    }
+    *reinterpret_cast<f32x4 *>(out + (size_t)r * ldo + coff) = o;
+}
+
+// long rows, small-graph route: one lane group per segment -> partial[seg, :]
+template <int LPR>
+__global__ __launch_bounds__(LT_BLOCK) void k_spmm_segments(
+    int n_seg, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ long_row,
+    const int32_t *__restrict__ seg_long, const int32_t *__restrict__ seg_begin,
+    const int32_t *__restrict__ col, const float *__restrict__ val, const float *__restrict__ S,
+    int lds, int ncols, float *__restrict__ partial, int ldp) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
+    const int gl = lane & (LPR - 1);
+    int sg = wave * RPW + lane / LPR;
+    if (LPR == 64) sg = __builtin_amdgcn_readfirstlane(sg);
+    if (sg >= n_seg) return;
+    const int coff = 4 * gl;
+    if (coff >= ncols) return;
+    const int r = long_row[seg_long[sg]];
+    const int b = seg_begin[sg];
+    const int e = min(b + LT_ROW_SEG, rowptr[r + 1]);
+    const f32x4 acc = seg_chain(col, val, b, e, S, lds, coff, true, -1, nullptr, f32x4{0.f, 0.f, 0.f, 0.f});
+    *reinterpret_cast<f32x4 *>(partial + (size_t)sg * ldp + coff) = acc;
+}
+
+// ... then one thread per (long row, column): segment sums added in segment order, epilogue, store
+__global__ void k_spmm_long_combine(int n_long, const int32_t *__restrict__ long_row,
+                                    const int32_t *__restrict__ long_segptr,
+                                    const float *__restrict__ partial, long ldp, int ncols,
+                                    const float *__restrict__ bias, int relu, float *__restrict__ out,
+                                    long ldo) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n_long * ncols) return;
+    const int li = (int)(i / ncols), c = (int)(i % ncols);
+    float acc = partial[(size_t)long_segptr[li] * ldp + c];
+    for (int sg = long_segptr[li] + 1; sg < long_segptr[li + 1]; ++sg) acc += partial[(size_t)sg * ldp + c];
+    if (bias) acc += bias[c];
+    if (relu) acc = fmaxf(acc, 0.f);
+    out[(size_t)long_row[li] * ldo + c] = acc;
+}
+
+// SpMM, narrow right-hand side (ncols <= 8), 8 lanes per row (the layer-2 shape).
+template <int CP>
+__global__ __launch_bounds__(LT_BLOCK) void k_spmm_narrow(
+    int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const float *__restrict__ T, int ldt, int C,
+    const float *__restrict__ bias, int relu, float *__restrict__ out, int ldo) {
+    const int gid = (blockIdx.x * LT_BLOCK + threadIdx.x) / LT_L2_LANES;
+    const int q = threadIdx.x & (LT_L2_LANES - 1);
+    if (gid >= n) return;  // whole 8-lane groups exit together
+    float acc[CP];
+    row2_dot<CP>(col, val, rowptr[gid], rowptr[gid + 1], q, C,
+                 [&](int c, int) { return T + (size_t)c * ldt; }, acc);
+    if (q == 0) {
+#pragma unroll
+        for (int c = 0; c < CP; ++c)
+            if (c < C) {
+                float o = acc[c];
+                if (bias) o += bias[c];
+                if (relu) o = fmaxf(o, 0.f);
+                out[(size_t)gid * ldo + c] = o;
+            }
+    }
+}
+
+static inline unsigned blocks_for(long n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+extern "C" int lt_spmm_csr_f32(const lt_graph *g, const float *S, int64_t lds, int32_t ncols,
+                               const float *bias, int32_t relu, float *out, int64_t ldo,
+                               void *stream) {
+    LT_REQUIRE(g != nullptr, "lt_spmm_csr_f32: graph is NULL");
+    LT_REQUIRE(ncols > 0, "lt_spmm_csr_f32: ncols=%d", ncols);
+    LT_REQUIRE(S != nullptr && out != nullptr, "lt_spmm_csr_f32: S/out is NULL");
+    LT_REQUIRE(lds >= ncols && ldo >= ncols, "lt_spmm_csr_f32: leading dimension < ncols");
+    LT_REQUIRE(lds < INT32_MAX && ldo < INT32_MAX, "lt_spmm_csr_f32: leading dimension too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (g->n == 0) return LT_OK;
+    lt_prof_scope prof_(LT_K_SPMM, st);
+    if (ncols <= LT_MAX_C && !(ncols % 4 == 0 && lds % 4 == 0 && ldo % 4 == 0)) {
+        const unsigned grid = blocks_for(g->n, LT_BLOCK / LT_L2_LANES);
+        LT_DISPATCH_CP(lt_cp_for(ncols),
+            hipLaunchKernelGGL((k_spmm_narrow<CP_>), dim3(grid), dim3(LT_BLOCK), 0, st, g->n,
+                               g->rowptr, g->col, g->val, S, (int)lds, ncols, bias, relu, out,
+                               (int)ldo));
+        LT_CHECK_LAUNCH();
+        return LT_OK;
+    }
+    if (ncols % 4 != 0 || ncols > LT_MAX_H)
+        return lt_set_error(LT_ERR_UNSUPPORTED,
+                            "lt_spmm_csr_f32: ncols=%d (need ncols %% 4 == 0 and <= %d, or <= %d)",
+                            ncols, LT_MAX_H, LT_MAX_C);
+    LT_REQUIRE(lds % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)S % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+                   (!bias || (uintptr_t)bias % 16 == 0),
+               "lt_spmm_csr_f32: wide path needs 16-byte aligned S/out/bias and ld %% 4 == 0");
+    const int lpr = lt_lpr_for(ncols);
+    if (lt_tiled_wanted(g, ncols)) {
+        const int rc = lt_launch_rows_tiled(g, S, lds, ncols, nullptr, bias, relu, out, ldo, g->p_seg_scratch, LT_MAX_H, st);
+        if (rc) return rc;
+    } else {
+        const unsigned grid = blocks_for(g->n, (LT_BLOCK / 64) * (64 / lpr));
+        LT_DISPATCH_LPR(lpr,
+            hipLaunchKernelGGL((k_spmm_rows<LPR_>), dim3(grid), dim3(LT_BLOCK), 0, st, g->n, g->rowptr,
+                               g->col, g->val, S, (int)lds, ncols, bias, relu, out, (int)ldo));
+        LT_CHECK_LAUNCH();
+        if (g->p_n_long > 0) {
+            const unsigned gseg = blocks_for(g->p_n_seg, (LT_BLOCK / 64) * (64 / lpr));
+            LT_DISPATCH_LPR(lpr,
+                hipLaunchKernelGGL((k_spmm_segments<LPR_>), dim3(gseg), dim3(LT_BLOCK), 0, st, g->p_n_seg,
+                                   g->rowptr, g->p_long_row, g->p_seg_long, g->p_seg_begin, g->col, g->val, S,
+                                   (int)lds, ncols, g->p_seg_scratch, LT_MAX_H));
+            LT_CHECK_LAUNCH();
+        }
+    }
+    if (g->p_n_long > 0) {
+        const long tot = (long)g->p_n_long * ncols;
+        hipLaunchKernelGGL(k_spmm_long_combine, dim3(blocks_for(tot, 256)), dim3(256), 0, st, g->p_n_long,
+                           g->p_long_row, g->p_long_segptr, g->p_seg_scratch, (long)LT_MAX_H, ncols, bias, relu, out,
+                           (long)ldo);
+        LT_CHECK_LAUNCH();
+    }
+    return LT_OK;
+}

@@ -38,9 +38,68 @@ def all_gather_rows(local_rows: torch.Tensor, n_total: int, async_op: bool = Fal
     else:
         slab = torch.zeros((per, n_obs), dtype=local_rows.dtype, device=local_rows.device)
         slab[: local_rows.shape[0]] = local_rows
+    if slab.is_cuda and dist.get_backend() == "gloo":
+        # gloo has no all-gather for device tensors (test hook: several ranks on one GPU): stage through the host
+        full_h = torch.empty((ws * per, n_obs), dtype=slab.dtype)
+        dist.all_gather_into_tensor(full_h, slab.cpu())
+        full = full_h.to(slab.device)[:n_total]
+        return (full, None) if async_op else full
     full = torch.empty((ws * per, n_obs), dtype=local_rows.dtype, device=local_rows.device)
     if async_op:
         work = dist.all_gather_into_tensor(full, slab, async_op=True)
         return full[:n_total], work
     dist.all_gather_into_tensor(full, slab)
     return full[:n_total]
+
+
+def all_gather_into(full: torch.Tensor, shard: torch.Tensor):
+    """``full[world * k, ...] <- all ranks' shard[k, ...]`` on the current stream order (one all_gather_into_tensor)."""
+    if shard.is_cuda and dist.get_backend() == "gloo":      # test hook, see all_gather_rows
+        full_h = torch.empty(full.shape, dtype=full.dtype)
+        dist.all_gather_into_tensor(full_h, shard.cpu())
+        full.copy_(full_h)
+        return
+    dist.all_gather_into_tensor(full, shard)
+
+
+def shard_baseline_policy() -> str:
+    """LT_SHARD_BASELINE: '0' replicate X W1 on every rank, '1' shard it + all-gather S1, 'auto' (default) time both
+    at first use and keep the faster (the product is small at twitch size: whether the all-gather beats recomputing
+    depends on the link latency, not on arithmetic)."""
+    import os
+    v = os.environ.get("LT_SHARD_BASELINE", "auto").lower()
+    return v if v in ("0", "1", "auto") else "auto"
+
+
+def choose_baseline_sharding(base, trials: int = 5) -> bool:
+    """Apply shard_baseline_policy() to an engine.Baseline; every rank takes the same decision (max over ranks of the
+    measured refresh time, replicated vs sharded).  Returns True when the sharded refresh is on."""
+    import time
+    rank, ws = world()
+    pol = shard_baseline_policy()
+    if ws == 1 or pol == "0":
+        base.shard_refresh(False)
+        return False
+    if pol == "1":
+        base.shard_refresh(True)
+        return True
+    times = []
+    for enable in (False, True):
+        base.shard_refresh(enable)
+        for _ in range(2):
+            base.refresh()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(trials):
+            base.refresh()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if dist.get_backend() != "gloo":
+            t = t.to(base.x.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        times.append(float(t.item()))
+    use = times[1] < times[0]
+    base.shard_refresh(use)
+    base.refresh()
+    return use

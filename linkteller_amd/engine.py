@@ -88,6 +88,8 @@ class Baseline:
         self.n, self.f, self.h, self.c = n, f, self.w1.shape[1], self.w2.shape[1]
         if n != self.graph.n or self.w1.shape[0] != f or self.w2.shape[0] != self.h:
             raise ValueError("inconsistent GCN shapes")
+        if self.graph.device_index != self.x.device.index:
+            raise ValueError(f"the graph lives on cuda:{self.graph.device_index}, the features on {self.x.device}")
         h = C.c_void_p()
         _lib.check(_lib.lib().lt_baseline_create(self.graph.handle, self.x.data_ptr(), f, f, self.w1.data_ptr(),
                                                  self.b1.data_ptr(), self.h, self.w2.data_ptr(),
@@ -97,13 +99,46 @@ class Baseline:
         self._finalizer = weakref.finalize(self, _lib.lib().lt_baseline_destroy, h)
         self._ws = {}
         self._fp64 = False
+        self._shard = None          # (row_begin, row_end, per) while the sharded refresh is on
+        self._s1_full = None        # torch-owned S1 storage once attached (kept alive for the handle's lifetime)
+        self._send = None
 
     @property
     def handle(self):
         return self._h
 
     def refresh(self):
-        _lib.check(_lib.lib().lt_baseline_refresh(self._h, _stream()), "lt_baseline_refresh")
+        """Recompute S1 = X W1 from the (borrowed) inputs; the layers that depend on it are recomputed lazily.
+        With ``shard_refresh`` on, this rank computes only its rows and one all-gather rebuilds S1 on every rank."""
+        if self._shard is None:
+            _lib.check(_lib.lib().lt_baseline_refresh(self._h, _stream()), "lt_baseline_refresh")
+            return
+        import torch.distributed as dist
+        from . import dist as lt_dist
+        b, e, _ = self._shard
+        _lib.check(_lib.lib().lt_baseline_refresh_rows(self._h, b, e, self._send.data_ptr(), _stream()),
+                   "lt_baseline_refresh_rows")
+        lt_dist.all_gather_into(self._s1_full, self._send)
+
+    def shard_refresh(self, enable=True):
+        """Multi-GPU: shard the loop-invariant X W1 over the ranks of the initialised process group
+        instead of replicating it.  S1 moves to a torch-owned [world * ceil(n / world), Hp] tensor (the all-gather's
+        output) that the library reads in place.  Bits are those of the replicated product."""
+        from . import dist as lt_dist
+        rank, world = lt_dist.world()
+        if not enable or world == 1:
+            self._shard = None
+            return self
+        b, e, per = lt_dist.shard_bounds(self.n, rank, world)
+        hp = (self.h + 3) // 4 * 4
+        if self._s1_full is None or self._s1_full.shape[0] != world * per:
+            s1_full = torch.zeros((world * per, hp), dtype=torch.float32, device=self.x.device)
+            _lib.check(_lib.lib().lt_baseline_attach_s1(self._h, s1_full.data_ptr(), hp, _stream()), "lt_baseline_attach_s1")
+            torch.cuda.current_stream().synchronize()        # the previous storage may be released now
+            self._s1_full = s1_full
+            self._send = torch.zeros((per, hp), dtype=torch.float32, device=self.x.device)
+        self._shard = (b, e, per)
+        return self
 
     def logits(self) -> torch.Tensor:
         out = torch.empty((self.n, self.c), dtype=torch.float32, device=self.x.device)

@@ -154,9 +154,11 @@ class HipGraph:
         h = C.c_void_p()
         _lib.check(_lib.lib().lt_graph_create(n, int(col.shape[0]), rowptr.ctypes.data, col.ctypes.data,
                                               val.ctypes.data, C.byref(h)), "lt_graph_create")
+        import torch
         self._h = h
         self.n = n
         self.nnz = int(col.shape[0])
+        self.device_index = torch.cuda.current_device()      # lt_graph_create uploads to the current device
         self._finalizer = weakref.finalize(self, _lib.lib().lt_graph_destroy, h)
 
     @property

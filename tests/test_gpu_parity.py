@@ -8,7 +8,10 @@ Tolerances (see DESIGN.md "Parity"):
     (fp32 cancellation amplified by 1/delta = 1e4), so it cannot itself be the
     1e-4 target; it is checked to be *further* from fp64 than we are.
   * influence, modes 'full'/'sparse' (the fp32 finite difference, same noise class as the
-    reference): error vs fp64 <= 3x the reference-fp32's own error.  'sparse' == 'full' bit for bit.
+    reference): error vs fp64 <= 2x the reference-fp32's own error (measured 0.5 .. 1.5x; tiny cases where that
+    error is itself a few ulps keep an absolute floor).  'sparse' == 'full' bit for bit.
+  * AUC / AP from our scores (reference pair lookup + sklearn): delta within 1e-4 of the reference evaluated in
+    fp64; full within 2x the reference's own fp32 <-> fp64 gap of that fixture (+ FULL_METRIC_FLOOR).
   * exact zeros: every pair the reference scores exactly 0 in fp64 is exactly 0 here (all modes).
 """
 import numpy as np
@@ -18,6 +21,8 @@ import torch
 from conftest import csr_from, golden_args
 
 pytestmark = pytest.mark.gpu
+
+FULL_METRIC_FLOOR = 1e-3   # AUC / AP slack of the fp32 finite-difference modes on top of 2x the reference's own fp32 <-> fp64 gap
 
 
 def _setup(g, key, dev):
@@ -65,10 +70,25 @@ def test_influence_matrix(influence_golden, gpu, key):
     print(f"{key}: max score {scale:.3f}; |ref32-ref64|={err32:.2e}; |delta-ref64|={e_delta:.2e}; |full-ref64|={e_full:.2e}")
     assert e_delta <= 1e-5 * scale   # north_star asks 1e-4; measured 3e-7 (fp64 kink test, lt_fp64.hip)
     assert e_delta < err32
-    assert e_full <= 3.0 * err32
+    assert e_full <= 2.0 * err32     # measured 0.5 .. 1.5 x the reference's own fp32 error
     zero64 = ref64 == 0
     for m, r in res.items():
         assert np.all(r[zero64] == 0), f"{m}: non-zero where the reference is exactly zero"
+    # AUC / AP (north_star: "influence scores and AUC within 1e-4"): the attack's own metrics from OUR scores,
+    # through the reference's pair lookup and sklearn calls (attacker.py:233-247, 378-386).  delta sits within 1e-4 of
+    # the reference evaluated in fp64; full sits inside the band the reference's own fp32 <-> fp64 runs span.
+    from oracle import linkteller_oracle as O
+    ex, nex = g[f"{key}.ref32.exist"].tolist(), g[f"{key}.ref32.nonexist"].tolist()
+    auc64, ap64 = float(g[f"{key}.ref64.auc"]), float(g[f"{key}.ref64.ap"])
+    auc32, ap32 = float(g[f"{key}.ref32.auc"]), float(g[f"{key}.ref32.ap"])
+    got = {m: O.attack_metrics(*O.pair_scores(res[m], nodes, ex, nex)) for m in ("delta", "full")}
+    print(f"{key}: auc ref64 {auc64:.6f} ref32 {auc32:.6f} delta {got['delta']['auc']:.6f} full {got['full']['auc']:.6f}; "
+          f"ap ref64 {ap64:.6f} ref32 {ap32:.6f} delta {got['delta']['ap']:.6f} full {got['full']['ap']:.6f}")
+    assert abs(got["delta"]["auc"] - auc64) <= 1e-4 and abs(got["delta"]["ap"] - ap64) <= 1e-4
+    # (the band of a single fixture can be tiny by chance -- rand400: 7e-5 -- while the noise class is 5e-4 .. 5e-3
+    # over the five fixtures, hence the floor)
+    assert abs(got["full"]["auc"] - auc64) <= 2.0 * abs(auc32 - auc64) + FULL_METRIC_FLOOR
+    assert abs(got["full"]["ap"] - ap64) <= 2.0 * abs(ap32 - ap64) + FULL_METRIC_FLOOR
 
 
 def _hub_graph(n, e, hub_deg, seed):
@@ -231,7 +251,7 @@ def test_gcn3_efficient_attack_on_device(gpu, tmp_path, monkeypatch):
     infl = atk.influence_matrix()
     ref64, ref32 = g["gcn3.ref64.influence_val"], g["gcn3.ref32.influence_val"]
     e32 = np.abs(ref32 - ref64).max()
-    assert np.abs(infl - ref64).max() <= 3.0 * e32            # fp32 finite difference: the reference's noise class
+    assert np.abs(infl - ref64).max() <= 2.0 * e32            # fp32 finite difference: the reference's noise class
     assert np.all(infl[ref64 == 0] == 0)
     # logits of the 3-layer model through the unfused HIP layers
     with torch.no_grad():
@@ -286,7 +306,7 @@ def test_shapes_and_edge_cases(gpu, h, c, norm):
     res = {m: base.influence_rows(probes, observe, 1e-4, m).cpu().numpy().astype(np.float64) for m in ("full", "sparse", "delta")}
     assert np.array_equal(res["full"], res["sparse"])
     assert np.abs(res["delta"] - ref64).max() <= 1e-5 * scale
-    assert np.abs(res["full"] - ref64).max() <= 3.0 * e32 + 1e-4 * scale
+    assert np.abs(res["full"] - ref64).max() <= 2.0 * e32 + 1e-4 * scale
     for r in res.values():
         assert np.all(r[ref64 == 0] == 0)
     assert np.array_equal(res["full"][-1], res["full"][-2])          # duplicate probe -> identical rows
@@ -333,11 +353,15 @@ def test_probe_chunking_is_transparent(gpu, influence_golden, monkeypatch):
     args, base = _setup(g, "pl600", gpu)
     nodes = g["pl600.ref32.test_nodes"]
     ref = {m: base.influence_rows(nodes, nodes, args["influence"], m).cpu().numpy() for m in ("full", "sparse", "delta")}
-    monkeypatch.setenv("LT_CHUNK_BUDGET_BYTES", str(120 * 1024))     # ~10 probes per chunk at n=600, H=256
-    args2, base2 = _setup(g, "pl600", gpu)
-    for m in ("full", "sparse", "delta"):
-        got = base2.influence_rows(nodes, nodes, args["influence"], m).cpu().numpy()
-        assert np.array_equal(got, ref[m]), m
+    from linkteller_amd import _lib
+    _lib.set_tuning("chunk_budget_bytes", 120 * 1024)     # ~10 probes per chunk at n=600, H=256
+    try:
+        args2, base2 = _setup(g, "pl600", gpu)
+        for m in ("full", "sparse", "delta"):
+            got = base2.influence_rows(nodes, nodes, args["influence"], m).cpu().numpy()
+            assert np.array_equal(got, ref[m]), m
+    finally:
+        _lib.set_tuning("chunk_budget_bytes", None)
 
 
 def test_rmat_shape_scaled_config5(gpu):
@@ -361,7 +385,7 @@ def test_rmat_shape_scaled_config5(gpu):
     res = {m: base.influence_rows(probes, observe, 1e-4, m).cpu().numpy().astype(np.float64) for m in ("full", "sparse", "delta")}
     assert np.array_equal(res["full"], res["sparse"])
     assert np.abs(res["delta"] - ref64).max() <= 1e-5 * ref64.max()
-    assert np.abs(res["full"] - ref64).max() <= 3.0 * np.abs(ref32 - ref64).max() + 1e-4 * ref64.max()
+    assert np.abs(res["full"] - ref64).max() <= 2.0 * np.abs(ref32 - ref64).max() + 1e-4 * ref64.max()
     assert np.all(res["full"][ref64 == 0] == 0) and np.all(res["delta"][ref64 == 0] == 0)
 
 
@@ -375,14 +399,15 @@ def _two_hop_mask(a_hat, probes, observe):
     return reach[:, observe]
 
 
-@pytest.mark.parametrize("n_test,served", [(500, "clean"), (2000, "clean"), (500, "lapgraph")])
-def test_full_size_twitch_ru(gpu, n_test, served):
-    """BASELINE configs[1], [2] (on one GPU) and [3] at their full sizes: twitch-RU shape (N=4385, F=3170,
-    H=256), n_test probes.  The oracle checks a sample of probe rows; the whole matrix is checked through
+@pytest.mark.parametrize("workload,n_test,served", [("twitch-ES", 64, "clean"), ("twitch-RU", 500, "clean"),
+                                                    ("twitch-RU", 2000, "clean"), ("twitch-RU", 500, "lapgraph")])
+def test_full_size_twitch(gpu, workload, n_test, served):
+    """BASELINE configs[0] (twitch-ES shape N=4648, n_test=64), [1], [2] (on one GPU) and [3] at their full sizes:
+    twitch-RU shape (N=4385, F=3170, H=256), n_test probes.  The oracle checks a sample of probe rows; the whole matrix is checked through
     size-independent properties: 'sparse' == 'full' bit for bit, exact zeros outside the 2-hop set, non-zero
     inside it (up to ReLU-dead paths), 'delta' close to 'full', symmetry of the support."""
     from linkteller_amd import dp, engine, graph, synth
-    adj, x, w = synth.twitch_like_problem("twitch-RU", hidden=256, n_classes=2, seed=0)
+    adj, x, w = synth.twitch_like_problem(workload, hidden=256, n_classes=2, seed=0)
     if served == "lapgraph":
         adj = dp.perturb_adj(adj, "continuous", 5.0, noise_seed=42)       # worker.py:206-335 (config 4)
     a_hat = graph.first_order_gcn(adj)
@@ -401,50 +426,47 @@ def test_full_size_twitch_ru(gpu, n_test, served):
     scale = float(res["delta"].max())
     # the fp32 finite difference (full) sits within its own noise class of the exact perturbation (delta)
     gap = np.abs(res["full"].astype(np.float64) - res["delta"]).max()
-    print(f"n_test={n_test} served={served}: max score {scale:.4g}, |full - delta| max {gap:.4g}, nnz(A_hat) {a_hat.nnz}")
+    print(f"{workload} n_test={n_test} served={served}: max score {scale:.4g}, |full - delta| max {gap:.4g}, nnz(A_hat) {a_hat.nnz}")
     assert gap <= 0.05 * scale
     sample = np.random.RandomState(11).choice(n_test, 6, replace=False)
     ref64 = _oracle_matrix(a_hat, x, w, nodes[sample], nodes, 1e-4, torch.float64)
     ref32 = _oracle_matrix(a_hat, x, w, nodes[sample], nodes, 1e-4, torch.float32)
     e32 = np.abs(ref32 - ref64).max()
     assert np.abs(res["delta"][sample] - ref64).max() <= 1e-5 * ref64.max()
-    assert np.abs(res["full"][sample] - ref64).max() <= 3.0 * e32 + 1e-4 * ref64.max()
+    assert np.abs(res["full"][sample] - ref64).max() <= 2.0 * e32
     assert np.all(res["full"][sample][ref64 == 0] == 0)
 
 
 @pytest.mark.parametrize("p,long_par", [(8, 1), (16, 1), (32, 1), (8, 0), (16, 0), (32, 0)])
-def test_every_probes_per_wave_variant(gpu, p, long_par, tmp_path):
+def test_every_probes_per_wave_variant(gpu, p, long_par):
     """The wide stage-A kernel exists for 8, 16 and 32 probes per wave (picked from the probe count), and hub
-    rows take one of two routes (segments in separate waves, LT_LONG_PAR=1, or one wave per row walking its
-    segments, LT_LONG_PAR=0: picked from the size of the graph); each combination, pinned in a fresh process,
+    rows take one of two routes (segments in separate waves, long_par = 1, or one wave per row walking its
+    segments, long_par = 0: picked from the size of the graph); each combination, pinned through lt_set_tuning,
     must give the bits of `sparse` on a graph with hub rows, for probe counts that leave partial groups."""
-    import os, subprocess, sys, textwrap
-    code = textwrap.dedent('''
-        import numpy as np, torch
-        from linkteller_amd import engine, graph, synth
-        adj = synth.powerlaw_graph(700, 4000, seed=5)
-        a_hat = graph.first_order_gcn(adj)
-        n = adj.shape[0]
-        assert np.diff(a_hat.indptr).max() > 300          # rows of several 128-entry segments
-        x = synth.gaussian_features(n, 96, seed=2)
-        w = synth.gcn_weights(96, 256, 2, seed=3)
-        dev = torch.device("cuda", 0)
-        base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(dev),
-                               *[torch.from_numpy(w[k]).to(dev) for k in ("W1", "b1", "W2", "b2")])
+    from linkteller_amd import _lib, engine, graph, synth
+    adj = synth.powerlaw_graph(700, 4000, seed=5)
+    a_hat = graph.first_order_gcn(adj)
+    n = adj.shape[0]
+    assert np.diff(a_hat.indptr).max() > 300          # rows of several 128-entry segments
+    x = synth.gaussian_features(n, 96, seed=2)
+    w = synth.gcn_weights(96, 256, 2, seed=3)
+    _lib.set_tuning("full_p", p)
+    _lib.set_tuning("long_par", long_par)
+    _lib.set_tuning("item_bits", long_par)             # 0: no membership bitmap either
+    try:
+        base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu),
+                               *[torch.from_numpy(w[k]).to(gpu) for k in ("W1", "b1", "W2", "b2")])
         rng = np.random.RandomState(1)
         for n_probe in (1, 7, 33, 77):
             probes = rng.choice(n, n_probe, replace=False)
             obs = rng.choice(n, 150, replace=False)
             f = base.influence_rows(probes, obs, 1e-4, "full").cpu().numpy()
-            s = base.influence_rows(probes, obs, 1e-4, "sparse").cpu().numpy()
-            assert np.array_equal(f, s), n_probe
+            s_ = base.influence_rows(probes, obs, 1e-4, "sparse").cpu().numpy()
+            assert np.array_equal(f, s_), n_probe
             assert np.isfinite(f).all() and f.max() > 0
-        print("ok")
-    ''')
-    env = dict(os.environ, LT_FULL_P=str(p), LT_LONG_PAR=str(long_par), LT_ITEM_BITS=str(long_par),   # 0: no bitmap either
-               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+    finally:
+        for k in ("full_p", "long_par", "item_bits"):
+            _lib.set_tuning(k, None)
 
 
 def test_row_that_contains_every_probe(gpu):
@@ -471,7 +493,7 @@ def test_row_that_contains_every_probe(gpu):
         ref64 = _oracle_matrix(a_hat, x, w, probes, observe, 1e-4, torch.float64)
         ref32 = _oracle_matrix(a_hat, x, w, probes, observe, 1e-4, torch.float32)
         assert np.abs(res["delta"] - ref64).max() <= 1e-5 * ref64.max()
-        assert np.abs(res["full"] - ref64).max() <= 3.0 * np.abs(ref32 - ref64).max() + 1e-4 * ref64.max()
+        assert np.abs(res["full"] - ref64).max() <= 2.0 * np.abs(ref32 - ref64).max() + 1e-4 * ref64.max()
     logits = base.logits().cpu().numpy()
     from oracle import linkteller_oracle as O
     ref_logits = O.gcn_forward(torch.from_numpy(x).double(), O.to_torch_sparse(a_hat).double(),

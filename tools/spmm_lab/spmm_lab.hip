@@ -245,7 +245,7 @@ static T *upload(const std::vector<T> &v, size_t pad = 0) {
     return d;
 }
 
-static Work build_work(const HostCsr &g, int H, int SEG) {
+static Work build_work(const HostCsr &g, int H, int SEG, int ordering) {
     Work w;
     struct Item { int32_t e0, cnt, dst; };
     std::vector<Item> items;
@@ -261,8 +261,21 @@ static Work build_work(const HostCsr &g, int H, int SEG) {
         }
         lptr.push_back(nseg);
     }
-    // length classes (ceil(cnt / 16) blocks), longest first, natural order inside a class
-    std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return (a.cnt + 15) / 16 > (b.cnt + 15) / 16; });
+    if (ordering == 0) {
+        // length classes (ceil(cnt / 16) blocks), longest first, natural order inside a class
+        std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return (a.cnt + 15) / 16 > (b.cnt + 15) / 16; });
+    } else {
+        // segments of long rows first, by the column their first entry reads (concurrent waves then gather from one
+        // sliding window of S); then the short rows by length class
+        const int n = g.n;
+        const int32_t *colp = g.col.data();
+        std::stable_sort(items.begin(), items.end(), [n, colp](const Item &a, const Item &b) {
+            const bool sa = a.dst >= n, sb = b.dst >= n;
+            if (sa != sb) return sa;
+            if (sa) return colp[a.e0] < colp[b.e0];
+            return (a.cnt + 15) / 16 > (b.cnt + 15) / 16;
+        });
+    }
     std::vector<int32_t> e0(items.size()), cnt(items.size()), dst(items.size());
     for (size_t i = 0; i < items.size(); ++i) { e0[i] = items[i].e0; cnt[i] = items[i].cnt; dst[i] = items[i].dst; }
     w.n_items = (int)items.size();
@@ -278,24 +291,26 @@ struct Ctx {
     int32_t *rowptr, *col; float *val, *S, *out, *ref;
     int32_t *colh[4];   // col with bit 31 set on cold columns, for hot sets of 8K / 12K / 16K / 24K columns
     Work work;
+    Work work_col;   // segments ordered by first column
     lt_graph *lg;
 };
 
-template <int GL, int U, bool NT, bool SORTED, int HINT = 0, bool SEQ = false, int HOTSET = 0>
+template <int GL, int U, bool NT, bool SORTED, int HINT = 0, bool SEQ = false, int HOTSET = 0, int ORDER = 0>
 static void run_sliced(Ctx &c, hipStream_t st) {
+    Work &W = ORDER ? c.work_col : c.work;
     const int ns = c.H / (4 * GL) > 0 ? (c.H + 4 * GL - 1) / (4 * GL) : 1;
     const int xps = 8 / ns;
     constexpr int IPB = 4 * (64 / GL);
-    const int n_items = SORTED ? c.work.n_items : c.g->n;
+    const int n_items = SORTED ? W.n_items : c.g->n;
     const int chunks = (n_items + IPB - 1) / IPB;
     const int grid = SEQ ? chunks * ns : 8 * ((chunks + xps - 1) / xps);
     const int32_t *colp = HINT ? c.colh[HOTSET] : c.col;
-    hipLaunchKernelGGL((k_spmm_sliced<GL, U, NT, SORTED, HINT, SEQ>), dim3(grid), dim3(256), 0, st, n_items, c.work.e0, c.work.cnt,
-                       c.work.dst, c.rowptr, c.g->n, colp, c.val, c.S, c.H, c.H, c.out, c.H, c.work.partial, c.H, ns);
-    if (SORTED && c.work.n_long > 0) {
-        const int tot = c.work.n_long * c.H;
-        hipLaunchKernelGGL(k_combine, dim3((tot + 255) / 256), dim3(256), 0, st, c.work.n_long, c.work.long_row,
-                           c.work.long_segptr, c.work.partial, c.H, c.H, c.out, c.H);
+    hipLaunchKernelGGL((k_spmm_sliced<GL, U, NT, SORTED, HINT, SEQ>), dim3(grid), dim3(256), 0, st, n_items, W.e0, W.cnt,
+                       W.dst, c.rowptr, c.g->n, colp, c.val, c.S, c.H, c.H, c.out, c.H, W.partial, c.H, ns);
+    if (SORTED && W.n_long > 0) {
+        const int tot = W.n_long * c.H;
+        hipLaunchKernelGGL(k_combine, dim3((tot + 255) / 256), dim3(256), 0, st, W.n_long, W.long_row,
+                           W.long_segptr, W.partial, c.H, c.H, c.out, c.H);
     }
 }
 
@@ -333,7 +348,8 @@ int main(int argc, char **argv) {
     }
     CK(hipMalloc((void **)&c.out, (size_t)g.n * H * sizeof(float)));
     CK(hipMalloc((void **)&c.ref, (size_t)g.n * H * sizeof(float)));
-    c.work = build_work(g, H, 128);   // the library's canonical order: 128-entry segments added in order (lt_rows.cuh row_dot)
+    c.work = build_work(g, H, 128, 0);
+    c.work_col = build_work(g, H, 128, 1);   // the library's canonical order: 128-entry segments added in order (lt_rows.cuh row_dot)
     {
         // hot sets by in-degree (= row length: the matrix is symmetric)
         std::vector<int> deg((size_t)g.n);
@@ -364,22 +380,15 @@ int main(int argc, char **argv) {
 
     std::vector<Variant> vs = {
         {"lib", run_lib},
-        {"g64_u8_srt_nt", run_sliced<64, 8, true, true>},
-        {"g16_u8_srt_nt", run_sliced<16, 8, true, true>},
-        {"g8_u8_srt_nt", run_sliced<8, 8, true, true>},
-        {"g16_seq", run_sliced<16, 8, true, true, 0, true>},
-        {"g8_seq", run_sliced<8, 8, true, true, 0, true>},
-        {"g16_asm0", run_sliced<16, 8, true, true, 0 + 5, false, 1>},   // HINT 5 = plain policy for cold too (asm path cost)
-        {"g16_nt_h8k", run_sliced<16, 8, true, true, 1, false, 0>},
-        {"g16_nt_h12k", run_sliced<16, 8, true, true, 1, false, 1>},
-        {"g16_nt_h16k", run_sliced<16, 8, true, true, 1, false, 2>},
-        {"g16_sc1_h12k", run_sliced<16, 8, true, true, 2, false, 1>},
-        {"g16_sc01_h12k", run_sliced<16, 8, true, true, 3, false, 1>},
-        {"g16_sc1nt_h12k", run_sliced<16, 8, true, true, 4, false, 1>},
-        {"g8_nt_h16k", run_sliced<8, 8, true, true, 1, false, 2>},
-        {"g8_nt_h24k", run_sliced<8, 8, true, true, 1, false, 3>},
-        {"g8_sc1nt_h24k", run_sliced<8, 8, true, true, 4, false, 3>},
-        {"g16_seq_nt_h12k", run_sliced<16, 8, true, true, 1, true, 1>},
+        {"g16", run_sliced<16, 8, true, true>},
+        {"g64", run_sliced<64, 8, true, true>},
+        {"g16_col", run_sliced<16, 8, true, true, 0, false, 0, 1>},
+        {"g16_col_u4", run_sliced<16, 4, true, true, 0, false, 0, 1>},
+        {"g8_col", run_sliced<8, 8, true, true, 0, false, 0, 1>},
+        {"g32_col", run_sliced<32, 8, true, true, 0, false, 0, 1>},
+        {"g64_col", run_sliced<64, 8, true, true, 0, false, 0, 1>},
+        {"g16_col_seq", run_sliced<16, 8, true, true, 0, true, 0, 1>},
+        {"g16_col_nt12k", run_sliced<16, 8, true, true, 1, false, 1, 1>},
     };
     hipStream_t st;
     CK(hipStreamCreate(&st));
