@@ -7,7 +7,8 @@ Same constructor, method names, prints and result file as the reference, so
 rank's rows on the device and a single copy brings the matrix back.
 
 Extra, optional ``args`` fields (absent in the reference's namespace -> defaults):
-    influence_mode   'sparse' (default; bit-identical to 'full') | 'full' | 'delta'   (see include/linkteller_hip.h)
+    influence_mode   'delta' (default: the perturbation propagated exactly; AUC / AP equal the reference evaluated
+                     in fp64) | 'sparse' (the reference's fp32 finite difference, bit-identical to 'full') | 'full'
 """
 from __future__ import annotations
 
@@ -111,7 +112,7 @@ class Attacker:
     def _rows(self, probe_nodes, observe_nodes, mode=None):
         """[len(probe_nodes), len(observe_nodes)] influence rows on the device."""
         if self._is_two_layer():
-            mode = mode or getattr(self.args, "influence_mode", None) or os.environ.get("LT_INFLUENCE_MODE", "sparse")
+            mode = mode or getattr(self.args, "influence_mode", None) or os.environ.get("LT_INFLUENCE_MODE", "delta")
             return self.baseline().influence_rows(probe_nodes, observe_nodes, float(self.args.influence), mode)
         return self._rows_generic(probe_nodes, observe_nodes)
 

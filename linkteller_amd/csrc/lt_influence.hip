@@ -895,6 +895,15 @@ static bool long_rows_parallel(const lt_graph *g, int Hp) {
     return (size_t)g->p_n_seg * Hp * sizeof(float) * 9 / 8 <= LT_LONG_PAR_BYTES;
 }
 
+// K-slice of the perturbed-row GEMM.  "probe_kslice" = 0 (default): the slicing of the baseline X*W1, so that a probe
+// row S1'[v] = (x_v + x_v d) W1 and its baseline S1[v] are summed in the SAME order and their rounding errors largely
+// cancel in the finite difference -- as they do in the reference, whose two torch.mm calls share one summation order;
+// > 0: that many columns per slice (256 was the round-1 setting: more workgroups for few probes, uncorrelated rounding).
+static int probe_kslice(const lt_baseline *b) {
+    const int k = lt_tune().probe_kslice;
+    return k > 0 ? (k + 15) / 16 * 16 : lt_gemm_pick_kslice(b->n, b->H, b->F);
+}
+
 struct infl_ws {
     float *Sp, *S2p;       // FULL / SPARSE: S1 rows of the perturbed probes; FULL: per-probe S2
     float *lpart;          // FULL: segment sums of the long rows [segment][group][P + 1][Hp]
@@ -911,7 +920,7 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
     const size_t n = (size_t)b->n, C = (size_t)b->C, Hp = (size_t)b->Hp, F = (size_t)b->F;
     const size_t maxc = (size_t)(b->g->max_col_nnz > 0 ? b->g->max_col_nnz : 1);
     size_t per_probe = 0;
-    const size_t splitk = ((F + LT_KSLICE_PROBE - 1) / LT_KSLICE_PROBE) * (size_t)b->H;
+    const size_t splitk = ((F + probe_kslice(b) - 1) / probe_kslice(b)) * (size_t)b->H;
     const size_t nseg = long_rows_parallel(b->g, b->Hp) ? (size_t)b->g->p_n_seg : 0;
     if (mode == LT_MODE_FULL) per_probe = (n * C + Hp + splitk) * sizeof(float) + nseg * Hp * sizeof(float) * 9 / 8;
     else if (mode == LT_MODE_SPARSE) per_probe = (maxc * C + Hp + splitk) * sizeof(float) + sizeof(int32_t);
@@ -930,7 +939,7 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
     };
     if (mode == LT_MODE_FULL || mode == LT_MODE_SPARSE) {
         w.Sp = (float *)take(chunk * Hp * sizeof(float));
-        w.slabs = (float *)take(lt_gemm_splitk_slab_bytes((int)chunk, b->H, b->F, LT_KSLICE_PROBE));
+        w.slabs = (float *)take(lt_gemm_splitk_slab_bytes((int)chunk, b->H, b->F, probe_kslice(b)));
     }
     if (mode == LT_MODE_FULL) {
         w.S2p = (float *)take((chunk + 1) * n * C * sizeof(float));   // + the baseline column
@@ -997,7 +1006,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
             // perturbed rows and their S1 rows: Sp = (X[v] + X[v]*d) W1            attacker.py:101-105
             if (Hp != b->H) LT_HIP(hipMemsetAsync(w.Sp, 0, (size_t)nb * Hp * sizeof(float), st));
             // (the GEMM gathers row probes[i] of X and perturbs it while loading: no Xp buffer, no extra kernel)
-            int rc = lt_launch_gemm_splitk(b->X, b->ldx, b->W1, b->H, w.Sp, Hp, nb, b->H, b->F, LT_KSLICE_PROBE, w.slabs, st,
+            int rc = lt_launch_gemm_splitk(b->X, b->ldx, b->W1, b->H, w.Sp, Hp, nb, b->H, b->F, probe_kslice(b), w.slabs, st,
                                            probes, delta);
             if (rc) return rc;
         }

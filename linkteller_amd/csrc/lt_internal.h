@@ -93,6 +93,7 @@ struct lt_tuning {
     int overlap;                 // hub-row kernels on the baseline's side stream (LT_OVERLAP)
     int item_bits;               // SPARSE / DELTA stage B membership bitmap (LT_ITEM_BITS)
     int wide_min_hp;             // smallest padded hidden width served by the batched stage-A kernel (LT_WIDE_MIN_HP)
+    int probe_kslice;            // K-slice of the perturbed-row GEMM, 0 = the baseline product's slicing (LT_PROBE_KSLICE)
 };
 lt_tuning &lt_tune();
 
@@ -152,7 +153,6 @@ int lt_launch_layer2(const lt_graph *g, const float *S2, int C, const float *b2,
                      hipStream_t st);
 int lt_launch_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
                    int64_t ldc, int M, int N, int K, hipStream_t st);
-#define LT_KSLICE_PROBE 256   // perturbed-row GEMM (M = probes of a chunk)
 #define LT_KSLICE_BASE 400    // fp64 X*W1 of the delta mode (64x64 tiles)
 size_t lt_gemm_splitk_slab_bytes(int M, int N, int K, int kslice);
 int lt_gemm_pick_kslice(int M, int N, int K);   // baseline X*W1: slice length that fills the CUs in whole rounds

@@ -34,9 +34,10 @@ _OPTIONS = {
     "cluster-seed": (int, 42), "knn": (int, -1), "noise-type": (str, "laplace"),
     "perturb-type": (str, "discrete", ["discrete", "continuous"]),
     "attack-mode": (str, "efficient", _ATTACK_MODES), "coeff": (float, 1), "degree": (int, 2),
-    # additions (never renames): how lt_influence_rows evaluates a probe ('sparse' is bit-identical to 'full', the
-    # per-probe full forward the reference runs, and skips the rows a probe cannot change); where ./data lives
-    "influence-mode": (str, "sparse", ["full", "sparse", "delta"]), "data-root": (str, "./data"),
+    # additions (never renames): how lt_influence_rows evaluates a probe.  'delta' propagates the perturbation exactly
+    # (scores / AUC / AP equal the reference evaluated in fp64); 'sparse' is the reference's fp32 finite difference
+    # restricted to the rows a probe can change, bit-identical to 'full' (every probe a full forward); where ./data lives
+    "influence-mode": (str, "delta", ["full", "sparse", "delta"]), "data-root": (str, "./data"),
 }
 _SWITCHES = ["no-cuda", "fastmode", "approx", "attack", "test", "break-down", "display", "same-size",
              "eval-degree", "trainable", "early", "fnormalize"]

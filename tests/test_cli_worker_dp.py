@@ -32,7 +32,7 @@ def test_cli_accepts_reference_flags_with_reference_defaults():
     a = lt_main.get_arguments("--mode vanilla --dataset twitch/ES/RU --hidden 256 --norm FirstOrderGCN --test "
                               "--model-path m.pt --attack --attack-mode efficient --sample-type unbalanced "
                               "--n-test 500 --eps 5 --perturb-type continuous".split())
-    assert a.epsilon == 5 and a.n_test == 500 and a.attack and a.test and a.influence_mode == "sparse"
+    assert a.epsilon == 5 and a.n_test == 500 and a.attack and a.test and a.influence_mode == "delta"
     with pytest.raises(NotImplementedError):
         lt_main.main(["--dataset", "twitch/ES/RU"])           # training is refused, not faked
 
