@@ -30,7 +30,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_layer1(
     const int coff = 4 * gl;
     const bool active = coff < Hp;
     const f32x4 b1v = active ? ld4(b1p + coff) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 z = row_dot(col, val, rowptr[r], rowptr[r + 1], S1, Hp, coff, active, -1, nullptr, b1v);
+    const f32x4 z = row_dot<8>(col, val, rowptr[r], rowptr[r + 1], S1, Hp, coff, active, -1, nullptr, b1v);
     float part[CP];
 #pragma unroll
     for (int c = 0; c < CP; ++c) part[c] = 0.f;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_layer1_seg(
     const int coff = 4 * gl;
     const bool active = coff < Hp;
     const f32x4 init = (active && e0 == rowptr[r]) ? ld4(b1p + coff) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 z = seg_chain(col, val, e0, e1, S1, Hp, coff, active, -1, nullptr, init);
+    const f32x4 z = seg_chain<16>(col, val, e0, e1, S1, Hp, coff, active, -1, nullptr, init);
     if (active) *reinterpret_cast<f32x4 *>(part + (size_t)sg * Hp + coff) = z;
 }
 // ... and one group per long ROW adds them in segment order and finishes like k_layer1.
@@ -149,10 +149,11 @@ template <int CP>
 __global__ __launch_bounds__(LT_BLOCK) void k_layer2(
     int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ S2, int C,
-    const float *__restrict__ b2, float *__restrict__ OUT) {
+    const float *__restrict__ b2, float *__restrict__ OUT, int skip_long) {
     const int gid = (blockIdx.x * LT_BLOCK + threadIdx.x) / LT_L2_LANES;
     const int q = threadIdx.x & (LT_L2_LANES - 1);
     if (gid >= n) return;
+    if (skip_long && rowptr[gid + 1] - rowptr[gid] > LT_ROW_SEG) return;   // hub rows: k_layer2_long
     float acc[CP];
     row2_dot<CP>(col, val, rowptr[gid], rowptr[gid + 1], q, C,
                  [&](int c, int) { return S2 + (size_t)c * C; }, acc);
@@ -160,6 +161,69 @@ __global__ __launch_bounds__(LT_BLOCK) void k_layer2(
 #pragma unroll
         for (int c = 0; c < CP; ++c)
             if (c < C) OUT[(size_t)gid * C + c] = acc[c] + b2[c];
+    }
+}
+
+// Layer 2 of a hub row: a row of 10^3 entries is 10^2 dependent load round trips for the 8 lanes of k_layer2 and the
+// whole launch waits for it.  Here a block takes one long row: all 256 threads fetch entries (val, S2 row) into LDS,
+// LT_L2_CHUNK at a time, and the 8 chain lanes then run row2_dot's chains out of LDS -- entry e still goes to chain
+// (e - e0) & 7, chains still k-ordered, same butterfly: the bits of k_layer2.
+#define LT_L2_CHUNK 1024
+template <int CP>
+__global__ __launch_bounds__(LT_BLOCK) void k_layer2_long(
+    const int32_t *__restrict__ long_row, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const float *__restrict__ S2, int C, const float *__restrict__ b2,
+    float *__restrict__ OUT) {
+    __shared__ float sv[LT_L2_CHUNK];
+    __shared__ float sT[LT_L2_CHUNK][CP];
+    const int r = long_row[blockIdx.x];
+    const int e0 = rowptr[r], e1 = rowptr[r + 1];
+    const int tid = threadIdx.x;
+    float acc[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) acc[c] = 0.f;
+    for (int cb = e0; cb < e1; cb += LT_L2_CHUNK) {
+        const int nc = min(LT_L2_CHUNK, e1 - cb);
+        __syncthreads();
+        for (int i = tid; i < nc; i += LT_BLOCK) {
+            const int cc = col[cb + i];
+            sv[i] = val[cb + i];
+#pragma unroll
+            for (int c = 0; c < CP; ++c) sT[i][c] = c < C ? S2[(size_t)cc * C + c] : 0.f;
+        }
+        __syncthreads();
+        if (tid < LT_L2_LANES) {
+            int i = tid;
+            for (; i + 7 * LT_L2_LANES < nc; i += 8 * LT_L2_LANES) {   // 8 LDS reads in flight, FMAs in entry order
+                float a[8], t[8][CP];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    a[k] = sv[i + k * LT_L2_LANES];
+#pragma unroll
+                    for (int c = 0; c < CP; ++c) t[k][c] = sT[i + k * LT_L2_LANES][c];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+#pragma unroll
+                    for (int c = 0; c < CP; ++c)
+                        if (c < C) acc[c] = fmaf(a[k], t[k][c], acc[c]);
+            }
+            for (; i < nc; i += LT_L2_LANES) {
+                const float a = sv[i];
+#pragma unroll
+                for (int c = 0; c < CP; ++c)
+                    if (c < C) acc[c] = fmaf(a, sT[i][c], acc[c]);
+            }
+        }
+    }
+    if (tid < 64) {   // the wave that holds the chain lanes
+#pragma unroll
+        for (int c = 0; c < CP; ++c) acc[c] = group_sum<LT_L2_LANES>(acc[c]);
+        if (tid == 0) {
+#pragma unroll
+            for (int c = 0; c < CP; ++c)
+                if (c < C) OUT[(size_t)r * C + c] = acc[c] + b2[c];
+        }
     }
 }
 
@@ -229,9 +293,16 @@ int lt_launch_layer2(const lt_graph *g, const float *S2, int C, const float *b2,
     if (g->n == 0) return LT_OK;
     const unsigned grid = blocks_for_rows(g->n, LT_BLOCK / LT_L2_LANES);
     lt_prof_scope prof_(LT_K_LAYER2, st);
+    const int have_long = g->p_n_long > 0 ? 1 : 0;
+    if (have_long) {
+        LT_DISPATCH_CP(lt_cp_for(C),
+            hipLaunchKernelGGL((k_layer2_long<CP_>), dim3(g->p_n_long), dim3(LT_BLOCK), 0, st, g->p_long_row, g->rowptr,
+                               g->col, g->val, S2, C, b2, OUT));
+        LT_CHECK_LAUNCH();
+    }
     LT_DISPATCH_CP(lt_cp_for(C),
         hipLaunchKernelGGL((k_layer2<CP_>), dim3(grid), dim3(LT_BLOCK), 0, st, g->n, g->rowptr,
-                           g->col, g->val, S2, C, b2, OUT));
+                           g->col, g->val, S2, C, b2, OUT, have_long));
     LT_CHECK_LAUNCH();
     return LT_OK;
 }
@@ -342,6 +413,21 @@ static void free_baseline(lt_baseline *b) {
     delete b;
 }
 
+// b1 / W2 zero-padded to Hp rows: the caller's tensors themselves when nothing needs padding, else copies
+static int refresh_padding(lt_baseline *b, hipStream_t st) {
+    if (b->Hp == b->H && ((uintptr_t)b->b1 % 16) == 0) {
+        b->b1p = b->b1;
+        b->W2p = b->W2;
+        return LT_OK;
+    }
+    hipLaunchKernelGGL(k_pad_b1_w2, dim3((b->Hp * (b->C + 1) + 255) / 256), dim3(256), 0, st, b->b1, b->W2, b->H,
+                       b->Hp, b->C, b->b1p_buf, b->W2p_buf);
+    LT_CHECK_LAUNCH();
+    b->b1p = b->b1p_buf;
+    b->W2p = b->W2p_buf;
+    return LT_OK;
+}
+
 extern "C" int lt_baseline_refresh(lt_baseline *b, void *stream) {
     LT_REQUIRE(b != nullptr, "lt_baseline_refresh: baseline is NULL");
     hipStream_t st = (hipStream_t)stream;
@@ -364,17 +450,9 @@ extern "C" int lt_baseline_refresh_rows(lt_baseline *b, int32_t row_begin, int32
     hipStream_t st = (hipStream_t)stream;
     b->layers_fresh = false;
     b->fp64_fresh = false;
-    // b1 / W2 padding follows the weights exactly as in lt_baseline_refresh
-    if (b->Hp == b->H && ((uintptr_t)b->b1 % 16) == 0) {
-        b->b1p = b->b1;
-        b->W2p = b->W2;
-    } else {
-        hipLaunchKernelGGL(k_pad_b1_w2, dim3((b->Hp * (b->C + 1) + 255) / 256), dim3(256), 0, st, b->b1, b->W2, b->H,
-                           b->Hp, b->C, b->b1p_buf, b->W2p_buf);
-        LT_CHECK_LAUNCH();
-        b->b1p = b->b1p_buf;
-        b->W2p = b->W2p_buf;
-    }
+    // b1 / W2 padding follows the weights exactly as in lt_baseline_refresh; the rest of S1 is the caller's all-gather
+    const int rcp = refresh_padding(b, st);
+    if (rcp) return rcp;
     const int m = row_end - row_begin;
     if (m == 0) return LT_OK;
     if (b->Hp != b->H) LT_HIP(hipMemsetAsync(dst, 0, (size_t)m * b->Hp * sizeof(float), st));

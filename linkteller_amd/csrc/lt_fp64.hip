@@ -121,13 +121,19 @@ __global__ void k_sum_slabs_f64(const double *__restrict__ slabs, long slab_stri
 }
 
 // Z1d[r, :] = sum_e val[e] * S1d[col[e], :] + b1     (fp64 fma chain in CSR order, 4 columns per lane)
-template <int LPR>
+// SEG = false: one lane group per row of up to LT_ROW_SEG entries (longer rows are skipped when the graph has a
+// segment table); SEG = true: one lane group per SEGMENT of a long row, raw sum into out[segment] (k_spmm_f64_long
+// adds them in segment order and the bias).  fp64: the cut only decides how a hub row's work is spread.
+template <int LPR, bool SEG>
 __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restrict__ rowptr,
                                                   const int32_t *__restrict__ col,
                                                   const float *__restrict__ val,
                                                   const double *__restrict__ S, int ld,
                                                   const float *__restrict__ b1p,
-                                                  double *__restrict__ out) {
+                                                  double *__restrict__ out, int skip_long,
+                                                  const int32_t *__restrict__ seg_begin,
+                                                  const int32_t *__restrict__ seg_long,
+                                                  const int32_t *__restrict__ long_row) {
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -138,8 +144,15 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
     const int coff = 4 * gl;
     if (coff >= ld) return;
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-    int e = rowptr[r];
-    const int e1 = rowptr[r + 1];
+    int e, e1;
+    if (SEG) {
+        e = seg_begin[r];
+        e1 = min(e + LT_ROW_SEG, rowptr[long_row[seg_long[r]] + 1]);
+    } else {
+        e = rowptr[r];
+        e1 = rowptr[r + 1];
+        if (skip_long && e1 - e > LT_ROW_SEG) return;
+    }
     for (; e + 4 <= e1; e += 4) {   // four gathers in flight; the fma chain stays in entry order
         double a[4];
         f64x4 s[4];
@@ -159,10 +172,22 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[k] = fma(a, s[k], acc[k]);
     }
-    const f32x4 b = ld4(b1p + coff);
+    if (!SEG) {
+        const f32x4 b = ld4(b1p + coff);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] += (double)b[k];
+        for (int k = 0; k < 4; ++k) acc[k] += (double)b[k];
+    }
     *reinterpret_cast<f64x4 *>(out + (size_t)r * ld + coff) = acc;
+}
+__global__ void k_spmm_f64_long(int n_long, const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_segptr,
+                                const double *__restrict__ part, int ld, const float *__restrict__ b1p,
+                                double *__restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n_long * ld) return;
+    const int li = (int)(i / ld), c = (int)(i % ld);
+    double acc = part[(size_t)long_segptr[li] * ld + c];
+    for (int sg = long_segptr[li] + 1; sg < long_segptr[li + 1]; ++sg) acc += part[(size_t)sg * ld + c];
+    out[(size_t)long_row[li] * ld + c] = acc + (double)b1p[c];
 }
 
 static int compute_z1d(lt_baseline *b, hipStream_t st) {
@@ -186,8 +211,22 @@ static int compute_z1d(lt_baseline *b, hipStream_t st) {
     LT_CHECK_LAUNCH();
     const int lpr = lt_lpr_for(Hp);
     const unsigned g2 = (unsigned)((n + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr)));
-    LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_>), dim3(g2), dim3(256), 0, st, n, b->g->rowptr,
-                                            b->g->col, b->g->val, b->S1d, Hp, b->b1p, b->Z1d));
+    const lt_graph *g = b->g;
+    const int have_long = (g->p_n_long > 0 && b->seg_d) ? 1 : 0;
+    if (have_long) {
+        const unsigned gs = (unsigned)((g->p_n_seg + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr)));
+        LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, true>), dim3(gs), dim3(256), 0, st, g->p_n_seg, g->rowptr,
+                                                g->col, g->val, b->S1d, Hp, b->b1p, b->seg_d, 0, g->p_seg_begin,
+                                                g->p_seg_long, g->p_long_row));
+        LT_CHECK_LAUNCH();
+        const long tot = (long)g->p_n_long * Hp;
+        hipLaunchKernelGGL(k_spmm_f64_long, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, g->p_n_long,
+                           g->p_long_row, g->p_long_segptr, b->seg_d, Hp, b->b1p, b->Z1d);
+        LT_CHECK_LAUNCH();
+    }
+    LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, false>), dim3(g2), dim3(256), 0, st, n, g->rowptr,
+                                            g->col, g->val, b->S1d, Hp, b->b1p, b->Z1d, have_long,
+                                            (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr));
     LT_CHECK_LAUNCH();
     return LT_OK;
 }
@@ -201,16 +240,17 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     if (b->Z1d) return LT_OK;   // Z1d is set only once all three buffers exist (see below)
     const size_t nh = (size_t)(b->n > 0 ? b->n : 1) * b->Hp * sizeof(double);
     const int splits = (b->F + LT_KSLICE_BASE - 1) / LT_KSLICE_BASE;
-    double *s1d = nullptr, *z1d = nullptr, *slabs = nullptr;
+    double *s1d = nullptr, *z1d = nullptr, *slabs = nullptr, *segd = nullptr;
     hipError_t e = hipMalloc((void **)&s1d, nh);
     if (e == hipSuccess) e = hipMalloc((void **)&z1d, nh);
+    if (e == hipSuccess && b->g->p_n_seg > 0) e = hipMalloc((void **)&segd, (size_t)b->g->p_n_seg * b->Hp * sizeof(double));
     if (e == hipSuccess && splits > 1)
         e = hipMalloc((void **)&slabs, (size_t)splits * (b->n > 0 ? b->n : 1) * b->H * sizeof(double));
     if (e != hipSuccess) {   // all or nothing: a retry starts from a clean state, nothing leaks
-        (void)hipFree(s1d); (void)hipFree(z1d); (void)hipFree(slabs);
+        (void)hipFree(s1d); (void)hipFree(z1d); (void)hipFree(slabs); (void)hipFree(segd);
         return lt_set_error(LT_ERR_HIP, "lt_baseline_enable_fp64: hipMalloc failed: %s", hipGetErrorString(e));
     }
-    b->S1d = s1d; b->Z1d = z1d; b->slabs_d = slabs;
+    b->S1d = s1d; b->Z1d = z1d; b->slabs_d = slabs; b->seg_d = segd;
     const int rc = compute_z1d(b, (hipStream_t)stream);
     b->fp64_fresh = rc == LT_OK;
     return rc;
@@ -220,6 +260,7 @@ void lt_baseline_free_fp64(lt_baseline *b) {
     (void)hipFree(b->S1d);
     (void)hipFree(b->Z1d);
     (void)hipFree(b->slabs_d);
-    b->S1d = b->Z1d = b->slabs_d = nullptr;
+    (void)hipFree(b->seg_d);
+    b->S1d = b->Z1d = b->slabs_d = b->seg_d = nullptr;
     b->fp64_fresh = false;
 }

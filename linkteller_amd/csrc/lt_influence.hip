@@ -27,7 +27,7 @@
 #define LT_BLOCK 256
 #define LT_CHUNK_BUDGET ((size_t)1 << 30)  // bytes of per-probe scratch per chunk
 #define LT_ITEM_GRID 2048                  // blocks of the grid-stride item kernels
-#define LT_BITS_MAX_BYTES ((size_t)64 << 20)  // stage B of the item modes tests membership in R_v through a bitmap up to this size
+#define LT_BITS_MAX_BYTES ((size_t)128 << 20)  // stage B of the item modes tests membership in R_v through a bitmap up to this size
 #define LT_SB_AHEAD 24                     // FULL stage B: entries in flight per wave (a multiple of LT_L2_LANES)
 
 // ------------------------------------------------------------------------------------------------
@@ -488,7 +488,15 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_long_combine(
         return *reinterpret_cast<const f32x4 *>(lpart + ((size_t)(s * groups + g) * (P + 1) + sl) * Hp + coff);
     };
     f32x4 z = slot(s0);
-    for (int s = s0 + 1; s < s1; ++s) {
+    int s = s0 + 1;
+    for (; s + 8 <= s1; s += 8) {   // 8 segment sums in flight, added in segment order
+        f32x4 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = slot(s + k);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { z.x += t[k].x; z.y += t[k].y; z.z += t[k].z; z.w += t[k].w; }
+    }
+    for (; s < s1; ++s) {
         const f32x4 t = slot(s);
         z.x += t.x; z.y += t.y; z.z += t.z; z.w += t.w;
     }
@@ -782,19 +790,30 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
     }
 }
 
-// bits[b][r >> 5] bit (r & 31) = 1  <=>  r in R_v of probe b: one load tells stage B whether an entry of an
-// observed row can be affected by the probe (a binary search in R_v otherwise); one block per probe
+// bits[b][r >> 5] = { mask, base }: bit (r & 31) of mask = 1  <=>  r in R_v of probe b, and base = the position in
+// R_v (the ascending CSC list of column v) of the lowest member of this word, so that ONE 8-byte load tells stage B
+// both whether an entry of an observed row is affected by the probe and which item replaces it:
+//     position(r) = base + popcount(mask & ((1 << (r & 31)) - 1))
+// (without the bitmap -- huge graphs -- both questions are a binary search in R_v).  One block per probe.
 __global__ __launch_bounds__(256) void k_item_bits(const int32_t *__restrict__ tptr, const int32_t *__restrict__ trow,
                                                    const int32_t *__restrict__ probes, int words,
-                                                   uint32_t *__restrict__ bits) {
-    uint32_t *mine = bits + (size_t)blockIdx.x * words;
-    for (int i = threadIdx.x; i < words; i += blockDim.x) mine[i] = 0u;
+                                                   uint2 *__restrict__ bits) {
+    uint2 *mine = bits + (size_t)blockIdx.x * words;
+    for (int i = threadIdx.x; i < words; i += blockDim.x) mine[i] = make_uint2(0u, 0xffffffffu);
     __syncthreads();
     const int v = probes[blockIdx.x];
-    for (int t = tptr[v] + threadIdx.x; t < tptr[v + 1]; t += blockDim.x) {
+    const int t0 = tptr[v];
+    for (int t = t0 + threadIdx.x; t < tptr[v + 1]; t += blockDim.x) {
         const int r = trow[t];
-        atomicOr(&mine[r >> 5], 1u << (r & 31));
+        atomicOr(&mine[r >> 5].x, 1u << (r & 31));
+        atomicMin(&mine[r >> 5].y, (unsigned)(t - t0));
     }
+}
+// position of column c in R_v from the probe's bitmap row, or -1
+__device__ __forceinline__ int bits_pos(const uint2 *__restrict__ mb, int c) {
+    const uint2 w = mb[c >> 5];
+    const unsigned bit = 1u << (c & 31);
+    return (w.x & bit) ? (int)(w.y + __popc(w.x & (bit - 1u))) : -1;
 }
 
 // SPARSE / DELTA stage B: 8 lanes per (probe, observed node).
@@ -806,7 +825,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
     const float *__restrict__ b2, const float *__restrict__ OUT,
     const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
     const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
-    float *__restrict__ out, long ldo, const uint32_t *__restrict__ bits, int words) {
+    float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words, int skip_long) {
     const long gid = ((long)blockIdx.x * LT_BLOCK + threadIdx.x) / LT_L2_LANES;
     const int q = threadIdx.x & (LT_L2_LANES - 1);
     if (gid >= (long)nb * n_obs) return;
@@ -817,13 +836,14 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
     const int cnt = tptr[v + 1] - tptr[v];
     const float *items = S2x + (size_t)off[b] * C;
     const int e0 = rowptr[u], e1 = rowptr[u + 1];
+    if (skip_long && e1 - e0 > LT_ROW_SEG) return;   // an observed hub: k_item_stageB_long
 
     // does row u touch R_v at all?  (otherwise the perturbed logits ARE the baseline logits)
-    const uint32_t *mb = bits ? bits + (size_t)b * words : nullptr;
-    // membership of column c in R_v: the bitmap when there is one, the search otherwise
-    auto member = [&](int c) { return mb ? ((mb[c >> 5] >> (c & 31)) & 1u) != 0u : find_row(rv, cnt, c) >= 0; };
+    const uint2 *mb = bits ? bits + (size_t)b * words : nullptr;
+    // position of column c in R_v (-1: not a member): the bitmap when there is one, the search otherwise
+    auto pos = [&](int c) { return mb ? bits_pos(mb, c) : find_row(rv, cnt, c); };
     bool touch = false;
-    for (int e = e0 + q; e < e1; e += LT_L2_LANES) touch |= member(col[e]);
+    for (int e = e0 + q; e < e1; e += LT_L2_LANES) touch |= pos(col[e]) >= 0;
     // 8-lane any(): xor butterfly on an int
     int t = touch ? 1 : 0;
 #pragma unroll
@@ -835,7 +855,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
             // d_out[c] = sum over e with col[e] in R_v of val[e] * dS2[item(col[e]), c]
             row2_dot<CP>(col, val, e0, e1, q, C,
                          [&](int c, int) {
-                             const int p = (!mb || member(c)) ? find_row(rv, cnt, c) : -1;
+                             const int p = pos(c);
                              return p >= 0 ? items + (size_t)p * C : (const float *)nullptr;
                          },
                          acc);
@@ -850,7 +870,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
         } else {
             row2_dot<CP>(col, val, e0, e1, q, C,
                          [&](int c, int) {
-                             const int p = (!mb || member(c)) ? find_row(rv, cnt, c) : -1;
+                             const int p = pos(c);
                              return p >= 0 ? items + (size_t)p * C : S2 + (size_t)c * C;
                          },
                          acc);
@@ -858,6 +878,113 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
         }
     }
     if (q == 0) out[(long)b * ldo + j] = res;
+}
+
+// SPARSE / DELTA stage B for an OBSERVED HUB (a row of more than LT_ROW_SEG entries): in k_item_stageB the 8 lanes of
+// a (probe, hub) pair walk 10^3 entries, each step a dependent col -> membership -> value round trip, and the launch
+// waits for those pairs.  Here a block takes one observed hub and 32 probes (a wave = 8 probes x the 8 chain lanes):
+// the row's (col, val, baseline S2 row) are fetched into LDS once per chunk by all 256 threads and shared by the 32
+// probes; the membership tests of a lane's next 8 entries are in flight together.  Same chains (entry e -> chain
+// (e - e0) & 7, k-ordered, non-members skipped in DELTA), same butterfly, same tail: the bits of k_item_stageB.
+#define LT_SBL_CHUNK 1024
+#define LT_SBL_UN 8
+template <int CP, bool DELTA>
+__global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_long(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const int32_t *__restrict__ tptr,
+    const int32_t *__restrict__ trow, const float *__restrict__ S2, int C,
+    const float *__restrict__ b2, const float *__restrict__ OUT,
+    const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
+    const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
+    float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words) {
+    __shared__ int sc[LT_SBL_CHUNK];
+    __shared__ float sv[LT_SBL_CHUNK];
+    __shared__ float sT[DELTA ? 1 : LT_SBL_CHUNK][CP];
+    const int pblocks = (nb + LT_BLOCK / LT_L2_LANES - 1) / (LT_BLOCK / LT_L2_LANES);
+    const int j = blockIdx.x / pblocks;
+    const int u = observe[j];
+    const int e0 = rowptr[u], e1 = rowptr[u + 1];
+    if (e1 - e0 <= LT_ROW_SEG) return;           // not a hub: k_item_stageB has it (block-uniform exit)
+    const int tid = threadIdx.x;
+    const int q = tid & (LT_L2_LANES - 1);
+    const int b = (blockIdx.x % pblocks) * (LT_BLOCK / LT_L2_LANES) + tid / LT_L2_LANES;
+    const bool live = b < nb;
+    const int v = probes[live ? b : 0];
+    const int32_t *rv = trow + tptr[v];
+    const int cnt = tptr[v + 1] - tptr[v];
+    const float *items = S2x + (size_t)off[live ? b : 0] * C;
+    const uint2 *mb = bits ? bits + (size_t)(live ? b : 0) * words : nullptr;
+    auto pos = [&](int c) { return mb ? bits_pos(mb, c) : find_row(rv, cnt, c); };
+    float acc[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) acc[c] = 0.f;
+    bool touch = false;
+    for (int cb = e0; cb < e1; cb += LT_SBL_CHUNK) {
+        const int nc = min(LT_SBL_CHUNK, e1 - cb);
+        __syncthreads();
+        for (int i = tid; i < nc; i += LT_BLOCK) {
+            const int cc = col[cb + i];
+            sc[i] = cc;
+            sv[i] = val[cb + i];
+            if (!DELTA) {
+#pragma unroll
+                for (int c = 0; c < CP; ++c) sT[i][c] = c < C ? S2[(size_t)cc * C + c] : 0.f;
+            }
+        }
+        __syncthreads();
+        if (live) {
+            for (int i = q; i < nc; i += LT_L2_LANES * LT_SBL_UN) {
+                int mp[LT_SBL_UN];
+                float a_[LT_SBL_UN], tb[LT_SBL_UN][CP];
+#pragma unroll
+                for (int k = 0; k < LT_SBL_UN; ++k) {   // the membership loads of 8 entries in flight together
+                    const int ii = i + k * LT_L2_LANES;
+                    mp[k] = ii < nc ? pos(sc[ii]) : -1;
+                    a_[k] = ii < nc ? sv[ii] : 0.f;
+#pragma unroll
+                    for (int c = 0; c < CP; ++c) tb[k][c] = (!DELTA && ii < nc) ? sT[ii][c] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < LT_SBL_UN; ++k) {
+                    const int ii = i + k * LT_L2_LANES;
+                    if (ii >= nc) break;
+                    const float a = a_[k];
+                    if (mp[k] >= 0) {
+                        touch = true;
+                        const float *t = items + (size_t)mp[k] * C;
+#pragma unroll
+                        for (int c = 0; c < CP; ++c)
+                            if (c < C) acc[c] = fmaf(a, t[c], acc[c]);
+                    } else if (!DELTA) {
+#pragma unroll
+                        for (int c = 0; c < CP; ++c)
+                            if (c < C) acc[c] = fmaf(a, tb[k][c], acc[c]);
+                    }
+                }
+            }
+        }
+    }
+    int t = touch ? 1 : 0;
+#pragma unroll
+    for (int m = LT_L2_LANES / 2; m >= 1; m >>= 1) t |= __shfl_xor(t, m, 64);
+#pragma unroll
+    for (int c = 0; c < CP; ++c) acc[c] = group_sum<LT_L2_LANES>(acc[c]);
+    float res = 0.f;
+    if (t) {
+        if (DELTA) {
+            float ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < CP; ++c)
+                if (c < C) {
+                    const float d = acc[c] / delta;
+                    ss = fmaf(d, d, ss);
+                }
+            res = sqrtf(ss);
+        } else {
+            res = diff_norm<CP>(acc, b2, OUT + (size_t)u * C, C, delta);
+        }
+    }
+    if (live && q == 0) out[(long)b * ldo + j] = res;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -910,7 +1037,7 @@ struct infl_ws {
     float *slabs;          // FULL / SPARSE: split-K partials of the perturbed-row GEMM
     float *S2x;            // SPARSE / DELTA: per-item values
     int32_t *off;          // SPARSE / DELTA: item offsets [chunk + 1]
-    uint32_t *bits;        // SPARSE / DELTA: membership bitmap of R_v per probe [chunk][ceil(n / 32)], or NULL (huge graphs)
+    uint2 *bits;           // SPARSE / DELTA: membership bitmap + positions of R_v per probe [chunk][ceil(n / 32)], or NULL (huge graphs)
     size_t bytes;
     int chunk;
 };
@@ -952,7 +1079,7 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
         const size_t bw = (n + 31) / 32;
         // ("item_bits" = 0 forces the search path a huge graph takes: tests)
         const bool no_bits = lt_tune().item_bits == 0;
-        w.bits = (!no_bits && chunk * bw * sizeof(uint32_t) <= LT_BITS_MAX_BYTES) ? (uint32_t *)take(chunk * bw * sizeof(uint32_t)) : nullptr;
+        w.bits = (!no_bits && chunk * bw * sizeof(uint2) <= LT_BITS_MAX_BYTES) ? (uint2 *)take(chunk * bw * sizeof(uint2)) : nullptr;
     }
     w.bytes = offb;
     return w;
@@ -997,7 +1124,8 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
         const int32_t *probes = probe_nodes + p0;
         float *orow = out + (int64_t)p0 * ldo;
         const long pairs = (long)nb * n_obs;
-        LT_REQUIRE(mode == LT_MODE_FULL || (pairs * LT_L2_LANES + LT_BLOCK - 1) / LT_BLOCK < 2147483647L,
+        LT_REQUIRE(mode == LT_MODE_FULL || ((pairs * LT_L2_LANES + LT_BLOCK - 1) / LT_BLOCK < 2147483647L &&
+                                            ((nb + 31) / 32) * (long)n_obs < 2147483647L),
                    "lt_influence_rows: %d probes x %d observed nodes per chunk exceed the grid limit (lower chunk_budget_bytes)",
                    nb, n_obs);
         const unsigned gridB = (unsigned)((pairs * LT_L2_LANES + LT_BLOCK - 1) / LT_BLOCK);
@@ -1119,7 +1247,15 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
                                                        g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
                                                        nb, w.off, w.S2x, observe_nodes, n_obs, delta,
-                                                       orow, (long)ldo, w.bits, words));
+                                                       orow, (long)ldo, w.bits, words, g->p_n_long > 0 ? 1 : 0));
+                if (g->p_n_long > 0) {
+                    LT_CHECK_LAUNCH();
+                    LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_long<CP_, false>),
+                                                           dim3((unsigned)(((nb + 31) / 32) * (long)n_obs)), dim3(LT_BLOCK), 0, st, g->rowptr,
+                                                           g->col, g->val, g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
+                                                           nb, w.off, w.S2x, observe_nodes, n_obs, delta, orow, (long)ldo,
+                                                           w.bits, words));
+                }
             } else {
                 { lt_prof_scope prof_(LT_K_ITEM_A, st);
                 if (b->Z1d) {
@@ -1143,7 +1279,15 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
                                                        g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
                                                        nb, w.off, w.S2x, observe_nodes, n_obs, delta,
-                                                       orow, (long)ldo, w.bits, words));
+                                                       orow, (long)ldo, w.bits, words, g->p_n_long > 0 ? 1 : 0));
+                if (g->p_n_long > 0) {
+                    LT_CHECK_LAUNCH();
+                    LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_long<CP_, true>),
+                                                           dim3((unsigned)(((nb + 31) / 32) * (long)n_obs)), dim3(LT_BLOCK), 0, st, g->rowptr,
+                                                           g->col, g->val, g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
+                                                           nb, w.off, w.S2x, observe_nodes, n_obs, delta, orow, (long)ldo,
+                                                           w.bits, words));
+                }
             }
             LT_CHECK_LAUNCH();
         }

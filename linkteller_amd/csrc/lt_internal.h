@@ -70,6 +70,7 @@ struct lt_baseline {
     double *S1d = nullptr;      // [n, Hp]
     double *Z1d = nullptr;      // [n, Hp]
     double *slabs_d = nullptr;  // split-K partials
+    double *seg_d = nullptr;    // [g->p_n_seg, Hp] fp64 segment sums of the long rows
     // lt_baseline_refresh recomputes S1 and marks what depends on it stale; Z1 / S2 / OUT (and Z1d) are
     // recomputed by the first call that reads them (logits, SPARSE / DELTA rows) -- FULL rows never do: their
     // stage A yields the baseline S2 as a by-product and stage B forms the baseline logits itself.

@@ -66,28 +66,51 @@ __device__ __forceinline__ void relu_w2_partial(f32x4 z, const float *w2, int C,
 // (the first starts from `init`, the others from +0) and the segment sums are added in segment order,
 // z = ((seg0 + seg1) + seg2) + ...  A row of up to LT_ROW_SEG entries is therefore one plain chain.  The cut is
 // what lets FULL stage A give the segments of a hub row to different waves and still produce these bits.
+// AHEAD = gathers issued before their FMAs run (the FMAs stay in entry order whatever AHEAD is: same chain, same
+// bits).  4 suits the probe kernels (registers); the baseline kernels, whose run time on a graph with hub rows is
+// the latency tail of their longest chains, use 8 / 16.
+template <int AHEAD = 4>
 __device__ __forceinline__ f32x4 seg_chain(const int32_t *__restrict__ col, const float *__restrict__ val,
                                            int e0, int e1, const float *__restrict__ S, int ld, int coff,
                                            bool active, int subst_col, const float *__restrict__ subst_row,
                                            f32x4 init) {
     f32x4 acc = init;
     int e = e0;
-    for (; e + 4 <= e1; e += 4) {
-        int c[4];
-        float a[4];
-        f32x4 s[4];
+    for (; e + AHEAD <= e1; e += AHEAD) {
+        int c[AHEAD];
+        float a[AHEAD];
+        f32x4 s[AHEAD];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < AHEAD; ++k) {
             c[k] = col[e + k];
             a[k] = val[e + k];
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < AHEAD; ++k) {
             const float *src = (c[k] == subst_col) ? subst_row : S + (size_t)c[k] * ld;
             s[k] = active ? ld4(src + coff) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc = fma4(a[k], s[k], acc);
+        for (int k = 0; k < AHEAD; ++k) acc = fma4(a[k], s[k], acc);
+    }
+    if (AHEAD > 4) {   // the tail in blocks of 4, then singly
+        for (; e + 4 <= e1; e += 4) {
+            int c[4];
+            float a[4];
+            f32x4 s[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                c[k] = col[e + k];
+                a[k] = val[e + k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float *src = (c[k] == subst_col) ? subst_row : S + (size_t)c[k] * ld;
+                s[k] = active ? ld4(src + coff) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = fma4(a[k], s[k], acc);
+        }
     }
     for (; e < e1; ++e) {
         const int c = col[e];
@@ -98,16 +121,17 @@ __device__ __forceinline__ f32x4 seg_chain(const int32_t *__restrict__ col, cons
     }
     return acc;
 }
+template <int AHEAD = 4>
 __device__ __forceinline__ f32x4 row_dot(const int32_t *__restrict__ col,
                                          const float *__restrict__ val, int e0, int e1,
                                          const float *__restrict__ S, int ld, int coff,
                                          bool active, int subst_col,
                                          const float *__restrict__ subst_row,
                                          f32x4 init = f32x4{0.f, 0.f, 0.f, 0.f}) {
-    f32x4 total = seg_chain(col, val, e0, min(e1, e0 + LT_ROW_SEG), S, ld, coff, active, subst_col, subst_row, init);
+    f32x4 total = seg_chain<AHEAD>(col, val, e0, min(e1, e0 + LT_ROW_SEG), S, ld, coff, active, subst_col, subst_row, init);
     for (int s0 = e0 + LT_ROW_SEG; s0 < e1; s0 += LT_ROW_SEG) {   // long rows only
-        const f32x4 t = seg_chain(col, val, s0, min(e1, s0 + LT_ROW_SEG), S, ld, coff, active, subst_col, subst_row,
-                                  f32x4{0.f, 0.f, 0.f, 0.f});
+        const f32x4 t = seg_chain<AHEAD>(col, val, s0, min(e1, s0 + LT_ROW_SEG), S, ld, coff, active, subst_col, subst_row,
+                                         f32x4{0.f, 0.f, 0.f, 0.f});
         total.x += t.x; total.y += t.y; total.z += t.z; total.w += t.w;
     }
     return total;

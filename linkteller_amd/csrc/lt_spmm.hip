@@ -175,7 +175,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_spmm_rows(
     const bool active = coff < ncols;
     const int e0 = rowptr[r], e1 = rowptr[r + 1];
     if (e1 - e0 > LT_ROW_SEG) return;  // long rows: k_spmm_segments + k_spmm_long_combine
-    const f32x4 acc = seg_chain(col, val, e0, e1, S, lds, coff, active, -1, nullptr, f32x4{0.f, 0.f, 0.f, 0.f});
+    const f32x4 acc = seg_chain<8>(col, val, e0, e1, S, lds, coff, active, -1, nullptr, f32x4{0.f, 0.f, 0.f, 0.f});
     if (!active) return;
     f32x4 o = acc;
     if (bias) {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_spmm_segments(
     const int r = long_row[seg_long[sg]];
     const int b = seg_begin[sg];
     const int e = min(b + LT_ROW_SEG, rowptr[r + 1]);
-    const f32x4 acc = seg_chain(col, val, b, e, S, lds, coff, true, -1, nullptr, f32x4{0.f, 0.f, 0.f, 0.f});
+    const f32x4 acc = seg_chain<16>(col, val, b, e, S, lds, coff, true, -1, nullptr, f32x4{0.f, 0.f, 0.f, 0.f});
     *reinterpret_cast<f32x4 *>(partial + (size_t)sg * ldp + coff) = acc;
 }
 
