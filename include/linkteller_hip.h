@@ -155,6 +155,28 @@ int lt_influence_rows(const lt_baseline *b, const int32_t *probe_nodes, int32_t 
                       float *out, int64_t ldo, void *workspace, size_t workspace_bytes,
                       void *stream);
 
+/* ---- the same for the 3-layer model (GCN3, gcn/models.py:28-46; --n-layer 3, gcn_trainer.py:81-86) -------------
+ *   logits = A (relu(A (relu(A (X W1) + b1) W2) + b2) W3) + b3,   H1, H2 <= 256, C <= 8.
+ * lt_baseline3_create computes the unperturbed forward (owns S1, H1, S2, Z2, S3, OUT; borrows X and the six
+ * parameter tensors; lt_baseline3_refresh recomputes everything from them).  lt_influence3_rows evaluates the
+ * reference's fp32 finite difference (f(X + d e_v x_v^T) - f(X))[u] / d only where it can be non-zero: the rows a
+ * probe reaches in 1, 2 and 3 hops, each recomputed with the arithmetic of the baseline forward, so unreachable
+ * pairs are exactly 0.  One 4-byte device-to-host read per probe chunk (an item count sizes a GEMM); otherwise
+ * the conventions of lt_influence_rows. */
+typedef struct lt_baseline3 lt_baseline3;
+int lt_baseline3_create(const lt_graph *g, const float *X, int64_t ldx, int32_t F,
+                        const float *W1, const float *b1, int32_t H1,
+                        const float *W2, const float *b2, int32_t H2,
+                        const float *W3, const float *b3, int32_t C,
+                        void *stream, lt_baseline3 **out);
+int lt_baseline3_refresh(lt_baseline3 *b, void *stream);
+int lt_baseline3_destroy(lt_baseline3 *b);
+int lt_baseline3_logits(const lt_baseline3 *b, float *dst, void *stream);
+size_t lt_influence3_workspace_bytes(const lt_baseline3 *b, int32_t n_probe, int32_t n_obs);
+int lt_influence3_rows(const lt_baseline3 *b, const int32_t *probe_nodes, int32_t n_probe,
+                       const int32_t *observe_nodes, int32_t n_obs, float delta,
+                       float *out, int64_t ldo, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- per-kernel timing (used by bench.py for the roofline object) --------------------------
  * lt_profile_enable(mask): bit k of mask set = launches of kernel class k are bracketed by a pair of
  * hipEvents on the caller's stream (mask 0 = off, -1 = every class; an event pair costs a few

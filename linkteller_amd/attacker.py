@@ -85,9 +85,10 @@ class Attacker:
         return out
 
     def _rows_generic(self, probe_nodes, observe_nodes):
-        """Probe rows for models the fused kernels do not cover (GCN3, --n-layer 3): per probe, row v of
-        S1 = X W1 is replaced by (x_v + x_v*d) W1 and the remaining layers run through lt_spmm_csr_f32 /
-        lt_gemm_f32.  Same quantity, ~2 launches per layer per probe; not a benchmarked path."""
+        """Probe rows for GraphConvolution stacks neither probe primitive covers (more than 3 layers, or a GCN3
+        wider than 256 hidden units / 8 classes): per probe, row v of S1 = X W1 is replaced by (x_v + x_v*d) W1 and
+        the remaining layers run through lt_spmm_csr_f32 / lt_gemm_f32.  Same quantity, ~2 launches per layer per
+        probe; kept as the reference implementation the 3-layer primitive is tested against."""
         layers = self._layers()
         x, delta = self.features, float(self.args.influence)
         g = engine.as_hip_graph(self.adj)
@@ -109,11 +110,37 @@ class Attacker:
             rows[i] = ((rest(s1p)[obs] - base) / delta).norm(dim=1)
         return rows
 
+    def _is_three_layer(self):
+        """GCN3 (gcn/models.py:28-46) within what lt_baseline3 serves: hidden widths <= 256, <= 8 classes."""
+        sd = self.model.state_dict()
+        if set(sd.keys()) != {f"gc{i}.{p}" for i in (1, 2, 3) for p in ("weight", "bias")}:
+            return False
+        return sd["gc1.weight"].shape[1] <= 256 and sd["gc2.weight"].shape[1] <= 256 and sd["gc3.weight"].shape[1] <= 8
+
+    def baseline3(self) -> engine.Baseline3:
+        """The 3-layer counterpart of ``baseline()``: same caching rule (rebuilt when features / adjacency /
+        parameters were replaced, refreshed on every attack)."""
+        dev = self.features.device
+        sd = self.model.state_dict()
+        src = [sd[f"gc{i}.{p}"].detach() for i in (1, 2, 3) for p in ("weight", "bias")]
+        off_device = any(p.device != dev for p in src)
+        key = ("gcn3", id(self.adj), self.features.data_ptr(),
+               tuple((p.data_ptr(), p._version if off_device else 0) for p in src))
+        if self._baseline is None or self._baseline_key != key:
+            self._baseline = engine.Baseline3(self.adj, self.features, *[p.to(dev) for p in src])
+            self._baseline_key = key
+        else:
+            self._baseline.refresh()
+        return self._baseline
+
     def _rows(self, probe_nodes, observe_nodes, mode=None):
         """[len(probe_nodes), len(observe_nodes)] influence rows on the device."""
         if self._is_two_layer():
             mode = mode or getattr(self.args, "influence_mode", None) or os.environ.get("LT_INFLUENCE_MODE", "delta")
             return self.baseline().influence_rows(probe_nodes, observe_nodes, float(self.args.influence), mode)
+        if self._is_three_layer():
+            # the 3-hop probe primitive: the reference's fp32 finite difference on the rows a probe can reach
+            return self.baseline3().influence_rows(probe_nodes, observe_nodes, float(self.args.influence))
         return self._rows_generic(probe_nodes, observe_nodes)
 
     def baseline(self) -> engine.Baseline:

@@ -1,0 +1,445 @@
+// The probe primitive for the 3-layer model (GCN3, gcn/models.py:28-46; reached with --n-layer 3,
+// gcn_trainer.py:81-86):   out = A (relu(A (relu(A (X W1) + b1) W2) + b2) W3) + b3
+//
+// Same idea as the 2-layer SPARSE mode, one hop deeper.  X + pert_v differs from X in row v only, so
+//   S1 = X W1              changes in row v,
+//   H1 = relu(A S1 + b1)   changes on R1 = {r : A[r,v] != 0},          S2 = H1 W2 on the same rows,
+//   H2 = relu(A S2 + b2)   changes on R2 = {r2 : A[r2,r] != 0, r in R1}, S3 = H2 W3 on the same rows,
+//   out = A S3 + b3        changes on the 3-hop set; only the observed rows are formed.
+// Per probe chunk (one 4-byte read-back of the item count per chunk, for the GEMM's M):  level-1 items (b, r in R1) -> H1x rows (k3_rows_relu with row v substituted) -> one MFMA GEMM
+// S2x = H1x W2 -> R2 by marking (k3_mark2: the thread that flips a bit appends the item) -> level-2 items (b, r2):
+// k3_stageB runs the layer-2 chain of row r2 with the rows of R1 looked up in S2x (bitmap with positions), relu,
+// . W3 -> S3x[b][r2] -> k3_stageC: layer-3 row of each observed node with the rows of R2 looked up in S3x, minus the
+// baseline logits, / delta, L2 norm.
+//
+// Arithmetic = the fp32 finite difference of the reference (attacker.py:105-106), evaluated only where it can be
+// non-zero: every recomputed row goes through the SAME device functions as the baseline forward below (row_dot chains
+// started from the bias, relu_w2_partial + group_sum, row2_dot), so rows a probe cannot reach difference to exactly 0
+// and rows it can reach carry only the perturbation and fp32 rounding -- the reference's noise class.
+#include <new>
+
+#include "lt_items.cuh"
+
+#define LT_BLOCK 256
+#define LT3_GRID 2048
+
+struct lt_baseline3 {
+    const lt_graph *g = nullptr;
+    int32_t n = 0, F = 0, H1 = 0, H2 = 0, C = 0, Hp1 = 0, Hp2 = 0;
+    const float *X = nullptr;
+    int64_t ldx = 0;
+    const float *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr, *W3 = nullptr, *b3 = nullptr;
+    // owned
+    float *S1 = nullptr;    // [n, Hp1]  X W1
+    float *Act1 = nullptr;  // [n, Hp1]  H1 = relu(A S1 + b1)
+    float *S2 = nullptr;    // [n, Hp2]  H1 W2
+    float *Z2 = nullptr;    // [n, Hp2]  A S2 + b2
+    float *S3 = nullptr;    // [n, C]    relu(Z2) W3
+    float *OUT = nullptr;   // [n, C]    A S3 + b3
+    float *b1p = nullptr, *b2p = nullptr, *W3p = nullptr;   // zero-padded to Hp1 / Hp2 / [Hp2, C]
+    float *slabs = nullptr;     // split-K partials of X W1
+    float *seg_part = nullptr;  // [g->p_n_seg, Hp2] segment sums of the hub rows (layer 2)
+};
+
+// h[dst] = relu(A[r,:] S + bias): all rows (items == NULL), or the level-1 items of a probe chunk, whose row reads
+// Sp[b] in place of S[v] (the perturbed row of probe b)
+template <int LPR>
+__global__ __launch_bounds__(LT_BLOCK) void k3_rows_relu(
+    int n_rows, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
+    const float *__restrict__ S, int Hp, const float *__restrict__ biasp, float *__restrict__ out,
+    const int32_t *__restrict__ tptr, const int32_t *__restrict__ trow, const int32_t *__restrict__ probes, int nb,
+    const int32_t *__restrict__ off, const float *__restrict__ Sp) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & (LPR - 1);
+    const int coff = 4 * gl;
+    const bool active = coff < Hp;
+    const bool items = off != nullptr;
+    const int total = items ? off[nb] : n_rows;
+    const int wave0 = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
+    const int nwaves = gridDim.x * (LT_BLOCK / 64);
+    for (int base = wave0 * RPW; base < total; base += nwaves * RPW) {
+        const int it = base + lane / LPR;
+        if (it >= total || !active) continue;
+        int r = it, v = -1;
+        const float *sub = nullptr;
+        if (items) {
+            const int b = find_probe(off, nb, it);
+            v = probes[b];
+            r = trow[tptr[v] + (it - off[b])];
+            sub = Sp + (size_t)b * Hp;
+        }
+        const f32x4 z = row_dot<8>(col, val, rowptr[r], rowptr[r + 1], S, Hp, coff, true, v, sub, ld4(biasp + coff));
+        f32x4 h;
+        h.x = fmaxf(z.x, 0.f); h.y = fmaxf(z.y, 0.f); h.z = fmaxf(z.z, 0.f); h.w = fmaxf(z.w, 0.f);
+        *reinterpret_cast<f32x4 *>(out + (size_t)it * Hp + coff) = h;
+    }
+}
+
+// R2 of every probe: for each level-1 item (b, r) the rows r2 that read row r (CSC column r) are marked in the
+// probe's bitmap; the thread that flips a bit appends (b, r2) to the level-2 item list (order irrelevant: every item
+// is computed on its own and lands in S3x[b][r2])
+__global__ __launch_bounds__(LT_BLOCK) void k3_mark2(
+    const int32_t *__restrict__ tptr, const int32_t *__restrict__ trow, const int32_t *__restrict__ probes, int nb,
+    const int32_t *__restrict__ off, int words, uint32_t *__restrict__ bits2, int2 *__restrict__ items2,
+    int32_t *__restrict__ n_items2) {
+    const int lane = threadIdx.x & 63;
+    const int total = off[nb];
+    const int wave0 = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
+    const int nwaves = gridDim.x * (LT_BLOCK / 64);
+    for (int it = wave0; it < total; it += nwaves) {
+        const int b = find_probe(off, nb, it);
+        const int v = probes[b];
+        const int r = trow[tptr[v] + (it - off[b])];
+        for (int t = tptr[r] + lane; t < tptr[r + 1]; t += 64) {
+            const int r2 = trow[t];
+            const unsigned bit = 1u << (r2 & 31);
+            const unsigned old = atomicOr(&bits2[(size_t)b * words + (r2 >> 5)], bit);
+            if (!(old & bit)) items2[atomicAdd(n_items2, 1)] = make_int2(b, r2);
+        }
+    }
+}
+
+// One CSR row against S2 with the rows of R1(b) replaced by their perturbed versions (S2x, found through the probe's
+// bitmap with positions): row_dot's canonical order -- 128-entry fmaf chains, the first started from `init`, their
+// sums added in segment order -- so an unperturbed row gives the bits of the baseline kernel.
+__device__ __forceinline__ f32x4 row_dot_lookup(const int32_t *__restrict__ col, const float *__restrict__ val, int e0,
+                                                int e1, const float *__restrict__ S, int ld, int coff,
+                                                const uint2 *__restrict__ mb, const float *__restrict__ items, f32x4 init) {
+    f32x4 total = init;
+    for (int s0 = e0; s0 < e1 || s0 == e0; s0 += LT_ROW_SEG) {
+        const int s1 = min(e1, s0 + LT_ROW_SEG);
+        f32x4 acc = s0 == e0 ? init : f32x4{0.f, 0.f, 0.f, 0.f};
+        int e = s0;
+        for (; e + 4 <= s1; e += 4) {
+            float a[4];
+            f32x4 s[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = col[e + k];
+                a[k] = val[e + k];
+                const int p = bits_pos(mb, c);
+                s[k] = ld4((p >= 0 ? items + (size_t)p * ld : S + (size_t)c * ld) + coff);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = fma4(a[k], s[k], acc);
+        }
+        for (; e < s1; ++e) {
+            const int c = col[e];
+            const int p = bits_pos(mb, c);
+            acc = fma4(val[e], ld4((p >= 0 ? items + (size_t)p * ld : S + (size_t)c * ld) + coff), acc);
+        }
+        if (s0 == e0) total = acc;
+        else { total.x += acc.x; total.y += acc.y; total.z += acc.z; total.w += acc.w; }
+        if (s1 >= e1) break;
+    }
+    return total;
+}
+
+// level-2 items: S3x[b][r2] = relu(A[r2,:] S2' + b2) . W3
+template <int LPR, int CP>
+__global__ __launch_bounds__(LT_BLOCK) void k3_stageB(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
+    const float *__restrict__ S2, int Hp2, const float *__restrict__ b2p, const float *__restrict__ W3p, int C,
+    const int32_t *__restrict__ off, const float *__restrict__ S2x, const uint2 *__restrict__ bits1, int words,
+    const int2 *__restrict__ items2, const int32_t *__restrict__ n_items2, int n, float *__restrict__ S3x) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & (LPR - 1);
+    const int coff = 4 * gl;
+    const bool active = coff < Hp2;
+    const int total = *n_items2;
+    const int wave0 = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
+    const int nwaves = gridDim.x * (LT_BLOCK / 64);
+    for (int base = wave0 * RPW; base < total; base += nwaves * RPW) {
+        const int it = base + lane / LPR;
+        const bool live = it < total;   // group-uniform; dead groups still join the shuffles
+        float part[CP];
+#pragma unroll
+        for (int c = 0; c < CP; ++c) part[c] = 0.f;
+        int b = 0, r2 = 0;
+        if (live) {
+            const int2 w = items2[it];
+            b = w.x; r2 = w.y;
+            if (active) {
+                const f32x4 z = row_dot_lookup(col, val, rowptr[r2], rowptr[r2 + 1], S2, Hp2, coff,
+                                               bits1 + (size_t)b * words, S2x + (size_t)off[b] * Hp2, ld4(b2p + coff));
+                relu_w2_partial<CP>(z, W3p + (size_t)coff * C, C, part);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CP; ++c) part[c] = group_sum<LPR>(part[c]);
+        if (live && gl == 0) {
+#pragma unroll
+            for (int c = 0; c < CP; ++c)
+                if (c < C) S3x[((size_t)b * n + r2) * C + c] = part[c];
+        }
+    }
+}
+
+// observed rows: out[b][j] = || (A[u,:] S3' + b3 - OUT[u]) / delta ||, 8 lanes per (probe, observed node)
+template <int CP>
+__global__ __launch_bounds__(LT_BLOCK) void k3_stageC(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
+    const float *__restrict__ S3, int C, const float *__restrict__ b3, const float *__restrict__ OUT, int nb, int n,
+    const float *__restrict__ S3x, const uint32_t *__restrict__ bits2, int words, const int32_t *__restrict__ observe,
+    int n_obs, float delta, float *__restrict__ out, long ldo) {
+    const long gid = ((long)blockIdx.x * LT_BLOCK + threadIdx.x) / LT_L2_LANES;
+    const int q = threadIdx.x & (LT_L2_LANES - 1);
+    if (gid >= (long)nb * n_obs) return;
+    const int b = (int)(gid / n_obs), j = (int)(gid % n_obs);
+    const int u = observe[j];
+    const uint32_t *mb = bits2 + (size_t)b * words;
+    const float *mine = S3x + (size_t)b * n * C;
+    const int e0 = rowptr[u], e1 = rowptr[u + 1];
+    auto member = [&](int c) { return ((mb[c >> 5] >> (c & 31)) & 1u) != 0u; };
+    bool touch = false;
+    for (int e = e0 + q; e < e1; e += LT_L2_LANES) touch |= member(col[e]);
+    int t = touch ? 1 : 0;
+#pragma unroll
+    for (int m = LT_L2_LANES / 2; m >= 1; m >>= 1) t |= __shfl_xor(t, m, 64);
+    float res = 0.f;
+    if (t) {
+        float acc[CP];
+        row2_dot<CP>(col, val, e0, e1, q, C,
+                     [&](int c, int) { return member(c) ? mine + (size_t)c * C : S3 + (size_t)c * C; }, acc);
+        res = diff_norm<CP>(acc, b3, OUT + (size_t)u * C, C, delta);
+    }
+    if (q == 0) out[(long)b * ldo + j] = res;
+}
+
+__global__ void k3_pad(const float *__restrict__ b1, int H1, int Hp1, const float *__restrict__ b2, int H2, int Hp2,
+                       const float *__restrict__ W3, int C, float *__restrict__ b1p, float *__restrict__ b2p,
+                       float *__restrict__ W3p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Hp1) b1p[i] = i < H1 ? b1[i] : 0.f;
+    if (i < Hp2) b2p[i] = i < H2 ? b2[i] : 0.f;
+    if (i < Hp2 * C) W3p[i] = (i / C) < H2 ? W3[i] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+static void free_baseline3(lt_baseline3 *b) {
+    if (!b) return;
+    (void)hipFree(b->S1); (void)hipFree(b->Act1); (void)hipFree(b->S2); (void)hipFree(b->Z2); (void)hipFree(b->S3);
+    (void)hipFree(b->OUT); (void)hipFree(b->b1p); (void)hipFree(b->b2p); (void)hipFree(b->W3p); (void)hipFree(b->slabs);
+    (void)hipFree(b->seg_part);
+    delete b;
+}
+
+static inline unsigned blocks_for(long n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+extern "C" int lt_baseline3_refresh(lt_baseline3 *b, void *stream) {
+    LT_REQUIRE(b != nullptr, "lt_baseline3_refresh: baseline is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    const lt_graph *g = b->g;
+    const int n = b->n;
+    if (n == 0) return LT_OK;
+    const int mx = (b->Hp1 > b->Hp2 * b->C ? b->Hp1 : b->Hp2 * b->C);
+    hipLaunchKernelGGL(k3_pad, dim3((mx + 255) / 256), dim3(256), 0, st, b->b1, b->H1, b->Hp1, b->b2, b->H2, b->Hp2, b->W3,
+                       b->C, b->b1p, b->b2p, b->W3p);
+    LT_CHECK_LAUNCH();
+    // S1 = X W1 (pad columns zero)
+    if (b->Hp1 != b->H1) LT_HIP(hipMemsetAsync(b->S1, 0, (size_t)n * b->Hp1 * sizeof(float), st));
+    int rc = b->slabs ? lt_launch_gemm_splitk(b->X, b->ldx, b->W1, b->H1, b->S1, b->Hp1, n, b->H1, b->F,
+                                              lt_gemm_pick_kslice(n, b->H1, b->F), b->slabs, st)
+                      : lt_launch_gemm(b->X, b->ldx, b->W1, b->H1, b->S1, b->Hp1, n, b->H1, b->F, st);
+    if (rc) return rc;
+    // H1 = relu(A S1 + b1)
+    const int lpr1 = lt_lpr_for(b->Hp1);
+    LT_DISPATCH_LPR(lpr1, hipLaunchKernelGGL((k3_rows_relu<LPR_>), dim3(blocks_for(n, (LT_BLOCK / 64) * (64 / lpr1))),
+                                             dim3(LT_BLOCK), 0, st, n, g->rowptr, g->col, g->val, b->S1, b->Hp1, b->b1p, b->Act1,
+                                             (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, 0,
+                                             (const int32_t *)nullptr, (const float *)nullptr));
+    LT_CHECK_LAUNCH();
+    // S2 = H1 W2
+    if (b->Hp2 != b->H2) LT_HIP(hipMemsetAsync(b->S2, 0, (size_t)n * b->Hp2 * sizeof(float), st));
+    rc = lt_launch_gemm(b->Act1, b->Hp1, b->W2, b->H2, b->S2, b->Hp2, n, b->H2, b->H1, st);
+    if (rc) return rc;
+    // S3 = relu(A S2 + b2) W3, OUT = A S3 + b3: the fused layer kernels of the 2-layer path
+    rc = lt_launch_layer1(g, b->S2, b->Hp2, b->b2p, b->W3p, b->C, b->Z2, b->S3, st, b->seg_part);
+    if (rc) return rc;
+    return lt_launch_layer2(g, b->S3, b->C, b->b3, b->OUT, st);
+}
+
+extern "C" int lt_baseline3_create(const lt_graph *g, const float *X, int64_t ldx, int32_t F, const float *W1,
+                                   const float *b1, int32_t H1, const float *W2, const float *b2, int32_t H2,
+                                   const float *W3, const float *b3, int32_t C, void *stream, lt_baseline3 **out) {
+    LT_REQUIRE(out != nullptr, "lt_baseline3_create: out is NULL");
+    *out = nullptr;
+    LT_REQUIRE(g != nullptr, "lt_baseline3_create: graph is NULL");
+    LT_REQUIRE(F > 0 && H1 > 0 && H2 > 0 && C > 0, "lt_baseline3_create: F=%d H1=%d H2=%d C=%d must be positive", F, H1, H2, C);
+    if (H1 > LT_MAX_H || H2 > LT_MAX_H || C > LT_MAX_C)
+        return lt_set_error(LT_ERR_UNSUPPORTED, "lt_baseline3_create: H1=%d H2=%d C=%d (supported: H <= %d, C <= %d)", H1, H2, C,
+                            LT_MAX_H, LT_MAX_C);
+    LT_REQUIRE(X && W1 && b1 && W2 && b2 && W3 && b3, "lt_baseline3_create: NULL tensor pointer");
+    LT_REQUIRE(ldx >= F, "lt_baseline3_create: ldx=%lld < F=%d", (long long)ldx, F);
+    lt_baseline3 *b = new (std::nothrow) lt_baseline3();
+    if (!b) return lt_set_error(LT_ERR_NOMEM, "lt_baseline3_create: out of host memory");
+    b->g = g; b->n = g->n; b->F = F; b->H1 = H1; b->H2 = H2; b->C = C;
+    b->Hp1 = lt_round_up(H1, 4); b->Hp2 = lt_round_up(H2, 4);
+    b->X = X; b->ldx = ldx; b->W1 = W1; b->b1 = b1; b->W2 = W2; b->b2 = b2; b->W3 = W3; b->b3 = b3;
+    const size_t n1 = (size_t)(b->n > 0 ? b->n : 1);
+#define B3_HIP(call)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            free_baseline3(b);                                                              \
+            return lt_set_error(LT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+        }                                                                                   \
+    } while (0)
+    B3_HIP(hipMalloc((void **)&b->S1, n1 * b->Hp1 * sizeof(float)));
+    B3_HIP(hipMalloc((void **)&b->Act1, n1 * b->Hp1 * sizeof(float)));
+    B3_HIP(hipMalloc((void **)&b->S2, n1 * b->Hp2 * sizeof(float)));
+    B3_HIP(hipMalloc((void **)&b->Z2, n1 * b->Hp2 * sizeof(float)));
+    B3_HIP(hipMalloc((void **)&b->S3, n1 * C * sizeof(float)));
+    B3_HIP(hipMalloc((void **)&b->OUT, n1 * C * sizeof(float)));
+    B3_HIP(hipMalloc((void **)&b->b1p, (size_t)b->Hp1 * sizeof(float)));
+    B3_HIP(hipMalloc((void **)&b->b2p, (size_t)b->Hp2 * sizeof(float)));
+    B3_HIP(hipMalloc((void **)&b->W3p, (size_t)b->Hp2 * C * sizeof(float)));
+    if (g->p_n_seg > 0) B3_HIP(hipMalloc((void **)&b->seg_part, (size_t)g->p_n_seg * b->Hp2 * sizeof(float)));
+    const size_t sb = lt_gemm_splitk_slab_bytes(b->n, H1, F, lt_gemm_pick_kslice(b->n, H1, F));
+    if (sb) B3_HIP(hipMalloc((void **)&b->slabs, sb));
+#undef B3_HIP
+    const int rc = lt_baseline3_refresh(b, stream);
+    if (rc) {
+        free_baseline3(b);
+        return rc;
+    }
+    *out = b;
+    return LT_OK;
+}
+
+extern "C" int lt_baseline3_destroy(lt_baseline3 *b) {
+    free_baseline3(b);
+    return LT_OK;
+}
+
+extern "C" int lt_baseline3_logits(const lt_baseline3 *b, float *dst, void *stream) {
+    LT_REQUIRE(b != nullptr && dst != nullptr, "lt_baseline3_logits: NULL argument");
+    if (b->n == 0) return LT_OK;
+    LT_HIP(hipMemcpyAsync(dst, b->OUT, (size_t)b->n * b->C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return LT_OK;
+}
+
+// ---- workspace ------------------------------------------------------------------------------
+struct infl3_ws {
+    float *Sp, *slabs, *H1x, *S2x, *S3x;
+    int32_t *off, *n_items2;
+    uint2 *bits1;
+    uint32_t *bits2;
+    int2 *items2;
+    size_t bytes;
+    int chunk;
+};
+
+static int probe_kslice3(const lt_baseline3 *b) { return lt_gemm_pick_kslice(b->n, b->H1, b->F); }
+
+static infl3_ws carve3(void *base, const lt_baseline3 *b, int n_probe) {
+    infl3_ws w = {};
+    const size_t n = (size_t)b->n, C = (size_t)b->C, Hp1 = (size_t)b->Hp1, Hp2 = (size_t)b->Hp2;
+    const size_t maxc = (size_t)(b->g->max_col_nnz > 0 ? b->g->max_col_nnz : 1);
+    const size_t words = (n + 31) / 32;
+    const size_t splitk = (((size_t)b->F + probe_kslice3(b) - 1) / probe_kslice3(b)) * (size_t)b->H1;
+    const size_t per_probe = (Hp1 + splitk + maxc * (Hp1 + Hp2) + n * C) * sizeof(float) + n * sizeof(int2) +
+                             words * (sizeof(uint2) + sizeof(uint32_t)) + sizeof(int32_t);
+    size_t chunk = (size_t)lt_tune().chunk_budget / per_probe;
+    if (chunk < 1) chunk = 1;
+    if (chunk > 65534) chunk = 65534;
+    if (chunk > (size_t)(n_probe > 0 ? n_probe : 1)) chunk = (size_t)(n_probe > 0 ? n_probe : 1);
+    w.chunk = (int)chunk;
+    size_t offb = 0;
+    char *p = (char *)base;
+    auto take = [&](size_t bytes) {
+        void *q = p ? (void *)(p + offb) : nullptr;
+        offb += lt_align_up(bytes ? bytes : 1, 256);
+        return q;
+    };
+    w.Sp = (float *)take(chunk * Hp1 * sizeof(float));
+    w.slabs = (float *)take(lt_gemm_splitk_slab_bytes((int)chunk, b->H1, b->F, probe_kslice3(b)));
+    w.off = (int32_t *)take((chunk + 1) * sizeof(int32_t));
+    w.n_items2 = (int32_t *)take(sizeof(int32_t));
+    w.H1x = (float *)take(chunk * maxc * Hp1 * sizeof(float));
+    w.S2x = (float *)take(chunk * maxc * Hp2 * sizeof(float));
+    w.bits1 = (uint2 *)take(chunk * words * sizeof(uint2));
+    w.bits2 = (uint32_t *)take(chunk * words * sizeof(uint32_t));
+    w.items2 = (int2 *)take(chunk * n * sizeof(int2));
+    w.S3x = (float *)take(chunk * n * C * sizeof(float));
+    w.bytes = offb;
+    return w;
+}
+
+extern "C" size_t lt_influence3_workspace_bytes(const lt_baseline3 *b, int32_t n_probe, int32_t n_obs) {
+    (void)n_obs;
+    if (!b || n_probe < 0) return 0;
+    return carve3(nullptr, b, n_probe).bytes;
+}
+
+extern "C" int lt_influence3_rows(const lt_baseline3 *b, const int32_t *probe_nodes, int32_t n_probe,
+                                  const int32_t *observe_nodes, int32_t n_obs, float delta, float *out, int64_t ldo,
+                                  void *workspace, size_t workspace_bytes, void *stream) {
+    LT_REQUIRE(b != nullptr, "lt_influence3_rows: baseline is NULL");
+    LT_REQUIRE(n_probe >= 0 && n_obs >= 0, "lt_influence3_rows: negative count");
+    LT_REQUIRE(delta != 0.f && delta == delta, "lt_influence3_rows: delta must be a non-zero number");
+    if (n_probe == 0 || n_obs == 0) return LT_OK;
+    LT_REQUIRE(probe_nodes && observe_nodes && out, "lt_influence3_rows: NULL pointer");
+    LT_REQUIRE(ldo >= n_obs, "lt_influence3_rows: ldo=%lld < n_obs=%d", (long long)ldo, n_obs);
+    LT_REQUIRE(b->n > 0, "lt_influence3_rows: empty graph");
+    const size_t need = lt_influence3_workspace_bytes(b, n_probe, n_obs);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace % 256))
+        return lt_set_error(LT_ERR_WORKSPACE, "lt_influence3_rows: workspace needs %zu bytes, 256-byte aligned", need);
+    hipStream_t st = (hipStream_t)stream;
+    const lt_graph *g = b->g;
+    const infl3_ws w = carve3(workspace, b, n_probe);
+    const int n = b->n, C = b->C, Hp1 = b->Hp1, Hp2 = b->Hp2, cp = lt_cp_for(C);
+    const int lpr1 = lt_lpr_for(Hp1), lpr2 = lt_lpr_for(Hp2);
+    const int words = (n + 31) / 32;
+    const long maxc = g->max_col_nnz > 0 ? g->max_col_nnz : 1;
+    for (int p0 = 0; p0 < n_probe; p0 += w.chunk) {
+        const int nb = (n_probe - p0) < w.chunk ? (n_probe - p0) : w.chunk;
+        const int32_t *probes = probe_nodes + p0;
+        float *orow = out + (int64_t)p0 * ldo;
+        LT_REQUIRE(((long)nb * n_obs * LT_L2_LANES + LT_BLOCK - 1) / LT_BLOCK < 2147483647L,
+                   "lt_influence3_rows: %d probes x %d observed nodes per chunk exceed the grid limit", nb, n_obs);
+        // perturbed rows: Sp = (X[v] + X[v] d) W1, the slicing of the baseline product          attacker.py:101-105
+        if (Hp1 != b->H1) LT_HIP(hipMemsetAsync(w.Sp, 0, (size_t)nb * Hp1 * sizeof(float), st));
+        int rc = lt_launch_gemm_splitk(b->X, b->ldx, b->W1, b->H1, w.Sp, Hp1, nb, b->H1, b->F, probe_kslice3(b), w.slabs, st,
+                                       probes, delta);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_probe_offsets, dim3(1), dim3(1024), 0, st, g->tptr, probes, nb, w.off);
+        LT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_item_bits, dim3(nb), dim3(256), 0, st, g->tptr, g->trow, probes, words, w.bits1);
+        LT_CHECK_LAUNCH();
+        // level 1: H1x rows, then S2x = H1x W2 (M = number of items, only known on the device: the GEMM runs over the
+        // chunk's upper bound nb * max column length and rows past the item count are never read)
+        LT_DISPATCH_LPR(lpr1, hipLaunchKernelGGL((k3_rows_relu<LPR_>), dim3(LT3_GRID), dim3(LT_BLOCK), 0, st, 0, g->rowptr,
+                                                 g->col, g->val, b->S1, Hp1, b->b1p, w.H1x, g->tptr, g->trow, probes, nb, w.off,
+                                                 w.Sp));
+        LT_CHECK_LAUNCH();
+        // the GEMM's M is the item count, which lives on the device: ONE 4-byte read-back per chunk (the only host
+        // synchronisation of this entry point; the 2-layer lt_influence_rows has none)
+        int32_t m1 = 0;
+        LT_HIP(hipMemcpyAsync(&m1, w.off + nb, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        LT_HIP(hipStreamSynchronize(st));
+        LT_REQUIRE(m1 >= 0 && (long)m1 <= (long)nb * maxc, "lt_influence3_rows: item count %d out of range", m1);
+        if (Hp2 != b->H2) LT_HIP(hipMemsetAsync(w.S2x, 0, (size_t)m1 * Hp2 * sizeof(float), st));
+        rc = lt_launch_gemm(w.H1x, Hp1, b->W2, b->H2, w.S2x, Hp2, m1, b->H2, b->H1, st);
+        if (rc) return rc;
+        // level 2: R2 and its items
+        LT_HIP(hipMemsetAsync(w.bits2, 0, (size_t)nb * words * sizeof(uint32_t), st));
+        LT_HIP(hipMemsetAsync(w.n_items2, 0, sizeof(int32_t), st));
+        hipLaunchKernelGGL(k3_mark2, dim3(LT3_GRID), dim3(LT_BLOCK), 0, st, g->tptr, g->trow, probes, nb, w.off, words, w.bits2,
+                           w.items2, w.n_items2);
+        LT_CHECK_LAUNCH();
+        LT_DISPATCH_LPR(lpr2, LT_DISPATCH_CP(cp,
+            hipLaunchKernelGGL((k3_stageB<LPR_, CP_>), dim3(LT3_GRID), dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, b->S2,
+                               Hp2, b->b2p, b->W3p, C, w.off, w.S2x, w.bits1, words, w.items2, w.n_items2, n, w.S3x)));
+        LT_CHECK_LAUNCH();
+        // level 3: observed rows
+        const unsigned gridC = (unsigned)(((long)nb * n_obs * LT_L2_LANES + LT_BLOCK - 1) / LT_BLOCK);
+        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k3_stageC<CP_>), dim3(gridC), dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
+                                              b->S3, C, b->b3, b->OUT, nb, n, w.S3x, w.bits2, words, observe_nodes, n_obs,
+                                              delta, orow, (long)ldo));
+        LT_CHECK_LAUNCH();
+    }
+    return LT_OK;
+}

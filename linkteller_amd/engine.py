@@ -171,6 +171,63 @@ class Baseline:
         return out
 
 
+class Baseline3:
+    """Unperturbed forward state of the 3-layer model (reference gcn/models.py:28-46) + its probe primitive
+    (lt_baseline3_create / lt_influence3_rows): the reference's fp32 finite difference, evaluated on the rows a
+    probe reaches in 1 / 2 / 3 hops."""
+
+    def __init__(self, adj, x, w1, b1, w2, b2, w3, b3):
+        self.graph: HipGraph = as_hip_graph(adj)
+        self.x, self.w1, self.b1, self.w2, self.b2, self.w3, self.b3 = (
+            _f32(t, n) for t, n in ((x, "x"), (w1, "W1"), (b1, "b1"), (w2, "W2"), (b2, "b2"), (w3, "W3"), (b3, "b3")))
+        n, f = self.x.shape
+        self.n, self.f = n, f
+        self.h1, self.h2, self.c = self.w1.shape[1], self.w2.shape[1], self.w3.shape[1]
+        if (n != self.graph.n or self.w1.shape[0] != f or self.w2.shape[0] != self.h1 or self.w3.shape[0] != self.h2
+                or self.b1.numel() != self.h1 or self.b2.numel() != self.h2 or self.b3.numel() != self.c):
+            raise ValueError("inconsistent GCN3 shapes")
+        if self.graph.device_index != self.x.device.index:
+            raise ValueError(f"the graph lives on cuda:{self.graph.device_index}, the features on {self.x.device}")
+        h = C.c_void_p()
+        _lib.check(_lib.lib().lt_baseline3_create(self.graph.handle, self.x.data_ptr(), f, f, self.w1.data_ptr(),
+                                                  self.b1.data_ptr(), self.h1, self.w2.data_ptr(), self.b2.data_ptr(),
+                                                  self.h2, self.w3.data_ptr(), self.b3.data_ptr(), self.c, _stream(),
+                                                  C.byref(h)), "lt_baseline3_create")
+        self._h = h
+        self._finalizer = weakref.finalize(self, _lib.lib().lt_baseline3_destroy, h)
+        self._ws = {}
+
+    def refresh(self):
+        _lib.check(_lib.lib().lt_baseline3_refresh(self._h, _stream()), "lt_baseline3_refresh")
+
+    def logits(self) -> torch.Tensor:
+        out = torch.empty((self.n, self.c), dtype=torch.float32, device=self.x.device)
+        _lib.check(_lib.lib().lt_baseline3_logits(self._h, out.data_ptr(), _stream()), "lt_baseline3_logits")
+        return out
+
+    def influence_rows(self, probe_nodes, observe_nodes, delta: float, mode="sparse", out=None) -> torch.Tensor:
+        if mode not in ("sparse", "full", None):
+            raise NotImplementedError("the 3-layer probe primitive evaluates the fp32 finite difference ('sparse'); "
+                                      "there is no 'delta' propagation for GCN3")
+        dev = self.x.device
+        probes = _as_nodes(probe_nodes, self.n, dev, "probe_nodes")
+        obs = _as_nodes(observe_nodes, self.n, dev, "observe_nodes")
+        npb, nob = probes.numel(), obs.numel()
+        if out is None:
+            out = torch.empty((npb, nob), dtype=torch.float32, device=dev)
+        elif out.shape != (npb, nob) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float32 [n_probe, n_obs] tensor")
+        key = (npb, nob)
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = _workspace(_lib.lib().lt_influence3_workspace_bytes(self._h, npb, nob), dev)
+            self._ws = {key: ws}
+        _lib.check(_lib.lib().lt_influence3_rows(self._h, probes.data_ptr(), npb, obs.data_ptr(), nob, float(delta),
+                                                 out.data_ptr(), nob, ws.data_ptr(), ws.numel(), _stream()),
+                   "lt_influence3_rows")
+        return out
+
+
 def _as_nodes(nodes, n, device, name) -> torch.Tensor:
     if isinstance(nodes, torch.Tensor) and nodes.is_cuda and nodes.dtype == torch.int32:
         return nodes.contiguous()          # trusted fast path (already validated by the caller)

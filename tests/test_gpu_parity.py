@@ -267,11 +267,29 @@ def test_gcn3_efficient_attack_on_device(gpu, tmp_path, monkeypatch):
     atk = Attacker(args, model, w)
     atk.prepare_test_data()
     assert np.array_equal(atk.test_nodes, g["gcn3.ref32.test_nodes"])
-    infl = atk.influence_matrix()
+    assert atk._is_three_layer()
+    infl = atk.influence_matrix()                              # lt_influence3_rows: the 3-hop probe primitive
     ref64, ref32 = g["gcn3.ref64.influence_val"], g["gcn3.ref32.influence_val"]
     e32 = np.abs(ref32 - ref64).max()
+    print(f"gcn3: |ref32-ref64|={e32:.3e} |ours-ref64|={np.abs(infl - ref64).max():.3e}")
     assert np.abs(infl - ref64).max() <= 2.0 * e32            # fp32 finite difference: the reference's noise class
     assert np.all(infl[ref64 == 0] == 0)
+    # the per-probe loop over the unfused layers (what round 1 shipped) is the same noise class, and slower
+    import time
+    nodes = np.asarray(atk.test_nodes, dtype=np.int64)
+    loop = atk._rows_generic(nodes, nodes).cpu().numpy().astype(np.float64)
+    assert np.abs(loop - ref64).max() <= 2.0 * e32
+    assert np.all(loop[ref64 == 0] == 0)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(5):
+        atk._rows(nodes, nodes)
+    torch.cuda.synchronize()
+    t_prim = (time.time() - t0) / 5
+    print(f"gcn3 n_test=32: probe primitive {t_prim * 1e3:.3f} ms per matrix (baseline refresh included)")
+    assert t_prim < 5e-3
+    # the baseline logits of the primitive equal the model's forward within fp32 rounding
+    base_logits = atk.baseline3().logits().cpu().numpy().astype(np.float64)
     # logits of the 3-layer model through the unfused HIP layers
     with torch.no_grad():
         out = model(w.features_2, w.adj_2).cpu().numpy().astype(np.float64)
@@ -280,6 +298,7 @@ def test_gcn3_efficient_attack_on_device(gpu, tmp_path, monkeypatch):
           ("W2", "gc2.weight"), ("b2", "gc2.bias"), ("W3", "gc3.weight"), ("b3", "gc3.bias"))}
     ref = O.gcn3_forward(torch.from_numpy(g["x"]).double(), O.to_torch_sparse(O.first_order_gcn(a)).double(), P3).numpy()
     assert np.abs(out - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
+    assert np.abs(base_logits - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
 
 
 def _oracle_matrix(adj_hat_csr, x, w, probes, observe, delta, dtype):

@@ -347,3 +347,66 @@ def test_rmat_scale21_config5_full_size(gpu):
     with open(os.path.join(REPO, "gpurun_out", "rmat_scale21_test.txt"), "w") as fh:
         fh.write("\n".join(log) + "\n")
     print("\n".join(log))
+
+
+@pytest.mark.parametrize("h1,h2,c,hub", [(32, 16, 2, False), (100, 36, 3, True), (256, 64, 2, True), (20, 256, 8, False)])
+def test_gcn3_probe_primitive_against_oracle(gpu, h1, h2, c, hub):
+    """lt_influence3_rows on graphs with isolated nodes / a hub row (several 128-entry segments in every layer),
+    widths that need padding, 1..8 classes, duplicate probes, observe list != probe list: the fp32 finite difference
+    of the reference's 3-layer forward (oracle, fp64 and fp32), exact zeros outside the 3-hop set."""
+    import scipy.sparse as sp
+    from test_gpu_parity import _hub_graph
+    from linkteller_amd import engine, graph, synth
+    from oracle import linkteller_oracle as O
+    n, f = (700, 48) if hub else (220, 40)
+    if hub:
+        a = _hub_graph(n, 2500, 400, seed=h1)
+    else:
+        a = synth.powerlaw_graph(n, 600, seed=h1).tolil()
+        for k in (5, 17, 99):
+            a[k, :] = 0
+            a[:, k] = 0
+        a = sp.csr_matrix(a)
+        a.eliminate_zeros()
+    a_hat = graph.first_order_gcn(a)
+    x = synth.gaussian_features(n, f, seed=3)
+    rng = np.random.RandomState(h2)
+
+    def u(shape, fan):
+        s = 1.0 / np.sqrt(fan)
+        return rng.uniform(-s, s, size=shape).astype(np.float32)
+
+    P = dict(W1=u((f, h1), h1), b1=u((h1,), h1), W2=u((h1, h2), h2), b2=u((h2,), h2), W3=u((h2, c), c), b3=u((c,), c))
+    dev_p = [torch.from_numpy(P[k]).to(gpu) for k in ("W1", "b1", "W2", "b2", "W3", "b3")]
+    base = engine.Baseline3(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *dev_p)
+    probes = np.concatenate([rng.choice(n, 19, replace=False), [0, 5], [3, 3]])
+    observe = np.concatenate([rng.choice(n, 40, replace=False), [0, 99]])
+    got = base.influence_rows(probes, observe, 1e-4).cpu().numpy().astype(np.float64)
+    adj_t = O.to_torch_sparse(a_hat)
+    ref = {}
+    for dt in (torch.float64, torch.float32):
+        Pd = {k: torch.from_numpy(v).to(dt) for k, v in P.items()}
+        xt = torch.from_numpy(x).to(dt)
+        m = np.zeros((len(probes), len(observe)))
+        with torch.no_grad():
+            for i, v in enumerate(probes):
+                gm = O.get_gradient_eps_mat(xt, adj_t.to(dt), Pd, int(v), 1e-4, forward=O.gcn3_forward)
+                m[i] = gm[torch.as_tensor(observe)].norm(dim=1).numpy()
+        ref[dt] = m
+    e32 = np.abs(ref[torch.float32] - ref[torch.float64]).max()
+    scale = ref[torch.float64].max()
+    print(f"gcn3 h1={h1} h2={h2} c={c} hub={hub}: max {scale:.3g} |ref32-ref64| {e32:.2e} |ours-ref64| {np.abs(got - ref[torch.float64]).max():.2e}")
+    assert np.abs(got - ref[torch.float64]).max() <= 2.0 * e32 + 1e-4 * scale
+    assert np.all(got[ref[torch.float64] == 0] == 0)
+    assert np.array_equal(got[-1], got[-2])                         # duplicate probe -> identical rows
+    logits = base.logits().cpu().numpy().astype(np.float64)
+    ref_logits = O.gcn3_forward(torch.from_numpy(x).double(), adj_t.double(), {k: torch.from_numpy(v).double() for k, v in P.items()}).numpy()
+    assert np.abs(logits - ref_logits).max() <= 2e-5 * max(1.0, np.abs(ref_logits).max())
+    # a tiny chunk budget splits the probe list: same bits
+    from linkteller_amd import _lib
+    _lib.set_tuning("chunk_budget_bytes", 64 * 1024)
+    try:
+        base2 = engine.Baseline3(base.graph, base.x, *dev_p)
+        assert np.array_equal(base2.influence_rows(probes, observe, 1e-4).cpu().numpy().astype(np.float64), got)
+    finally:
+        _lib.set_tuning("chunk_budget_bytes", None)
