@@ -25,6 +25,16 @@ def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
+def _require_finite(**tensors):
+    """ReLU is one ``v_max_f32`` in the kernels: a NaN pre-activation becomes 0 where torch keeps NaN (DESIGN.md
+    section 3), so non-finite inputs would be hidden instead of propagated.  They are refused up front (one device
+    reduction per tensor when a baseline is created, never on the per-step path)."""
+    for name, t in tensors.items():
+        if not bool(torch.isfinite(t).all()):
+            raise ValueError(f"{name} holds non-finite values (NaN / Inf): the reference would propagate them through "
+                             f"every score; refusing rather than masking them")
+
+
 def _workspace(nbytes: int, device) -> torch.Tensor:
     # torch's caching allocator returns >= 512-byte aligned blocks
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
@@ -90,6 +100,7 @@ class Baseline:
             raise ValueError("inconsistent GCN shapes")
         if self.graph.device_index != self.x.device.index:
             raise ValueError(f"the graph lives on cuda:{self.graph.device_index}, the features on {self.x.device}")
+        _require_finite(features=self.x, W1=self.w1, b1=self.b1, W2=self.w2, b2=self.b2)
         h = C.c_void_p()
         _lib.check(_lib.lib().lt_baseline_create(self.graph.handle, self.x.data_ptr(), f, f, self.w1.data_ptr(),
                                                  self.b1.data_ptr(), self.h, self.w2.data_ptr(),
@@ -188,6 +199,7 @@ class Baseline3:
             raise ValueError("inconsistent GCN3 shapes")
         if self.graph.device_index != self.x.device.index:
             raise ValueError(f"the graph lives on cuda:{self.graph.device_index}, the features on {self.x.device}")
+        _require_finite(features=self.x, W1=self.w1, b1=self.b1, W2=self.w2, b2=self.b2, W3=self.w3, b3=self.b3)
         h = C.c_void_p()
         _lib.check(_lib.lib().lt_baseline3_create(self.graph.handle, self.x.data_ptr(), f, f, self.w1.data_ptr(),
                                                   self.b1.data_ptr(), self.h1, self.w2.data_ptr(), self.b2.data_ptr(),

@@ -59,3 +59,45 @@ def test_single_process_is_identity():
     assert lt_dist.all_gather_rows(x, 3) is x
     y, work = lt_dist.all_gather_rows(x, 3, async_op=True)
     assert y is x and work is None
+
+
+def _cli_worker(rank, ws, port, tmp, q):
+    """What `torchrun -m linkteller_amd.main` does per rank before the attack: join the group (gloo hook), then the
+    result file is written by rank 0 alone (attacker.compute_and_save)."""
+    import argparse
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(ws),
+                      LOCAL_RANK=str(rank), LT_DIST_BACKEND="gloo")
+    from linkteller_amd import main as lt_main
+    from linkteller_amd.attacker import Attacker
+    assert lt_main.init_distributed() is True
+    assert lt_main.init_distributed() is False                  # already initialised: the caller keeps ownership
+    ok = lt_dist.world() == (rank, ws)
+    os.chdir(tmp)
+    atk = Attacker.__new__(Attacker)                            # only the result writer is exercised here
+    atk.args = argparse.Namespace(mode="vanilla-clean", attack_mode="efficient", sample_type="unbalanced", n_test=4,
+                                  sample_seed=42)
+    atk.dataset = "twitch/ES/RU"
+    atk.compute_and_save([0.9, 0.8, 0.4], [0.1, 0.5, 0.0, 0.0])
+    dist.barrier()
+    q.put((rank, ok, os.path.exists(os.path.join(tmp, atk.result_filename()))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cli_ranks_join_group_and_rank0_writes(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    dirs = [str(tmp_path / f"r{r}") for r in range(2)]          # one working directory per rank: who wrote is visible
+    for d in dirs:
+        os.makedirs(d)
+    procs = [ctx.Process(target=_cli_worker, args=(r, 2, port, dirs[r], q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True, True), (1, True, False)]

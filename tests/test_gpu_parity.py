@@ -377,6 +377,11 @@ def test_empty_and_degenerate_calls(gpu):
     with pytest.raises(_lib.LinkTellerHipError):
         engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), torch.zeros(12, 16, device=gpu),
                         torch.zeros(16, device=gpu), torch.zeros(16, 9, device=gpu), torch.zeros(9, device=gpu))
+    # non-finite inputs are refused, not masked (ReLU is a v_max: NaN -> 0 would hide them; torch propagates NaN)
+    x_bad = torch.from_numpy(x).to(gpu).clone()
+    x_bad[3, 2] = float("nan")
+    with pytest.raises(ValueError, match="non-finite"):
+        engine.Baseline(graph.HipGraph(a_hat), x_bad, *[torch.from_numpy(w[k]).to(gpu) for k in ("W1", "b1", "W2", "b2")])
     # graph with no edges at all: A_hat = I, influence is purely the self term
     eye = graph.first_order_gcn(sp.csr_matrix((50, 50), dtype=np.float32))
     b2 = engine.Baseline(graph.HipGraph(eye), torch.from_numpy(x).to(gpu),
