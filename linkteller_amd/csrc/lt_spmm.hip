@@ -77,13 +77,22 @@ __global__ __launch_bounds__(LT_BLOCK) void k_rows_tiled(
     const size_t rowbytes = (size_t)lds * 4u;
     const unsigned loff = (unsigned)coff * 4u;
     const int e1 = e0 + cnt;
+    // (col, val) of the NEXT 16-entry block are requested before the gathers of the current one go out
+    int nxc = 0;
+    float nxa = 0.f;
+    if (e0 + j < e1) {
+        nxc = __builtin_nontemporal_load(col + e0 + j);
+        nxa = __builtin_nontemporal_load(val + e0 + j);
+    }
     for (int eb = e0; eb < e1; eb += GL) {
         const int me = eb + j;
-        int myc = 0;
-        float mya = 0.f;
-        if (me < e1) {
-            myc = __builtin_nontemporal_load(col + me);
-            mya = __builtin_nontemporal_load(val + me);
+        const int myc = nxc;
+        const float mya = nxa;
+        nxc = 0;
+        nxa = 0.f;
+        if (me + GL < e1) {
+            nxc = __builtin_nontemporal_load(col + me + GL);
+            nxa = __builtin_nontemporal_load(val + me + GL);
         }
         const int left = e1 - eb;
         static_for<GL / U>([&](auto kbt) {

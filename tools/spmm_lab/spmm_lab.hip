@@ -85,7 +85,7 @@ __device__ __forceinline__ void gload(f32x4 &d, unsigned off, const char *base) 
 // HINT 0: compiler-managed plain gathers.  HINT > 0: bit 31 of a column index marks a COLD column (few readers): its
 // gather uses cache policy HINT, hot columns use plain loads; all gathers are inline asm with one explicit wait.
 // SEQ: blocks walk the slices one after the other (all XCDs on one slice at a time) instead of slice = f(XCD).
-template <int GL, int U, bool NT, bool SORTED, int HINT = 0, bool SEQ = false>
+template <int GL, int U, bool NT, bool SORTED, int HINT = 0, bool SEQ = false, bool PF = false>
 __global__ __launch_bounds__(256) void k_spmm_sliced(
     int n_items, const int32_t *__restrict__ w_e0, const int32_t *__restrict__ w_cnt,
     const int32_t *__restrict__ w_dst, const int32_t *__restrict__ rowptr, int n,
@@ -122,11 +122,18 @@ __global__ __launch_bounds__(256) void k_spmm_sliced(
     const char *Sb = reinterpret_cast<const char *>(S);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int e1 = e0 + cnt;
+    int nxc = 0;
+    float nxa = 0.f;
+    if (PF && e0 + j < e1) { nxc = __builtin_nontemporal_load(col + e0 + j); nxa = __builtin_nontemporal_load(val + e0 + j); }
     for (int eb = e0; eb < e1; eb += GL) {
         const int me = eb + j;
         int myc = 0;
         float mya = 0.f;
-        if (me < e1) {
+        if (PF) {
+            myc = nxc; mya = nxa;
+            nxc = 0; nxa = 0.f;
+            if (me + GL < e1) { nxc = __builtin_nontemporal_load(col + me + GL); nxa = __builtin_nontemporal_load(val + me + GL); }
+        } else if (me < e1) {
             if (NT) { myc = __builtin_nontemporal_load(col + me); mya = __builtin_nontemporal_load(val + me); }
             else { myc = col[me]; mya = val[me]; }
         }
@@ -275,6 +282,19 @@ static Work build_work(const HostCsr &g, int H, int SEG, int ordering) {
             if (sa) return colp[a.e0] < colp[b.e0];
             return (a.cnt + 15) / 16 > (b.cnt + 15) / 16;
         });
+        if (ordering == 2) {
+            // blocks of 16 items are dealt to a slice's two XCDs alternately (chunk parity): give the even chunks the
+            // first half of the column-ordered segments and the odd chunks the second half
+            size_t nseg_items = 0;
+            while (nseg_items < items.size() && items[nseg_items].dst >= n) ++nseg_items;
+            const size_t blocks = nseg_items / 16, hb = blocks / 2;
+            std::vector<Item> re(items.begin(), items.end());
+            for (size_t bi = 0; bi < 2 * hb; ++bi) {
+                const size_t src = (bi & 1) ? hb + bi / 2 : bi / 2;
+                for (int k = 0; k < 16; ++k) re[bi * 16 + k] = items[src * 16 + k];
+            }
+            items.swap(re);
+        }
     }
     std::vector<int32_t> e0(items.size()), cnt(items.size()), dst(items.size());
     for (size_t i = 0; i < items.size(); ++i) { e0[i] = items[i].e0; cnt[i] = items[i].cnt; dst[i] = items[i].dst; }
@@ -292,12 +312,13 @@ struct Ctx {
     int32_t *colh[4];   // col with bit 31 set on cold columns, for hot sets of 8K / 12K / 16K / 24K columns
     Work work;
     Work work_col;   // segments ordered by first column
+    Work work_half;  // ... and dealt so that each of a slice's two XCDs sweeps its own half of the column range
     lt_graph *lg;
 };
 
-template <int GL, int U, bool NT, bool SORTED, int HINT = 0, bool SEQ = false, int HOTSET = 0, int ORDER = 0>
+template <int GL, int U, bool NT, bool SORTED, int HINT = 0, bool SEQ = false, int HOTSET = 0, int ORDER = 0, bool PF = false>
 static void run_sliced(Ctx &c, hipStream_t st) {
-    Work &W = ORDER ? c.work_col : c.work;
+    Work &W = ORDER == 2 ? c.work_half : (ORDER ? c.work_col : c.work);
     const int ns = c.H / (4 * GL) > 0 ? (c.H + 4 * GL - 1) / (4 * GL) : 1;
     const int xps = 8 / ns;
     constexpr int IPB = 4 * (64 / GL);
@@ -305,7 +326,7 @@ static void run_sliced(Ctx &c, hipStream_t st) {
     const int chunks = (n_items + IPB - 1) / IPB;
     const int grid = SEQ ? chunks * ns : 8 * ((chunks + xps - 1) / xps);
     const int32_t *colp = HINT ? c.colh[HOTSET] : c.col;
-    hipLaunchKernelGGL((k_spmm_sliced<GL, U, NT, SORTED, HINT, SEQ>), dim3(grid), dim3(256), 0, st, n_items, W.e0, W.cnt,
+    hipLaunchKernelGGL((k_spmm_sliced<GL, U, NT, SORTED, HINT, SEQ, PF>), dim3(grid), dim3(256), 0, st, n_items, W.e0, W.cnt,
                        W.dst, c.rowptr, c.g->n, colp, c.val, c.S, c.H, c.H, c.out, c.H, W.partial, c.H, ns);
     if (SORTED && W.n_long > 0) {
         const int tot = W.n_long * c.H;
@@ -349,7 +370,8 @@ int main(int argc, char **argv) {
     CK(hipMalloc((void **)&c.out, (size_t)g.n * H * sizeof(float)));
     CK(hipMalloc((void **)&c.ref, (size_t)g.n * H * sizeof(float)));
     c.work = build_work(g, H, 128, 0);
-    c.work_col = build_work(g, H, 128, 1);   // the library's canonical order: 128-entry segments added in order (lt_rows.cuh row_dot)
+    c.work_col = build_work(g, H, 128, 1);
+    c.work_half = build_work(g, H, 128, 2);   // the library's canonical order: 128-entry segments added in order (lt_rows.cuh row_dot)
     {
         // hot sets by in-degree (= row length: the matrix is symmetric)
         std::vector<int> deg((size_t)g.n);
@@ -380,15 +402,13 @@ int main(int argc, char **argv) {
 
     std::vector<Variant> vs = {
         {"lib", run_lib},
-        {"g16", run_sliced<16, 8, true, true>},
-        {"g64", run_sliced<64, 8, true, true>},
         {"g16_col", run_sliced<16, 8, true, true, 0, false, 0, 1>},
-        {"g16_col_u4", run_sliced<16, 4, true, true, 0, false, 0, 1>},
-        {"g8_col", run_sliced<8, 8, true, true, 0, false, 0, 1>},
+        {"g16_col_pf", run_sliced<16, 8, true, true, 0, false, 0, 1, true>},
+        {"g16_half", run_sliced<16, 8, true, true, 0, false, 0, 2>},
+        {"g16_half_pf", run_sliced<16, 8, true, true, 0, false, 0, 2, true>},
         {"g32_col", run_sliced<32, 8, true, true, 0, false, 0, 1>},
-        {"g64_col", run_sliced<64, 8, true, true, 0, false, 0, 1>},
-        {"g16_col_seq", run_sliced<16, 8, true, true, 0, true, 0, 1>},
-        {"g16_col_nt12k", run_sliced<16, 8, true, true, 1, false, 1, 1>},
+        {"g32_col_pf", run_sliced<32, 8, true, true, 0, false, 0, 1, true>},
+        {"g16_col_u4_pf", run_sliced<16, 4, true, true, 0, false, 0, 1, true>},
     };
     hipStream_t st;
     CK(hipStreamCreate(&st));
