@@ -630,7 +630,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
     const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
     const float *__restrict__ Sp, float delta, float *__restrict__ S2x, int n_long,
     const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_segptr,
-    const float *__restrict__ seg_part) {
+    const float *__restrict__ seg_part, const int2 *__restrict__ item_pr) {
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int gl = lane & (LPR - 1);
@@ -646,10 +646,11 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
 #pragma unroll
         for (int c = 0; c < CP; ++c) part[c] = 0.f;
         if (live) {
-            const int b = find_probe(off, nb, item);
+            // (probe index, row) of the item: written by k_item_bits (one load instead of a search in `off`)
+            const int2 pr = item_pr[item];
+            const int b = pr.x, r = pr.y;
             const int v = probes[b];
             const int t = tptr[v] + (item - off[b]);
-            const int r = trow[t];
             if (active) {
                 const f32x4 b1v = ld4(b1p + coff);
                 if (DELTA) {
@@ -947,6 +948,7 @@ struct infl_ws {
     float *slabs;          // FULL / SPARSE: split-K partials of the perturbed-row GEMM
     float *S2x;            // SPARSE / DELTA: per-item values
     int32_t *off;          // SPARSE / DELTA: item offsets [chunk + 1]
+    int2 *item_pr;         // SPARSE / DELTA: (probe index, row) of every item
     uint2 *bits;           // SPARSE / DELTA: membership bitmap + positions of R_v per probe [chunk][ceil(n / 32)], or NULL (huge graphs)
     size_t bytes;
     int chunk;
@@ -960,8 +962,8 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
     const size_t splitk = ((F + probe_kslice(b) - 1) / probe_kslice(b)) * (size_t)b->H;
     const size_t nseg = long_rows_parallel(b->g, b->Hp) ? (size_t)b->g->p_n_seg : 0;
     if (mode == LT_MODE_FULL) per_probe = (n * C + Hp + splitk) * sizeof(float) + nseg * Hp * sizeof(float) * 9 / 8;
-    else if (mode == LT_MODE_SPARSE) per_probe = (maxc * C + Hp + splitk) * sizeof(float) + sizeof(int32_t);
-    else per_probe = maxc * C * sizeof(float) + sizeof(int32_t);
+    else if (mode == LT_MODE_SPARSE) per_probe = (maxc * C + Hp + splitk) * sizeof(float) + sizeof(int32_t) + maxc * sizeof(int2);
+    else per_probe = maxc * C * sizeof(float) + sizeof(int32_t) + maxc * sizeof(int2);
     size_t chunk = chunk_budget() / (per_probe ? per_probe : 1);
     if (chunk < 1) chunk = 1;
     if (chunk > 65534) chunk = 65534;  // grid.y (FULL, narrow kernel: probes + 1)
@@ -986,6 +988,7 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
     if (mode != LT_MODE_FULL) {
         w.S2x = (float *)take(chunk * maxc * C * sizeof(float));
         w.off = (int32_t *)take((chunk + 1) * sizeof(int32_t));
+        w.item_pr = (int2 *)take(chunk * maxc * sizeof(int2));
         const size_t bw = (n + 31) / 32;
         // ("item_bits" = 0 forces the search path a huge graph takes: tests)
         const bool no_bits = lt_tune().item_bits == 0;
@@ -1139,10 +1142,8 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
             hipLaunchKernelGGL(k_probe_offsets, dim3(1), dim3(1024), 0, st, g->tptr, probes, nb, w.off);
             LT_CHECK_LAUNCH();
             const int words = (n + 31) / 32;
-            if (w.bits) {
-                hipLaunchKernelGGL(k_item_bits, dim3(nb), dim3(256), 0, st, g->tptr, g->trow, probes, words, w.bits);
-                LT_CHECK_LAUNCH();
-            }
+            hipLaunchKernelGGL(k_item_bits, dim3(nb), dim3(256), 0, st, g->tptr, g->trow, probes, words, w.bits, w.off, w.item_pr);
+            LT_CHECK_LAUNCH();
             if (mode == LT_MODE_SPARSE) {
                 { lt_prof_scope prof_(LT_K_ITEM_A, st);
                 LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
@@ -1150,7 +1151,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, g->tptr,
                                        g->trow, g->tval, b->S1, b->Z1, b->Z1d, Hp, b->b1p, b->W2p, C, probes, nb,
                                        w.off, w.Sp, delta, w.S2x, g->p_n_long, g->p_long_row, g->p_long_segptr,
-                                       b->seg_part))); }
+                                       b->seg_part, w.item_pr))); }
                 LT_CHECK_LAUNCH();
                 lt_prof_scope prof_(LT_K_ITEM_B, st);
                 LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, false>), dim3(gridB),
@@ -1174,14 +1175,14 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                            st, g->rowptr, g->col, g->val, g->tptr, g->trow, g->tval, b->S1,
                                            b->Z1, b->Z1d, Hp, b->b1p, b->W2p, C, probes, nb, w.off,
                                            (const float *)nullptr, delta, w.S2x, 0, (const int32_t *)nullptr,
-                                           (const int32_t *)nullptr, (const float *)nullptr)));
+                                           (const int32_t *)nullptr, (const float *)nullptr, w.item_pr)));
                 } else {
                     LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
                         hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, 1>), dim3(LT_ITEM_GRID), dim3(LT_BLOCK), 0,
                                            st, g->rowptr, g->col, g->val, g->tptr, g->trow, g->tval, b->S1,
                                            b->Z1, b->Z1d, Hp, b->b1p, b->W2p, C, probes, nb, w.off,
                                            (const float *)nullptr, delta, w.S2x, 0, (const int32_t *)nullptr,
-                                           (const int32_t *)nullptr, (const float *)nullptr)));
+                                           (const int32_t *)nullptr, (const float *)nullptr, w.item_pr)));
                 } }
                 LT_CHECK_LAUNCH();
                 lt_prof_scope prof_(LT_K_ITEM_B, st);

@@ -62,16 +62,25 @@ __device__ __forceinline__ int find_row(const int32_t *__restrict__ rows, int cn
 // (without the bitmap -- huge graphs -- both questions are a binary search in R_v).  One block per probe.
 static __global__ __launch_bounds__(256) void k_item_bits(const int32_t *__restrict__ tptr, const int32_t *__restrict__ trow,
                                                    const int32_t *__restrict__ probes, int words,
-                                                   uint2 *__restrict__ bits) {
-    uint2 *mine = bits + (size_t)blockIdx.x * words;
-    for (int i = threadIdx.x; i < words; i += blockDim.x) mine[i] = make_uint2(0u, 0xffffffffu);
-    __syncthreads();
+                                                   uint2 *__restrict__ bits, const int32_t *__restrict__ off,
+                                                   int2 *__restrict__ item_pr) {
+    // bits == NULL: only the (probe, row) table of the items is written (huge graphs have no bitmap)
+    uint2 *mine = bits ? bits + (size_t)blockIdx.x * words : nullptr;
+    if (mine) {
+        for (int i = threadIdx.x; i < words; i += blockDim.x) mine[i] = make_uint2(0u, 0xffffffffu);
+        __syncthreads();
+    }
     const int v = probes[blockIdx.x];
     const int t0 = tptr[v];
+    int2 *items = item_pr ? item_pr + off[blockIdx.x] : nullptr;
     for (int t = t0 + threadIdx.x; t < tptr[v + 1]; t += blockDim.x) {
         const int r = trow[t];
-        atomicOr(&mine[r >> 5].x, 1u << (r & 31));
-        atomicMin(&mine[r >> 5].y, (unsigned)(t - t0));
+        if (mine) {
+            atomicOr(&mine[r >> 5].x, 1u << (r & 31));
+            atomicMin(&mine[r >> 5].y, (unsigned)(t - t0));
+        }
+        // item (off[b] + position in R_v) = (probe index, row): stage A reads it instead of searching `off`
+        if (items) items[t - t0] = make_int2((int)blockIdx.x, r);
     }
 }
 // position of column c in R_v from the probe's bitmap row, or -1
