@@ -342,6 +342,8 @@ static void run_lib(Ctx &c, hipStream_t st) {
     }
 }
 
+static void run_lib_rows(Ctx &c, hipStream_t st) { lt_set_tuning("tiled_min_bytes", 1LL << 60); run_lib(c, st); lt_set_tuning("tiled_min_bytes", LT_TUNING_DEFAULT); }
+static void run_lib_tiled(Ctx &c, hipStream_t st) { lt_set_tuning("tiled_min_bytes", 0); run_lib(c, st); lt_set_tuning("tiled_min_bytes", LT_TUNING_DEFAULT); }
 struct Variant { const char *name; void (*fn)(Ctx &, hipStream_t); };
 
 int main(int argc, char **argv) {
@@ -402,6 +404,8 @@ int main(int argc, char **argv) {
 
     std::vector<Variant> vs = {
         {"lib", run_lib},
+        {"lib_rows", run_lib_rows},
+        {"lib_tiled", run_lib_tiled},
         {"g16_col", run_sliced<16, 8, true, true, 0, false, 0, 1>},
         {"g16_col_pf", run_sliced<16, 8, true, true, 0, false, 0, 1, true>},
         {"g16_half", run_sliced<16, 8, true, true, 0, false, 0, 2>},
