@@ -90,7 +90,15 @@ __global__ __launch_bounds__(LT_BLOCK) void k_layer1_long(
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     if (active) {
         z = *reinterpret_cast<const f32x4 *>(part + (size_t)s0 * Hp + coff);
-        for (int s = s0 + 1; s < s1; ++s) {
+        int s = s0 + 1;
+        for (; s + 8 <= s1; s += 8) {   // 8 segment sums in flight (a hub has hundreds), added in segment order
+            f32x4 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const f32x4 *>(part + (size_t)(s + k) * Hp + coff);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { z.x += t[k].x; z.y += t[k].y; z.z += t[k].z; z.w += t[k].w; }
+        }
+        for (; s < s1; ++s) {
             const f32x4 t = *reinterpret_cast<const f32x4 *>(part + (size_t)s * Hp + coff);
             z.x += t.x; z.y += t.y; z.z += t.z; z.w += t.w;
         }

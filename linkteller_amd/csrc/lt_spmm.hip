@@ -229,8 +229,18 @@ __global__ void k_spmm_long_combine(int n_long, const int32_t *__restrict__ long
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)n_long * ncols) return;
     const int li = (int)(i / ncols), c = (int)(i % ncols);
-    float acc = partial[(size_t)long_segptr[li] * ldp + c];
-    for (int sg = long_segptr[li] + 1; sg < long_segptr[li + 1]; ++sg) acc += partial[(size_t)sg * ldp + c];
+    // the biggest hub has hundreds of segments: 16 loads in flight, adds in segment order
+    const int s0 = long_segptr[li], s1 = long_segptr[li + 1];
+    float acc = partial[(size_t)s0 * ldp + c];
+    int sg = s0 + 1;
+    for (; sg + 16 <= s1; sg += 16) {
+        float t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t[k] = __builtin_nontemporal_load(partial + (size_t)(sg + k) * ldp + c);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += t[k];
+    }
+    for (; sg < s1; ++sg) acc += partial[(size_t)sg * ldp + c];
     if (bias) acc += bias[c];
     if (relu) acc = fmaxf(acc, 0.f);
     out[(size_t)long_row[li] * ldo + c] = acc;

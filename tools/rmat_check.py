@@ -16,12 +16,19 @@ t0 = time.time()
 base = engine.Baseline(graph.HipGraph(a_hat), x, *[torch.from_numpy(w[k]).cuda() for k in ("W1", "b1", "W2", "b2")])
 torch.cuda.synchronize(); print('baseline create', round(time.time() - t0, 3), 's')
 np.random.seed(42)
-nodes = np.random.choice(np.arange(n), n_test, replace=False)
+n_obs = int(sys.argv[4]) if len(sys.argv) > 4 else n_test      # observed nodes (BASELINE configs[4]: 4096, probes sharded 512 per GPU)
+obs = np.random.choice(np.arange(n), n_obs, replace=False)
+nodes = obs[:n_test] if n_test <= n_obs else np.random.choice(np.arange(n), n_test, replace=False)
 res = {}
 for m in modes:
-    base.influence_rows(nodes, nodes, 1e-4, m); torch.cuda.synchronize()
-    t0 = time.time(); res[m] = base.influence_rows(nodes, nodes, 1e-4, m); torch.cuda.synchronize()
-    print(m, round((time.time() - t0) * 1e3, 3), 'ms')
+    base.influence_rows(nodes, obs, 1e-4, m); torch.cuda.synchronize()
+    t0 = time.time(); res[m] = base.influence_rows(nodes, obs, 1e-4, m); torch.cuda.synchronize()
+    print(m, f'{len(nodes)} probes x {len(obs)} observed:', round((time.time() - t0) * 1e3, 3), 'ms')
+for m in modes:
+    if m == 'full':
+        continue
+    t0 = time.time(); base.refresh(); base.influence_rows(nodes, obs, 1e-4, m); torch.cuda.synchronize()
+    print(m, 'incl. baseline refresh (X*W1 + layers):', round((time.time() - t0) * 1e3, 3), 'ms')
 if 'full' in res and 'sparse' in res:
     print('full == sparse:', bool(torch.equal(res['full'], res['sparse'])))
 if 'sparse' in res and 'delta' in res:
