@@ -410,3 +410,23 @@ def test_gcn3_probe_primitive_against_oracle(gpu, h1, h2, c, hub):
         assert np.array_equal(base2.influence_rows(probes, observe, 1e-4).cpu().numpy().astype(np.float64), got)
     finally:
         _lib.set_tuning("chunk_budget_bytes", None)
+
+
+@pytest.mark.parametrize("seed,tiled", [(0, False), (1, True)])
+def test_randomised_cross_check(gpu, seed, tiled, monkeypatch):
+    """tools/fuzz_gpu.py inside the suite: 20 random (graph family, width, classes, normaliser, probe / observe list)
+    combinations per seed -- full == sparse bit for bit, delta within 1e-5 of the fp64 oracle, exact zeros, logits;
+    once on the default routes, once with the tiled SpMM / layer-1 route forced on every graph."""
+    import importlib.util
+    from linkteller_amd import _lib
+    spec = importlib.util.spec_from_file_location("fuzz_gpu", os.path.join(REPO, "tools", "fuzz_gpu.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    monkeypatch.chdir(REPO)
+    spec.loader.exec_module(fuzz)
+    monkeypatch.setattr(sys, "argv", ["fuzz_gpu.py", "20", str(seed)])
+    if tiled:
+        _lib.set_tuning("tiled_min_bytes", 0)
+    try:
+        fuzz.main()
+    finally:
+        _lib.set_tuning("tiled_min_bytes", None)
