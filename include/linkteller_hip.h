@@ -111,8 +111,9 @@ int lt_gcn2_forward(const lt_graph *g, const float *X, int64_t ldx, int32_t F,
 /* ---- baseline state for the probe loop --------------------------------------------------
  * The reference recomputes model(features, adj) for every probe (attacker.py:106); it is
  * loop-invariant, so it is computed once here: S1 = X*W1, Z1 = A_hat*S1 + b1,
- * S2 = relu(Z1)*W2, OUT = A_hat*S2 + b2.  Owns those four device buffers; borrows
- * X, W1, b1, W2, b2 (needed again by LT_MODE_FULL for the perturbed row X'[v]*W1). */
+ * S2 = relu(Z1)*W2, OUT = A_hat*S2 + b2 -- lazily, by the first call that reads them (see lt_baseline_refresh).
+ * Owns those four device buffers, the scratch of its hub rows and the side stream / events lt_influence_rows forks
+ * hub-row work onto; borrows X, W1, b1, W2, b2 (needed again for the perturbed rows X'[v]*W1). */
 int lt_baseline_create(const lt_graph *g, const float *X, int64_t ldx, int32_t F,
                        const float *W1, const float *b1, int32_t H,
                        const float *W2, const float *b2, int32_t C,
@@ -122,11 +123,12 @@ int lt_baseline_create(const lt_graph *g, const float *X, int64_t ldx, int32_t F
  * test on it, which is what brings it within 1e-6 of an fp64 run of the reference; without it the
  * delta mode still works but entries that cross a kink carry ~1e-4 relative error. */
 int lt_baseline_enable_fp64(lt_baseline *b, void *stream);
-/* Re-reads X and the weights (same pointers; e.g. once per benchmark step): S1 = X*W1 is recomputed on
- * `stream` now; Z1 / S2 / OUT (and the fp64 Z1) are marked stale and recomputed by the first call that reads
- * them -- lt_baseline_logits, LT_MODE_SPARSE / LT_MODE_DELTA rows -- on THAT call's stream, so a caller that
- * uses several streams orders them itself.  LT_MODE_FULL rows never need them: their stage A yields the
- * unperturbed layer as a by-product and stage B forms the baseline logits of the observed nodes itself. */
+/* The borrowed inputs (X, weights; same pointers) changed, e.g. once per benchmark step.  Launches nothing: everything
+ * derived from them is marked stale and recomputed by the first call that reads it, on THAT call's stream (a caller that
+ * uses several streams orders them itself) -- S1 = X*W1 by LT_MODE_FULL / LT_MODE_SPARSE rows and lt_baseline_logits;
+ * Z1 / S2 / OUT by SPARSE rows and lt_baseline_logits (FULL rows never need them: their stage A yields the unperturbed
+ * layer as a by-product and stage B forms the baseline logits of the observed nodes itself); the fp64 pre-activation by
+ * LT_MODE_DELTA rows, which then read nothing fp32 of the baseline (the probe's S1 row comes off the fp64 product). */
 int lt_baseline_refresh(lt_baseline *b, void *stream);
 /* Multi-GPU: the loop-invariant X*W1 sharded over ranks instead of replicated.
  * lt_baseline_attach_s1: the baseline reads S1 = X*W1 from caller-owned storage from now on ([>= n, Hp] fp32 with

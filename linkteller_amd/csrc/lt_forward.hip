@@ -436,14 +436,37 @@ static int refresh_padding(lt_baseline *b, hipStream_t st) {
     return LT_OK;
 }
 
+// The borrowed inputs changed: everything derived from them is stale and is recomputed by the first call that reads it,
+// on THAT call's stream -- S1 = X*W1 by FULL / SPARSE rows and the logits, the fp32 layers by SPARSE rows and the logits,
+// the fp64 pre-activation (and nothing in fp32) by DELTA rows.  Launches nothing.
 extern "C" int lt_baseline_refresh(lt_baseline *b, void *stream) {
     LT_REQUIRE(b != nullptr, "lt_baseline_refresh: baseline is NULL");
-    hipStream_t st = (hipStream_t)stream;
-    if (b->n == 0) return LT_OK;
+    (void)stream;
+    b->s1_fresh = false;
+    b->pad_fresh = false;
     b->layers_fresh = false;
     b->fp64_fresh = false;
-    return prepare_layer_inputs(b->n, b->X, b->ldx, b->F, b->W1, b->b1, b->H, b->W2, b->C, b->S1,
-                                b->b1p_buf, b->W2p_buf, &b->b1p, &b->W2p, b->slabs, st);
+    return LT_OK;
+}
+
+int lt_baseline_ensure_padding(const lt_baseline *cb, hipStream_t st) {
+    lt_baseline *b = const_cast<lt_baseline *>(cb);   // cache state only
+    if (b->pad_fresh) return LT_OK;
+    const int rc = refresh_padding(b, st);
+    if (rc) return rc;
+    b->pad_fresh = true;
+    return LT_OK;
+}
+
+int lt_baseline_ensure_s1(const lt_baseline *cb, hipStream_t st) {
+    lt_baseline *b = const_cast<lt_baseline *>(cb);   // cache state only
+    if (b->s1_fresh || b->n == 0) return LT_OK;
+    const int rc = prepare_layer_inputs(b->n, b->X, b->ldx, b->F, b->W1, b->b1, b->H, b->W2, b->C, b->S1,
+                                        b->b1p_buf, b->W2p_buf, &b->b1p, &b->W2p, b->slabs, st);
+    if (rc) return rc;
+    b->s1_fresh = true;
+    b->pad_fresh = true;
+    return LT_OK;
 }
 
 // Rows [row_begin, row_end) of X*W1 into dst[(row_end - row_begin), Hp] -- the sharded baseline of a multi-GPU run:
@@ -461,6 +484,8 @@ extern "C" int lt_baseline_refresh_rows(lt_baseline *b, int32_t row_begin, int32
     // b1 / W2 padding follows the weights exactly as in lt_baseline_refresh; the rest of S1 is the caller's all-gather
     const int rcp = refresh_padding(b, st);
     if (rcp) return rcp;
+    b->pad_fresh = true;
+    b->s1_fresh = true;      // this rank's rows now, the others by the caller's all-gather
     const int m = row_end - row_begin;
     if (m == 0) return LT_OK;
     if (b->Hp != b->H) LT_HIP(hipMemsetAsync(dst, 0, (size_t)m * b->Hp * sizeof(float), st));
@@ -478,6 +503,8 @@ extern "C" int lt_baseline_attach_s1(lt_baseline *b, float *S1, int64_t ld, void
     LT_REQUIRE(ld == b->Hp, "lt_baseline_attach_s1: ld=%lld, must equal the padded hidden width %d", (long long)ld, b->Hp);
     LT_REQUIRE(((uintptr_t)S1 % 16) == 0, "lt_baseline_attach_s1: storage must be 16-byte aligned");
     if (S1 == b->S1) return LT_OK;
+    const int rce = lt_baseline_ensure_s1(b, (hipStream_t)stream);
+    if (rce) return rce;
     if (b->n > 0)
         LT_HIP(hipMemcpyAsync(S1, b->S1, (size_t)b->n * b->Hp * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (b->S1_owned) {
@@ -490,18 +517,24 @@ extern "C" int lt_baseline_attach_s1(lt_baseline *b, float *S1, int64_t ld, void
 }
 
 // Z1 / S2 / OUT (and the fp64 pre-activation when enabled and asked for) from the current S1, if stale
-int lt_baseline_ensure_layers(const lt_baseline *cb, bool need_fp64, hipStream_t st) {
+int lt_baseline_ensure_layers(const lt_baseline *cb, bool need_fp64, hipStream_t st, bool need_fp32) {
     lt_baseline *b = const_cast<lt_baseline *>(cb);   // cache state only: logically const for the caller
     if (b->n == 0) return LT_OK;
-    if (!b->layers_fresh) {
-        int rc = lt_launch_layer1(b->g, b->S1, b->Hp, b->b1p, b->W2p, b->C, b->Z1, b->S2, st, b->seg_part);
+    int rc = lt_baseline_ensure_padding(b, st);
+    if (rc) return rc;
+    if (need_fp32) {
+        rc = lt_baseline_ensure_s1(b, st);
         if (rc) return rc;
-        rc = lt_launch_layer2(b->g, b->S2, b->C, b->b2, b->OUT, st);
-        if (rc) return rc;
-        b->layers_fresh = true;
+        if (!b->layers_fresh) {
+            rc = lt_launch_layer1(b->g, b->S1, b->Hp, b->b1p, b->W2p, b->C, b->Z1, b->S2, st, b->seg_part);
+            if (rc) return rc;
+            rc = lt_launch_layer2(b->g, b->S2, b->C, b->b2, b->OUT, st);
+            if (rc) return rc;
+            b->layers_fresh = true;
+        }
     }
     if (need_fp64 && b->Z1d && !b->fp64_fresh) {
-        const int rc = lt_baseline_refresh_fp64(b, st);
+        rc = lt_baseline_refresh_fp64(b, st);
         if (rc) return rc;
         b->fp64_fresh = true;
     }

@@ -251,7 +251,9 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
         return lt_set_error(LT_ERR_HIP, "lt_baseline_enable_fp64: hipMalloc failed: %s", hipGetErrorString(e));
     }
     b->S1d = s1d; b->Z1d = z1d; b->slabs_d = slabs; b->seg_d = segd;
-    const int rc = compute_z1d(b, (hipStream_t)stream);
+    int rc = lt_baseline_ensure_padding(b, (hipStream_t)stream);   // (the padded bias the fp64 SpMM adds)
+    if (rc) return rc;
+    rc = compute_z1d(b, (hipStream_t)stream);
     b->fp64_fresh = rc == LT_OK;
     return rc;
 }

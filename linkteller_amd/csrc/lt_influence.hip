@@ -625,7 +625,8 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const int32_t *__restrict__ tptr,
     const int32_t *__restrict__ trow, const float *__restrict__ tval,
-    const float *__restrict__ S1, const float *__restrict__ Z1, const double *__restrict__ Z1d, int Hp,
+    const float *__restrict__ S1, const float *__restrict__ Z1, const double *__restrict__ Z1d,
+    const double *__restrict__ S1d, int Hp,
     const float *__restrict__ b1p, const float *__restrict__ W2p, int C,
     const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
     const float *__restrict__ Sp, float delta, float *__restrict__ S2x, int n_long,
@@ -655,7 +656,13 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
                 const f32x4 b1v = ld4(b1p + coff);
                 if (DELTA) {
                     const float arv = tval[t];
-                    const f32x4 s = ld4(S1 + (size_t)v * Hp + coff);
+                    f32x4 s;
+                    if (DELTA == 2) {   // the probe's S1 row off the fp64 product (the fp32 one is not even computed for this mode)
+                        const double *sp = S1d + (size_t)v * Hp + coff;
+                        s = f32x4{(float)sp[0], (float)sp[1], (float)sp[2], (float)sp[3]};
+                    } else {
+                        s = ld4(S1 + (size_t)v * Hp + coff);
+                    }
                     float dh[4];
                     if (DELTA == 2) {
                         // kink test on the fp64-accumulated pre-activation (see lt_fp64.hip)
@@ -1027,8 +1034,16 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
     const int lpr = lt_lpr_for(b->Hp), cp = lt_cp_for(b->C), C = b->C, Hp = b->Hp, n = b->n;
     // SPARSE / DELTA read the baseline activations (Z1, S2, OUT; DELTA the fp64 Z1 when enabled); FULL forms
     // what it needs of them itself
-    if (mode != LT_MODE_FULL) {
-        const int rc = lt_baseline_ensure_layers(b, mode == LT_MODE_DELTA, st);
+    // what the mode reads of the baseline (recomputed here if lt_baseline_refresh marked it stale): FULL the product
+    // S1 = X*W1 only (its stage A yields the unperturbed layer itself); SPARSE S1 and the fp32 layers; DELTA with the
+    // fp64 pre-activation enabled nothing in fp32 at all -- the probe's own S1 row is read off the fp64 product --
+    // and without it S1 and the fp32 layers
+    const bool delta64 = mode == LT_MODE_DELTA && b->Z1d != nullptr;
+    {
+        int rc = lt_baseline_ensure_padding(b, st);
+        if (rc) return rc;
+        if (mode == LT_MODE_FULL) rc = lt_baseline_ensure_s1(b, st);
+        else rc = lt_baseline_ensure_layers(b, mode == LT_MODE_DELTA, st, !delta64);
         if (rc) return rc;
     }
 
@@ -1149,7 +1164,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                 LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
                     hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, 0>), dim3(LT_ITEM_GRID),
                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, g->tptr,
-                                       g->trow, g->tval, b->S1, b->Z1, b->Z1d, Hp, b->b1p, b->W2p, C, probes, nb,
+                                       g->trow, g->tval, b->S1, b->Z1, b->Z1d, b->S1d, Hp, b->b1p, b->W2p, C, probes, nb,
                                        w.off, w.Sp, delta, w.S2x, g->p_n_long, g->p_long_row, g->p_long_segptr,
                                        b->seg_part, w.item_pr))); }
                 LT_CHECK_LAUNCH();
@@ -1173,14 +1188,14 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                     LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
                         hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, 2>), dim3(LT_ITEM_GRID), dim3(LT_BLOCK), 0,
                                            st, g->rowptr, g->col, g->val, g->tptr, g->trow, g->tval, b->S1,
-                                           b->Z1, b->Z1d, Hp, b->b1p, b->W2p, C, probes, nb, w.off,
+                                           b->Z1, b->Z1d, b->S1d, Hp, b->b1p, b->W2p, C, probes, nb, w.off,
                                            (const float *)nullptr, delta, w.S2x, 0, (const int32_t *)nullptr,
                                            (const int32_t *)nullptr, (const float *)nullptr, w.item_pr)));
                 } else {
                     LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
                         hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, 1>), dim3(LT_ITEM_GRID), dim3(LT_BLOCK), 0,
                                            st, g->rowptr, g->col, g->val, g->tptr, g->trow, g->tval, b->S1,
-                                           b->Z1, b->Z1d, Hp, b->b1p, b->W2p, C, probes, nb, w.off,
+                                           b->Z1, b->Z1d, b->S1d, Hp, b->b1p, b->W2p, C, probes, nb, w.off,
                                            (const float *)nullptr, delta, w.S2x, 0, (const int32_t *)nullptr,
                                            (const int32_t *)nullptr, (const float *)nullptr, w.item_pr)));
                 } }

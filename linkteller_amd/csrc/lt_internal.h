@@ -74,6 +74,8 @@ struct lt_baseline {
     // lt_baseline_refresh recomputes S1 and marks what depends on it stale; Z1 / S2 / OUT (and Z1d) are
     // recomputed by the first call that reads them (logits, SPARSE / DELTA rows) -- FULL rows never do: their
     // stage A yields the baseline S2 as a by-product and stage B forms the baseline logits itself.
+    mutable bool s1_fresh = false;      // S1 matches the borrowed inputs
+    mutable bool pad_fresh = false;     // b1p / W2p match the borrowed weights
     mutable bool layers_fresh = false;
     mutable bool fp64_fresh = false;
     // FULL rows on a graph with hub rows: the segment kernel + combine run on `side` next to the plain-row
@@ -133,7 +135,11 @@ struct lt_prof_scope {
 };
 
 int lt_baseline_refresh_fp64(lt_baseline *b, hipStream_t st);
-int lt_baseline_ensure_layers(const lt_baseline *b, bool need_fp64, hipStream_t st);
+// what a call needs of the baseline, recomputed here if lt_baseline_refresh marked it stale: need_fp32 = S1 and the
+// fp32 layers Z1 / S2 / OUT, need_fp64 = the fp64 pre-activation (when enabled); b1p / W2p always
+int lt_baseline_ensure_layers(const lt_baseline *b, bool need_fp64, hipStream_t st, bool need_fp32 = true);
+int lt_baseline_ensure_s1(const lt_baseline *b, hipStream_t st);
+int lt_baseline_ensure_padding(const lt_baseline *b, hipStream_t st);
 void lt_baseline_free_fp64(lt_baseline *b);
 
 // ---- launchers implemented in the kernel translation units --------------------------------
