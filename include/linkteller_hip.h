@@ -69,6 +69,7 @@ int lt_device_count(int *count);
  *   "overlap"             hub-row kernels on the baseline's side stream (1) or on the caller's (0)
  *   "item_bits"           SPARSE / DELTA stage B membership bitmap on (1) / off (0)
  *   "wide_min_hp"         smallest padded hidden width served by the batched stage-A kernel
+ *   "tiled_big"           1 = the tiled SpMM uses its 64-bit gather offsets on any graph (test hook; default: S >= 4 GiB)
  *   "probe_kslice"        K-slice of the perturbed-row GEMM; 0 = the slicing of the baseline X*W1 (default: S1'[v] and
  *                         S1[v] then share one summation order, like the reference's two torch.mm calls)
  * value = LT_TUNING_DEFAULT restores the default. */

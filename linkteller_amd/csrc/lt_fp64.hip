@@ -9,6 +9,8 @@
 //     an ordered slab sum;
 //   * Z1d = A_hat*S1d + b1, row-owned fp64 fma chains.
 // One-off cost per baseline (not per probe); only built when delta mode is used.
+#include <stdlib.h>
+
 #include <new>
 
 #include "lt_rows.cuh"
@@ -190,11 +192,29 @@ __global__ void k_spmm_f64_long(int n_long, const int32_t *__restrict__ long_row
     out[(size_t)long_row[li] * ld + c] = acc + (double)b1p[c];
 }
 
+// K slice of the fp64 product (64x64 tiles, 4 waves, 8 workgroups per CU): the fewest slices (at least 400 deep) whose
+// workgroups still occupy every CU, and never more workgroups than are resident at once (256 CUs x 8) -- a ninth per CU
+// runs alone after the others (twitch-RU: 8 slices = 2208 workgroups, 134 us; 7 slices = 1932, all resident).
+// LT_F64_KSLICE overrides (experiments).
+static int fp64_kslice(int n, int H, int F) {
+    static const long long forced = getenv("LT_F64_KSLICE") ? atoll(getenv("LT_F64_KSLICE")) : 0;
+    if (forced > 0) return (int)((forced + 15) / 16 * 16);
+    const long tiles = (long)((n + GD_BM - 1) / GD_BM) * ((H + GD_BN - 1) / GD_BN);
+    int best = (F + 15) / 16 * 16;
+    for (int s = 2; s <= 64; ++s) {
+        const int ks = ((F + s - 1) / s + 15) / 16 * 16;
+        if (ks < 400 && tiles * (s - 1) >= 512) break;
+        if (tiles * ((F + ks - 1) / ks) > 2048) break;
+        best = ks;
+    }
+    return best > 0 ? best : 16;
+}
+
 static int compute_z1d(lt_baseline *b, hipStream_t st) {
     if (b->n == 0) return LT_OK;
     const int Hp = b->Hp, H = b->H, n = b->n, F = b->F;
     if (Hp != H) LT_HIP(hipMemsetAsync(b->S1d, 0, (size_t)n * Hp * sizeof(double), st));
-    const int kslice = LT_KSLICE_BASE;
+    const int kslice = fp64_kslice(n, H, F);
     const int splits = (F + kslice - 1) / kslice;
     dim3 grid((n + GD_BM - 1) / GD_BM, (H + GD_BN - 1) / GD_BN, splits);
     if (splits > 1) {
@@ -239,7 +259,8 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     LT_REQUIRE(b != nullptr, "lt_baseline_enable_fp64: baseline is NULL");
     if (b->Z1d) return LT_OK;   // Z1d is set only once all three buffers exist (see below)
     const size_t nh = (size_t)(b->n > 0 ? b->n : 1) * b->Hp * sizeof(double);
-    const int splits = (b->F + LT_KSLICE_BASE - 1) / LT_KSLICE_BASE;
+    const int ks_ = fp64_kslice(b->n, b->H, b->F);
+    const int splits = (b->F + ks_ - 1) / ks_;
     double *s1d = nullptr, *z1d = nullptr, *slabs = nullptr, *segd = nullptr;
     hipError_t e = hipMalloc((void **)&s1d, nh);
     if (e == hipSuccess) e = hipMalloc((void **)&z1d, nh);

@@ -64,7 +64,7 @@ struct lt_baseline {
     const float *W2p = nullptr;
     float *b1p_buf = nullptr;  // [Hp]
     float *W2p_buf = nullptr;  // [Hp, C]
-    float *slabs = nullptr;  // split-K partials of X*W1 (only when F > LT_KSLICE_BASE)
+    float *slabs = nullptr;  // split-K partials of X*W1 (only when the product is K-sliced)
     float *seg_part = nullptr;  // [g->p_n_seg, Hp] segment sums of the long rows of Z1 (SPARSE recomputes one segment of a hub row)
     // optional fp64-accumulated copies for the kink test of LT_MODE_DELTA (lt_baseline_enable_fp64)
     double *S1d = nullptr;      // [n, Hp]
@@ -97,6 +97,7 @@ struct lt_tuning {
     int item_bits;               // SPARSE / DELTA stage B membership bitmap (LT_ITEM_BITS)
     int wide_min_hp;             // smallest padded hidden width served by the batched stage-A kernel (LT_WIDE_MIN_HP)
     int probe_kslice;            // K-slice of the perturbed-row GEMM, 0 = the baseline product's slicing (LT_PROBE_KSLICE)
+    int tiled_big;               // 1: the tiled SpMM always uses 64-bit gather offsets (test hook; default: only when S spans >= 4 GiB)
 };
 lt_tuning &lt_tune();
 
@@ -160,7 +161,6 @@ int lt_launch_layer2(const lt_graph *g, const float *S2, int C, const float *b2,
                      hipStream_t st);
 int lt_launch_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
                    int64_t ldc, int M, int N, int K, hipStream_t st);
-#define LT_KSLICE_BASE 400    // fp64 X*W1 of the delta mode (64x64 tiles)
 size_t lt_gemm_splitk_slab_bytes(int M, int N, int K, int kslice);
 int lt_gemm_pick_kslice(int M, int N, int K);   // baseline X*W1: slice length that fills the CUs in whole rounds
 // gather_rows != NULL: row m of the A operand is row gather_rows[m] of A, perturbed by x + x * delta

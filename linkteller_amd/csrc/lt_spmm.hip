@@ -152,7 +152,7 @@ int lt_launch_rows_tiled(const lt_graph *g, const float *S, int64_t lds, int nco
     const long chunks = ((long)g->w_n + IPB - 1) / IPB;
     const long grid = 8 * ((chunks + xps - 1) / xps);
     LT_REQUIRE(grid < 2147483647L, "tiled SpMM: grid limit");
-    const bool big = (unsigned long long)g->n * (unsigned long long)lds * 4ull >= (1ull << 32);
+    const bool big = lt_tune().tiled_big != 0 || (unsigned long long)g->n * (unsigned long long)lds * 4ull >= (1ull << 32);
     if (big)
         hipLaunchKernelGGL(k_rows_tiled<true>, dim3((unsigned)grid), dim3(LT_BLOCK), 0, st, g->w_n, g->w_e0, g->w_cnt, g->w_dst,
                            g->n, g->col, g->val, S, (long)lds, ncols, init, bias_after, relu, out, (long)ldo, seg_out,

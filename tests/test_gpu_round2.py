@@ -49,6 +49,13 @@ def test_tiled_spmm_equals_row_kernel_bit_for_bit(gpu, ncols, bias, relu):
     finally:
         _lib.set_tuning("tiled_min_bytes", None)
     assert np.array_equal(small, tiled)
+    _lib.set_tuning("tiled_min_bytes", 0)
+    _lib.set_tuning("tiled_big", 1)                       # the 64-bit offset instantiation (S of 4 GiB and more)
+    try:
+        assert np.array_equal(engine.spmm(hg, s, b, relu=relu).cpu().numpy(), small)
+    finally:
+        _lib.set_tuning("tiled_min_bytes", None)
+        _lib.set_tuning("tiled_big", None)
     want = a_hat.astype(np.float64) @ s.cpu().numpy().astype(np.float64)
     if bias:
         want = want + b.cpu().numpy()
