@@ -17,15 +17,33 @@ __global__ __launch_bounds__(LT_BLOCK) void k_layer1(
     int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ S1, int Hp,
     const float *__restrict__ b1p, const float *__restrict__ W2p, int C,
-    float *__restrict__ Z1, float *__restrict__ S2, int skip_long) {
+    float *__restrict__ Z1, float *__restrict__ S2, int skip_long, int seg_blocks, int n_seg,
+    const int32_t *__restrict__ seg_long, const int32_t *__restrict__ seg_begin,
+    const int32_t *__restrict__ long_row, float *__restrict__ seg_part) {
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
     const int gl = lane & (LPR - 1);
+    if ((int)blockIdx.x < seg_blocks) {
+        // the first blocks of the launch take the SEGMENTS of the hub rows (one lane group per segment, the chain of a
+        // row's first segment started from the bias: row_dot's canonical order); k_layer1_long adds them afterwards.
+        // Same launch as the plain rows: a graph with a few hubs does not pay a launch of its own for them.
+        int sg = ((blockIdx.x * LT_BLOCK + threadIdx.x) >> 6) * RPW + lane / LPR;
+        if (LPR == 64) sg = __builtin_amdgcn_readfirstlane(sg);
+        if (sg >= n_seg) return;
+        const int rs = long_row[seg_long[sg]];
+        const int s0 = seg_begin[sg], s1 = min(rowptr[rs + 1], s0 + LT_ROW_SEG);
+        const int co = 4 * gl;
+        const bool act = co < Hp;
+        const f32x4 init = (act && s0 == rowptr[rs]) ? ld4(b1p + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 zs = seg_chain<16>(col, val, s0, s1, S1, Hp, co, act, -1, nullptr, init);
+        if (act) *reinterpret_cast<f32x4 *>(seg_part + (size_t)sg * Hp + co) = zs;
+        return;
+    }
+    const int wave = (((int)blockIdx.x - seg_blocks) * LT_BLOCK + threadIdx.x) >> 6;
     int r = wave * RPW + lane / LPR;
     if (LPR == 64) r = __builtin_amdgcn_readfirstlane(r);
     if (r >= n) return;  // LPR-lane groups exit together; shuffles below stay inside a group
-    // rows of more than LT_ROW_SEG entries are summed segment by segment by k_layer1_seg / k_layer1_long
+    // rows of more than LT_ROW_SEG entries are summed segment by segment (above) and finished by k_layer1_long
     if (skip_long && rowptr[r + 1] - rowptr[r] > LT_ROW_SEG) return;
     const int coff = 4 * gl;
     const bool active = coff < Hp;
@@ -47,29 +65,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_layer1(
     }
 }
 
-// Long rows of layer 1 (hubs): one LPR-lane group per SEGMENT writes the segment's chain sum (the first
-// segment's chain starts from the bias, row_dot's canonical order) ...
-template <int LPR>
-__global__ __launch_bounds__(LT_BLOCK) void k_layer1_seg(
-    int n_seg, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-    const float *__restrict__ val, const int32_t *__restrict__ seg_long,
-    const int32_t *__restrict__ seg_begin, const int32_t *__restrict__ long_row,
-    const float *__restrict__ S1, int Hp, const float *__restrict__ b1p, float *__restrict__ part) {
-    constexpr int RPW = 64 / LPR;
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
-    const int gl = lane & (LPR - 1);
-    int sg = wave * RPW + lane / LPR;
-    if (LPR == 64) sg = __builtin_amdgcn_readfirstlane(sg);
-    if (sg >= n_seg) return;
-    const int r = long_row[seg_long[sg]];
-    const int e0 = seg_begin[sg], e1 = min(rowptr[r + 1], e0 + LT_ROW_SEG);
-    const int coff = 4 * gl;
-    const bool active = coff < Hp;
-    const f32x4 init = (active && e0 == rowptr[r]) ? ld4(b1p + coff) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 z = seg_chain<16>(col, val, e0, e1, S1, Hp, coff, active, -1, nullptr, init);
-    if (active) *reinterpret_cast<f32x4 *>(part + (size_t)sg * Hp + coff) = z;
-}
+// Long rows of layer 1 (hubs): their segment sums come out of k_layer1's first blocks (or the tiled kernel) ...
 // ... and one group per long ROW adds them in segment order and finishes like k_layer1.
 template <int LPR, int CP>
 __global__ __launch_bounds__(LT_BLOCK) void k_layer1_long(
@@ -152,39 +148,18 @@ __global__ __launch_bounds__(LT_BLOCK) void k_layer1_tail(
     }
 }
 
-// Layer 2 for every row: OUT[r] = A_hat[r,:]*S2 + b2
-template <int CP>
-__global__ __launch_bounds__(LT_BLOCK) void k_layer2(
-    int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-    const float *__restrict__ val, const float *__restrict__ S2, int C,
-    const float *__restrict__ b2, float *__restrict__ OUT, int skip_long) {
-    const int gid = (blockIdx.x * LT_BLOCK + threadIdx.x) / LT_L2_LANES;
-    const int q = threadIdx.x & (LT_L2_LANES - 1);
-    if (gid >= n) return;
-    if (skip_long && rowptr[gid + 1] - rowptr[gid] > LT_ROW_SEG) return;   // hub rows: k_layer2_long
-    float acc[CP];
-    row2_dot<CP>(col, val, rowptr[gid], rowptr[gid + 1], q, C,
-                 [&](int c, int) { return S2 + (size_t)c * C; }, acc);
-    if (q == 0) {
-#pragma unroll
-        for (int c = 0; c < CP; ++c)
-            if (c < C) OUT[(size_t)gid * C + c] = acc[c] + b2[c];
-    }
-}
-
 // Layer 2 of a hub row: a row of 10^3 entries is 10^2 dependent load round trips for the 8 lanes of k_layer2 and the
-// whole launch waits for it.  Here a block takes one long row: all 256 threads fetch entries (val, S2 row) into LDS,
+// whole launch waits for it.  Here a block (the first blocks of k_layer2's launch) takes one long row: all 256 threads fetch entries (val, S2 row) into LDS,
 // LT_L2_CHUNK at a time, and the 8 chain lanes then run row2_dot's chains out of LDS -- entry e still goes to chain
 // (e - e0) & 7, chains still k-ordered, same butterfly: the bits of k_layer2.
 #define LT_L2_CHUNK 1024
 template <int CP>
-__global__ __launch_bounds__(LT_BLOCK) void k_layer2_long(
-    const int32_t *__restrict__ long_row, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+__device__ __forceinline__ void layer2_long_row(
+    int r, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ S2, int C, const float *__restrict__ b2,
     float *__restrict__ OUT) {
     __shared__ float sv[LT_L2_CHUNK];
     __shared__ float sT[LT_L2_CHUNK][CP];
-    const int r = long_row[blockIdx.x];
     const int e0 = rowptr[r], e1 = rowptr[r + 1];
     const int tid = threadIdx.x;
     float acc[CP];
@@ -235,6 +210,30 @@ __global__ __launch_bounds__(LT_BLOCK) void k_layer2_long(
     }
 }
 
+// Layer 2 for every row: OUT[r] = A_hat[r,:]*S2 + b2
+template <int CP>
+__global__ __launch_bounds__(LT_BLOCK) void k_layer2(
+    int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const float *__restrict__ S2, int C,
+    const float *__restrict__ b2, float *__restrict__ OUT, int n_long, const int32_t *__restrict__ long_row) {
+    if ((int)blockIdx.x < n_long) {   // the first blocks of the launch: one hub row each
+        layer2_long_row<CP>(long_row[blockIdx.x], rowptr, col, val, S2, C, b2, OUT);
+        return;
+    }
+    const int gid = (((int)blockIdx.x - n_long) * LT_BLOCK + threadIdx.x) / LT_L2_LANES;
+    const int q = threadIdx.x & (LT_L2_LANES - 1);
+    if (gid >= n) return;
+    if (n_long > 0 && rowptr[gid + 1] - rowptr[gid] > LT_ROW_SEG) return;   // a hub row: one of the first blocks
+    float acc[CP];
+    row2_dot<CP>(col, val, rowptr[gid], rowptr[gid + 1], q, C,
+                 [&](int c, int) { return S2 + (size_t)c * C; }, acc);
+    if (q == 0) {
+#pragma unroll
+        for (int c = 0; c < CP; ++c)
+            if (c < C) OUT[(size_t)gid * C + c] = acc[c] + b2[c];
+    }
+}
+
 // b1p[Hp] = b1[H] then zeros and W2p[Hp, C] = W2[H, C] then zero rows, in one launch
 __global__ void k_pad_b1_w2(const float *__restrict__ b1, const float *__restrict__ W2, int H, int Hp, int C,
                             float *__restrict__ b1p, float *__restrict__ W2p) {
@@ -277,22 +276,20 @@ int lt_launch_layer1(const lt_graph *g, const float *S1, int Hp, const float *b1
         LT_CHECK_LAUNCH();
         return LT_OK;
     }
-    if (have_long) {   // hub rows first: segment sums, then their ordered sum (uses the graph's scratch)
-        LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_layer1_seg<LPR_>), dim3(blocks_for_rows(g->p_n_seg, rpb)),
-                                                 dim3(LT_BLOCK), 0, st, g->p_n_seg, g->rowptr, g->col, g->val,
-                                                 g->p_seg_long, g->p_seg_begin, g->p_long_row, S1, Hp, b1p,
-                                                 seg_part));
-        LT_CHECK_LAUNCH();
+    // plain rows and (first blocks) the segments of the hub rows in one launch, then the hub rows' ordered sums
+    const unsigned seg_blocks = have_long ? blocks_for_rows(g->p_n_seg, rpb) : 0u;
+    LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
+        hipLaunchKernelGGL((k_layer1<LPR_, CP_>), dim3(grid + seg_blocks), dim3(LT_BLOCK), 0, st, g->n,
+                           g->rowptr, g->col, g->val, S1, Hp, b1p, W2p, C, Z1, S2, have_long, (int)seg_blocks, g->p_n_seg,
+                           g->p_seg_long, g->p_seg_begin, g->p_long_row, seg_part)));
+    LT_CHECK_LAUNCH();
+    if (have_long) {
         LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
             hipLaunchKernelGGL((k_layer1_long<LPR_, CP_>), dim3(blocks_for_rows(g->p_n_long, rpb)), dim3(LT_BLOCK), 0,
                                st, g->p_n_long, g->p_long_row, g->p_long_segptr, seg_part, Hp, W2p, C,
                                Z1, S2)));
         LT_CHECK_LAUNCH();
     }
-    LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
-        hipLaunchKernelGGL((k_layer1<LPR_, CP_>), dim3(grid), dim3(LT_BLOCK), 0, st, g->n,
-                           g->rowptr, g->col, g->val, S1, Hp, b1p, W2p, C, Z1, S2, have_long)));
-    LT_CHECK_LAUNCH();
     return LT_OK;
 }
 
@@ -301,16 +298,9 @@ int lt_launch_layer2(const lt_graph *g, const float *S2, int C, const float *b2,
     if (g->n == 0) return LT_OK;
     const unsigned grid = blocks_for_rows(g->n, LT_BLOCK / LT_L2_LANES);
     lt_prof_scope prof_(LT_K_LAYER2, st);
-    const int have_long = g->p_n_long > 0 ? 1 : 0;
-    if (have_long) {
-        LT_DISPATCH_CP(lt_cp_for(C),
-            hipLaunchKernelGGL((k_layer2_long<CP_>), dim3(g->p_n_long), dim3(LT_BLOCK), 0, st, g->p_long_row, g->rowptr,
-                               g->col, g->val, S2, C, b2, OUT));
-        LT_CHECK_LAUNCH();
-    }
     LT_DISPATCH_CP(lt_cp_for(C),
-        hipLaunchKernelGGL((k_layer2<CP_>), dim3(grid), dim3(LT_BLOCK), 0, st, g->n, g->rowptr,
-                           g->col, g->val, S2, C, b2, OUT, have_long));
+        hipLaunchKernelGGL((k_layer2<CP_>), dim3(grid + (unsigned)g->p_n_long), dim3(LT_BLOCK), 0, st, g->n, g->rowptr,
+                           g->col, g->val, S2, C, b2, OUT, g->p_n_long, g->p_long_row));
     LT_CHECK_LAUNCH();
     return LT_OK;
 }

@@ -123,26 +123,28 @@ __global__ void k_sum_slabs_f64(const double *__restrict__ slabs, long slab_stri
 }
 
 // Z1d[r, :] = sum_e val[e] * S1d[col[e], :] + b1     (fp64 fma chain in CSR order, 4 columns per lane)
-// SEG = false: one lane group per row of up to LT_ROW_SEG entries (longer rows are skipped when the graph has a
-// segment table); SEG = true: one lane group per SEGMENT of a long row, raw sum into out[segment] (k_spmm_f64_long
-// adds them in segment order and the bias).  fp64: the cut only decides how a hub row's work is spread.
-template <int LPR, bool SEG>
+// One lane group per row of up to LT_ROW_SEG entries; on a graph with hub rows the first seg_blocks blocks of the
+// launch take one SEGMENT of a long row per lane group instead, raw sum into seg_out[segment] (k_spmm_f64_long adds
+// them in segment order and the bias).  fp64: the cut only decides how a hub row's work is spread.
+template <int LPR>
 __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restrict__ rowptr,
                                                   const int32_t *__restrict__ col,
                                                   const float *__restrict__ val,
                                                   const double *__restrict__ S, int ld,
                                                   const float *__restrict__ b1p,
-                                                  double *__restrict__ out, int skip_long,
+                                                  double *__restrict__ out, int seg_blocks, int n_seg,
                                                   const int32_t *__restrict__ seg_begin,
                                                   const int32_t *__restrict__ seg_long,
-                                                  const int32_t *__restrict__ long_row) {
+                                                  const int32_t *__restrict__ long_row,
+                                                  double *__restrict__ seg_out) {
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const int gl = lane & (LPR - 1);
+    const bool SEG = (int)blockIdx.x < seg_blocks;      // block-uniform: the first blocks take the segments of the hub rows
+    const int wave = ((SEG ? (int)blockIdx.x : (int)blockIdx.x - seg_blocks) * 256 + threadIdx.x) >> 6;
     int r = wave * RPW + lane / LPR;
     if (LPR == 64) r = __builtin_amdgcn_readfirstlane(r);
-    if (r >= n) return;
+    if (r >= (SEG ? n_seg : n)) return;
     const int coff = 4 * gl;
     if (coff >= ld) return;
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
     } else {
         e = rowptr[r];
         e1 = rowptr[r + 1];
-        if (skip_long && e1 - e > LT_ROW_SEG) return;
+        if (seg_blocks > 0 && e1 - e > LT_ROW_SEG) return;
     }
     for (; e + 4 <= e1; e += 4) {   // four gathers in flight; the fma chain stays in entry order
         double a[4];
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[k] += (double)b[k];
     }
-    *reinterpret_cast<f64x4 *>(out + (size_t)r * ld + coff) = acc;
+    *reinterpret_cast<f64x4 *>((SEG ? seg_out : out) + (size_t)r * ld + coff) = acc;
 }
 __global__ void k_spmm_f64_long(int n_long, const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_segptr,
                                 const double *__restrict__ part, int ld, const float *__restrict__ b1p,
@@ -233,21 +235,17 @@ static int compute_z1d(lt_baseline *b, hipStream_t st) {
     const unsigned g2 = (unsigned)((n + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr)));
     const lt_graph *g = b->g;
     const int have_long = (g->p_n_long > 0 && b->seg_d) ? 1 : 0;
+    const unsigned gs = have_long ? (unsigned)((g->p_n_seg + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr))) : 0u;
+    LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_>), dim3(g2 + gs), dim3(256), 0, st, n, g->rowptr,
+                                            g->col, g->val, b->S1d, Hp, b->b1p, b->Z1d, (int)gs, g->p_n_seg, g->p_seg_begin,
+                                            g->p_seg_long, g->p_long_row, b->seg_d));
+    LT_CHECK_LAUNCH();
     if (have_long) {
-        const unsigned gs = (unsigned)((g->p_n_seg + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr)));
-        LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, true>), dim3(gs), dim3(256), 0, st, g->p_n_seg, g->rowptr,
-                                                g->col, g->val, b->S1d, Hp, b->b1p, b->seg_d, 0, g->p_seg_begin,
-                                                g->p_seg_long, g->p_long_row));
-        LT_CHECK_LAUNCH();
         const long tot = (long)g->p_n_long * Hp;
         hipLaunchKernelGGL(k_spmm_f64_long, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, g->p_n_long,
                            g->p_long_row, g->p_long_segptr, b->seg_d, Hp, b->b1p, b->Z1d);
         LT_CHECK_LAUNCH();
     }
-    LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, false>), dim3(g2), dim3(256), 0, st, n, g->rowptr,
-                                            g->col, g->val, b->S1d, Hp, b->b1p, b->Z1d, have_long,
-                                            (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr));
-    LT_CHECK_LAUNCH();
     return LT_OK;
 }
 

@@ -734,98 +734,35 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
     }
 }
 
-// SPARSE / DELTA stage B: 8 lanes per (probe, observed node).
-template <int CP, bool DELTA>
-__global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
-    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-    const float *__restrict__ val, const int32_t *__restrict__ tptr,
-    const int32_t *__restrict__ trow, const float *__restrict__ S2, int C,
-    const float *__restrict__ b2, const float *__restrict__ OUT,
-    const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
-    const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
-    float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words, int skip_long) {
-    const long gid = ((long)blockIdx.x * LT_BLOCK + threadIdx.x) / LT_L2_LANES;
-    const int q = threadIdx.x & (LT_L2_LANES - 1);
-    if (gid >= (long)nb * n_obs) return;
-    const int b = (int)(gid / n_obs), j = (int)(gid % n_obs);
-    const int u = observe[j];
-    const int v = probes[b];
-    const int32_t *rv = trow + tptr[v];
-    const int cnt = tptr[v + 1] - tptr[v];
-    const float *items = S2x + (size_t)off[b] * C;
-    const int e0 = rowptr[u], e1 = rowptr[u + 1];
-    if (skip_long && e1 - e0 > LT_ROW_SEG) return;   // an observed hub: k_item_stageB_long
-
-    // does row u touch R_v at all?  (otherwise the perturbed logits ARE the baseline logits)
-    const uint2 *mb = bits ? bits + (size_t)b * words : nullptr;
-    // position of column c in R_v (-1: not a member): the bitmap when there is one, the search otherwise
-    auto pos = [&](int c) { return mb ? bits_pos(mb, c) : find_row(rv, cnt, c); };
-    bool touch = false;
-    for (int e = e0 + q; e < e1; e += LT_L2_LANES) touch |= pos(col[e]) >= 0;
-    // 8-lane any(): xor butterfly on an int
-    int t = touch ? 1 : 0;
-#pragma unroll
-    for (int m = LT_L2_LANES / 2; m >= 1; m >>= 1) t |= __shfl_xor(t, m, 64);
-    float res = 0.f;
-    if (t) {  // group-uniform
-        float acc[CP];
-        if (DELTA) {
-            // d_out[c] = sum over e with col[e] in R_v of val[e] * dS2[item(col[e]), c]
-            row2_dot<CP>(col, val, e0, e1, q, C,
-                         [&](int c, int) {
-                             const int p = pos(c);
-                             return p >= 0 ? items + (size_t)p * C : (const float *)nullptr;
-                         },
-                         acc);
-            float ss = 0.f;
-#pragma unroll
-            for (int c = 0; c < CP; ++c)
-                if (c < C) {
-                    const float d = acc[c] / delta;
-                    ss = fmaf(d, d, ss);
-                }
-            res = sqrtf(ss);
-        } else {
-            row2_dot<CP>(col, val, e0, e1, q, C,
-                         [&](int c, int) {
-                             const int p = pos(c);
-                             return p >= 0 ? items + (size_t)p * C : S2 + (size_t)c * C;
-                         },
-                         acc);
-            res = diff_norm<CP>(acc, b2, OUT + (size_t)u * C, C, delta);
-        }
-    }
-    if (q == 0) out[(long)b * ldo + j] = res;
-}
-
 // SPARSE / DELTA stage B for an OBSERVED HUB (a row of more than LT_ROW_SEG entries): in k_item_stageB the 8 lanes of
 // a (probe, hub) pair walk 10^3 entries, each step a dependent col -> membership -> value round trip, and the launch
-// waits for those pairs.  Here a block takes one observed hub and 32 probes (a wave = 8 probes x the 8 chain lanes):
+// waits for those pairs.  Here a block (the first blocks of k_item_stageB's launch) takes one observed hub and 32 probes (a wave = 8 probes x the 8 chain lanes):
 // the row's (col, val, baseline S2 row) are fetched into LDS once per chunk by all 256 threads and shared by the 32
 // probes; the membership tests of a lane's next 8 entries are in flight together.  Same chains (entry e -> chain
 // (e - e0) & 7, k-ordered, non-members skipped in DELTA), same butterfly, same tail: the bits of k_item_stageB.
 #define LT_SBL_CHUNK 1024
 #define LT_SBL_UN 8
 template <int CP, bool DELTA>
-__global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_long(
-    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+__device__ __forceinline__ void stageB_long_block(
+    int bid, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const int32_t *__restrict__ tptr,
     const int32_t *__restrict__ trow, const float *__restrict__ S2, int C,
     const float *__restrict__ b2, const float *__restrict__ OUT,
     const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
     const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
     float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words) {
-    __shared__ int sc[LT_SBL_CHUNK];
-    __shared__ float sv[LT_SBL_CHUNK];
-    __shared__ float sT[DELTA ? 1 : LT_SBL_CHUNK][CP];
+    constexpr int CHUNK = CP <= 2 ? LT_SBL_CHUNK : (CP <= 4 ? LT_SBL_CHUNK / 2 : LT_SBL_CHUNK / 4);   // LDS: <= 16 KB
+    __shared__ int sc[CHUNK];
+    __shared__ float sv[CHUNK];
+    __shared__ float sT[DELTA ? 1 : CHUNK][CP];
     const int pblocks = (nb + LT_BLOCK / LT_L2_LANES - 1) / (LT_BLOCK / LT_L2_LANES);
-    const int j = blockIdx.x / pblocks;
+    const int j = bid / pblocks;
     const int u = observe[j];
     const int e0 = rowptr[u], e1 = rowptr[u + 1];
     if (e1 - e0 <= LT_ROW_SEG) return;           // not a hub: k_item_stageB has it (block-uniform exit)
     const int tid = threadIdx.x;
     const int q = tid & (LT_L2_LANES - 1);
-    const int b = (blockIdx.x % pblocks) * (LT_BLOCK / LT_L2_LANES) + tid / LT_L2_LANES;
+    const int b = (bid % pblocks) * (LT_BLOCK / LT_L2_LANES) + tid / LT_L2_LANES;
     const bool live = b < nb;
     const int v = probes[live ? b : 0];
     const int32_t *rv = trow + tptr[v];
@@ -837,8 +774,8 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_long(
 #pragma unroll
     for (int c = 0; c < CP; ++c) acc[c] = 0.f;
     bool touch = false;
-    for (int cb = e0; cb < e1; cb += LT_SBL_CHUNK) {
-        const int nc = min(LT_SBL_CHUNK, e1 - cb);
+    for (int cb = e0; cb < e1; cb += CHUNK) {
+        const int nc = min(CHUNK, e1 - cb);
         __syncthreads();
         for (int i = tid; i < nc; i += LT_BLOCK) {
             const int cc = col[cb + i];
@@ -903,6 +840,78 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_long(
         }
     }
     if (live && q == 0) out[(long)b * ldo + j] = res;
+}
+
+// SPARSE / DELTA stage B: 8 lanes per (probe, observed node).
+template <int CP, bool DELTA>
+__global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const int32_t *__restrict__ tptr,
+    const int32_t *__restrict__ trow, const float *__restrict__ S2, int C,
+    const float *__restrict__ b2, const float *__restrict__ OUT,
+    const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
+    const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
+    float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words, int long_blocks) {
+    // long_blocks > 0 (the graph has hub rows): the first long_blocks blocks serve the observed hubs
+    // (stageB_long_block: most of them find a plain row and exit), the pairs below skip those rows
+    if ((int)blockIdx.x < long_blocks) {
+        stageB_long_block<CP, DELTA>((int)blockIdx.x, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off, S2x,
+                                     observe, n_obs, delta, out, ldo, bits, words);
+        return;
+    }
+    const bool skip_long = long_blocks > 0;
+    const long gid = ((long)(blockIdx.x - long_blocks) * LT_BLOCK + threadIdx.x) / LT_L2_LANES;
+    const int q = threadIdx.x & (LT_L2_LANES - 1);
+    if (gid >= (long)nb * n_obs) return;
+    const int b = (int)(gid / n_obs), j = (int)(gid % n_obs);
+    const int u = observe[j];
+    const int v = probes[b];
+    const int32_t *rv = trow + tptr[v];
+    const int cnt = tptr[v + 1] - tptr[v];
+    const float *items = S2x + (size_t)off[b] * C;
+    const int e0 = rowptr[u], e1 = rowptr[u + 1];
+    if (skip_long && e1 - e0 > LT_ROW_SEG) return;   // an observed hub: one of the first blocks
+
+    // does row u touch R_v at all?  (otherwise the perturbed logits ARE the baseline logits)
+    const uint2 *mb = bits ? bits + (size_t)b * words : nullptr;
+    // position of column c in R_v (-1: not a member): the bitmap when there is one, the search otherwise
+    auto pos = [&](int c) { return mb ? bits_pos(mb, c) : find_row(rv, cnt, c); };
+    bool touch = false;
+    for (int e = e0 + q; e < e1; e += LT_L2_LANES) touch |= pos(col[e]) >= 0;
+    // 8-lane any(): xor butterfly on an int
+    int t = touch ? 1 : 0;
+#pragma unroll
+    for (int m = LT_L2_LANES / 2; m >= 1; m >>= 1) t |= __shfl_xor(t, m, 64);
+    float res = 0.f;
+    if (t) {  // group-uniform
+        float acc[CP];
+        if (DELTA) {
+            // d_out[c] = sum over e with col[e] in R_v of val[e] * dS2[item(col[e]), c]
+            row2_dot<CP>(col, val, e0, e1, q, C,
+                         [&](int c, int) {
+                             const int p = pos(c);
+                             return p >= 0 ? items + (size_t)p * C : (const float *)nullptr;
+                         },
+                         acc);
+            float ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < CP; ++c)
+                if (c < C) {
+                    const float d = acc[c] / delta;
+                    ss = fmaf(d, d, ss);
+                }
+            res = sqrtf(ss);
+        } else {
+            row2_dot<CP>(col, val, e0, e1, q, C,
+                         [&](int c, int) {
+                             const int p = pos(c);
+                             return p >= 0 ? items + (size_t)p * C : S2 + (size_t)c * C;
+                         },
+                         acc);
+            res = diff_norm<CP>(acc, b2, OUT + (size_t)u * C, C, delta);
+        }
+    }
+    if (q == 0) out[(long)b * ldo + j] = res;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1057,6 +1066,9 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                    "lt_influence_rows: %d probes x %d observed nodes per chunk exceed the grid limit (lower chunk_budget_bytes)",
                    nb, n_obs);
         const unsigned gridB = (unsigned)((pairs * LT_L2_LANES + LT_BLOCK - 1) / LT_BLOCK);
+        // SPARSE / DELTA on a graph with hub rows: blocks for the observed hubs ride in front of stage B's launch
+        const long long_blocks = (mode != LT_MODE_FULL && g->p_n_long > 0) ? ((nb + 31) / 32) * (long)n_obs : 0;
+        LT_REQUIRE(gridB + long_blocks < 2147483647L, "lt_influence_rows: stage-B grid limit");
 
         if (mode != LT_MODE_DELTA) {
             // perturbed rows and their S1 rows: Sp = (X[v] + X[v]*d) W1            attacker.py:101-105
@@ -1169,19 +1181,11 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                        b->seg_part, w.item_pr))); }
                 LT_CHECK_LAUNCH();
                 lt_prof_scope prof_(LT_K_ITEM_B, st);
-                LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, false>), dim3(gridB),
+                LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, false>), dim3(gridB + (unsigned)long_blocks),
                                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
                                                        g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
                                                        nb, w.off, w.S2x, observe_nodes, n_obs, delta,
-                                                       orow, (long)ldo, w.bits, words, g->p_n_long > 0 ? 1 : 0));
-                if (g->p_n_long > 0) {
-                    LT_CHECK_LAUNCH();
-                    LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_long<CP_, false>),
-                                                           dim3((unsigned)(((nb + 31) / 32) * (long)n_obs)), dim3(LT_BLOCK), 0, st, g->rowptr,
-                                                           g->col, g->val, g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
-                                                           nb, w.off, w.S2x, observe_nodes, n_obs, delta, orow, (long)ldo,
-                                                           w.bits, words));
-                }
+                                                       orow, (long)ldo, w.bits, words, (int)long_blocks));
             } else {
                 { lt_prof_scope prof_(LT_K_ITEM_A, st);
                 if (b->Z1d) {
@@ -1201,19 +1205,11 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                 } }
                 LT_CHECK_LAUNCH();
                 lt_prof_scope prof_(LT_K_ITEM_B, st);
-                LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, true>), dim3(gridB),
+                LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, true>), dim3(gridB + (unsigned)long_blocks),
                                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
                                                        g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
                                                        nb, w.off, w.S2x, observe_nodes, n_obs, delta,
-                                                       orow, (long)ldo, w.bits, words, g->p_n_long > 0 ? 1 : 0));
-                if (g->p_n_long > 0) {
-                    LT_CHECK_LAUNCH();
-                    LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_long<CP_, true>),
-                                                           dim3((unsigned)(((nb + 31) / 32) * (long)n_obs)), dim3(LT_BLOCK), 0, st, g->rowptr,
-                                                           g->col, g->val, g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
-                                                           nb, w.off, w.S2x, observe_nodes, n_obs, delta, orow, (long)ldo,
-                                                           w.bits, words));
-                }
+                                                       orow, (long)ldo, w.bits, words, (int)long_blocks));
             }
             LT_CHECK_LAUNCH();
         }
