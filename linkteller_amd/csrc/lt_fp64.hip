@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include <new>
+#include <type_traits>
 
 #include "lt_rows.cuh"
 
@@ -113,6 +114,149 @@ __global__ __launch_bounds__(256) void k_gemm_f64acc(const float *__restrict__ A
         }
 }
 
+// ---- 128x128 block tile for the big product (N a multiple of 128, M >= 1024): each of the 4 waves owns a 64x64
+// quadrant = 4x4 MFMA tiles of 16x16, so one k-step (4 deep) is 16 v_mfma_f64_16x16x4_f64 (1024 cycles) fed by 4 + 4
+// LDS fragment reads; global loads run two k-tiles ahead of the LDS stores in two register stages and the steady
+// state is branch-free, exactly as in k_gemm_f32_mfma_128 (lt_gemm.hip).  fp32 operands are widened on the LDS read.
+#define GE_BM 128
+#define GE_BN 128
+#define GE_BK 16
+#define GE_LDA (GE_BK + 1)
+#define GE_LDB (GE_BN + 16)   // +16 floats: the k-rows a 32-lane group reads land in disjoint banks
+#define GE_PASS (GE_BK / 8)
+__global__ __launch_bounds__(256, 2) void k_gemm_f64acc_128(const float *__restrict__ A, long lda,
+                                                         const float *__restrict__ B, long ldb,
+                                                         double *__restrict__ C, long ldc, int M, int N, int K,
+                                                         int kslice, long slab_stride) {
+    __shared__ __attribute__((aligned(16))) float As[2][GE_BM * GE_LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GE_BK * GE_LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int m0 = blockIdx.x * GE_BM, n0 = blockIdx.y * GE_BN;
+    const int kb = blockIdx.z * kslice, ke = min(K, kb + kslice);
+    C += (long)blockIdx.z * slab_stride;
+    constexpr int A_TPR = GE_BK / 4, A_RPP = 256 / A_TPR;
+    const int a_row = tid / A_TPR, a_col = (tid % A_TPR) * 4;
+    const int b_row = tid >> 5, b_col = (tid & 31) * 4;
+    const float *a_ptr[GE_PASS], *b_ptr[GE_PASS];
+#pragma unroll
+    for (int p = 0; p < GE_PASS; ++p) {
+        a_ptr[p] = A + (long)min(m0 + a_row + p * A_RPP, M - 1) * lda + a_col + kb;   // rows past M: clamped, never stored
+        b_ptr[p] = B + (long)(kb + b_row + 8 * p) * ldb + n0 + b_col;
+    }
+    const long b_step = (long)GE_BK * ldb;
+    f32x4 ra[2][GE_PASS], rb[2][GE_PASS];
+    auto load_full = [&](auto stage_tag) {
+        constexpr int S = decltype(stage_tag)::value;
+#pragma unroll
+        for (int p = 0; p < GE_PASS; ++p) {
+            ra[S][p] = *reinterpret_cast<const f32x4u_ *>(a_ptr[p]);
+            rb[S][p] = *reinterpret_cast<const f32x4u_ *>(b_ptr[p]);
+            a_ptr[p] += GE_BK;
+            b_ptr[p] += b_step;
+        }
+    };
+    auto load_tail = [&](int k0, auto stage_tag) {
+        constexpr int S = decltype(stage_tag)::value;
+#pragma unroll
+        for (int p = 0; p < GE_PASS; ++p) {
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k0 + a_col + j < ke) r[j] = a_ptr[p][j];
+            ra[S][p] = r;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (k0 + b_row + 8 * p < ke) t = *reinterpret_cast<const f32x4u_ *>(b_ptr[p]);
+            rb[S][p] = t;
+        }
+    };
+    auto store_tiles = [&](int buf, auto stage_tag) {
+        constexpr int S = decltype(stage_tag)::value;
+#pragma unroll
+        for (int p = 0; p < GE_PASS; ++p) {
+            float *as = &As[buf][(a_row + p * A_RPP) * GE_LDA + a_col];
+            as[0] = ra[S][p].x; as[1] = ra[S][p].y; as[2] = ra[S][p].z; as[3] = ra[S][p].w;
+            *reinterpret_cast<f32x4 *>(&Bs[buf][(b_row + 8 * p) * GE_LDB + b_col]) = rb[S][p];
+        }
+    };
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+    // operands of v_mfma_f64_16x16x4_f64: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15]
+    const int a_frag = (wr * 64 + (lane & 15)) * GE_LDA + (lane >> 4);
+    const int b_frag = (lane >> 4) * GE_LDB + wc * 64 + (lane & 15);
+    auto multiply = [&](int buf) {
+        const float *as = &As[buf][a_frag];
+        const float *bs = &Bs[buf][b_frag];
+#pragma unroll
+        for (int kk = 0; kk < GE_BK; kk += 4) {
+            double a[4], bq[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[t] = (double)as[t * 16 * GE_LDA + kk];
+                bq[t] = (double)bs[kk * GE_LDB + t * 16];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bq[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    const int nfull = (ke - kb) / GE_BK;
+    const bool partial = (ke - kb) % GE_BK != 0;
+    if (nfull > 0) {
+        load_full(S0{});
+        store_tiles(0, S0{});
+        if (nfull > 1) load_full(S1{});
+        __syncthreads();
+        auto step = [&](int kt, auto even_tag) {
+            constexpr int E = decltype(even_tag)::value;
+            if (kt + 2 < nfull) load_full(std::integral_constant<int, E>{});
+            multiply(E);
+            if (kt + 1 < nfull) store_tiles(E ^ 1, std::integral_constant<int, E ^ 1>{});
+            __syncthreads();
+        };
+        int kt = 0;
+        for (; kt + 3 < nfull; kt += 2) {     // steady state: two tiles per trip, everything unconditional
+            load_full(S0{});
+            multiply(0);
+            store_tiles(1, S1{});
+            __syncthreads();
+            load_full(S1{});
+            multiply(1);
+            store_tiles(0, S0{});
+            __syncthreads();
+        }
+        for (; kt + 1 < nfull; kt += 2) {
+            step(kt, S0{});
+            step(kt + 1, S1{});
+        }
+        if (kt < nfull) step(kt, S0{});
+    }
+    if (partial) {
+        load_tail(kb + nfull * GE_BK, S0{});
+        store_tiles(0, S0{});
+        __syncthreads();
+        multiply(0);
+    }
+    // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cn = n0 + wc * 64 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cm = m0 + wr * 64 + i * 16 + (lane >> 4) + 4 * reg;
+                if (cm < M) C[(long)cm * ldc + cn] = acc[i][j][reg];
+            }
+        }
+}
+
 __global__ void k_sum_slabs_f64(const double *__restrict__ slabs, long slab_stride, int splits, long total,
                                 int N, double *__restrict__ C, long ldc) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -198,9 +342,24 @@ __global__ void k_spmm_f64_long(int n_long, const int32_t *__restrict__ long_row
 // workgroups still occupy every CU, and never more workgroups than are resident at once (256 CUs x 8) -- a ninth per CU
 // runs alone after the others (twitch-RU: 8 slices = 2208 workgroups, 134 us; 7 slices = 1932, all resident).
 // LT_F64_KSLICE overrides (experiments).
+static bool fp64_big(int n, int H) { return n >= 1024 && H % GE_BN == 0; }
 static int fp64_kslice(int n, int H, int F) {
     static const long long forced = getenv("LT_F64_KSLICE") ? atoll(getenv("LT_F64_KSLICE")) : 0;
     if (forced > 0) return (int)((forced + 15) / 16 * 16);
+    if (fp64_big(n, H)) {
+        // 128x128 tiles, two workgroups per CU: the slicing rule of the f32 product (whole rounds of 256 CUs)
+        const long tiles = (long)((n + GE_BM - 1) / GE_BM) * (H / GE_BN);
+        int best = (F + 15) / 16 * 16;
+        double best_cost = 1e30;
+        for (int s2 = 1; s2 <= 16; ++s2) {
+            const int ks = ((F + s2 - 1) / s2 + 15) / 16 * 16;
+            const int slices = (F + ks - 1) / ks;
+            const long rounds = (tiles * slices + 255) / 256;
+            const double cost = (double)rounds * (ks / 16) + 2.2 * (slices - 1);
+            if (cost < best_cost - 1e-9) { best_cost = cost; best = ks; }
+        }
+        return best;
+    }
     const long tiles = (long)((n + GD_BM - 1) / GD_BM) * ((H + GD_BN - 1) / GD_BN);
     int best = (F + 15) / 16 * 16;
     for (int s = 2; s <= 64; ++s) {
@@ -218,17 +377,22 @@ static int compute_z1d(lt_baseline *b, hipStream_t st) {
     if (Hp != H) LT_HIP(hipMemsetAsync(b->S1d, 0, (size_t)n * Hp * sizeof(double), st));
     const int kslice = fp64_kslice(n, H, F);
     const int splits = (F + kslice - 1) / kslice;
-    dim3 grid((n + GD_BM - 1) / GD_BM, (H + GD_BN - 1) / GD_BN, splits);
+    const bool big = fp64_big(n, H);
+    dim3 grid(big ? (n + GE_BM - 1) / GE_BM : (n + GD_BM - 1) / GD_BM, big ? H / GE_BN : (H + GD_BN - 1) / GD_BN, splits);
+    double *dst = splits > 1 ? b->slabs_d : b->S1d;
+    const long ldd = splits > 1 ? (long)H : (long)Hp;
+    const long stride = splits > 1 ? (long)n * H : 0L;
+    if (big)
+        hipLaunchKernelGGL(k_gemm_f64acc_128, grid, dim3(256), 0, st, b->X, (long)b->ldx, b->W1, (long)H, dst, ldd, n, H, F,
+                           splits > 1 ? kslice : (F > 0 ? F : 1), stride);
+    else
+        hipLaunchKernelGGL(k_gemm_f64acc, grid, dim3(256), 0, st, b->X, (long)b->ldx, b->W1, (long)H, dst, ldd, n, H, F,
+                           splits > 1 ? kslice : (F > 0 ? F : 1), stride);
     if (splits > 1) {
-        hipLaunchKernelGGL(k_gemm_f64acc, grid, dim3(256), 0, st, b->X, (long)b->ldx, b->W1, (long)H,
-                           b->slabs_d, (long)H, n, H, F, kslice, (long)n * H);
         LT_CHECK_LAUNCH();
         const long tot = (long)n * H;
         hipLaunchKernelGGL(k_sum_slabs_f64, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, b->slabs_d,
                            tot, splits, tot, H, b->S1d, (long)Hp);
-    } else {
-        hipLaunchKernelGGL(k_gemm_f64acc, grid, dim3(256), 0, st, b->X, (long)b->ldx, b->W1, (long)H, b->S1d,
-                           (long)Hp, n, H, F, F > 0 ? F : 1, 0L);
     }
     LT_CHECK_LAUNCH();
     const int lpr = lt_lpr_for(Hp);
