@@ -1166,10 +1166,9 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
             } }
             LT_CHECK_LAUNCH();
         } else {
-            hipLaunchKernelGGL(k_probe_offsets, dim3(1), dim3(1024), 0, st, g->tptr, probes, nb, w.off);
-            LT_CHECK_LAUNCH();
             const int words = (n + 31) / 32;
-            hipLaunchKernelGGL(k_item_bits, dim3(nb), dim3(256), 0, st, g->tptr, g->trow, probes, words, w.bits, w.off, w.item_pr);
+            // item offsets, the (probe, row) table of the items and the membership bitmap, one block per probe
+            hipLaunchKernelGGL(k_item_bits, dim3(nb), dim3(256), 0, st, g->tptr, g->trow, probes, nb, words, w.bits, w.off, w.item_pr);
             LT_CHECK_LAUNCH();
             if (mode == LT_MODE_SPARSE) {
                 { lt_prof_scope prof_(LT_K_ITEM_A, st);

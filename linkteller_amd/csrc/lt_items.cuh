@@ -3,36 +3,6 @@
 #pragma once
 #include "lt_rows.cuh"
 
-static __global__ __launch_bounds__(1024) void k_probe_offsets(const int32_t *__restrict__ tptr,
-                                                        const int32_t *__restrict__ probes, int nb,
-                                                        int32_t *__restrict__ off) {
-    __shared__ int32_t buf[1024];
-    __shared__ int32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < nb; base += 1024) {
-        const int b = base + threadIdx.x;
-        int d = 0;
-        if (b < nb) {
-            const int v = probes[b];
-            d = tptr[v + 1] - tptr[v];
-        }
-        buf[threadIdx.x] = d;
-        __syncthreads();
-        for (int s = 1; s < 1024; s <<= 1) {
-            const int add = threadIdx.x >= s ? buf[threadIdx.x - s] : 0;
-            __syncthreads();
-            buf[threadIdx.x] += add;
-            __syncthreads();
-        }
-        if (b < nb) off[b] = carry + buf[threadIdx.x] - d;  // exclusive
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += buf[1023];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) off[nb] = carry;
-}
-
 __device__ __forceinline__ int find_probe(const int32_t *__restrict__ off, int nb, int item) {
     int lo = 0, hi = nb;  // off[lo] <= item < off[hi]
     while (hi - lo > 1) {
@@ -61,26 +31,42 @@ __device__ __forceinline__ int find_row(const int32_t *__restrict__ rows, int cn
 //     position(r) = base + popcount(mask & ((1 << (r & 31)) - 1))
 // (without the bitmap -- huge graphs -- both questions are a binary search in R_v).  One block per probe.
 static __global__ __launch_bounds__(256) void k_item_bits(const int32_t *__restrict__ tptr, const int32_t *__restrict__ trow,
-                                                   const int32_t *__restrict__ probes, int words,
-                                                   uint2 *__restrict__ bits, const int32_t *__restrict__ off,
+                                                   const int32_t *__restrict__ probes, int nb, int words,
+                                                   uint2 *__restrict__ bits, int32_t *__restrict__ off,
                                                    int2 *__restrict__ item_pr) {
-    // bits == NULL: only the (probe, row) table of the items is written (huge graphs have no bitmap)
-    uint2 *mine = bits ? bits + (size_t)blockIdx.x * words : nullptr;
-    if (mine) {
-        for (int i = threadIdx.x; i < words; i += blockDim.x) mine[i] = make_uint2(0u, 0xffffffffu);
-        __syncthreads();
+    // One block per probe.  It also forms the probe's item offset off[b] = sum of |R_v| over the probes before it
+    // (every block sums its own prefix: nb^2 / 2 four-byte loads in all, no scan kernel in front), the last block
+    // writes the total off[nb].  bits == NULL: no bitmap (huge graphs); item_pr == NULL: no (probe, row) table.
+    __shared__ int32_t red[4];
+    const int b = blockIdx.x;
+    int part = 0;
+    for (int i = threadIdx.x; i < b; i += blockDim.x) {
+        const int vi = probes[i];
+        part += tptr[vi + 1] - tptr[vi];
     }
-    const int v = probes[blockIdx.x];
-    const int t0 = tptr[v];
-    int2 *items = item_pr ? item_pr + off[blockIdx.x] : nullptr;
-    for (int t = t0 + threadIdx.x; t < tptr[v + 1]; t += blockDim.x) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    uint2 *mine = bits ? bits + (size_t)b * words : nullptr;
+    if (mine)
+        for (int i = threadIdx.x; i < words; i += blockDim.x) mine[i] = make_uint2(0u, 0xffffffffu);
+    __syncthreads();
+    const int my_off = red[0] + red[1] + red[2] + red[3];
+    const int v = probes[b];
+    const int t0 = tptr[v], t1 = tptr[v + 1];
+    if (threadIdx.x == 0) {
+        off[b] = my_off;
+        if (b == nb - 1) off[nb] = my_off + (t1 - t0);
+    }
+    int2 *items = item_pr ? item_pr + my_off : nullptr;
+    for (int t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
         const int r = trow[t];
         if (mine) {
             atomicOr(&mine[r >> 5].x, 1u << (r & 31));
             atomicMin(&mine[r >> 5].y, (unsigned)(t - t0));
         }
         // item (off[b] + position in R_v) = (probe index, row): stage A reads it instead of searching `off`
-        if (items) items[t - t0] = make_int2((int)blockIdx.x, r);
+        if (items) items[t - t0] = make_int2(b, r);
     }
 }
 // position of column c in R_v from the probe's bitmap row, or -1
