@@ -152,6 +152,11 @@ def main():
                 "units_per_launch": f"one SpMM A_hat[{big.shape[0]}^2, nnz={big.nnz}] x S[{big.shape[0]}x{hcols}] fp32 "
                                     f"(R-MAT scale {scale}, max row {int(np.diff(big.indptr).max())})",
                 "gathered_bytes_per_launch": int(big.nnz) * hcols * 4, "host_graph_build_s": round(host_s, 1),
+                # every gathered byte passes L2 (~20 TB/s chip-wide when it hits): the cap on the ALGORITHMIC rate of a
+                # row-gather SpMM whatever the input's locality; measured 1.37 TB/s on a 2 M-node banded graph
+                "l2_gather_bound": {"L2_gather_GBps": 20000.0,
+                                    "max_algorithmic_GBps": round(20000.0 * byts / (int(big.nnz) * hcols * 4), 1),
+                                    "frac_of_that": round(byts / sec / 1e9 / (20000.0 * byts / (int(big.nnz) * hcols * 4)), 4)},
                 "note": "algorithmic bytes = SURVEY 8(d) (CSR once, S once, result once); a row-gather SpMM moves nnz*H*4 "
                         "bytes of gathered rows through L2, and what it cannot hold comes over the fabric: `traffic` "
                         "(FETCH_SIZE*2 + WRITE_SIZE, PMC) over avg_launch_us is the real HBM-side rate"}

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <functional>
 #include <new>
 #include <vector>
 
@@ -122,12 +123,14 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
     std::vector<int32_t> tptr((size_t)n + 1, 0), trow;
     std::vector<float> tval;
     int32_t max_row = 0;
+    int64_t n_local = 0;
     for (int32_t r = 0; r < n; ++r) {
         const int32_t b = rowptr[r], e = rowptr[r + 1];
         LT_REQUIRE(b <= e, "lt_graph_create: rowptr not monotone at row %d", r);
         if (e - b > max_row) max_row = e - b;
         for (int32_t k = b; k < e; ++k) {
             const int32_t c = col[k];
+            n_local += (c >= r ? c - r : r - c) <= LT_LOCAL_WINDOW;
             LT_REQUIRE(c >= 0 && c < n, "lt_graph_create: column %d out of range at row %d", c, r);
             LT_REQUIRE(k == b || col[k - 1] < c,
                        "lt_graph_create: columns of row %d are not strictly increasing", r);
@@ -135,6 +138,18 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
         }
     }
     int32_t max_col = 0;
+    double hot_frac = 1.0;
+    if (n > LT_HOT_COLUMNS && nnz > 0) {   // entries that read the LT_HOT_COLUMNS most-read columns
+        try {
+            std::vector<int32_t> indeg(tptr.begin() + 1, tptr.end());
+            std::nth_element(indeg.begin(), indeg.begin() + LT_HOT_COLUMNS, indeg.end(), std::greater<int32_t>());
+            int64_t hot = 0;
+            for (int i = 0; i < LT_HOT_COLUMNS; ++i) hot += indeg[i];
+            hot_frac = (double)hot / (double)nnz;
+        } catch (const std::bad_alloc &) {
+            return lt_set_error(LT_ERR_NOMEM, "lt_graph_create: host allocation failed");
+        }
+    }
     for (int32_t c = 0; c < n; ++c) {
         if (tptr[(size_t)c + 1] > max_col) max_col = tptr[(size_t)c + 1];
         tptr[(size_t)c + 1] += tptr[c];
@@ -161,6 +176,8 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
     g->nnz = nnz;
     g->max_row_nnz = max_row;
     g->max_col_nnz = max_col;
+    g->local_frac = nnz > 0 ? (float)((double)n_local / (double)nnz) : 1.f;
+    g->hot_frac = (float)hot_frac;
     const size_t pb = ((size_t)n + 1) * sizeof(int32_t);
     // +LT_CSR_PAD zero entries: the LDS-ring probe kernel reads (col, val) in 4-entry scalar bursts that
     // may run past a row's (and so the array's) end; padded columns are 0 (a valid node), values 0

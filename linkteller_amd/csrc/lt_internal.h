@@ -15,6 +15,8 @@ struct lt_graph {
     int64_t nnz = 0;
     int32_t max_row_nnz = 0;
     int32_t max_col_nnz = 0;
+    float local_frac = 0.f;   // share of the entries whose column lies within LT_LOCAL_WINDOW rows of their row
+    float hot_frac = 0.f;     // share of the entries that read one of the LT_HOT_COLUMNS most-read columns (skew)
     // CSR of A_hat (device)
     int32_t *rowptr = nullptr;
     int32_t *col = nullptr;
@@ -41,6 +43,8 @@ struct lt_graph {
     int32_t *w_cnt = nullptr;   // [w_n] entries (<= LT_ROW_SEG)
     int32_t *w_dst = nullptr;   // [w_n] row id, or n + segment id (index into the p_seg_* tables)
 };
+#define LT_HOT_COLUMNS 16384   // one XCD L2 (4 MiB) holds this many 256-byte row slices
+#define LT_LOCAL_WINDOW 8192   // |col - row| up to this counts as a local entry (8192 rows x 1 KiB = two XCD L2s)
 #define LT_ROW_SEG 128   // layer-1 chains: entries per segment (rows up to this length are one plain chain)
 #define LT_CSR_PAD 16   // zero entries appended to col/val
 

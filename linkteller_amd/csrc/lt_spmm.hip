@@ -136,8 +136,17 @@ __global__ __launch_bounds__(LT_BLOCK) void k_rows_tiled(
     __builtin_nontemporal_store(acc, reinterpret_cast<f32x4 *>(d));
 }
 
+// The tiled route pays when the gathers MISS and the misses are SKEWED: S beyond the L2s, a natural order without
+// locality, hot columns that a quarter-of-S-per-XCD cache can keep (R-MAT, power laws).  Measured on 2 M-node graphs of
+// average degree 33 (profiles/r02_spmm_lab_banded.txt): neighbours within +-4096 of the row index -- row kernel 3.5 ms
+// (whole-row 1 KiB gathers hit L2 and move at the L2 gather rate, 20 TB/s), tiled 5.5; uniformly random neighbours,
+// no hubs -- row kernel 11.2 ms, tiled 12.4 (nothing to keep in L2, and 256-byte pieces cost more per byte);
+// R-MAT -- row kernel 13.1 ms, tiled 7.6.  tiled_min_bytes <= 0 forces the tiled route (tests).
 bool lt_tiled_wanted(const lt_graph *g, int ncols) {
-    return g->w_n > 0 && ncols % 4 == 0 && (long long)g->n * ncols * (long long)sizeof(float) >= lt_tune().tiled_min_bytes;
+    if (g->w_n == 0 || ncols % 4 != 0) return false;
+    const long long thr = lt_tune().tiled_min_bytes;
+    if (thr <= 0) return true;
+    return (long long)g->n * ncols * (long long)sizeof(float) >= thr && g->local_frac < 0.5f && g->hot_frac >= 0.2f;
 }
 
 int lt_launch_rows_tiled(const lt_graph *g, const float *S, int64_t lds, int ncols, const float *init,

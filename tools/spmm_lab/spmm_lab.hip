@@ -243,6 +243,41 @@ static HostCsr make_rmat(int scale, long draws, uint64_t seed) {
     return g;
 }
 
+// a graph WITH locality: every node draws its neighbours within +-window of its own index (symmetrised, + I)
+static HostCsr make_banded(int scale, int deg, int window, uint64_t seed) {
+    const int n = 1 << scale;
+    std::mt19937_64 rng(seed);
+    std::vector<uint64_t> keys;
+    keys.reserve((size_t)n * (deg + 1) * 2);
+    for (int i = 0; i < n; ++i) {
+        for (int k = 0; k < deg / 2; ++k) {
+            long j = (long)i + (long)(rng() % (2 * window + 1)) - window;
+            if (j < 0) j += n;
+            if (j >= n) j -= n;
+            if (j == i) continue;
+            keys.push_back((uint64_t)i << 32 | (uint64_t)j);
+            keys.push_back((uint64_t)j << 32 | (uint64_t)i);
+        }
+        keys.push_back((uint64_t)i << 32 | (uint64_t)i);
+    }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    HostCsr g;
+    g.n = n;
+    g.rowptr.assign((size_t)n + 1, 0);
+    g.col.resize(keys.size());
+    g.val.resize(keys.size());
+    for (size_t i = 0; i < keys.size(); ++i) {
+        g.rowptr[(keys[i] >> 32) + 1]++;
+        g.col[i] = (int32_t)(keys[i] & 0xffffffffu);
+    }
+    for (int i = 0; i < n; ++i) g.rowptr[i + 1] += g.rowptr[i];
+    for (int r = 0; r < n; ++r)
+        for (int e = g.rowptr[r]; e < g.rowptr[r + 1]; ++e)
+            g.val[e] = g.col[e] == r ? 1.0f : 1.0f / (float)(g.rowptr[r + 1] - g.rowptr[r]);
+    return g;
+}
+
 template <typename T>
 static T *upload(const std::vector<T> &v, size_t pad = 0) {
     T *d = nullptr;
@@ -353,7 +388,9 @@ int main(int argc, char **argv) {
     const int reps = argc > 4 ? atoi(argv[4]) : 10;
     const char *only = argc > 5 ? argv[5] : "";
     auto t0 = std::chrono::steady_clock::now();
-    HostCsr g = make_rmat(scale, (long)ef << scale, 42);
+    // LAB_BANDED=<window>: a graph with locality instead of R-MAT (edge factor = average degree / 2)
+    const int banded = getenv("LAB_BANDED") ? atoi(getenv("LAB_BANDED")) : 0;
+    HostCsr g = banded ? make_banded(scale, 2 * ef, banded, 42) : make_rmat(scale, (long)ef << scale, 42);
     const long nnz = (long)g.col.size();
     int maxd = 0;
     for (int r = 0; r < g.n; ++r) maxd = std::max(maxd, g.rowptr[r + 1] - g.rowptr[r]);
