@@ -437,3 +437,35 @@ def test_randomised_cross_check(gpu, seed, tiled, monkeypatch):
         fuzz.main()
     finally:
         _lib.set_tuning("tiled_min_bytes", None)
+
+
+def test_auc_ap_at_config1_size(gpu):
+    """north_star: 'influence scores and AUC within 1e-4' -- at the BASELINE configs[1] graph size (twitch-RU shape,
+    N = 4385, F = 3170, H = 256), the reference's own sampler (unbalanced, seed 42) and pair lookup, n_test = 160 so that
+    the fp64 oracle (verbatim reference op sequence, 2 x 160 full forwards in fp64) stays within a minute: AUC and AP of
+    the delta-mode scores equal the fp64 reference's within 1e-4; full / sparse within their quantisation class."""
+    from linkteller_amd import engine, graph, synth
+    from linkteller_amd.sampling import construct_edge_sets_from_random_subgraph
+    from oracle import linkteller_oracle as O
+    adj, x, w = synth.twitch_like_problem("twitch-RU", hidden=256, n_classes=2, seed=0)
+    a_hat = graph.first_order_gcn(adj)
+    np.random.seed(42)
+    (ex, nex), nodes = construct_edge_sets_from_random_subgraph("twitch/ES/RU", "unbalanced", adj, 160)
+    nodes = np.asarray(nodes, dtype=np.int64)
+    base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *_params(w, gpu))
+    res = {m: base.influence_rows(nodes, nodes, 1e-4, m).cpu().numpy().astype(np.float64) for m in ("delta", "full", "sparse")}
+    assert np.array_equal(res["full"], res["sparse"])
+    t0 = time.time()
+    P64 = {k: torch.from_numpy(w[k]).double() for k in ("W1", "b1", "W2", "b2")}
+    ref64 = O.influence_matrix(torch.from_numpy(x).double(), O.to_torch_sparse(a_hat).double(), P64, nodes, 1e-4)
+    t_oracle = time.time() - t0
+    m64 = O.attack_metrics(*O.pair_scores(ref64, list(nodes), ex, nex))
+    got = {m: O.attack_metrics(*O.pair_scores(res[m], list(nodes), ex, nex)) for m in ("delta", "full")}
+    print(f"configs[1] size, n_test=160 ({len(ex)} edges / {len(nex)} non-edges; fp64 oracle {t_oracle:.0f} s): "
+          f"AUC ref64 {m64['auc']:.6f} delta {got['delta']['auc']:.6f} full {got['full']['auc']:.6f}; "
+          f"AP ref64 {m64['ap']:.6f} delta {got['delta']['ap']:.6f} full {got['full']['ap']:.6f}; "
+          f"max|delta-ref64| {np.abs(res['delta'] - ref64).max():.2e} on max score {ref64.max():.3g}")
+    assert np.abs(res["delta"] - ref64).max() <= 1e-5 * ref64.max()
+    assert abs(got["delta"]["auc"] - m64["auc"]) <= 1e-4 and abs(got["delta"]["ap"] - m64["ap"]) <= 1e-4
+    assert np.all(res["full"][ref64 == 0] == 0)
+    assert abs(got["full"]["auc"] - m64["auc"]) <= 2.5 / max(len(ex), 1)      # a couple of low-score edges quantised to 0
