@@ -9,8 +9,6 @@
 //     an ordered slab sum;
 //   * Z1d = A_hat*S1d + b1, row-owned fp64 fma chains.
 // One-off cost per baseline (not per probe); only built when delta mode is used.
-#include <stdlib.h>
-
 #include <new>
 #include <type_traits>
 
@@ -340,12 +338,10 @@ __global__ void k_spmm_f64_long(int n_long, const int32_t *__restrict__ long_row
 
 // K slice of the fp64 product (64x64 tiles, 4 waves, 8 workgroups per CU): the fewest slices (at least 400 deep) whose
 // workgroups still occupy every CU, and never more workgroups than are resident at once (256 CUs x 8) -- a ninth per CU
-// runs alone after the others (twitch-RU: 8 slices = 2208 workgroups, 134 us; 7 slices = 1932, all resident).
-// LT_F64_KSLICE overrides (experiments).
+// runs alone after the others (twitch-RU: 8 slices = 2208 workgroups; 7 slices = 1932, all resident; measured 134-137 us
+// for 6 ... 8 slices alike, the 64x64 kernel is not sensitive to it).
 static bool fp64_big(int n, int H) { return n >= 1024 && H % GE_BN == 0; }
 static int fp64_kslice(int n, int H, int F) {
-    static const long long forced = getenv("LT_F64_KSLICE") ? atoll(getenv("LT_F64_KSLICE")) : 0;
-    if (forced > 0) return (int)((forced + 15) / 16 * 16);
     if (fp64_big(n, H)) {
         // 128x128 tiles, two workgroups per CU: the slicing rule of the f32 product (whole rounds of 256 CUs)
         const long tiles = (long)((n + GE_BM - 1) / GE_BM) * (H / GE_BN);
