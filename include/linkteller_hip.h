@@ -68,6 +68,9 @@ int lt_device_count(int *count);
  *   "long_par"            hub rows in FULL stage A: 1 = segments in separate waves, 0 = one wave per row
  *   "overlap"             hub-row kernels on the baseline's side stream (1) or on the caller's (0)
  *   "item_bits"           SPARSE / DELTA stage B membership bitmap on (1) / off (0)
+ *   "pair_marks"          SPARSE / DELTA stage B: calls of at least this many (probe, observed) pairs per chunk -- and every
+ *                         call too large for a membership bitmap -- find the affected pairs through a join over the
+ *                         middle nodes; 0 = always, negative = never (default 2^22)
  *   "wide_min_hp"         smallest padded hidden width served by the batched stage-A kernel
  *   "tiled_big"           1 = the tiled SpMM uses its 64-bit gather offsets on any graph (test hook; default: S >= 4 GiB)
  *   "probe_kslice"        K-slice of the perturbed-row GEMM; 0 = the slicing of the baseline X*W1 (default: S1'[v] and

@@ -41,6 +41,7 @@ static lt_tuning tuning_defaults() {
     t.wide_min_hp = w > 0 ? (int)w : 24;
     const long long pk = env_ll("LT_PROBE_KSLICE", 0);
     t.probe_kslice = pk > 0 ? (int)pk : 0;
+    t.pair_marks = env_ll("LT_PAIR_MARKS", (long long)1 << 22);
     t.tiled_big = 0;
     return t;
 }
@@ -68,7 +69,8 @@ extern "C" int lt_set_tuning(const char *key, long long value) {
     else if (!strcmp(key, "wide_min_hp")) {
         LT_REQUIRE(reset || value > 0, "lt_set_tuning: wide_min_hp must be positive");
         t.wide_min_hp = reset ? d.wide_min_hp : (int)value;
-    } else if (!strcmp(key, "tiled_big")) t.tiled_big = reset ? 0 : (value != 0);
+    } else if (!strcmp(key, "pair_marks")) t.pair_marks = reset ? d.pair_marks : value;
+    else if (!strcmp(key, "tiled_big")) t.tiled_big = reset ? 0 : (value != 0);
     else if (!strcmp(key, "probe_kslice")) {
         LT_REQUIRE(reset || (value >= 0 && value <= 1 << 20), "lt_set_tuning: probe_kslice must be >= 0");
         t.probe_kslice = reset ? d.probe_kslice : (int)value;

@@ -405,7 +405,7 @@ extern "C" int lt_influence3_rows(const lt_baseline3 *b, const int32_t *probe_no
         int rc = lt_launch_gemm_splitk(b->X, b->ldx, b->W1, b->H1, w.Sp, Hp1, nb, b->H1, b->F, probe_kslice3(b), w.slabs, st,
                                        probes, delta);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_item_bits, dim3(nb), dim3(256), 0, st, g->tptr, g->trow, probes, nb, words, w.bits1, w.off, (int2 *)nullptr);
+        hipLaunchKernelGGL(k_item_bits, dim3(nb), dim3(256), 0, st, g->tptr, g->trow, probes, nb, words, w.bits1, w.off, (int2 *)nullptr, (uint2 *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
         LT_CHECK_LAUNCH();
         // level 1: H1x rows, then S2x = H1x W2 (M = number of items, only known on the device: the GEMM runs over the
         // chunk's upper bound nb * max column length and rows past the item count are never read)

@@ -411,9 +411,17 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma_128(const float *__restri
 int lt_launch_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
                    int M, int N, int K, hipStream_t st) {
     if (M == 0 || N == 0) return LT_OK;
+    lt_prof_scope prof_(LT_K_GEMM, st);
+    if (M >= 1024 && N % GL_BN == 0 && K > 0) {
+        // many rows, one slice (a 2 M-node graph with F = 256): the 128 x 128 tiles of the split-K product, same k order
+        dim3 gridl((M + GL_BM - 1) / GL_BM, N / GL_BN);
+        hipLaunchKernelGGL(k_gemm_f32_mfma_128, gridl, dim3(256), 0, st, A, (long)lda, B, (long)ldb, C, (long)ldc, M, N, K,
+                           K, 0L);
+        LT_CHECK_LAUNCH();
+        return LT_OK;
+    }
     dim3 grid((M + GM_BM - 1) / GM_BM, (N + GM_BN - 1) / GM_BN);
     LT_REQUIRE(grid.y <= 65535u, "lt_gemm_f32: N=%d too large", N);
-    lt_prof_scope prof_(LT_K_GEMM, st);
     hipLaunchKernelGGL(k_gemm_f32_mfma<false>, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, C,
                        (long)ldc, M, N, K, K > 0 ? K : 1, 0L, (const int32_t *)nullptr, 0.f);
     LT_CHECK_LAUNCH();

@@ -734,14 +734,25 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
     }
 }
 
-// SPARSE / DELTA stage B for an OBSERVED HUB (a row of more than LT_ROW_SEG entries): in k_item_stageB the 8 lanes of
-// a (probe, hub) pair walk 10^3 entries, each step a dependent col -> membership -> value round trip, and the launch
-// waits for those pairs.  Here a block (the first blocks of k_item_stageB's launch) takes one observed hub and 32 probes (a wave = 8 probes x the 8 chain lanes):
-// the row's (col, val, baseline S2 row) are fetched into LDS once per chunk by all 256 threads and shared by the 32
-// probes; the membership tests of a lane's next 8 entries are in flight together.  Same chains (entry e -> chain
+// SPARSE / DELTA stage B for an OBSERVED HUB (a row of more than LT_ROW_SEG entries).  A block (the first blocks of
+// k_item_stageB's launch) takes one observed hub and 32 probes, 8 chain lanes per probe.  A pair (hub u, probe v) is
+// affected through the members of row(u) /\ R_v, and which entries those are is found from the SHORT side:
+//   light probe (R_v short against the row -- see `heavy` below): its 8 lanes look every r of R_v up in the
+//       hub's sorted columns (branch-free lower bound, LT_SBL_NS searches in flight per lane) -- |R_v| log d loads
+//       instead of one membership test per ENTRY of the row (a 43 075-entry hub x 512 probes of ~ 30 neighbours each
+//       took 7.5 ms of lane-serial lookups that way).  DELTA adds the members it finds straight into the chains and
+//       never walks the row; SPARSE keeps them as a short sorted list and walks the row (it must: the whole chain is
+//       re-summed) comparing against the next member -- no lookups in the walk.
+//       The list holds LT_SBL_MC members at a time and is refilled as the walk passes them.
+//   heavy probe (R_v long against the row): one membership test per entry as before -- through the probe's bitmap
+//       row when it has one (all probes of a small call, the big probes of a large one: k_item_bits).
+// The row's (col, val, baseline S2 row) are fetched into LDS once per chunk by all 256 threads and shared by the 32
+// probes; the walk happens only if some probe of the block needs it.  Same chains in every route (entry e -> chain
 // (e - e0) & 7, k-ordered, non-members skipped in DELTA), same butterfly, same tail: the bits of k_item_stageB.
 #define LT_SBL_CHUNK 1024
 #define LT_SBL_UN 8
+#define LT_SBL_NS 8        // light probes: searches in flight per lane
+#define LT_SBL_MC 128      // SPARSE: members of a light probe kept in LDS at a time (> 64 + a search round: see fill)
 template <int CP, bool DELTA>
 __device__ __forceinline__ void stageB_long_block(
     int bid, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
@@ -750,54 +761,173 @@ __device__ __forceinline__ void stageB_long_block(
     const float *__restrict__ b2, const float *__restrict__ OUT,
     const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
     const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
-    float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words) {
+    float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words,
+    const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot) {
     constexpr int CHUNK = CP <= 2 ? LT_SBL_CHUNK : (CP <= 4 ? LT_SBL_CHUNK / 2 : LT_SBL_CHUNK / 4);   // LDS: <= 16 KB
+    constexpr int GROUPS = LT_BLOCK / LT_L2_LANES;
     __shared__ int sc[CHUNK];
     __shared__ float sv[CHUNK];
     __shared__ float sT[DELTA ? 1 : CHUNK][CP];
-    const int pblocks = (nb + LT_BLOCK / LT_L2_LANES - 1) / (LT_BLOCK / LT_L2_LANES);
+    __shared__ int2 smem[DELTA ? 1 : GROUPS][DELTA ? 1 : LT_SBL_MC];   // SPARSE, light probes: (entry - e0, position in R_v)
+    const int pblocks = (nb + GROUPS - 1) / GROUPS;
     const int j = bid / pblocks;
     const int u = observe[j];
     const int e0 = rowptr[u], e1 = rowptr[u + 1];
     if (e1 - e0 <= LT_ROW_SEG) return;           // not a hub: k_item_stageB has it (block-uniform exit)
+    const int d = e1 - e0;
     const int tid = threadIdx.x;
     const int q = tid & (LT_L2_LANES - 1);
-    const int b = (bid % pblocks) * (LT_BLOCK / LT_L2_LANES) + tid / LT_L2_LANES;
+    const int grp = tid / LT_L2_LANES;
+    const int b = (bid % pblocks) * GROUPS + grp;
     const bool live = b < nb;
     const int v = probes[live ? b : 0];
     const int32_t *rv = trow + tptr[v];
     const int cnt = tptr[v + 1] - tptr[v];
     const float *items = S2x + (size_t)off[live ? b : 0] * C;
-    const uint2 *mb = bits ? bits + (size_t)(live ? b : 0) * words : nullptr;
+    const uint2 *mb = nullptr;
+    if (bits) mb = bits + (size_t)(live ? b : 0) * words;
+    else if (big_slot && live && big_slot[b] >= 0) mb = big_bits + (size_t)big_slot[b] * words;
     auto pos = [&](int c) { return mb ? bits_pos(mb, c) : find_row(rv, cnt, c); };
     float acc[CP];
 #pragma unroll
     for (int c = 0; c < CP; ++c) acc[c] = 0.f;
     bool touch = false;
-    for (int cb = e0; cb < e1; cb += CHUNK) {
-        const int nc = min(CHUNK, e1 - cb);
-        __syncthreads();
-        for (int i = tid; i < nc; i += LT_BLOCK) {
-            const int cc = col[cb + i];
-            sc[i] = cc;
-            sv[i] = val[cb + i];
-            if (!DELTA) {
+    // ---- light probes: the members of row(u) /\ R_v from the R_v side ---------------------------------------------
+    // (group-uniform) per-entry tests cost d / 64 rounds of one load (a miss, ~ 2x an L2 hit) with a bitmap row, of
+    // log |R_v| loads without; the search from the R_v side costs |R_v| / (8 NS) rounds of log d loads
+    const int lg_d = 32 - __clz(d), lg_c = 32 - __clz(cnt > 1 ? cnt : 1);
+    const bool heavy = live && (mb ? (long)cnt * lg_d > d : 2L * cnt * lg_d > (long)d * lg_c);
+    const bool light = live && !heavy;
+    const int32_t *cu = col + e0;
+    const int gl0 = (tid & 63) & ~(LT_L2_LANES - 1);    // first lane of the group inside its wave
+    int nmem = 0;       // SPARSE: members in the list (group-uniform)
+    int r_next = 0;     // next position of R_v to look up (group-uniform)
+    // one round: R_v[r_next + (0 .. 8 * NS)) looked up in the hub's columns, the finds handed round the group in
+    // ascending order of R_v (= ascending entry).  DELTA: chain (e & 7) adds its own; SPARSE: appended to the list.
+    auto search_round = [&]() {
+        int fe[LT_SBL_NS], key[LT_SBL_NS], base[LT_SBL_NS];
 #pragma unroll
-                for (int c = 0; c < CP; ++c) sT[i][c] = c < C ? S2[(size_t)cc * C + c] : 0.f;
-            }
+        for (int k = 0; k < LT_SBL_NS; ++k) {
+            const int idx = r_next + k * LT_L2_LANES + q;
+            key[k] = idx < cnt ? rv[idx] : 0x7fffffff;
+            base[k] = 0;
         }
-        __syncthreads();
-        if (live) {
+        // branch-free lower bound over cu[0, d): LT_SBL_NS independent searches per lane, one load each per step
+        for (int nrem = d; nrem > 1;) {
+            const int half = nrem >> 1;
+#pragma unroll
+            for (int k = 0; k < LT_SBL_NS; ++k) base[k] = cu[base[k] + half - 1] < key[k] ? base[k] + half : base[k];
+            nrem -= half;
+        }
+#pragma unroll
+        for (int k = 0; k < LT_SBL_NS; ++k) {
+            if (cu[base[k]] < key[k]) ++base[k];
+            fe[k] = (base[k] < d && cu[base[k]] == key[k]) ? base[k] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < LT_SBL_NS; ++k)
+#pragma unroll
+            for (int t = 0; t < LT_L2_LANES; ++t) {
+                const int e = __shfl(fe[k], gl0 + t, 64);
+                if (e < 0) continue;                       // group-uniform
+                const int p = r_next + k * LT_L2_LANES + t;   // position in R_v
+                if (DELTA) {
+                    touch = true;
+                    if ((e & (LT_L2_LANES - 1)) == q) {
+                        const float a = val[e0 + e];
+                        const float *tr = items + (size_t)p * C;
+#pragma unroll
+                        for (int c = 0; c < CP; ++c)
+                            if (c < C) acc[c] = fmaf(a, tr[c], acc[c]);
+                    }
+                } else {
+                    if (q == 0) smem[grp][nmem] = make_int2(e, p);
+                    ++nmem;
+                }
+            }
+        r_next += LT_L2_LANES * LT_SBL_NS;
+        if (!DELTA) __builtin_amdgcn_wave_barrier();    // lane 0's list writes stay ahead of the group's reads
+    };
+    // SPARSE: (re)fill the member list -- drop the members every lane has passed (entry < base_e), search on until the
+    // list holds more than LT_SBL_MC - 8 * LT_SBL_NS members (then it reaches past the 64 entries the group handles next) or R_v
+    // is exhausted
+    auto fill = [&](int base_e) {
+        int f = 0;
+        while (f < nmem && smem[grp][f].x < base_e) ++f;
+        if (f > 0) {
+            for (int i = q; i < nmem - f; i += LT_L2_LANES) {     // lockstep: the reads of a trip precede its writes
+                const int2 m = smem[grp][f + i];
+                __builtin_amdgcn_wave_barrier();
+                smem[grp][i] = m;
+            }
+            __builtin_amdgcn_wave_barrier();
+            nmem -= f;
+        }
+        while (r_next < cnt && nmem <= LT_SBL_MC - LT_L2_LANES * LT_SBL_NS) search_round();
+    };
+    if (light) {
+        if (DELTA) while (r_next < cnt) search_round();
+        else fill(0);
+    }
+    // ---- the walk: heavy probes test every entry, SPARSE light probes with members re-sum the row against their list
+    const bool walk = live && (heavy || (!DELTA && nmem > 0));
+    if (__syncthreads_or(walk ? 1 : 0)) {
+        // SPARSE light (all group-uniform): mg = first listed member not yet behind the group, next_e = its entry,
+        // last_e = the entry of the last listed member
+        int mg = 0;
+        int next_e = (!DELTA && nmem > 0) ? smem[grp][0].x : 0x7fffffff;
+        int last_e = (!DELTA && nmem > 0) ? smem[grp][nmem - 1].x : -1;
+        for (int cb = e0; cb < e1; cb += CHUNK) {
+            const int nc = min(CHUNK, e1 - cb);
+            __syncthreads();
+            for (int i = tid; i < nc; i += LT_BLOCK) {
+                const int cc = col[cb + i];
+                sc[i] = cc;
+                sv[i] = val[cb + i];
+                if (!DELTA) {
+#pragma unroll
+                    for (int c = 0; c < CP; ++c) sT[i][c] = c < C ? S2[(size_t)cc * C + c] : 0.f;
+                }
+            }
+            __syncthreads();
+            if (!walk) continue;
             for (int i = q; i < nc; i += LT_L2_LANES * LT_SBL_UN) {
                 int mp[LT_SBL_UN];
                 float a_[LT_SBL_UN], tb[LT_SBL_UN][CP];
 #pragma unroll
-                for (int k = 0; k < LT_SBL_UN; ++k) {   // the membership loads of 8 entries in flight together
+                for (int k = 0; k < LT_SBL_UN; ++k) {
                     const int ii = i + k * LT_L2_LANES;
-                    mp[k] = ii < nc ? pos(sc[ii]) : -1;
+                    mp[k] = -1;
                     a_[k] = ii < nc ? sv[ii] : 0.f;
 #pragma unroll
                     for (int c = 0; c < CP; ++c) tb[k][c] = (!DELTA && ii < nc) ? sT[ii][c] : 0.f;
+                }
+                if (heavy) {
+#pragma unroll
+                    for (int k = 0; k < LT_SBL_UN; ++k) {   // the membership loads of 8 entries in flight together
+                        const int ii = i + k * LT_L2_LANES;
+                        if (ii < nc) mp[k] = pos(sc[ii]);
+                    }
+                } else if (!DELTA) {
+                    const int base_e = cb - e0 + (i - q);       // the group's next 64 entries start here
+                    const int end_e = base_e + LT_L2_LANES * LT_SBL_UN;
+                    if (r_next < cnt && last_e < end_e) {       // the list may end inside them: refill it
+                        fill(base_e);
+                        mg = 0;
+                        next_e = nmem > 0 ? smem[grp][0].x : 0x7fffffff;
+                        last_e = nmem > 0 ? smem[grp][nmem - 1].x : -1;
+                    }
+                    while (next_e < base_e) { ++mg; next_e = mg < nmem ? smem[grp][mg].x : 0x7fffffff; }
+                    // the members among the 64 (group-uniform trips, usually none): entry base_e + 8 k + q is lane q's k-th
+                    while (next_e < end_e) {
+                        const int rel = next_e - base_e, p = smem[grp][mg].y;
+                        const bool mine = (rel & (LT_L2_LANES - 1)) == q;
+#pragma unroll
+                        for (int k = 0; k < LT_SBL_UN; ++k)
+                            if (mine && (rel >> 3) == k) mp[k] = p;
+                        ++mg;
+                        next_e = mg < nmem ? smem[grp][mg].x : 0x7fffffff;
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < LT_SBL_UN; ++k) {
@@ -831,8 +961,8 @@ __device__ __forceinline__ void stageB_long_block(
 #pragma unroll
             for (int c = 0; c < CP; ++c)
                 if (c < C) {
-                    const float d = acc[c] / delta;
-                    ss = fmaf(d, d, ss);
+                    const float d_ = acc[c] / delta;
+                    ss = fmaf(d_, d_, ss);
                 }
             res = sqrtf(ss);
         } else {
@@ -851,12 +981,13 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
     const float *__restrict__ b2, const float *__restrict__ OUT,
     const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
     const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
-    float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words, int long_blocks) {
+    float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words, int long_blocks,
+    const unsigned *__restrict__ marks, const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot) {
     // long_blocks > 0 (the graph has hub rows): the first long_blocks blocks serve the observed hubs
     // (stageB_long_block: most of them find a plain row and exit), the pairs below skip those rows
     if ((int)blockIdx.x < long_blocks) {
         stageB_long_block<CP, DELTA>((int)blockIdx.x, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off, S2x,
-                                     observe, n_obs, delta, out, ldo, bits, words);
+                                     observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot);
         return;
     }
     const bool skip_long = long_blocks > 0;
@@ -873,15 +1004,21 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
     if (skip_long && e1 - e0 > LT_ROW_SEG) return;   // an observed hub: one of the first blocks
 
     // does row u touch R_v at all?  (otherwise the perturbed logits ARE the baseline logits)
-    const uint2 *mb = bits ? bits + (size_t)b * words : nullptr;
+    const uint2 *mb = bits ? bits + (size_t)b * words
+                           : ((big_slot && big_slot[b] >= 0) ? big_bits + (size_t)big_slot[b] * words : nullptr);
     // position of column c in R_v (-1: not a member): the bitmap when there is one, the search otherwise
     auto pos = [&](int c) { return mb ? bits_pos(mb, c) : find_row(rv, cnt, c); };
-    bool touch = false;
-    for (int e = e0 + q; e < e1; e += LT_L2_LANES) touch |= pos(col[e]) >= 0;
-    // 8-lane any(): xor butterfly on an int
-    int t = touch ? 1 : 0;
+    int t;
+    if (marks) {   // the join over the middle nodes has answered it (k_pm_mark): one bit per pair
+        t = (marks[gid >> 5] >> (gid & 31)) & 1u;
+    } else {
+        bool touch = false;
+        for (int e = e0 + q; e < e1; e += LT_L2_LANES) touch |= pos(col[e]) >= 0;
+        // 8-lane any(): xor butterfly on an int
+        t = touch ? 1 : 0;
 #pragma unroll
-    for (int m = LT_L2_LANES / 2; m >= 1; m >>= 1) t |= __shfl_xor(t, m, 64);
+        for (int m = LT_L2_LANES / 2; m >= 1; m >>= 1) t |= __shfl_xor(t, m, 64);
+    }
     float res = 0.f;
     if (t) {  // group-uniform
         float acc[CP];
@@ -965,12 +1102,16 @@ struct infl_ws {
     float *S2x;            // SPARSE / DELTA: per-item values
     int32_t *off;          // SPARSE / DELTA: item offsets [chunk + 1]
     int2 *item_pr;         // SPARSE / DELTA: (probe index, row) of every item
+    int32_t *pm_cnt, *pm_start, *pm_rank, *pm_list;   // SPARSE / DELTA pair marks: per-node lists of observed nodes (lt_items.cuh)
+    unsigned *pm_marks;    // SPARSE / DELTA: one bit per (probe of the chunk, observed node)
+    uint2 *big_bits;       // SPARSE / DELTA without `bits`: bitmap rows of the chunk's big probes [LT_BIG_SLOTS][ceil(n / 32)]
+    int32_t *big_slot;     // [chunk + 1] slot of each probe (-1: none) + the slot counter
     uint2 *bits;           // SPARSE / DELTA: membership bitmap + positions of R_v per probe [chunk][ceil(n / 32)], or NULL (huge graphs)
     size_t bytes;
     int chunk;
 };
 
-static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mode) {
+static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int n_obs, int mode) {
     infl_ws w = {};
     const size_t n = (size_t)b->n, C = (size_t)b->C, Hp = (size_t)b->Hp, F = (size_t)b->F;
     const size_t maxc = (size_t)(b->g->max_col_nnz > 0 ? b->g->max_col_nnz : 1);
@@ -1009,6 +1150,18 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
         // ("item_bits" = 0 forces the search path a huge graph takes: tests)
         const bool no_bits = lt_tune().item_bits == 0;
         w.bits = (!no_bits && chunk * bw * sizeof(uint2) <= LT_BITS_MAX_BYTES) ? (uint2 *)take(chunk * bw * sizeof(uint2)) : nullptr;
+        if (!w.bits && !no_bits) {
+            w.big_bits = (uint2 *)take((size_t)LT_BIG_SLOTS * bw * sizeof(uint2));
+            w.big_slot = (int32_t *)take((chunk + 1) * sizeof(int32_t));
+        }
+        if (lt_tune().pair_marks >= 0) {
+            const size_t slots = (size_t)(n_obs > 0 ? n_obs : 1) * LT_ROW_SEG;
+            w.pm_cnt = (int32_t *)take((n + 1) * sizeof(int32_t));     // [n] counts + the list cursor
+            w.pm_start = (int32_t *)take(n * sizeof(int32_t));
+            w.pm_rank = (int32_t *)take(slots * sizeof(int32_t));
+            w.pm_list = (int32_t *)take(slots * sizeof(int32_t));
+            w.pm_marks = (unsigned *)take((chunk * (size_t)(n_obs > 0 ? n_obs : 1) + 31) / 32 * sizeof(unsigned));
+        }
     }
     w.bytes = offb;
     return w;
@@ -1016,9 +1169,8 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int mod
 
 extern "C" size_t lt_influence_workspace_bytes(const lt_baseline *b, int32_t n_probe, int32_t n_obs,
                                                int32_t mode) {
-    (void)n_obs;
-    if (!b || n_probe < 0 || mode < LT_MODE_FULL || mode > LT_MODE_DELTA) return 0;
-    return carve_infl(nullptr, b, n_probe, mode).bytes;
+    if (!b || n_probe < 0 || n_obs < 0 || mode < LT_MODE_FULL || mode > LT_MODE_DELTA) return 0;
+    return carve_infl(nullptr, b, n_probe, n_obs, mode).bytes;
 }
 
 extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_nodes, int32_t n_probe,
@@ -1039,7 +1191,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
 
     hipStream_t st = (hipStream_t)stream;
     const lt_graph *g = b->g;
-    const infl_ws w = carve_infl(workspace, b, n_probe, mode);
+    const infl_ws w = carve_infl(workspace, b, n_probe, n_obs, mode);
     const int lpr = lt_lpr_for(b->Hp), cp = lt_cp_for(b->C), C = b->C, Hp = b->Hp, n = b->n;
     // SPARSE / DELTA read the baseline activations (Z1, S2, OUT; DELTA the fp64 Z1 when enabled); FULL forms
     // what it needs of them itself
@@ -1054,6 +1206,23 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
         if (mode == LT_MODE_FULL) rc = lt_baseline_ensure_s1(b, st);
         else rc = lt_baseline_ensure_layers(b, mode == LT_MODE_DELTA, st, !delta64);
         if (rc) return rc;
+    }
+
+    // SPARSE / DELTA, large calls: the per-node lists of observed nodes, once per call (lt_items.cuh "pair marks")
+    // (with a membership bitmap the per-pair scan is one load per entry and the join pays from ~ 4 M pairs on -- measured
+    // at twitch-RU size, tools/marks_ab.py; without one -- large graphs -- it always does)
+    const bool use_marks = mode != LT_MODE_FULL && w.pm_cnt != nullptr &&
+                           (w.bits == nullptr || (long long)(n_probe < w.chunk ? n_probe : w.chunk) * n_obs >= lt_tune().pair_marks);
+    if (use_marks) {
+        LT_REQUIRE((long)n_obs * LT_ROW_SEG / 256 + 1 < 2147483647L, "lt_influence_rows: n_obs=%d exceeds the grid limit", n_obs);
+        const unsigned gl = (unsigned)(((long)n_obs * LT_ROW_SEG + 255) / 256);
+        LT_HIP(hipMemsetAsync(w.pm_cnt, 0, ((size_t)n + 1) * sizeof(int32_t), st));
+#define LT_PM_ARGS g->rowptr, g->col, observe_nodes, n_obs, w.pm_cnt, w.pm_start, w.pm_rank, w.pm_list, w.pm_cnt + n
+        hipLaunchKernelGGL(k_pm_lists<0>, dim3(gl), dim3(256), 0, st, LT_PM_ARGS);
+        hipLaunchKernelGGL(k_pm_lists<1>, dim3(gl), dim3(256), 0, st, LT_PM_ARGS);
+        hipLaunchKernelGGL(k_pm_lists<2>, dim3(gl), dim3(256), 0, st, LT_PM_ARGS);
+#undef LT_PM_ARGS
+        LT_CHECK_LAUNCH();
     }
 
     for (int p0 = 0; p0 < n_probe; p0 += w.chunk) {
@@ -1168,8 +1337,18 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
         } else {
             const int words = (n + 31) / 32;
             // item offsets, the (probe, row) table of the items and the membership bitmap, one block per probe
-            hipLaunchKernelGGL(k_item_bits, dim3(nb), dim3(256), 0, st, g->tptr, g->trow, probes, nb, words, w.bits, w.off, w.item_pr);
+            if (w.big_slot) LT_HIP(hipMemsetAsync(w.big_slot + w.chunk, 0, sizeof(int32_t), st));
+            hipLaunchKernelGGL(k_item_bits, dim3(nb), dim3(256), 0, st, g->tptr, g->trow, probes, nb, words, w.bits, w.off, w.item_pr,
+                               w.big_bits, w.big_slot, w.big_slot ? w.big_slot + w.chunk : (int32_t *)nullptr);
             LT_CHECK_LAUNCH();
+            const unsigned *marks = nullptr;
+            if (use_marks) {
+                LT_HIP(hipMemsetAsync(w.pm_marks, 0, (size_t)((pairs + 31) / 32) * sizeof(unsigned), st));
+                hipLaunchKernelGGL(k_pm_mark, dim3(LT_ITEM_GRID), dim3(256), 0, st, w.off, nb, w.item_pr, w.pm_cnt, w.pm_start,
+                                   w.pm_list, n_obs, w.pm_marks);
+                LT_CHECK_LAUNCH();
+                marks = w.pm_marks;
+            }
             if (mode == LT_MODE_SPARSE) {
                 { lt_prof_scope prof_(LT_K_ITEM_A, st);
                 LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
@@ -1184,7 +1363,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
                                                        g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
                                                        nb, w.off, w.S2x, observe_nodes, n_obs, delta,
-                                                       orow, (long)ldo, w.bits, words, (int)long_blocks));
+                                                       orow, (long)ldo, w.bits, words, (int)long_blocks, marks, w.big_bits, w.big_slot));
             } else {
                 { lt_prof_scope prof_(LT_K_ITEM_A, st);
                 if (b->Z1d) {
@@ -1208,7 +1387,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
                                                        g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
                                                        nb, w.off, w.S2x, observe_nodes, n_obs, delta,
-                                                       orow, (long)ldo, w.bits, words, (int)long_blocks));
+                                                       orow, (long)ldo, w.bits, words, (int)long_blocks, marks, w.big_bits, w.big_slot));
             }
             LT_CHECK_LAUNCH();
         }

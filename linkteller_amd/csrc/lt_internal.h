@@ -101,6 +101,9 @@ struct lt_tuning {
     int item_bits;               // SPARSE / DELTA stage B membership bitmap (LT_ITEM_BITS)
     int wide_min_hp;             // smallest padded hidden width served by the batched stage-A kernel (LT_WIDE_MIN_HP)
     int probe_kslice;            // K-slice of the perturbed-row GEMM, 0 = the baseline product's slicing (LT_PROBE_KSLICE)
+    long long pair_marks;        // SPARSE / DELTA stage B: chunks of at least this many (probe, observed) pairs -- and any call without
+                                 // a membership bitmap -- find the affected pairs through the middle-node join (k_pm_*); 0 = always,
+                                 // < 0 = never (LT_PAIR_MARKS)
     int tiled_big;               // 1: the tiled SpMM always uses 64-bit gather offsets (test hook; default: only when S spans >= 4 GiB)
 };
 lt_tuning &lt_tune();

@@ -30,15 +30,24 @@ __device__ __forceinline__ int find_row(const int32_t *__restrict__ rows, int cn
 // both whether an entry of an observed row is affected by the probe and which item replaces it:
 //     position(r) = base + popcount(mask & ((1 << (r & 31)) - 1))
 // (without the bitmap -- huge graphs -- both questions are a binary search in R_v).  One block per probe.
+// A call too large for a bitmap row per probe (bits == NULL) still gives one to its BIG probes -- the up to
+// LT_BIG_SLOTS probes of the chunk whose R_v has more than LT_BIG_RV members (a hub probed): big_bits[slot], slot =
+// big_slot[b] (or -1).  Searching such a list once per entry of an observed hub row is what made those pairs slow.
+#define LT_BIG_RV 512
+#define LT_BIG_SLOTS 64
 static __global__ __launch_bounds__(256) void k_item_bits(const int32_t *__restrict__ tptr, const int32_t *__restrict__ trow,
                                                    const int32_t *__restrict__ probes, int nb, int words,
                                                    uint2 *__restrict__ bits, int32_t *__restrict__ off,
-                                                   int2 *__restrict__ item_pr) {
+                                                   int2 *__restrict__ item_pr, uint2 *__restrict__ big_bits,
+                                                   int32_t *__restrict__ big_slot, int32_t *__restrict__ big_count) {
     // One block per probe.  It also forms the probe's item offset off[b] = sum of |R_v| over the probes before it
     // (every block sums its own prefix: nb^2 / 2 four-byte loads in all, no scan kernel in front), the last block
     // writes the total off[nb].  bits == NULL: no bitmap (huge graphs); item_pr == NULL: no (probe, row) table.
     __shared__ int32_t red[4];
+    __shared__ int32_t s_slot;
     const int b = blockIdx.x;
+    const int v = probes[b];
+    const int t0 = tptr[v], t1 = tptr[v + 1];
     int part = 0;
     for (int i = threadIdx.x; i < b; i += blockDim.x) {
         const int vi = probes[i];
@@ -47,13 +56,21 @@ static __global__ __launch_bounds__(256) void k_item_bits(const int32_t *__restr
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
-    uint2 *mine = bits ? bits + (size_t)b * words : nullptr;
+    if (threadIdx.x == 0) {
+        int slot = -1;
+        if (!bits && big_bits && t1 - t0 > LT_BIG_RV) {
+            slot = atomicAdd(big_count, 1);
+            if (slot >= LT_BIG_SLOTS) slot = -1;
+        }
+        s_slot = slot;
+        if (big_slot) big_slot[b] = slot;
+    }
+    __syncthreads();
+    uint2 *mine = bits ? bits + (size_t)b * words : (s_slot >= 0 ? big_bits + (size_t)s_slot * words : nullptr);
     if (mine)
         for (int i = threadIdx.x; i < words; i += blockDim.x) mine[i] = make_uint2(0u, 0xffffffffu);
     __syncthreads();
     const int my_off = red[0] + red[1] + red[2] + red[3];
-    const int v = probes[b];
-    const int t0 = tptr[v], t1 = tptr[v + 1];
     if (threadIdx.x == 0) {
         off[b] = my_off;
         if (b == nb - 1) off[nb] = my_off + (t1 - t0);
@@ -74,6 +91,58 @@ __device__ __forceinline__ int bits_pos(const uint2 *__restrict__ mb, int c) {
     const uint2 w = mb[c >> 5];
     const unsigned bit = 1u << (c & 31);
     return (w.x & bit) ? (int)(w.y + __popc(w.x & (bit - 1u))) : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pair marks (large calls): which (probe b, observed j) pairs does a probe reach at all?  Pair (b, j) is affected
+// iff some entry r of row u_j is an item of probe b (r in R_v) -- a path u_j - r - v.  Testing that per pair costs
+// deg(u_j) membership lookups for EVERY pair (2 M pairs x 31 entries at BASELINE configs[4], 98 % of them for
+// nothing); the join over the middle node r costs (entries of the observed rows) + (items) + (paths):
+//   k_pm_count / k_pm_alloc / k_pm_place   once per call: for every node r the list of observed j whose row holds r
+//                                          (counts, a cursor-allocated slice of `list`, the members; the order inside a
+//                                          slice is arbitrary -- marks are an OR)
+//   k_pm_mark                              per probe chunk: item (b, r) -> set bit (b, j) for every j listed under r
+// Observed hubs (rows of more than LT_ROW_SEG entries) are not listed: stage B serves them for every probe anyway
+// (stageB_long_block), so an observed row contributes at most LT_ROW_SEG entries and slot k = j * LT_ROW_SEG + i needs
+// no prefix sum.  Stage B then reads one bit per pair; the marked pairs are computed exactly as before.
+// ------------------------------------------------------------------------------------------------
+template <int PHASE>   // 0 count, 1 allocate, 2 place
+static __global__ __launch_bounds__(256) void k_pm_lists(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                         const int32_t *__restrict__ observe, int n_obs,
+                                                         int32_t *__restrict__ cnt, int32_t *__restrict__ start,
+                                                         int32_t *__restrict__ rank, int32_t *__restrict__ list,
+                                                         int32_t *__restrict__ cursor) {
+    const long k = (long)blockIdx.x * 256 + threadIdx.x;
+    const int j = (int)(k / LT_ROW_SEG), i = (int)(k % LT_ROW_SEG);
+    if (j >= n_obs) return;
+    const int u = observe[j];
+    const int e0 = rowptr[u], d = rowptr[u + 1] - e0;
+    if (d > LT_ROW_SEG || i >= d) return;
+    const int r = col[e0 + i];
+    if (PHASE == 0) rank[k] = atomicAdd(&cnt[r], 1);
+    else if (PHASE == 1) { if (rank[k] == 0) start[r] = atomicAdd(cursor, cnt[r]); }
+    else list[start[r] + rank[k]] = j;
+}
+
+// 8 lanes per item: the item's list of observed nodes is a contiguous slice
+static __global__ __launch_bounds__(256) void k_pm_mark(const int32_t *__restrict__ off, int nb, const int2 *__restrict__ item_pr,
+                                                        const int32_t *__restrict__ cnt, const int32_t *__restrict__ start,
+                                                        const int32_t *__restrict__ list, int n_obs,
+                                                        unsigned *__restrict__ marks) {
+    const int total = off[nb];
+    const int q = threadIdx.x & 7;
+    const long g0 = ((long)blockIdx.x * 256 + threadIdx.x) >> 3, gstride = (long)gridDim.x * 32;
+    for (long item = g0; item < total; item += gstride) {
+        const int2 pr = item_pr[item];
+        const int c = cnt[pr.y];
+        if (c == 0) continue;
+        const int32_t *l = list + start[pr.y];
+        const long base = (long)pr.x * n_obs;
+        for (int t = q; t < c; t += 8) {
+            const long p = base + l[t];
+            atomicOr(&marks[p >> 5], 1u << (p & 31));
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -172,9 +172,10 @@ class Baseline:
         elif out.shape != (npb, nob) or out.dtype != torch.float32 or not out.is_contiguous():
             raise ValueError("out must be a contiguous float32 [n_probe, n_obs] tensor")
         key = (npb, nob, m)
+        need = _lib.lib().lt_influence_workspace_bytes(self._h, npb, nob, m)   # host arithmetic; depends on the tuning knobs too
         ws = self._ws.get(key)
-        if ws is None:
-            ws = _workspace(_lib.lib().lt_influence_workspace_bytes(self._h, npb, nob, m), dev)
+        if ws is None or ws.numel() < need:
+            ws = _workspace(need, dev)
             self._ws = {key: ws}   # keep only the latest: sizes repeat across steps
         _lib.check(_lib.lib().lt_influence_rows(self._h, probes.data_ptr(), npb, obs.data_ptr(), nob,
                                                 float(delta), m, out.data_ptr(), nob, ws.data_ptr(),

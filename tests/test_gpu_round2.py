@@ -469,3 +469,76 @@ def test_auc_ap_at_config1_size(gpu):
     assert abs(got["delta"]["auc"] - m64["auc"]) <= 1e-4 and abs(got["delta"]["ap"] - m64["ap"]) <= 1e-4
     assert np.all(res["full"][ref64 == 0] == 0)
     assert abs(got["full"]["auc"] - m64["auc"]) <= 2.5 / max(len(ex), 1)      # a couple of low-score edges quantised to 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["powerlaw", "er", "directed"])
+def test_pair_marks_route_keeps_every_bit(gpu, family):
+    """Large SPARSE / DELTA calls find the affected (probe, observed) pairs through a join over the middle nodes
+    (`pair_marks`, lt_items.cuh) instead of a membership scan per pair.  Forced on (0) and off (-1) on small graphs
+    -- hub rows on both sides, a non-symmetric pattern, several probe chunks, with and without the membership
+    bitmap, duplicated observed nodes -- the matrices must agree bit for bit, and `sparse` must still equal `full`."""
+    import scipy.sparse as sp
+    from linkteller_amd import _lib, engine, graph, synth
+    if family == "powerlaw":
+        a_hat = graph.first_order_gcn(synth.powerlaw_graph(900, 6000, seed=7))
+        assert np.diff(a_hat.indptr).max() > 300
+    elif family == "er":
+        a_hat = graph.first_order_gcn(synth.erdos_renyi_graph(1200, 9000, seed=3))
+    else:   # a pattern that is NOT symmetric: paths u - r - v must follow rows on one side and columns on the other
+        rng = np.random.RandomState(5)
+        n = 800
+        m = sp.random(n, n, density=0.01, random_state=rng, format="csr", dtype=np.float32)
+        m.data[:] = rng.uniform(0.05, 0.5, m.nnz).astype(np.float32)
+        a_hat = (m + sp.eye(n, dtype=np.float32, format="csr") * 0.3).tocsr()
+        a_hat.sort_indices()
+        assert (a_hat != a_hat.T).nnz > 0
+    n = a_hat.shape[0]
+    x = synth.gaussian_features(n, 64, seed=2)
+    w = synth.gcn_weights(64, 256, 3, seed=3)
+    base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *_params(w, gpu))
+    rng = np.random.RandomState(1)
+    deg = np.diff(a_hat.indptr)
+    hub = int(np.argmax(deg))
+    try:
+        for n_probe, n_obs, budget, bits in ((1, 1, None, 1), (37, 150, None, 1), (90, 333, 1 << 16, 1), (64, 200, None, 0)):
+            probes = rng.choice(n, n_probe, replace=False)
+            obs = rng.choice(n, n_obs, replace=False)
+            if n_obs > 10:
+                obs[0] = hub                     # an observed hub (served by the long blocks, not listed)
+                obs[5] = obs[6]                  # a duplicate
+                probes[0] = hub if n_probe > 1 else probes[0]
+            _lib.set_tuning("chunk_budget_bytes", budget)
+            _lib.set_tuning("item_bits", bits)
+            res = {}
+            for pm in (-1, 0):
+                _lib.set_tuning("pair_marks", pm)
+                for mode in ("sparse", "delta"):
+                    res[pm, mode] = base.influence_rows(probes, obs, 1e-4, mode).cpu().numpy()
+            for mode in ("sparse", "delta"):
+                assert np.array_equal(res[-1, mode], res[0, mode]), (family, n_probe, n_obs, mode)
+            full = base.influence_rows(probes, obs, 1e-4, "full").cpu().numpy()
+            assert np.array_equal(full, res[0, "sparse"])
+            assert np.isfinite(full).all() and (n_probe == 1 or full.max() > 0)
+    finally:
+        for k in ("chunk_budget_bytes", "item_bits", "pair_marks"):
+            _lib.set_tuning(k, None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,k,n", [(1500, 256, 256), (2048, 77, 128), (1031, 300, 256)])
+def test_gemm_tile_routes_give_the_same_rows(gpu, m, k, n):
+    """`lt_gemm_f32` serves a tall product (M >= 1024, N a multiple of 128: X*W1 of a 2 M-node graph with F = 256) with
+    the 128 x 128 tiles and everything else with 64 x 64 ones.  Both sum a row's products in the same k order, so a row
+    has the same bits whichever route the call's shape selects -- and both sit within fp32 rounding of the fp64 product."""
+    from linkteller_amd import engine
+    rng = np.random.RandomState(m + k)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    b = rng.standard_normal((k, n)).astype(np.float32)
+    at, bt = torch.from_numpy(a).to(gpu), torch.from_numpy(b).to(gpu)
+    tall = engine.gemm(at, bt).cpu().numpy()                     # 128-tile route
+    for r0, r1 in ((0, 700), (700, m)):                          # < 1024 rows per call: 64-tile route
+        part = engine.gemm(at[r0:r1].contiguous(), bt).cpu().numpy()
+        assert np.array_equal(part, tall[r0:r1]), (r0, r1)
+    ref = a.astype(np.float64) @ b.astype(np.float64)
+    assert np.abs(tall - ref).max() <= 2e-6 * np.abs(a).astype(np.float64).dot(np.abs(b).astype(np.float64)).max()

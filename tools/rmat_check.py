@@ -1,6 +1,7 @@
 """Sanity/perf on an R-MAT graph (BASELINE configs[4] shape, scaled): full == sparse bitwise, timings per mode."""
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from linkteller_amd import engine, graph, synth
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 n_test = int(sys.argv[2]) if len(sys.argv) > 2 else 128
