@@ -126,7 +126,32 @@ def main():
     from linkteller_amd import _lib, engine, graph, synth
     from linkteller_amd import dist as lt_dist
 
-    def spmm_rmat_leg(scale, hcols, reps=10):
+    def influence_shard(gb, nb_, scale, hcols):
+        """The influence build on the R-MAT graph at the shape ONE of 8 ranks gets in BASELINE configs[4] (n_test = 4096 ->
+        512 probes x 4096 observed nodes, F = H = 256): the product's default mode, with and without the loop-invariant
+        baseline (X*W1 and the fp64 pre-activation), and the bit-faithful `sparse`."""
+        xb = torch.from_numpy(synth.gaussian_features(nb_, 256, seed=1)).to(dev)
+        wb = synth.gcn_weights(256, hcols, 2, seed=42)
+        bb = engine.Baseline(gb, xb, *[torch.from_numpy(wb[k]).to(dev) for k in ("W1", "b1", "W2", "b2")])
+        rs = np.random.RandomState(42)
+        ob = rs.choice(nb_, 4096, replace=False)
+        pb = ob[:512]
+        shard = {"workload": f"R-MAT scale {scale}, F=256 H={hcols}: 512 probes x 4096 observed (BASELINE configs[4], one rank of 8)"}
+
+        def wall(fn, reps_=3):
+            fn(); torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(reps_):
+                fn()
+            torch.cuda.synchronize()
+            return round((time.perf_counter() - t) / reps_ * 1e3, 3)
+        for m_ in ("delta", "sparse"):
+            shard[f"{m_}_ms"] = wall(lambda: bb.influence_rows(pb, ob, 1e-4, m_))
+            shard[f"{m_}_incl_baseline_ms"] = wall(lambda: (bb.refresh(), bb.influence_rows(pb, ob, 1e-4, m_)))
+        shard["pairs_per_s_delta_incl_baseline"] = round(512 * 4096 / (shard["delta_incl_baseline_ms"] * 1e-3), 1)
+        return shard
+
+    def spmm_rmat_leg(scale, hcols, reps=10, with_shard=True):
         """Standalone SpMM (lt_spmm_csr_f32) on an R-MAT graph whose S exceeds every cache: the 'SpMM HBM GB/s' half of
         the metric, at BASELINE configs[4] size by default.  Kernel time from HIP events on the launch stream."""
         t0 = time.perf_counter()
@@ -145,7 +170,11 @@ def main():
         sec = tot / cnt * 1e-3
         byts = spmm_bytes(big.shape[0], big.nnz, hcols)
         key = f"spmm_rmat{scale}"
-        return {"kernel": "k_rows_tiled (+ k_spmm_long_combine for the hub rows)", "bound": "hbm",
+        del sb
+        shard = None
+        if with_shard:
+            shard = influence_shard(gb, big.shape[0], scale, hcols)
+        return {"influence_shard": shard, "kernel": "k_rows_tiled (+ k_spmm_long_combine for the hub rows)", "bound": "hbm",
                 "achieved": round(byts / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(byts / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": measured_traffic(key),
                 "algorithmic_bytes_per_launch": int(byts), "avg_launch_us": round(sec * 1e6, 1),
@@ -162,7 +191,7 @@ def main():
                         "(FETCH_SIZE*2 + WRITE_SIZE, PMC) over avg_launch_us is the real HBM-side rate"}
 
     if a.only_spmm:
-        print(json.dumps({"roofline_spmm": spmm_rmat_leg(a.spmm_scale, a.hidden, reps=4)}))
+        print(json.dumps({"roofline_spmm": spmm_rmat_leg(a.spmm_scale, a.hidden, reps=4, with_shard=False)}))
         return
 
     # ---------------- workload (identical on every rank: seeded) ----------------

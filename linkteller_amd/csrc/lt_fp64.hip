@@ -395,6 +395,18 @@ static int compute_z1d(lt_baseline *b, hipStream_t st) {
     const unsigned g2 = (unsigned)((n + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr)));
     const lt_graph *g = b->g;
     const int have_long = (g->p_n_long > 0 && b->seg_d) ? 1 : 0;
+    if (lt_tiled_wanted(g, Hp) && (g->p_n_long == 0 || b->seg_d)) {
+        // S1d beyond the caches (R-MAT scale 21: 4.3 GB): the column-sliced work-item route of lt_spmm.hip, same chains
+        int rc = lt_launch_rows_tiled_f64(g, b->S1d, Hp, Hp, b->b1p, b->Z1d, Hp, b->seg_d, Hp, st);
+        if (rc) return rc;
+        if (have_long) {
+            const long tot = (long)g->p_n_long * Hp;
+            hipLaunchKernelGGL(k_spmm_f64_long, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, g->p_n_long,
+                               g->p_long_row, g->p_long_segptr, b->seg_d, Hp, b->b1p, b->Z1d);
+            LT_CHECK_LAUNCH();
+        }
+        return LT_OK;
+    }
     const unsigned gs = have_long ? (unsigned)((g->p_n_seg + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr))) : 0u;
     LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_>), dim3(g2 + gs), dim3(256), 0, st, n, g->rowptr,
                                             g->col, g->val, b->S1d, Hp, b->b1p, b->Z1d, (int)gs, g->p_n_seg, g->p_seg_begin,

@@ -164,6 +164,9 @@ bool lt_tiled_wanted(const lt_graph *g, int ncols);
 int lt_launch_rows_tiled(const lt_graph *g, const float *S, int64_t lds, int ncols, const float *init,
                          const float *bias_after, int relu, float *out, int64_t ldo, float *seg_out,
                          int64_t ld_seg, hipStream_t st);
+// fp64 twin (S, out, seg_out double; chains from zero, + bias_after on short rows): the pre-activation of LT_MODE_DELTA
+int lt_launch_rows_tiled_f64(const lt_graph *g, const double *S, int64_t lds, int ncols, const float *bias_after,
+                             double *out, int64_t ldo, double *seg_out, int64_t ld_seg, hipStream_t st);
 int lt_launch_layer2(const lt_graph *g, const float *S2, int C, const float *b2, float *OUT,
                      hipStream_t st);
 int lt_launch_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, float *C,

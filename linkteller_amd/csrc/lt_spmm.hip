@@ -136,6 +136,104 @@ __global__ __launch_bounds__(LT_BLOCK) void k_rows_tiled(
     __builtin_nontemporal_store(acc, reinterpret_cast<f32x4 *>(d));
 }
 
+// fp64 twin of k_rows_tiled for the pre-activation of LT_MODE_DELTA (lt_fp64.hip): S and the result are double, the
+// values stay the graph's floats.  A lane holds 2 columns (16 bytes, as in the f32 kernel), so a 16-lane group covers a
+// 32-column slice -- 256 bytes of a gathered row again -- and 256 columns make 8 slices: one per XCD.  Chains start
+// from zero and the bias is added after (k_spmm_f64's order); segment sums go raw to seg_out for k_spmm_f64_long.
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(LT_BLOCK) void k_rows_tiled_f64(
+    int n_items, const int32_t *__restrict__ w_e0, const int32_t *__restrict__ w_cnt,
+    const int32_t *__restrict__ w_dst, int n, const int32_t *__restrict__ col, const float *__restrict__ val,
+    const double *__restrict__ S, long lds, int ncols, const float *__restrict__ bias_after,
+    double *__restrict__ out, long ldo, double *__restrict__ seg_out, long ld_seg, int ns) {
+    constexpr int GL = LT_TILE_GL, U = LT_TILE_U;
+    constexpr int GPW = 64 / GL, IPB = (LT_BLOCK / 64) * GPW;
+    const int lane = threadIdx.x & 63;
+    const int j = lane & (GL - 1);
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int xps = 8 / ns;
+    const int slice = xcd % ns;
+    const int it = (q * xps + xcd / ns) * IPB + (threadIdx.x >> 6) * GPW + lane / GL;
+    if (it >= n_items) return;
+    const int e0 = __builtin_nontemporal_load(w_e0 + it);
+    const int cnt = __builtin_nontemporal_load(w_cnt + it);
+    const int dst = __builtin_nontemporal_load(w_dst + it);
+    const int coff = slice * 2 * GL + 2 * j;
+    const bool active = coff < ncols;
+    f64x2 acc = {0.0, 0.0};
+    const char *Sb = reinterpret_cast<const char *>(S);
+    const size_t rowbytes = (size_t)lds * 8u;
+    const size_t loff = (size_t)coff * 8u;
+    const int e1 = e0 + cnt;
+    int nxc = 0;
+    float nxa = 0.f;
+    if (e0 + j < e1) {
+        nxc = __builtin_nontemporal_load(col + e0 + j);
+        nxa = __builtin_nontemporal_load(val + e0 + j);
+    }
+    for (int eb = e0; eb < e1; eb += GL) {
+        const int me = eb + j;
+        const int myc = nxc;
+        const float mya = nxa;
+        nxc = 0;
+        nxa = 0.f;
+        if (me + GL < e1) {
+            nxc = __builtin_nontemporal_load(col + me + GL);
+            nxa = __builtin_nontemporal_load(val + me + GL);
+        }
+        const int left = e1 - eb;
+        static_for<GL / U>([&](auto kbt) {
+            constexpr int kb = decltype(kbt)::value * U;
+            if (kb < left) {
+                f64x2 s[U];
+                double a[U];
+                static_for<U>([&](auto ut) {
+                    constexpr int u = decltype(ut)::value;
+                    constexpr int k = kb + u;
+                    const int c = row_bcast<k>(myc);
+                    a[u] = (double)__builtin_bit_cast(float, row_bcast<k>(__builtin_bit_cast(int, mya)));
+                    s[u] = f64x2{0.0, 0.0};
+                    if (k < left && active) s[u] = *reinterpret_cast<const f64x2 *>(Sb + ((size_t)c * rowbytes + loff));
+                });
+                static_for<U>([&](auto ut) {
+                    constexpr int u = decltype(ut)::value;
+                    if (kb + u < left) {
+                        acc.x = fma(a[u], s[u].x, acc.x);
+                        acc.y = fma(a[u], s[u].y, acc.y);
+                    }
+                });
+            }
+        });
+    }
+    if (!active) return;
+    double *d;
+    if (dst < n) {
+        acc.x += (double)bias_after[coff];
+        acc.y += (double)bias_after[coff + 1];
+        d = out + (size_t)dst * ldo + coff;
+    } else {
+        d = seg_out + (size_t)(dst - n) * ld_seg + coff;
+    }
+    __builtin_nontemporal_store(acc, reinterpret_cast<f64x2 *>(d));
+}
+
+int lt_launch_rows_tiled_f64(const lt_graph *g, const double *S, int64_t lds, int ncols, const float *bias_after,
+                             double *out, int64_t ldo, double *seg_out, int64_t ld_seg, hipStream_t st) {
+    if (g->w_n == 0) return LT_OK;
+    int ns = (ncols + 2 * LT_TILE_GL - 1) / (2 * LT_TILE_GL);   // 32-column slices: 1, 2, 4, 8
+    ns = ns <= 1 ? 1 : (ns == 2 ? 2 : (ns <= 4 ? 4 : 8));
+    LT_REQUIRE(ncols % 2 == 0 && ncols <= 2 * LT_TILE_GL * 8, "tiled fp64 SpMM: ncols=%d", ncols);
+    const int xps = 8 / ns;
+    constexpr int IPB = (LT_BLOCK / 64) * (64 / LT_TILE_GL);
+    const long chunks = ((long)g->w_n + IPB - 1) / IPB;
+    const long grid = 8 * ((chunks + xps - 1) / xps);
+    LT_REQUIRE(grid < 2147483647L, "tiled fp64 SpMM: grid limit");
+    hipLaunchKernelGGL(k_rows_tiled_f64, dim3((unsigned)grid), dim3(LT_BLOCK), 0, st, g->w_n, g->w_e0, g->w_cnt, g->w_dst,
+                       g->n, g->col, g->val, S, (long)lds, ncols, bias_after, out, (long)ldo, seg_out, (long)ld_seg, ns);
+    LT_CHECK_LAUNCH();
+    return LT_OK;
+}
+
 // The tiled route pays when the gathers MISS and the misses are SKEWED: S beyond the L2s, a natural order without
 // locality, hot columns that a quarter-of-S-per-XCD cache can keep (R-MAT, power laws).  Measured on 2 M-node graphs of
 // average degree 33 (profiles/r02_spmm_lab_banded.txt): neighbours within +-4096 of the row index -- row kernel 3.5 ms

@@ -542,3 +542,28 @@ def test_gemm_tile_routes_give_the_same_rows(gpu, m, k, n):
         assert np.array_equal(part, tall[r0:r1]), (r0, r1)
     ref = a.astype(np.float64) @ b.astype(np.float64)
     assert np.abs(tall - ref).max() <= 2e-6 * np.abs(a).astype(np.float64).dot(np.abs(b).astype(np.float64)).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden", [256, 100, 24])
+def test_tiled_fp64_preactivation_keeps_every_bit(gpu, hidden):
+    """The fp64 pre-activation of `delta` takes the column-sliced work-item route on graphs beyond the caches
+    (k_rows_tiled_f64).  Forced on a small hub-heavy graph (tiled_min_bytes = 0) it must give the bits of the row
+    kernel: same entry-ordered fma chains, same ordered segment sums -- checked through the `delta` matrix."""
+    from linkteller_amd import _lib, engine, graph, synth
+    a_hat = graph.first_order_gcn(synth.powerlaw_graph(1100, 7000, seed=11))
+    assert np.diff(a_hat.indptr).max() > 300
+    n = a_hat.shape[0]
+    x = synth.gaussian_features(n, 80, seed=2)
+    w = synth.gcn_weights(80, hidden, 2, seed=3)
+    base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *_params(w, gpu))
+    rng = np.random.RandomState(2)
+    probes, obs = rng.choice(n, 60, replace=False), rng.choice(n, 200, replace=False)
+    rows = base.influence_rows(probes, obs, 1e-4, "delta").cpu().numpy()
+    _lib.set_tuning("tiled_min_bytes", 0)
+    try:
+        base.refresh()
+        tiled = base.influence_rows(probes, obs, 1e-4, "delta").cpu().numpy()
+    finally:
+        _lib.set_tuning("tiled_min_bytes", None)
+    assert rows.max() > 0 and np.array_equal(rows, tiled)
