@@ -68,6 +68,8 @@ int lt_device_count(int *count);
  *   "long_par"            hub rows in FULL stage A: 1 = segments in separate waves, 0 = one wave per row
  *   "overlap"             hub-row kernels on the baseline's side stream (1) or on the caller's (0)
  *   "item_bits"           SPARSE / DELTA stage B membership bitmap on (1) / off (0)
+ *   "bits_max_bytes"      SPARSE / DELTA stage B keeps a membership bitmap row per probe while a chunk's rows fit this many
+ *                         bytes (default 128 MiB); larger calls give rows to their big probes only
  *   "pair_marks"          SPARSE / DELTA stage B: calls of at least this many (probe, observed) pairs per chunk -- and every
  *                         call too large for a membership bitmap -- find the affected pairs through a join over the
  *                         middle nodes; 0 = always, negative = never (default 2^22)

@@ -28,7 +28,6 @@
 #define LT_BLOCK 256
 #define LT_CHUNK_BUDGET ((size_t)1 << 30)  // bytes of per-probe scratch per chunk
 #define LT_ITEM_GRID 2048                  // blocks of the grid-stride item kernels
-#define LT_BITS_MAX_BYTES ((size_t)128 << 20)  // stage B of the item modes tests membership in R_v through a bitmap up to this size
 #define LT_SB_AHEAD 24                     // FULL stage B: entries in flight per wave (a multiple of LT_L2_LANES)
 
 // ------------------------------------------------------------------------------------------------
@@ -1149,7 +1148,7 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int n_o
         const size_t bw = (n + 31) / 32;
         // ("item_bits" = 0 forces the search path a huge graph takes: tests)
         const bool no_bits = lt_tune().item_bits == 0;
-        w.bits = (!no_bits && chunk * bw * sizeof(uint2) <= LT_BITS_MAX_BYTES) ? (uint2 *)take(chunk * bw * sizeof(uint2)) : nullptr;
+        w.bits = (!no_bits && (long long)(chunk * bw * sizeof(uint2)) <= lt_tune().bits_max_bytes) ? (uint2 *)take(chunk * bw * sizeof(uint2)) : nullptr;
         if (!w.bits && !no_bits) {
             w.big_bits = (uint2 *)take((size_t)LT_BIG_SLOTS * bw * sizeof(uint2));
             w.big_slot = (int32_t *)take((chunk + 1) * sizeof(int32_t));

@@ -526,6 +526,38 @@ def test_pair_marks_route_keeps_every_bit(gpu, family):
 
 
 @pytest.mark.gpu
+def test_big_probe_bitmap_rows_keep_every_bit(gpu):
+    """A call too large for a bitmap row per probe (forced here: bits_max_bytes = 1) gives rows to its big probes only
+    (|R_v| > 512, at most 64 per chunk); all other probes search.  Hubs probed AND observed -- every combination of
+    light / heavy probe with short / long observed row -- must give the bits of the all-bitmap route, for more big
+    probes than there are slots too."""
+    from linkteller_amd import _lib, engine, graph, synth
+    a_hat = graph.first_order_gcn(synth.powerlaw_graph(8000, 300000, seed=13, exponent=1.8))
+    deg = np.diff(a_hat.indptr)
+    n = a_hat.shape[0]
+    big = np.argsort(-deg)[:80]
+    assert deg[big[70]] > 512, int(deg[big[70]])       # more big probes than the 64 slots
+    x = synth.gaussian_features(n, 48, seed=2)
+    w = synth.gcn_weights(48, 128, 2, seed=3)
+    base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *_params(w, gpu))
+    rng = np.random.RandomState(4)
+    probes = np.concatenate([big, rng.choice(np.setdiff1d(np.arange(n), big), 120, replace=False)])
+    obs = np.concatenate([big[:20], rng.choice(n, 300, replace=False)])
+    try:
+        ref = {m: base.influence_rows(probes, obs, 1e-4, m).cpu().numpy() for m in ("sparse", "delta")}
+        _lib.set_tuning("bits_max_bytes", 1)
+        for pm in (0, -1):
+            _lib.set_tuning("pair_marks", pm)
+            for m in ("sparse", "delta"):
+                got = base.influence_rows(probes, obs, 1e-4, m).cpu().numpy()
+                assert np.array_equal(got, ref[m]), (pm, m)
+        assert ref["sparse"].max() > 0 and np.isfinite(ref["sparse"]).all()
+    finally:
+        for k in ("bits_max_bytes", "pair_marks"):
+            _lib.set_tuning(k, None)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("m,k,n", [(1500, 256, 256), (2048, 77, 128), (1031, 300, 256)])
 def test_gemm_tile_routes_give_the_same_rows(gpu, m, k, n):
     """`lt_gemm_f32` serves a tall product (M >= 1024, N a multiple of 128: X*W1 of a 2 M-node graph with F = 256) with
