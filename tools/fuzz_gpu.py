@@ -8,7 +8,7 @@ import scipy.sparse as sp
 import torch
 
 sys.path.insert(0, ".")
-from linkteller_amd import engine, graph, synth          # noqa: E402
+from linkteller_amd import _lib, engine, graph, synth    # noqa: E402
 from oracle import linkteller_oracle as O                # noqa: E402
 
 
@@ -66,6 +66,21 @@ def main():
         ref32 = oracle_matrix(a_hat, x, w, probes, observe, 1e-4, torch.float32)
         scale = max(ref64.max(), 1e-6)
         res = {m: base.influence_rows(probes, observe, 1e-4, m).cpu().numpy().astype(np.float64) for m in ("full", "sparse", "delta")}
+        # the routes of the item modes (pair marks, no per-probe bitmap + rows for big probes only, tiled layers, chunking)
+        # picked at random: the same bits
+        knobs = {"pair_marks": int(rng.choice([-1, 0])), "bits_max_bytes": int(rng.choice([1, 1 << 27])),
+                 "item_bits": int(rng.choice([0, 1, 1])), "tiled_min_bytes": int(rng.choice([0, 1 << 25])),
+                 "chunk_budget_bytes": int(rng.choice([1 << 14, 1 << 30]))}
+        for k, v in knobs.items():
+            _lib.set_tuning(k, v)
+        try:
+            base.refresh()
+            for m in ("sparse", "delta"):
+                alt = base.influence_rows(probes, observe, 1e-4, m).cpu().numpy().astype(np.float64)
+                assert np.array_equal(alt, res[m]), (it, m, knobs)
+        finally:
+            for k in knobs:
+                _lib.set_tuning(k, None)
         logits_ref = O.gcn_forward(torch.from_numpy(x).double(), O.to_torch_sparse(a_hat).double(),
                                    {k: torch.from_numpy(w[k]).double() for k in ("W1", "b1", "W2", "b2")}).numpy()
         tag = f"case {it}: {kind} n={n} H={h} C={c} F={f} {norm} probes={len(probes)} obs={len(observe)} maxdeg={int(np.diff(a_hat.indptr).max())}"
