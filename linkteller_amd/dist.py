@@ -84,15 +84,21 @@ def choose_baseline_sharding(base, trials: int = 5) -> bool:
         base.shard_refresh(True)
         return True
     times = []
+
+    def refresh_and_use():
+        # the replicated refresh is lazy (it only marks S1 stale): the logits make it materialise, and cost the same
+        # layers on top in both settings
+        base.refresh()
+        base.logits()
     for enable in (False, True):
         base.shard_refresh(enable)
         for _ in range(2):
-            base.refresh()
+            refresh_and_use()
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
         for _ in range(trials):
-            base.refresh()
+            refresh_and_use()
         torch.cuda.synchronize()
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
         if dist.get_backend() != "gloo":

@@ -245,7 +245,7 @@ def test_sharded_influence_matrix_equals_single_rank(gpu, influence_golden, tmp_
     nodes = g["pl600.ref32.test_nodes"]
     single = {m: base.influence_rows(nodes, nodes, args["influence"], m).cpu().numpy().astype(np.float64)
               for m in ("full", "sparse", "delta")}
-    for shard_baseline in ("0", "1"):
+    for shard_baseline in ("0", "1") + (("auto",) if world == 2 else ()):    # auto: both are timed, the faster kept
         out = tmp_path / f"ranks{world}_{shard_baseline}.npz"
         _run_ranks(code, world, {"LT_TEST_OUT": str(out), "LT_SHARD_BASELINE": shard_baseline})
         got = np.load(out)
