@@ -155,7 +155,7 @@ def main():
         """Standalone SpMM (lt_spmm_csr_f32) on an R-MAT graph whose S exceeds every cache: the 'SpMM HBM GB/s' half of
         the metric, at BASELINE configs[4] size by default.  Kernel time from HIP events on the launch stream."""
         t0 = time.perf_counter()
-        big = graph.first_order_gcn(synth.rmat_graph(scale, (1 << scale) * 16, seed=42))
+        big = graph.first_order_gcn(synth.rmat_graph(scale, synth.rmat_draws(scale), seed=42))
         gb = graph.HipGraph(big)
         host_s = time.perf_counter() - t0
         sb = torch.randn((big.shape[0], hcols), device=dev)

@@ -96,6 +96,12 @@ def rmat_graph(scale: int, n_draws: int, seed: int = 42,
     return _symmetric_csr(rows, cols, 1 << scale)
 
 
+def rmat_draws(scale: int) -> int:
+    """Directed draws for an R-MAT graph of 2^scale nodes: 40 M at scale 21 (BASELINE configs[4]: |V| = 2 M, |E| = 40 M),
+    the same 19.07 per node at other scales."""
+    return 40_000_000 if scale == 21 else int(round((1 << scale) * 40_000_000 / (1 << 21)))
+
+
 def standard_scale(x: np.ndarray) -> np.ndarray:
     """Column standardisation with zero-variance columns left at scale 1 (sklearn semantics)."""
     mean = x.mean(axis=0)

@@ -279,18 +279,18 @@ def test_cli_two_ranks_write_one_result_file(gpu, tmp_path):
 
 
 def test_rmat_scale21_config5_full_size(gpu):
-    """BASELINE configs[4] at its full size on ONE GPU: R-MAT scale 21 (2 097 152 nodes, 16 x 2^21 draws -> nnz(A_hat)
-    ~ 65 M, hub rows of 10^5 entries), F = H = 256, C = 2.  Size-independent properties -- `sparse` == `full` bit for
+    """BASELINE configs[4] at its full size on ONE GPU: R-MAT scale 21 (2 097 152 nodes, 40 M directed draws -> nnz(A_hat)
+    ~ 78 M, hub rows of 10^5 entries), F = H = 256, C = 2.  Size-independent properties -- `sparse` == `full` bit for
     bit, the tiled SpMM == the row kernel bit for bit, the tiled layer 1 == the fused one through the logits, exact
     zeros off the 2-hop set -- and the fp64 oracle on one probe row.  Timings go to gpurun_out/ (copied to profiles/)."""
     from linkteller_amd import _lib, engine, graph, synth
     from oracle import linkteller_oracle as O
     t0 = time.time()
-    adj = synth.rmat_graph(21, (1 << 21) * 16, seed=42)
+    adj = synth.rmat_graph(21, synth.rmat_draws(21), seed=42)
     a_hat = graph.first_order_gcn(adj)
     n = adj.shape[0]
     deg = np.diff(a_hat.indptr)
-    assert n == 1 << 21 and a_hat.nnz > 60_000_000 and deg.max() > 50_000
+    assert n == 1 << 21 and a_hat.nnz > 70_000_000 and deg.max() > 50_000
     x_np = synth.gaussian_features(n, 256, seed=1)
     w = synth.gcn_weights(256, 256, 2, seed=42)
     t_host = time.time() - t0

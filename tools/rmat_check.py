@@ -7,7 +7,7 @@ scale = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 n_test = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 modes = sys.argv[3].split(',') if len(sys.argv) > 3 else ['full', 'sparse', 'delta']
 t0 = time.time()
-adj = synth.rmat_graph(scale, (1 << scale) * 16, seed=42)
+adj = synth.rmat_graph(scale, synth.rmat_draws(scale), seed=42)
 a_hat = graph.first_order_gcn(adj)
 n = adj.shape[0]
 print('n', n, 'nnz', a_hat.nnz, 'max deg', int(np.diff(a_hat.indptr).max()), ' host graph build', round(time.time() - t0, 1), 's')

@@ -6,7 +6,7 @@ from linkteller_amd import _lib, engine, graph, synth
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 21
 n_probe = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 n_obs = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
-adj = synth.rmat_graph(scale, (1 << scale) * 16, seed=42)
+adj = synth.rmat_graph(scale, synth.rmat_draws(scale), seed=42)
 a_hat = graph.first_order_gcn(adj)
 n = adj.shape[0]
 deg = np.diff(a_hat.indptr)
