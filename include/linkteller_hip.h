@@ -68,6 +68,9 @@ int lt_device_count(int *count);
  *   "long_par"            hub rows in FULL stage A: 1 = segments in separate waves, 0 = one wave per row
  *   "overlap"             hub-row kernels on the baseline's side stream (1) or on the caller's (0)
  *   "item_bits"           SPARSE / DELTA stage B membership bitmap on (1) / off (0)
+ *   "hub_short_side"      SPARSE / DELTA stage B on observed hub rows: 1 = the members of row(u) and R_v are found from the
+ *                         shorter list, 0 = every entry is tested against every probe, negative = by whether the call has a
+ *                         bitmap row per probe (default)
  *   "bits_max_bytes"      SPARSE / DELTA stage B keeps a membership bitmap row per probe while a chunk's rows fit this many
  *                         bytes (default 128 MiB); larger calls give rows to their big probes only
  *   "pair_marks"          SPARSE / DELTA stage B: calls of at least this many (probe, observed) pairs per chunk -- and every

@@ -42,6 +42,7 @@ static lt_tuning tuning_defaults() {
     const long long pk = env_ll("LT_PROBE_KSLICE", 0);
     t.probe_kslice = pk > 0 ? (int)pk : 0;
     t.pair_marks = env_ll("LT_PAIR_MARKS", (long long)1 << 22);
+    t.hub_short_side = getenv("LT_HUB_SHORT_SIDE") ? (env_ll("LT_HUB_SHORT_SIDE", 0) != 0 ? 1 : 0) : -1;
     t.bits_max_bytes = env_ll("LT_BITS_MAX_BYTES", (long long)128 << 20);
     t.tiled_big = 0;
     return t;
@@ -71,6 +72,7 @@ extern "C" int lt_set_tuning(const char *key, long long value) {
         LT_REQUIRE(reset || value > 0, "lt_set_tuning: wide_min_hp must be positive");
         t.wide_min_hp = reset ? d.wide_min_hp : (int)value;
     } else if (!strcmp(key, "pair_marks")) t.pair_marks = reset ? d.pair_marks : value;
+    else if (!strcmp(key, "hub_short_side")) t.hub_short_side = reset ? d.hub_short_side : (value < 0 ? -1 : (value != 0));
     else if (!strcmp(key, "bits_max_bytes")) t.bits_max_bytes = reset ? d.bits_max_bytes : value;
     else if (!strcmp(key, "tiled_big")) t.tiled_big = reset ? 0 : (value != 0);
     else if (!strcmp(key, "probe_kslice")) {

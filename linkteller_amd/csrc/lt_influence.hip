@@ -752,7 +752,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
 #define LT_SBL_UN 8
 #define LT_SBL_NS 8        // light probes: searches in flight per lane
 #define LT_SBL_MC 128      // SPARSE: members of a light probe kept in LDS at a time (> 64 + a search round: see fill)
-template <int CP, bool DELTA>
+template <int CP, bool DELTA, bool SHORT>   // SHORT: the short-side search (without it every probe tests every entry, no member lists in LDS)
 __device__ __forceinline__ void stageB_long_block(
     int bid, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const int32_t *__restrict__ tptr,
@@ -767,7 +767,7 @@ __device__ __forceinline__ void stageB_long_block(
     __shared__ int sc[CHUNK];
     __shared__ float sv[CHUNK];
     __shared__ float sT[DELTA ? 1 : CHUNK][CP];
-    __shared__ int2 smem[DELTA ? 1 : GROUPS][DELTA ? 1 : LT_SBL_MC];   // SPARSE, light probes: (entry - e0, position in R_v)
+    __shared__ int2 smem[(DELTA || !SHORT) ? 1 : GROUPS][(DELTA || !SHORT) ? 1 : LT_SBL_MC];   // SPARSE, light probes: (entry - e0, position in R_v)
     const int pblocks = (nb + GROUPS - 1) / GROUPS;
     const int j = bid / pblocks;
     const int u = observe[j];
@@ -795,7 +795,7 @@ __device__ __forceinline__ void stageB_long_block(
     // (group-uniform) per-entry tests cost d / 64 rounds of one load (a miss, ~ 2x an L2 hit) with a bitmap row, of
     // log |R_v| loads without; the search from the R_v side costs |R_v| / (8 NS) rounds of log d loads
     const int lg_d = 32 - __clz(d), lg_c = 32 - __clz(cnt > 1 ? cnt : 1);
-    const bool heavy = live && (mb ? (long)cnt * lg_d > d : 2L * cnt * lg_d > (long)d * lg_c);
+    const bool heavy = live && (!SHORT || (mb ? (long)cnt * lg_d > d : 2L * cnt * lg_d > (long)d * lg_c));
     const bool light = live && !heavy;
     const int32_t *cu = col + e0;
     const int gl0 = (tid & 63) & ~(LT_L2_LANES - 1);    // first lane of the group inside its wave
@@ -971,6 +971,23 @@ __device__ __forceinline__ void stageB_long_block(
     if (live && q == 0) out[(long)b * ldo + j] = res;
 }
 
+// The observed hubs of SPARSE in a launch of their own: stageB_long_block's member lists take 48 KB of LDS per block, which
+// as part of k_item_stageB capped every block of that launch -- the pairs too -- at three per CU (28 -> 55 us at twitch
+// size, hubs or not).  DELTA's hub blocks need 8 KB and stay in front of the pair launch.
+template <int CP, bool DELTA, bool SHORT>
+__global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_hubs(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const int32_t *__restrict__ tptr,
+    const int32_t *__restrict__ trow, const float *__restrict__ S2, int C,
+    const float *__restrict__ b2, const float *__restrict__ OUT,
+    const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
+    const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
+    float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words,
+    const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot) {
+    stageB_long_block<CP, DELTA, SHORT>((int)blockIdx.x, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off, S2x,
+                                        observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot);
+}
+
 // SPARSE / DELTA stage B: 8 lanes per (probe, observed node).
 template <int CP, bool DELTA>
 __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
@@ -980,16 +997,23 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
     const float *__restrict__ b2, const float *__restrict__ OUT,
     const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
     const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
-    float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words, int long_blocks,
-    const unsigned *__restrict__ marks, const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot) {
+    float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words, int long_blocks, int skip_long,
+    const unsigned *__restrict__ marks, const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot,
+    int hub_short) {
     // long_blocks > 0 (the graph has hub rows): the first long_blocks blocks serve the observed hubs
-    // (stageB_long_block: most of them find a plain row and exit), the pairs below skip those rows
+    // (stageB_long_block: most of them find a plain row and exit); skip_long: the pairs below leave those rows alone
+    // (SPARSE with the short-side search: k_item_stageB_hubs has them, long_blocks = 0 here)
     if ((int)blockIdx.x < long_blocks) {
-        stageB_long_block<CP, DELTA>((int)blockIdx.x, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off, S2x,
-                                     observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot);
+        if (hub_short) {
+            if constexpr (DELTA)
+                stageB_long_block<CP, DELTA, true>((int)blockIdx.x, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off,
+                                                   S2x, observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot);
+        } else {
+            stageB_long_block<CP, DELTA, false>((int)blockIdx.x, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off,
+                                                S2x, observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot);
+        }
         return;
     }
-    const bool skip_long = long_blocks > 0;
     const long gid = ((long)(blockIdx.x - long_blocks) * LT_BLOCK + threadIdx.x) / LT_L2_LANES;
     const int q = threadIdx.x & (LT_L2_LANES - 1);
     if (gid >= (long)nb * n_obs) return;
@@ -1212,6 +1236,10 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
     // at twitch-RU size, tools/marks_ab.py; without one -- large graphs -- it always does)
     const bool use_marks = mode != LT_MODE_FULL && w.pm_cnt != nullptr &&
                            (w.bits == nullptr || (long long)(n_probe < w.chunk ? n_probe : w.chunk) * n_obs >= lt_tune().pair_marks);
+    // observed hubs (stageB_long_block): members found from the short side, or every entry tested against every probe.
+    // With a bitmap row per probe (twitch size) the per-entry test is one cached load and wins; without one it is a search
+    // per entry and loses by 10x.  "hub_short_side" pins the choice (tests).
+    const bool hub_short = mode != LT_MODE_FULL && (lt_tune().hub_short_side >= 0 ? lt_tune().hub_short_side != 0 : w.bits == nullptr);
     if (use_marks) {
         LT_REQUIRE((long)n_obs * LT_ROW_SEG / 256 + 1 < 2147483647L, "lt_influence_rows: n_obs=%d exceeds the grid limit", n_obs);
         const unsigned gl = (unsigned)(((long)n_obs * LT_ROW_SEG + 255) / 256);
@@ -1358,11 +1386,21 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                        b->seg_part, w.item_pr))); }
                 LT_CHECK_LAUNCH();
                 lt_prof_scope prof_(LT_K_ITEM_B, st);
-                LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, false>), dim3(gridB + (unsigned)long_blocks),
+                if (long_blocks > 0 && hub_short) {
+                    LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_hubs<CP_, false, true>), dim3((unsigned)long_blocks),
+                                                           dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
+                                                           g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
+                                                           nb, w.off, w.S2x, observe_nodes, n_obs, delta,
+                                                           orow, (long)ldo, w.bits, words, w.big_bits, w.big_slot));
+                    LT_CHECK_LAUNCH();
+                }
+                const unsigned inl = hub_short ? 0u : (unsigned)long_blocks;   // hub blocks in front of the pair launch
+                LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, false>), dim3(gridB + inl),
                                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
                                                        g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
                                                        nb, w.off, w.S2x, observe_nodes, n_obs, delta,
-                                                       orow, (long)ldo, w.bits, words, (int)long_blocks, marks, w.big_bits, w.big_slot));
+                                                       orow, (long)ldo, w.bits, words, (int)inl, long_blocks > 0 ? 1 : 0, marks,
+                                                       w.big_bits, w.big_slot, 0));
             } else {
                 { lt_prof_scope prof_(LT_K_ITEM_A, st);
                 if (b->Z1d) {
@@ -1386,7 +1424,8 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
                                                        g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
                                                        nb, w.off, w.S2x, observe_nodes, n_obs, delta,
-                                                       orow, (long)ldo, w.bits, words, (int)long_blocks, marks, w.big_bits, w.big_slot));
+                                                       orow, (long)ldo, w.bits, words, (int)long_blocks, long_blocks > 0 ? 1 : 0,
+                                                       marks, w.big_bits, w.big_slot, hub_short ? 1 : 0));
             }
             LT_CHECK_LAUNCH();
         }

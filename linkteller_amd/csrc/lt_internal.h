@@ -104,6 +104,7 @@ struct lt_tuning {
     long long pair_marks;        // SPARSE / DELTA stage B: chunks of at least this many (probe, observed) pairs -- and any call without
                                  // a membership bitmap -- find the affected pairs through the middle-node join (k_pm_*); 0 = always,
                                  // < 0 = never (LT_PAIR_MARKS)
+    int hub_short_side;          // SPARSE / DELTA stage B, observed hubs: 1 short-side search, 0 per-entry tests, -1 by bitmap (LT_HUB_SHORT_SIDE)
     long long bits_max_bytes;    // SPARSE / DELTA: a bitmap row per probe only while the chunk's rows fit this (default 128 MiB);
                                  // beyond it only the chunk's big probes get rows (LT_BITS_MAX_BYTES)
     int tiled_big;               // 1: the tiled SpMM always uses 64-bit gather offsets (test hook; default: only when S spans >= 4 GiB)

@@ -513,6 +513,8 @@ def test_pair_marks_route_keeps_every_bit(gpu, family):
             res = {}
             for pm in (-1, 0):
                 _lib.set_tuning("pair_marks", pm)
+                # observed hubs: every entry tested against every probe (0) / members found from the shorter list (1)
+                _lib.set_tuning("hub_short_side", 0 if pm < 0 else 1)
                 for mode in ("sparse", "delta"):
                     res[pm, mode] = base.influence_rows(probes, obs, 1e-4, mode).cpu().numpy()
             for mode in ("sparse", "delta"):
@@ -521,7 +523,7 @@ def test_pair_marks_route_keeps_every_bit(gpu, family):
             assert np.array_equal(full, res[0, "sparse"])
             assert np.isfinite(full).all() and (n_probe == 1 or full.max() > 0)
     finally:
-        for k in ("chunk_budget_bytes", "item_bits", "pair_marks"):
+        for k in ("chunk_budget_bytes", "item_bits", "pair_marks", "hub_short_side"):
             _lib.set_tuning(k, None)
 
 
@@ -548,12 +550,14 @@ def test_big_probe_bitmap_rows_keep_every_bit(gpu):
         _lib.set_tuning("bits_max_bytes", 1)
         for pm in (0, -1):
             _lib.set_tuning("pair_marks", pm)
-            for m in ("sparse", "delta"):
-                got = base.influence_rows(probes, obs, 1e-4, m).cpu().numpy()
-                assert np.array_equal(got, ref[m]), (pm, m)
+            for hs in (1, 0):
+                _lib.set_tuning("hub_short_side", hs)
+                for m in ("sparse", "delta"):
+                    got = base.influence_rows(probes, obs, 1e-4, m).cpu().numpy()
+                    assert np.array_equal(got, ref[m]), (pm, hs, m)
         assert ref["sparse"].max() > 0 and np.isfinite(ref["sparse"]).all()
     finally:
-        for k in ("bits_max_bytes", "pair_marks"):
+        for k in ("bits_max_bytes", "pair_marks", "hub_short_side"):
             _lib.set_tuning(k, None)
 
 

@@ -69,7 +69,7 @@ def main():
         # the routes of the item modes (pair marks, no per-probe bitmap + rows for big probes only, tiled layers, chunking)
         # picked at random: the same bits
         knobs = {"pair_marks": int(rng.choice([-1, 0])), "bits_max_bytes": int(rng.choice([1, 1 << 27])),
-                 "item_bits": int(rng.choice([0, 1, 1])), "tiled_min_bytes": int(rng.choice([0, 1 << 25])),
+                 "item_bits": int(rng.choice([0, 1, 1])), "hub_short_side": int(rng.choice([0, 1])), "tiled_min_bytes": int(rng.choice([0, 1 << 25])),
                  "chunk_budget_bytes": int(rng.choice([1 << 14, 1 << 30]))}
         for k, v in knobs.items():
             _lib.set_tuning(k, v)
