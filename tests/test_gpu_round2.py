@@ -603,3 +603,28 @@ def test_tiled_fp64_preactivation_keeps_every_bit(gpu, hidden):
     finally:
         _lib.set_tuning("tiled_min_bytes", None)
     assert rows.max() > 0 and np.array_equal(rows, tiled)
+
+
+@pytest.mark.gpu
+def test_delta_without_the_fp64_preactivation(gpu, influence_golden):
+    """`lt_influence_rows(mode = LT_MODE_DELTA)` on a baseline that never had `lt_baseline_enable_fp64` called (a C-ABI
+    caller may skip it; the Python engine never does): the kink test then reads the fp32 pre-activation.  Exact zeros
+    off the 2-hop set, and the scores within the fp32 forward's own noise class of the fp64 reference (the propagation
+    itself is exact; only hidden units within rounding of a ReLU kink can be classified differently)."""
+    from test_gpu_parity import _setup
+    g = influence_golden
+    for key in ("pl600", "er300"):
+        if key + ".ref64.influence_val" not in g:
+            continue
+        args, base = _setup(g, key, gpu)
+        nodes = g[key + ".ref32.test_nodes"]
+        ref64 = g[key + ".ref64.influence_val"]
+        base._fp64 = True                      # keep influence_rows from enabling the fp64 buffers: Z1d stays NULL
+        got = base.influence_rows(nodes, nodes, args["influence"], "delta").cpu().numpy().astype(np.float64)
+        base._fp64 = False
+        exact = base.influence_rows(nodes, nodes, args["influence"], "delta").cpu().numpy().astype(np.float64)
+        scale = ref64.max()
+        print(f"{key}: |delta(fp32 Z1) - ref64| max {np.abs(got - ref64).max():.3e}, |delta(fp64 Z1) - ref64| max "
+              f"{np.abs(exact - ref64).max():.3e}, scale {scale:.3e}")
+        assert np.all(got[ref64 == 0] == 0)
+        assert np.abs(got - ref64).max() <= 1e-3 * scale
