@@ -172,8 +172,8 @@ int lt_influence_rows(const lt_baseline *b, const int32_t *probe_nodes, int32_t 
  * parameter tensors; lt_baseline3_refresh recomputes everything from them).  lt_influence3_rows evaluates the
  * reference's fp32 finite difference (f(X + d e_v x_v^T) - f(X))[u] / d only where it can be non-zero: the rows a
  * probe reaches in 1, 2 and 3 hops, each recomputed with the arithmetic of the baseline forward, so unreachable
- * pairs are exactly 0.  One 4-byte device-to-host read per probe chunk (an item count sizes a GEMM); otherwise
- * the conventions of lt_influence_rows. */
+ * pairs are exactly 0.  The conventions of lt_influence_rows (enqueue only, no host synchronisation: the item
+ * count that sizes the level-2 GEMM stays on the device). */
 typedef struct lt_baseline3 lt_baseline3;
 int lt_baseline3_create(const lt_graph *g, const float *X, int64_t ldx, int32_t F,
                         const float *W1, const float *b1, int32_t H1,

@@ -6,7 +6,7 @@
 //   H1 = relu(A S1 + b1)   changes on R1 = {r : A[r,v] != 0},          S2 = H1 W2 on the same rows,
 //   H2 = relu(A S2 + b2)   changes on R2 = {r2 : A[r2,r] != 0, r in R1}, S3 = H2 W3 on the same rows,
 //   out = A S3 + b3        changes on the 3-hop set; only the observed rows are formed.
-// Per probe chunk (one 4-byte read-back of the item count per chunk, for the GEMM's M):  level-1 items (b, r in R1) -> H1x rows (k3_rows_relu with row v substituted) -> one MFMA GEMM
+// Per probe chunk (no read-back: the GEMM's row count stays on the device, lt_launch_gemm_mdev):  level-1 items (b, r in R1) -> H1x rows (k3_rows_relu with row v substituted) -> one MFMA GEMM
 // S2x = H1x W2 -> R2 by marking (k3_mark2: the thread that flips a bit appends the item) -> level-2 items (b, r2):
 // k3_stageB runs the layer-2 chain of row r2 with the rows of R1 looked up in S2x (bitmap with positions), relu,
 // . W3 -> S3x[b][r2] -> k3_stageC: layer-3 row of each observed node with the rows of R2 looked up in S3x, minus the
@@ -413,14 +413,12 @@ extern "C" int lt_influence3_rows(const lt_baseline3 *b, const int32_t *probe_no
                                                  g->col, g->val, b->S1, Hp1, b->b1p, w.H1x, g->tptr, g->trow, probes, nb, w.off,
                                                  w.Sp));
         LT_CHECK_LAUNCH();
-        // the GEMM's M is the item count, which lives on the device: ONE 4-byte read-back per chunk (the only host
-        // synchronisation of this entry point; the 2-layer lt_influence_rows has none)
-        int32_t m1 = 0;
-        LT_HIP(hipMemcpyAsync(&m1, w.off + nb, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        LT_HIP(hipStreamSynchronize(st));
-        LT_REQUIRE(m1 >= 0 && (long)m1 <= (long)nb * maxc, "lt_influence3_rows: item count %d out of range", m1);
-        if (Hp2 != b->H2) LT_HIP(hipMemsetAsync(w.S2x, 0, (size_t)m1 * Hp2 * sizeof(float), st));
-        rc = lt_launch_gemm(w.H1x, Hp1, b->W2, b->H2, w.S2x, Hp2, m1, b->H2, b->H1, st);
+        // the GEMM's M is the item count, which lives on the device (off[nb]): its grid covers the chunk's bound
+        // nb * max column length and the tiles past the count exit -- no read-back, no host synchronisation
+        const long m_bound = (long)nb * maxc;
+        LT_REQUIRE(m_bound < 2147483647L, "lt_influence3_rows: %d probes x %ld rows per chunk exceed the grid limit", nb, maxc);
+        if (Hp2 != b->H2) LT_HIP(hipMemsetAsync(w.S2x, 0, (size_t)m_bound * Hp2 * sizeof(float), st));
+        rc = lt_launch_gemm_mdev(w.H1x, Hp1, b->W2, b->H2, w.S2x, Hp2, (int)m_bound, w.off + nb, b->H2, b->H1, st);
         if (rc) return rc;
         // level 2: R2 and its items
         LT_HIP(hipMemsetAsync(w.bits2, 0, (size_t)nb * words * sizeof(uint32_t), st));

@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma(const float *__restrict__
                                                        const float *__restrict__ B, long ldb,
                                                        float *__restrict__ C, long ldc, int M, int N,
                                                        int K, int kslice, long slab_stride,
-                                                       const int32_t *__restrict__ rows, float delta) {
+                                                       const int32_t *__restrict__ rows, float delta,
+                                                       const int32_t *__restrict__ m_dev) {
     __shared__ __attribute__((aligned(16))) float As[2][GM_BM * GM_LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][GM_BK * GM_BN];
 
@@ -38,6 +39,12 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma(const float *__restrict__
     const int wr = wid >> 1, wc = wid & 1;
     const int m0 = blockIdx.x * GM_BM;  // M tiles on x: neighbours share the B (weight) tiles in L2
     const int n0 = blockIdx.y * GM_BN;
+    // m_dev: the row count lives on the device (an item count formed by an earlier kernel); the grid covers the
+    // caller's upper bound M and the tiles past the real count leave at once
+    if (m_dev != nullptr) {
+        M = min(M, *m_dev);
+        if (m0 >= M) return;
+    }
 
     // staging coordinates: A tile 64 x 16 (thread -> row tid/4, 4 floats), B tile 16 x 64
     const int a_row = tid >> 2, a_col = (tid & 3) * 4;
@@ -423,7 +430,21 @@ int lt_launch_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, flo
     dim3 grid((M + GM_BM - 1) / GM_BM, (N + GM_BN - 1) / GM_BN);
     LT_REQUIRE(grid.y <= 65535u, "lt_gemm_f32: N=%d too large", N);
     hipLaunchKernelGGL(k_gemm_f32_mfma<false>, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, C,
-                       (long)ldc, M, N, K, K > 0 ? K : 1, 0L, (const int32_t *)nullptr, 0.f);
+                       (long)ldc, M, N, K, K > 0 ? K : 1, 0L, (const int32_t *)nullptr, 0.f, (const int32_t *)nullptr);
+    LT_CHECK_LAUNCH();
+    return LT_OK;
+}
+
+// C[0 .. *m_dev) = A B with the row count on the device: the grid covers m_bound rows (64 x 64 tiles, one K slice),
+// tiles past the count exit.  Rows are summed exactly as lt_launch_gemm sums them.
+int lt_launch_gemm_mdev(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                        int m_bound, const int32_t *m_dev, int N, int K, hipStream_t st) {
+    if (m_bound == 0 || N == 0) return LT_OK;
+    dim3 grid((m_bound + GM_BM - 1) / GM_BM, (N + GM_BN - 1) / GM_BN);
+    LT_REQUIRE(grid.y <= 65535u, "lt_gemm: N=%d too large", N);
+    lt_prof_scope prof_(LT_K_GEMM, st);
+    hipLaunchKernelGGL(k_gemm_f32_mfma<false>, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, C,
+                       (long)ldc, m_bound, N, K, K > 0 ? K : 1, 0L, (const int32_t *)nullptr, 0.f, m_dev);
     LT_CHECK_LAUNCH();
     return LT_OK;
 }
@@ -494,10 +515,10 @@ int lt_launch_gemm_splitk(const float *A, int64_t lda, const float *B, int64_t l
                                ldd, M, N, K, kslice, stride, (const int32_t *)nullptr, 0.f);
         else if (gather_rows)
             hipLaunchKernelGGL(k_gemm_f32_mfma<true>, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, dst, ldd,
-                               M, N, K, kslice, stride, gather_rows, delta);
+                               M, N, K, kslice, stride, gather_rows, delta, (const int32_t *)nullptr);
         else
             hipLaunchKernelGGL(k_gemm_f32_mfma<false>, grid, dim3(256), 0, st, A, (long)lda, B, (long)ldb, dst, ldd,
-                               M, N, K, kslice, stride, (const int32_t *)nullptr, 0.f);
+                               M, N, K, kslice, stride, (const int32_t *)nullptr, 0.f, (const int32_t *)nullptr);
         LT_CHECK_LAUNCH();
         if (splits > 1) {
             const long tot = (long)M * N;

@@ -174,6 +174,8 @@ int lt_launch_layer2(const lt_graph *g, const float *S2, int C, const float *b2,
                      hipStream_t st);
 int lt_launch_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
                    int64_t ldc, int M, int N, int K, hipStream_t st);
+int lt_launch_gemm_mdev(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                        int m_bound, const int32_t *m_dev, int N, int K, hipStream_t st);
 size_t lt_gemm_splitk_slab_bytes(int M, int N, int K, int kslice);
 int lt_gemm_pick_kslice(int M, int N, int K);   // baseline X*W1: slice length that fills the CUs in whole rounds
 // gather_rows != NULL: row m of the A operand is row gather_rows[m] of A, perturbed by x + x * delta
