@@ -628,3 +628,89 @@ def test_delta_without_the_fp64_preactivation(gpu, influence_golden):
               f"{np.abs(exact - ref64).max():.3e}, scale {scale:.3e}")
         assert np.all(got[ref64 == 0] == 0)
         assert np.abs(got - ref64).max() <= 1e-3 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["er", "powerlaw"])
+def test_a_step_is_hipgraph_capturable(gpu, family):
+    """include/linkteller_hip.h promises launch functions that only enqueue -- no host synchronisation, no allocation,
+    no stream or event creation -- so a whole step (lt_baseline_refresh + lt_influence_rows, any mode; on a graph with
+    hub rows FULL forks onto the baseline's side stream and joins it back) can be captured into a hipGraph.  Captured
+    once, replayed after the output was cleared and after the weights changed in place: the bits of the eager calls."""
+    from linkteller_amd import engine, graph, synth
+    gen = synth.powerlaw_graph if family == "powerlaw" else synth.erdos_renyi_graph
+    a_hat = graph.first_order_gcn(gen(700, 4000, seed=5))
+    n = a_hat.shape[0]
+    x = torch.from_numpy(synth.gaussian_features(n, 96, seed=2)).to(gpu)
+    w = synth.gcn_weights(96, 256, 2, seed=3)
+    p = _params(w, gpu)
+    base = engine.Baseline(graph.HipGraph(a_hat), x, *p)
+    rng = np.random.RandomState(1)
+    nodes = torch.from_numpy(rng.choice(n, 120, replace=False).astype(np.int32)).to(gpu)
+    for mode in ("full", "sparse", "delta"):
+        out = torch.empty((120, 120), dtype=torch.float32, device=gpu)
+
+        def step():
+            base.refresh()
+            base.influence_rows(nodes, nodes, 1e-4, mode, out=out)
+        step()
+        eager = out.clone()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            step()                      # workspaces and the fp64 buffers exist before the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            step()
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager), (family, mode)
+        # the graph reads the borrowed tensors: an in-place weight update shows in the next replay
+        with torch.no_grad():
+            p[0].mul_(1.5)
+        g.replay()
+        torch.cuda.synchronize()
+        replayed = out.clone()
+        step()
+        torch.cuda.synchronize()
+        assert torch.equal(replayed, out) and not torch.equal(replayed, eager), (family, mode)
+        with torch.no_grad():
+            p[0].div_(1.5)
+        del g
+
+
+@pytest.mark.gpu
+def test_gcn3_step_is_hipgraph_capturable(gpu):
+    """The 3-layer primitive too: since the level-2 GEMM reads its row count from the device, lt_influence3_rows has no
+    host synchronisation left and a refresh + rows step replays from a captured hipGraph with the eager bits."""
+    from linkteller_amd import engine, graph, synth
+    a_hat = graph.first_order_gcn(synth.powerlaw_graph(500, 2500, seed=9))
+    n, f, h1, h2, c = a_hat.shape[0], 40, 64, 32, 3
+    rng = np.random.RandomState(3)
+
+    def u(shape, fan):
+        s = 1.0 / np.sqrt(fan)
+        return torch.from_numpy(rng.uniform(-s, s, size=shape).astype(np.float32)).to(gpu)
+    p = [u((f, h1), h1), u((h1,), h1), u((h1, h2), h2), u((h2,), h2), u((h2, c), c), u((c,), c)]
+    base = engine.Baseline3(graph.HipGraph(a_hat), torch.from_numpy(synth.gaussian_features(n, f, seed=1)).to(gpu), *p)
+    nodes = torch.from_numpy(rng.choice(n, 40, replace=False).astype(np.int32)).to(gpu)
+    holder = {}
+
+    def step():
+        base.refresh()
+        holder["out"] = base.influence_rows(nodes, nodes, 1e-4)
+    step()
+    eager = holder["out"].clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        step()
+    captured = holder["out"]
+    captured.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert eager.max() > 0 and torch.equal(captured, eager)
