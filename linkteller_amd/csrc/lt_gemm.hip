@@ -251,6 +251,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma_deep(const float *__restr
 // on this part (tools/fold_test/mfma_peak.hip); the LDS store + barrier per k-tile is the largest rest.
 #define GL_BM 128
 #define GL_BN 128
+#ifdef LT_GEMM_TRACE
+__device__ unsigned long long *g_lt_gemm_trace = nullptr;
+#endif
 #ifndef GL_BK
 #define GL_BK 16        // k-depth of a tile (32 measured 8 % slower, also with the two-stage prefetch)
 #endif
@@ -261,6 +264,17 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma_128(const float *__restri
                                                            float *__restrict__ C, long ldc, int M, int N,
                                                            int K, int kslice, long slab_stride) {
     // requires N % 128 == 0 (every B tile is full; the launcher falls back to the 64x64 kernel otherwise)
+#ifdef LT_GEMM_TRACE   // tools/gemm_lab: start / end time of every workgroup (constant 100 MHz clock)
+    const unsigned lt_trace_id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (threadIdx.x == 0 && g_lt_gemm_trace) {
+        g_lt_gemm_trace[3 * lt_trace_id] = wall_clock64();
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        g_lt_gemm_trace[3 * lt_trace_id + 2] = ((unsigned long long)(xcc & 0xf) << 32) | hwid;
+    }
+#endif
     __shared__ __attribute__((aligned(16))) float As[2][GL_BM * GL_LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][GL_BK * GL_BN];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -413,6 +427,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma_128(const float *__restri
                 if (cm < M) C[(long)cm * ldc + cn] = acc[i][j][reg];
             }
         }
+#ifdef LT_GEMM_TRACE
+    if (threadIdx.x == 0 && g_lt_gemm_trace) g_lt_gemm_trace[3 * lt_trace_id + 1] = wall_clock64();
+#endif
 }
 
 int lt_launch_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
