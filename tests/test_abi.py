@@ -82,3 +82,25 @@ def test_workspace_queries_and_argument_errors(lt):
     assert h.lt_profile_summary(99, C.byref(tot), C.byref(cnt)) == -1
     assert h.lt_profile_enable(0) == 0 and h.lt_profile_reset() == 0
     assert h.lt_profile_summary(0, C.byref(tot), C.byref(cnt)) == 0 and cnt.value == 0
+
+
+def test_every_documented_tuning_key_is_accepted(lt):
+    """The tuning keys listed in the header comment of lt_set_tuning are the keys the library knows (host-side state
+    only: callable without a GPU); unknown keys and out-of-range values are refused with LT_ERR_INVALID."""
+    src = open(os.path.join(REPO, "include", "linkteller_hip.h")).read()
+    block = src[src.index("tuning knobs"):src.index("#define LT_TUNING_DEFAULT")]
+    keys = re.findall(r'^ \*\s+"([a-z0-9_]+)"', block, flags=re.M)
+    assert len(keys) >= 12 and len(set(keys)) == len(keys)
+    for k in keys:
+        lt.set_tuning(k, None)                      # restoring the default is always valid
+    # every key the library parses is documented
+    core = open(os.path.join(REPO, "linkteller_amd", "csrc", "lt_core.hip")).read()
+    parsed = set(re.findall(r'strcmp\(key, "([a-z0-9_]+)"\)', core))
+    assert parsed == set(keys), parsed ^ set(keys)
+    h = lt.lib()
+    assert h.lt_set_tuning(b"no_such_knob", 1) == -1 and b"unknown key" in h.lt_last_error()
+    assert h.lt_set_tuning(b"full_p", 12) == -1
+    assert h.lt_set_tuning(b"chunk_budget_bytes", 0) == -1
+    assert h.lt_set_tuning(None, 1) == -1
+    for k in keys:
+        lt.set_tuning(k, None)
