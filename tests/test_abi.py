@@ -104,3 +104,35 @@ def test_every_documented_tuning_key_is_accepted(lt):
     assert h.lt_set_tuning(None, 1) == -1
     for k in keys:
         lt.set_tuning(k, None)
+
+
+def test_header_is_plain_c_and_links_from_c(lt, tmp_path):
+    """The boundary is a C ABI: include/linkteller_hip.h compiles as C99 with -pedantic (and as C++), and a C program
+    that binds a few entry points links against the shared object and runs without a GPU (host-only calls)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "c_caller.c"
+    src.write_text('#include <stdio.h>\n#include <string.h>\n#include "linkteller_hip.h"\n'
+                   'int main(void) {\n'
+                   '    int n = -1;\n'
+                   '    if (lt_abi_version() != LT_ABI_VERSION) return 1;\n'
+                   '    if (lt_device_count(&n) != LT_OK || n < 0) return 2;\n'
+                   '    if (lt_set_tuning("full_p", 12) != LT_ERR_INVALID) return 3;\n'
+                   '    if (strstr(lt_last_error(), "full_p") == NULL) return 4;\n'
+                   '    if (lt_set_tuning("full_p", LT_TUNING_DEFAULT) != LT_OK) return 5;\n'
+                   '    lt_graph *g = NULL;\n'
+                   '    if (lt_graph_create(-1, 0, NULL, NULL, NULL, &g) != LT_ERR_INVALID || g != NULL) return 6;\n'
+                   '    printf("ok %d\\n", n);\n    return 0;\n}\n')
+    inc = os.path.join(REPO, "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, "-fsyntax-only", str(src)], check=True)
+    if shutil.which("g++"):
+        subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)], check=True)
+    exe = tmp_path / "c_caller"
+    libdir = os.path.dirname(lt.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-llinkteller_hip",
+                        f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and run.stdout.startswith("ok"), (run.returncode, run.stdout, run.stderr[-500:])
