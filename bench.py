@@ -174,9 +174,13 @@ def main():
         shard = None
         if with_shard:
             shard = influence_shard(gb, big.shape[0], scale, hcols)
+        tr = measured_traffic(key)
         return {"influence_shard": shard, "kernel": "k_rows_tiled (+ k_spmm_long_combine for the hub rows)", "bound": "hbm",
+                # the HBM-side rate of the bytes the kernel really moves (PMC traffic over the measured duration)
+                "traffic_GBps": round(tr / sec / 1e9, 1) if tr else None,
+                "traffic_frac_of_peak": round(tr / sec / 1e9 / HBM_PEAK_GBS, 4) if tr else None,
                 "achieved": round(byts / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(byts / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": measured_traffic(key),
+                "frac": round(byts / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": tr,
                 "algorithmic_bytes_per_launch": int(byts), "avg_launch_us": round(sec * 1e6, 1),
                 "units_per_launch": f"one SpMM A_hat[{big.shape[0]}^2, nnz={big.nnz}] x S[{big.shape[0]}x{hcols}] fp32 "
                                     f"(R-MAT scale {scale}, max row {int(np.diff(big.indptr).max())})",
