@@ -135,6 +135,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma(const float *__restrict__
 // per call); a 64-deep tile carries 32 MFMAs per wave (0.85 us) behind one round of loads, the next tile's
 // loads are in flight meanwhile, and a slice is 4 trips.  Requires N % 64 == 0 (full B tiles); rows past M
 // are clamped (they feed output rows that are never stored).  Same k-ordered chains, same bits.
+#ifdef LT_GEMM_TRACE
+__device__ unsigned long long *g_lt_gemm_trace = nullptr;
+#endif
 #define GD_BK 64
 #define GD_LDA (GD_BK + 1)
 #define GD_PASS 4   // 256 threads x float4 cover 16 rows x 64 floats per pass
@@ -144,6 +147,13 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma_deep(const float *__restr
                                                             float *__restrict__ C, long ldc, int M, int N,
                                                             int K, int kslice, long slab_stride,
                                                             const int32_t *__restrict__ rows, float delta) {
+#ifdef LT_GEMM_TRACE
+    const unsigned lt_trace_id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (threadIdx.x == 0 && g_lt_gemm_trace) {
+        g_lt_gemm_trace[3 * lt_trace_id] = wall_clock64();
+        g_lt_gemm_trace[3 * lt_trace_id + 2] = 0;
+    }
+#endif
     __shared__ __attribute__((aligned(16))) float As[2][GM_BM * GD_LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][GD_BK * GM_BN];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -238,6 +248,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma_deep(const float *__restr
         const int cm = m0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         if (cm < M) C[(long)cm * ldc + cn] = acc[reg];
     }
+#ifdef LT_GEMM_TRACE
+    if (threadIdx.x == 0 && g_lt_gemm_trace) g_lt_gemm_trace[3 * lt_trace_id + 1] = wall_clock64();
+#endif
 }
 
 
@@ -251,9 +264,6 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma_deep(const float *__restr
 // on this part (tools/fold_test/mfma_peak.hip); the LDS store + barrier per k-tile is the largest rest.
 #define GL_BM 128
 #define GL_BN 128
-#ifdef LT_GEMM_TRACE
-__device__ unsigned long long *g_lt_gemm_trace = nullptr;
-#endif
 #ifndef GL_BK
 #define GL_BK 16        // k-depth of a tile (32 measured 8 % slower, also with the two-stage prefetch)
 #endif

@@ -14,10 +14,11 @@ int main(int argc, char **argv) {
     float *A, *B, *C, *slabs;
     hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&B, (size_t)K * N * 4); hipMalloc(&C, (size_t)M * N * 4);
     hipMemset(A, 0, (size_t)M * K * 4); hipMemset(B, 0, (size_t)K * N * 4);
-    const int ks = lt_gemm_pick_kslice(M, N, K);
+    const int ks = argc > 4 ? atoi(argv[4]) : lt_gemm_pick_kslice(M, N, K);      // argv[4]: K slice (the product slices the probe rows as it slices X*W1)
     const int splits = (K + ks - 1) / ks;
     hipMalloc(&slabs, lt_gemm_splitk_slab_bytes(M, N, K, ks) + 16);
-    const int nwg = ((M + 127) / 128) * (N / 128) * splits;
+    const bool big = M >= 1024 && N % 128 == 0;     // fewer rows: the 64 x 64 kernel (k_gemm_f32_mfma_deep)
+    const int nwg = big ? ((M + 127) / 128) * (N / 128) * splits : ((M + 63) / 64) * ((N + 63) / 64) * splits;
     unsigned long long *trace;
     hipMalloc(&trace, (size_t)nwg * 3 * 8);
     hipMemcpyToSymbol(HIP_SYMBOL(g_lt_gemm_trace), &trace, sizeof(trace));
