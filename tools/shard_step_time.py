@@ -1,21 +1,22 @@
 """What one rank of N does per step at twitch-RU size (n_test = 500 -> ceil(500 / N) probes x 500 observed, baseline
 replicated): eager calls vs a captured hipGraph -- is the step GPU-bound or bound by the host's launch rate?
-python tools/shard_step_time.py [mode]"""
+python tools/shard_step_time.py [mode] [n_test]"""
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from linkteller_amd import engine, graph, synth
 mode = sys.argv[1] if len(sys.argv) > 1 else "full"
+n_test = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 adj, x_np, w = synth.twitch_like_problem("twitch-RU", hidden=256)
 a_hat = graph.first_order_gcn(adj)
 dev = torch.device("cuda:0")
 base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x_np).to(dev), *[torch.from_numpy(w[k]).to(dev) for k in ("W1", "b1", "W2", "b2")])
 np.random.seed(42)
-nodes = np.random.choice(np.arange(adj.shape[0]), 500, replace=False).astype(np.int32)
+nodes = np.random.choice(np.arange(adj.shape[0]), n_test, replace=False).astype(np.int32)
 obs = torch.from_numpy(nodes).to(dev)
 for N in (1, 2, 4, 8):
-    per = (500 + N - 1) // N
+    per = (n_test + N - 1) // N
     probes = torch.from_numpy(nodes[:per]).to(dev)
-    out = torch.empty((per, 500), dtype=torch.float32, device=dev)
+    out = torch.empty((per, n_test), dtype=torch.float32, device=dev)
     def step():
         base.refresh()
         base.influence_rows(probes, obs, 1e-4, mode, out=out)
