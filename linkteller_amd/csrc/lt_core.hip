@@ -5,7 +5,10 @@
 
 #include <algorithm>
 #include <functional>
+#include <memory>
 #include <new>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include "lt_internal.h"
@@ -125,55 +128,112 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
     LT_REQUIRE(rowptr[0] == 0, "lt_graph_create: rowptr[0]=%d, expected 0", rowptr[0]);
     LT_REQUIRE((int64_t)rowptr[n] == nnz, "lt_graph_create: rowptr[n]=%d != nnz=%lld", rowptr[n], (long long)nnz);
 
-    // validate + build the transpose on the host (counting sort keeps rows ascending per column)
-    std::vector<int32_t> tptr((size_t)n + 1, 0), trow;
-    std::vector<float> tval;
-    int32_t max_row = 0;
+    // validate + build the transpose on the host: a counting sort that keeps the rows ascending inside each column,
+    // split over threads by contiguous row ranges (thread t counts / fills its rows; its cursors start behind the
+    // entries of the threads with lower rows, so the result does not depend on the thread count).  A 77 M-entry graph:
+    // ~1 s single-threaded, most of it the scattered fill.
+    std::vector<int32_t> tptr;
+    std::unique_ptr<int32_t[]> trow;     // (uninitialised: the threads of the fill touch the pages, not a zeroing pass)
+    std::unique_ptr<float[]> tval;
+    int32_t max_row = 0, max_col = 0;
     int64_t n_local = 0;
-    for (int32_t r = 0; r < n; ++r) {
-        const int32_t b = rowptr[r], e = rowptr[r + 1];
-        LT_REQUIRE(b <= e, "lt_graph_create: rowptr not monotone at row %d", r);
-        if (e - b > max_row) max_row = e - b;
-        for (int32_t k = b; k < e; ++k) {
-            const int32_t c = col[k];
-            n_local += (c >= r ? c - r : r - c) <= LT_LOCAL_WINDOW;
-            LT_REQUIRE(c >= 0 && c < n, "lt_graph_create: column %d out of range at row %d", c, r);
-            LT_REQUIRE(k == b || col[k - 1] < c,
-                       "lt_graph_create: columns of row %d are not strictly increasing", r);
-            tptr[(size_t)c + 1]++;
-        }
-    }
-    int32_t max_col = 0;
     double hot_frac = 1.0;
-    if (n > LT_HOT_COLUMNS && nnz > 0) {   // entries that read the LT_HOT_COLUMNS most-read columns
-        try {
+    try {
+        tptr.assign((size_t)n + 1, 0);
+        unsigned T = 1;
+        if (nnz >= (1 << 20)) {
+            T = std::thread::hardware_concurrency();
+            if (T < 1) T = 1;
+            if (T > 16) T = 16;
+            while (T > 1 && (size_t)T * (size_t)n > ((size_t)1 << 28)) --T;   // <= 1 GiB of per-thread counters
+            if ((int64_t)T > (int64_t)n) T = n > 0 ? (unsigned)n : 1;
+        }
+        // row ranges with about nnz / T entries each
+        std::vector<int32_t> rb(T + 1, n);
+        rb[0] = 0;
+        for (unsigned t = 1; t < T; ++t) {
+            const int64_t want = nnz / T * t;
+            rb[t] = (int32_t)(std::lower_bound(rowptr, rowptr + n, (int32_t)want) - rowptr);
+            if (rb[t] < rb[t - 1]) rb[t] = rb[t - 1];
+        }
+        struct part { int64_t n_local = 0; int32_t max_row = 0; int32_t bad_row = -1, bad_col = 0; int bad_kind = 0; };
+        std::vector<part> parts(T);
+        std::vector<std::vector<int32_t>> cnt(T);
+        for (unsigned t = 0; t < T; ++t) cnt[t].assign((size_t)n, 0);
+        auto run = [&](auto &&fn) {
+            if (T == 1) { fn(0u); return; }
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < T; ++t) th.emplace_back(fn, t);
+            for (auto &x : th) x.join();
+        };
+        run([&](unsigned t) {
+            part &pt = parts[t];
+            int32_t *ct = cnt[t].data();
+            for (int32_t r = rb[t]; r < rb[t + 1]; ++r) {
+                const int32_t b = rowptr[r], e = rowptr[r + 1];
+                if (b > e) { pt.bad_row = r; pt.bad_kind = 1; return; }
+                if (e - b > pt.max_row) pt.max_row = e - b;
+                for (int32_t k = b; k < e; ++k) {
+                    const int32_t c = col[k];
+                    if (c < 0 || c >= n) { pt.bad_row = r; pt.bad_col = c; pt.bad_kind = 2; return; }
+                    if (k != b && col[k - 1] >= c) { pt.bad_row = r; pt.bad_kind = 3; return; }
+                    pt.n_local += (c >= r ? c - r : r - c) <= LT_LOCAL_WINDOW;
+                    ct[c]++;
+                }
+            }
+        });
+        for (unsigned t = 0; t < T; ++t) {       // the first offending row, as a single pass would report it
+            const part &pt = parts[t];
+            if (pt.bad_kind == 1) return lt_set_error(LT_ERR_INVALID, "lt_graph_create: rowptr not monotone at row %d", pt.bad_row);
+            if (pt.bad_kind == 2) return lt_set_error(LT_ERR_INVALID, "lt_graph_create: column %d out of range at row %d", pt.bad_col, pt.bad_row);
+            if (pt.bad_kind == 3) return lt_set_error(LT_ERR_INVALID, "lt_graph_create: columns of row %d are not strictly increasing", pt.bad_row);
+            n_local += pt.n_local;
+            if (pt.max_row > max_row) max_row = pt.max_row;
+        }
+        // column totals -> tptr; the per-thread counters become per-thread cursors (column ranges in parallel)
+        run([&](unsigned t) {
+            const int32_t c0 = (int32_t)((int64_t)n * t / T), c1 = (int32_t)((int64_t)n * (t + 1) / T);
+            for (int32_t c = c0; c < c1; ++c) {
+                int32_t tot = 0;
+                for (unsigned u = 0; u < T; ++u) tot += cnt[u][c];
+                tptr[(size_t)c + 1] = tot;
+            }
+        });
+        if (n > LT_HOT_COLUMNS && nnz > 0) {   // entries that read the LT_HOT_COLUMNS most-read columns
             std::vector<int32_t> indeg(tptr.begin() + 1, tptr.end());
             std::nth_element(indeg.begin(), indeg.begin() + LT_HOT_COLUMNS, indeg.end(), std::greater<int32_t>());
             int64_t hot = 0;
             for (int i = 0; i < LT_HOT_COLUMNS; ++i) hot += indeg[i];
             hot_frac = (double)hot / (double)nnz;
-        } catch (const std::bad_alloc &) {
-            return lt_set_error(LT_ERR_NOMEM, "lt_graph_create: host allocation failed");
         }
-    }
-    for (int32_t c = 0; c < n; ++c) {
-        if (tptr[(size_t)c + 1] > max_col) max_col = tptr[(size_t)c + 1];
-        tptr[(size_t)c + 1] += tptr[c];
-    }
-    try {
-        trow.resize((size_t)nnz);
-        tval.resize((size_t)nnz);
-    } catch (const std::bad_alloc &) {
-        return lt_set_error(LT_ERR_NOMEM, "lt_graph_create: host allocation of %lld entries failed", (long long)nnz);
-    }
-    {
-        std::vector<int32_t> cursor(tptr.begin(), tptr.end() - 1);
-        for (int32_t r = 0; r < n; ++r)
-            for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
-                const int32_t p = cursor[col[k]]++;
-                trow[p] = r;
-                tval[p] = val[k];
+        for (int32_t c = 0; c < n; ++c) {
+            if (tptr[(size_t)c + 1] > max_col) max_col = tptr[(size_t)c + 1];
+            tptr[(size_t)c + 1] += tptr[c];
+        }
+        run([&](unsigned t) {
+            const int32_t c0 = (int32_t)((int64_t)n * t / T), c1 = (int32_t)((int64_t)n * (t + 1) / T);
+            for (int32_t c = c0; c < c1; ++c) {
+                int32_t at = tptr[c];
+                for (unsigned u = 0; u < T; ++u) { const int32_t k = cnt[u][c]; cnt[u][c] = at; at += k; }
             }
+        });
+        trow.reset(new int32_t[(size_t)nnz + 1]);
+        tval.reset(new float[(size_t)nnz + 1]);
+        int32_t *trow_p = trow.get();
+        float *tval_p = tval.get();
+        run([&](unsigned t) {
+            int32_t *cur = cnt[t].data();
+            for (int32_t r = rb[t]; r < rb[t + 1]; ++r)
+                for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+                    const int32_t p = cur[col[k]]++;
+                    trow_p[p] = r;
+                    tval_p[p] = val[k];
+                }
+        });
+    } catch (const std::bad_alloc &) {
+        return lt_set_error(LT_ERR_NOMEM, "lt_graph_create: host allocation for %lld entries failed", (long long)nnz);
+    } catch (const std::system_error &) {
+        return lt_set_error(LT_ERR_NOMEM, "lt_graph_create: could not start the host threads");
     }
 
     lt_graph *g = new (std::nothrow) lt_graph();
@@ -210,8 +270,8 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
     if (nnz > 0) {
         G_HIP(hipMemcpy(g->col, col, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
         G_HIP(hipMemcpy(g->val, val, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice));
-        G_HIP(hipMemcpy(g->trow, trow.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
-        G_HIP(hipMemcpy(g->tval, tval.data(), (size_t)nnz * sizeof(float), hipMemcpyHostToDevice));
+        G_HIP(hipMemcpy(g->trow, trow.get(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+        G_HIP(hipMemcpy(g->tval, tval.get(), (size_t)nnz * sizeof(float), hipMemcpyHostToDevice));
     }
     // segment table of the long rows (LT_ROW_SEG entries per segment)
     {
@@ -250,13 +310,21 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
                 items.push_back({sbeg[sg], left < LT_ROW_SEG ? left : LT_ROW_SEG, n + (int32_t)sg});
             }
             std::stable_sort(items.begin(), items.end(), [col](const item &a, const item &b) { return col[a.e0] < col[b.e0]; });
+            // the short rows by length class (16 entries), longest first, row order kept inside a class: a counting sort
             const size_t nseg_items = items.size();
+            constexpr int NCLS = LT_ROW_SEG / 16 + 1;
+            size_t cls_n[NCLS] = {};
             for (int32_t r = 0; r < n; ++r) {
                 const int32_t d = rowptr[r + 1] - rowptr[r];
-                if (d <= LT_ROW_SEG) items.push_back({rowptr[r], d, r});
+                if (d <= LT_ROW_SEG) cls_n[(d + 15) / 16]++;
             }
-            std::stable_sort(items.begin() + nseg_items, items.end(),
-                             [](const item &a, const item &b) { return (a.cnt + 15) / 16 > (b.cnt + 15) / 16; });
+            size_t cls_at[NCLS], at = nseg_items;
+            for (int k = NCLS - 1; k >= 0; --k) { cls_at[k] = at; at += cls_n[k]; }
+            items.resize(at);
+            for (int32_t r = 0; r < n; ++r) {
+                const int32_t d = rowptr[r + 1] - rowptr[r];
+                if (d <= LT_ROW_SEG) items[cls_at[(d + 15) / 16]++] = {rowptr[r], d, r};
+            }
         } catch (const std::bad_alloc &) {
             free_graph(g);
             return lt_set_error(LT_ERR_NOMEM, "lt_graph_create: host allocation of the work list failed");
