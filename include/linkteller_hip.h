@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 1
+#define LT_ABI_VERSION 2   /* 2: lt_baseline_refresh launches nothing (lazy recomputation on the first reader's stream); fp64 shard entry points;
+                            profile classes 9-11 */
 
 typedef enum lt_status {
     LT_OK = 0,
@@ -78,6 +79,11 @@ int lt_device_count(int *count);
  *                         middle nodes; 0 = always, negative = never (default 2^22)
  *   "wide_min_hp"         smallest padded hidden width served by the batched stage-A kernel
  *   "tiled_big"           1 = the tiled SpMM uses its 64-bit gather offsets on any graph (test hook; default: S >= 4 GiB)
+ *   "feature_delta"       fp64 product X*W1 of LT_MODE_DELTA from the differences of the feature rows to one reference row
+ *                         (one pass over X when every column holds two values, as standardised indicator features do;
+ *                         exact for any X): 0 = never, 1 = always try, negative = when lt_baseline_enable_fp64 found the
+ *                         features to be of that kind (default).  The only knob that changes fp64 summation ORDER (the
+ *                         results agree to ~1e-16 relative before the final rounding to fp32).
  *   "probe_kslice"        K-slice of the perturbed-row GEMM; 0 = the slicing of the baseline X*W1 (default: S1'[v] and
  *                         S1[v] then share one summation order, like the reference's two torch.mm calls)
  * value = LT_TUNING_DEFAULT restores the default. */
@@ -101,11 +107,15 @@ int lt_gemm_f32(const float *A, int64_t lda, const float *B, int64_t ldb, float 
 
 /* ---- SpMM out[n,ncols] = A_hat * S (+ bias) (ReLU)  (torch.spmm + bias at
  * gcn/layers.py:32-36, F.relu at gcn/models.py:20) ---------------------------------------
- * ncols % 4 == 0 and ncols <= 256, or ncols <= 8; S/out 16-byte aligned when ncols % 4 == 0.
- * Row-owned, fixed-order fmaf chains: deterministic and run-to-run reproducible. */
+ * Any ncols (the reference has no width limit): columns are independent chains, so wide layers are served in slices of
+ * 256 columns; the 16-byte vector path takes what is aligned (S / out / bias 16-byte aligned, lds and ldo multiples of
+ * 4), a tail of ncols % 4 columns and unaligned operands go through an 8-lane kernel, 8 columns per launch.
+ * Row-owned, fixed-order fmaf chains: deterministic and run-to-run reproducible.
+ * lt_spmm_route: 1 when the call takes the tiled (column-sliced work-item) route on this graph, 0 for the row kernels. */
 int lt_spmm_csr_f32(const lt_graph *g, const float *S, int64_t lds, int32_t ncols,
                     const float *bias_or_null, int32_t relu, float *out, int64_t ldo,
                     void *stream);
+int lt_spmm_route(const lt_graph *g, int32_t ncols);
 
 /* ---- 2-layer GCN forward (GCN.forward, gcn/models.py:19-24, eval mode) ------------------
  * logits[n,C] = A_hat * (relu(A_hat * (X*W1) + b1) * W2) + b2.   H <= 256, C <= 8.
@@ -148,6 +158,17 @@ int lt_baseline_refresh(lt_baseline *b, void *stream);
  *   job; Z1 / S2 / OUT are marked stale exactly as by lt_baseline_refresh. */
 int lt_baseline_attach_s1(lt_baseline *b, float *S1, int64_t ld, void *stream);
 int lt_baseline_refresh_rows(lt_baseline *b, int32_t row_begin, int32_t row_end, float *dst, void *stream);
+/* The fp64 twins (LT_MODE_DELTA with lt_baseline_enable_fp64 on): lt_baseline_attach_s1d hands the library caller-owned
+ * storage for S1d = X*W1 in fp64 ([>= n, Hp] doubles, ld == Hp, 16-byte aligned: the output of the ranks' all-gather) and
+ * switches the baseline to "S1d arrives from outside"; lt_baseline_refresh_rows_fp64 computes rows [row_begin, row_end)
+ * of the fp64 product into dst[row_end - row_begin, Hp] (the rank's send buffer).  Same K slicing whatever the range, so a
+ * row carries the same bits whichever rank computed it.  lt_baseline_fp64_route: 1 when the baseline's features were
+ * found to be sparse differences to a reference row (two-valued columns, as standardised indicator features are) and
+ * the fp64 product therefore costs one pass over X -- then sharding it buys nothing -- 0 when it runs on the f64
+ * matrix cores, -1 when fp64 is not enabled. */
+int lt_baseline_attach_s1d(lt_baseline *b, double *S1d, int64_t ld, void *stream);
+int lt_baseline_refresh_rows_fp64(lt_baseline *b, int32_t row_begin, int32_t row_end, double *dst, void *stream);
+int lt_baseline_fp64_route(const lt_baseline *b, int32_t *route);
 int lt_baseline_destroy(lt_baseline *b);
 /* copies the baseline logits OUT [n, C] (dense, ld = C) to a device buffer */
 int lt_baseline_logits(const lt_baseline *b, float *dst, void *stream);
@@ -205,7 +226,10 @@ typedef enum lt_kernel_id {
     LT_K_ITEM_A = 6,      /* k_item_stageA (sparse / delta)            */
     LT_K_ITEM_B = 7,      /* k_item_stageB (sparse / delta)            */
     LT_K_SPMM = 8,        /* k_spmm_rows / k_spmm_narrow               */
-    LT_K_COUNT = 9
+    LT_K_FP64_PRODUCT = 9,/* S1d = X*W1 in fp64: k_s1d_feature_rows (+ the reference row's product), or k_gemm_f64acc_128 + k_sum_slabs_f64 */
+    LT_K_FP64_SPMM = 10,  /* Z1d = A_hat*S1d + b1: k_spmm_f64 / k_rows_tiled_f64 (+ long-row combine) */
+    LT_K_ITEM_BITS = 11,  /* k_item_bits (+ the pair-mark kernels): item offsets, (probe, row) table, membership bitmap */
+    LT_K_COUNT = 12
 } lt_kernel_id;
 int lt_profile_enable(int mask);
 int lt_profile_reset(void);

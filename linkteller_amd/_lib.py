@@ -38,6 +38,7 @@ SIGNATURES = {
                               C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "lt_spmm_csr_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32,
                                   C.c_void_p, C.c_int64, C.c_void_p]),
+    "lt_spmm_route": (C.c_int, [C.c_void_p, C.c_int32]),
     "lt_gcn2_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "lt_gcn2_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
@@ -49,6 +50,9 @@ SIGNATURES = {
     "lt_baseline_attach_s1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "lt_baseline_refresh_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "lt_baseline_enable_fp64": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lt_baseline_attach_s1d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "lt_baseline_refresh_rows_fp64": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "lt_baseline_fp64_route": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "lt_baseline_destroy": (C.c_int, [C.c_void_p]),
     "lt_baseline_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "lt_influence_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
@@ -68,7 +72,8 @@ SIGNATURES = {
     "lt_profile_summary": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 KERNEL_IDS = {"gemm": 0, "layer1": 1, "layer2": 2, "perturb": 3, "full_stageA": 4, "full_stageB": 5,
-              "item_stageA": 6, "item_stageB": 7, "spmm": 8}
+              "item_stageA": 6, "item_stageB": 7, "spmm": 8, "fp64_product": 9, "fp64_spmm": 10, "item_bits": 11}
+ABI_VERSION = 2
 
 
 def lib():

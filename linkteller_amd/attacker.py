@@ -133,39 +133,61 @@ class Attacker:
             self._baseline.refresh()
         return self._baseline
 
+    def _mode(self, mode=None):
+        return mode or getattr(self.args, "influence_mode", None) or os.environ.get("LT_INFLUENCE_MODE", "delta")
+
     def _rows(self, probe_nodes, observe_nodes, mode=None):
         """[len(probe_nodes), len(observe_nodes)] influence rows on the device."""
         if self._is_two_layer():
-            mode = mode or getattr(self.args, "influence_mode", None) or os.environ.get("LT_INFLUENCE_MODE", "delta")
-            return self.baseline().influence_rows(probe_nodes, observe_nodes, float(self.args.influence), mode)
+            mode = self._mode(mode)
+            base = self.baseline(mode)
+            if isinstance(base, engine.WideBaseline) and mode == "delta":
+                # no exact propagation outside the fused widths: say so once instead of silently serving another mode
+                if not getattr(self, "_warned_wide", False):
+                    print("influence-mode 'delta' is not available for layers wider than 256 hidden units / 8 classes: "
+                          "using the reference's fp32 finite difference ('sparse') on the unfused HIP layers")
+                    self._warned_wide = True
+                mode = "sparse"
+            return base.influence_rows(probe_nodes, observe_nodes, float(self.args.influence), mode)
         if self._is_three_layer():
             # the 3-hop probe primitive: the reference's fp32 finite difference on the rows a probe can reach
+            if self._mode(mode) == "delta" and not getattr(self, "_warned_gcn3", False):
+                print("influence-mode 'delta' is not implemented for the 3-layer model: using the reference's fp32 finite "
+                      "difference on the 3-hop set (lt_influence3_rows)")
+                self._warned_gcn3 = True
             return self.baseline3().influence_rows(probe_nodes, observe_nodes, float(self.args.influence))
         return self._rows_generic(probe_nodes, observe_nodes)
 
-    def baseline(self) -> engine.Baseline:
+    def baseline(self, mode=None) -> engine.Baseline:
         """Loop-invariant model(features, adj) of attacker.py:106: built once per (features, adj, parameters) --
         rebuilt when any of them was replaced, refreshed (X W1 recomputed from the borrowed tensors) on every attack
-        so that in-place weight updates are seen.  With several ranks X W1 is sharded or replicated per
-        ``dist.choose_baseline_sharding``."""
+        so that in-place weight updates are seen.  With several ranks the product the MODE reads (fp32 X W1 for `full` /
+        `sparse`, the fp64 one for `delta`) is sharded or replicated per ``dist.choose_baseline_sharding``."""
+        mode = self._mode(mode)
         dev = self.features.device
         src = self._params()
         off_device = any(p.device != dev for p in src)
         # parameters held on another device are copied: then an in-place update (p._version) means a rebuild too
         key = (id(self.adj), self.features.data_ptr(), tuple((p.data_ptr(), p._version if off_device else 0) for p in src))
-        if self._baseline is None or self._baseline_key != key:
-            self._baseline = engine.Baseline(self.adj, self.features, *[p.to(dev) for p in src])
+        created = self._baseline is None or self._baseline_key != key
+        if created:
+            self._baseline = engine.baseline_for(self.adj, self.features, *[p.to(dev) for p in src])
             self._baseline_key = key
-            lt_dist.choose_baseline_sharding(self._baseline)
-        else:
-            self._baseline.refresh()
+            self._sharding_mode = None
+        refreshed = created and lt_dist.world()[1] == 1           # a new baseline computes everything on first use
+        if getattr(self, "_sharding_mode", None) != mode:
+            lt_dist.choose_baseline_sharding(self._baseline, mode=mode)      # (several ranks: ends with a refresh for `mode`)
+            self._sharding_mode = mode
+            refreshed = refreshed or lt_dist.world()[1] > 1
+        if not refreshed:
+            self._baseline.refresh(mode)
         return self._baseline
 
     def get_gradient_eps_mat(self, v):
         """attacker.py:100-108: (model(X + pert_v, A) - model(X, A)) / influence as an [N, C] tensor.
         Kept for API parity (one probe, all nodes observed); the attack itself uses the batched
         primitive and never materialises this matrix."""
-        base = self.baseline()
+        base = self.baseline("full")
         delta = float(self.args.influence)
         x = self.features
         xp = x.clone()

@@ -48,6 +48,7 @@ static lt_tuning tuning_defaults() {
     t.hub_short_side = getenv("LT_HUB_SHORT_SIDE") ? (env_ll("LT_HUB_SHORT_SIDE", 0) != 0 ? 1 : 0) : -1;
     t.bits_max_bytes = env_ll("LT_BITS_MAX_BYTES", (long long)128 << 20);
     t.tiled_big = 0;
+    t.feature_delta = getenv("LT_FEATURE_DELTA") ? (env_ll("LT_FEATURE_DELTA", 0) != 0 ? 1 : 0) : -1;
     return t;
 }
 lt_tuning &lt_tune() {
@@ -78,6 +79,7 @@ extern "C" int lt_set_tuning(const char *key, long long value) {
     else if (!strcmp(key, "hub_short_side")) t.hub_short_side = reset ? d.hub_short_side : (value < 0 ? -1 : (value != 0));
     else if (!strcmp(key, "bits_max_bytes")) t.bits_max_bytes = reset ? d.bits_max_bytes : value;
     else if (!strcmp(key, "tiled_big")) t.tiled_big = reset ? 0 : (value != 0);
+    else if (!strcmp(key, "feature_delta")) t.feature_delta = reset ? d.feature_delta : (value < 0 ? -1 : (value != 0));
     else if (!strcmp(key, "probe_kslice")) {
         LT_REQUIRE(reset || (value >= 0 && value <= 1 << 20), "lt_set_tuning: probe_kslice must be >= 0");
         t.probe_kslice = reset ? d.probe_kslice : (int)value;
@@ -153,6 +155,7 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
         rb[0] = 0;
         for (unsigned t = 1; t < T; ++t) {
             const int64_t want = nnz / T * t;
+            // (on a malformed, non-monotone rowptr the search lands anywhere in [0, n]; the pass below reports the row)
             rb[t] = (int32_t)(std::lower_bound(rowptr, rowptr + n, (int32_t)want) - rowptr);
             if (rb[t] < rb[t - 1]) rb[t] = rb[t - 1];
         }
@@ -162,16 +165,22 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
         for (unsigned t = 0; t < T; ++t) cnt[t].assign((size_t)n, 0);
         auto run = [&](auto &&fn) {
             if (T == 1) { fn(0u); return; }
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < T; ++t) th.emplace_back(fn, t);
-            for (auto &x : th) x.join();
+            // (a std::thread constructor may throw std::system_error: the threads already running are joined before
+            // it travels on -- destroying a joinable std::thread would call std::terminate)
+            struct joiner {
+                std::vector<std::thread> th;
+                ~joiner() { for (auto &x : th) if (x.joinable()) x.join(); }
+            } j;
+            j.th.reserve(T);
+            for (unsigned t = 0; t < T; ++t) j.th.emplace_back(fn, t);
         };
         run([&](unsigned t) {
             part &pt = parts[t];
             int32_t *ct = cnt[t].data();
             for (int32_t r = rb[t]; r < rb[t + 1]; ++r) {
                 const int32_t b = rowptr[r], e = rowptr[r + 1];
-                if (b > e) { pt.bad_row = r; pt.bad_kind = 1; return; }
+                // (each thread starts in the middle of rowptr: every offset is range-checked before col[] is read)
+                if (b < 0 || (int64_t)e > nnz || b > e) { pt.bad_row = r; pt.bad_kind = 1; return; }
                 if (e - b > pt.max_row) pt.max_row = e - b;
                 for (int32_t k = b; k < e; ++k) {
                     const int32_t c = col[k];

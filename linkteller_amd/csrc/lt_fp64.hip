@@ -26,7 +26,8 @@ typedef float f32x4u_ __attribute__((ext_vector_type(4), aligned(4)));
 __global__ __launch_bounds__(256) void k_gemm_f64acc(const float *__restrict__ A, long lda,
                                                      const float *__restrict__ B, long ldb,
                                                      double *__restrict__ C, long ldc, int M, int N, int K,
-                                                     int kslice, long slab_stride) {
+                                                     int kslice, long slab_stride, const int *__restrict__ gate) {
+    if (gate && *gate == 0) return;   // the feature-difference product served every row: nothing to do (see k_s1d_feature_rows)
     __shared__ __attribute__((aligned(16))) float As[2][GD_BM * GD_LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][GD_BK * GD_LDB];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -125,7 +126,8 @@ __global__ __launch_bounds__(256) void k_gemm_f64acc(const float *__restrict__ A
 __global__ __launch_bounds__(256, 2) void k_gemm_f64acc_128(const float *__restrict__ A, long lda,
                                                          const float *__restrict__ B, long ldb,
                                                          double *__restrict__ C, long ldc, int M, int N, int K,
-                                                         int kslice, long slab_stride) {
+                                                         int kslice, long slab_stride, const int *__restrict__ gate) {
+    if (gate && *gate == 0) return;
     __shared__ __attribute__((aligned(16))) float As[2][GE_BM * GE_LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][GE_BK * GE_LDB];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -256,7 +258,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64acc_128(const float *__restr
 }
 
 __global__ void k_sum_slabs_f64(const double *__restrict__ slabs, long slab_stride, int splits, long total,
-                                int N, double *__restrict__ C, long ldc) {
+                                int N, double *__restrict__ C, long ldc, const int *__restrict__ gate) {
+    if (gate && *gate == 0) return;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     double acc = slabs[i];
@@ -336,6 +339,116 @@ __global__ void k_spmm_f64_long(int n_long, const int32_t *__restrict__ long_row
     out[(size_t)long_row[li] * ld + c] = acc + (double)b1p[c];
 }
 
+// ---- S1d = X*W1 from the DIFFERENCES of the feature rows to one reference row ---------------------------------------
+//   S1d[i, :] = S1d[ref, :] + sum_{j : X[i,j] != X[ref,j]} (X[i,j] - X[ref,j]) * W1[j, :]
+// is an identity for any X (in fp64 the difference of two fp32 values is exact, so the terms are the exact products the
+// dense sum holds; only the order of an fp64 summation changes).  It pays when rows differ from the reference row in few
+// columns -- which is how the reference's own twitch features look: utils/load.py:53-59 builds 0/1 indicator rows
+// (a few dozen of 3170 set) and worker.py standardises them per column, so every column holds TWO values and a row
+// differs from any other in ~ 2 x (features set) places.  Then the fp64 product is one pass over X (HBM-bound: N*F*4
+// bytes) and ~ 40 W1 rows per node instead of 2*N*F*H flops on the f64 matrix cores (twitch-RU: 7.1 GFLOP -> 0.1).
+// One wave per row: the lanes compare their pieces of the row with the reference row (staged in LDS), the differing
+// columns are compacted into a per-wave LDS list (ballot + prefix), then every lane walks the list for its 4 hidden
+// columns.  A row with more than FD_CAP differing columns (dense features: Gaussian, embeddings) raises `gate` and the
+// matrix-core product, launched behind this kernel, runs instead (it returns at once while `gate` is 0).
+#define FD_CAP 384
+#define FD_WAVES 4
+template <int VEC>   // floats per lane and load: 2 when the rows of X are 8-byte aligned, else 1
+__global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
+    int n, int F, int H, int Hp, const float *__restrict__ X, long ldx, int ref, const float *__restrict__ W1,
+    const double *__restrict__ cref, double *__restrict__ S1d, int *__restrict__ gate) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fd_smem[];
+    float *sref = reinterpret_cast<float *>(fd_smem);                              // [Fp] the reference row
+    const int Fp = (F + 1) & ~1;
+    double *ldv = reinterpret_cast<double *>(fd_smem + (((size_t)Fp * 4 + 15) & ~(size_t)15));   // [FD_WAVES][FD_CAP]
+    int *lj = reinterpret_cast<int *>(ldv + FD_WAVES * FD_CAP);                    // [FD_WAVES][FD_CAP]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int j = tid; j < Fp; j += 64 * FD_WAVES) sref[j] = j < F ? X[(long)ref * ldx + j] : 0.f;
+    __syncthreads();
+    const int i = blockIdx.x * FD_WAVES + wid;
+    if (i >= n) return;
+    const float *xr = X + (long)i * ldx;
+    double *mv = ldv + wid * FD_CAP;
+    int *mj = lj + wid * FD_CAP;
+    int cnt = 0;                                    // wave-uniform
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    constexpr int STEP = 64 * VEC, UN = 8;
+    for (int j0 = 0; j0 < F; j0 += STEP * UN) {
+        float x[UN][VEC];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {              // UN loads in flight per lane
+            const int j = j0 + u * STEP + lane * VEC;
+            if constexpr (VEC == 2) {
+                float2 t = make_float2(0.f, 0.f);
+                if (j + 1 < F) t = *reinterpret_cast<const float2 *>(xr + j);
+                else if (j < F) t.x = xr[j];
+                x[u][0] = t.x; x[u][1] = t.y;
+            } else {
+                x[u][0] = j < F ? xr[j] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const int j = j0 + u * STEP + lane * VEC + v;
+                const float r = j < F ? sref[j] : 0.f;
+                const bool diff = j < F && x[u][v] != r;
+                const unsigned long long m = __ballot(diff);
+                if (m) {
+                    const int pos = cnt + __popcll(m & lt);
+                    if (diff && pos < FD_CAP) { mj[pos] = j; mv[pos] = (double)x[u][v] - (double)r; }
+                    cnt += __popcll(m);
+                }
+            }
+        }
+        if (cnt > FD_CAP) {                          // not a sparse-difference row: the matrix cores take the product
+            if (lane == 0) *gate = 1;
+            return;
+        }
+    }
+    // (LDS writes of this wave's list are visible to its own lanes after the waitcnt the compiler puts before the reads)
+    const int c0 = 4 * lane;
+    if (c0 >= Hp) return;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool vec_ok = (H % 4 == 0) && c0 + 3 < H;
+    int e = 0;
+    for (; e + 4 <= cnt; e += 4) {
+        f32x4 w[4];
+        double d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = mj[e + k];
+            d[k] = mv[e + k];
+            if (vec_ok) w[k] = ld4(W1 + (size_t)j * H + c0);
+            else
+#pragma unroll
+                for (int t = 0; t < 4; ++t) w[k][t] = c0 + t < H ? W1[(size_t)j * H + c0 + t] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = fma(d[k], (double)w[k][t], acc[t]);
+    }
+    for (; e < cnt; ++e) {
+        const int j = mj[e];
+        const double d = mv[e];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float w = c0 + t < H ? W1[(size_t)j * H + c0 + t] : 0.f;
+            acc[t] = fma(d, (double)w, acc[t]);
+        }
+    }
+    f64x4 o;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o[t] = c0 + t < H ? cref[c0 + t] + acc[t] : 0.0;
+    *reinterpret_cast<f64x4 *>(S1d + (size_t)i * Hp + c0) = o;
+}
+static size_t fd_smem_bytes(int F) {
+    const size_t Fp = (size_t)((F + 1) & ~1);
+    return ((Fp * 4 + 15) & ~(size_t)15) + (size_t)FD_WAVES * FD_CAP * (sizeof(double) + sizeof(int));
+}
+
 // K slice of the fp64 product (64x64 tiles, 4 waves, 8 workgroups per CU): the fewest slices (at least 400 deep) whose
 // workgroups still occupy every CU, and never more workgroups than are resident at once (256 CUs x 8) -- a ninth per CU
 // runs alone after the others (twitch-RU: 8 slices = 2208 workgroups; 7 slices = 1932, all resident; measured 134-137 us
@@ -367,30 +480,95 @@ static int fp64_kslice(int n, int H, int F) {
     return best > 0 ? best : 16;
 }
 
-static int compute_z1d(lt_baseline *b, hipStream_t st) {
-    if (b->n == 0) return LT_OK;
-    const int Hp = b->Hp, H = b->H, n = b->n, F = b->F;
-    if (Hp != H) LT_HIP(hipMemsetAsync(b->S1d, 0, (size_t)n * Hp * sizeof(double), st));
+// The dense product S1d = X*W1 on the f64 matrix cores (rows [r0, r1) into dst[(r1 - r0), ldd]); `gate` != NULL: the
+// kernels return at once while *gate == 0 (the feature-difference product has served every row).
+static int launch_dense_s1d(lt_baseline *b, int r0, int r1, double *dst, long ldd_out, const int *gate, hipStream_t st) {
+    const int H = b->H, n = b->n, F = b->F, m = r1 - r0;
+    if (m <= 0) return LT_OK;
+    // the K slicing is that of the FULL product whatever the row range: a row has the same bits whichever rank computed it
     const int kslice = fp64_kslice(n, H, F);
     const int splits = (F + kslice - 1) / kslice;
     const bool big = fp64_big(n, H);
-    dim3 grid(big ? (n + GE_BM - 1) / GE_BM : (n + GD_BM - 1) / GD_BM, big ? H / GE_BN : (H + GD_BN - 1) / GD_BN, splits);
-    double *dst = splits > 1 ? b->slabs_d : b->S1d;
-    const long ldd = splits > 1 ? (long)H : (long)Hp;
-    const long stride = splits > 1 ? (long)n * H : 0L;
+    dim3 grid(big ? (m + GE_BM - 1) / GE_BM : (m + GD_BM - 1) / GD_BM, big ? H / GE_BN : (H + GD_BN - 1) / GD_BN, splits);
+    double *out = splits > 1 ? b->slabs_d : dst;
+    const long ldd = splits > 1 ? (long)H : ldd_out;
+    const long stride = splits > 1 ? (long)m * H : 0L;
+    const float *A = b->X + (size_t)r0 * b->ldx;
     if (big)
-        hipLaunchKernelGGL(k_gemm_f64acc_128, grid, dim3(256), 0, st, b->X, (long)b->ldx, b->W1, (long)H, dst, ldd, n, H, F,
-                           splits > 1 ? kslice : (F > 0 ? F : 1), stride);
+        hipLaunchKernelGGL(k_gemm_f64acc_128, grid, dim3(256), 0, st, A, (long)b->ldx, b->W1, (long)H, out, ldd, m, H, F,
+                           splits > 1 ? kslice : (F > 0 ? F : 1), stride, gate);
     else
-        hipLaunchKernelGGL(k_gemm_f64acc, grid, dim3(256), 0, st, b->X, (long)b->ldx, b->W1, (long)H, dst, ldd, n, H, F,
-                           splits > 1 ? kslice : (F > 0 ? F : 1), stride);
-    if (splits > 1) {
-        LT_CHECK_LAUNCH();
-        const long tot = (long)n * H;
-        hipLaunchKernelGGL(k_sum_slabs_f64, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, b->slabs_d,
-                           tot, splits, tot, H, b->S1d, (long)Hp);
-    }
+        hipLaunchKernelGGL(k_gemm_f64acc, grid, dim3(256), 0, st, A, (long)b->ldx, b->W1, (long)H, out, ldd, m, H, F,
+                           splits > 1 ? kslice : (F > 0 ? F : 1), stride, gate);
     LT_CHECK_LAUNCH();
+    if (splits > 1) {
+        const long tot = (long)m * H;
+        hipLaunchKernelGGL(k_sum_slabs_f64, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, b->slabs_d,
+                           tot, splits, tot, H, dst, ldd_out, gate);
+        LT_CHECK_LAUNCH();
+    }
+    return LT_OK;
+}
+
+// Whether this refresh tries the feature-difference product (k_s1d_feature_rows): the "feature_delta" knob, else what
+// the probe of lt_baseline_enable_fp64 found (feat_sparse: -1 unknown = try, the gated matrix-core product stands behind it).
+static bool want_feature_rows(const lt_baseline *b) {
+    if (!b->fd_cref || b->n < 2) return false;
+    const int knob = lt_tune().feature_delta;
+    return knob == 0 ? false : (knob > 0 ? true : b->feat_sparse != 0);
+}
+
+static int launch_feature_s1d(lt_baseline *b, hipStream_t st) {
+    const int Hp = b->Hp, H = b->H, n = b->n, F = b->F;
+    LT_HIP(hipMemsetAsync(b->fd_gate, 0, sizeof(int), st));
+    // the reference row's own product on the matrix cores (M = 1, K-sliced, ordered slab sum): cref[Hp]
+    {
+        const int ks = 64, splits = (F + ks - 1) / ks;
+        dim3 grid(1, (H + GD_BN - 1) / GD_BN, splits);
+        if (splits > 1) {
+            hipLaunchKernelGGL(k_gemm_f64acc, grid, dim3(256), 0, st, b->X, (long)b->ldx, b->W1, (long)H, b->fd_slabs, (long)H, 1, H, F,
+                               ks, (long)H, (const int *)nullptr);
+            LT_CHECK_LAUNCH();
+            hipLaunchKernelGGL(k_sum_slabs_f64, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, st, b->fd_slabs, (long)H, splits,
+                               (long)H, H, b->fd_cref, (long)Hp, (const int *)nullptr);
+        } else {
+            hipLaunchKernelGGL(k_gemm_f64acc, grid, dim3(256), 0, st, b->X, (long)b->ldx, b->W1, (long)H, b->fd_cref, (long)Hp, 1, H, F,
+                               F, 0L, (const int *)nullptr);
+        }
+        LT_CHECK_LAUNCH();
+    }
+    const unsigned blocks = (unsigned)((n + FD_WAVES - 1) / FD_WAVES);
+    const size_t smem = fd_smem_bytes(F);
+    if (b->ldx % 2 == 0 && ((uintptr_t)b->X % 8) == 0)
+        hipLaunchKernelGGL((k_s1d_feature_rows<2>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx, 0,
+                           b->W1, b->fd_cref, b->S1d, b->fd_gate);
+    else
+        hipLaunchKernelGGL((k_s1d_feature_rows<1>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx, 0,
+                           b->W1, b->fd_cref, b->S1d, b->fd_gate);
+    LT_CHECK_LAUNCH();
+    return LT_OK;
+}
+
+static int compute_z1d(lt_baseline *b, hipStream_t st) {
+    if (b->n == 0) return LT_OK;
+    const int Hp = b->Hp, H = b->H, n = b->n;
+    { lt_prof_scope prof_(LT_K_FP64_PRODUCT, st);
+    if (b->S1d_external) {
+        // multi-GPU: S1d arrives by the caller's all-gather of the ranks' row shards (lt_baseline_refresh_rows_fp64)
+    } else if (want_feature_rows(b)) {
+        // (pad columns: the feature kernel writes zeros for the rows it serves, the dense kernels never touch them)
+        if (Hp != H) LT_HIP(hipMemsetAsync(b->S1d, 0, (size_t)n * Hp * sizeof(double), st));
+        int rc = launch_feature_s1d(b, st);
+        if (rc) return rc;
+        // the matrix-core product behind it: every workgroup returns at once unless a row raised the gate
+        rc = launch_dense_s1d(b, 0, n, b->S1d, (long)Hp, b->fd_gate, st);
+        if (rc) return rc;
+    } else {
+        if (Hp != H) LT_HIP(hipMemsetAsync(b->S1d, 0, (size_t)n * Hp * sizeof(double), st));
+        int rc = launch_dense_s1d(b, 0, n, b->S1d, (long)Hp, nullptr, st);
+        if (rc) return rc;
+    } }
+    lt_prof_scope prof_(LT_K_FP64_SPMM, st);
     const int lpr = lt_lpr_for(Hp);
     const unsigned g2 = (unsigned)((n + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr)));
     const lt_graph *g = b->g;
@@ -427,33 +605,115 @@ int lt_baseline_refresh_fp64(lt_baseline *b, hipStream_t st) {
 
 extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     LT_REQUIRE(b != nullptr, "lt_baseline_enable_fp64: baseline is NULL");
-    if (b->Z1d) return LT_OK;   // Z1d is set only once all three buffers exist (see below)
+    if (b->Z1d) return LT_OK;   // Z1d is set only once all the buffers exist (see below)
     const size_t nh = (size_t)(b->n > 0 ? b->n : 1) * b->Hp * sizeof(double);
     const int ks_ = fp64_kslice(b->n, b->H, b->F);
     const int splits = (b->F + ks_ - 1) / ks_;
-    double *s1d = nullptr, *z1d = nullptr, *slabs = nullptr, *segd = nullptr;
+    double *s1d = nullptr, *z1d = nullptr, *slabs = nullptr, *segd = nullptr, *cref = nullptr, *fslabs = nullptr;
+    int *gate = nullptr;
+    // the feature-difference route needs the reference row in LDS next to the per-wave lists
+    const bool fd_possible = b->n >= 2 && fd_smem_bytes(b->F) <= (size_t)60 * 1024;
     hipError_t e = hipMalloc((void **)&s1d, nh);
     if (e == hipSuccess) e = hipMalloc((void **)&z1d, nh);
     if (e == hipSuccess && b->g->p_n_seg > 0) e = hipMalloc((void **)&segd, (size_t)b->g->p_n_seg * b->Hp * sizeof(double));
     if (e == hipSuccess && splits > 1)
         e = hipMalloc((void **)&slabs, (size_t)splits * (b->n > 0 ? b->n : 1) * b->H * sizeof(double));
+    if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&cref, (size_t)b->Hp * sizeof(double));
+    if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fslabs, (size_t)((b->F + 63) / 64) * b->H * sizeof(double));
+    if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&gate, sizeof(int));
     if (e != hipSuccess) {   // all or nothing: a retry starts from a clean state, nothing leaks
         (void)hipFree(s1d); (void)hipFree(z1d); (void)hipFree(slabs); (void)hipFree(segd);
+        (void)hipFree(cref); (void)hipFree(fslabs); (void)hipFree(gate);
         return lt_set_error(LT_ERR_HIP, "lt_baseline_enable_fp64: hipMalloc failed: %s", hipGetErrorString(e));
     }
     b->S1d = s1d; b->Z1d = z1d; b->slabs_d = slabs; b->seg_d = segd;
-    int rc = lt_baseline_ensure_padding(b, (hipStream_t)stream);   // (the padded bias the fp64 SpMM adds)
+    b->fd_cref = cref; b->fd_slabs = fslabs; b->fd_gate = gate;
+    b->S1d_owned = true; b->S1d_external = false; b->feat_sparse = -1;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = lt_baseline_ensure_padding(b, st);   // (the padded bias the fp64 SpMM adds)
     if (rc) return rc;
-    rc = compute_z1d(b, (hipStream_t)stream);
+    if (fd_possible && lt_tune().feature_delta != 0) {
+        // Probe once (this call allocates, so it may synchronise): do the feature rows differ from the reference row in few
+        // columns?  The answer only picks the route later refreshes TRY FIRST -- a refresh whose rows turn out dense
+        // raises the gate on the device and the matrix-core product behind it runs, so it is never a correctness matter.
+        rc = launch_feature_s1d(b, st);
+        if (rc) return rc;
+        int g = 1;
+        LT_HIP(hipMemcpyAsync(&g, b->fd_gate, sizeof(int), hipMemcpyDeviceToHost, st));
+        LT_HIP(hipStreamSynchronize(st));
+        b->feat_sparse = g == 0 ? 1 : 0;
+    }
+    rc = compute_z1d(b, st);
     b->fp64_fresh = rc == LT_OK;
     return rc;
 }
 
+extern "C" int lt_baseline_fp64_route(const lt_baseline *b, int32_t *route) {
+    LT_REQUIRE(b != nullptr && route != nullptr, "lt_baseline_fp64_route: NULL argument");
+    *route = !b->Z1d ? -1 : (want_feature_rows(b) ? 1 : 0);
+    return LT_OK;
+}
+
+// Multi-GPU, dense features: rows [row_begin, row_end) of the fp64 product into dst[(row_end - row_begin), Hp] (the rank's
+// send buffer); the ranks' all-gather rebuilds S1d in the storage attached with lt_baseline_attach_s1d.  The K slicing
+// is the one of the full product, so a row has the same bits whichever rank computed it.
+extern "C" int lt_baseline_refresh_rows_fp64(lt_baseline *b, int32_t row_begin, int32_t row_end, double *dst, void *stream) {
+    LT_REQUIRE(b != nullptr, "lt_baseline_refresh_rows_fp64: baseline is NULL");
+    LT_REQUIRE(b->Z1d != nullptr, "lt_baseline_refresh_rows_fp64: call lt_baseline_enable_fp64 first");
+    LT_REQUIRE(row_begin >= 0 && row_begin <= row_end && row_end <= b->n,
+               "lt_baseline_refresh_rows_fp64: rows [%d, %d) outside [0, %d]", row_begin, row_end, b->n);
+    LT_REQUIRE(dst != nullptr && ((uintptr_t)dst % 16) == 0, "lt_baseline_refresh_rows_fp64: dst is NULL or not 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    b->fp64_fresh = false;
+    const int m = row_end - row_begin;
+    if (m == 0) return LT_OK;
+    if (b->Hp != b->H) LT_HIP(hipMemsetAsync(dst, 0, (size_t)m * b->Hp * sizeof(double), st));
+    lt_prof_scope prof_(LT_K_FP64_PRODUCT, st);
+    return launch_dense_s1d(b, row_begin, row_end, dst, (long)b->Hp, nullptr, st);
+}
+
+// S1d lives in caller-owned storage from now on and is filled from outside (the ranks' all-gather of the shards
+// lt_baseline_refresh_rows_fp64 produced): a refresh then recomputes only Z1d = A_hat*S1d + b1.  S1d == NULL returns to
+// the library's own storage and product.
+extern "C" int lt_baseline_attach_s1d(lt_baseline *b, double *S1d, int64_t ld, void *stream) {
+    LT_REQUIRE(b != nullptr, "lt_baseline_attach_s1d: baseline is NULL");
+    LT_REQUIRE(b->Z1d != nullptr, "lt_baseline_attach_s1d: call lt_baseline_enable_fp64 first");
+    hipStream_t st = (hipStream_t)stream;
+    if (S1d == nullptr) {
+        if (!b->S1d_owned) {
+            double *own = nullptr;
+            LT_HIP(hipMalloc((void **)&own, (size_t)(b->n > 0 ? b->n : 1) * b->Hp * sizeof(double)));
+            b->S1d = own;
+            b->S1d_owned = true;
+        }
+        b->S1d_external = false;
+        b->fp64_fresh = false;
+        return LT_OK;
+    }
+    LT_REQUIRE(ld == b->Hp, "lt_baseline_attach_s1d: ld=%lld, must equal the padded hidden width %d", (long long)ld, b->Hp);
+    LT_REQUIRE(((uintptr_t)S1d % 16) == 0, "lt_baseline_attach_s1d: storage must be 16-byte aligned");
+    if (S1d != b->S1d) {
+        if (b->S1d_owned) {
+            LT_HIP(hipStreamSynchronize(st));   // kernels in flight may still read the buffer freed below
+            (void)hipFree(b->S1d);
+        }
+        b->S1d = S1d;
+        b->S1d_owned = false;
+    }
+    b->S1d_external = true;
+    b->fp64_fresh = false;
+    return LT_OK;
+}
+
 void lt_baseline_free_fp64(lt_baseline *b) {
-    (void)hipFree(b->S1d);
+    if (b->S1d_owned) (void)hipFree(b->S1d);
     (void)hipFree(b->Z1d);
     (void)hipFree(b->slabs_d);
     (void)hipFree(b->seg_d);
-    b->S1d = b->Z1d = b->slabs_d = b->seg_d = nullptr;
+    (void)hipFree(b->fd_cref);
+    (void)hipFree(b->fd_slabs);
+    (void)hipFree(b->fd_gate);
+    b->S1d = b->Z1d = b->slabs_d = b->seg_d = b->fd_cref = b->fd_slabs = nullptr;
+    b->fd_gate = nullptr;
     b->fp64_fresh = false;
 }

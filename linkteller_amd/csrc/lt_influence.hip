@@ -1365,17 +1365,18 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
             const int words = (n + 31) / 32;
             // item offsets, the (probe, row) table of the items and the membership bitmap, one block per probe
             if (w.big_slot) LT_HIP(hipMemsetAsync(w.big_slot + w.chunk, 0, sizeof(int32_t), st));
+            const unsigned *marks = nullptr;
+            { lt_prof_scope prof_(LT_K_ITEM_BITS, st);
             hipLaunchKernelGGL(k_item_bits, dim3(nb), dim3(256), 0, st, g->tptr, g->trow, probes, nb, words, w.bits, w.off, w.item_pr,
                                w.big_bits, w.big_slot, w.big_slot ? w.big_slot + w.chunk : (int32_t *)nullptr);
             LT_CHECK_LAUNCH();
-            const unsigned *marks = nullptr;
             if (use_marks) {
                 LT_HIP(hipMemsetAsync(w.pm_marks, 0, (size_t)((pairs + 31) / 32) * sizeof(unsigned), st));
                 hipLaunchKernelGGL(k_pm_mark, dim3(LT_ITEM_GRID), dim3(256), 0, st, w.off, nb, w.item_pr, w.pm_cnt, w.pm_start,
                                    w.pm_list, n_obs, w.pm_marks);
                 LT_CHECK_LAUNCH();
                 marks = w.pm_marks;
-            }
+            } }
             if (mode == LT_MODE_SPARSE) {
                 { lt_prof_scope prof_(LT_K_ITEM_A, st);
                 LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,

@@ -75,6 +75,13 @@ struct lt_baseline {
     double *Z1d = nullptr;      // [n, Hp]
     double *slabs_d = nullptr;  // split-K partials
     double *seg_d = nullptr;    // [g->p_n_seg, Hp] fp64 segment sums of the long rows
+    bool S1d_owned = true;      // false after lt_baseline_attach_s1d: S1d is caller storage filled by the ranks' all-gather
+    bool S1d_external = false;  // the fp64 product arrives from outside (lt_baseline_refresh_rows_fp64 + the caller's all-gather)
+    // feature-difference route of the fp64 product (lt_fp64.hip, k_s1d_feature_rows)
+    double *fd_cref = nullptr;  // [Hp] the reference row's product
+    double *fd_slabs = nullptr; // [ceil(F / 64), H] its split-K partials
+    int *fd_gate = nullptr;     // device flag: a row was not a sparse difference -> the matrix-core product runs
+    int feat_sparse = -1;       // what the probe at lt_baseline_enable_fp64 found: 1 sparse differences, 0 dense, -1 not probed
     // lt_baseline_refresh recomputes S1 and marks what depends on it stale; Z1 / S2 / OUT (and Z1d) are
     // recomputed by the first call that reads them (logits, SPARSE / DELTA rows) -- FULL rows never do: their
     // stage A yields the baseline S2 as a by-product and stage B forms the baseline logits itself.
@@ -108,6 +115,8 @@ struct lt_tuning {
     long long bits_max_bytes;    // SPARSE / DELTA: a bitmap row per probe only while the chunk's rows fit this (default 128 MiB);
                                  // beyond it only the chunk's big probes get rows (LT_BITS_MAX_BYTES)
     int tiled_big;               // 1: the tiled SpMM always uses 64-bit gather offsets (test hook; default: only when S spans >= 4 GiB)
+    int feature_delta;           // fp64 product X*W1 from the feature rows' differences to a reference row: 0 never, 1 always try,
+                                 // -1 when the baseline's features were found to be sparse differences (LT_FEATURE_DELTA)
 };
 lt_tuning &lt_tune();
 

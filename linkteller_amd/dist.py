@@ -71,27 +71,52 @@ def shard_baseline_policy() -> str:
     return v if v in ("0", "1", "auto") else "auto"
 
 
-def choose_baseline_sharding(base, trials: int = 5) -> bool:
-    """Apply shard_baseline_policy() to an engine.Baseline; every rank takes the same decision (max over ranks of the
-    measured refresh time, replicated vs sharded).  Returns True when the sharded refresh is on."""
+def choose_baseline_sharding(base, trials: int = 5, mode: str = "full") -> bool:
+    use = _choose_baseline_sharding(base, trials, mode)
+    if world()[1] > 1:
+        base.refresh(mode)          # whatever was decided: the products the mode reads are current on every rank
+    return use
+
+
+def _choose_baseline_sharding(base, trials, mode) -> bool:
+    """Apply shard_baseline_policy() to an engine.Baseline FOR THE MODE THE CALLER WILL USE; every rank takes the same
+    decision (max over ranks of the measured time of a refresh + the first reader of that mode, replicated vs sharded).
+    `full` / `sparse` read the fp32 product S1 = X W1 (sharded: lt_baseline_refresh_rows + all-gather of S1); `delta` with
+    the fp64 pre-activation reads nothing fp32, so what is sharded there is the fp64 product (lt_baseline_refresh_rows_fp64
+    + all-gather of S1d) -- unless the features are sparse differences to a reference row (engine.Baseline.fp64_route()
+    == 1: the product is one pass over X on every rank, cheaper than any collective).  Returns True when a sharded refresh
+    is on."""
     import time
     rank, ws = world()
     pol = shard_baseline_policy()
+    is_delta = mode == "delta"
+    shard = base.shard_refresh_fp64 if is_delta else base.shard_refresh
+    other = base.shard_refresh if is_delta else base.shard_refresh_fp64
+    other(False)
+    if is_delta and ws > 1:
+        base.enable_fp64()
+        if base.fp64_route() == 1:      # same features on every rank -> same answer on every rank
+            shard(False)
+            return False
     if ws == 1 or pol == "0":
-        base.shard_refresh(False)
+        shard(False)
         return False
     if pol == "1":
-        base.shard_refresh(True)
+        shard(True)
         return True
     times = []
+    nodes = torch.zeros(1, dtype=torch.int32, device=base.x.device)
 
     def refresh_and_use():
-        # the replicated refresh is lazy (it only marks S1 stale): the logits make it materialise, and cost the same
-        # layers on top in both settings
-        base.refresh()
-        base.logits()
+        # the replicated refresh is lazy (it only marks things stale): the first reader makes them materialise -- the
+        # logits for the fp32 layers, a one-pair call for the fp64 pre-activation -- and costs the same in both settings
+        base.refresh(mode)
+        if is_delta:
+            base.influence_rows(nodes, nodes, 1e-4, "delta")
+        else:
+            base.logits()
     for enable in (False, True):
-        base.shard_refresh(enable)
+        shard(enable)
         for _ in range(2):
             refresh_and_use()
         torch.cuda.synchronize()
@@ -106,6 +131,5 @@ def choose_baseline_sharding(base, trials: int = 5) -> bool:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         times.append(float(t.item()))
     use = times[1] < times[0]
-    base.shard_refresh(use)
-    base.refresh()
+    shard(use)
     return use

@@ -78,6 +78,8 @@ def gcn2_forward(adj, x, w1, b1, w2, b2) -> torch.Tensor:
     h, c = w1.shape[1], w2.shape[1]
     if n != g.n or w1.shape[0] != f or w2.shape[0] != h or b1.numel() != h or b2.numel() != c:
         raise ValueError("inconsistent GCN shapes")
+    if not fused_shapes(h, c):      # wider than the fused kernels: the same layers unfused (GraphConvolution.forward x 2)
+        return spmm(g, gemm(spmm(g, gemm(x, w1), b1, relu=True), w2), b2)
     out = torch.empty((n, c), dtype=torch.float32, device=x.device)
     nbytes = _lib.lib().lt_gcn2_workspace_bytes(n, f, h, c)
     ws = _workspace(nbytes, x.device)
@@ -110,26 +112,77 @@ class Baseline:
         self._finalizer = weakref.finalize(self, _lib.lib().lt_baseline_destroy, h)
         self._ws = {}
         self._fp64 = False
-        self._shard = None          # (row_begin, row_end, per) while the sharded refresh is on
+        self._shard = None          # (row_begin, row_end, per) while the sharded refresh of the fp32 product is on
         self._s1_full = None        # torch-owned S1 storage once attached (kept alive for the handle's lifetime)
         self._send = None
+        self._shard64 = None        # the same for the fp64 product of `delta` (lt_baseline_refresh_rows_fp64)
+        self._s1d_full = None
+        self._send64 = None
 
     @property
     def handle(self):
         return self._h
 
-    def refresh(self):
-        """Recompute S1 = X W1 from the (borrowed) inputs; the layers that depend on it are recomputed lazily.
-        With ``shard_refresh`` on, this rank computes only its rows and one all-gather rebuilds S1 on every rank."""
-        if self._shard is None:
-            _lib.check(_lib.lib().lt_baseline_refresh(self._h, _stream()), "lt_baseline_refresh")
-            return
-        import torch.distributed as dist
+    def refresh(self, mode=None):
+        """The borrowed inputs changed: everything derived from them is recomputed by the next call that reads it.
+        ``mode`` (the mode of the calls that follow, when known) lets a multi-GPU run move only what that mode reads:
+        with ``shard_refresh`` on, `full` / `sparse` compute this rank's rows of the fp32 X W1 and all-gather S1; `delta`
+        with the fp64 pre-activation does the same for the fp64 product (``shard_refresh_fp64``) and touches nothing
+        fp32.  Without a mode both sharded products (if enabled) are refreshed."""
+        m = None if mode is None else (_lib.MODES[mode] if isinstance(mode, str) else int(mode))
+        only64 = m == _lib.MODE_DELTA and self._fp64
+        only32 = m is not None and not only64
         from . import dist as lt_dist
-        b, e, _ = self._shard
-        _lib.check(_lib.lib().lt_baseline_refresh_rows(self._h, b, e, self._send.data_ptr(), _stream()),
-                   "lt_baseline_refresh_rows")
-        lt_dist.all_gather_into(self._s1_full, self._send)
+        if self._shard is not None and not only64:
+            b, e, _ = self._shard
+            _lib.check(_lib.lib().lt_baseline_refresh_rows(self._h, b, e, self._send.data_ptr(), _stream()),
+                       "lt_baseline_refresh_rows")
+            lt_dist.all_gather_into(self._s1_full, self._send)
+        else:
+            _lib.check(_lib.lib().lt_baseline_refresh(self._h, _stream()), "lt_baseline_refresh")
+        if self._shard64 is not None and not only32:
+            b, e, _ = self._shard64
+            _lib.check(_lib.lib().lt_baseline_refresh_rows_fp64(self._h, b, e, self._send64.data_ptr(), _stream()),
+                       "lt_baseline_refresh_rows_fp64")
+            lt_dist.all_gather_into(self._s1d_full, self._send64)
+
+    def enable_fp64(self):
+        """The fp64-accumulated pre-activation `delta` evaluates its ReLU kink test on (lt_baseline_enable_fp64):
+        allocates S1d / Z1d (2 * n * Hp * 8 bytes -- 8.6 GB at n = 2 M, H = 256) and computes them once."""
+        if not self._fp64:
+            _lib.check(_lib.lib().lt_baseline_enable_fp64(self._h, _stream()), "lt_baseline_enable_fp64")
+            self._fp64 = True
+        return self
+
+    def fp64_route(self) -> int:
+        """1: the fp64 product comes from the feature rows' differences to a reference row (one pass over X; sharding it
+        buys nothing), 0: it runs on the f64 matrix cores, -1: fp64 not enabled."""
+        r = C.c_int32(-1)
+        _lib.check(_lib.lib().lt_baseline_fp64_route(self._h, C.byref(r)), "lt_baseline_fp64_route")
+        return r.value
+
+    def shard_refresh_fp64(self, enable=True):
+        """Multi-GPU: shard the fp64 product X W1 of `delta` over the ranks (rows of k_gemm_f64acc_128 + one all-gather
+        of S1d) instead of recomputing it on every rank.  Bits are those of the replicated product."""
+        from . import dist as lt_dist
+        rank, world = lt_dist.world()
+        if not enable or world == 1:
+            if self._shard64 is not None:
+                _lib.check(_lib.lib().lt_baseline_attach_s1d(self._h, None, 0, _stream()), "lt_baseline_attach_s1d")
+                torch.cuda.current_stream().synchronize()
+                self._s1d_full = self._send64 = None
+            self._shard64 = None
+            return self
+        self.enable_fp64()
+        b, e, per = lt_dist.shard_bounds(self.n, rank, world)
+        hp = (self.h + 3) // 4 * 4
+        if self._s1d_full is None or self._s1d_full.shape[0] != world * per:
+            s1d = torch.zeros((world * per, hp), dtype=torch.float64, device=self.x.device)
+            _lib.check(_lib.lib().lt_baseline_attach_s1d(self._h, s1d.data_ptr(), hp, _stream()), "lt_baseline_attach_s1d")
+            self._s1d_full = s1d
+            self._send64 = torch.zeros((per, hp), dtype=torch.float64, device=self.x.device)
+        self._shard64 = (b, e, per)
+        return self
 
     def shard_refresh(self, enable=True):
         """Multi-GPU: shard the loop-invariant X W1 over the ranks of the initialised process group
@@ -164,8 +217,7 @@ class Baseline:
         m = _lib.MODES[mode] if isinstance(mode, str) else int(mode)
         if m == _lib.MODE_DELTA and not self._fp64:
             # kink test on an fp64-accumulated pre-activation (one-off cost, kept fresh by refresh())
-            _lib.check(_lib.lib().lt_baseline_enable_fp64(self._h, _stream()), "lt_baseline_enable_fp64")
-            self._fp64 = True
+            self.enable_fp64()
         npb, nob = probes.numel(), obs.numel()
         if out is None:
             out = torch.empty((npb, nob), dtype=torch.float32, device=dev)
@@ -181,6 +233,92 @@ class Baseline:
                                                 float(delta), m, out.data_ptr(), nob, ws.data_ptr(),
                                                 ws.numel(), _stream()), "lt_influence_rows")
         return out
+
+
+class WideBaseline:
+    """The probe loop for 2-layer models outside what the fused kernels are built for (hidden width > 256 or more than
+    8 classes; the reference has no such limit: gcn/layers.py:30-36, main.py:30).  Same interface as ``Baseline``; every
+    probe runs the reference's own op sequence on the unfused HIP layers -- row v of S1 = X W1 replaced by
+    (x_v + x_v d) W1, then lt_spmm_csr_f32 (column-sliced) / lt_gemm_f32 for the two layers -- and the fp32 finite
+    difference (f(X + d e_v x_v^T) - f(X))[u] / d of attacker.py:100-108.  ~5 launches per probe instead of one call for
+    all probes: the slow, general route (`sparse` / `full` name the same thing here; there is no `delta` propagation)."""
+
+    def __init__(self, adj, x, w1, b1, w2, b2):
+        self.graph: HipGraph = as_hip_graph(adj)
+        self.x, self.w1, self.b1, self.w2, self.b2 = (
+            _f32(t, n) for t, n in ((x, "x"), (w1, "W1"), (b1, "b1"), (w2, "W2"), (b2, "b2")))
+        n, f = self.x.shape
+        self.n, self.f, self.h, self.c = n, f, self.w1.shape[1], self.w2.shape[1]
+        if n != self.graph.n or self.w1.shape[0] != f or self.w2.shape[0] != self.h or self.b1.numel() != self.h or self.b2.numel() != self.c:
+            raise ValueError("inconsistent GCN shapes")
+        if self.graph.device_index != self.x.device.index:
+            raise ValueError(f"the graph lives on cuda:{self.graph.device_index}, the features on {self.x.device}")
+        _require_finite(features=self.x, W1=self.w1, b1=self.b1, W2=self.w2, b2=self.b2)
+        self._s1 = None
+        self._out = None
+
+    def refresh(self, mode=None):
+        self._s1 = self._out = None
+
+    def shard_refresh(self, enable=True):
+        return self
+
+    shard_refresh_fp64 = shard_refresh
+
+    def enable_fp64(self):
+        return self
+
+    def fp64_route(self) -> int:
+        return -1
+
+    def _rest(self, s1):
+        h1 = spmm(self.graph, s1, self.b1, relu=True)
+        return spmm(self.graph, gemm(h1, self.w2), self.b2)
+
+    def _ensure(self):
+        if self._s1 is None:
+            self._s1 = gemm(self.x, self.w1)
+            self._out = self._rest(self._s1)
+
+    def logits(self) -> torch.Tensor:
+        self._ensure()
+        return self._out.clone()
+
+    def influence_rows(self, probe_nodes, observe_nodes, delta: float, mode="sparse", out=None) -> torch.Tensor:
+        if mode not in ("sparse", "full", 0, 1, None):
+            raise NotImplementedError("layers wider than 256 hidden units / 8 classes run the reference's fp32 finite difference "
+                                      "('sparse' / 'full') on the unfused HIP layers; there is no 'delta' propagation for them")
+        dev = self.x.device
+        probes = _as_nodes(probe_nodes, self.n, dev, "probe_nodes").long()
+        obs = _as_nodes(observe_nodes, self.n, dev, "observe_nodes").long()
+        npb, nob = probes.numel(), obs.numel()
+        if out is None:
+            out = torch.empty((npb, nob), dtype=torch.float32, device=dev)
+        elif out.shape != (npb, nob) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float32 [n_probe, n_obs] tensor")
+        if npb == 0 or nob == 0:
+            return out
+        self._ensure()
+        base = self._out[obs]
+        s1p = self._s1.clone()
+        d = float(delta)
+        for i in range(npb):
+            v = int(probes[i])
+            xv = self.x[v]
+            s1p[v] = gemm((xv + xv * d)[None, :].contiguous(), self.w1)[0]      # two roundings, as attacker.py:103,105
+            out[i] = ((self._rest(s1p)[obs] - base) / d).norm(dim=1)
+            s1p[v] = self._s1[v]
+        return out
+
+
+def fused_shapes(h: int, c: int) -> bool:
+    """What lt_baseline_create / lt_influence_rows are built for (one pass of the row kernels, fused layer-2 epilogue)."""
+    return h <= 256 and c <= 8
+
+
+def baseline_for(adj, x, w1, b1, w2, b2):
+    """``Baseline`` (the fused probe primitive) when the layer widths allow it, else ``WideBaseline``."""
+    return (Baseline if fused_shapes(w1.shape[1], w2.shape[1]) else WideBaseline)(adj, x, w1, b1, w2, b2)
 
 
 class Baseline3:
@@ -231,9 +369,10 @@ class Baseline3:
         elif out.shape != (npb, nob) or out.dtype != torch.float32 or not out.is_contiguous():
             raise ValueError("out must be a contiguous float32 [n_probe, n_obs] tensor")
         key = (npb, nob)
+        need = _lib.lib().lt_influence3_workspace_bytes(self._h, npb, nob)   # depends on the tuning knobs too
         ws = self._ws.get(key)
-        if ws is None:
-            ws = _workspace(_lib.lib().lt_influence3_workspace_bytes(self._h, npb, nob), dev)
+        if ws is None or ws.numel() < need:
+            ws = _workspace(need, dev)
             self._ws = {key: ws}
         _lib.check(_lib.lib().lt_influence3_rows(self._h, probes.data_ptr(), npb, obs.data_ptr(), nob, float(delta),
                                                  out.data_ptr(), nob, ws.data_ptr(), ws.numel(), _stream()),

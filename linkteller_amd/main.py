@@ -89,7 +89,12 @@ def main(argv=None):
     owns_group = init_distributed()
     try:
         _run(args)
-    finally:
+    except BaseException:
+        # A rank that failed must NOT enter a barrier: its peers sit in the all-gather (or in the sharding policy's
+        # collectives), the barrier would be a mismatched collective and the job would hang until the RCCL timeout with
+        # the real exception hidden.  Re-raise at once; the launcher (torchrun) tears the other ranks down.
+        raise
+    else:
         if owns_group:
             import torch.distributed as dist
             dist.barrier()

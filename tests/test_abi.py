@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lt):
         assert hasattr(handle, n), f"{n} declared in the header but not exported"
         assert n in lt.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(lt.SIGNATURES) == names
-    assert handle.lt_abi_version() == 1
+    assert handle.lt_abi_version() == lt.ABI_VERSION == 2
 
 
 def test_no_gpu_means_loud_failure_not_fallback(lt):
@@ -66,6 +66,17 @@ def test_graph_create_validation(lt):
     assert create(2, [0, 2, 2], [1, 0], [1, 1]) == -1 and b"strictly increasing" in h.lt_last_error()
     assert create(2, [0, 2, 2], [1, 1], [1, 1]) == -1     # duplicate column
     assert h.lt_graph_create(2, 0, None, None, None, C.byref(out)) == -1
+    # a graph large enough for the multi-threaded validation (nnz >= 2^20): offsets that are negative / beyond nnz /
+    # decreasing in the part of rowptr a LATER thread starts in must be refused before any col[] is read through them
+    n, deg = 1 << 17, 8
+    rp = (np.arange(n + 1, dtype=np.int64) * deg).astype(np.int32)
+    ci = np.tile(np.arange(deg, dtype=np.int32), n)
+    va = np.ones(n * deg, dtype=np.float32)
+    for row, bad in ((n - 5, -7), (n // 2 + 3, 2 ** 31 - 1), (3 * n // 4, 11)):
+        rp2 = rp.copy()
+        rp2[row] = bad
+        assert h.lt_graph_create(n, len(ci), rp2.ctypes.data, ci.ctypes.data, va.ctypes.data, C.byref(out)) == -1
+        assert b"monotone" in h.lt_last_error() or b"rowptr" in h.lt_last_error()
     assert h.lt_graph_info(None, None, None, None) == -1
     assert h.lt_graph_destroy(None) == 0
 

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import REPO, csr_from, golden_args, load_golden
+from conftest import REPO, csr_from, golden_args, load_golden, noise_gate
 
 pytestmark = pytest.mark.gpu
 
@@ -135,10 +135,10 @@ def test_get_gradient_eps_mat_matches_oracle(gpu, influence_golden):
             ref32 = O.get_gradient_eps_mat(x_cpu, adj_o, P32, v, args["influence"]).numpy().astype(np.float64)
         assert got.shape == ref64.shape
         e32 = np.abs(ref32 - ref64).max()
-        assert np.abs(got - ref64).max() <= 2.0 * e32
+        noise_gate(f"eps_mat.pl600.v{v}.logit_diff", np.abs(got - ref64).max() / e32)
         assert np.all(got[np.all(ref64 == 0, axis=1)] == 0)          # untouched rows: exactly zero
         rows = atk.baseline().influence_rows([v], np.arange(a.shape[0]), args["influence"], "full").cpu().numpy()[0]
-        assert np.abs(np.linalg.norm(got, axis=1) - rows).max() <= 2.0 * e32
+        noise_gate(f"eps_mat.pl600.v{v}.norm_vs_rows", np.abs(np.linalg.norm(got, axis=1) - rows).max() / e32)
 
 
 def test_integration_md_stub_runs_as_written(gpu, influence_golden, tmp_path):
@@ -176,7 +176,7 @@ def test_integration_md_stub_runs_as_written(gpu, influence_golden, tmp_path):
     ref64, ref32 = g["pl600.ref64.influence_val"], g["pl600.ref32.influence_val"]
     assert np.array_equal(out["full"], out["sparse"])
     assert np.abs(out["delta"] - ref64).max() <= 1e-4 * ref64.max()      # (no fp64 kink copy in the minimal stub)
-    assert np.abs(out["full"] - ref64).max() <= 2.0 * np.abs(ref32 - ref64).max()
+    noise_gate("integration_stub.pl600.full", np.abs(out["full"] - ref64).max() / np.abs(ref32 - ref64).max())
 
 
 def _free_port():
@@ -245,9 +245,22 @@ def test_sharded_influence_matrix_equals_single_rank(gpu, influence_golden, tmp_
     nodes = g["pl600.ref32.test_nodes"]
     single = {m: base.influence_rows(nodes, nodes, args["influence"], m).cpu().numpy().astype(np.float64)
               for m in ("full", "sparse", "delta")}
-    for shard_baseline in ("0", "1") + (("auto",) if world == 2 else ()):    # auto: both are timed, the faster kept
+    # auto: both are timed, the faster kept; "1d": the fp64 product of `delta` forced onto the matrix cores
+    # (LT_FEATURE_DELTA=0), so that it is the product that gets sharded (lt_baseline_refresh_rows_fp64 + all-gather of S1d)
+    for shard_baseline in ("0", "1", "1d") + (("auto",) if world == 2 else ()):
         out = tmp_path / f"ranks{world}_{shard_baseline}.npz"
-        _run_ranks(code, world, {"LT_TEST_OUT": str(out), "LT_SHARD_BASELINE": shard_baseline})
+        env = {"LT_TEST_OUT": str(out), "LT_SHARD_BASELINE": shard_baseline[0] if shard_baseline != "auto" else "auto"}
+        if shard_baseline == "1d":
+            env["LT_FEATURE_DELTA"] = "0"
+            from linkteller_amd import _lib
+            _lib.set_tuning("feature_delta", 0)
+            try:
+                single_d = base.influence_rows(nodes, nodes, args["influence"], "delta").cpu().numpy().astype(np.float64)
+            finally:
+                _lib.set_tuning("feature_delta", None)
+                base.refresh()
+            single = dict(single, delta=single_d)
+        _run_ranks(code, world, env)
         got = np.load(out)
         for m in ("full", "sparse", "delta"):
             assert got[m].shape == single[m].shape and np.array_equal(got[m], single[m]), (world, shard_baseline, m)
@@ -282,7 +295,8 @@ def test_rmat_scale21_config5_full_size(gpu):
     """BASELINE configs[4] at its full size on ONE GPU: R-MAT scale 21 (2 097 152 nodes, 40 M directed draws -> nnz(A_hat)
     ~ 78 M, hub rows of 10^5 entries), F = H = 256, C = 2.  Size-independent properties -- `sparse` == `full` bit for
     bit, the tiled SpMM == the row kernel bit for bit, the tiled layer 1 == the fused one through the logits, exact
-    zeros off the 2-hop set -- and the fp64 oracle on one probe row.  Timings go to gpurun_out/ (copied to profiles/)."""
+    zeros off the 2-hop set -- at the per-rank shape of the config (512 probes x 4096 observed, hubs on both sides), and the
+    fp64 oracle on 8 probe rows.  Timings go to gpurun_out/ (copied to profiles/)."""
     from linkteller_amd import _lib, engine, graph, synth
     from oracle import linkteller_oracle as O
     t0 = time.time()
@@ -328,11 +342,14 @@ def test_rmat_scale21_config5_full_size(gpu):
     base.refresh()
     logits_tiled = base.logits()
     assert torch.equal(logits_tiled, logits_rows)
-    # probes: the biggest hub, two mid-degree nodes, random ones; observed: hub + random
+    # The PER-RANK SHAPE of configs[4] (n_test = 4096 over 8 GPUs): 512 probes x 4096 observed nodes, the probes being the
+    # first 512 of the observed list as in the sharded product path; the three biggest hubs sit on BOTH sides.
+    import scipy.sparse as sp
     rng = np.random.RandomState(3)
-    hub = int(np.argmax(deg))
-    probes = np.concatenate([[hub], rng.choice(n, 63, replace=False)])
-    observe = np.concatenate([[hub], rng.choice(n, 511, replace=False)])
+    hubs = np.argsort(-deg)[:3].astype(np.int64)
+    rest = rng.choice(np.setdiff1d(np.arange(n), hubs), 4096 - len(hubs), replace=False)
+    observe = np.concatenate([hubs, rest])
+    probes = observe[:512]
     res = {}
     for m in ("full", "sparse", "delta"):
         res[m], t = timed(lambda: base.influence_rows(probes, observe, 1e-4, m), reps=1)
@@ -340,16 +357,36 @@ def test_rmat_scale21_config5_full_size(gpu):
     full, sparse, delta = (res[m].cpu().numpy() for m in ("full", "sparse", "delta"))
     assert np.array_equal(full, sparse)
     assert np.isfinite(full).all() and np.isfinite(delta).all()
-    assert np.array_equal(full == 0, delta == 0) or np.all(full[delta == 0] == 0)
+    # exact zeros off the 2-hop set (attacker.py:220-229: identical inputs -> identical outputs), every mode; the mask is
+    # the pattern product restricted to the observed columns: reach = (E_probes P^T) (P^T)[:, observe]
+    pat = sp.csr_matrix((np.ones(a_hat.nnz, np.float32), a_hat.indices, a_hat.indptr), shape=a_hat.shape)
+    r1 = pat.T.tocsr()[probes]                                   # row i: the rows r with A_hat[r, probes[i]] != 0
+    mask = np.asarray((r1 @ pat[observe].T.tocsc()).todense()) > 0
+    for m, r in (("full", full), ("delta", delta)):
+        assert np.all(r[~mask] == 0), m
+    assert (delta[mask] > 0).mean() > 0.9
+    log.append(f"2-hop pairs {int(mask.sum())} of {mask.size}; non-zero scores: full {int((full > 0).sum())}, delta {int((delta > 0).sum())}")
     assert np.abs(full - delta).max() <= 0.05 * delta.max()
-    # fp64 oracle (verbatim reference op sequence) on one random probe row
+    # fp64 oracle (verbatim reference op sequence, attacker.py:100-108 + the norm of :227-229) on 8 probe rows: the biggest
+    # hub, a mid-degree node, six random ones
     P64 = {k: torch.from_numpy(w[k]).double() for k in ("W1", "b1", "W2", "b2")}
     adj_o = O.to_torch_sparse(a_hat).double()
-    with torch.no_grad():
-        gm = O.get_gradient_eps_mat(torch.from_numpy(x_np).double(), adj_o, P64, int(probes[1]), 1e-4)
-        ref64 = gm[torch.as_tensor(observe)].norm(dim=1).numpy()
-    assert np.abs(delta[1] - ref64).max() <= 1e-5 * max(ref64.max(), 1e-3)
-    assert np.all(full[1][ref64 == 0] == 0)
+    x64 = torch.from_numpy(x_np).double()
+    pdeg = deg[probes]
+    rows = np.unique(np.concatenate([[0, int(np.argsort(pdeg)[len(pdeg) // 2])], rng.choice(512, 6, replace=False)]))[:8]
+    t0 = time.time()
+    worst = 0.0
+    for i in rows:
+        with torch.no_grad():
+            gm = O.get_gradient_eps_mat(x64, adj_o, P64, int(probes[i]), 1e-4)
+            ref64 = gm[torch.as_tensor(observe)].norm(dim=1).numpy()
+        err = np.abs(delta[i] - ref64).max() / max(ref64.max(), 1e-3)
+        worst = max(worst, err)
+        assert err <= 1e-5, (int(i), int(probes[i]), err)
+        assert np.all(full[i][ref64 == 0] == 0) and np.all(delta[i][ref64 == 0] == 0)
+        assert np.array_equal(ref64 > 0, mask[i]) or np.all(mask[i][ref64 > 0])
+    log.append(f"fp64 oracle on probe rows {rows.tolist()} (degrees {pdeg[rows].tolist()}): worst |delta - ref64| / max = {worst:.2e} "
+               f"({time.time() - t0:.0f} s of oracle)")
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     with open(os.path.join(REPO, "gpurun_out", "rmat_scale21_test.txt"), "w") as fh:
         fh.write("\n".join(log) + "\n")
@@ -403,7 +440,7 @@ def test_gcn3_probe_primitive_against_oracle(gpu, h1, h2, c, hub):
     e32 = np.abs(ref[torch.float32] - ref[torch.float64]).max()
     scale = ref[torch.float64].max()
     print(f"gcn3 h1={h1} h2={h2} c={c} hub={hub}: max {scale:.3g} |ref32-ref64| {e32:.2e} |ours-ref64| {np.abs(got - ref[torch.float64]).max():.2e}")
-    assert np.abs(got - ref[torch.float64]).max() <= 2.0 * e32 + 1e-4 * scale
+    noise_gate(f"gcn3.h{h1}.{h2}.c{c}.hub{int(hub)}", np.abs(got - ref[torch.float64]).max() / max(e32, 1e-4 * scale))
     assert np.all(got[ref[torch.float64] == 0] == 0)
     assert np.array_equal(got[-1], got[-2])                         # duplicate probe -> identical rows
     logits = base.logits().cpu().numpy().astype(np.float64)

@@ -1,0 +1,198 @@
+"""GPU tests added in round 3: the unbalanced LSA2 attacks on the device forward, bench.py at N = 2 through its own
+launcher, layers wider than one pass of the row kernels, the sharded / on-demand fp64 pre-activation, the device top-k
+of LapGraph."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, csr_from, load_golden, noise_gate
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(w, dev):
+    return [torch.from_numpy(w[k]).to(dev) for k in ("W1", "b1", "W2", "b2")]
+
+
+def test_unbalanced_lsa2_attacks_on_device(gpu, tmp_path, monkeypatch):
+    """attacker.py:287-334 (`baseline` = LSA2-post, `baseline-feat` = LSA2-attr) with sample_type `unbalanced`: the
+    posteriors come from the HIP forward (GCN.forward -> lt_gemm_f32 / lt_spmm_csr_f32), the correlation math runs as in
+    the reference; scores against the reference's own (tests/golden/next_rows.npz), file name and schema included."""
+    import argparse
+    import types
+    from linkteller_amd import graph
+    from linkteller_amd.attacker import Attacker
+    from linkteller_amd.gcn import GCN
+    g = load_golden("next_rows.npz")
+    a = csr_from(g, "adj")
+    x = torch.from_numpy(g["x"]).to(gpu)
+    adj_t = graph.sparse_mx_to_torch_sparse_tensor(graph.first_order_gcn(a)).to(gpu)
+    w = types.SimpleNamespace(features_2=x, adj_2=adj_t, adj_ori=a, n_nodes=a.shape[0])
+    sd = {k: torch.from_numpy(g[f"sd.{k}"]) for k in ("gc1.weight", "gc1.bias", "gc2.weight", "gc2.bias")}
+    model = GCN(x.shape[1], sd["gc1.weight"].shape[1], sd["gc2.weight"].shape[1], 0.5)
+    model.load_state_dict(sd)
+    model.to(gpu).eval()
+    monkeypatch.chdir(tmp_path)
+    for mode in ("baseline", "baseline-feat"):
+        args = argparse.Namespace(dataset="twitch/ES/RU", sample_type="unbalanced", n_test=40, sample_seed=42,
+                                  influence=1e-4, mode="vanilla-clean", attack_mode=mode)
+        atk = Attacker(args, model, w)
+        atk.prepare_test_data()
+        assert np.array_equal(np.asarray(atk.test_nodes), g[f"{mode}.test_nodes"])
+        atk.baseline_attack()
+        saved = torch.load(str(g[f"{mode}.filename"]), weights_only=False)
+        assert set(saved) == {"auc", "pr", "result"}
+        ref = np.concatenate([g[f"{mode}.norm_exist"], g[f"{mode}.norm_nonexist"]])
+        got = np.asarray(saved["result"]["pred"])
+        assert got.shape == ref.shape
+        # correlations of fp32 posteriors: our logits differ from torch's by fp32 rounding (2e-5 relative, tested in
+        # test_forward_logits); with C = 2 the centred softmax posteriors are collinear, so the correlations are +-1 and
+        # only a sign flip of a near-zero centred vector could move one -- none does on the fixture
+        assert np.abs(got - ref).max() <= (2e-5 if mode == "baseline" else 2e-6), mode
+        if mode == "baseline-feat":
+            assert abs(atk.auc - float(g[f"{mode}.auc"])) <= 1e-4 and abs(atk.ap - float(g[f"{mode}.ap"])) <= 1e-4
+
+
+def _bench(args, env=None, timeout=900):
+    e = dict(os.environ, PYTHONPATH=REPO, **(env or {}))
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("mode,extra", [("delta", {}), ("delta", {"LT_FEATURE_DELTA": "0", "LT_SHARD_BASELINE": "1"}),
+                                        ("full", {"LT_SHARD_BASELINE": "1"})])
+def test_bench_two_ranks_through_its_own_launcher(gpu, tmp_path, mode, extra):
+    """`python bench.py --gpus 2` starts its two ranks itself (fresh child processes, before anything touches the GPU).
+    On a 1-GPU box the ranks share device 0 over gloo (LT_BENCH_BACKEND / LT_BENCH_DEVICE): one parsed JSON line with
+    n_gpus == 2, a non-zero collective, and the matrix of the last step equal to the one-rank run's bit for bit -- with the
+    loop-invariant product replicated, sharded (fp32 X W1 for `full`; the fp64 product for `delta` on dense-feature
+    routing), or served by the feature-difference route."""
+    common = ["--steps", "3", "--warmup", "1", "--blocks", "2", "--no-cpu-baseline", "--no-extras", "--no-pmc", "--mode", mode,
+              "--n-test", "120"]
+    one = _bench(common, {"LT_BENCH_DUMP": str(tmp_path / "one.npy"), **extra})
+    two = _bench(common + ["--gpus", "2"], {"LT_BENCH_BACKEND": "gloo", "LT_BENCH_DEVICE": "0",
+                                            "LT_BENCH_DUMP": str(tmp_path / "two.npy"), **extra})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["config"]["probes_per_rank"] == 60 and two["config"]["collective_bytes_per_step"] >= 120 * 120 * 4
+    assert two["scaling"] == "strong" and two["value"] > 0 and len(two["timing"]["block_ms"]) == 2
+    if extra.get("LT_SHARD_BASELINE") == "1":
+        assert "sharded" in two["config"]["baseline_XW1"], two["config"]
+        assert two["config"]["collective_bytes_per_step"] > 120 * 120 * 4
+    a, b = np.load(tmp_path / "one.npy"), np.load(tmp_path / "two.npy")
+    assert a.shape == (120, 120) and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("ncols", [260, 300, 510, 512, 1000, 12, 9])
+def test_spmm_any_width(gpu, ncols):
+    """lt_spmm_csr_f32 has no width limit (gcn/layers.py:30-36): 256-column slices on the vector path, tails and
+    unaligned widths through the 8-lane kernel; against an fp64 host product, on a graph with hub rows."""
+    from test_gpu_parity import _hub_graph
+    from linkteller_amd import engine, graph
+    a_hat = graph.first_order_gcn(_hub_graph(1200, 6000, 700, seed=5))
+    rng = np.random.RandomState(ncols)
+    s = rng.standard_normal((a_hat.shape[0], ncols)).astype(np.float32)
+    b = rng.standard_normal(ncols).astype(np.float32)
+    got = engine.spmm(graph.HipGraph(a_hat), torch.from_numpy(s).to(gpu), torch.from_numpy(b).to(gpu), relu=True).cpu().numpy()
+    want = np.maximum(a_hat.astype(np.float64) @ s.astype(np.float64) + b, 0)
+    assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("h,c", [(512, 16), (300, 2), (64, 121)])
+def test_layers_wider_than_the_fused_kernels(gpu, h, c):
+    """--hidden 512 (main.py:30 has no limit) and class counts beyond 8 (ppi: 121): GCN.forward and the probe loop run on
+    the unfused HIP layers (engine.WideBaseline): logits and influence rows against the oracle (fp64 and fp32)."""
+    from test_gpu_parity import _oracle_matrix
+    from linkteller_amd import engine, graph, synth
+    from linkteller_amd.gcn import GCN
+    from oracle import linkteller_oracle as O
+    n, f = 220, 40
+    a_hat = graph.first_order_gcn(synth.powerlaw_graph(n, 700, seed=h))
+    x = synth.gaussian_features(n, f, seed=3)
+    w = synth.gcn_weights(f, h, c, seed=c)
+    hg = graph.HipGraph(a_hat)
+    base = engine.baseline_for(hg, torch.from_numpy(x).to(gpu), *_params(w, gpu))
+    assert isinstance(base, engine.WideBaseline)
+    rng = np.random.RandomState(1)
+    probes = np.concatenate([rng.choice(n, 9, replace=False), [3, 3]])
+    observe = rng.choice(n, 40, replace=False)
+    ref64 = _oracle_matrix(a_hat, x, w, probes, observe, 1e-4, torch.float64)
+    ref32 = _oracle_matrix(a_hat, x, w, probes, observe, 1e-4, torch.float32)
+    got = base.influence_rows(probes, observe, 1e-4, "sparse").cpu().numpy().astype(np.float64)
+    e32 = np.abs(ref32 - ref64).max()
+    noise_gate(f"wide.h{h}c{c}.sparse", np.abs(got - ref64).max() / max(e32, 1e-4 * ref64.max()))
+    assert np.all(got[ref64 == 0] == 0)
+    assert np.array_equal(got[-1], got[-2])
+    with pytest.raises(NotImplementedError):
+        base.influence_rows(probes, observe, 1e-4, "delta")
+    P64 = {k: torch.from_numpy(w[k]).double() for k in w}
+    ref_logits = O.gcn_forward(torch.from_numpy(x).double(), O.to_torch_sparse(a_hat).double(), P64).numpy()
+    tol = 2e-5 * max(1.0, np.abs(ref_logits).max())
+    assert np.abs(base.logits().cpu().numpy() - ref_logits).max() <= tol
+    model = GCN(f, h, c, 0.5)
+    model.load_state_dict({"gc1.weight": torch.from_numpy(w["W1"]), "gc1.bias": torch.from_numpy(w["b1"]),
+                           "gc2.weight": torch.from_numpy(w["W2"]), "gc2.bias": torch.from_numpy(w["b2"])})
+    model.to(gpu).eval()
+    with torch.no_grad():
+        out = model(torch.from_numpy(x).to(gpu), hg).cpu().numpy()
+    assert np.abs(out - ref_logits).max() <= tol
+    assert np.abs(engine.gcn2_forward(hg, torch.from_numpy(x).to(gpu), *_params(w, gpu)).cpu().numpy() - ref_logits).max() <= tol
+
+
+def test_feature_difference_route_of_the_fp64_product(gpu):
+    """The fp64 product X W1 of `delta` from the feature rows' differences to a reference row (lt_fp64.hip,
+    k_s1d_feature_rows): taken for standardised indicator features (what the reference's twitch loader produces), not for
+    Gaussian ones; `delta` within 1e-5 of the fp64 oracle on both routes, the two routes within fp32 rounding of each
+    other; and a baseline whose features BECOME dense after the route was chosen falls back on the device (the gate) to
+    the matrix-core product, giving the bits of a baseline created on the dense features."""
+    from test_gpu_parity import _oracle_matrix
+    from linkteller_amd import _lib, engine, graph, synth
+    n, f, h = 900, 700, 102            # H needs padding (Hp = 104): the pad columns of S1d must stay zero on every route
+    a_hat = graph.first_order_gcn(synth.powerlaw_graph(n, 4000, seed=2))
+    x = synth.twitch_like_features(n, f, seed=4, density=0.02)
+    w = synth.gcn_weights(f, h, 3, seed=5)
+    hg = graph.HipGraph(a_hat)
+    xt = torch.from_numpy(x).to(gpu)
+    base = engine.Baseline(hg, xt, *_params(w, gpu)).enable_fp64()
+    assert base.fp64_route() == 1
+    rng = np.random.RandomState(0)
+    probes, observe = rng.choice(n, 40, replace=False), rng.choice(n, 200, replace=False)
+    ref64 = _oracle_matrix(a_hat, x, w, probes, observe, 1e-4, torch.float64)
+    got = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
+    assert np.abs(got - ref64).max() <= 1e-5 * ref64.max()
+    _lib.set_tuning("feature_delta", 0)
+    try:
+        base.refresh()
+        assert base.fp64_route() == 0
+        dense = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
+    finally:
+        _lib.set_tuning("feature_delta", None)
+    assert np.abs(dense - ref64).max() <= 1e-5 * ref64.max()
+    assert np.abs(dense - got).max() <= 1e-6 * ref64.max()
+    # dense features from the start: the probe at enable_fp64 picks the matrix cores
+    xg = synth.gaussian_features(n, f, seed=9)
+    bg = engine.Baseline(hg, torch.from_numpy(xg).to(gpu), *_params(w, gpu)).enable_fp64()
+    assert bg.fp64_route() == 0
+    want = bg.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy()
+    # features that turn dense under a baseline that chose the sparse route: same bits through the device-side gate
+    xt.copy_(torch.from_numpy(xg).to(gpu))
+    base.refresh()
+    assert base.fp64_route() == 1
+    assert np.array_equal(base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy(), want)
+    refg = _oracle_matrix(a_hat, xg, w, probes[:6], observe, 1e-4, torch.float64)
+    assert np.abs(want[:6] - refg).max() <= 1e-5 * refg.max()
+    # a single dense row among sparse ones also raises the gate
+    xm = x.copy()
+    xm[17] = xg[17]
+    xt.copy_(torch.from_numpy(xm).to(gpu))
+    base.refresh()
+    got_m = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
+    refm = _oracle_matrix(a_hat, xm, w, probes[:6], observe, 1e-4, torch.float64)
+    assert np.abs(got_m[:6] - refm).max() <= 1e-5 * refm.max()

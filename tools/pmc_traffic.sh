@@ -6,8 +6,8 @@ scale=${1:-21}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_traffic; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --output-format csv -d $O/step_$ctr -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 > $O/step_$ctr.log 2>&1
-  rocprofv3 --pmc $ctr --output-format csv -d $O/spmm_$ctr -- python3 $R/bench.py --only-spmm --spmm-scale $scale > $O/spmm_$ctr.log 2>&1
+  rocprofv3 --pmc $ctr --output-format csv -d $O/step_$ctr -- python3 $R/bench.py --no-cpu-baseline --no-extras --no-pmc --steps 3 --warmup 1 > $O/step_$ctr.log 2>&1
+  rocprofv3 --pmc $ctr --output-format csv -d $O/spmm_$ctr -- python3 $R/bench.py --only-spmm --no-pmc --spmm-scale $scale > $O/spmm_$ctr.log 2>&1
 done
 python3 - <<PY
 import csv, glob, json, collections, subprocess, sys

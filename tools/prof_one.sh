@@ -3,7 +3,7 @@
 tag=$1; shift
 O=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 3 "$@" > $O.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras --no-pmc --steps 20 --warmup 3 "$@" > $O.log 2>&1
 python3 - <<PY
 import csv,glob
 f=glob.glob("$O/*/*kernel_stats.csv")[0]

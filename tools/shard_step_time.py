@@ -18,7 +18,7 @@ for N in (1, 2, 4, 8):
     probes = torch.from_numpy(nodes[:per]).to(dev)
     out = torch.empty((per, n_test), dtype=torch.float32, device=dev)
     def step():
-        base.refresh()
+        base.refresh(mode)
         base.influence_rows(probes, obs, 1e-4, mode, out=out)
     for _ in range(5): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
