@@ -84,6 +84,10 @@ int lt_device_count(int *count);
  *                         exact for any X): 0 = never, 1 = always try, negative = when lt_baseline_enable_fp64 found the
  *                         features to be of that kind (default).  The only knob that changes fp64 summation ORDER (the
  *                         results agree to ~1e-16 relative before the final rounding to fp32).
+ *   "aggregate_first"     fp64 pre-activation of LT_MODE_DELTA as Z1d[r] = (A_hat X)[r] W1 + b1, computed only on the rows the
+ *                         probes of a call reach (no n x F x H product): 0 = never, 1 = whenever the shapes allow (F <= 2 Hp,
+ *                         F <= 512; set it before lt_baseline_enable_fp64 allocates), negative = then and when the features
+ *                         are not sparse differences (default).  Like "feature_delta" it changes fp64 summation order only.
  *   "probe_kslice"        K-slice of the perturbed-row GEMM; 0 = the slicing of the baseline X*W1 (default: S1'[v] and
  *                         S1[v] then share one summation order, like the reference's two torch.mm calls)
  * value = LT_TUNING_DEFAULT restores the default. */
@@ -165,7 +169,8 @@ int lt_baseline_refresh_rows(lt_baseline *b, int32_t row_begin, int32_t row_end,
  * row carries the same bits whichever rank computed it.  lt_baseline_fp64_route: 1 when the baseline's features were
  * found to be sparse differences to a reference row (two-valued columns, as standardised indicator features are) and
  * the fp64 product therefore costs one pass over X -- then sharding it buys nothing -- 0 when it runs on the f64
- * matrix cores, -1 when fp64 is not enabled. */
+ * matrix cores, 2 when the pre-activation is formed aggregate-first on the rows a call needs (no S1d at all), -1 when fp64 is
+ * not enabled. */
 int lt_baseline_attach_s1d(lt_baseline *b, double *S1d, int64_t ld, void *stream);
 int lt_baseline_refresh_rows_fp64(lt_baseline *b, int32_t row_begin, int32_t row_end, double *dst, void *stream);
 int lt_baseline_fp64_route(const lt_baseline *b, int32_t *route);
@@ -208,6 +213,19 @@ size_t lt_influence3_workspace_bytes(const lt_baseline3 *b, int32_t n_probe, int
 int lt_influence3_rows(const lt_baseline3 *b, const int32_t *probe_nodes, int32_t n_probe,
                        const int32_t *observe_nodes, int32_t n_obs, float delta,
                        float *out, int64_t ldo, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- LapGraph cell selection (worker.py:302-335: A += noise, the n_keep largest cells of the strict lower
+ * triangle by a 50-way np.argpartition) --------------------------------------------------------------------------------
+ * The noise stays numpy's (stream compatibility with --noise-seed): the host draws the N x N float64 matrix and uploads
+ * it as `cells` (device, [n, n], only j < i is read; overwritten with adjacency + noise).  lower_rowptr / lower_col:
+ * device CSR of the 0/1 adjacency (entries with j >= i are ignored).  The call adds 1.0 on the edges (the reference's fp64
+ * add), radix-selects the n_keep-th largest key and writes the flat indices i * n + j of the selected cells to out_idx
+ * ([n_keep] int64, device, unordered).  work: >= 4096 bytes of device scratch.  threshold_out (host, may be NULL): the
+ * n_keep-th largest value.  Synchronises the stream.  The selected set equals np.argpartition's unless the threshold
+ * value is tied; a threshold <= 0 (the selection would reach the zero cells of the upper triangle, where the reference
+ * asserts) returns LT_ERR_UNSUPPORTED. */
+int lt_lapgraph_select(int32_t n, const int32_t *lower_rowptr, const int32_t *lower_col, double *cells, int64_t n_keep,
+                       int64_t *out_idx, void *work, size_t work_bytes, double *threshold_out, void *stream);
 
 /* ---- per-kernel timing (used by bench.py for the roofline object) --------------------------
  * lt_profile_enable(mask): bit k of mask set = launches of kernel class k are bracketed by a pair of

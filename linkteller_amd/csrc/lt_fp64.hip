@@ -510,6 +510,156 @@ static int launch_dense_s1d(lt_baseline *b, int r0, int r1, double *dst, long ld
     return LT_OK;
 }
 
+// ---- aggregate-first route: Z1d[r] = (A_hat X)[r] * W1 + b1 on the rows a call's probes reach ------------------------
+// LT_MODE_DELTA reads the fp64 pre-activation only on its items' rows r (the union of R_v over the probes) and the fp64
+// product only on the probes' own rows.  For features no wider than ~2 H (BASELINE configs[4]: F = H = 256) it is cheaper
+// to aggregate first -- Y[r] = sum_c A_hat[r,c] X[c], fp32 gathers of F columns, fp64 chains, ONLY for the rows needed --
+// and to multiply those few rows by W1 afterwards, than to form S1d = X W1 for all n rows (2 n F H flops) and gather
+// 8-byte S1d rows for every row of the graph: R-MAT scale 21, 512 probes: 15 K of 2 M rows are needed.
+//   k_z_mark            items (b, r) -> rows with no valid pre-activation since the last refresh: zstate 0 -> 2, listed
+//   k_rows_tiled_xf64   (lt_spmm.hip) the work items of the marked rows; k_y_long adds the segment sums of marked hub rows
+//   k_gemm_f64_rows     Z1d[rows[i]] = Y[rows[i]] W1 + b1 (f64 matrix cores, rows through the list, count on the device),
+//                       zstate -> 1; the same kernel with fp32 A forms the probes' product rows Spd = X[probes] W1
+static __global__ __launch_bounds__(256) void k_z_mark(const int32_t *__restrict__ off, int nb, const int2 *__restrict__ item_pr,
+                                                       int32_t *__restrict__ zstate, int32_t *__restrict__ zrows,
+                                                       int32_t *__restrict__ zcount) {
+    const int total = off[nb];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = item_pr[i].y;
+        if (zstate[r] != 0) continue;                       // valid already, or claimed by another item of this chunk
+        if (atomicCAS(&zstate[r], 0, 2) == 0) zrows[atomicAdd(zcount, 1)] = r;   // (list order is arbitrary: rows are independent)
+    }
+}
+static __global__ void k_y_long(int n_long, const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_segptr,
+                                const double *__restrict__ part, int ld, const int32_t *__restrict__ zstate,
+                                double *__restrict__ Y) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n_long * ld) return;
+    const int li = (int)(i / ld), c = (int)(i % ld);
+    const int r = long_row[li];
+    if (zstate[r] != 2) return;
+    double acc = part[(size_t)long_segptr[li] * ld + c];
+    for (int sg = long_segptr[li] + 1; sg < long_segptr[li + 1]; ++sg) acc += part[(size_t)sg * ld + c];
+    Y[(size_t)r * ld + c] = acc;
+}
+
+// C[row(i), 0..N) = A[rows[i], 0..K) * B[K, N] (+ bias), i < M, on v_mfma_f64_16x16x4_f64: 64 x 64 tiles, a fixed grid
+// walking the tiles (M may live on the device).  AT = double (the aggregated rows) or float (feature rows, widened).
+// scatter: 1 = row(i) = rows[i] (results land at the node's row), 0 = row(i) = i.  state != NULL: state[rows[i]] = 1.
+template <typename AT>
+__global__ __launch_bounds__(256) void k_gemm_f64_rows(const AT *__restrict__ A, long lda, const int32_t *__restrict__ rows,
+                                                       const int32_t *__restrict__ m_dev, int m_host,
+                                                       const float *__restrict__ B, long ldb, int N, int K,
+                                                       const float *__restrict__ bias, double *__restrict__ C, long ldc,
+                                                       int scatter, int32_t *__restrict__ state) {
+    __shared__ __attribute__((aligned(16))) double As[GD_BM * GD_LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[GD_BK * GD_LDB];
+    const int M = m_dev ? *m_dev : m_host;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int ntn = (N + GD_BN - 1) / GD_BN;
+    const long tiles = (long)((M + GD_BM - 1) / GD_BM) * ntn;
+    const int a_row = tid >> 2, a_col = (tid & 3) * 4;
+    const int b_row = tid >> 4, b_col = (tid & 15) * 4;
+    const int a_frag = (wr * 32 + (lane & 15)) * GD_LDA + (lane >> 4);
+    const int b_frag = (lane >> 4) * GD_LDB + wc * 32 + (lane & 15);
+    for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int m0 = (int)(tile / ntn) * GD_BM, n0 = (int)(tile % ntn) * GD_BN;
+        const bool a_ok = m0 + a_row < M;
+        const AT *ap = A + (size_t)(a_ok ? rows[m0 + a_row] : 0) * lda;
+        f64x4 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < K; k0 += GD_BK) {
+            double ra[4] = {0.0, 0.0, 0.0, 0.0};
+            float rb[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a_ok)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k0 + a_col + j < K) ra[j] = (double)ap[k0 + a_col + j];
+            if (k0 + b_row < K)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (n0 + b_col + j < N) rb[j] = B[(size_t)(k0 + b_row) * ldb + n0 + b_col + j];
+            __syncthreads();   // the previous k-step's fragment reads are done
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                As[a_row * GD_LDA + a_col + j] = ra[j];
+                Bs[b_row * GD_LDB + b_col + j] = rb[j];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < GD_BK; kk += 4) {
+                const double a0 = As[a_frag + kk], a1 = As[a_frag + 16 * GD_LDA + kk];
+                const double b0 = (double)Bs[b_frag + kk * GD_LDB], b1 = (double)Bs[b_frag + kk * GD_LDB + 16];
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+        // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cn = n0 + wc * 32 + j * 16 + (lane & 15);
+                if (cn >= N) continue;
+                const double bv = bias ? (double)bias[cn] : 0.0;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int cm = m0 + wr * 32 + i * 16 + (lane >> 4) + 4 * reg;
+                    if (cm < M) C[(size_t)(scatter ? rows[cm] : cm) * ldc + cn] = acc[i][j][reg] + bv;
+                }
+            }
+        if (state && n0 == 0 && tid < GD_BM && m0 + tid < M) state[rows[m0 + tid]] = 1;
+        __syncthreads();
+    }
+}
+
+static bool agg_shapes_ok(const lt_baseline *b) {
+    return b->n > 0 && b->F <= 2 * b->Hp && lt_round_up(b->F, 4) <= 512 && b->g->w_n > 0;
+}
+bool lt_fp64_agg_active(const lt_baseline *b) {
+    if (!b->Z1d || !b->Yd) return false;
+    const int knob = lt_tune().aggregate_first;
+    if (knob == 0) return false;
+    if (knob > 0) return true;
+    return b->agg_default;
+}
+
+int lt_fp64_prepare_items(const lt_baseline *b, const int32_t *off, int nb, const int2 *item_pr, const int32_t *probes,
+                          double *Spd, hipStream_t st) {
+    const lt_graph *g = b->g;
+    const int Hp = b->Hp, H = b->H, F = b->F, Fp = b->Fp;
+    { lt_prof_scope prof_(LT_K_FP64_SPMM, st);
+    LT_HIP(hipMemsetAsync(b->zcount, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_z_mark, dim3(1024), dim3(256), 0, st, off, nb, item_pr, b->zstate, b->zrows, b->zcount);
+    LT_CHECK_LAUNCH();
+    int rc = lt_launch_rows_tiled_xf64(g, b->X, b->ldx, F, b->Yd, Fp, b->seg_y, Fp, b->zstate, st);
+    if (rc) return rc;
+    if (g->p_n_long > 0) {
+        const long tot = (long)g->p_n_long * Fp;
+        hipLaunchKernelGGL(k_y_long, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, g->p_n_long, g->p_long_row,
+                           g->p_long_segptr, b->seg_y, Fp, b->zstate, b->Yd);
+        LT_CHECK_LAUNCH();
+    } }
+    lt_prof_scope prof_(LT_K_FP64_PRODUCT, st);
+    // (Yd rows hold F valid columns; K = F, so the pad columns of Yd are never read)
+    hipLaunchKernelGGL((k_gemm_f64_rows<double>), dim3(2048), dim3(256), 0, st, b->Yd, (long)Fp, b->zrows, b->zcount, 0, b->W1,
+                       (long)H, H, F, b->b1, b->Z1d, (long)Hp, 1, b->zstate);
+    LT_CHECK_LAUNCH();
+    if (Hp != H) LT_HIP(hipMemsetAsync(Spd, 0, (size_t)nb * Hp * sizeof(double), st));
+    const int tiles = ((nb + GD_BM - 1) / GD_BM) * ((H + GD_BN - 1) / GD_BN);
+    hipLaunchKernelGGL((k_gemm_f64_rows<float>), dim3((unsigned)(tiles < 2048 ? tiles : 2048)), dim3(256), 0, st, b->X, (long)b->ldx,
+                       probes, (const int32_t *)nullptr, nb, b->W1, (long)H, H, F, (const float *)nullptr, Spd, (long)Hp, 0,
+                       (int32_t *)nullptr);
+    LT_CHECK_LAUNCH();
+    return LT_OK;
+}
+
 // Whether this refresh tries the feature-difference product (k_s1d_feature_rows): the "feature_delta" knob, else what
 // the probe of lt_baseline_enable_fp64 found (feat_sparse: -1 unknown = try, the gated matrix-core product stands behind it).
 static bool want_feature_rows(const lt_baseline *b) {
@@ -552,6 +702,14 @@ static int launch_feature_s1d(lt_baseline *b, hipStream_t st) {
 static int compute_z1d(lt_baseline *b, hipStream_t st) {
     if (b->n == 0) return LT_OK;
     const int Hp = b->Hp, H = b->H, n = b->n;
+    if (lt_fp64_agg_active(b)) {
+        // aggregate-first: nothing is computed here; every pre-activation row is stale until a call's items ask for it
+        LT_HIP(hipMemsetAsync(b->zstate, 0, (size_t)n * sizeof(int32_t), st));
+        return LT_OK;
+    }
+    if (!b->S1d)
+        return lt_set_error(LT_ERR_UNSUPPORTED, "fp64 pre-activation: the S1d route was not allocated (set \"aggregate_first\" "
+                                                "before lt_baseline_enable_fp64)");
     { lt_prof_scope prof_(LT_K_FP64_PRODUCT, st);
     if (b->S1d_external) {
         // multi-GPU: S1d arrives by the caller's all-gather of the ranks' row shards (lt_baseline_refresh_rows_fp64)
@@ -606,43 +764,82 @@ int lt_baseline_refresh_fp64(lt_baseline *b, hipStream_t st) {
 extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     LT_REQUIRE(b != nullptr, "lt_baseline_enable_fp64: baseline is NULL");
     if (b->Z1d) return LT_OK;   // Z1d is set only once all the buffers exist (see below)
-    const size_t nh = (size_t)(b->n > 0 ? b->n : 1) * b->Hp * sizeof(double);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n1 = (size_t)(b->n > 0 ? b->n : 1);
+    const size_t nh = n1 * b->Hp * sizeof(double);
+    b->Fp = lt_round_up(b->F, 4);
+    // Which route forms the pre-activation is decided here, once, from the features and the shapes (the knobs pin it):
+    //   1. feature rows that are sparse differences to a reference row (standardised indicators)  -> k_s1d_feature_rows
+    //   2. else features no wider than ~2 H                                                       -> aggregate-first
+    //   3. else                                                                                   -> the f64 matrix cores
+    // Routes 1 / 3 share S1d + the all-rows fp64 SpMM; route 2 has its own buffers.  Small problems get both sets (the
+    // knobs may then switch at any time); large ones only the chosen set.
+    const bool fd_possible = b->n >= 2 && fd_smem_bytes(b->F) <= (size_t)60 * 1024 && lt_tune().feature_delta != 0;
+    int feat = -1;
+    if (fd_possible) {
+        // probe (this call allocates, so it may synchronise): does any row differ from the reference row in more than
+        // FD_CAP columns?  Temporary buffers: the real ones are allocated once the route is known.
+        double *cref = nullptr, *fslabs = nullptr, *s1d = nullptr;
+        int *gate = nullptr;
+        hipError_t e = hipMalloc((void **)&cref, (size_t)b->Hp * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&fslabs, (size_t)((b->F + 63) / 64) * b->H * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&gate, sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&s1d, nh);
+        if (e == hipSuccess) {
+            b->fd_cref = cref; b->fd_slabs = fslabs; b->fd_gate = gate; b->S1d = s1d;
+            int rc = launch_feature_s1d(b, st);
+            int g = 1;
+            if (rc == LT_OK && hipMemcpyAsync(&g, gate, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                hipStreamSynchronize(st) == hipSuccess)
+                feat = g == 0 ? 1 : 0;
+            b->fd_cref = b->fd_slabs = nullptr; b->fd_gate = nullptr; b->S1d = nullptr;
+        }
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(cref); (void)hipFree(fslabs); (void)hipFree(gate); (void)hipFree(s1d);
+        (void)hipGetLastError();
+    }
+    const int aknob = lt_tune().aggregate_first;
+    const bool agg_ok = agg_shapes_ok(b) && aknob != 0;
+    const bool agg_chosen = agg_ok && (aknob > 0 || feat != 1);
+    const bool small = nh <= ((size_t)256 << 20);
+    const bool alloc_s1d = !agg_chosen || small;
+    const bool alloc_agg = agg_chosen || (agg_ok && small);
+
     const int ks_ = fp64_kslice(b->n, b->H, b->F);
     const int splits = (b->F + ks_ - 1) / ks_;
     double *s1d = nullptr, *z1d = nullptr, *slabs = nullptr, *segd = nullptr, *cref = nullptr, *fslabs = nullptr;
+    double *yd = nullptr, *segy = nullptr;
     int *gate = nullptr;
-    // the feature-difference route needs the reference row in LDS next to the per-wave lists
-    const bool fd_possible = b->n >= 2 && fd_smem_bytes(b->F) <= (size_t)60 * 1024;
-    hipError_t e = hipMalloc((void **)&s1d, nh);
-    if (e == hipSuccess) e = hipMalloc((void **)&z1d, nh);
-    if (e == hipSuccess && b->g->p_n_seg > 0) e = hipMalloc((void **)&segd, (size_t)b->g->p_n_seg * b->Hp * sizeof(double));
-    if (e == hipSuccess && splits > 1)
-        e = hipMalloc((void **)&slabs, (size_t)splits * (b->n > 0 ? b->n : 1) * b->H * sizeof(double));
-    if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&cref, (size_t)b->Hp * sizeof(double));
-    if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fslabs, (size_t)((b->F + 63) / 64) * b->H * sizeof(double));
-    if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&gate, sizeof(int));
+    int32_t *zst = nullptr, *zrw = nullptr, *zct = nullptr;
+    hipError_t e = hipMalloc((void **)&z1d, nh);
+    if (e == hipSuccess) e = hipMemsetAsync(z1d, 0, nh, st);      // (pad columns stay zero on every route)
+    if (alloc_s1d) {
+        if (e == hipSuccess) e = hipMalloc((void **)&s1d, nh);
+        if (e == hipSuccess && b->g->p_n_seg > 0) e = hipMalloc((void **)&segd, (size_t)b->g->p_n_seg * b->Hp * sizeof(double));
+        if (e == hipSuccess && splits > 1) e = hipMalloc((void **)&slabs, (size_t)splits * n1 * b->H * sizeof(double));
+        if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&cref, (size_t)b->Hp * sizeof(double));
+        if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fslabs, (size_t)((b->F + 63) / 64) * b->H * sizeof(double));
+        if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&gate, sizeof(int));
+    }
+    if (alloc_agg) {
+        if (e == hipSuccess) e = hipMalloc((void **)&yd, n1 * b->Fp * sizeof(double));
+        if (e == hipSuccess && b->g->p_n_seg > 0) e = hipMalloc((void **)&segy, (size_t)b->g->p_n_seg * b->Fp * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&zst, n1 * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&zrw, n1 * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&zct, sizeof(int32_t));
+    }
     if (e != hipSuccess) {   // all or nothing: a retry starts from a clean state, nothing leaks
         (void)hipFree(s1d); (void)hipFree(z1d); (void)hipFree(slabs); (void)hipFree(segd);
         (void)hipFree(cref); (void)hipFree(fslabs); (void)hipFree(gate);
+        (void)hipFree(yd); (void)hipFree(segy); (void)hipFree(zst); (void)hipFree(zrw); (void)hipFree(zct);
         return lt_set_error(LT_ERR_HIP, "lt_baseline_enable_fp64: hipMalloc failed: %s", hipGetErrorString(e));
     }
     b->S1d = s1d; b->Z1d = z1d; b->slabs_d = slabs; b->seg_d = segd;
     b->fd_cref = cref; b->fd_slabs = fslabs; b->fd_gate = gate;
-    b->S1d_owned = true; b->S1d_external = false; b->feat_sparse = -1;
-    hipStream_t st = (hipStream_t)stream;
+    b->Yd = yd; b->seg_y = segy; b->zstate = zst; b->zrows = zrw; b->zcount = zct;
+    b->S1d_owned = true; b->S1d_external = false; b->feat_sparse = feat; b->agg_default = agg_chosen;
     int rc = lt_baseline_ensure_padding(b, st);   // (the padded bias the fp64 SpMM adds)
     if (rc) return rc;
-    if (fd_possible && lt_tune().feature_delta != 0) {
-        // Probe once (this call allocates, so it may synchronise): do the feature rows differ from the reference row in few
-        // columns?  The answer only picks the route later refreshes TRY FIRST -- a refresh whose rows turn out dense
-        // raises the gate on the device and the matrix-core product behind it runs, so it is never a correctness matter.
-        rc = launch_feature_s1d(b, st);
-        if (rc) return rc;
-        int g = 1;
-        LT_HIP(hipMemcpyAsync(&g, b->fd_gate, sizeof(int), hipMemcpyDeviceToHost, st));
-        LT_HIP(hipStreamSynchronize(st));
-        b->feat_sparse = g == 0 ? 1 : 0;
-    }
     rc = compute_z1d(b, st);
     b->fp64_fresh = rc == LT_OK;
     return rc;
@@ -650,7 +847,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
 
 extern "C" int lt_baseline_fp64_route(const lt_baseline *b, int32_t *route) {
     LT_REQUIRE(b != nullptr && route != nullptr, "lt_baseline_fp64_route: NULL argument");
-    *route = !b->Z1d ? -1 : (want_feature_rows(b) ? 1 : 0);
+    *route = !b->Z1d ? -1 : (lt_fp64_agg_active(b) ? 2 : (want_feature_rows(b) ? 1 : 0));
     return LT_OK;
 }
 
@@ -660,6 +857,9 @@ extern "C" int lt_baseline_fp64_route(const lt_baseline *b, int32_t *route) {
 extern "C" int lt_baseline_refresh_rows_fp64(lt_baseline *b, int32_t row_begin, int32_t row_end, double *dst, void *stream) {
     LT_REQUIRE(b != nullptr, "lt_baseline_refresh_rows_fp64: baseline is NULL");
     LT_REQUIRE(b->Z1d != nullptr, "lt_baseline_refresh_rows_fp64: call lt_baseline_enable_fp64 first");
+    if (lt_fp64_agg_active(b) || !b->S1d)
+        return lt_set_error(LT_ERR_UNSUPPORTED, "lt_baseline_refresh_rows_fp64: this baseline forms its pre-activation aggregate-first "
+                                                "(no S1d to shard: lt_baseline_fp64_route == 2)");
     LT_REQUIRE(row_begin >= 0 && row_begin <= row_end && row_end <= b->n,
                "lt_baseline_refresh_rows_fp64: rows [%d, %d) outside [0, %d]", row_begin, row_end, b->n);
     LT_REQUIRE(dst != nullptr && ((uintptr_t)dst % 16) == 0, "lt_baseline_refresh_rows_fp64: dst is NULL or not 16-byte aligned");
@@ -678,6 +878,9 @@ extern "C" int lt_baseline_refresh_rows_fp64(lt_baseline *b, int32_t row_begin, 
 extern "C" int lt_baseline_attach_s1d(lt_baseline *b, double *S1d, int64_t ld, void *stream) {
     LT_REQUIRE(b != nullptr, "lt_baseline_attach_s1d: baseline is NULL");
     LT_REQUIRE(b->Z1d != nullptr, "lt_baseline_attach_s1d: call lt_baseline_enable_fp64 first");
+    if (S1d != nullptr && (lt_fp64_agg_active(b) || !b->S1d))
+        return lt_set_error(LT_ERR_UNSUPPORTED, "lt_baseline_attach_s1d: this baseline forms its pre-activation aggregate-first "
+                                                "(no S1d: lt_baseline_fp64_route == 2)");
     hipStream_t st = (hipStream_t)stream;
     if (S1d == nullptr) {
         if (!b->S1d_owned) {
@@ -713,7 +916,13 @@ void lt_baseline_free_fp64(lt_baseline *b) {
     (void)hipFree(b->fd_cref);
     (void)hipFree(b->fd_slabs);
     (void)hipFree(b->fd_gate);
-    b->S1d = b->Z1d = b->slabs_d = b->seg_d = b->fd_cref = b->fd_slabs = nullptr;
+    (void)hipFree(b->Yd);
+    (void)hipFree(b->seg_y);
+    (void)hipFree(b->zstate);
+    (void)hipFree(b->zrows);
+    (void)hipFree(b->zcount);
+    b->S1d = b->Z1d = b->slabs_d = b->seg_d = b->fd_cref = b->fd_slabs = b->Yd = b->seg_y = nullptr;
     b->fd_gate = nullptr;
+    b->zstate = b->zrows = b->zcount = nullptr;
     b->fp64_fresh = false;
 }

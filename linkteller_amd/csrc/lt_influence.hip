@@ -630,7 +630,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
     const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
     const float *__restrict__ Sp, float delta, float *__restrict__ S2x, int n_long,
     const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_segptr,
-    const float *__restrict__ seg_part, const int2 *__restrict__ item_pr) {
+    const float *__restrict__ seg_part, const int2 *__restrict__ item_pr, const double *__restrict__ Spd) {
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int gl = lane & (LPR - 1);
@@ -657,7 +657,8 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
                     const float arv = tval[t];
                     f32x4 s;
                     if (DELTA == 2) {   // the probe's S1 row off the fp64 product (the fp32 one is not even computed for this mode)
-                        const double *sp = S1d + (size_t)v * Hp + coff;
+                        // (aggregate-first route: the probes' own product rows Spd[b], there is no S1d)
+                        const double *sp = Spd ? Spd + (size_t)b * Hp + coff : S1d + (size_t)v * Hp + coff;
                         s = f32x4{(float)sp[0], (float)sp[1], (float)sp[2], (float)sp[3]};
                     } else {
                         s = ld4(S1 + (size_t)v * Hp + coff);
@@ -1123,6 +1124,7 @@ struct infl_ws {
     float *lpart;          // FULL: segment sums of the long rows [segment][group][P + 1][Hp]
     float *slabs;          // FULL / SPARSE: split-K partials of the perturbed-row GEMM
     float *S2x;            // SPARSE / DELTA: per-item values
+    double *Spd;           // DELTA, aggregate-first route: fp64 product rows of the chunk's probes [chunk, Hp]
     int32_t *off;          // SPARSE / DELTA: item offsets [chunk + 1]
     int2 *item_pr;         // SPARSE / DELTA: (probe index, row) of every item
     int32_t *pm_cnt, *pm_start, *pm_rank, *pm_list;   // SPARSE / DELTA pair marks: per-node lists of observed nodes (lt_items.cuh)
@@ -1165,6 +1167,7 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int n_o
         // groups * (P + 1) slots per segment: at most ceil(chunk / 8) * 9 (P = 8), or chunk / 32 * 33 + 33
         w.lpart = (float *)take(nseg * (((chunk + 7) / 8) * 9 + 33) * Hp * sizeof(float));
     }
+    if (mode == LT_MODE_DELTA) w.Spd = (double *)take(chunk * Hp * sizeof(double));   // aggregate-first: X[probes] W1 in fp64
     if (mode != LT_MODE_FULL) {
         w.S2x = (float *)take(chunk * maxc * C * sizeof(float));
         w.off = (int32_t *)take((chunk + 1) * sizeof(int32_t));
@@ -1384,7 +1387,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, g->tptr,
                                        g->trow, g->tval, b->S1, b->Z1, b->Z1d, b->S1d, Hp, b->b1p, b->W2p, C, probes, nb,
                                        w.off, w.Sp, delta, w.S2x, g->p_n_long, g->p_long_row, g->p_long_segptr,
-                                       b->seg_part, w.item_pr))); }
+                                       b->seg_part, w.item_pr, (const double *)nullptr))); }
                 LT_CHECK_LAUNCH();
                 lt_prof_scope prof_(LT_K_ITEM_B, st);
                 if (long_blocks > 0 && hub_short) {
@@ -1403,6 +1406,13 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                        orow, (long)ldo, w.bits, words, (int)inl, long_blocks > 0 ? 1 : 0, marks,
                                                        w.big_bits, w.big_slot, 0));
             } else {
+                const double *spd = nullptr;
+                if (b->Z1d && lt_fp64_agg_active(b)) {
+                    // aggregate-first: the pre-activation rows this chunk's items read, and the probes' product rows
+                    const int rc = lt_fp64_prepare_items(b, w.off, nb, w.item_pr, probes, w.Spd, st);
+                    if (rc) return rc;
+                    spd = w.Spd;
+                }
                 { lt_prof_scope prof_(LT_K_ITEM_A, st);
                 if (b->Z1d) {
                     LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
@@ -1410,14 +1420,14 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                            st, g->rowptr, g->col, g->val, g->tptr, g->trow, g->tval, b->S1,
                                            b->Z1, b->Z1d, b->S1d, Hp, b->b1p, b->W2p, C, probes, nb, w.off,
                                            (const float *)nullptr, delta, w.S2x, 0, (const int32_t *)nullptr,
-                                           (const int32_t *)nullptr, (const float *)nullptr, w.item_pr)));
+                                           (const int32_t *)nullptr, (const float *)nullptr, w.item_pr, spd)));
                 } else {
                     LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
                         hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, 1>), dim3(LT_ITEM_GRID), dim3(LT_BLOCK), 0,
                                            st, g->rowptr, g->col, g->val, g->tptr, g->trow, g->tval, b->S1,
                                            b->Z1, b->Z1d, b->S1d, Hp, b->b1p, b->W2p, C, probes, nb, w.off,
                                            (const float *)nullptr, delta, w.S2x, 0, (const int32_t *)nullptr,
-                                           (const int32_t *)nullptr, (const float *)nullptr, w.item_pr)));
+                                           (const int32_t *)nullptr, (const float *)nullptr, w.item_pr, (const double *)nullptr)));
                 } }
                 LT_CHECK_LAUNCH();
                 lt_prof_scope prof_(LT_K_ITEM_B, st);

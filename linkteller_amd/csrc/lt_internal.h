@@ -82,6 +82,15 @@ struct lt_baseline {
     double *fd_slabs = nullptr; // [ceil(F / 64), H] its split-K partials
     int *fd_gate = nullptr;     // device flag: a row was not a sparse difference -> the matrix-core product runs
     int feat_sparse = -1;       // what the probe at lt_baseline_enable_fp64 found: 1 sparse differences, 0 dense, -1 not probed
+    // aggregate-first route of the fp64 pre-activation (lt_fp64.hip): Z1d[r] = (A_hat X)[r] W1 + b1 on the rows a call's
+    // probes reach, nothing for the others -- no n x F x H product, no S1d
+    int Fp = 0;                 // F rounded up to a multiple of 4 (leading dimension of Yd)
+    bool agg_default = false;   // the route lt_baseline_enable_fp64 chose for these shapes / features
+    double *Yd = nullptr;       // [n, Fp] (A_hat X) rows, valid where zstate != 0
+    double *seg_y = nullptr;    // [g->p_n_seg, Fp] segment sums of the long rows
+    int32_t *zstate = nullptr;  // [n] 0: Z1d row not computed since the last refresh, 2: wanted by the chunk in flight, 1: valid
+    int32_t *zrows = nullptr;   // [n] the rows marked 2 by the chunk in flight
+    int32_t *zcount = nullptr;  // [1] their number
     // lt_baseline_refresh recomputes S1 and marks what depends on it stale; Z1 / S2 / OUT (and Z1d) are
     // recomputed by the first call that reads them (logits, SPARSE / DELTA rows) -- FULL rows never do: their
     // stage A yields the baseline S2 as a by-product and stage B forms the baseline logits itself.
@@ -115,6 +124,8 @@ struct lt_tuning {
     long long bits_max_bytes;    // SPARSE / DELTA: a bitmap row per probe only while the chunk's rows fit this (default 128 MiB);
                                  // beyond it only the chunk's big probes get rows (LT_BITS_MAX_BYTES)
     int tiled_big;               // 1: the tiled SpMM always uses 64-bit gather offsets (test hook; default: only when S spans >= 4 GiB)
+    int aggregate_first;         // fp64 pre-activation as (A_hat X) W1 on the rows a call needs: 0 never, 1 whenever the shapes allow,
+                                 // -1 when they do and the features are not sparse differences (LT_AGGREGATE_FIRST)
     int feature_delta;           // fp64 product X*W1 from the feature rows' differences to a reference row: 0 never, 1 always try,
                                  // -1 when the baseline's features were found to be sparse differences (LT_FEATURE_DELTA)
 };
@@ -177,6 +188,13 @@ int lt_launch_rows_tiled(const lt_graph *g, const float *S, int64_t lds, int nco
                          const float *bias_after, int relu, float *out, int64_t ldo, float *seg_out,
                          int64_t ld_seg, hipStream_t st);
 // fp64 twin (S, out, seg_out double; chains from zero, + bias_after on short rows): the pre-activation of LT_MODE_DELTA
+int lt_launch_rows_tiled_xf64(const lt_graph *g, const float *X, int64_t ldx, int ncols, double *out, int64_t ldo,
+                              double *seg_out, int64_t ld_seg, const int32_t *state, hipStream_t st);
+// aggregate-first route active for this baseline right now?  lt_fp64_prepare_items: per probe chunk of an LT_MODE_DELTA call,
+// the fp64 pre-activation rows the chunk's items read (Z1d) and the probes' own fp64 product rows Spd[nb, Hp]
+bool lt_fp64_agg_active(const lt_baseline *b);
+int lt_fp64_prepare_items(const lt_baseline *b, const int32_t *off, int nb, const int2 *item_pr, const int32_t *probes,
+                          double *Spd, hipStream_t st);
 int lt_launch_rows_tiled_f64(const lt_graph *g, const double *S, int64_t lds, int ncols, const float *bias_after,
                              double *out, int64_t ldo, double *seg_out, int64_t ld_seg, hipStream_t st);
 int lt_launch_layer2(const lt_graph *g, const float *S2, int C, const float *b2, float *OUT,

@@ -2,8 +2,9 @@
 EdgeRand (``--perturb-type discrete``, reference worker.py:213-278) and LapGraph
 (``--perturb-type continuous``, reference worker.py:281-335).
 
-Host numpy, vectorised, consuming numpy's legacy global stream in the reference's draw order so a
-given ``--noise-seed`` yields the reference's graph (pinned by tests/golden/dp_adjacency.npz).
+The random draws are host numpy, consuming numpy's legacy global stream in the reference's draw order so a
+given ``--noise-seed`` yields the reference's graph (pinned by tests/golden/dp_adjacency.npz); LapGraph's
+O(N^2) add + top-k select run on the GPU when one is visible (``lt_lapgraph_select``, csrc/lt_dp.hip).
 """
 from __future__ import annotations
 
@@ -46,27 +47,67 @@ def perturb_adj_discrete(adj, epsilon, noise_seed):
     return noisy
 
 
-def perturb_adj_continuous(adj, epsilon, noise_seed, noise_type="laplace", delta=1e-5):
-    """LapGraph: Laplace(1/eps2) noise on the strict lower triangle, keep the top-(E + noise) cells,
-    symmetrise (worker.py:281-335).  eps is split 1 % / 99 % between the edge count and the cells.
-    The reference selects the top cells with a 50-way split + argpartition; the selected *set* is the
-    plain top-k (ties only among exact zeros, which are never reached), so one argpartition suffices."""
+def _lapgraph_inputs(adj, epsilon, noise_seed, noise_type, delta):
+    """The two seeded draws of worker.py:291-304 in the reference's order: the N x N cell noise, then the edge-count noise."""
     n = adj.shape[0]
     n_edges = len(adj.data) // 2
     eps_1 = epsilon * 0.01
     eps_2 = epsilon - eps_1
     noise = get_noise(noise_type, (n, n), noise_seed, eps=eps_2, delta=delta, sensitivity=1)
-    noise *= np.tri(n, n, k=-1, dtype=bool)
-    cells = np.asarray(sp.tril(adj, k=-1) + noise).ravel()
     n_keep = n_edges + int(get_noise(noise_type, 1, noise_seed, eps=eps_1, delta=delta, sensitivity=1)[0])
     print(f"edge number from {n_edges} to {n_keep}")
-    top = np.argpartition(cells, -n_keep)[-n_keep:]
+    return n, noise, n_keep
+
+
+def perturb_adj_continuous(adj, epsilon, noise_seed, noise_type="laplace", delta=1e-5, backend="auto"):
+    """LapGraph: Laplace(1/eps2) noise on the strict lower triangle, keep the top-(E + noise) cells,
+    symmetrise (worker.py:281-335).  eps is split 1 % / 99 % between the edge count and the cells.
+    The reference selects the top cells with a 50-way split + argpartition; the selected *set* is the
+    plain top-k (ties only among exact zeros, which are never reached).
+
+    backend: "hip" -- the noise (numpy's stream, drawn here) is uploaded and the add + top-k select run on the GPU
+    (lt_lapgraph_select); "host" -- numpy argpartition, as the reference; "auto" -- "hip" when a HIP device is visible.
+    Both give the same cells (tests/golden/dp_adjacency.npz)."""
+    if backend == "auto":
+        import torch
+        backend = "hip" if torch.cuda.is_available() else "host"
+    n, noise, n_keep = _lapgraph_inputs(adj, epsilon, noise_seed, noise_type, delta)
+    if backend == "hip":
+        top = _lapgraph_select_hip(adj, noise, n_keep)
+    elif backend == "host":
+        noise *= np.tri(n, n, k=-1, dtype=bool)
+        cells = np.asarray(sp.tril(adj, k=-1) + noise).ravel()
+        top = np.argpartition(cells, -n_keep)[-n_keep:]
+    else:
+        raise ValueError(f"backend = {backend!r}")
     mat = sp.csr_matrix((np.ones(n_keep, dtype=np.int32), (top // n, top % n)), shape=(n, n))
     return mat + mat.T
 
 
-def perturb_adj(adj, perturb_type, epsilon, noise_seed, noise_type="laplace", delta=1e-5):
+def _lapgraph_select_hip(adj, noise, n_keep):
+    """Flat indices of the n_keep largest cells of tril(adj, -1) + noise, selected on the device."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    _lib.require_gpu()
+    n = adj.shape[0]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    low = sp.csr_matrix(adj)
+    low.sort_indices()
+    rowptr = torch.from_numpy(low.indptr.astype(np.int32)).to(dev)
+    col = torch.from_numpy(low.indices.astype(np.int32)).to(dev)
+    cells = torch.from_numpy(np.ascontiguousarray(noise, dtype=np.float64)).to(dev)
+    out = torch.empty(n_keep, dtype=torch.int64, device=dev)
+    work = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    thr = C.c_double(0.0)
+    _lib.check(_lib.lib().lt_lapgraph_select(n, rowptr.data_ptr(), col.data_ptr(), cells.data_ptr(), int(n_keep), out.data_ptr(),
+                                             work.data_ptr(), work.numel(), C.byref(thr),
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "lt_lapgraph_select")
+    return out.cpu().numpy()
+
+
+def perturb_adj(adj, perturb_type, epsilon, noise_seed, noise_type="laplace", delta=1e-5, backend="auto"):
     """Dispatch of worker.py:206-210."""
     if perturb_type == "discrete":
         return perturb_adj_discrete(adj, epsilon, noise_seed)
-    return perturb_adj_continuous(adj, epsilon, noise_seed, noise_type, delta)
+    return perturb_adj_continuous(adj, epsilon, noise_seed, noise_type, delta, backend=backend)

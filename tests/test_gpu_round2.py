@@ -629,16 +629,19 @@ def test_tiled_fp64_preactivation_keeps_every_bit(gpu, hidden):
     n = a_hat.shape[0]
     x = synth.gaussian_features(n, 80, seed=2)
     w = synth.gcn_weights(80, hidden, 2, seed=3)
-    base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *_params(w, gpu))
-    rng = np.random.RandomState(2)
-    probes, obs = rng.choice(n, 60, replace=False), rng.choice(n, 200, replace=False)
-    rows = base.influence_rows(probes, obs, 1e-4, "delta").cpu().numpy()
-    _lib.set_tuning("tiled_min_bytes", 0)
+    _lib.set_tuning("aggregate_first", 0)      # (these shapes would take the aggregate-first route, which has no S1d SpMM)
     try:
+        base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *_params(w, gpu)).enable_fp64()
+        assert base.fp64_route() == 0
+        rng = np.random.RandomState(2)
+        probes, obs = rng.choice(n, 60, replace=False), rng.choice(n, 200, replace=False)
+        rows = base.influence_rows(probes, obs, 1e-4, "delta").cpu().numpy()
+        _lib.set_tuning("tiled_min_bytes", 0)
         base.refresh()
         tiled = base.influence_rows(probes, obs, 1e-4, "delta").cpu().numpy()
     finally:
         _lib.set_tuning("tiled_min_bytes", None)
+        _lib.set_tuning("aggregate_first", None)
     assert rows.max() > 0 and np.array_equal(rows, tiled)
 
 

@@ -196,3 +196,94 @@ def test_feature_difference_route_of_the_fp64_product(gpu):
     got_m = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
     refm = _oracle_matrix(a_hat, xm, w, probes[:6], observe, 1e-4, torch.float64)
     assert np.abs(got_m[:6] - refm).max() <= 1e-5 * refm.max()
+
+
+@pytest.mark.parametrize("f,h,c,hub", [(256, 256, 2, True), (64, 100, 3, True), (33, 24, 2, False), (130, 66, 7, True)])
+def test_aggregate_first_route_of_the_fp64_preactivation(gpu, f, h, c, hub):
+    """`delta` on dense features no wider than ~2 H (BASELINE configs[4]: F = H = 256): the pre-activation is formed as
+    (A_hat X)[r] W1 + b1 on the rows the call's probes reach, on demand (lt_fp64.hip "aggregate-first"; lt_baseline_fp64_route
+    == 2).  Against the fp64 oracle (1e-5 of the largest score) and the S1d route (fp64 summation order only: fp32
+    rounding of the result); rows stay valid across calls and chunks, a refresh invalidates them, hub rows go through the
+    segment sums, widths that need padding and unaligned feature rows (F = 33) included."""
+    from test_gpu_parity import _hub_graph, _oracle_matrix
+    from linkteller_amd import _lib, engine, graph, synth
+    n = 1300
+    adj = _hub_graph(n, 6000, 700, seed=f) if hub else synth.erdos_renyi_graph(n, 4000, seed=f)
+    a_hat = graph.first_order_gcn(adj)
+    x = synth.gaussian_features(n, f, seed=1)
+    w = synth.gcn_weights(f, h, c, seed=2)
+    hg = graph.HipGraph(a_hat)
+    xt = torch.from_numpy(x).to(gpu)
+    base = engine.Baseline(hg, xt, *_params(w, gpu)).enable_fp64()
+    assert base.fp64_route() == 2
+    rng = np.random.RandomState(3)
+    probes = np.concatenate([[0], rng.choice(np.arange(1, n), 47, replace=False)])      # node 0 is the hub
+    observe = np.concatenate([[0], rng.choice(np.arange(1, n), 150, replace=False)])
+    ref64 = _oracle_matrix(a_hat, x, w, probes, observe, 1e-4, torch.float64)
+    got = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
+    assert np.abs(got - ref64).max() <= 1e-5 * ref64.max()
+    assert np.all(got[ref64 == 0] == 0)
+    # a second call with other probes reuses the rows that are valid and adds the missing ones; then everything again in
+    # chunks of a few probes: same bits as the one-chunk call
+    probes2 = np.concatenate([probes[10:30], rng.choice(n, 30, replace=False)])
+    got2 = base.influence_rows(probes2, observe, 1e-4, "delta").cpu().numpy()
+    _lib.set_tuning("chunk_budget_bytes", 40 * 1024)
+    try:
+        base.refresh()
+        chunked = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
+        chunked2 = base.influence_rows(probes2, observe, 1e-4, "delta").cpu().numpy()
+    finally:
+        _lib.set_tuning("chunk_budget_bytes", None)
+    assert np.array_equal(chunked, got) and np.array_equal(chunked2, got2)
+    ref2 = _oracle_matrix(a_hat, x, w, probes2[:8], observe, 1e-4, torch.float64)
+    assert np.abs(got2[:8] - ref2).max() <= 1e-5 * ref2.max()
+    # the S1d route on the same inputs
+    _lib.set_tuning("aggregate_first", 0)
+    try:
+        base.refresh()
+        assert base.fp64_route() == 0
+        s1d = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
+    finally:
+        _lib.set_tuning("aggregate_first", None)
+    assert np.abs(s1d - ref64).max() <= 1e-5 * ref64.max()
+    assert np.abs(s1d - got).max() <= 1e-6 * ref64.max()
+    # in-place weight update + refresh: the stale rows are recomputed
+    base.w1.mul_(1.02)
+    base.refresh()
+    w2 = dict(w, W1=base.w1.cpu().numpy())
+    ref3 = _oracle_matrix(a_hat, x, w2, probes[:8], observe, 1e-4, torch.float64)
+    got3 = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
+    assert np.abs(got3[:8] - ref3).max() <= 1e-5 * ref3.max()
+    # `full` / `sparse` are untouched by the route
+    assert np.array_equal(base.influence_rows(probes, observe, 1e-4, "full").cpu().numpy(),
+                          base.influence_rows(probes, observe, 1e-4, "sparse").cpu().numpy())
+
+
+def test_lapgraph_topk_on_the_device(gpu, capsys):
+    """LapGraph's N x N add + top-k select on the GPU (lt_lapgraph_select; the Laplace draws stay numpy's
+    for stream compatibility).  Bit-exact against the reference's own perturbed graphs (tests/golden/dp_adjacency.npz,
+    eps 5 and 1) and against the host route; at the BASELINE configs[3] size (twitch-RU shape, eps = 5) the two routes
+    give the same CSR and the timings are printed."""
+    import time
+    import scipy.sparse as sp
+    from linkteller_amd import dp, synth
+    g = load_golden("dp_adjacency.npz")
+    a = csr_from(g, "adj")
+    for eps in (5.0, 1.0):
+        res = sp.csr_matrix(dp.perturb_adj(sp.csr_matrix(a), "continuous", eps, 42, backend="hip"))
+        res.sort_indices()
+        tag = f"continuous.eps{eps:g}"
+        assert np.array_equal(res.indptr, g[f"{tag}.indptr"]), tag
+        assert np.array_equal(res.indices, g[f"{tag}.indices"]), tag
+        assert np.array_equal(np.asarray(res.data, dtype=np.float64), g[f"{tag}.data"]), tag
+    adj, _, _ = synth.twitch_like_problem("twitch-RU", hidden=256, n_classes=2, seed=0)
+    out = {}
+    for backend in ("hip", "host", "hip"):
+        t0 = time.time()
+        r = sp.csr_matrix(dp.perturb_adj(adj, "continuous", 5.0, 42, backend=backend))
+        out[backend] = (r, time.time() - t0)
+        r.sort_indices()
+    assert (out["hip"][0] != out["host"][0]).nnz == 0 and np.array_equal(out["hip"][0].indices, out["host"][0].indices)
+    with capsys.disabled():
+        print(f"\nLapGraph N={adj.shape[0]} eps=5: device select {out['hip'][1]:.2f} s, host argpartition {out['host'][1]:.2f} s "
+              f"(both include the 0.2-0.3 s numpy Laplace draw of N^2 cells)")
