@@ -372,7 +372,7 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     int *mj = lj + wid * FD_CAP;
     int cnt = 0;                                    // wave-uniform
     const unsigned long long lt = (1ull << lane) - 1ull;
-    constexpr int STEP = 64 * VEC, UN = 8;
+    constexpr int STEP = 64 * VEC, UN = 16;   // F = 3170: the row in two trips of 16 loads per lane
     for (int j0 = 0; j0 < F; j0 += STEP * UN) {
         float x[UN][VEC];
 #pragma unroll
@@ -413,11 +413,12 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     const bool vec_ok = (H % 4 == 0) && c0 + 3 < H;
     int e = 0;
-    for (; e + 4 <= cnt; e += 4) {
-        f32x4 w[4];
-        double d[4];
+    constexpr int PU = 8;                     // W1 rows in flight per lane (L2-resident: a trip costs one L2 latency)
+    for (; e + PU <= cnt; e += PU) {
+        f32x4 w[PU];
+        double d[PU];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < PU; ++k) {
             const int j = mj[e + k];
             d[k] = mv[e + k];
             if (vec_ok) w[k] = ld4(W1 + (size_t)j * H + c0);
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
                 for (int t = 0; t < 4; ++t) w[k][t] = c0 + t < H ? W1[(size_t)j * H + c0 + t] : 0.f;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < PU; ++k)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = fma(d[k], (double)w[k][t], acc[t]);
     }

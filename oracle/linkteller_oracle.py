@@ -165,6 +165,41 @@ def influence_matrix(features, adj, params, test_nodes, influence, forward=gcn_f
     return influence_val
 
 
+class RestrictedOracle:
+    """The SAME fp64 quantity as ``influence_matrix`` for graphs where two full forwards per probe take minutes (R-MAT
+    scale 21: 26 s each on 256 host threads): the baseline forward once, and per probe only the rows that can differ
+    from it -- X' differs from X in row v (attacker.py:101-105), so S1' differs in row v, Z1' on R_v = {r : A[r, v] != 0}
+    and the logits on the rows reading a member of R_v; everything else cancels EXACTLY in attacker.py:106's difference.
+    Restated from the reference's algebra (not its op sequence); pinned against ``influence_matrix`` -- the verbatim
+    restatement, itself pinned to the reference -- in tests/test_oracle_golden.py (agreement to ~1e-12 of the scores:
+    fp64 reassociation), and against two verbatim probe rows wherever a GPU test uses it."""
+
+    def __init__(self, x, a_hat, params):
+        # the served adjacency is a FloatTensor in the reference (utils/load.py:552-559) whatever precision the model runs in
+        self.a = sp.csr_matrix(a_hat).astype(np.float32).astype(np.float64)
+        self.at = self.a.T.tocsr()                               # row v of a^T = column v of a: R_v and A[r, v]
+        self.x = np.asarray(x, dtype=np.float64)
+        self.p = {k: np.asarray(v, dtype=np.float64) for k, v in params.items()}
+        self.s1 = self.x @ self.p["W1"]
+        self.z1 = self.a @ self.s1 + self.p["b1"]
+        self.h1 = np.maximum(self.z1, 0.0)
+
+    def rows(self, probes, observe, influence):
+        observe = np.asarray(observe, dtype=np.int64)
+        a_obs = self.a[observe]                                  # [n_obs, n]
+        out = np.zeros((len(probes), len(observe)))
+        for i, v in enumerate(np.asarray(probes, dtype=np.int64)):
+            xv = self.x[v] + self.x[v] * influence               # attacker.py:103,105 (two roundings, in fp64 here)
+            ds1 = xv @ self.p["W1"] - self.s1[v]
+            col = self.at[v]
+            r, arv = col.indices, col.data
+            h1p = np.maximum(self.z1[r] + arv[:, None] * ds1[None, :], 0.0)
+            ds2 = (h1p - self.h1[r]) @ self.p["W2"]              # [|R_v|, C]
+            dout = a_obs[:, r] @ ds2                             # [n_obs, C]
+            out[i] = np.linalg.norm(dout / influence, axis=1)
+        return out
+
+
 def pair_scores(influence_val, test_nodes, exist_edges, nonexist_edges):
     """attacker.py:233-245: score of (u, v) is influence_val[ind[v]][ind[u]] (perturb v, observe u)."""
     node2ind = {node: i for i, node in enumerate(test_nodes)}

@@ -166,3 +166,21 @@ def test_next_rows_baseline_balanced_gcn3():
     infl64 = O.influence_matrix(x.double(), adj.double(), {k: v.double() for k, v in P3.items()}, nodes3, 1e-4,
                                 forward=O.gcn3_forward)
     assert np.array_equal(infl64, g["gcn3.ref64.influence_val"])
+
+
+@pytest.mark.parametrize("key", ["er300", "pl600", "lap600"])
+def test_restricted_oracle_equals_the_verbatim_one(key):
+    """oracle.RestrictedOracle (baseline once + only the rows a probe can change; used where two full fp64 forwards per
+    probe take minutes) gives the quantity of the verbatim restatement -- here against the REFERENCE's own fp64 matrices."""
+    from conftest import csr_from, golden_args, load_golden
+    from oracle import linkteller_oracle as O
+    g = load_golden("influence.npz")
+    args = golden_args(g, key)
+    served = csr_from(g, f"{key}.served") if f"{key}.served.n" in g else csr_from(g, f"{key}.adj")
+    a_hat = O.NORMALIZERS[args["norm"]](served)
+    P = {k: g[f"{key}.sd.{n}"] for k, n in (("W1", "gc1.weight"), ("b1", "gc1.bias"), ("W2", "gc2.weight"), ("b2", "gc2.bias"))}
+    nodes = g[f"{key}.ref64.test_nodes"] if f"{key}.ref64.test_nodes" in g else g[f"{key}.ref32.test_nodes"]
+    ref64 = g[f"{key}.ref64.influence_val"]
+    got = O.RestrictedOracle(g[f"{key}.x"], a_hat, P).rows(nodes, nodes, args["influence"])
+    assert np.abs(got - ref64).max() <= 1e-9 * ref64.max()
+    assert np.array_equal(got == 0, ref64 == 0)
