@@ -45,13 +45,15 @@ FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 matrix peak
 FP64_MFMA_PEAK_TFLOPS = 78.6
 
 # kernel name (prefix) -> profile class, for the PMC passes
-KERNEL_CLASS = (("k_s1d_feature_rows", "fp64_product"), ("k_gemm_f64acc", "fp64_product"), ("k_sum_slabs_f64", "fp64_product"),
-                ("k_spmm_f64", "fp64_spmm"), ("k_rows_tiled_f64", "fp64_spmm"),
+KERNEL_CLASS = (("k_s1d_feature_rows", "fp64_product"), ("k_ref_row_product", "fp64_product"), ("k_gemm_f64", "fp64_product"),
+                ("k_sum_slabs_f64", "fp64_product"), ("k_spmm_f64", "fp64_spmm"), ("k_rows_tiled_f64", "fp64_spmm"),
+                ("k_rows_tiled_xf64", "fp64_spmm"), ("k_z_mark", "fp64_spmm"), ("k_y_long", "fp64_spmm"),
                 ("k_item_bits", "item_bits"), ("k_pm_", "item_bits"), ("k_item_stageA", "item_stageA"),
                 ("k_item_stageB", "item_stageB"), ("k_full_stageA", "full_stageA"), ("k_full_long_combine", "full_stageA"),
                 ("k_full_stageB", "full_stageB"), ("k_gemm_f32_mfma", "gemm"), ("k_sum_slabs", "gemm"),
                 ("k_rows_tiled", "spmm"), ("k_spmm_long_combine", "spmm"), ("k_spmm_rows", "spmm"), ("k_spmm_seg", "spmm"))
-PRIMARY = {"fp64_product": ("k_s1d_feature_rows", "k_gemm_f64acc_128", "k_gemm_f64acc"), "fp64_spmm": ("k_spmm_f64<", "k_rows_tiled_f64"),
+PRIMARY = {"fp64_product": ("k_s1d_feature_rows", "k_gemm_f64acc_128", "k_gemm_f64acc", "k_gemm_f64_rows<double>"),
+           "fp64_spmm": ("k_spmm_f64<", "k_rows_tiled_f64", "k_rows_tiled_xf64"),
            "item_bits": ("k_item_bits",), "item_stageA": ("k_item_stageA",), "item_stageB": ("k_item_stageB<",),
            "full_stageA": ("k_full_stageA_lds<2, 32, 0>", "k_full_stageA_lds", "k_full_stageA"), "full_stageB": ("k_full_stageB",),
            "gemm": ("k_gemm_f32_mfma_128",), "spmm": ("k_rows_tiled<", "k_spmm_rows")}
@@ -476,7 +478,7 @@ def main():
                     "avg_launch_us": us, "units_per_launch": f"per step: X[{rows_x}x{f}] * W1[{f}x{h}] and X'[{n_probe_local} probes] * W1, exact fp32 MFMA"}
         if cls == "fp64_product" and fp64_route == 1:
             alg = n * f * 4 + f * h * 4 + n * hp * 8
-            return {"kernel": "k_s1d_feature_rows (+ the reference row's product; the gated matrix-core product behind it returns at once)",
+            return {"kernel": "k_s1d_feature_rows (+ k_ref_row_product: the reference row's own product)",
                     "bound": "hbm", "achieved": round(alg / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(alg / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": tr, "algorithmic_bytes_per_launch": int(alg), "avg_launch_us": us,
                     "units_per_launch": f"one pass over X[{n}x{f}] fp32 -> S1d = X*W1 [{n}x{h}] fp64 (feature rows as differences to a reference row); "
@@ -681,6 +683,7 @@ def main():
                                    "produces: utils/load.py:53-59 + StandardScaler)",
                        "mode": a.mode, "probes_per_rank": n_probe_local, "baseline_XW1": shard_note,
                        "fp64_product_route": {1: "feature rows as differences to a reference row (k_s1d_feature_rows)",
+                                              2: "aggregate-first on the rows the probes reach (k_rows_tiled_xf64 + k_gemm_f64_rows)",
                                               0: "f64 matrix cores (k_gemm_f64acc_128)", -1: "not used"}[fp64_route],
                        "collective_bytes_per_step": coll,
                        "step": "baseline forward of the mode + all probes + norms" + (" + all-gather" if world > 1 else "")},

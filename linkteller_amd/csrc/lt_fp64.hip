@@ -26,8 +26,7 @@ typedef float f32x4u_ __attribute__((ext_vector_type(4), aligned(4)));
 __global__ __launch_bounds__(256) void k_gemm_f64acc(const float *__restrict__ A, long lda,
                                                      const float *__restrict__ B, long ldb,
                                                      double *__restrict__ C, long ldc, int M, int N, int K,
-                                                     int kslice, long slab_stride, const int *__restrict__ gate) {
-    if (gate && *gate == 0) return;   // the feature-difference product served every row: nothing to do (see k_s1d_feature_rows)
+                                                     int kslice, long slab_stride) {
     __shared__ __attribute__((aligned(16))) float As[2][GD_BM * GD_LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][GD_BK * GD_LDB];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -126,8 +125,7 @@ __global__ __launch_bounds__(256) void k_gemm_f64acc(const float *__restrict__ A
 __global__ __launch_bounds__(256, 2) void k_gemm_f64acc_128(const float *__restrict__ A, long lda,
                                                          const float *__restrict__ B, long ldb,
                                                          double *__restrict__ C, long ldc, int M, int N, int K,
-                                                         int kslice, long slab_stride, const int *__restrict__ gate) {
-    if (gate && *gate == 0) return;
+                                                         int kslice, long slab_stride) {
     __shared__ __attribute__((aligned(16))) float As[2][GE_BM * GE_LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][GE_BK * GE_LDB];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -258,8 +256,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64acc_128(const float *__restr
 }
 
 __global__ void k_sum_slabs_f64(const double *__restrict__ slabs, long slab_stride, int splits, long total,
-                                int N, double *__restrict__ C, long ldc, const int *__restrict__ gate) {
-    if (gate && *gate == 0) return;
+                                int N, double *__restrict__ C, long ldc) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     double acc = slabs[i];
@@ -302,7 +299,20 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
         e1 = rowptr[r + 1];
         if (seg_blocks > 0 && e1 - e > LT_ROW_SEG) return;
     }
-    for (; e + 4 <= e1; e += 4) {   // four gathers in flight; the fma chain stays in entry order
+    for (; e + 8 <= e1; e += 8) {   // eight gathers in flight (a trip costs one L2 / Infinity-Cache latency); entry order kept
+        double a[8];
+        f64x4 s[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a[j] = (double)val[e + j];
+            s[j] = *reinterpret_cast<const f64x4 *>(S + (size_t)col[e + j] * ld + coff);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = fma(a[j], s[j][k], acc[k]);
+    }
+    for (; e + 4 <= e1; e += 4) {
         double a[4];
         f64x4 s[4];
 #pragma unroll
@@ -345,18 +355,20 @@ __global__ void k_spmm_f64_long(int n_long, const int32_t *__restrict__ long_row
 // dense sum holds; only the order of an fp64 summation changes).  It pays when rows differ from the reference row in few
 // columns -- which is how the reference's own twitch features look: utils/load.py:53-59 builds 0/1 indicator rows
 // (a few dozen of 3170 set) and worker.py standardises them per column, so every column holds TWO values and a row
-// differs from any other in ~ 2 x (features set) places.  Then the fp64 product is one pass over X (HBM-bound: N*F*4
-// bytes) and ~ 40 W1 rows per node instead of 2*N*F*H flops on the f64 matrix cores (twitch-RU: 7.1 GFLOP -> 0.1).
+// differs from any other in ~ 2 x (features set) places.  Then the fp64 product is one pass over X (N*F*4 bytes) and
+// ~ 40 W1 rows per node instead of 2*N*F*H flops on the f64 matrix cores (twitch-RU: 7.1 GFLOP -> 0.1).
 // One wave per row: the lanes compare their pieces of the row with the reference row (staged in LDS), the differing
-// columns are compacted into a per-wave LDS list (ballot + prefix), then every lane walks the list for its 4 hidden
-// columns.  A row with more than FD_CAP differing columns (dense features: Gaussian, embeddings) raises `gate` and the
-// matrix-core product, launched behind this kernel, runs instead (it returns at once while `gate` is 0).
+// columns are compacted into a per-wave LDS list (ballot + prefix) and every lane walks the list for its 4 hidden
+// columns (a full list is walked and emptied, so ANY row is served correctly, a dense one just slowly).  A row with more
+// than `hint_cap` differing columns (dense features: Gaussian, embeddings) sets *dense_hint -- a word of mapped host
+// memory the host looks at before the NEXT refresh to move the baseline to the matrix-core product for good.
 #define FD_CAP 384
 #define FD_WAVES 4
+#define FD_PU 8          // W1 rows in flight per lane while a list is walked (FD_CAP is a multiple)
 template <int VEC>   // floats per lane and load: 2 when the rows of X are 8-byte aligned, else 1
 __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     int n, int F, int H, int Hp, const float *__restrict__ X, long ldx, int ref, const float *__restrict__ W1,
-    const double *__restrict__ cref, double *__restrict__ S1d, int *__restrict__ gate) {
+    const double *__restrict__ cref, double *__restrict__ S1d, int hint_cap, int *__restrict__ dense_hint) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fd_smem[];
     float *sref = reinterpret_cast<float *>(fd_smem);                              // [Fp] the reference row
     const int Fp = (F + 1) & ~1;
@@ -370,9 +382,37 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     const float *xr = X + (long)i * ldx;
     double *mv = ldv + wid * FD_CAP;
     int *mj = lj + wid * FD_CAP;
-    int cnt = 0;                                    // wave-uniform
+    const int c0 = 4 * lane;
+    const bool own = c0 < Hp;                       // this lane holds 4 hidden columns
+    const bool vec_ok = (H % 4 == 0) && c0 + 3 < H;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    int cnt = 0, total = 0;                         // wave-uniform: entries in the list / differing columns so far
+    // walk the list (entries 0 .. cnt, padded with zero terms to a multiple of FD_PU) and empty it
+    auto flush = [&]() {
+        const int padded = (cnt + FD_PU - 1) / FD_PU * FD_PU;
+        if (lane < padded - cnt) { mj[cnt + lane] = 0; mv[cnt + lane] = 0.0; }      // (d = 0: the term adds exactly nothing)
+        if (own)
+            for (int e = 0; e < padded; e += FD_PU) {
+                f32x4 w[FD_PU];
+                double d[FD_PU];
+#pragma unroll
+                for (int k = 0; k < FD_PU; ++k) {
+                    const int j = mj[e + k];
+                    d[k] = mv[e + k];
+                    if (vec_ok) w[k] = ld4(W1 + (size_t)j * H + c0);
+                    else
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) w[k][t] = c0 + t < H ? W1[(size_t)j * H + c0 + t] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < FD_PU; ++k)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = fma(d[k], (double)w[k][t], acc[t]);
+            }
+        cnt = 0;
+    };
     const unsigned long long lt = (1ull << lane) - 1ull;
-    constexpr int STEP = 64 * VEC, UN = 16;   // F = 3170: the row in two trips of 16 loads per lane
+    constexpr int STEP = 64 * VEC, UN = 16;         // F = 3170: the row in two trips of 16 loads per lane
     for (int j0 = 0; j0 < F; j0 += STEP * UN) {
         float x[UN][VEC];
 #pragma unroll
@@ -396,50 +436,18 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
                 const bool diff = j < F && x[u][v] != r;
                 const unsigned long long m = __ballot(diff);
                 if (m) {
-                    const int pos = cnt + __popcll(m & lt);
-                    if (diff && pos < FD_CAP) { mj[pos] = j; mv[pos] = (double)x[u][v] - (double)r; }
-                    cnt += __popcll(m);
+                    if (cnt + 64 > FD_CAP) flush();                  // (wave-uniform)
+                    if (diff) { const int pos = cnt + __popcll(m & lt); mj[pos] = j; mv[pos] = (double)x[u][v] - (double)r; }
+                    const int c = __popcll(m);
+                    cnt += c;
+                    total += c;
                 }
             }
         }
-        if (cnt > FD_CAP) {                          // not a sparse-difference row: the matrix cores take the product
-            if (lane == 0) *gate = 1;
-            return;
-        }
     }
-    // (LDS writes of this wave's list are visible to its own lanes after the waitcnt the compiler puts before the reads)
-    const int c0 = 4 * lane;
-    if (c0 >= Hp) return;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    const bool vec_ok = (H % 4 == 0) && c0 + 3 < H;
-    int e = 0;
-    constexpr int PU = 8;                     // W1 rows in flight per lane (L2-resident: a trip costs one L2 latency)
-    for (; e + PU <= cnt; e += PU) {
-        f32x4 w[PU];
-        double d[PU];
-#pragma unroll
-        for (int k = 0; k < PU; ++k) {
-            const int j = mj[e + k];
-            d[k] = mv[e + k];
-            if (vec_ok) w[k] = ld4(W1 + (size_t)j * H + c0);
-            else
-#pragma unroll
-                for (int t = 0; t < 4; ++t) w[k][t] = c0 + t < H ? W1[(size_t)j * H + c0 + t] : 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < PU; ++k)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = fma(d[k], (double)w[k][t], acc[t]);
-    }
-    for (; e < cnt; ++e) {
-        const int j = mj[e];
-        const double d = mv[e];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float w = c0 + t < H ? W1[(size_t)j * H + c0 + t] : 0.f;
-            acc[t] = fma(d, (double)w, acc[t]);
-        }
-    }
+    flush();
+    if (total > hint_cap && lane == 0) *dense_hint = 1;
+    if (!own) return;
     f64x4 o;
 #pragma unroll
     for (int t = 0; t < 4; ++t) o[t] = c0 + t < H ? cref[c0 + t] + acc[t] : 0.0;
@@ -448,6 +456,36 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
 static size_t fd_smem_bytes(int F) {
     const size_t Fp = (size_t)((F + 1) & ~1);
     return ((Fp * 4 + 15) & ~(size_t)15) + (size_t)FD_WAVES * FD_CAP * (sizeof(double) + sizeof(int));
+}
+// rows with more differing columns than this are "dense" for the route decision: the list walk costs ~ cnt * H fp64 FMAs and
+// cnt row gathers per node, the matrix cores F * H at ~10 x the rate
+static int fd_hint_cap(int F) { const int c = F / 16; return c < 8 ? 8 : (c > FD_CAP ? FD_CAP : c); }
+
+// The reference row's own product cref[0..H) = X[ref, :] * W1 in fp64, one launch: block z sums its 64-deep K slice for
+// every column, the block that finishes last adds the slices in slice order (a fixed order whoever comes last).
+__global__ __launch_bounds__(256) void k_ref_row_product(int F, int H, int Hp, const float *__restrict__ xref,
+                                                         const float *__restrict__ W1, double *__restrict__ slabs,
+                                                         double *__restrict__ cref, unsigned *__restrict__ counter) {
+    __shared__ unsigned s_last;
+    const int k0 = blockIdx.x * 64, k1 = min(F, k0 + 64);
+    for (int c = threadIdx.x; c < H; c += 256) {
+        double a = 0.0;
+        for (int k = k0; k < k1; ++k) a = fma((double)xref[k], (double)W1[(size_t)k * H + c], a);
+        slabs[(size_t)blockIdx.x * H + c] = a;
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    for (int c = threadIdx.x; c < Hp; c += 256) {
+        double a = 0.0;
+        if (c < H)
+            for (unsigned z = 0; z < gridDim.x; ++z) a += __builtin_nontemporal_load(slabs + (size_t)z * H + c);
+        cref[c] = a;
+    }
+    if (threadIdx.x == 0) *counter = 0;              // ready for the next launch
 }
 
 // K slice of the fp64 product (64x64 tiles, 4 waves, 8 workgroups per CU): the fewest slices (at least 400 deep) whose
@@ -481,9 +519,8 @@ static int fp64_kslice(int n, int H, int F) {
     return best > 0 ? best : 16;
 }
 
-// The dense product S1d = X*W1 on the f64 matrix cores (rows [r0, r1) into dst[(r1 - r0), ldd]); `gate` != NULL: the
-// kernels return at once while *gate == 0 (the feature-difference product has served every row).
-static int launch_dense_s1d(lt_baseline *b, int r0, int r1, double *dst, long ldd_out, const int *gate, hipStream_t st) {
+// The dense product S1d = X*W1 on the f64 matrix cores: rows [r0, r1) into dst[(r1 - r0), ldd].
+static int launch_dense_s1d(lt_baseline *b, int r0, int r1, double *dst, long ldd_out, hipStream_t st) {
     const int H = b->H, n = b->n, F = b->F, m = r1 - r0;
     if (m <= 0) return LT_OK;
     // the K slicing is that of the FULL product whatever the row range: a row has the same bits whichever rank computed it
@@ -497,15 +534,15 @@ static int launch_dense_s1d(lt_baseline *b, int r0, int r1, double *dst, long ld
     const float *A = b->X + (size_t)r0 * b->ldx;
     if (big)
         hipLaunchKernelGGL(k_gemm_f64acc_128, grid, dim3(256), 0, st, A, (long)b->ldx, b->W1, (long)H, out, ldd, m, H, F,
-                           splits > 1 ? kslice : (F > 0 ? F : 1), stride, gate);
+                           splits > 1 ? kslice : (F > 0 ? F : 1), stride);
     else
         hipLaunchKernelGGL(k_gemm_f64acc, grid, dim3(256), 0, st, A, (long)b->ldx, b->W1, (long)H, out, ldd, m, H, F,
-                           splits > 1 ? kslice : (F > 0 ? F : 1), stride, gate);
+                           splits > 1 ? kslice : (F > 0 ? F : 1), stride);
     LT_CHECK_LAUNCH();
     if (splits > 1) {
         const long tot = (long)m * H;
         hipLaunchKernelGGL(k_sum_slabs_f64, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, b->slabs_d,
-                           tot, splits, tot, H, dst, ldd_out, gate);
+                           tot, splits, tot, H, dst, ldd_out);
         LT_CHECK_LAUNCH();
     }
     return LT_OK;
@@ -661,41 +698,30 @@ int lt_fp64_prepare_items(const lt_baseline *b, const int32_t *off, int nb, cons
     return LT_OK;
 }
 
-// Whether this refresh tries the feature-difference product (k_s1d_feature_rows): the "feature_delta" knob, else what
-// the probe of lt_baseline_enable_fp64 found (feat_sparse: -1 unknown = try, the gated matrix-core product stands behind it).
-static bool want_feature_rows(const lt_baseline *b) {
-    if (!b->fd_cref || b->n < 2) return false;
+// Whether this refresh takes the feature-difference product (k_s1d_feature_rows): the "feature_delta" knob, else what the
+// probe of lt_baseline_enable_fp64 found -- corrected by the hint word the kernel sets when it meets dense rows (the
+// refresh that met them was still served correctly by the kernel, only slowly; from the next one on the matrix cores run).
+static bool want_feature_rows(const lt_baseline *cb) {
+    lt_baseline *b = const_cast<lt_baseline *>(cb);
+    if (!b->fd_cref || !b->S1d || b->n < 2) return false;
+    if (b->fd_hint_host && *(volatile int *)b->fd_hint_host != 0) b->feat_sparse = 0;
     const int knob = lt_tune().feature_delta;
     return knob == 0 ? false : (knob > 0 ? true : b->feat_sparse != 0);
 }
 
-static int launch_feature_s1d(lt_baseline *b, hipStream_t st) {
-    const int Hp = b->Hp, H = b->H, n = b->n, F = b->F;
-    LT_HIP(hipMemsetAsync(b->fd_gate, 0, sizeof(int), st));
-    // the reference row's own product on the matrix cores (M = 1, K-sliced, ordered slab sum): cref[Hp]
-    {
-        const int ks = 64, splits = (F + ks - 1) / ks;
-        dim3 grid(1, (H + GD_BN - 1) / GD_BN, splits);
-        if (splits > 1) {
-            hipLaunchKernelGGL(k_gemm_f64acc, grid, dim3(256), 0, st, b->X, (long)b->ldx, b->W1, (long)H, b->fd_slabs, (long)H, 1, H, F,
-                               ks, (long)H, (const int *)nullptr);
-            LT_CHECK_LAUNCH();
-            hipLaunchKernelGGL(k_sum_slabs_f64, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, st, b->fd_slabs, (long)H, splits,
-                               (long)H, H, b->fd_cref, (long)Hp, (const int *)nullptr);
-        } else {
-            hipLaunchKernelGGL(k_gemm_f64acc, grid, dim3(256), 0, st, b->X, (long)b->ldx, b->W1, (long)H, b->fd_cref, (long)Hp, 1, H, F,
-                               F, 0L, (const int *)nullptr);
-        }
-        LT_CHECK_LAUNCH();
-    }
+static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1) {
+    const int Hp = b->Hp, H = b->H, n = n_rows < 0 ? b->n : n_rows, F = b->F;
+    hipLaunchKernelGGL(k_ref_row_product, dim3((unsigned)((F + 63) / 64)), dim3(256), 0, st, F, H, Hp, b->X, b->W1, b->fd_slabs,
+                       b->fd_cref, (unsigned *)b->fd_gate);
+    LT_CHECK_LAUNCH();
     const unsigned blocks = (unsigned)((n + FD_WAVES - 1) / FD_WAVES);
     const size_t smem = fd_smem_bytes(F);
     if (b->ldx % 2 == 0 && ((uintptr_t)b->X % 8) == 0)
         hipLaunchKernelGGL((k_s1d_feature_rows<2>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx, 0,
-                           b->W1, b->fd_cref, b->S1d, b->fd_gate);
+                           b->W1, b->fd_cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev);
     else
         hipLaunchKernelGGL((k_s1d_feature_rows<1>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx, 0,
-                           b->W1, b->fd_cref, b->S1d, b->fd_gate);
+                           b->W1, b->fd_cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev);
     LT_CHECK_LAUNCH();
     return LT_OK;
 }
@@ -715,16 +741,11 @@ static int compute_z1d(lt_baseline *b, hipStream_t st) {
     if (b->S1d_external) {
         // multi-GPU: S1d arrives by the caller's all-gather of the ranks' row shards (lt_baseline_refresh_rows_fp64)
     } else if (want_feature_rows(b)) {
-        // (pad columns: the feature kernel writes zeros for the rows it serves, the dense kernels never touch them)
-        if (Hp != H) LT_HIP(hipMemsetAsync(b->S1d, 0, (size_t)n * Hp * sizeof(double), st));
-        int rc = launch_feature_s1d(b, st);
-        if (rc) return rc;
-        // the matrix-core product behind it: every workgroup returns at once unless a row raised the gate
-        rc = launch_dense_s1d(b, 0, n, b->S1d, (long)Hp, b->fd_gate, st);
+        int rc = launch_feature_s1d(b, st);          // (writes the pad columns of S1d as zeros itself)
         if (rc) return rc;
     } else {
         if (Hp != H) LT_HIP(hipMemsetAsync(b->S1d, 0, (size_t)n * Hp * sizeof(double), st));
-        int rc = launch_dense_s1d(b, 0, n, b->S1d, (long)Hp, nullptr, st);
+        int rc = launch_dense_s1d(b, 0, n, b->S1d, (long)Hp, st);
         if (rc) return rc;
     } }
     lt_prof_scope prof_(LT_K_FP64_SPMM, st);
@@ -777,27 +798,38 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     // knobs may then switch at any time); large ones only the chosen set.
     const bool fd_possible = b->n >= 2 && fd_smem_bytes(b->F) <= (size_t)60 * 1024 && lt_tune().feature_delta != 0;
     int feat = -1;
+    int *hint_host = nullptr, *hint_dev = nullptr;
     if (fd_possible) {
-        // probe (this call allocates, so it may synchronise): does any row differ from the reference row in more than
-        // FD_CAP columns?  Temporary buffers: the real ones are allocated once the route is known.
+        // the word k_s1d_feature_rows sets when it meets dense rows: mapped host memory, read by want_feature_rows()
+        if (hipHostMalloc((void **)&hint_host, sizeof(int), hipHostMallocMapped) == hipSuccess) {
+            *hint_host = 0;
+            if (hipHostGetDevicePointer((void **)&hint_dev, hint_host, 0) != hipSuccess) { (void)hipHostFree(hint_host); hint_host = nullptr; }
+        }
+        (void)hipGetLastError();
+    }
+    if (fd_possible && hint_host) {
+        // probe (this call allocates, so it may synchronise): do the first rows differ from the reference row in few columns?
+        // Temporary buffers: the real ones are allocated once the route is known.
+        const int n_probe = b->n < 4096 ? b->n : 4096;
         double *cref = nullptr, *fslabs = nullptr, *s1d = nullptr;
         int *gate = nullptr;
         hipError_t e = hipMalloc((void **)&cref, (size_t)b->Hp * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&fslabs, (size_t)((b->F + 63) / 64) * b->H * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&gate, sizeof(int));
-        if (e == hipSuccess) e = hipMalloc((void **)&s1d, nh);
+        if (e == hipSuccess) e = hipMemsetAsync(gate, 0, sizeof(int), st);
+        if (e == hipSuccess) e = hipMalloc((void **)&s1d, (size_t)n_probe * b->Hp * sizeof(double));
         if (e == hipSuccess) {
             b->fd_cref = cref; b->fd_slabs = fslabs; b->fd_gate = gate; b->S1d = s1d;
-            int rc = launch_feature_s1d(b, st);
-            int g = 1;
-            if (rc == LT_OK && hipMemcpyAsync(&g, gate, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
-                hipStreamSynchronize(st) == hipSuccess)
-                feat = g == 0 ? 1 : 0;
+            b->fd_hint_host = hint_host; b->fd_hint_dev = hint_dev;
+            const int rc = launch_feature_s1d(b, st, n_probe);
+            if (rc == LT_OK && hipStreamSynchronize(st) == hipSuccess) feat = *(volatile int *)hint_host == 0 ? 1 : 0;
             b->fd_cref = b->fd_slabs = nullptr; b->fd_gate = nullptr; b->S1d = nullptr;
+            b->fd_hint_host = b->fd_hint_dev = nullptr;
         }
         (void)hipStreamSynchronize(st);
         (void)hipFree(cref); (void)hipFree(fslabs); (void)hipFree(gate); (void)hipFree(s1d);
         (void)hipGetLastError();
+        *hint_host = 0;
     }
     const int aknob = lt_tune().aggregate_first;
     const bool agg_ok = agg_shapes_ok(b) && aknob != 0;
@@ -821,6 +853,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&cref, (size_t)b->Hp * sizeof(double));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fslabs, (size_t)((b->F + 63) / 64) * b->H * sizeof(double));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&gate, sizeof(int));
+        if (e == hipSuccess && fd_possible) e = hipMemsetAsync(gate, 0, sizeof(int), st);     // (the slice counter of k_ref_row_product)
     }
     if (alloc_agg) {
         if (e == hipSuccess) e = hipMalloc((void **)&yd, n1 * b->Fp * sizeof(double));
@@ -833,10 +866,13 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
         (void)hipFree(s1d); (void)hipFree(z1d); (void)hipFree(slabs); (void)hipFree(segd);
         (void)hipFree(cref); (void)hipFree(fslabs); (void)hipFree(gate);
         (void)hipFree(yd); (void)hipFree(segy); (void)hipFree(zst); (void)hipFree(zrw); (void)hipFree(zct);
+        if (hint_host) (void)hipHostFree(hint_host);
         return lt_set_error(LT_ERR_HIP, "lt_baseline_enable_fp64: hipMalloc failed: %s", hipGetErrorString(e));
     }
     b->S1d = s1d; b->Z1d = z1d; b->slabs_d = slabs; b->seg_d = segd;
     b->fd_cref = cref; b->fd_slabs = fslabs; b->fd_gate = gate;
+    b->fd_hint_host = hint_host; b->fd_hint_dev = hint_dev;
+    if (!cref && hint_host) { (void)hipHostFree(hint_host); b->fd_hint_host = b->fd_hint_dev = nullptr; }
     b->Yd = yd; b->seg_y = segy; b->zstate = zst; b->zrows = zrw; b->zcount = zct;
     b->S1d_owned = true; b->S1d_external = false; b->feat_sparse = feat; b->agg_default = agg_chosen;
     int rc = lt_baseline_ensure_padding(b, st);   // (the padded bias the fp64 SpMM adds)
@@ -870,7 +906,7 @@ extern "C" int lt_baseline_refresh_rows_fp64(lt_baseline *b, int32_t row_begin, 
     if (m == 0) return LT_OK;
     if (b->Hp != b->H) LT_HIP(hipMemsetAsync(dst, 0, (size_t)m * b->Hp * sizeof(double), st));
     lt_prof_scope prof_(LT_K_FP64_PRODUCT, st);
-    return launch_dense_s1d(b, row_begin, row_end, dst, (long)b->Hp, nullptr, st);
+    return launch_dense_s1d(b, row_begin, row_end, dst, (long)b->Hp, st);
 }
 
 // S1d lives in caller-owned storage from now on and is filled from outside (the ranks' all-gather of the shards
@@ -917,6 +953,8 @@ void lt_baseline_free_fp64(lt_baseline *b) {
     (void)hipFree(b->fd_cref);
     (void)hipFree(b->fd_slabs);
     (void)hipFree(b->fd_gate);
+    if (b->fd_hint_host) (void)hipHostFree(b->fd_hint_host);
+    b->fd_hint_host = b->fd_hint_dev = nullptr;
     (void)hipFree(b->Yd);
     (void)hipFree(b->seg_y);
     (void)hipFree(b->zstate);

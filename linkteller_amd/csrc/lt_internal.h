@@ -80,7 +80,8 @@ struct lt_baseline {
     // feature-difference route of the fp64 product (lt_fp64.hip, k_s1d_feature_rows)
     double *fd_cref = nullptr;  // [Hp] the reference row's product
     double *fd_slabs = nullptr; // [ceil(F / 64), H] its split-K partials
-    int *fd_gate = nullptr;     // device flag: a row was not a sparse difference -> the matrix-core product runs
+    int *fd_gate = nullptr;     // device word: the slice counter of k_ref_row_product
+    int *fd_hint_host = nullptr, *fd_hint_dev = nullptr;   // mapped host word the feature kernel sets when it meets dense rows
     int feat_sparse = -1;       // what the probe at lt_baseline_enable_fp64 found: 1 sparse differences, 0 dense, -1 not probed
     // aggregate-first route of the fp64 pre-activation (lt_fp64.hip): Z1d[r] = (A_hat X)[r] W1 + b1 on the rows a call's
     // probes reach, nothing for the others -- no n x F x H product, no S1d

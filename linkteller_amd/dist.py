@@ -95,7 +95,9 @@ def _choose_baseline_sharding(base, trials, mode) -> bool:
     other(False)
     if is_delta and ws > 1:
         base.enable_fp64()
-        if base.fp64_route() == 1:      # same features on every rank -> same answer on every rank
+        if base.fp64_route() in (1, 2):     # (same features and shapes on every rank -> same answer on every rank)
+            # 1: the fp64 product is one pass over X; 2: the pre-activation is formed on the rows a rank's own probes reach
+            # (aggregate-first, no S1d at all) -- nothing worth exchanging either way
             shard(False)
             return False
     if ws == 1 or pol == "0":

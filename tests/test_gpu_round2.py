@@ -251,13 +251,17 @@ def test_sharded_influence_matrix_equals_single_rank(gpu, influence_golden, tmp_
         out = tmp_path / f"ranks{world}_{shard_baseline}.npz"
         env = {"LT_TEST_OUT": str(out), "LT_SHARD_BASELINE": shard_baseline[0] if shard_baseline != "auto" else "auto"}
         if shard_baseline == "1d":
-            env["LT_FEATURE_DELTA"] = "0"
+            env["LT_FEATURE_DELTA"] = env["LT_AGGREGATE_FIRST"] = "0"
             from linkteller_amd import _lib
             _lib.set_tuning("feature_delta", 0)
+            _lib.set_tuning("aggregate_first", 0)
             try:
+                base.refresh()
+                assert base.fp64_route() == 0
                 single_d = base.influence_rows(nodes, nodes, args["influence"], "delta").cpu().numpy().astype(np.float64)
             finally:
                 _lib.set_tuning("feature_delta", None)
+                _lib.set_tuning("aggregate_first", None)
                 base.refresh()
             single = dict(single, delta=single_d)
         _run_ranks(code, world, env)

@@ -67,7 +67,7 @@ def _bench(args, env=None, timeout=900):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("mode,extra", [("delta", {}), ("delta", {"LT_FEATURE_DELTA": "0", "LT_SHARD_BASELINE": "1"}),
+@pytest.mark.parametrize("mode,extra", [("delta", {}), ("delta", {"LT_FEATURE_DELTA": "0", "LT_AGGREGATE_FIRST": "0", "LT_SHARD_BASELINE": "1"}),
                                         ("full", {"LT_SHARD_BASELINE": "1"})])
 def test_bench_two_ranks_through_its_own_launcher(gpu, tmp_path, mode, extra):
     """`python bench.py --gpus 2` starts its two ranks itself (fresh child processes, before anything touches the GPU).
@@ -151,7 +151,7 @@ def test_feature_difference_route_of_the_fp64_product(gpu):
     k_s1d_feature_rows): taken for standardised indicator features (what the reference's twitch loader produces), not for
     Gaussian ones; `delta` within 1e-5 of the fp64 oracle on both routes, the two routes within fp32 rounding of each
     other; and a baseline whose features BECOME dense after the route was chosen falls back on the device (the gate) to
-    the matrix-core product, giving the bits of a baseline created on the dense features."""
+    the matrix-core product from the next refresh on, giving the bits of a baseline created on the dense features."""
     from test_gpu_parity import _oracle_matrix
     from linkteller_amd import _lib, engine, graph, synth
     n, f, h = 900, 700, 102            # H needs padding (Hp = 104): the pad columns of S1d must stay zero on every route
@@ -181,24 +181,31 @@ def test_feature_difference_route_of_the_fp64_product(gpu):
     bg = engine.Baseline(hg, torch.from_numpy(xg).to(gpu), *_params(w, gpu)).enable_fp64()
     assert bg.fp64_route() == 0
     want = bg.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy()
-    # features that turn dense under a baseline that chose the sparse route: same bits through the device-side gate
+    # features that turn dense under a baseline that chose the sparse route: the refresh that meets them is still served by
+    # the feature kernel (full lists are walked and emptied: correct, just slow) and its hint word moves the baseline to
+    # the matrix cores from the next refresh on -- then the bits are those of a baseline created on the dense features
     xt.copy_(torch.from_numpy(xg).to(gpu))
     base.refresh()
     assert base.fp64_route() == 1
-    assert np.array_equal(base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy(), want)
+    slow = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
     refg = _oracle_matrix(a_hat, xg, w, probes[:6], observe, 1e-4, torch.float64)
-    assert np.abs(want[:6] - refg).max() <= 1e-5 * refg.max()
-    # a single dense row among sparse ones also raises the gate
+    assert np.abs(slow[:6] - refg).max() <= 1e-5 * refg.max()
+    assert np.abs(slow - want).max() <= 1e-6 * refg.max()
+    torch.cuda.synchronize()
+    base.refresh()
+    assert base.fp64_route() == 0
+    assert np.array_equal(base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy(), want)
+    # a single dense row among sparse ones is served too (and flips the route the same way)
+    base2 = engine.Baseline(hg, xt, *_params(w, gpu))
     xm = x.copy()
     xm[17] = xg[17]
     xt.copy_(torch.from_numpy(xm).to(gpu))
-    base.refresh()
-    got_m = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
+    base2.enable_fp64()
+    got_m = base2.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
     refm = _oracle_matrix(a_hat, xm, w, probes[:6], observe, 1e-4, torch.float64)
     assert np.abs(got_m[:6] - refm).max() <= 1e-5 * refm.max()
 
 
-@pytest.mark.parametrize("f,h,c,hub", [(256, 256, 2, True), (64, 100, 3, True), (33, 24, 2, False), (130, 66, 7, True)])
 def test_aggregate_first_route_of_the_fp64_preactivation(gpu, f, h, c, hub):
     """`delta` on dense features no wider than ~2 H (BASELINE configs[4]: F = H = 256): the pre-activation is formed as
     (A_hat X)[r] W1 + b1 on the rows the call's probes reach, on demand (lt_fp64.hip "aggregate-first"; lt_baseline_fp64_route
