@@ -386,9 +386,8 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     const bool own = c0 < Hp;                       // this lane holds 4 hidden columns
     const bool vec_ok = (H % 4 == 0) && c0 + 3 < H;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    int cnt = 0, total = 0;                         // wave-uniform: entries in the list / differing columns so far
-    // walk the list (entries 0 .. cnt, padded with zero terms to a multiple of FD_PU) and empty it
-    auto flush = [&]() {
+    // walk the wave's list (entries 0 .. cnt, padded with zero terms to a multiple of FD_PU)
+    auto walk = [&](int cnt) {
         const int padded = (cnt + FD_PU - 1) / FD_PU * FD_PU;
         if (lane < padded - cnt) { mj[cnt + lane] = 0; mv[cnt + lane] = 0.0; }      // (d = 0: the term adds exactly nothing)
         if (own)
@@ -409,14 +408,16 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
 #pragma unroll
                     for (int t = 0; t < 4; ++t) acc[t] = fma(d[k], (double)w[k][t], acc[t]);
             }
-        cnt = 0;
     };
     const unsigned long long lt = (1ull << lane) - 1ull;
+    // pass 1 (the common case is all there is): the whole row with many loads in flight; differing columns beyond the
+    // list's capacity are only counted
+    int total = 0;                                  // wave-uniform: differing columns of the row
     constexpr int STEP = 64 * VEC, UN = 16;         // F = 3170: the row in two trips of 16 loads per lane
     for (int j0 = 0; j0 < F; j0 += STEP * UN) {
         float x[UN][VEC];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {              // UN loads in flight per lane
+        for (int u = 0; u < UN; ++u) {
             const int j = j0 + u * STEP + lane * VEC;
             if constexpr (VEC == 2) {
                 float2 t = make_float2(0.f, 0.f);
@@ -436,16 +437,28 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
                 const bool diff = j < F && x[u][v] != r;
                 const unsigned long long m = __ballot(diff);
                 if (m) {
-                    if (cnt + 64 > FD_CAP) flush();                  // (wave-uniform)
-                    if (diff) { const int pos = cnt + __popcll(m & lt); mj[pos] = j; mv[pos] = (double)x[u][v] - (double)r; }
-                    const int c = __popcll(m);
-                    cnt += c;
-                    total += c;
+                    const int pos = total + __popcll(m & lt);
+                    if (diff && pos < FD_CAP) { mj[pos] = j; mv[pos] = (double)x[u][v] - (double)r; }
+                    total += __popcll(m);
                 }
             }
         }
     }
-    flush();
+    if (total <= FD_CAP) {
+        walk(total);
+    } else {
+        // a dense row: what pass 1 listed is incomplete, so the row is read again, one piece at a time, and every piece's
+        // list is walked before the next is made (slow and correct; the hint below moves the baseline off this route)
+        for (int j0 = 0; j0 < F; j0 += 64) {
+            const int j = j0 + lane;
+            const float xv = j < F ? xr[j] : 0.f;
+            const float r = j < F ? sref[j] : 0.f;
+            const bool diff = j < F && xv != r;
+            const unsigned long long m = __ballot(diff);
+            if (diff) { const int pos = __popcll(m & lt); mj[pos] = j; mv[pos] = (double)xv - (double)r; }
+            walk(__popcll(m));
+        }
+    }
     if (total > hint_cap && lane == 0) *dense_hint = 1;
     if (!own) return;
     f64x4 o;
@@ -470,7 +483,15 @@ __global__ __launch_bounds__(256) void k_ref_row_product(int F, int H, int Hp, c
     const int k0 = blockIdx.x * 64, k1 = min(F, k0 + 64);
     for (int c = threadIdx.x; c < H; c += 256) {
         double a = 0.0;
-        for (int k = k0; k < k1; ++k) a = fma((double)xref[k], (double)W1[(size_t)k * H + c], a);
+        int k = k0;
+        for (; k + 16 <= k1; k += 16) {          // 16 loads in flight, the chain in k order
+            float w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = W1[(size_t)(k + u) * H + c];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a = fma((double)xref[k + u], (double)w[u], a);
+        }
+        for (; k < k1; ++k) a = fma((double)xref[k], (double)W1[(size_t)k * H + c], a);
         slabs[(size_t)blockIdx.x * H + c] = a;
     }
     __threadfence();
@@ -479,10 +500,20 @@ __global__ __launch_bounds__(256) void k_ref_row_product(int F, int H, int Hp, c
     __syncthreads();
     if (!s_last) return;
     __threadfence();
+    const unsigned nz = gridDim.x;
     for (int c = threadIdx.x; c < Hp; c += 256) {
         double a = 0.0;
-        if (c < H)
-            for (unsigned z = 0; z < gridDim.x; ++z) a += __builtin_nontemporal_load(slabs + (size_t)z * H + c);
+        if (c < H) {
+            unsigned z = 0;
+            for (; z + 16 <= nz; z += 16) {      // slices added in slice order, 16 loads in flight
+                double t[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t[u] = __builtin_nontemporal_load(slabs + (size_t)(z + u) * H + c);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) a += t[u];
+            }
+            for (; z < nz; ++z) a += __builtin_nontemporal_load(slabs + (size_t)z * H + c);
+        }
         cref[c] = a;
     }
     if (threadIdx.x == 0) *counter = 0;              // ready for the next launch

@@ -206,6 +206,7 @@ def test_feature_difference_route_of_the_fp64_product(gpu):
     assert np.abs(got_m[:6] - refm).max() <= 1e-5 * refm.max()
 
 
+@pytest.mark.parametrize("f,h,c,hub", [(256, 256, 2, True), (64, 100, 3, True), (33, 24, 2, False), (130, 66, 7, True)])
 def test_aggregate_first_route_of_the_fp64_preactivation(gpu, f, h, c, hub):
     """`delta` on dense features no wider than ~2 H (BASELINE configs[4]: F = H = 256): the pre-activation is formed as
     (A_hat X)[r] W1 + b1 on the rows the call's probes reach, on demand (lt_fp64.hip "aggregate-first"; lt_baseline_fp64_route
