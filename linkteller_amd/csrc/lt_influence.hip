@@ -1075,6 +1075,91 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
     if (q == 0) out[(long)b * ldo + j] = res;
 }
 
+// SPARSE / DELTA stage B, calls with a bitmap row per probe (twitch size): one block per (observed node, slice of the
+// probes) instead of one 8-lane group per pair.  k_item_stageB pays the chain observe[j] -> rowptr[u] -> col[e] -> bitmap
+// for every one of the 250 K pairs of a 500 x 500 call although 93 % of them turn out untouched; here the observed row
+// is staged in LDS once and each 8-lane group then tests LT_SB_UNR probes at a time against it (independent bitmap loads,
+// the only global traffic of an untouched pair).  The touched pairs run row2_dot over the staged row: same chains
+// (entry e -> chain (e - e0) & 7, k-ordered), same butterfly, same tail -- the bits of k_item_stageB.
+#define LT_SB_UNR 4
+template <int CP, bool DELTA>
+__global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_rows(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
+    const float *__restrict__ S2, int C, const float *__restrict__ b2, const float *__restrict__ OUT, int nb,
+    const int32_t *__restrict__ off, const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs,
+    float delta, float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words, int psplit) {
+    __shared__ int32_t scol[LT_ROW_SEG];
+    __shared__ float sval[LT_ROW_SEG];
+    const int j = (int)blockIdx.x / psplit, part = (int)blockIdx.x % psplit;
+    const int u = observe[j];
+    const int e0 = rowptr[u], d = rowptr[u + 1] - e0;
+    if (d > LT_ROW_SEG) return;          // an observed hub: stageB_long_block (the hub blocks of k_item_stageB's launch)
+    for (int i = threadIdx.x; i < d; i += LT_BLOCK) { scol[i] = col[e0 + i]; sval[i] = val[e0 + i]; }
+    __syncthreads();
+    const int q = threadIdx.x & (LT_L2_LANES - 1), grp = threadIdx.x / LT_L2_LANES;
+    constexpr int GROUPS = LT_BLOCK / LT_L2_LANES;
+    const int per = (nb + psplit - 1) / psplit;
+    const int b_begin = part * per, b_end = min(nb, b_begin + per);
+    const int32_t *lc = scol - e0;       // row2_dot indexes its arrays with the CSR entry number
+    const float *lv = sval - e0;
+    for (int b0 = b_begin + grp; b0 < b_end; b0 += GROUPS * LT_SB_UNR) {
+        int t[LT_SB_UNR];
+#pragma unroll
+        for (int k = 0; k < LT_SB_UNR; ++k) {
+            const int b = b0 + k * GROUPS;
+            unsigned hit = 0u;
+            if (b < b_end) {
+                const uint2 *mb = bits + (size_t)b * words;
+                for (int e = q; e < d; e += LT_L2_LANES) {
+                    const int c = scol[e];
+                    hit |= (mb[c >> 5].x >> (c & 31)) & 1u;
+                }
+            }
+            t[k] = (int)hit;
+        }
+#pragma unroll
+        for (int k = 0; k < LT_SB_UNR; ++k)
+#pragma unroll
+            for (int m = LT_L2_LANES / 2; m >= 1; m >>= 1) t[k] |= __shfl_xor(t[k], m, 64);
+#pragma unroll
+        for (int k = 0; k < LT_SB_UNR; ++k) {
+            const int b = b0 + k * GROUPS;
+            if (b >= b_end) continue;     // group-uniform
+            float res = 0.f;
+            if (t[k]) {                   // group-uniform
+                const uint2 *mb = bits + (size_t)b * words;
+                const float *items = S2x + (size_t)off[b] * C;
+                float acc[CP];
+                if (DELTA) {
+                    row2_dot<CP>(lc, lv, e0, e0 + d, q, C,
+                                 [&](int c, int) {
+                                     const int p = bits_pos(mb, c);
+                                     return p >= 0 ? items + (size_t)p * C : (const float *)nullptr;
+                                 },
+                                 acc);
+                    float ss = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CP; ++c)
+                        if (c < C) {
+                            const float dd = acc[c] / delta;
+                            ss = fmaf(dd, dd, ss);
+                        }
+                    res = sqrtf(ss);
+                } else {
+                    row2_dot<CP>(lc, lv, e0, e0 + d, q, C,
+                                 [&](int c, int) {
+                                     const int p = bits_pos(mb, c);
+                                     return p >= 0 ? items + (size_t)p * C : S2 + (size_t)c * C;
+                                 },
+                                 acc);
+                    res = diff_norm<CP>(acc, b2, OUT + (size_t)u * C, C, delta);
+                }
+            }
+            if (q == 0) out[(long)b * ldo + j] = res;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1243,6 +1328,15 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
     // With a bitmap row per probe (twitch size) the per-entry test is one cached load and wins; without one it is a search
     // per entry and loses by 10x.  "hub_short_side" pins the choice (tests).
     const bool hub_short = mode != LT_MODE_FULL && (lt_tune().hub_short_side >= 0 ? lt_tune().hub_short_side != 0 : w.bits == nullptr);
+    // stage B per observed row (k_item_stageB_rows) instead of per pair: calls with a bitmap row per probe and no pair marks
+    // ("stageb_rows" = 0 keeps the per-pair kernel; results are bit-identical)
+    const bool rows_route = mode != LT_MODE_FULL && w.bits != nullptr && !use_marks && lt_tune().stageb_rows != 0;
+    // probes of a chunk split over `psplit` blocks per observed node so that the launch fills the chip
+    int psplit = 1;
+    {
+        const int chunk_nb = n_probe < w.chunk ? n_probe : w.chunk;
+        while ((long)n_obs * psplit < 2048 && psplit * 32 * LT_SB_UNR < chunk_nb) psplit *= 2;
+    }
     if (use_marks) {
         LT_REQUIRE((long)n_obs * LT_ROW_SEG / 256 + 1 < 2147483647L, "lt_influence_rows: n_obs=%d exceeds the grid limit", n_obs);
         const unsigned gl = (unsigned)(((long)n_obs * LT_ROW_SEG + 255) / 256);
@@ -1399,6 +1493,20 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                     LT_CHECK_LAUNCH();
                 }
                 const unsigned inl = hub_short ? 0u : (unsigned)long_blocks;   // hub blocks in front of the pair launch
+                if (rows_route) {
+                    if (inl > 0) {       // the observed hubs: the hub blocks of the pair kernel, launched without its pairs
+                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, false>), dim3(inl), dim3(LT_BLOCK), 0, st,
+                                                               g->rowptr, g->col, g->val, g->tptr, g->trow, b->S2, C, b->b2,
+                                                               b->OUT, probes, nb, w.off, w.S2x, observe_nodes, n_obs, delta,
+                                                               orow, (long)ldo, w.bits, words, (int)inl, 1, marks, w.big_bits,
+                                                               w.big_slot, 0));
+                        LT_CHECK_LAUNCH();
+                    }
+                    LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_rows<CP_, false>), dim3((unsigned)((long)n_obs * psplit)),
+                                                           dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, b->S2, C, b->b2,
+                                                           b->OUT, nb, w.off, w.S2x, observe_nodes, n_obs, delta, orow, (long)ldo,
+                                                           w.bits, words, psplit));
+                } else
                 LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, false>), dim3(gridB + inl),
                                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
                                                        g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
@@ -1431,6 +1539,20 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                 } }
                 LT_CHECK_LAUNCH();
                 lt_prof_scope prof_(LT_K_ITEM_B, st);
+                if (rows_route) {
+                    if (long_blocks > 0) {
+                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, true>), dim3((unsigned)long_blocks), dim3(LT_BLOCK), 0,
+                                                               st, g->rowptr, g->col, g->val, g->tptr, g->trow, b->S2, C, b->b2,
+                                                               b->OUT, probes, nb, w.off, w.S2x, observe_nodes, n_obs, delta, orow,
+                                                               (long)ldo, w.bits, words, (int)long_blocks, 1, marks, w.big_bits,
+                                                               w.big_slot, hub_short ? 1 : 0));
+                        LT_CHECK_LAUNCH();
+                    }
+                    LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_rows<CP_, true>), dim3((unsigned)((long)n_obs * psplit)),
+                                                           dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, b->S2, C, b->b2,
+                                                           b->OUT, nb, w.off, w.S2x, observe_nodes, n_obs, delta, orow, (long)ldo,
+                                                           w.bits, words, psplit));
+                } else
                 LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, true>), dim3(gridB + (unsigned)long_blocks),
                                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
                                                        g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,

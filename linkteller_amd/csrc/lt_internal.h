@@ -125,6 +125,8 @@ struct lt_tuning {
     long long bits_max_bytes;    // SPARSE / DELTA: a bitmap row per probe only while the chunk's rows fit this (default 128 MiB);
                                  // beyond it only the chunk's big probes get rows (LT_BITS_MAX_BYTES)
     int tiled_big;               // 1: the tiled SpMM always uses 64-bit gather offsets (test hook; default: only when S spans >= 4 GiB)
+    int stageb_rows;             // SPARSE / DELTA stage B with a bitmap: 1 one block per (observed row, probe slice), 0 one 8-lane group
+                                 // per pair (LT_STAGEB_ROWS)
     int aggregate_first;         // fp64 pre-activation as (A_hat X) W1 on the rows a call needs: 0 never, 1 whenever the shapes allow,
                                  // -1 when they do and the features are not sparse differences (LT_AGGREGATE_FIRST)
     int feature_delta;           // fp64 product X*W1 from the feature rows' differences to a reference row: 0 never, 1 always try,

@@ -295,3 +295,47 @@ def test_lapgraph_topk_on_the_device(gpu, capsys):
     with capsys.disabled():
         print(f"\nLapGraph N={adj.shape[0]} eps=5: device select {out['hip'][1]:.2f} s, host argpartition {out['host'][1]:.2f} s "
               f"(both include the 0.2-0.3 s numpy Laplace draw of N^2 cells)")
+
+
+@pytest.mark.parametrize("family", ["powerlaw", "er", "directed"])
+def test_stage_b_per_observed_row_keeps_every_bit(gpu, family):
+    """SPARSE / DELTA stage B of calls with a bitmap row per probe runs one block per (observed node, probe slice) with
+    the observed row staged in LDS (k_item_stageB_rows) instead of one 8-lane group per pair.  Same chains, same
+    butterfly: pinned off ("stageb_rows" = 0) it must give the same bits -- hub rows on both sides, a non-symmetric
+    pattern, several probe chunks, probe counts that leave partial groups and partial slices."""
+    import scipy.sparse as sp
+    from linkteller_amd import _lib, engine, graph, synth
+    n = 1500
+    if family == "powerlaw":
+        a_hat = graph.first_order_gcn(synth.powerlaw_graph(n, 9000, seed=3))
+        assert np.diff(a_hat.indptr).max() > 300
+    elif family == "er":
+        a_hat = graph.first_order_gcn(synth.erdos_renyi_graph(n, 12000, seed=4))
+    else:
+        rng = np.random.RandomState(5)
+        m = sp.csr_matrix((rng.uniform(0.1, 1.0, 14000).astype(np.float32), (rng.randint(0, n, 14000), rng.randint(0, n, 14000))), shape=(n, n))
+        m.sum_duplicates()
+        m.sort_indices()
+        a_hat = m
+    x = synth.gaussian_features(n, 48, seed=1)
+    w = synth.gcn_weights(48, 64, 3, seed=2)
+    base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *_params(w, gpu))
+    rng = np.random.RandomState(6)
+    deg = np.diff(sp.csr_matrix(a_hat).indptr)
+    big = np.argsort(-deg)[:5]
+    try:
+        for n_probe, n_obs in ((1, 40), (33, 200), (300, 700), (517, 90)):
+            probes = np.concatenate([big[:min(3, n_probe)], rng.choice(n, max(0, n_probe - 3), replace=False)])[:n_probe]
+            obs = np.concatenate([big[:2], rng.choice(n, n_obs - 2, replace=False)])
+            for budget in (None, 1 << 16):
+                _lib.set_tuning("chunk_budget_bytes", budget)
+                got = {}
+                for rows in (1, 0):
+                    _lib.set_tuning("stageb_rows", rows)
+                    got[rows] = {m: base.influence_rows(probes, obs, 1e-4, m).cpu().numpy() for m in ("sparse", "delta")}
+                for m in ("sparse", "delta"):
+                    assert np.array_equal(got[0][m], got[1][m]), (family, n_probe, n_obs, budget, m)
+                assert np.array_equal(got[1]["sparse"], base.influence_rows(probes, obs, 1e-4, "full").cpu().numpy())
+    finally:
+        _lib.set_tuning("stageb_rows", None)
+        _lib.set_tuning("chunk_budget_bytes", None)
