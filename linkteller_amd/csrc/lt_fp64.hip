@@ -350,36 +350,60 @@ __global__ void k_spmm_f64_long(int n_long, const int32_t *__restrict__ long_row
 }
 
 // ---- S1d = X*W1 from the DIFFERENCES of the feature rows to one reference row ---------------------------------------
-//   S1d[i, :] = S1d[ref, :] + sum_{j : X[i,j] != X[ref,j]} (X[i,j] - X[ref,j]) * W1[j, :]
-// is an identity for any X (in fp64 the difference of two fp32 values is exact, so the terms are the exact products the
-// dense sum holds; only the order of an fp64 summation changes).  It pays when rows differ from the reference row in few
-// columns -- which is how the reference's own twitch features look: utils/load.py:53-59 builds 0/1 indicator rows
-// (a few dozen of 3170 set) and worker.py standardises them per column, so every column holds TWO values and a row
-// differs from any other in ~ 2 x (features set) places.  Then the fp64 product is one pass over X (N*F*4 bytes) and
-// ~ 40 W1 rows per node instead of 2*N*F*H flops on the f64 matrix cores (twitch-RU: 7.1 GFLOP -> 0.1).
-// One wave per row: the lanes compare their pieces of the row with the reference row (staged in LDS), the differing
-// columns are compacted into a per-wave LDS list (ballot + prefix) and every lane walks the list for its 4 hidden
-// columns (a full list is walked and emptied, so ANY row is served correctly, a dense one just slowly).  A row with more
-// than `hint_cap` differing columns (dense features: Gaussian, embeddings) sets *dense_hint -- a word of mapped host
-// memory the host looks at before the NEXT refresh to move the baseline to the matrix-core product for good.
+//   S1d[i, :] = m W1 + sum_{j : X[i,j] != m[j]} (X[i,j] - m[j]) * W1[j, :]
+// is an identity for ANY reference vector m (in fp64 the difference of two fp32 values is exact, so the terms are the
+// exact products the dense sum holds; only the order of an fp64 summation changes).  It pays when the rows differ from m
+// in few columns -- which is how the reference's own twitch features look: utils/load.py:53-59 builds 0/1 indicator
+// rows (a few dozen of 3170 set) and worker.py standardises them per column, so every column holds TWO values and, with
+// m[j] = the value most of the rows hold, a row differs from m exactly where its own features are set.  Then the fp64
+// product is one pass over X (N*F*4 bytes) and ~ 20 W1 rows per node instead of 2*N*F*H flops on the f64 matrix cores
+// (twitch-RU: 7.1 GFLOP -> 0.05).
+//   k_ref_row_product   m[j] = the more frequent of (min, max) of column j over the first <= 64 rows, and cref = m W1
+//   k_s1d_feature_rows  one wave per row: ALL loads of the row go out first (one HBM round trip), the reference vector is
+//                       staged in LDS meanwhile, the differing columns are compacted into a per-wave LDS list (ballot +
+//                       prefix) and every lane walks the list for its 4 hidden columns.  A row with more differing columns
+//                       than the list holds is read again piecewise (slow and correct); a row with more than `hint_cap`
+//                       sets *dense_hint -- a word of mapped host memory the host looks at before the NEXT refresh to move
+//                       the baseline to the matrix-core product for good.
 #define FD_CAP 384
 #define FD_WAVES 4
 #define FD_PU 8          // W1 rows in flight per lane while a list is walked (FD_CAP is a multiple)
+#define FD_UN 26         // loads in flight per lane in the row pass (x 128 floats: F <= 3328 is one trip)
 template <int VEC>   // floats per lane and load: 2 when the rows of X are 8-byte aligned, else 1
 __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
-    int n, int F, int H, int Hp, const float *__restrict__ X, long ldx, int ref, const float *__restrict__ W1,
-    const double *__restrict__ cref, double *__restrict__ S1d, int hint_cap, int *__restrict__ dense_hint) {
+    int n, int F, int H, int Hp, const float *__restrict__ X, long ldx, const float *__restrict__ ref,
+    const float *__restrict__ W1, const double *__restrict__ cref, double *__restrict__ S1d, int hint_cap,
+    int *__restrict__ dense_hint) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fd_smem[];
-    float *sref = reinterpret_cast<float *>(fd_smem);                              // [Fp] the reference row
+    float *sref = reinterpret_cast<float *>(fd_smem);                              // [Fp] the reference vector
     const int Fp = (F + 1) & ~1;
     double *ldv = reinterpret_cast<double *>(fd_smem + (((size_t)Fp * 4 + 15) & ~(size_t)15));   // [FD_WAVES][FD_CAP]
     int *lj = reinterpret_cast<int *>(ldv + FD_WAVES * FD_CAP);                    // [FD_WAVES][FD_CAP]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (int j = tid; j < Fp; j += 64 * FD_WAVES) sref[j] = j < F ? X[(long)ref * ldx + j] : 0.f;
-    __syncthreads();
     const int i = blockIdx.x * FD_WAVES + wid;
-    if (i >= n) return;
-    const float *xr = X + (long)i * ldx;
+    const bool live = i < n;                        // (waves past the last row still help staging and join the barrier)
+    const float *xr = X + (long)(live ? i : 0) * ldx;
+    constexpr int STEP = 64 * VEC;
+    // the first trip's loads of the row go out BEFORE the reference vector is staged: one round trip covers both
+    float x[FD_UN][VEC];
+    auto load_trip = [&](int j0) {
+#pragma unroll
+        for (int u = 0; u < FD_UN; ++u) {
+            const int j = j0 + u * STEP + lane * VEC;
+            if constexpr (VEC == 2) {
+                float2 t = make_float2(0.f, 0.f);
+                if (j + 1 < F) t = *reinterpret_cast<const float2 *>(xr + j);
+                else if (j < F) t.x = xr[j];
+                x[u][0] = t.x; x[u][1] = t.y;
+            } else {
+                x[u][0] = j < F ? xr[j] : 0.f;
+            }
+        }
+    };
+    load_trip(0);
+    for (int j = tid; j < Fp; j += 64 * FD_WAVES) sref[j] = j < F ? ref[j] : 0.f;
+    __syncthreads();
+    if (!live) return;
     double *mv = ldv + wid * FD_CAP;
     int *mj = lj + wid * FD_CAP;
     const int c0 = 4 * lane;
@@ -410,26 +434,12 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
             }
     };
     const unsigned long long lt = (1ull << lane) - 1ull;
-    // pass 1 (the common case is all there is): the whole row with many loads in flight; differing columns beyond the
-    // list's capacity are only counted
+    // pass 1 (the common case is all there is); differing columns beyond the list's capacity are only counted
     int total = 0;                                  // wave-uniform: differing columns of the row
-    constexpr int STEP = 64 * VEC, UN = 16;         // F = 3170: the row in two trips of 16 loads per lane
-    for (int j0 = 0; j0 < F; j0 += STEP * UN) {
-        float x[UN][VEC];
+    for (int j0 = 0; j0 < F; j0 += STEP * FD_UN) {
+        if (j0 > 0) load_trip(j0);
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int j = j0 + u * STEP + lane * VEC;
-            if constexpr (VEC == 2) {
-                float2 t = make_float2(0.f, 0.f);
-                if (j + 1 < F) t = *reinterpret_cast<const float2 *>(xr + j);
-                else if (j < F) t.x = xr[j];
-                x[u][0] = t.x; x[u][1] = t.y;
-            } else {
-                x[u][0] = j < F ? xr[j] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
+        for (int u = 0; u < FD_UN; ++u) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 const int j = j0 + u * STEP + lane * VEC + v;
@@ -474,13 +484,50 @@ static size_t fd_smem_bytes(int F) {
 // cnt row gathers per node, the matrix cores F * H at ~10 x the rate
 static int fd_hint_cap(int F) { const int c = F / 16; return c < 8 ? 8 : (c > FD_CAP ? FD_CAP : c); }
 
-// The reference row's own product cref[0..H) = X[ref, :] * W1 in fp64, one launch: block z sums its 64-deep K slice for
-// every column, the block that finishes last adds the slices in slice order (a fixed order whoever comes last).
-__global__ __launch_bounds__(256) void k_ref_row_product(int F, int H, int Hp, const float *__restrict__ xref,
-                                                         const float *__restrict__ W1, double *__restrict__ slabs,
-                                                         double *__restrict__ cref, unsigned *__restrict__ counter) {
+// The reference vector and its product, one launch.  Block z owns the 64-deep K slice [64 z, 64 z + 64): it picks m[k] for
+// its columns -- the more frequent of (min, max) of X[0 .. rows, k] over the first rows <= 64 rows: the majority value of a
+// two-valued column -- writes it to ref[], and sums its slice of cref = m W1 for every hidden column; the block that
+// finishes last adds the slices in slice order (a fixed order whoever comes last).
+__global__ __launch_bounds__(256) void k_ref_row_product(int n, int F, int H, int Hp, const float *__restrict__ X, long ldx,
+                                                         const float *__restrict__ W1, float *__restrict__ ref,
+                                                         double *__restrict__ slabs, double *__restrict__ cref,
+                                                         unsigned *__restrict__ counter) {
     __shared__ unsigned s_last;
+    __shared__ float s_m[64];
+    __shared__ float s_x[4][64];
     const int k0 = blockIdx.x * 64, k1 = min(F, k0 + 64);
+    const int rows = n < 64 ? n : 64;
+    {   // thread (q, t): column k0 + t, sample rows q, q + 4, ...: min / max, then the count of the min
+        const int t = threadIdx.x & 63, q = threadIdx.x >> 6;
+        const bool ok = k0 + t < k1;
+        float xv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) xv[u] = (ok && q + 4 * u < rows) ? X[(long)(q + 4 * u) * ldx + k0 + t] : 0.f;
+        float mn = 3.4e38f, mx = -3.4e38f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (q + 4 * u < rows) { mn = fminf(mn, xv[u]); mx = fmaxf(mx, xv[u]); }
+        s_x[q][t] = mn;
+        __syncthreads();
+        mn = fminf(fminf(s_x[0][t], s_x[1][t]), fminf(s_x[2][t], s_x[3][t]));
+        __syncthreads();
+        s_x[q][t] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(s_x[0][t], s_x[1][t]), fmaxf(s_x[2][t], s_x[3][t]));
+        __syncthreads();
+        int c = 0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) c += (q + 4 * u < rows && xv[u] == mn) ? 1 : 0;
+        s_x[q][t] = (float)c;
+        __syncthreads();
+        if (q == 0) {
+            const float cm = s_x[0][t] + s_x[1][t] + s_x[2][t] + s_x[3][t];
+            const float m = (2.f * cm >= (float)rows) ? mn : mx;
+            s_m[t] = ok ? m : 0.f;
+            if (ok) ref[k0 + t] = m;
+        }
+        __syncthreads();
+    }
     for (int c = threadIdx.x; c < H; c += 256) {
         double a = 0.0;
         int k = k0;
@@ -489,9 +536,9 @@ __global__ __launch_bounds__(256) void k_ref_row_product(int F, int H, int Hp, c
 #pragma unroll
             for (int u = 0; u < 16; ++u) w[u] = W1[(size_t)(k + u) * H + c];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) a = fma((double)xref[k + u], (double)w[u], a);
+            for (int u = 0; u < 16; ++u) a = fma((double)s_m[k - k0 + u], (double)w[u], a);
         }
-        for (; k < k1; ++k) a = fma((double)xref[k], (double)W1[(size_t)k * H + c], a);
+        for (; k < k1; ++k) a = fma((double)s_m[k - k0], (double)W1[(size_t)k * H + c], a);
         slabs[(size_t)blockIdx.x * H + c] = a;
     }
     __threadfence();
@@ -504,15 +551,13 @@ __global__ __launch_bounds__(256) void k_ref_row_product(int F, int H, int Hp, c
     for (int c = threadIdx.x; c < Hp; c += 256) {
         double a = 0.0;
         if (c < H) {
-            unsigned z = 0;
-            for (; z + 16 <= nz; z += 16) {      // slices added in slice order, 16 loads in flight
+            for (unsigned z = 0; z < nz; z += 16) {      // slices added in slice order, 16 loads in flight
                 double t[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) t[u] = __builtin_nontemporal_load(slabs + (size_t)(z + u) * H + c);
+                for (int u = 0; u < 16; ++u) t[u] = z + u < nz ? __builtin_nontemporal_load(slabs + (size_t)(z + u) * H + c) : 0.0;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) a += t[u];
+                for (int u = 0; u < 16; ++u) if (z + u < nz) a += t[u];
             }
-            for (; z < nz; ++z) a += __builtin_nontemporal_load(slabs + (size_t)z * H + c);
         }
         cref[c] = a;
     }
@@ -742,17 +787,17 @@ static bool want_feature_rows(const lt_baseline *cb) {
 
 static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1) {
     const int Hp = b->Hp, H = b->H, n = n_rows < 0 ? b->n : n_rows, F = b->F;
-    hipLaunchKernelGGL(k_ref_row_product, dim3((unsigned)((F + 63) / 64)), dim3(256), 0, st, F, H, Hp, b->X, b->W1, b->fd_slabs,
-                       b->fd_cref, (unsigned *)b->fd_gate);
+    hipLaunchKernelGGL(k_ref_row_product, dim3((unsigned)((F + 63) / 64)), dim3(256), 0, st, n, F, H, Hp, b->X, (long)b->ldx, b->W1,
+                       b->fd_ref, b->fd_slabs, b->fd_cref, (unsigned *)b->fd_gate);
     LT_CHECK_LAUNCH();
     const unsigned blocks = (unsigned)((n + FD_WAVES - 1) / FD_WAVES);
     const size_t smem = fd_smem_bytes(F);
     if (b->ldx % 2 == 0 && ((uintptr_t)b->X % 8) == 0)
-        hipLaunchKernelGGL((k_s1d_feature_rows<2>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx, 0,
-                           b->W1, b->fd_cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev);
+        hipLaunchKernelGGL((k_s1d_feature_rows<2>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx,
+                           b->fd_ref, b->W1, b->fd_cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev);
     else
-        hipLaunchKernelGGL((k_s1d_feature_rows<1>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx, 0,
-                           b->W1, b->fd_cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev);
+        hipLaunchKernelGGL((k_s1d_feature_rows<1>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx,
+                           b->fd_ref, b->W1, b->fd_cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev);
     LT_CHECK_LAUNCH();
     return LT_OK;
 }
@@ -843,22 +888,24 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
         // Temporary buffers: the real ones are allocated once the route is known.
         const int n_probe = b->n < 4096 ? b->n : 4096;
         double *cref = nullptr, *fslabs = nullptr, *s1d = nullptr;
+        float *fref = nullptr;
         int *gate = nullptr;
         hipError_t e = hipMalloc((void **)&cref, (size_t)b->Hp * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&fref, (size_t)(b->F + 64) * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&fslabs, (size_t)((b->F + 63) / 64) * b->H * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&gate, sizeof(int));
         if (e == hipSuccess) e = hipMemsetAsync(gate, 0, sizeof(int), st);
         if (e == hipSuccess) e = hipMalloc((void **)&s1d, (size_t)n_probe * b->Hp * sizeof(double));
         if (e == hipSuccess) {
-            b->fd_cref = cref; b->fd_slabs = fslabs; b->fd_gate = gate; b->S1d = s1d;
+            b->fd_cref = cref; b->fd_slabs = fslabs; b->fd_gate = gate; b->S1d = s1d; b->fd_ref = fref;
             b->fd_hint_host = hint_host; b->fd_hint_dev = hint_dev;
             const int rc = launch_feature_s1d(b, st, n_probe);
             if (rc == LT_OK && hipStreamSynchronize(st) == hipSuccess) feat = *(volatile int *)hint_host == 0 ? 1 : 0;
-            b->fd_cref = b->fd_slabs = nullptr; b->fd_gate = nullptr; b->S1d = nullptr;
+            b->fd_cref = b->fd_slabs = nullptr; b->fd_gate = nullptr; b->S1d = nullptr; b->fd_ref = nullptr;
             b->fd_hint_host = b->fd_hint_dev = nullptr;
         }
         (void)hipStreamSynchronize(st);
-        (void)hipFree(cref); (void)hipFree(fslabs); (void)hipFree(gate); (void)hipFree(s1d);
+        (void)hipFree(cref); (void)hipFree(fslabs); (void)hipFree(gate); (void)hipFree(s1d); (void)hipFree(fref);
         (void)hipGetLastError();
         *hint_host = 0;
     }
@@ -873,6 +920,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     const int splits = (b->F + ks_ - 1) / ks_;
     double *s1d = nullptr, *z1d = nullptr, *slabs = nullptr, *segd = nullptr, *cref = nullptr, *fslabs = nullptr;
     double *yd = nullptr, *segy = nullptr;
+    float *fref = nullptr;
     int *gate = nullptr;
     int32_t *zst = nullptr, *zrw = nullptr, *zct = nullptr;
     hipError_t e = hipMalloc((void **)&z1d, nh);
@@ -885,6 +933,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fslabs, (size_t)((b->F + 63) / 64) * b->H * sizeof(double));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&gate, sizeof(int));
         if (e == hipSuccess && fd_possible) e = hipMemsetAsync(gate, 0, sizeof(int), st);     // (the slice counter of k_ref_row_product)
+        if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fref, (size_t)(b->F + 64) * sizeof(float));
     }
     if (alloc_agg) {
         if (e == hipSuccess) e = hipMalloc((void **)&yd, n1 * b->Fp * sizeof(double));
@@ -895,13 +944,13 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     }
     if (e != hipSuccess) {   // all or nothing: a retry starts from a clean state, nothing leaks
         (void)hipFree(s1d); (void)hipFree(z1d); (void)hipFree(slabs); (void)hipFree(segd);
-        (void)hipFree(cref); (void)hipFree(fslabs); (void)hipFree(gate);
+        (void)hipFree(cref); (void)hipFree(fslabs); (void)hipFree(gate); (void)hipFree(fref);
         (void)hipFree(yd); (void)hipFree(segy); (void)hipFree(zst); (void)hipFree(zrw); (void)hipFree(zct);
         if (hint_host) (void)hipHostFree(hint_host);
         return lt_set_error(LT_ERR_HIP, "lt_baseline_enable_fp64: hipMalloc failed: %s", hipGetErrorString(e));
     }
     b->S1d = s1d; b->Z1d = z1d; b->slabs_d = slabs; b->seg_d = segd;
-    b->fd_cref = cref; b->fd_slabs = fslabs; b->fd_gate = gate;
+    b->fd_cref = cref; b->fd_slabs = fslabs; b->fd_gate = gate; b->fd_ref = fref;
     b->fd_hint_host = hint_host; b->fd_hint_dev = hint_dev;
     if (!cref && hint_host) { (void)hipHostFree(hint_host); b->fd_hint_host = b->fd_hint_dev = nullptr; }
     b->Yd = yd; b->seg_y = segy; b->zstate = zst; b->zrows = zrw; b->zcount = zct;
@@ -984,6 +1033,8 @@ void lt_baseline_free_fp64(lt_baseline *b) {
     (void)hipFree(b->fd_cref);
     (void)hipFree(b->fd_slabs);
     (void)hipFree(b->fd_gate);
+    (void)hipFree(b->fd_ref);
+    b->fd_ref = nullptr;
     if (b->fd_hint_host) (void)hipHostFree(b->fd_hint_host);
     b->fd_hint_host = b->fd_hint_dev = nullptr;
     (void)hipFree(b->Yd);

@@ -78,7 +78,8 @@ struct lt_baseline {
     bool S1d_owned = true;      // false after lt_baseline_attach_s1d: S1d is caller storage filled by the ranks' all-gather
     bool S1d_external = false;  // the fp64 product arrives from outside (lt_baseline_refresh_rows_fp64 + the caller's all-gather)
     // feature-difference route of the fp64 product (lt_fp64.hip, k_s1d_feature_rows)
-    double *fd_cref = nullptr;  // [Hp] the reference row's product
+    float *fd_ref = nullptr;    // [F] the reference vector m (majority value of each column over the first rows)
+    double *fd_cref = nullptr;  // [Hp] its product m W1
     double *fd_slabs = nullptr; // [ceil(F / 64), H] its split-K partials
     int *fd_gate = nullptr;     // device word: the slice counter of k_ref_row_product
     int *fd_hint_host = nullptr, *fd_hint_dev = nullptr;   // mapped host word the feature kernel sets when it meets dense rows
