@@ -45,7 +45,7 @@ FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 matrix peak
 FP64_MFMA_PEAK_TFLOPS = 78.6
 
 # kernel name (prefix) -> profile class, for the PMC passes
-KERNEL_CLASS = (("k_s1d_feature_rows", "fp64_product"), ("k_ref_row_product", "fp64_product"), ("k_gemm_f64", "fp64_product"),
+KERNEL_CLASS = (("k_s1d_feature_rows", "fp64_product"), ("k_ref_product", "fp64_product"), ("k_ref_vector", "fp64_product"), ("k_gemm_f64", "fp64_product"),
                 ("k_sum_slabs_f64", "fp64_product"), ("k_spmm_f64", "fp64_spmm"), ("k_rows_tiled_f64", "fp64_spmm"),
                 ("k_rows_tiled_xf64", "fp64_spmm"), ("k_z_mark", "fp64_spmm"), ("k_y_long", "fp64_spmm"),
                 ("k_item_bits", "item_bits"), ("k_pm_", "item_bits"), ("k_item_stageA", "item_stageA"),
@@ -478,7 +478,7 @@ def main():
                     "avg_launch_us": us, "units_per_launch": f"per step: X[{rows_x}x{f}] * W1[{f}x{h}] and X'[{n_probe_local} probes] * W1, exact fp32 MFMA"}
         if cls == "fp64_product" and fp64_route == 1:
             alg = n * f * 4 + f * h * 4 + n * hp * 8
-            return {"kernel": "k_s1d_feature_rows (+ k_ref_row_product: the reference row's own product)",
+            return {"kernel": "k_s1d_feature_rows (+ k_ref_product: the reference vector's own product)",
                     "bound": "hbm", "achieved": round(alg / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(alg / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": tr, "algorithmic_bytes_per_launch": int(alg), "avg_launch_us": us,
                     "units_per_launch": f"one pass over X[{n}x{f}] fp32 -> S1d = X*W1 [{n}x{h}] fp64 (feature rows as differences to a reference row); "

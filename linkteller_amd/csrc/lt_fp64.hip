@@ -358,13 +358,15 @@ __global__ void k_spmm_f64_long(int n_long, const int32_t *__restrict__ long_row
 // m[j] = the value most of the rows hold, a row differs from m exactly where its own features are set.  Then the fp64
 // product is one pass over X (N*F*4 bytes) and ~ 20 W1 rows per node instead of 2*N*F*H flops on the f64 matrix cores
 // (twitch-RU: 7.1 GFLOP -> 0.05).
-//   k_ref_row_product   m[j] = the more frequent of (min, max) of column j over the first <= 64 rows, and cref = m W1
+//   k_ref_vector        m[j] = the more frequent of (min, max) of column j over the first <= 64 rows (once per baseline)
+//   k_ref_product       cref = m W1 (every refresh: W1 may have changed)
 //   k_s1d_feature_rows  one wave per row: ALL loads of the row go out first (one HBM round trip), the reference vector is
 //                       staged in LDS meanwhile, the differing columns are compacted into a per-wave LDS list (ballot +
 //                       prefix) and every lane walks the list for its 4 hidden columns.  A row with more differing columns
 //                       than the list holds is read again piecewise (slow and correct); a row with more than `hint_cap`
 //                       sets *dense_hint -- a word of mapped host memory the host looks at before the NEXT refresh to move
 //                       the baseline to the matrix-core product for good.
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
 #define FD_CAP 384
 #define FD_WAVES 4
 #define FD_PU 8          // W1 rows in flight per lane while a list is walked (FD_CAP is a multiple)
@@ -390,13 +392,14 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
 #pragma unroll
         for (int u = 0; u < FD_UN; ++u) {
             const int j = j0 + u * STEP + lane * VEC;
+            // (non-temporal: the 4 N F bytes of X stream past the L2s, which keep W1 for the list walks)
             if constexpr (VEC == 2) {
-                float2 t = make_float2(0.f, 0.f);
-                if (j + 1 < F) t = *reinterpret_cast<const float2 *>(xr + j);
-                else if (j < F) t.x = xr[j];
+                f32x2_ t = {0.f, 0.f};
+                if (j + 1 < F) t = __builtin_nontemporal_load(reinterpret_cast<const f32x2_ *>(xr + j));
+                else if (j < F) t.x = __builtin_nontemporal_load(xr + j);
                 x[u][0] = t.x; x[u][1] = t.y;
             } else {
-                x[u][0] = j < F ? xr[j] : 0.f;
+                x[u][0] = j < F ? __builtin_nontemporal_load(xr + j) : 0.f;
             }
         }
     };
@@ -484,82 +487,96 @@ static size_t fd_smem_bytes(int F) {
 // cnt row gathers per node, the matrix cores F * H at ~10 x the rate
 static int fd_hint_cap(int F) { const int c = F / 16; return c < 8 ? 8 : (c > FD_CAP ? FD_CAP : c); }
 
-// The reference vector and its product, one launch.  Block z owns the 64-deep K slice [64 z, 64 z + 64): it picks m[k] for
-// its columns -- the more frequent of (min, max) of X[0 .. rows, k] over the first rows <= 64 rows: the majority value of a
-// two-valued column -- writes it to ref[], and sums its slice of cref = m W1 for every hidden column; the block that
-// finishes last adds the slices in slice order (a fixed order whoever comes last).
-__global__ __launch_bounds__(256) void k_ref_row_product(int n, int F, int H, int Hp, const float *__restrict__ X, long ldx,
-                                                         const float *__restrict__ W1, float *__restrict__ ref,
-                                                         double *__restrict__ slabs, double *__restrict__ cref,
-                                                         unsigned *__restrict__ counter) {
-    __shared__ unsigned s_last;
-    __shared__ float s_m[64];
-    __shared__ float s_x[4][64];
-    const int k0 = blockIdx.x * 64, k1 = min(F, k0 + 64);
+// The reference vector m[k] = the more frequent of (min, max) of X[0 .. rows, k] over the first rows <= 64 rows: the
+// majority value of a two-valued column.  Computed ONCE (lt_baseline_enable_fp64): any m is a correct reference, so a
+// later change of X costs speed at worst (and the dense hint then retires the route).
+__global__ __launch_bounds__(64) void k_ref_vector(int n, int F, const float *__restrict__ X, long ldx, float *__restrict__ ref) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= F) return;
     const int rows = n < 64 ? n : 64;
-    {   // thread (q, t): column k0 + t, sample rows q, q + 4, ...: min / max, then the count of the min
-        const int t = threadIdx.x & 63, q = threadIdx.x >> 6;
-        const bool ok = k0 + t < k1;
-        float xv[16];
+    float mn = 3.4e38f, mx = -3.4e38f;
+    for (int r = 0; r < rows; ++r) { const float v = X[(long)r * ldx + k]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    int c = 0;
+    for (int r = 0; r < rows; ++r) c += X[(long)r * ldx + k] == mn ? 1 : 0;
+    ref[k] = 2 * c >= rows ? mn : mx;
+}
+
+// cref = m W1 in fp64, one launch per refresh.  Block z owns the 64-deep K slice [64 z, 64 z + 64); thread (kq, cq) sums 16 of
+// its k's for the 4 columns 4 cq .. 4 cq + 3 (one trip of 16 float4 loads), the four k-quarters are added in order through
+// LDS into slabs[z]; the block that finishes last adds the slices in slice order the same way (a fixed order whoever comes
+// last).  H % 4 != 0 takes the column-per-thread form.
+__global__ __launch_bounds__(256) void k_ref_product(int F, int H, int Hp, const float *__restrict__ ref,
+                                                     const float *__restrict__ W1, double *__restrict__ slabs,
+                                                     double *__restrict__ cref, unsigned *__restrict__ counter) {
+    __shared__ unsigned s_last;
+    __shared__ double s_p[4][256];
+    const int k0 = blockIdx.x * 64, k1 = min(F, k0 + 64);
+    const unsigned nz = gridDim.x;
+    if (H % 4 == 0 && H <= 256) {
+        const int kq = threadIdx.x >> 6, cq = threadIdx.x & 63, c0 = 4 * cq;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        if (c0 < H) {
+            f32x4 w[16];
+            float m[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) xv[u] = (ok && q + 4 * u < rows) ? X[(long)(q + 4 * u) * ldx + k0 + t] : 0.f;
-        float mn = 3.4e38f, mx = -3.4e38f;
+            for (int u = 0; u < 16; ++u) {
+                const int k = k0 + 16 * kq + u;
+                m[u] = k < k1 ? ref[k] : 0.f;
+                w[u] = k < k1 ? ld4(W1 + (size_t)k * H + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
-            if (q + 4 * u < rows) { mn = fminf(mn, xv[u]); mx = fmaxf(mx, xv[u]); }
-        s_x[q][t] = mn;
-        __syncthreads();
-        mn = fminf(fminf(s_x[0][t], s_x[1][t]), fminf(s_x[2][t], s_x[3][t]));
-        __syncthreads();
-        s_x[q][t] = mx;
-        __syncthreads();
-        mx = fmaxf(fmaxf(s_x[0][t], s_x[1][t]), fmaxf(s_x[2][t], s_x[3][t]));
-        __syncthreads();
-        int c = 0;
+            for (int u = 0; u < 16; ++u)
 #pragma unroll
-        for (int u = 0; u < 16; ++u) c += (q + 4 * u < rows && xv[u] == mn) ? 1 : 0;
-        s_x[q][t] = (float)c;
-        __syncthreads();
-        if (q == 0) {
-            const float cm = s_x[0][t] + s_x[1][t] + s_x[2][t] + s_x[3][t];
-            const float m = (2.f * cm >= (float)rows) ? mn : mx;
-            s_m[t] = ok ? m : 0.f;
-            if (ok) ref[k0 + t] = m;
+                for (int t = 0; t < 4; ++t) a[t] = fma((double)m[u], (double)w[u][t], a[t]);
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s_p[kq][(c0 + t) & 255] = a[t];
         __syncthreads();
-    }
-    for (int c = threadIdx.x; c < H; c += 256) {
-        double a = 0.0;
-        int k = k0;
-        for (; k + 16 <= k1; k += 16) {          // 16 loads in flight, the chain in k order
-            float w[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) w[u] = W1[(size_t)(k + u) * H + c];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) a = fma((double)s_m[k - k0 + u], (double)w[u], a);
+        for (int c = threadIdx.x; c < H; c += 256) slabs[(size_t)blockIdx.x * H + c] = ((s_p[0][c] + s_p[1][c]) + s_p[2][c]) + s_p[3][c];
+    } else {
+        for (int c = threadIdx.x; c < H; c += 256) {
+            double a = 0.0;
+            for (int k = k0; k < k1; ++k) a = fma((double)ref[k], (double)W1[(size_t)k * H + c], a);
+            slabs[(size_t)blockIdx.x * H + c] = a;
         }
-        for (; k < k1; ++k) a = fma((double)s_m[k - k0], (double)W1[(size_t)k * H + c], a);
-        slabs[(size_t)blockIdx.x * H + c] = a;
     }
     __threadfence();
     __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+    if (threadIdx.x == 0) s_last = atomicAdd(counter, 1u) == nz - 1 ? 1u : 0u;
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    const unsigned nz = gridDim.x;
-    for (int c = threadIdx.x; c < Hp; c += 256) {
-        double a = 0.0;
-        if (c < H) {
-            for (unsigned z = 0; z < nz; z += 16) {      // slices added in slice order, 16 loads in flight
-                double t[16];
+    if (H <= 256) {
+        // thread (zq, c): the slices z = zq, zq + 4, ... of column c in one trip when there are <= 64 of them; the four partial
+        // sums are added in order -- a fixed association of the slices whoever runs this
+        const int zq = threadIdx.x >> 6;
+        for (int cb = 0; cb < H; cb += 64) {
+            const int c = cb + (threadIdx.x & 63);
+            double a = 0.0;
+            if (c < H)
+                for (unsigned z0 = 0; z0 < nz; z0 += 64) {
+                    double t[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) t[u] = z + u < nz ? __builtin_nontemporal_load(slabs + (size_t)(z + u) * H + c) : 0.0;
+                    for (int u = 0; u < 16; ++u) {
+                        const unsigned z = z0 + zq + 4u * u;
+                        t[u] = z < nz ? __builtin_nontemporal_load(slabs + (size_t)z * H + c) : 0.0;
+                    }
 #pragma unroll
-                for (int u = 0; u < 16; ++u) if (z + u < nz) a += t[u];
-            }
+                    for (int u = 0; u < 16; ++u) a += t[u];
+                }
+            __syncthreads();
+            s_p[zq][threadIdx.x & 63] = a;
+            __syncthreads();
+            if (zq == 0 && c < H) cref[c] = ((s_p[0][threadIdx.x] + s_p[1][threadIdx.x]) + s_p[2][threadIdx.x]) + s_p[3][threadIdx.x];
         }
-        cref[c] = a;
+        for (int c = H + threadIdx.x; c < Hp; c += 256) cref[c] = 0.0;
+    } else {
+        for (int c = threadIdx.x; c < Hp; c += 256) {
+            double a = 0.0;
+            if (c < H)
+                for (unsigned z = 0; z < nz; ++z) a += slabs[(size_t)z * H + c];
+            cref[c] = a;
+        }
     }
     if (threadIdx.x == 0) *counter = 0;              // ready for the next launch
 }
@@ -787,8 +804,13 @@ static bool want_feature_rows(const lt_baseline *cb) {
 
 static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1) {
     const int Hp = b->Hp, H = b->H, n = n_rows < 0 ? b->n : n_rows, F = b->F;
-    hipLaunchKernelGGL(k_ref_row_product, dim3((unsigned)((F + 63) / 64)), dim3(256), 0, st, n, F, H, Hp, b->X, (long)b->ldx, b->W1,
-                       b->fd_ref, b->fd_slabs, b->fd_cref, (unsigned *)b->fd_gate);
+    if (!b->fd_ref_valid) {       // once: any reference vector is correct, a good one makes the rows' lists short
+        hipLaunchKernelGGL(k_ref_vector, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, st, n, F, b->X, (long)b->ldx, b->fd_ref);
+        LT_CHECK_LAUNCH();
+        b->fd_ref_valid = true;
+    }
+    hipLaunchKernelGGL(k_ref_product, dim3((unsigned)((F + 63) / 64)), dim3(256), 0, st, F, H, Hp, b->fd_ref, b->W1, b->fd_slabs,
+                       b->fd_cref, (unsigned *)b->fd_gate);
     LT_CHECK_LAUNCH();
     const unsigned blocks = (unsigned)((n + FD_WAVES - 1) / FD_WAVES);
     const size_t smem = fd_smem_bytes(F);
@@ -898,11 +920,11 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
         if (e == hipSuccess) e = hipMalloc((void **)&s1d, (size_t)n_probe * b->Hp * sizeof(double));
         if (e == hipSuccess) {
             b->fd_cref = cref; b->fd_slabs = fslabs; b->fd_gate = gate; b->S1d = s1d; b->fd_ref = fref;
-            b->fd_hint_host = hint_host; b->fd_hint_dev = hint_dev;
+            b->fd_hint_host = hint_host; b->fd_hint_dev = hint_dev; b->fd_ref_valid = false;
             const int rc = launch_feature_s1d(b, st, n_probe);
             if (rc == LT_OK && hipStreamSynchronize(st) == hipSuccess) feat = *(volatile int *)hint_host == 0 ? 1 : 0;
             b->fd_cref = b->fd_slabs = nullptr; b->fd_gate = nullptr; b->S1d = nullptr; b->fd_ref = nullptr;
-            b->fd_hint_host = b->fd_hint_dev = nullptr;
+            b->fd_hint_host = b->fd_hint_dev = nullptr; b->fd_ref_valid = false;
         }
         (void)hipStreamSynchronize(st);
         (void)hipFree(cref); (void)hipFree(fslabs); (void)hipFree(gate); (void)hipFree(s1d); (void)hipFree(fref);
@@ -1035,6 +1057,7 @@ void lt_baseline_free_fp64(lt_baseline *b) {
     (void)hipFree(b->fd_gate);
     (void)hipFree(b->fd_ref);
     b->fd_ref = nullptr;
+    b->fd_ref_valid = false;
     if (b->fd_hint_host) (void)hipHostFree(b->fd_hint_host);
     b->fd_hint_host = b->fd_hint_dev = nullptr;
     (void)hipFree(b->Yd);

@@ -79,6 +79,7 @@ struct lt_baseline {
     bool S1d_external = false;  // the fp64 product arrives from outside (lt_baseline_refresh_rows_fp64 + the caller's all-gather)
     // feature-difference route of the fp64 product (lt_fp64.hip, k_s1d_feature_rows)
     float *fd_ref = nullptr;    // [F] the reference vector m (majority value of each column over the first rows)
+    bool fd_ref_valid = false;
     double *fd_cref = nullptr;  // [Hp] its product m W1
     double *fd_slabs = nullptr; // [ceil(F / 64), H] its split-K partials
     int *fd_gate = nullptr;     // device word: the slice counter of k_ref_row_product
