@@ -278,7 +278,9 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
                                                   const int32_t *__restrict__ seg_begin,
                                                   const int32_t *__restrict__ seg_long,
                                                   const int32_t *__restrict__ long_row,
-                                                  double *__restrict__ seg_out) {
+                                                  double *__restrict__ seg_out, int32_t *__restrict__ state) {
+    // state != NULL (on-demand, lt_fp64_prepare_rows): only the rows marked 2 are formed; a short row is marked 1 (valid) by its
+    // own lane group, a hub row by k_spmm_f64_long once its segments are summed
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int gl = lane & (LPR - 1);
@@ -292,9 +294,12 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
     int e, e1;
     if (SEG) {
+        const int lr = long_row[seg_long[r]];
+        if (state && state[lr] != 2) return;
         e = seg_begin[r];
-        e1 = min(e + LT_ROW_SEG, rowptr[long_row[seg_long[r]] + 1]);
+        e1 = min(e + LT_ROW_SEG, rowptr[lr + 1]);
     } else {
+        if (state && state[r] != 2) return;
         e = rowptr[r];
         e1 = rowptr[r + 1];
         if (seg_blocks > 0 && e1 - e > LT_ROW_SEG) return;
@@ -337,13 +342,21 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
         for (int k = 0; k < 4; ++k) acc[k] += (double)b[k];
     }
     *reinterpret_cast<f64x4 *>((SEG ? seg_out : out) + (size_t)r * ld + coff) = acc;
+    if (state && !SEG && coff == 0) state[r] = 1;
 }
+// the hub rows: segment sums added in segment order + the bias (`state`: as in k_spmm_f64; the marked rows are set valid by a
+// second launch with `finish` = 1, once every column of the row has been written)
 __global__ void k_spmm_f64_long(int n_long, const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_segptr,
                                 const double *__restrict__ part, int ld, const float *__restrict__ b1p,
-                                double *__restrict__ out) {
+                                double *__restrict__ out, int32_t *__restrict__ state, int finish) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (finish) {
+        if (i < n_long && state[long_row[i]] == 2) state[long_row[i]] = 1;
+        return;
+    }
     if (i >= (long)n_long * ld) return;
     const int li = (int)(i / ld), c = (int)(i % ld);
+    if (state && state[long_row[li]] != 2) return;
     double acc = part[(size_t)long_segptr[li] * ld + c];
     for (int sg = long_segptr[li] + 1; sg < long_segptr[li + 1]; ++sg) acc += part[(size_t)sg * ld + c];
     out[(size_t)long_row[li] * ld + c] = acc + (double)b1p[c];
@@ -824,18 +837,19 @@ static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1) {
     return LT_OK;
 }
 
-static int compute_z1d(lt_baseline *b, hipStream_t st) {
+// The fp64 product S1d = X W1 by the baseline's route (nothing on the aggregate-first route), and every pre-activation row
+// marked stale: Z1d is formed afterwards -- for all rows (form_z1d) or only for the rows a call's items read
+// (lt_fp64_prepare_rows / lt_fp64_prepare_items).
+static int compute_s1d(lt_baseline *b, hipStream_t st) {
     if (b->n == 0) return LT_OK;
     const int Hp = b->Hp, H = b->H, n = b->n;
-    if (lt_fp64_agg_active(b)) {
-        // aggregate-first: nothing is computed here; every pre-activation row is stale until a call's items ask for it
-        LT_HIP(hipMemsetAsync(b->zstate, 0, (size_t)n * sizeof(int32_t), st));
-        return LT_OK;
-    }
+    b->z_all_valid = false;
+    LT_HIP(hipMemsetAsync(b->zstate, 0, (size_t)n * sizeof(int32_t), st));
+    if (lt_fp64_agg_active(b)) return LT_OK;
     if (!b->S1d)
         return lt_set_error(LT_ERR_UNSUPPORTED, "fp64 pre-activation: the S1d route was not allocated (set \"aggregate_first\" "
                                                 "before lt_baseline_enable_fp64)");
-    { lt_prof_scope prof_(LT_K_FP64_PRODUCT, st);
+    lt_prof_scope prof_(LT_K_FP64_PRODUCT, st);
     if (b->S1d_external) {
         // multi-GPU: S1d arrives by the caller's all-gather of the ranks' row shards (lt_baseline_refresh_rows_fp64)
     } else if (want_feature_rows(b)) {
@@ -845,20 +859,25 @@ static int compute_z1d(lt_baseline *b, hipStream_t st) {
         if (Hp != H) LT_HIP(hipMemsetAsync(b->S1d, 0, (size_t)n * Hp * sizeof(double), st));
         int rc = launch_dense_s1d(b, 0, n, b->S1d, (long)Hp, st);
         if (rc) return rc;
-    } }
-    lt_prof_scope prof_(LT_K_FP64_SPMM, st);
+    }
+    return LT_OK;
+}
+
+// Z1d = A_hat S1d + b1: every row (state == NULL) or the rows marked 2 in `state`
+static int form_z1d(lt_baseline *b, int32_t *state, hipStream_t st) {
+    const int Hp = b->Hp, n = b->n;
     const int lpr = lt_lpr_for(Hp);
     const unsigned g2 = (unsigned)((n + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr)));
     const lt_graph *g = b->g;
     const int have_long = (g->p_n_long > 0 && b->seg_d) ? 1 : 0;
-    if (lt_tiled_wanted(g, Hp) && (g->p_n_long == 0 || b->seg_d)) {
+    if (!state && lt_tiled_wanted(g, Hp) && (g->p_n_long == 0 || b->seg_d)) {
         // S1d beyond the caches (R-MAT scale 21: 4.3 GB): the column-sliced work-item route of lt_spmm.hip, same chains
         int rc = lt_launch_rows_tiled_f64(g, b->S1d, Hp, Hp, b->b1p, b->Z1d, Hp, b->seg_d, Hp, st);
         if (rc) return rc;
         if (have_long) {
             const long tot = (long)g->p_n_long * Hp;
             hipLaunchKernelGGL(k_spmm_f64_long, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, g->p_n_long,
-                               g->p_long_row, g->p_long_segptr, b->seg_d, Hp, b->b1p, b->Z1d);
+                               g->p_long_row, g->p_long_segptr, b->seg_d, Hp, b->b1p, b->Z1d, (int32_t *)nullptr, 0);
             LT_CHECK_LAUNCH();
         }
         return LT_OK;
@@ -866,19 +885,49 @@ static int compute_z1d(lt_baseline *b, hipStream_t st) {
     const unsigned gs = have_long ? (unsigned)((g->p_n_seg + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr))) : 0u;
     LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_>), dim3(g2 + gs), dim3(256), 0, st, n, g->rowptr,
                                             g->col, g->val, b->S1d, Hp, b->b1p, b->Z1d, (int)gs, g->p_n_seg, g->p_seg_begin,
-                                            g->p_seg_long, g->p_long_row, b->seg_d));
+                                            g->p_seg_long, g->p_long_row, b->seg_d, state));
     LT_CHECK_LAUNCH();
     if (have_long) {
         const long tot = (long)g->p_n_long * Hp;
         hipLaunchKernelGGL(k_spmm_f64_long, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, g->p_n_long,
-                           g->p_long_row, g->p_long_segptr, b->seg_d, Hp, b->b1p, b->Z1d);
+                           g->p_long_row, g->p_long_segptr, b->seg_d, Hp, b->b1p, b->Z1d, state, 0);
         LT_CHECK_LAUNCH();
+        if (state) {
+            hipLaunchKernelGGL(k_spmm_f64_long, dim3((unsigned)((g->p_n_long + 255) / 256)), dim3(256), 0, st, g->p_n_long,
+                               g->p_long_row, g->p_long_segptr, b->seg_d, Hp, b->b1p, b->Z1d, state, 1);
+            LT_CHECK_LAUNCH();
+        }
     }
     return LT_OK;
 }
 
+// S1d routes, per probe chunk of an LT_MODE_DELTA call: make the pre-activation rows the chunk's items read valid.  A call
+// whose items cannot cover much of the graph (n_probe_call * average column length well below n: one rank of many) forms
+// only those rows (k_z_mark + the row kernel restricted to them; rows stay valid for later chunks and calls); otherwise all
+// rows once.  Same chains either way: the bits do not depend on which rows were asked for.
+int lt_fp64_prepare_rows(const lt_baseline *cb, const int32_t *off, int nb, const int2 *item_pr, int n_probe_call, hipStream_t st) {
+    lt_baseline *b = const_cast<lt_baseline *>(cb);   // cache state only
+    if (b->z_all_valid || b->n == 0) return LT_OK;
+    const lt_graph *g = b->g;
+    lt_prof_scope prof_(LT_K_FP64_SPMM, st);
+    const double avg = g->n > 0 ? (double)g->nnz / (double)g->n : 0.0;
+    const int knob = lt_tune().z_on_demand;
+    const bool tiled = lt_tiled_wanted(g, b->Hp) && (g->p_n_long == 0 || b->seg_d);
+    const bool ondemand = !tiled && (knob > 0 || (knob < 0 && (double)n_probe_call * avg * 2.0 < (double)g->n));
+    if (!ondemand) {
+        const int rc = form_z1d(b, nullptr, st);
+        if (rc) return rc;
+        b->z_all_valid = true;
+        return LT_OK;
+    }
+    LT_HIP(hipMemsetAsync(b->zcount, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_z_mark, dim3(256), dim3(256), 0, st, off, nb, item_pr, b->zstate, b->zrows, b->zcount);
+    LT_CHECK_LAUNCH();
+    return form_z1d(b, b->zstate, st);
+}
+
 int lt_baseline_refresh_fp64(lt_baseline *b, hipStream_t st) {
-    return b->Z1d ? compute_z1d(b, st) : LT_OK;
+    return b->Z1d ? compute_s1d(b, st) : LT_OK;
 }
 
 extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
@@ -960,10 +1009,11 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     if (alloc_agg) {
         if (e == hipSuccess) e = hipMalloc((void **)&yd, n1 * b->Fp * sizeof(double));
         if (e == hipSuccess && b->g->p_n_seg > 0) e = hipMalloc((void **)&segy, (size_t)b->g->p_n_seg * b->Fp * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void **)&zst, n1 * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMalloc((void **)&zrw, n1 * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMalloc((void **)&zct, sizeof(int32_t));
     }
+    // per-row validity of Z1d (every route): rows are formed for all, or on demand for the rows a call reads
+    if (e == hipSuccess) e = hipMalloc((void **)&zst, n1 * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&zrw, n1 * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&zct, sizeof(int32_t));
     if (e != hipSuccess) {   // all or nothing: a retry starts from a clean state, nothing leaks
         (void)hipFree(s1d); (void)hipFree(z1d); (void)hipFree(slabs); (void)hipFree(segd);
         (void)hipFree(cref); (void)hipFree(fslabs); (void)hipFree(gate); (void)hipFree(fref);
@@ -979,7 +1029,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     b->S1d_owned = true; b->S1d_external = false; b->feat_sparse = feat; b->agg_default = agg_chosen;
     int rc = lt_baseline_ensure_padding(b, st);   // (the padded bias the fp64 SpMM adds)
     if (rc) return rc;
-    rc = compute_z1d(b, st);
+    rc = compute_s1d(b, st);
     b->fp64_fresh = rc == LT_OK;
     return rc;
 }

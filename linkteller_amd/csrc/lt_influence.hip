@@ -1520,6 +1520,10 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                     const int rc = lt_fp64_prepare_items(b, w.off, nb, w.item_pr, probes, w.Spd, st);
                     if (rc) return rc;
                     spd = w.Spd;
+                } else if (b->Z1d) {
+                    // S1d routes: the pre-activation rows this chunk's items read (all rows, or on demand for a small call)
+                    const int rc = lt_fp64_prepare_rows(b, w.off, nb, w.item_pr, n_probe, st);
+                    if (rc) return rc;
                 }
                 { lt_prof_scope prof_(LT_K_ITEM_A, st);
                 if (b->Z1d) {

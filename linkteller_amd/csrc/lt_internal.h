@@ -101,6 +101,7 @@ struct lt_baseline {
     mutable bool pad_fresh = false;     // b1p / W2p match the borrowed weights
     mutable bool layers_fresh = false;
     mutable bool fp64_fresh = false;
+    mutable bool z_all_valid = false;   // every row of Z1d matches S1d (else: zstate per row)
     // FULL rows on a graph with hub rows: the segment kernel + combine run on `side` next to the plain-row
     // kernel (fork after the probe-row GEMM, join before stage B).  Created on first use.
     mutable hipStream_t side = nullptr;
@@ -127,6 +128,8 @@ struct lt_tuning {
     long long bits_max_bytes;    // SPARSE / DELTA: a bitmap row per probe only while the chunk's rows fit this (default 128 MiB);
                                  // beyond it only the chunk's big probes get rows (LT_BITS_MAX_BYTES)
     int tiled_big;               // 1: the tiled SpMM always uses 64-bit gather offsets (test hook; default: only when S spans >= 4 GiB)
+    int z_on_demand;             // fp64 pre-activation rows of the S1d routes: 1 only the rows a call reads, 0 all rows, -1 by the call's
+                                 // size (LT_Z_ON_DEMAND)
     int stageb_rows;             // SPARSE / DELTA stage B with a bitmap: 1 one block per (observed row, probe slice), 0 one 8-lane group
                                  // per pair (LT_STAGEB_ROWS)
     int aggregate_first;         // fp64 pre-activation as (A_hat X) W1 on the rows a call needs: 0 never, 1 whenever the shapes allow,
@@ -198,6 +201,7 @@ int lt_launch_rows_tiled_xf64(const lt_graph *g, const float *X, int64_t ldx, in
 // aggregate-first route active for this baseline right now?  lt_fp64_prepare_items: per probe chunk of an LT_MODE_DELTA call,
 // the fp64 pre-activation rows the chunk's items read (Z1d) and the probes' own fp64 product rows Spd[nb, Hp]
 bool lt_fp64_agg_active(const lt_baseline *b);
+int lt_fp64_prepare_rows(const lt_baseline *b, const int32_t *off, int nb, const int2 *item_pr, int n_probe_call, hipStream_t st);
 int lt_fp64_prepare_items(const lt_baseline *b, const int32_t *off, int nb, const int2 *item_pr, const int32_t *probes,
                           double *Spd, hipStream_t st);
 int lt_launch_rows_tiled_f64(const lt_graph *g, const double *S, int64_t lds, int ncols, const float *bias_after,

@@ -339,3 +339,39 @@ def test_stage_b_per_observed_row_keeps_every_bit(gpu, family):
     finally:
         _lib.set_tuning("stageb_rows", None)
         _lib.set_tuning("chunk_budget_bytes", None)
+
+
+@pytest.mark.parametrize("features", ["indicator", "gaussian"])
+def test_preactivation_rows_on_demand_keep_every_bit(gpu, features):
+    """On the S1d routes a small `delta` call (one rank of many) forms the fp64 pre-activation only on the rows its items read
+    ("z_on_demand"; rows stay valid until the next refresh), a large one on all rows.  Same chains: pinned on (1) and off (0) the
+    matrices are bit-identical -- hub rows included, across several calls and chunks, and after a refresh."""
+    from test_gpu_parity import _hub_graph
+    from linkteller_amd import _lib, engine, graph, synth
+    n, f = 1400, 600
+    a_hat = graph.first_order_gcn(_hub_graph(n, 6000, 500, seed=8))
+    x = synth.twitch_like_features(n, f, seed=4, density=0.02) if features == "indicator" else synth.gaussian_features(n, f, seed=4)
+    w = synth.gcn_weights(f, 64, 2, seed=5)
+    base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *_params(w, gpu)).enable_fp64()
+    assert base.fp64_route() == (1 if features == "indicator" else 0)
+    rng = np.random.RandomState(2)
+    obs = np.concatenate([[0], rng.choice(np.arange(1, n), 300, replace=False)])
+    calls = [np.concatenate([[0], rng.choice(n, 9, replace=False)]), rng.choice(n, 40, replace=False), rng.choice(n, 400, replace=False)]
+    got = {}
+    try:
+        for knob in (0, 1):
+            _lib.set_tuning("z_on_demand", knob)
+            base.refresh()
+            got[knob] = [base.influence_rows(p, obs, 1e-4, "delta").cpu().numpy() for p in calls]
+            _lib.set_tuning("chunk_budget_bytes", 1 << 15)
+            base.w1.mul_(1.0)      # (no change: a refresh alone must invalidate and rebuild)
+            base.refresh()
+            got[knob] += [base.influence_rows(p, obs, 1e-4, "delta").cpu().numpy() for p in calls]
+            _lib.set_tuning("chunk_budget_bytes", None)
+    finally:
+        _lib.set_tuning("z_on_demand", None)
+        _lib.set_tuning("chunk_budget_bytes", None)
+    for a, b in zip(got[0], got[1]):
+        assert np.array_equal(a, b)
+    for k in range(3):
+        assert np.array_equal(got[0][k], got[0][k + 3]) and got[0][k].max() > 0
