@@ -218,6 +218,15 @@ size_t lt_influence3_workspace_bytes(const lt_baseline3 *b, int32_t n_probe, int
 int lt_influence3_rows(const lt_baseline3 *b, const int32_t *probe_nodes, int32_t n_probe,
                        const int32_t *observe_nodes, int32_t n_obs, float delta,
                        float *out, int64_t ldo, void *workspace, size_t workspace_bytes, void *stream);
+/* The same with a mode: LT_MODE_SPARSE (= LT_MODE_FULL here: lt_influence3_rows, the fp32 finite difference on the 3-hop set)
+ * or LT_MODE_DELTA -- the perturbation propagated exactly through the three layers (no subtraction of nearly equal numbers;
+ * the two ReLU kink tests read fp64-accumulated pre-activations), which needs lt_baseline3_enable_fp64 first: an fp64 copy of
+ * the first two layers' pre-activations (the layer-1 product takes the routes of lt_baseline_enable_fp64), recomputed after
+ * every lt_baseline3_refresh when next needed. */
+int lt_baseline3_enable_fp64(lt_baseline3 *b, void *stream);
+int lt_influence3_rows_mode(const lt_baseline3 *b, const int32_t *probe_nodes, int32_t n_probe,
+                            const int32_t *observe_nodes, int32_t n_obs, float delta, int32_t mode,
+                            float *out, int64_t ldo, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- LapGraph cell selection (worker.py:302-335: A += noise, the n_keep largest cells of the strict lower
  * triangle by a 50-way np.argpartition) --------------------------------------------------------------------------------

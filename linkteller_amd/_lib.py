@@ -69,6 +69,9 @@ SIGNATURES = {
                                      C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "lt_lapgraph_select": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
                                     C.POINTER(C.c_double), C.c_void_p]),
+    "lt_baseline3_enable_fp64": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lt_influence3_rows_mode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p,
+                                         C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "lt_profile_enable": (C.c_int, [C.c_int]),
     "lt_profile_reset": (C.c_int, []),
     "lt_profile_summary": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -150,12 +150,9 @@ class Attacker:
                 mode = "sparse"
             return base.influence_rows(probe_nodes, observe_nodes, float(self.args.influence), mode)
         if self._is_three_layer():
-            # the 3-hop probe primitive: the reference's fp32 finite difference on the rows a probe can reach
-            if self._mode(mode) == "delta" and not getattr(self, "_warned_gcn3", False):
-                print("influence-mode 'delta' is not implemented for the 3-layer model: using the reference's fp32 finite "
-                      "difference on the 3-hop set (lt_influence3_rows)")
-                self._warned_gcn3 = True
-            return self.baseline3().influence_rows(probe_nodes, observe_nodes, float(self.args.influence))
+            # the 3-hop probe primitive: `delta` (default) propagates the perturbation exactly through the three layers,
+            # `sparse` / `full` are the reference's fp32 finite difference on the rows a probe can reach
+            return self.baseline3().influence_rows(probe_nodes, observe_nodes, float(self.args.influence), self._mode(mode))
         return self._rows_generic(probe_nodes, observe_nodes)
 
     def baseline(self, mode=None) -> engine.Baseline:

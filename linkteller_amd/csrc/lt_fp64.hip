@@ -695,7 +695,8 @@ __global__ __launch_bounds__(256) void k_gemm_f64_rows(const AT *__restrict__ A,
                                                        const int32_t *__restrict__ m_dev, int m_host,
                                                        const float *__restrict__ B, long ldb, int N, int K,
                                                        const float *__restrict__ bias, double *__restrict__ C, long ldc,
-                                                       int scatter, int32_t *__restrict__ state) {
+                                                       int scatter, int32_t *__restrict__ state, int relu_a) {
+    // rows == NULL: row(i) = i.  relu_a: A is read through max(., 0) (the hidden activation of a pre-activation matrix)
     __shared__ __attribute__((aligned(16))) double As[GD_BM * GD_LDA];
     __shared__ __attribute__((aligned(16))) float Bs[GD_BK * GD_LDB];
     const int M = m_dev ? *m_dev : m_host;
@@ -710,7 +711,7 @@ __global__ __launch_bounds__(256) void k_gemm_f64_rows(const AT *__restrict__ A,
     for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int m0 = (int)(tile / ntn) * GD_BM, n0 = (int)(tile % ntn) * GD_BN;
         const bool a_ok = m0 + a_row < M;
-        const AT *ap = A + (size_t)(a_ok ? rows[m0 + a_row] : 0) * lda;
+        const AT *ap = A + (size_t)(a_ok ? (rows ? rows[m0 + a_row] : m0 + a_row) : 0) * lda;
         f64x4 acc[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(256) void k_gemm_f64_rows(const AT *__restrict__ A,
             if (a_ok)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (k0 + a_col + j < K) ra[j] = (double)ap[k0 + a_col + j];
+                    if (k0 + a_col + j < K) { const double v = (double)ap[k0 + a_col + j]; ra[j] = (relu_a && v < 0.0) ? 0.0 : v; }
             if (k0 + b_row < K)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -755,7 +756,7 @@ __global__ __launch_bounds__(256) void k_gemm_f64_rows(const AT *__restrict__ A,
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int cm = m0 + wr * 32 + i * 16 + (lane >> 4) + 4 * reg;
-                    if (cm < M) C[(size_t)(scatter ? rows[cm] : cm) * ldc + cn] = acc[i][j][reg] + bv;
+                    if (cm < M) C[(size_t)((scatter && rows) ? rows[cm] : cm) * ldc + cn] = acc[i][j][reg] + bv;
                 }
             }
         if (state && n0 == 0 && tid < GD_BM && m0 + tid < M) state[rows[m0 + tid]] = 1;
@@ -764,7 +765,7 @@ __global__ __launch_bounds__(256) void k_gemm_f64_rows(const AT *__restrict__ A,
 }
 
 static bool agg_shapes_ok(const lt_baseline *b) {
-    return b->n > 0 && b->F <= 2 * b->Hp && lt_round_up(b->F, 4) <= 512 && b->g->w_n > 0;
+    return !b->no_agg && b->n > 0 && b->F <= 2 * b->Hp && lt_round_up(b->F, 4) <= 512 && b->g->w_n > 0;
 }
 bool lt_fp64_agg_active(const lt_baseline *b) {
     if (!b->Z1d || !b->Yd) return false;
@@ -793,13 +794,13 @@ int lt_fp64_prepare_items(const lt_baseline *b, const int32_t *off, int nb, cons
     lt_prof_scope prof_(LT_K_FP64_PRODUCT, st);
     // (Yd rows hold F valid columns; K = F, so the pad columns of Yd are never read)
     hipLaunchKernelGGL((k_gemm_f64_rows<double>), dim3(2048), dim3(256), 0, st, b->Yd, (long)Fp, b->zrows, b->zcount, 0, b->W1,
-                       (long)H, H, F, b->b1, b->Z1d, (long)Hp, 1, b->zstate);
+                       (long)H, H, F, b->b1, b->Z1d, (long)Hp, 1, b->zstate, 0);
     LT_CHECK_LAUNCH();
     if (Hp != H) LT_HIP(hipMemsetAsync(Spd, 0, (size_t)nb * Hp * sizeof(double), st));
     const int tiles = ((nb + GD_BM - 1) / GD_BM) * ((H + GD_BN - 1) / GD_BN);
     hipLaunchKernelGGL((k_gemm_f64_rows<float>), dim3((unsigned)(tiles < 2048 ? tiles : 2048)), dim3(256), 0, st, b->X, (long)b->ldx,
                        probes, (const int32_t *)nullptr, nb, b->W1, (long)H, H, F, (const float *)nullptr, Spd, (long)Hp, 0,
-                       (int32_t *)nullptr);
+                       (int32_t *)nullptr, 0);
     LT_CHECK_LAUNCH();
     return LT_OK;
 }
@@ -924,6 +925,60 @@ int lt_fp64_prepare_rows(const lt_baseline *cb, const int32_t *off, int nb, cons
     hipLaunchKernelGGL(k_z_mark, dim3(256), dim3(256), 0, st, off, nb, item_pr, b->zstate, b->zrows, b->zcount);
     LT_CHECK_LAUNCH();
     return form_z1d(b, b->zstate, st);
+}
+
+// ---- pieces the 3-layer model's `delta` (lt_gcn3.hip) builds its fp64 baseline from ------------------------------------
+// every row of Z1d valid (S1d routes only: the caller set no_agg before lt_baseline_enable_fp64)
+int lt_fp64_form_all(lt_baseline *b, hipStream_t st) {
+    int rc = lt_baseline_ensure_layers(b, true, st, false);
+    if (rc) return rc;
+    if (b->z_all_valid || b->n == 0) return LT_OK;
+    lt_prof_scope prof_(LT_K_FP64_SPMM, st);
+    rc = form_z1d(b, nullptr, st);
+    if (rc) return rc;
+    b->z_all_valid = true;
+    return LT_OK;
+}
+// C[i, 0..N) = act(A[i, 0..K)) * B + bias, i < M, fp64 accumulation on the matrix cores (A double; act = relu when relu_a)
+int lt_launch_gemm_f64_dense(const double *A, long lda, int M, const float *B, long ldb, int N, int K, const float *bias,
+                             double *C, long ldc, int relu_a, hipStream_t st) {
+    if (M <= 0) return LT_OK;
+    const long tiles = (long)((M + GD_BM - 1) / GD_BM) * ((N + GD_BN - 1) / GD_BN);
+    hipLaunchKernelGGL((k_gemm_f64_rows<double>), dim3((unsigned)(tiles < 4096 ? tiles : 4096)), dim3(256), 0, st, A, lda,
+                       (const int32_t *)nullptr, (const int32_t *)nullptr, M, B, ldb, N, K, bias, C, ldc, 0, (int32_t *)nullptr, relu_a);
+    LT_CHECK_LAUNCH();
+    return LT_OK;
+}
+// C[i, 0..N) = A[rows[i], 0..K) * B, i < M, A fp32 (feature rows), fp64 accumulation
+int lt_launch_gemm_f64_gather(const float *A, long lda, const int32_t *rows, int M, const float *B, long ldb, int N, int K,
+                              double *C, long ldc, hipStream_t st) {
+    if (M <= 0) return LT_OK;
+    const long tiles = (long)((M + GD_BM - 1) / GD_BM) * ((N + GD_BN - 1) / GD_BN);
+    hipLaunchKernelGGL((k_gemm_f64_rows<float>), dim3((unsigned)(tiles < 4096 ? tiles : 4096)), dim3(256), 0, st, A, lda, rows,
+                       (const int32_t *)nullptr, M, B, ldb, N, K, (const float *)nullptr, C, ldc, 0, (int32_t *)nullptr, 0);
+    LT_CHECK_LAUNCH();
+    return LT_OK;
+}
+// out[n, ld] = A_hat * S + bias (all rows, fp64 chains; seg_d: [g->p_n_seg, ld] scratch for the hub rows, may be NULL
+// when the graph has none)
+int lt_launch_spmm_f64(const lt_graph *g, const double *S, int ld, const float *biasp, double *out, double *seg_d, hipStream_t st) {
+    const int n = g->n;
+    if (n == 0) return LT_OK;
+    const int lpr = lt_lpr_for(ld);
+    const unsigned g2 = (unsigned)((n + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr)));
+    const int have_long = (g->p_n_long > 0 && seg_d) ? 1 : 0;
+    const unsigned gs = have_long ? (unsigned)((g->p_n_seg + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr))) : 0u;
+    LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_>), dim3(g2 + gs), dim3(256), 0, st, n, g->rowptr, g->col, g->val, S, ld,
+                                            biasp, out, (int)gs, g->p_n_seg, g->p_seg_begin, g->p_seg_long, g->p_long_row, seg_d,
+                                            (int32_t *)nullptr));
+    LT_CHECK_LAUNCH();
+    if (have_long) {
+        const long tot = (long)g->p_n_long * ld;
+        hipLaunchKernelGGL(k_spmm_f64_long, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, g->p_n_long, g->p_long_row,
+                           g->p_long_segptr, seg_d, ld, biasp, out, (int32_t *)nullptr, 0);
+        LT_CHECK_LAUNCH();
+    }
+    return LT_OK;
 }
 
 int lt_baseline_refresh_fp64(lt_baseline *b, hipStream_t st) {

@@ -39,6 +39,13 @@ struct lt_baseline3 {
     float *b1p = nullptr, *b2p = nullptr, *W3p = nullptr;   // zero-padded to Hp1 / Hp2 / [Hp2, C]
     float *slabs = nullptr;     // split-K partials of X W1
     float *seg_part = nullptr;  // [g->p_n_seg, Hp2] segment sums of the hub rows (layer 2)
+    // fp64 baseline for the exact (delta) propagation, lt_baseline3_enable_fp64: the layer-1 pre-activation Z1d lives in an
+    // inner 2-layer baseline handle (its fp64 routes: feature rows / matrix cores), the layer-2 one here
+    lt_baseline *l1 = nullptr;
+    double *S2d = nullptr;      // [n, Hp2]  relu(Z1d) W2
+    double *Z2d = nullptr;      // [n, Hp2]  A S2d + b2
+    double *seg2d = nullptr;    // [g->p_n_seg, Hp2]
+    bool fp64_fresh = false;
 };
 
 // h[dst] = relu(A[r,:] S + bias): all rows (items == NULL), or the level-1 items of a probe chunk, whose row reads
@@ -208,6 +215,137 @@ __global__ __launch_bounds__(LT_BLOCK) void k3_stageC(
     if (q == 0) out[(long)b * ldo + j] = res;
 }
 
+// ---- exact propagation (LT_MODE_DELTA) for three layers ---------------------------------------------------------------
+// The perturbation itself is pushed through the layers: dS1[v] = d * S1[v]; on the level-1 items dZ1[r] = A[r,v] dS1[v] and
+// dH1 = relu(Z1 + dZ1) - relu(Z1) evaluated piecewise on the fp64 pre-activation (the kink test of the 2-layer delta mode);
+// dS2 = dH1 W2 (the MFMA GEMM over the items); on the level-2 items dZ2[q] = sum over the members r of R1 in row q of
+// A[q,r] dS2[r], dH2 likewise on the fp64 layer-2 pre-activation Z2d, dS3 = dH2 W3; the observed rows sum A[u,q] dS3[q] over
+// the members of R2.  No subtraction of nearly equal numbers anywhere.
+__device__ __forceinline__ float relu_diff(double z, float dz) {
+    const double z1 = z + (double)dz;
+    return z > 0.0 ? (z1 > 0.0 ? dz : (float)(-z)) : (z1 > 0.0 ? (float)z1 : 0.f);
+}
+template <int LPR>
+__global__ __launch_bounds__(LT_BLOCK) void k3d_items1(
+    const int32_t *__restrict__ tptr, const int32_t *__restrict__ trow, const float *__restrict__ tval,
+    const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off, const double *__restrict__ Spd,
+    const double *__restrict__ Z1d, int Hp, float delta, float *__restrict__ dH1x) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int coff = 4 * (lane & (LPR - 1));
+    const int total = off[nb];
+    const int wave0 = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
+    const int nwaves = gridDim.x * (LT_BLOCK / 64);
+    for (int base = wave0 * RPW; base < total; base += nwaves * RPW) {
+        const int it = base + lane / LPR;
+        if (it >= total || coff >= Hp) continue;
+        const int b = find_probe(off, nb, it);
+        const int v = probes[b];
+        const int t = tptr[v] + (it - off[b]);
+        const int r = trow[t];
+        const float arv = tval[t];
+        const double *sp = Spd + (size_t)b * Hp + coff, *zp = Z1d + (size_t)r * Hp + coff;
+        f32x4 dh;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dh[k] = relu_diff(zp[k], arv * (delta * (float)sp[k]));
+        *reinterpret_cast<f32x4 *>(dH1x + (size_t)it * Hp + coff) = dh;
+    }
+}
+
+template <int LPR, int CP>
+__global__ __launch_bounds__(LT_BLOCK) void k3d_stageB(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
+    const double *__restrict__ Z2d, int Hp2, const float *__restrict__ W3p, int C, const int32_t *__restrict__ off,
+    const float *__restrict__ dS2x, const uint2 *__restrict__ bits1, int words, const int2 *__restrict__ items2,
+    const int32_t *__restrict__ n_items2, int n, float *__restrict__ dS3x) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & (LPR - 1);
+    const int coff = 4 * gl;
+    const bool active = coff < Hp2;
+    const int total = *n_items2;
+    const int wave0 = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
+    const int nwaves = gridDim.x * (LT_BLOCK / 64);
+    for (int base = wave0 * RPW; base < total; base += nwaves * RPW) {
+        const int it = base + lane / LPR;
+        const bool live = it < total;   // group-uniform; dead groups still join the shuffles
+        float part[CP];
+#pragma unroll
+        for (int c = 0; c < CP; ++c) part[c] = 0.f;
+        int b = 0, q = 0;
+        if (live) {
+            const int2 w = items2[it];
+            b = w.x; q = w.y;
+            if (active) {
+                const uint2 *mb = bits1 + (size_t)b * words;
+                const float *items = dS2x + (size_t)off[b] * Hp2;
+                f32x4 dz = {0.f, 0.f, 0.f, 0.f};
+                for (int e = rowptr[q]; e < rowptr[q + 1]; ++e) {        // members of R1 only, in entry order
+                    const int p = bits_pos(mb, col[e]);
+                    if (p >= 0) dz = fma4(val[e], ld4(items + (size_t)p * Hp2 + coff), dz);
+                }
+                const double *zp = Z2d + (size_t)q * Hp2 + coff;
+                float dh[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dh[k] = relu_diff(zp[k], dz[k]);
+                const float *w3 = W3p + (size_t)coff * C;
+#pragma unroll
+                for (int c = 0; c < CP; ++c)
+                    if (c < C) {
+                        float pr = dh[0] * w3[c];
+                        pr = fmaf(dh[1], w3[C + c], pr);
+                        pr = fmaf(dh[2], w3[2 * C + c], pr);
+                        pr = fmaf(dh[3], w3[3 * C + c], pr);
+                        part[c] = pr;
+                    }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CP; ++c) part[c] = group_sum<LPR>(part[c]);
+        if (live && gl == 0) {
+#pragma unroll
+            for (int c = 0; c < CP; ++c)
+                if (c < C) dS3x[((size_t)b * n + q) * C + c] = part[c];
+        }
+    }
+}
+
+template <int CP>
+__global__ __launch_bounds__(LT_BLOCK) void k3d_stageC(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val, int C, int nb, int n,
+    const float *__restrict__ dS3x, const uint32_t *__restrict__ bits2, int words, const int32_t *__restrict__ observe,
+    int n_obs, float delta, float *__restrict__ out, long ldo) {
+    const long gid = ((long)blockIdx.x * LT_BLOCK + threadIdx.x) / LT_L2_LANES;
+    const int q = threadIdx.x & (LT_L2_LANES - 1);
+    if (gid >= (long)nb * n_obs) return;
+    const int b = (int)(gid / n_obs), j = (int)(gid % n_obs);
+    const int u = observe[j];
+    const uint32_t *mb = bits2 + (size_t)b * words;
+    const float *mine = dS3x + (size_t)b * n * C;
+    const int e0 = rowptr[u], e1 = rowptr[u + 1];
+    auto member = [&](int c) { return ((mb[c >> 5] >> (c & 31)) & 1u) != 0u; };
+    bool touch = false;
+    for (int e = e0 + q; e < e1; e += LT_L2_LANES) touch |= member(col[e]);
+    int t = touch ? 1 : 0;
+#pragma unroll
+    for (int m = LT_L2_LANES / 2; m >= 1; m >>= 1) t |= __shfl_xor(t, m, 64);
+    float res = 0.f;
+    if (t) {
+        float acc[CP];
+        row2_dot<CP>(col, val, e0, e1, q, C,
+                     [&](int c, int) { return member(c) ? mine + (size_t)c * C : (const float *)nullptr; }, acc);
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < CP; ++c)
+            if (c < C) {
+                const float d = acc[c] / delta;
+                ss = fmaf(d, d, ss);
+            }
+        res = sqrtf(ss);
+    }
+    if (q == 0) out[(long)b * ldo + j] = res;
+}
+
 __global__ void k3_pad(const float *__restrict__ b1, int H1, int Hp1, const float *__restrict__ b2, int H2, int Hp2,
                        const float *__restrict__ W3, int C, float *__restrict__ b1p, float *__restrict__ b2p,
                        float *__restrict__ W3p) {
@@ -223,6 +361,8 @@ static void free_baseline3(lt_baseline3 *b) {
     (void)hipFree(b->S1); (void)hipFree(b->Act1); (void)hipFree(b->S2); (void)hipFree(b->Z2); (void)hipFree(b->S3);
     (void)hipFree(b->OUT); (void)hipFree(b->b1p); (void)hipFree(b->b2p); (void)hipFree(b->W3p); (void)hipFree(b->slabs);
     (void)hipFree(b->seg_part);
+    (void)hipFree(b->S2d); (void)hipFree(b->Z2d); (void)hipFree(b->seg2d);
+    if (b->l1) (void)lt_baseline_destroy(b->l1);
     delete b;
 }
 
@@ -233,6 +373,8 @@ extern "C" int lt_baseline3_refresh(lt_baseline3 *b, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const lt_graph *g = b->g;
     const int n = b->n;
+    b->fp64_fresh = false;
+    if (b->l1) (void)lt_baseline_refresh(b->l1, stream);
     if (n == 0) return LT_OK;
     const int mx = (b->Hp1 > b->Hp2 * b->C ? b->Hp1 : b->Hp2 * b->C);
     hipLaunchKernelGGL(k3_pad, dim3((mx + 255) / 256), dim3(256), 0, st, b->b1, b->H1, b->Hp1, b->b2, b->H2, b->Hp2, b->W3,
@@ -321,9 +463,52 @@ extern "C" int lt_baseline3_logits(const lt_baseline3 *b, float *dst, void *stre
     return LT_OK;
 }
 
+// fp64 baseline of the first two layers (the kink tests of LT_MODE_DELTA): Z1d through an inner 2-layer handle over the
+// same borrowed X / W1 / b1 (so that it takes the fp64 product routes of lt_fp64.hip), S2d = relu(Z1d) W2 and
+// Z2d = A S2d + b2 here.  Costs one more copy of the layer-1 buffers; redone after every lt_baseline3_refresh when next needed.
+extern "C" int lt_baseline3_enable_fp64(lt_baseline3 *b, void *stream) {
+    LT_REQUIRE(b != nullptr, "lt_baseline3_enable_fp64: baseline is NULL");
+    if (b->Z2d) return LT_OK;
+    lt_baseline *l1 = nullptr;
+    // (W2 / b2 of the inner handle are never used for arithmetic: only its fp64 pre-activation is read; C = 1 keeps its
+    // padding kernel inside W2's first H1 floats)
+    int rc = lt_baseline_create(b->g, b->X, b->ldx, b->F, b->W1, b->b1, b->H1, b->W2, b->b2, 1, stream, &l1);
+    if (rc) return rc;
+    l1->no_agg = true;
+    rc = lt_baseline_enable_fp64(l1, stream);
+    if (rc) { (void)lt_baseline_destroy(l1); return rc; }
+    const size_t n1 = (size_t)(b->n > 0 ? b->n : 1);
+    double *s2d = nullptr, *z2d = nullptr, *seg = nullptr;
+    hipError_t e = hipMalloc((void **)&s2d, n1 * b->Hp2 * sizeof(double));
+    if (e == hipSuccess) e = hipMemsetAsync(s2d, 0, n1 * b->Hp2 * sizeof(double), (hipStream_t)stream);   // pad columns stay zero
+    if (e == hipSuccess) e = hipMalloc((void **)&z2d, n1 * b->Hp2 * sizeof(double));
+    if (e == hipSuccess && b->g->p_n_seg > 0) e = hipMalloc((void **)&seg, (size_t)b->g->p_n_seg * b->Hp2 * sizeof(double));
+    if (e != hipSuccess) {
+        (void)hipFree(s2d); (void)hipFree(z2d); (void)hipFree(seg); (void)lt_baseline_destroy(l1);
+        return lt_set_error(LT_ERR_HIP, "lt_baseline3_enable_fp64: hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    b->l1 = l1; b->S2d = s2d; b->Z2d = z2d; b->seg2d = seg;
+    b->fp64_fresh = false;
+    return LT_OK;
+}
+
+static int ensure3_fp64(const lt_baseline3 *cb, hipStream_t st) {
+    lt_baseline3 *b = const_cast<lt_baseline3 *>(cb);   // cache state only
+    if (b->fp64_fresh || b->n == 0) return LT_OK;
+    int rc = lt_fp64_form_all(b->l1, st);               // Z1d, every row
+    if (rc) return rc;
+    rc = lt_launch_gemm_f64_dense(b->l1->Z1d, (long)b->Hp1, b->n, b->W2, (long)b->H2, b->H2, b->H1, nullptr, b->S2d, (long)b->Hp2, 1, st);
+    if (rc) return rc;
+    rc = lt_launch_spmm_f64(b->g, b->S2d, b->Hp2, b->b2p, b->Z2d, b->seg2d, st);
+    if (rc) return rc;
+    b->fp64_fresh = true;
+    return LT_OK;
+}
+
 // ---- workspace ------------------------------------------------------------------------------
 struct infl3_ws {
     float *Sp, *slabs, *H1x, *S2x, *S3x;
+    double *Spd;            // delta: fp64 product rows of the chunk's probes [chunk, Hp1]
     int32_t *off, *n_items2;
     uint2 *bits1;
     uint32_t *bits2;
@@ -355,6 +540,7 @@ static infl3_ws carve3(void *base, const lt_baseline3 *b, int n_probe) {
         return q;
     };
     w.Sp = (float *)take(chunk * Hp1 * sizeof(float));
+    w.Spd = (double *)take(chunk * Hp1 * sizeof(double));
     w.slabs = (float *)take(lt_gemm_splitk_slab_bytes((int)chunk, b->H1, b->F, probe_kslice3(b)));
     w.off = (int32_t *)take((chunk + 1) * sizeof(int32_t));
     w.n_items2 = (int32_t *)take(sizeof(int32_t));
@@ -377,7 +563,17 @@ extern "C" size_t lt_influence3_workspace_bytes(const lt_baseline3 *b, int32_t n
 extern "C" int lt_influence3_rows(const lt_baseline3 *b, const int32_t *probe_nodes, int32_t n_probe,
                                   const int32_t *observe_nodes, int32_t n_obs, float delta, float *out, int64_t ldo,
                                   void *workspace, size_t workspace_bytes, void *stream) {
+    return lt_influence3_rows_mode(b, probe_nodes, n_probe, observe_nodes, n_obs, delta, LT_MODE_SPARSE, out, ldo, workspace,
+                                   workspace_bytes, stream);
+}
+
+extern "C" int lt_influence3_rows_mode(const lt_baseline3 *b, const int32_t *probe_nodes, int32_t n_probe,
+                                       const int32_t *observe_nodes, int32_t n_obs, float delta, int32_t mode, float *out,
+                                       int64_t ldo, void *workspace, size_t workspace_bytes, void *stream) {
     LT_REQUIRE(b != nullptr, "lt_influence3_rows: baseline is NULL");
+    LT_REQUIRE(mode == LT_MODE_SPARSE || mode == LT_MODE_FULL || mode == LT_MODE_DELTA, "lt_influence3_rows_mode: unknown mode %d", mode);
+    const bool exact = mode == LT_MODE_DELTA;
+    LT_REQUIRE(!exact || b->Z2d != nullptr, "lt_influence3_rows_mode: LT_MODE_DELTA needs lt_baseline3_enable_fp64");
     LT_REQUIRE(n_probe >= 0 && n_obs >= 0, "lt_influence3_rows: negative count");
     LT_REQUIRE(delta != 0.f && delta == delta, "lt_influence3_rows: delta must be a non-zero number");
     if (n_probe == 0 || n_obs == 0) return LT_OK;
@@ -394,29 +590,45 @@ extern "C" int lt_influence3_rows(const lt_baseline3 *b, const int32_t *probe_no
     const int lpr1 = lt_lpr_for(Hp1), lpr2 = lt_lpr_for(Hp2);
     const int words = (n + 31) / 32;
     const long maxc = g->max_col_nnz > 0 ? g->max_col_nnz : 1;
+    if (exact) {
+        const int rc = ensure3_fp64(b, st);
+        if (rc) return rc;
+    }
     for (int p0 = 0; p0 < n_probe; p0 += w.chunk) {
         const int nb = (n_probe - p0) < w.chunk ? (n_probe - p0) : w.chunk;
         const int32_t *probes = probe_nodes + p0;
         float *orow = out + (int64_t)p0 * ldo;
         LT_REQUIRE(((long)nb * n_obs * LT_L2_LANES + LT_BLOCK - 1) / LT_BLOCK < 2147483647L,
                    "lt_influence3_rows: %d probes x %d observed nodes per chunk exceed the grid limit", nb, n_obs);
-        // perturbed rows: Sp = (X[v] + X[v] d) W1, the slicing of the baseline product          attacker.py:101-105
-        if (Hp1 != b->H1) LT_HIP(hipMemsetAsync(w.Sp, 0, (size_t)nb * Hp1 * sizeof(float), st));
-        int rc = lt_launch_gemm_splitk(b->X, b->ldx, b->W1, b->H1, w.Sp, Hp1, nb, b->H1, b->F, probe_kslice3(b), w.slabs, st,
-                                       probes, delta);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_item_bits, dim3(nb), dim3(256), 0, st, g->tptr, g->trow, probes, nb, words, w.bits1, w.off, (int2 *)nullptr, (uint2 *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
-        LT_CHECK_LAUNCH();
-        // level 1: H1x rows, then S2x = H1x W2 (M = number of items, only known on the device: the GEMM runs over the
-        // chunk's upper bound nb * max column length and rows past the item count are never read)
-        LT_DISPATCH_LPR(lpr1, hipLaunchKernelGGL((k3_rows_relu<LPR_>), dim3(LT3_GRID), dim3(LT_BLOCK), 0, st, 0, g->rowptr,
-                                                 g->col, g->val, b->S1, Hp1, b->b1p, w.H1x, g->tptr, g->trow, probes, nb, w.off,
-                                                 w.Sp));
-        LT_CHECK_LAUNCH();
-        // the GEMM's M is the item count, which lives on the device (off[nb]): its grid covers the chunk's bound
-        // nb * max column length and the tiles past the count exit -- no read-back, no host synchronisation
         const long m_bound = (long)nb * maxc;
         LT_REQUIRE(m_bound < 2147483647L, "lt_influence3_rows: %d probes x %ld rows per chunk exceed the grid limit", nb, maxc);
+        int rc;
+        if (!exact) {
+            // perturbed rows: Sp = (X[v] + X[v] d) W1, the slicing of the baseline product          attacker.py:101-105
+            if (Hp1 != b->H1) LT_HIP(hipMemsetAsync(w.Sp, 0, (size_t)nb * Hp1 * sizeof(float), st));
+            rc = lt_launch_gemm_splitk(b->X, b->ldx, b->W1, b->H1, w.Sp, Hp1, nb, b->H1, b->F, probe_kslice3(b), w.slabs, st,
+                                       probes, delta);
+            if (rc) return rc;
+        } else {
+            // the probes' own product rows in fp64 (dS1[v] = d * S1[v])
+            if (Hp1 != b->H1) LT_HIP(hipMemsetAsync(w.Spd, 0, (size_t)nb * Hp1 * sizeof(double), st));
+            rc = lt_launch_gemm_f64_gather(b->X, (long)b->ldx, probes, nb, b->W1, (long)b->H1, b->H1, b->F, w.Spd, (long)Hp1, st);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_item_bits, dim3(nb), dim3(256), 0, st, g->tptr, g->trow, probes, nb, words, w.bits1, w.off, (int2 *)nullptr, (uint2 *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+        LT_CHECK_LAUNCH();
+        // level 1: H1x rows (sparse: recomputed with row v substituted; delta: the change dH1), then S2x = H1x W2 (M = number of
+        // items, only known on the device: the GEMM runs over the chunk's upper bound nb * max column length, the tiles
+        // past the count exit -- no read-back, no host synchronisation)
+        if (!exact) {
+            LT_DISPATCH_LPR(lpr1, hipLaunchKernelGGL((k3_rows_relu<LPR_>), dim3(LT3_GRID), dim3(LT_BLOCK), 0, st, 0, g->rowptr,
+                                                     g->col, g->val, b->S1, Hp1, b->b1p, w.H1x, g->tptr, g->trow, probes, nb, w.off,
+                                                     w.Sp));
+        } else {
+            LT_DISPATCH_LPR(lpr1, hipLaunchKernelGGL((k3d_items1<LPR_>), dim3(LT3_GRID), dim3(LT_BLOCK), 0, st, g->tptr, g->trow,
+                                                     g->tval, probes, nb, w.off, w.Spd, b->l1->Z1d, Hp1, delta, w.H1x));
+        }
+        LT_CHECK_LAUNCH();
         if (Hp2 != b->H2) LT_HIP(hipMemsetAsync(w.S2x, 0, (size_t)m_bound * Hp2 * sizeof(float), st));
         rc = lt_launch_gemm_mdev(w.H1x, Hp1, b->W2, b->H2, w.S2x, Hp2, (int)m_bound, w.off + nb, b->H2, b->H1, st);
         if (rc) return rc;
@@ -426,15 +638,24 @@ extern "C" int lt_influence3_rows(const lt_baseline3 *b, const int32_t *probe_no
         hipLaunchKernelGGL(k3_mark2, dim3(LT3_GRID), dim3(LT_BLOCK), 0, st, g->tptr, g->trow, probes, nb, w.off, words, w.bits2,
                            w.items2, w.n_items2);
         LT_CHECK_LAUNCH();
-        LT_DISPATCH_LPR(lpr2, LT_DISPATCH_CP(cp,
-            hipLaunchKernelGGL((k3_stageB<LPR_, CP_>), dim3(LT3_GRID), dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, b->S2,
-                               Hp2, b->b2p, b->W3p, C, w.off, w.S2x, w.bits1, words, w.items2, w.n_items2, n, w.S3x)));
-        LT_CHECK_LAUNCH();
-        // level 3: observed rows
         const unsigned gridC = (unsigned)(((long)nb * n_obs * LT_L2_LANES + LT_BLOCK - 1) / LT_BLOCK);
-        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k3_stageC<CP_>), dim3(gridC), dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
-                                              b->S3, C, b->b3, b->OUT, nb, n, w.S3x, w.bits2, words, observe_nodes, n_obs,
-                                              delta, orow, (long)ldo));
+        if (!exact) {
+            LT_DISPATCH_LPR(lpr2, LT_DISPATCH_CP(cp,
+                hipLaunchKernelGGL((k3_stageB<LPR_, CP_>), dim3(LT3_GRID), dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, b->S2,
+                                   Hp2, b->b2p, b->W3p, C, w.off, w.S2x, w.bits1, words, w.items2, w.n_items2, n, w.S3x)));
+            LT_CHECK_LAUNCH();
+            // level 3: observed rows
+            LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k3_stageC<CP_>), dim3(gridC), dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
+                                                  b->S3, C, b->b3, b->OUT, nb, n, w.S3x, w.bits2, words, observe_nodes, n_obs,
+                                                  delta, orow, (long)ldo));
+        } else {
+            LT_DISPATCH_LPR(lpr2, LT_DISPATCH_CP(cp,
+                hipLaunchKernelGGL((k3d_stageB<LPR_, CP_>), dim3(LT3_GRID), dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, b->Z2d,
+                                   Hp2, b->W3p, C, w.off, w.S2x, w.bits1, words, w.items2, w.n_items2, n, w.S3x)));
+            LT_CHECK_LAUNCH();
+            LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k3d_stageC<CP_>), dim3(gridC), dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
+                                                  C, nb, n, w.S3x, w.bits2, words, observe_nodes, n_obs, delta, orow, (long)ldo));
+        }
         LT_CHECK_LAUNCH();
     }
     return LT_OK;

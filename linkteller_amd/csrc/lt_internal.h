@@ -89,6 +89,7 @@ struct lt_baseline {
     // probes reach, nothing for the others -- no n x F x H product, no S1d
     int Fp = 0;                 // F rounded up to a multiple of 4 (leading dimension of Yd)
     bool agg_default = false;   // the route lt_baseline_enable_fp64 chose for these shapes / features
+    bool no_agg = false;        // set before lt_baseline_enable_fp64: never the aggregate-first route (lt_gcn3.hip needs S1d / all rows)
     double *Yd = nullptr;       // [n, Fp] (A_hat X) rows, valid where zstate != 0
     double *seg_y = nullptr;    // [g->p_n_seg, Fp] segment sums of the long rows
     int32_t *zstate = nullptr;  // [n] 0: Z1d row not computed since the last refresh, 2: wanted by the chunk in flight, 1: valid
@@ -201,6 +202,12 @@ int lt_launch_rows_tiled_xf64(const lt_graph *g, const float *X, int64_t ldx, in
 // aggregate-first route active for this baseline right now?  lt_fp64_prepare_items: per probe chunk of an LT_MODE_DELTA call,
 // the fp64 pre-activation rows the chunk's items read (Z1d) and the probes' own fp64 product rows Spd[nb, Hp]
 bool lt_fp64_agg_active(const lt_baseline *b);
+int lt_fp64_form_all(lt_baseline *b, hipStream_t st);
+int lt_launch_gemm_f64_dense(const double *A, long lda, int M, const float *B, long ldb, int N, int K, const float *bias,
+                             double *C, long ldc, int relu_a, hipStream_t st);
+int lt_launch_gemm_f64_gather(const float *A, long lda, const int32_t *rows, int M, const float *B, long ldb, int N, int K,
+                              double *C, long ldc, hipStream_t st);
+int lt_launch_spmm_f64(const lt_graph *g, const double *S, int ld, const float *biasp, double *out, double *seg_d, hipStream_t st);
 int lt_fp64_prepare_rows(const lt_baseline *b, const int32_t *off, int nb, const int2 *item_pr, int n_probe_call, hipStream_t st);
 int lt_fp64_prepare_items(const lt_baseline *b, const int32_t *off, int nb, const int2 *item_pr, const int32_t *probes,
                           double *Spd, hipStream_t st);

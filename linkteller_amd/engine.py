@@ -347,6 +347,7 @@ class Baseline3:
         self._h = h
         self._finalizer = weakref.finalize(self, _lib.lib().lt_baseline3_destroy, h)
         self._ws = {}
+        self._fp64 = False
 
     def refresh(self):
         _lib.check(_lib.lib().lt_baseline3_refresh(self._h, _stream()), "lt_baseline3_refresh")
@@ -356,10 +357,19 @@ class Baseline3:
         _lib.check(_lib.lib().lt_baseline3_logits(self._h, out.data_ptr(), _stream()), "lt_baseline3_logits")
         return out
 
+    def enable_fp64(self):
+        """fp64 pre-activations of the first two layers for the exact (`delta`) propagation (lt_baseline3_enable_fp64)."""
+        if not self._fp64:
+            _lib.check(_lib.lib().lt_baseline3_enable_fp64(self._h, _stream()), "lt_baseline3_enable_fp64")
+            self._fp64 = True
+        return self
+
     def influence_rows(self, probe_nodes, observe_nodes, delta: float, mode="sparse", out=None) -> torch.Tensor:
-        if mode not in ("sparse", "full", None):
-            raise NotImplementedError("the 3-layer probe primitive evaluates the fp32 finite difference ('sparse'); "
-                                      "there is no 'delta' propagation for GCN3")
+        """`sparse` (= `full`): the reference's fp32 finite difference on the rows a probe reaches in 1 / 2 / 3 hops;
+        `delta`: the perturbation propagated exactly through the three layers (lt_influence3_rows_mode)."""
+        m = _lib.MODES[mode or "sparse"] if isinstance(mode, str) or mode is None else int(mode)
+        if m == _lib.MODE_DELTA:
+            self.enable_fp64()
         dev = self.x.device
         probes = _as_nodes(probe_nodes, self.n, dev, "probe_nodes")
         obs = _as_nodes(observe_nodes, self.n, dev, "observe_nodes")
@@ -374,9 +384,9 @@ class Baseline3:
         if ws is None or ws.numel() < need:
             ws = _workspace(need, dev)
             self._ws = {key: ws}
-        _lib.check(_lib.lib().lt_influence3_rows(self._h, probes.data_ptr(), npb, obs.data_ptr(), nob, float(delta),
-                                                 out.data_ptr(), nob, ws.data_ptr(), ws.numel(), _stream()),
-                   "lt_influence3_rows")
+        _lib.check(_lib.lib().lt_influence3_rows_mode(self._h, probes.data_ptr(), npb, obs.data_ptr(), nob, float(delta), m,
+                                                      out.data_ptr(), nob, ws.data_ptr(), ws.numel(), _stream()),
+                   "lt_influence3_rows_mode")
         return out
 
 

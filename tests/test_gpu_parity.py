@@ -281,7 +281,12 @@ def test_gcn3_efficient_attack_on_device(gpu, tmp_path, monkeypatch):
     atk.prepare_test_data()
     assert np.array_equal(atk.test_nodes, g["gcn3.ref32.test_nodes"])
     assert atk._is_three_layer()
-    infl = atk.influence_matrix()                              # lt_influence3_rows: the 3-hop probe primitive
+    infl = atk.influence_matrix("sparse")                      # lt_influence3_rows: the 3-hop probe primitive (fp32 finite difference)
+    exact = atk.influence_matrix("delta")                      # the perturbation propagated exactly through the three layers
+    ref64_ = g["gcn3.ref64.influence_val"]
+    print(f"gcn3 delta: |ours-ref64| / max = {np.abs(exact - ref64_).max() / ref64_.max():.2e}")
+    assert np.abs(exact - ref64_).max() <= 1e-5 * ref64_.max() and np.all(exact[ref64_ == 0] == 0)
+    assert np.array_equal(atk.influence_matrix(), exact)       # `delta` is the default mode, for three layers too
     ref64, ref32 = g["gcn3.ref64.influence_val"], g["gcn3.ref32.influence_val"]
     e32 = np.abs(ref32 - ref64).max()
     print(f"gcn3: |ref32-ref64|={e32:.3e} |ours-ref64|={np.abs(infl - ref64).max():.3e}")

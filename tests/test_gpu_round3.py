@@ -375,3 +375,75 @@ def test_preactivation_rows_on_demand_keep_every_bit(gpu, features):
         assert np.array_equal(a, b)
     for k in range(3):
         assert np.array_equal(got[0][k], got[0][k + 3]) and got[0][k].max() > 0
+
+
+@pytest.mark.parametrize("h1,h2,c,hub,features", [(32, 16, 2, False, "gaussian"), (100, 36, 3, True, "gaussian"),
+                                                  (256, 64, 2, True, "indicator"), (20, 256, 8, False, "indicator")])
+def test_gcn3_delta_mode_against_the_fp64_oracle(gpu, h1, h2, c, hub, features):
+    """`--n-layer 3` (gcn/models.py:28-46) with `--influence-mode delta`: the perturbation propagated exactly through the
+    three layers (lt_influence3_rows_mode, two ReLU kink tests on fp64 pre-activations).  Within 1e-5 of the largest score of
+    the reference evaluated in fp64 (oracle, verbatim op sequence), exact zeros off the 3-hop set, chunking transparent, a
+    refresh after an in-place weight change picked up; the fp32 finite difference (`sparse`) of the same baseline sits in
+    its recorded noise class next to it."""
+    import scipy.sparse as sp
+    from test_gpu_parity import _hub_graph
+    from linkteller_amd import _lib, engine, graph, synth
+    from oracle import linkteller_oracle as O
+    n, f = (700, 400) if hub else (220, 300)
+    if hub:
+        a = _hub_graph(n, 2500, 400, seed=h1)
+    else:
+        a = synth.powerlaw_graph(n, 600, seed=h1).tolil()
+        for k in (5, 17, 99):
+            a[k, :] = 0
+            a[:, k] = 0
+        a = sp.csr_matrix(a)
+        a.eliminate_zeros()
+    a_hat = graph.first_order_gcn(a)
+    x = synth.gaussian_features(n, f, seed=3) if features == "gaussian" else synth.twitch_like_features(n, f, seed=3, density=0.03)
+    rng = np.random.RandomState(h2)
+
+    def u(shape, fan):
+        s = 1.0 / np.sqrt(fan)
+        return rng.uniform(-s, s, size=shape).astype(np.float32)
+
+    P = dict(W1=u((f, h1), h1), b1=u((h1,), h1), W2=u((h1, h2), h2), b2=u((h2,), h2), W3=u((h2, c), c), b3=u((c,), c))
+    dev_p = [torch.from_numpy(P[k]).to(gpu) for k in ("W1", "b1", "W2", "b2", "W3", "b3")]
+    base = engine.Baseline3(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *dev_p)
+    probes = np.concatenate([rng.choice(n, 19, replace=False), [0, 5], [3, 3]])
+    observe = np.concatenate([rng.choice(n, 40, replace=False), [0, 99]])
+    adj_t = O.to_torch_sparse(a_hat)
+
+    def oracle(params):
+        Pd = {k: torch.from_numpy(v).double() for k, v in params.items()}
+        xt = torch.from_numpy(x).double()
+        m = np.zeros((len(probes), len(observe)))
+        with torch.no_grad():
+            for i, v in enumerate(probes):
+                gm = O.get_gradient_eps_mat(xt, adj_t.double(), Pd, int(v), 1e-4, forward=O.gcn3_forward)
+                m[i] = gm[torch.as_tensor(observe)].norm(dim=1).numpy()
+        return m
+
+    ref64 = oracle(P)
+    scale = ref64.max()
+    got = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
+    err = np.abs(got - ref64).max() / scale
+    print(f"gcn3 delta h1={h1} h2={h2} c={c} hub={hub} {features}: max {scale:.3g}, |delta - ref64| / max = {err:.2e}")
+    assert err <= 1e-5
+    assert np.all(got[ref64 == 0] == 0)
+    assert np.array_equal(got[-1], got[-2])                         # duplicate probe -> identical rows
+    sparse = base.influence_rows(probes, observe, 1e-4, "sparse").cpu().numpy().astype(np.float64)
+    assert np.abs(sparse - got).max() <= 0.05 * scale + 0.05
+    _lib.set_tuning("chunk_budget_bytes", 1 << 19)
+    try:
+        chunked = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
+    finally:
+        _lib.set_tuning("chunk_budget_bytes", None)
+    assert np.array_equal(chunked, got)
+    base.w2.mul_(1.03)
+    base.b1.add_(0.002)
+    base.refresh()
+    P2 = dict(P, W2=base.w2.cpu().numpy(), b1=base.b1.cpu().numpy())
+    ref2 = oracle(P2)
+    got2 = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
+    assert np.abs(got2 - ref2).max() <= 1e-5 * ref2.max()
