@@ -586,6 +586,26 @@ def main():
                                     "ms_per_step": round(res_h[a.mode] * 1e3, 4),
                                     **{f"{m}_ms_per_step": round(res_h[m] * 1e3, 4) for m in res_h if m != a.mode}}
             del base_h, out_h
+        # BASELINE configs[2] on ONE GPU (the config itself shards n_test = 2000 over 8): the same graph, 2000 probes x 2000 observed
+        if a.n_test != 2000 and n >= 2000:
+            np.random.seed(42)
+            nodes3 = torch.from_numpy(np.random.choice(np.arange(n), 2000, replace=False).astype(np.int32)).to(dev)
+            out3 = torch.empty((2000, 2000), dtype=torch.float32, device=dev)
+            res3 = {}
+            for m in ("delta", "sparse", "full"):
+                for _ in range(2):
+                    base.refresh(m); base.influence_rows(nodes3, nodes3, delta, m, out=out3)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    base.refresh(m); base.influence_rows(nodes3, nodes3, delta, m, out=out3)
+                torch.cuda.synchronize()
+                res3[m] = (time.perf_counter() - t0) / 5
+            extras["workload_3"] = {"workload": f"n_test=2000 on the same graph, one GPU (BASELINE configs[2] shards it over 8)",
+                                    "value": round(2000 ** 2 / res3[a.mode], 1), "unit": "node-pairs/s", "mode": a.mode,
+                                    **{f"{m}_ms_per_step": round(res3[m] * 1e3, 4) for m in res3}}
+            del out3
+            base.refresh()
         # standalone SpMM (lt_spmm_csr_f32) on this graph (cache-resident) and on the R-MAT graph of configs[4]
         def time_spmm(g_, s_, reps=20):
             for _ in range(3):
