@@ -84,6 +84,9 @@ int lt_device_count(int *count);
  *                         exact for any X): 0 = never, 1 = always try, negative = when lt_baseline_enable_fp64 found the
  *                         features to be of that kind (default).  The only knob that changes fp64 summation ORDER (the
  *                         results agree to ~1e-16 relative before the final rounding to fp32).
+ *   "defer_cref"          feature-difference route: 1 = the reference vector's product m W1 is formed by extra blocks of the rows'
+ *                         launch and added by the readers of S1d (the fp64 SpMM, stage A) (default), 0 = formed first and added
+ *                         by the rows kernel.  fp64 summation order only, like "feature_delta"
  *   "z_on_demand"         LT_MODE_DELTA on the S1d routes: 1 = the fp64 pre-activation is formed only on the rows a call's items
  *                         read (they stay valid until the next refresh), 0 = on all rows at the first call after a refresh,
  *                         negative = by the call's size (default: on demand when probes x average column length < n / 2)

@@ -278,7 +278,10 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
                                                   const int32_t *__restrict__ seg_begin,
                                                   const int32_t *__restrict__ seg_long,
                                                   const int32_t *__restrict__ long_row,
-                                                  double *__restrict__ seg_out, int32_t *__restrict__ state) {
+                                                  double *__restrict__ seg_out, int32_t *__restrict__ state,
+                                                  const double *__restrict__ rs, const double *__restrict__ crefv) {
+    // crefv != NULL: S holds the feature rows' products WITHOUT the reference vector's (S1d - cref, lt_fp64 "deferred cref");
+    // the row's share rs[r] * cref (rs = the row sum of A_hat) is added with the bias
     // state != NULL (on-demand, lt_fp64_prepare_rows): only the rows marked 2 are formed; a short row is marked 1 (valid) by its
     // own lane group, a hub row by k_spmm_f64_long once its segments are summed
     constexpr int RPW = 64 / LPR;
@@ -338,6 +341,11 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
     }
     if (!SEG) {
         const f32x4 b = ld4(b1p + coff);
+        if (crefv) {
+            const double w = rs[r];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = fma(w, crefv[coff + k], acc[k]);
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[k] += (double)b[k];
     }
@@ -348,7 +356,8 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
 // second launch with `finish` = 1, once every column of the row has been written)
 __global__ void k_spmm_f64_long(int n_long, const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_segptr,
                                 const double *__restrict__ part, int ld, const float *__restrict__ b1p,
-                                double *__restrict__ out, int32_t *__restrict__ state, int finish) {
+                                double *__restrict__ out, int32_t *__restrict__ state, int finish,
+                                const double *__restrict__ rs, const double *__restrict__ crefv) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (finish) {
         if (i < n_long && state[long_row[i]] == 2) state[long_row[i]] = 1;
@@ -359,6 +368,7 @@ __global__ void k_spmm_f64_long(int n_long, const int32_t *__restrict__ long_row
     if (state && state[long_row[li]] != 2) return;
     double acc = part[(size_t)long_segptr[li] * ld + c];
     for (int sg = long_segptr[li] + 1; sg < long_segptr[li + 1]; ++sg) acc += part[(size_t)sg * ld + c];
+    if (crefv) acc = fma(rs[long_row[li]], crefv[c], acc);
     out[(size_t)long_row[li] * ld + c] = acc + (double)b1p[c];
 }
 
@@ -388,14 +398,43 @@ template <int VEC>   // floats per lane and load: 2 when the rows of X are 8-byt
 __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     int n, int F, int H, int Hp, const float *__restrict__ X, long ldx, const float *__restrict__ ref,
     const float *__restrict__ W1, const double *__restrict__ cref, double *__restrict__ S1d, int hint_cap,
-    int *__restrict__ dense_hint) {
+    int *__restrict__ dense_hint, int nslab, double *__restrict__ slabs) {
+    // The first nslab blocks of the launch (deferred cref, nslab > 0) form the K slices of cref = m W1 instead of rows:
+    // block z sums slice [64 z, 64 z + 64) for every hidden column (thread (kq, cq): 16 k's x 4 columns, one trip; the four
+    // k-quarters added in order through LDS) into slabs[z]; k_cref_sum adds the slices afterwards, and the rows below are
+    // written WITHOUT cref (cref == NULL), which the fp64 SpMM and stage A add where they read them.
     extern __shared__ __attribute__((aligned(16))) unsigned char fd_smem[];
+    if ((int)blockIdx.x < nslab) {
+        double (*s_p)[256] = reinterpret_cast<double (*)[256]>(fd_smem);           // [4][256] (H <= 256, H % 4 == 0)
+        const int k0 = blockIdx.x * 64, k1 = min(F, k0 + 64);
+        const int kq = threadIdx.x >> 6, cq = threadIdx.x & 63, cc = 4 * cq;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        if (cc < H) {
+            f32x4 w[16];
+            float m[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = k0 + 16 * kq + u;
+                m[u] = k < k1 ? ref[k] : 0.f;
+                w[u] = k < k1 ? ld4(W1 + (size_t)k * H + cc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a[t] = fma((double)m[u], (double)w[u][t], a[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s_p[kq][(cc + t) & 255] = a[t];
+        __syncthreads();
+        for (int c = threadIdx.x; c < H; c += 256) slabs[(size_t)blockIdx.x * H + c] = ((s_p[0][c] + s_p[1][c]) + s_p[2][c]) + s_p[3][c];
+        return;
+    }
     float *sref = reinterpret_cast<float *>(fd_smem);                              // [Fp] the reference vector
     const int Fp = (F + 1) & ~1;
     double *ldv = reinterpret_cast<double *>(fd_smem + (((size_t)Fp * 4 + 15) & ~(size_t)15));   // [FD_WAVES][FD_CAP]
     int *lj = reinterpret_cast<int *>(ldv + FD_WAVES * FD_CAP);                    // [FD_WAVES][FD_CAP]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int i = blockIdx.x * FD_WAVES + wid;
+    const int i = ((int)blockIdx.x - nslab) * FD_WAVES + wid;
     const bool live = i < n;                        // (waves past the last row still help staging and join the barrier)
     const float *xr = X + (long)(live ? i : 0) * ldx;
     constexpr int STEP = 64 * VEC;
@@ -489,12 +528,13 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     if (!own) return;
     f64x4 o;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) o[t] = c0 + t < H ? cref[c0 + t] + acc[t] : 0.0;
+    for (int t = 0; t < 4; ++t) o[t] = c0 + t < H ? (cref ? cref[c0 + t] + acc[t] : acc[t]) : 0.0;
     *reinterpret_cast<f64x4 *>(S1d + (size_t)i * Hp + c0) = o;
 }
 static size_t fd_smem_bytes(int F) {
     const size_t Fp = (size_t)((F + 1) & ~1);
-    return ((Fp * 4 + 15) & ~(size_t)15) + (size_t)FD_WAVES * FD_CAP * (sizeof(double) + sizeof(int));
+    const size_t need = ((Fp * 4 + 15) & ~(size_t)15) + (size_t)FD_WAVES * FD_CAP * (sizeof(double) + sizeof(int));
+    return need < 8192 ? 8192 : need;      // (the slab blocks of the deferred-cref launch use 4 x 256 doubles of it)
 }
 // rows with more differing columns than this are "dense" for the route decision: the list walk costs ~ cnt * H fp64 FMAs and
 // cnt row gathers per node, the matrix cores F * H at ~10 x the rate
@@ -592,6 +632,40 @@ __global__ __launch_bounds__(256) void k_ref_product(int F, int H, int Hp, const
         }
     }
     if (threadIdx.x == 0) *counter = 0;              // ready for the next launch
+}
+
+// cref[c] = sum of the nz slices of slabs in a fixed association (thread (zq, c): slices zq, zq + 4, ..., then the four
+// partial sums in order); one block -- everything it reads was written by the previous launch
+__global__ __launch_bounds__(256) void k_cref_sum(int nz, int H, int Hp, const double *__restrict__ slabs, double *__restrict__ cref) {
+    __shared__ double s_p[4][64];
+    const int zq = threadIdx.x >> 6;
+    for (int cb = 0; cb < Hp; cb += 64) {
+        const int c = cb + (threadIdx.x & 63);
+        double a = 0.0;
+        if (c < H)
+            for (int z0 = 0; z0 < nz; z0 += 64) {
+                double t[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int z = z0 + zq + 4 * u;
+                    t[u] = z < nz ? slabs[(size_t)z * H + c] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) a += t[u];
+            }
+        __syncthreads();
+        s_p[zq][threadIdx.x & 63] = a;
+        __syncthreads();
+        if (zq == 0 && c < Hp) cref[c] = c < H ? ((s_p[0][threadIdx.x] + s_p[1][threadIdx.x]) + s_p[2][threadIdx.x]) + s_p[3][threadIdx.x] : 0.0;
+    }
+}
+// rs[r] = sum of row r of A_hat, fp64 (entry order)
+__global__ void k_row_sums(int n, const int32_t *__restrict__ rowptr, const float *__restrict__ val, double *__restrict__ rs) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    double a = 0.0;
+    for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) a += (double)val[e];
+    rs[r] = a;
 }
 
 // K slice of the fp64 product (64x64 tiles, 4 waves, 8 workgroups per CU): the fewest slices (at least 400 deep) whose
@@ -816,25 +890,38 @@ static bool want_feature_rows(const lt_baseline *cb) {
     return knob == 0 ? false : (knob > 0 ? true : b->feat_sparse != 0);
 }
 
-static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1) {
+static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, bool defer = false) {
     const int Hp = b->Hp, H = b->H, n = n_rows < 0 ? b->n : n_rows, F = b->F;
     if (!b->fd_ref_valid) {       // once: any reference vector is correct, a good one makes the rows' lists short
         hipLaunchKernelGGL(k_ref_vector, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, st, n, F, b->X, (long)b->ldx, b->fd_ref);
         LT_CHECK_LAUNCH();
         b->fd_ref_valid = true;
     }
-    hipLaunchKernelGGL(k_ref_product, dim3((unsigned)((F + 63) / 64)), dim3(256), 0, st, F, H, Hp, b->fd_ref, b->W1, b->fd_slabs,
-                       b->fd_cref, (unsigned *)b->fd_gate);
-    LT_CHECK_LAUNCH();
-    const unsigned blocks = (unsigned)((n + FD_WAVES - 1) / FD_WAVES);
+    const int nz = (F + 63) / 64;
+    // deferred cref: the slices of m W1 ride in the rows' own launch, one block adds them afterwards, and the readers of
+    // S1d add cref themselves (H a multiple of 4 and <= 256: the slab blocks' layout)
+    defer = defer && H % 4 == 0 && H <= 256 && b->fd_rs != nullptr;
+    if (!defer) {
+        hipLaunchKernelGGL(k_ref_product, dim3((unsigned)nz), dim3(256), 0, st, F, H, Hp, b->fd_ref, b->W1, b->fd_slabs,
+                           b->fd_cref, (unsigned *)b->fd_gate);
+        LT_CHECK_LAUNCH();
+    }
+    const int nslab = defer ? nz : 0;
+    const double *cref = defer ? (const double *)nullptr : b->fd_cref;
+    const unsigned blocks = (unsigned)((n + FD_WAVES - 1) / FD_WAVES + nslab);
     const size_t smem = fd_smem_bytes(F);
     if (b->ldx % 2 == 0 && ((uintptr_t)b->X % 8) == 0)
         hipLaunchKernelGGL((k_s1d_feature_rows<2>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx,
-                           b->fd_ref, b->W1, b->fd_cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev);
+                           b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs);
     else
         hipLaunchKernelGGL((k_s1d_feature_rows<1>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx,
-                           b->fd_ref, b->W1, b->fd_cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev);
+                           b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs);
     LT_CHECK_LAUNCH();
+    if (defer) {
+        hipLaunchKernelGGL(k_cref_sum, dim3(1), dim3(256), 0, st, nz, H, Hp, b->fd_slabs, b->fd_cref);
+        LT_CHECK_LAUNCH();
+    }
+    b->cref_deferred = defer;
     return LT_OK;
 }
 
@@ -851,10 +938,13 @@ static int compute_s1d(lt_baseline *b, hipStream_t st) {
         return lt_set_error(LT_ERR_UNSUPPORTED, "fp64 pre-activation: the S1d route was not allocated (set \"aggregate_first\" "
                                                 "before lt_baseline_enable_fp64)");
     lt_prof_scope prof_(LT_K_FP64_PRODUCT, st);
+    b->cref_deferred = false;
     if (b->S1d_external) {
         // multi-GPU: S1d arrives by the caller's all-gather of the ranks' row shards (lt_baseline_refresh_rows_fp64)
     } else if (want_feature_rows(b)) {
-        int rc = launch_feature_s1d(b, st);          // (writes the pad columns of S1d as zeros itself)
+        // (writes the pad columns of S1d as zeros itself; cref deferred to the readers unless the SpMM takes the tiled route)
+        const bool tiled = lt_tiled_wanted(b->g, Hp) && (b->g->p_n_long == 0 || b->seg_d);
+        int rc = launch_feature_s1d(b, st, -1, !tiled && lt_tune().defer_cref != 0);
         if (rc) return rc;
     } else {
         if (Hp != H) LT_HIP(hipMemsetAsync(b->S1d, 0, (size_t)n * Hp * sizeof(double), st));
@@ -878,24 +968,26 @@ static int form_z1d(lt_baseline *b, int32_t *state, hipStream_t st) {
         if (have_long) {
             const long tot = (long)g->p_n_long * Hp;
             hipLaunchKernelGGL(k_spmm_f64_long, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, g->p_n_long,
-                               g->p_long_row, g->p_long_segptr, b->seg_d, Hp, b->b1p, b->Z1d, (int32_t *)nullptr, 0);
+                               g->p_long_row, g->p_long_segptr, b->seg_d, Hp, b->b1p, b->Z1d, (int32_t *)nullptr, 0,
+                               (const double *)nullptr, (const double *)nullptr);
             LT_CHECK_LAUNCH();
         }
         return LT_OK;
     }
     const unsigned gs = have_long ? (unsigned)((g->p_n_seg + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr))) : 0u;
+    const double *crefv = b->cref_deferred ? b->fd_cref : nullptr;      // (deferred cref: S1d holds S1d - cref)
     LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_>), dim3(g2 + gs), dim3(256), 0, st, n, g->rowptr,
                                             g->col, g->val, b->S1d, Hp, b->b1p, b->Z1d, (int)gs, g->p_n_seg, g->p_seg_begin,
-                                            g->p_seg_long, g->p_long_row, b->seg_d, state));
+                                            g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv));
     LT_CHECK_LAUNCH();
     if (have_long) {
         const long tot = (long)g->p_n_long * Hp;
         hipLaunchKernelGGL(k_spmm_f64_long, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, g->p_n_long,
-                           g->p_long_row, g->p_long_segptr, b->seg_d, Hp, b->b1p, b->Z1d, state, 0);
+                           g->p_long_row, g->p_long_segptr, b->seg_d, Hp, b->b1p, b->Z1d, state, 0, b->fd_rs, crefv);
         LT_CHECK_LAUNCH();
         if (state) {
             hipLaunchKernelGGL(k_spmm_f64_long, dim3((unsigned)((g->p_n_long + 255) / 256)), dim3(256), 0, st, g->p_n_long,
-                               g->p_long_row, g->p_long_segptr, b->seg_d, Hp, b->b1p, b->Z1d, state, 1);
+                               g->p_long_row, g->p_long_segptr, b->seg_d, Hp, b->b1p, b->Z1d, state, 1, b->fd_rs, crefv);
             LT_CHECK_LAUNCH();
         }
     }
@@ -970,12 +1062,12 @@ int lt_launch_spmm_f64(const lt_graph *g, const double *S, int ld, const float *
     const unsigned gs = have_long ? (unsigned)((g->p_n_seg + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr))) : 0u;
     LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_>), dim3(g2 + gs), dim3(256), 0, st, n, g->rowptr, g->col, g->val, S, ld,
                                             biasp, out, (int)gs, g->p_n_seg, g->p_seg_begin, g->p_seg_long, g->p_long_row, seg_d,
-                                            (int32_t *)nullptr));
+                                            (int32_t *)nullptr, (const double *)nullptr, (const double *)nullptr));
     LT_CHECK_LAUNCH();
     if (have_long) {
         const long tot = (long)g->p_n_long * ld;
         hipLaunchKernelGGL(k_spmm_f64_long, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, g->p_n_long, g->p_long_row,
-                           g->p_long_segptr, seg_d, ld, biasp, out, (int32_t *)nullptr, 0);
+                           g->p_long_segptr, seg_d, ld, biasp, out, (int32_t *)nullptr, 0, (const double *)nullptr, (const double *)nullptr);
         LT_CHECK_LAUNCH();
     }
     return LT_OK;
@@ -1047,6 +1139,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     double *s1d = nullptr, *z1d = nullptr, *slabs = nullptr, *segd = nullptr, *cref = nullptr, *fslabs = nullptr;
     double *yd = nullptr, *segy = nullptr;
     float *fref = nullptr;
+    double *frs = nullptr;
     int *gate = nullptr;
     int32_t *zst = nullptr, *zrw = nullptr, *zct = nullptr;
     hipError_t e = hipMalloc((void **)&z1d, nh);
@@ -1060,6 +1153,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&gate, sizeof(int));
         if (e == hipSuccess && fd_possible) e = hipMemsetAsync(gate, 0, sizeof(int), st);     // (the slice counter of k_ref_row_product)
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fref, (size_t)(b->F + 64) * sizeof(float));
+        if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&frs, n1 * sizeof(double));
     }
     if (alloc_agg) {
         if (e == hipSuccess) e = hipMalloc((void **)&yd, n1 * b->Fp * sizeof(double));
@@ -1071,13 +1165,17 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     if (e == hipSuccess) e = hipMalloc((void **)&zct, sizeof(int32_t));
     if (e != hipSuccess) {   // all or nothing: a retry starts from a clean state, nothing leaks
         (void)hipFree(s1d); (void)hipFree(z1d); (void)hipFree(slabs); (void)hipFree(segd);
-        (void)hipFree(cref); (void)hipFree(fslabs); (void)hipFree(gate); (void)hipFree(fref);
+        (void)hipFree(cref); (void)hipFree(fslabs); (void)hipFree(gate); (void)hipFree(fref); (void)hipFree(frs);
         (void)hipFree(yd); (void)hipFree(segy); (void)hipFree(zst); (void)hipFree(zrw); (void)hipFree(zct);
         if (hint_host) (void)hipHostFree(hint_host);
         return lt_set_error(LT_ERR_HIP, "lt_baseline_enable_fp64: hipMalloc failed: %s", hipGetErrorString(e));
     }
     b->S1d = s1d; b->Z1d = z1d; b->slabs_d = slabs; b->seg_d = segd;
-    b->fd_cref = cref; b->fd_slabs = fslabs; b->fd_gate = gate; b->fd_ref = fref;
+    b->fd_cref = cref; b->fd_slabs = fslabs; b->fd_gate = gate; b->fd_ref = fref; b->fd_rs = frs;
+    if (frs && b->n > 0) {
+        hipLaunchKernelGGL(k_row_sums, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, st, b->n, b->g->rowptr, b->g->val, frs);
+        LT_CHECK_LAUNCH();
+    }
     b->fd_hint_host = hint_host; b->fd_hint_dev = hint_dev;
     if (!cref && hint_host) { (void)hipHostFree(hint_host); b->fd_hint_host = b->fd_hint_dev = nullptr; }
     b->Yd = yd; b->seg_y = segy; b->zstate = zst; b->zrows = zrw; b->zcount = zct;
@@ -1161,7 +1259,10 @@ void lt_baseline_free_fp64(lt_baseline *b) {
     (void)hipFree(b->fd_slabs);
     (void)hipFree(b->fd_gate);
     (void)hipFree(b->fd_ref);
+    (void)hipFree(b->fd_rs);
     b->fd_ref = nullptr;
+    b->fd_rs = nullptr;
+    b->cref_deferred = false;
     b->fd_ref_valid = false;
     if (b->fd_hint_host) (void)hipHostFree(b->fd_hint_host);
     b->fd_hint_host = b->fd_hint_dev = nullptr;

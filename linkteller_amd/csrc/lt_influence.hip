@@ -630,7 +630,8 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
     const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
     const float *__restrict__ Sp, float delta, float *__restrict__ S2x, int n_long,
     const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_segptr,
-    const float *__restrict__ seg_part, const int2 *__restrict__ item_pr, const double *__restrict__ Spd) {
+    const float *__restrict__ seg_part, const int2 *__restrict__ item_pr, const double *__restrict__ Spd,
+    const double *__restrict__ crefv) {
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int gl = lane & (LPR - 1);
@@ -659,6 +660,10 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
                     if (DELTA == 2) {   // the probe's S1 row off the fp64 product (the fp32 one is not even computed for this mode)
                         // (aggregate-first route: the probes' own product rows Spd[b], there is no S1d)
                         const double *sp = Spd ? Spd + (size_t)b * Hp + coff : S1d + (size_t)v * Hp + coff;
+                        if (crefv && !Spd)     // deferred cref: S1d holds the rows without the reference vector's product
+                            s = f32x4{(float)(sp[0] + crefv[coff]), (float)(sp[1] + crefv[coff + 1]), (float)(sp[2] + crefv[coff + 2]),
+                                      (float)(sp[3] + crefv[coff + 3])};
+                        else
                         s = f32x4{(float)sp[0], (float)sp[1], (float)sp[2], (float)sp[3]};
                     } else {
                         s = ld4(S1 + (size_t)v * Hp + coff);
@@ -1481,7 +1486,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, g->tptr,
                                        g->trow, g->tval, b->S1, b->Z1, b->Z1d, b->S1d, Hp, b->b1p, b->W2p, C, probes, nb,
                                        w.off, w.Sp, delta, w.S2x, g->p_n_long, g->p_long_row, g->p_long_segptr,
-                                       b->seg_part, w.item_pr, (const double *)nullptr))); }
+                                       b->seg_part, w.item_pr, (const double *)nullptr, (const double *)nullptr))); }
                 LT_CHECK_LAUNCH();
                 lt_prof_scope prof_(LT_K_ITEM_B, st);
                 if (long_blocks > 0 && hub_short) {
@@ -1532,14 +1537,16 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                            st, g->rowptr, g->col, g->val, g->tptr, g->trow, g->tval, b->S1,
                                            b->Z1, b->Z1d, b->S1d, Hp, b->b1p, b->W2p, C, probes, nb, w.off,
                                            (const float *)nullptr, delta, w.S2x, 0, (const int32_t *)nullptr,
-                                           (const int32_t *)nullptr, (const float *)nullptr, w.item_pr, spd)));
+                                           (const int32_t *)nullptr, (const float *)nullptr, w.item_pr, spd,
+                                           b->cref_deferred ? b->fd_cref : (const double *)nullptr)));
                 } else {
                     LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
                         hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, 1>), dim3(LT_ITEM_GRID), dim3(LT_BLOCK), 0,
                                            st, g->rowptr, g->col, g->val, g->tptr, g->trow, g->tval, b->S1,
                                            b->Z1, b->Z1d, b->S1d, Hp, b->b1p, b->W2p, C, probes, nb, w.off,
                                            (const float *)nullptr, delta, w.S2x, 0, (const int32_t *)nullptr,
-                                           (const int32_t *)nullptr, (const float *)nullptr, w.item_pr, (const double *)nullptr)));
+                                           (const int32_t *)nullptr, (const float *)nullptr, w.item_pr, (const double *)nullptr,
+                                           (const double *)nullptr)));
                 } }
                 LT_CHECK_LAUNCH();
                 lt_prof_scope prof_(LT_K_ITEM_B, st);

@@ -80,6 +80,8 @@ struct lt_baseline {
     // feature-difference route of the fp64 product (lt_fp64.hip, k_s1d_feature_rows)
     float *fd_ref = nullptr;    // [F] the reference vector m (majority value of each column over the first rows)
     bool fd_ref_valid = false;
+    double *fd_rs = nullptr;    // [n] row sums of A_hat in fp64 (deferred cref: Z1d[r] += rs[r] * cref)
+    mutable bool cref_deferred = false;   // S1d currently holds S1d - cref: its readers add fd_cref themselves
     double *fd_cref = nullptr;  // [Hp] its product m W1
     double *fd_slabs = nullptr; // [ceil(F / 64), H] its split-K partials
     int *fd_gate = nullptr;     // device word: the slice counter of k_ref_row_product
@@ -129,6 +131,8 @@ struct lt_tuning {
     long long bits_max_bytes;    // SPARSE / DELTA: a bitmap row per probe only while the chunk's rows fit this (default 128 MiB);
                                  // beyond it only the chunk's big probes get rows (LT_BITS_MAX_BYTES)
     int tiled_big;               // 1: the tiled SpMM always uses 64-bit gather offsets (test hook; default: only when S spans >= 4 GiB)
+    int defer_cref;              // feature-difference route: 1 the reference vector's product rides in the rows' launch and is added by the
+                                 // readers of S1d, 0 it is formed first and added by the rows kernel (LT_DEFER_CREF)
     int z_on_demand;             // fp64 pre-activation rows of the S1d routes: 1 only the rows a call reads, 0 all rows, -1 by the call's
                                  // size (LT_Z_ON_DEMAND)
     int stageb_rows;             // SPARSE / DELTA stage B with a bitmap: 1 one block per (observed row, probe slice), 0 one 8-lane group

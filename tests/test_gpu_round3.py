@@ -176,6 +176,15 @@ def test_feature_difference_route_of_the_fp64_product(gpu):
         _lib.set_tuning("feature_delta", None)
     assert np.abs(dense - ref64).max() <= 1e-5 * ref64.max()
     assert np.abs(dense - got).max() <= 1e-6 * ref64.max()
+    # the reference vector's product formed first and added by the rows kernel, instead of riding in its launch
+    _lib.set_tuning("defer_cref", 0)
+    try:
+        base.refresh()
+        early = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
+    finally:
+        _lib.set_tuning("defer_cref", None)
+        base.refresh()
+    assert np.abs(early - ref64).max() <= 1e-5 * ref64.max() and np.abs(early - got).max() <= 1e-6 * ref64.max()
     # dense features from the start: the probe at enable_fp64 picks the matrix cores
     xg = synth.gaussian_features(n, f, seed=9)
     bg = engine.Baseline(hg, torch.from_numpy(xg).to(gpu), *_params(w, gpu)).enable_fp64()
