@@ -398,7 +398,8 @@ template <int VEC>   // floats per lane and load: 2 when the rows of X are 8-byt
 __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     int n, int F, int H, int Hp, const float *__restrict__ X, long ldx, const float *__restrict__ ref,
     const float *__restrict__ W1, const double *__restrict__ cref, double *__restrict__ S1d, int hint_cap,
-    int *__restrict__ dense_hint, int nslab, double *__restrict__ slabs) {
+    int *__restrict__ dense_hint, int nslab, double *__restrict__ slabs, int32_t *__restrict__ zstate) {
+    // zstate != NULL: every row's pre-activation is marked stale here (saves the refresh its memset launch).
     // The first nslab blocks of the launch (deferred cref, nslab > 0) form the K slices of cref = m W1 instead of rows:
     // block z sums slice [64 z, 64 z + 64) for every hidden column (thread (kq, cq): 16 k's x 4 columns, one trip; the four
     // k-quarters added in order through LDS) into slabs[z]; k_cref_sum adds the slices afterwards, and the rows below are
@@ -410,18 +411,22 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
         const int kq = threadIdx.x >> 6, cq = threadIdx.x & 63, cc = 4 * cq;
         double a[4] = {0.0, 0.0, 0.0, 0.0};
         if (cc < H) {
-            f32x4 w[16];
-            float m[16];
+            // (two trips of 8 loads: the rows' path below must keep its 5 waves per SIMD, i.e. <= 102 VGPRs for the kernel)
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                f32x4 w[8];
+                float m[8];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int k = k0 + 16 * kq + u;
-                m[u] = k < k1 ? ref[k] : 0.f;
-                w[u] = k < k1 ? ld4(W1 + (size_t)k * H + cc) : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + 16 * kq + 8 * h + u;
+                    m[u] = k < k1 ? ref[k] : 0.f;
+                    w[u] = k < k1 ? ld4(W1 + (size_t)k * H + cc) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) a[t] = fma((double)m[u], (double)w[u][t], a[t]);
             }
-#pragma unroll
-            for (int u = 0; u < 16; ++u)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) a[t] = fma((double)m[u], (double)w[u][t], a[t]);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) s_p[kq][(cc + t) & 255] = a[t];
@@ -525,6 +530,7 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
         }
     }
     if (total > hint_cap && lane == 0) *dense_hint = 1;
+    if (zstate && lane == 0) zstate[i] = 0;
     if (!own) return;
     f64x4 o;
 #pragma unroll
@@ -890,7 +896,7 @@ static bool want_feature_rows(const lt_baseline *cb) {
     return knob == 0 ? false : (knob > 0 ? true : b->feat_sparse != 0);
 }
 
-static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, bool defer = false) {
+static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, bool defer = false, int32_t *zstate = nullptr) {
     const int Hp = b->Hp, H = b->H, n = n_rows < 0 ? b->n : n_rows, F = b->F;
     if (!b->fd_ref_valid) {       // once: any reference vector is correct, a good one makes the rows' lists short
         hipLaunchKernelGGL(k_ref_vector, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, st, n, F, b->X, (long)b->ldx, b->fd_ref);
@@ -912,10 +918,10 @@ static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, b
     const size_t smem = fd_smem_bytes(F);
     if (b->ldx % 2 == 0 && ((uintptr_t)b->X % 8) == 0)
         hipLaunchKernelGGL((k_s1d_feature_rows<2>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx,
-                           b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs);
+                           b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs, zstate);
     else
         hipLaunchKernelGGL((k_s1d_feature_rows<1>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx,
-                           b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs);
+                           b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs, zstate);
     LT_CHECK_LAUNCH();
     if (defer) {
         hipLaunchKernelGGL(k_cref_sum, dim3(1), dim3(256), 0, st, nz, H, Hp, b->fd_slabs, b->fd_cref);
@@ -932,7 +938,9 @@ static int compute_s1d(lt_baseline *b, hipStream_t st) {
     if (b->n == 0) return LT_OK;
     const int Hp = b->Hp, H = b->H, n = b->n;
     b->z_all_valid = false;
-    LT_HIP(hipMemsetAsync(b->zstate, 0, (size_t)n * sizeof(int32_t), st));
+    // every pre-activation row is stale from here on (the feature-rows kernel resets the words itself)
+    const bool feat = !lt_fp64_agg_active(b) && b->S1d && !b->S1d_external && want_feature_rows(b);
+    if (!feat) LT_HIP(hipMemsetAsync(b->zstate, 0, (size_t)n * sizeof(int32_t), st));
     if (lt_fp64_agg_active(b)) return LT_OK;
     if (!b->S1d)
         return lt_set_error(LT_ERR_UNSUPPORTED, "fp64 pre-activation: the S1d route was not allocated (set \"aggregate_first\" "
@@ -944,7 +952,7 @@ static int compute_s1d(lt_baseline *b, hipStream_t st) {
     } else if (want_feature_rows(b)) {
         // (writes the pad columns of S1d as zeros itself; cref deferred to the readers unless the SpMM takes the tiled route)
         const bool tiled = lt_tiled_wanted(b->g, Hp) && (b->g->p_n_long == 0 || b->seg_d);
-        int rc = launch_feature_s1d(b, st, -1, !tiled && lt_tune().defer_cref != 0);
+        int rc = launch_feature_s1d(b, st, -1, !tiled && lt_tune().defer_cref != 0, b->zstate);
         if (rc) return rc;
     } else {
         if (Hp != H) LT_HIP(hipMemsetAsync(b->S1d, 0, (size_t)n * Hp * sizeof(double), st));
