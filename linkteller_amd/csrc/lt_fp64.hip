@@ -268,11 +268,14 @@ __global__ void k_sum_slabs_f64(const double *__restrict__ slabs, long slab_stri
 // One lane group per row of up to LT_ROW_SEG entries; on a graph with hub rows the first seg_blocks blocks of the
 // launch take one SEGMENT of a long row per lane group instead, raw sum into seg_out[segment] (k_spmm_f64_long adds
 // them in segment order and the bias).  fp64: the cut only decides how a hub row's work is spread.
-template <int LPR>
+// ST = double, or float: the feature route stores its fp64-ACCUMULATED product rounded once to fp32 (S1x: 6e-8 relative, two
+// orders below what the kink test needs, and half the bytes every gather moves -- the 4.5 MB then sit in the L2s); the chains
+// accumulate in fp64 either way.
+template <int LPR, typename ST>
 __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restrict__ rowptr,
                                                   const int32_t *__restrict__ col,
                                                   const float *__restrict__ val,
-                                                  const double *__restrict__ S, int ld,
+                                                  const ST *__restrict__ S, int ld,
                                                   const float *__restrict__ b1p,
                                                   double *__restrict__ out, int seg_blocks, int n_seg,
                                                   const int32_t *__restrict__ seg_begin,
@@ -307,37 +310,38 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
         e1 = rowptr[r + 1];
         if (seg_blocks > 0 && e1 - e > LT_ROW_SEG) return;
     }
+    typedef ST sx4 __attribute__((ext_vector_type(4)));
     for (; e + 8 <= e1; e += 8) {   // eight gathers in flight (a trip costs one L2 / Infinity-Cache latency); entry order kept
         double a[8];
-        f64x4 s[8];
+        sx4 s[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             a[j] = (double)val[e + j];
-            s[j] = *reinterpret_cast<const f64x4 *>(S + (size_t)col[e + j] * ld + coff);
+            s[j] = *reinterpret_cast<const sx4 *>(S + (size_t)col[e + j] * ld + coff);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] = fma(a[j], s[j][k], acc[k]);
+            for (int k = 0; k < 4; ++k) acc[k] = fma(a[j], (double)s[j][k], acc[k]);
     }
     for (; e + 4 <= e1; e += 4) {
         double a[4];
-        f64x4 s[4];
+        sx4 s[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             a[j] = (double)val[e + j];
-            s[j] = *reinterpret_cast<const f64x4 *>(S + (size_t)col[e + j] * ld + coff);
+            s[j] = *reinterpret_cast<const sx4 *>(S + (size_t)col[e + j] * ld + coff);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] = fma(a[j], s[j][k], acc[k]);
+            for (int k = 0; k < 4; ++k) acc[k] = fma(a[j], (double)s[j][k], acc[k]);
     }
     for (; e < e1; ++e) {
         const double a = (double)val[e];
-        const f64x4 s = *reinterpret_cast<const f64x4 *>(S + (size_t)col[e] * ld + coff);
+        const sx4 s = *reinterpret_cast<const sx4 *>(S + (size_t)col[e] * ld + coff);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = fma(a, s[k], acc[k]);
+        for (int k = 0; k < 4; ++k) acc[k] = fma(a, (double)s[k], acc[k]);
     }
     if (!SEG) {
         const f32x4 b = ld4(b1p + coff);
@@ -398,7 +402,8 @@ template <int VEC>   // floats per lane and load: 2 when the rows of X are 8-byt
 __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     int n, int F, int H, int Hp, const float *__restrict__ X, long ldx, const float *__restrict__ ref,
     const float *__restrict__ W1, const double *__restrict__ cref, double *__restrict__ S1d, int hint_cap,
-    int *__restrict__ dense_hint, int nslab, double *__restrict__ slabs, int32_t *__restrict__ zstate) {
+    int *__restrict__ dense_hint, int nslab, double *__restrict__ slabs, int32_t *__restrict__ zstate,
+    float *__restrict__ S1x) {
     // zstate != NULL: every row's pre-activation is marked stale here (saves the refresh its memset launch).
     // The first nslab blocks of the launch (deferred cref, nslab > 0) form the K slices of cref = m W1 instead of rows:
     // block z sums slice [64 z, 64 z + 64) for every hidden column (thread (kq, cq): 16 k's x 4 columns, one trip; the four
@@ -535,7 +540,8 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     f64x4 o;
 #pragma unroll
     for (int t = 0; t < 4; ++t) o[t] = c0 + t < H ? (cref ? cref[c0 + t] + acc[t] : acc[t]) : 0.0;
-    *reinterpret_cast<f64x4 *>(S1d + (size_t)i * Hp + c0) = o;
+    if (S1x) *reinterpret_cast<f32x4 *>(S1x + (size_t)i * Hp + c0) = f32x4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+    else *reinterpret_cast<f64x4 *>(S1d + (size_t)i * Hp + c0) = o;
 }
 static size_t fd_smem_bytes(int F) {
     const size_t Fp = (size_t)((F + 1) & ~1);
@@ -897,6 +903,7 @@ static bool want_feature_rows(const lt_baseline *cb) {
 }
 
 static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, bool defer = false, int32_t *zstate = nullptr) {
+    // (fp32 storage of the fp64-accumulated rows goes with the deferred cref: the small-graph route whose readers know about both)
     const int Hp = b->Hp, H = b->H, n = n_rows < 0 ? b->n : n_rows, F = b->F;
     if (!b->fd_ref_valid) {       // once: any reference vector is correct, a good one makes the rows' lists short
         hipLaunchKernelGGL(k_ref_vector, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, st, n, F, b->X, (long)b->ldx, b->fd_ref);
@@ -914,20 +921,22 @@ static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, b
     }
     const int nslab = defer ? nz : 0;
     const double *cref = defer ? (const double *)nullptr : b->fd_cref;
+    float *s1x = (defer && b->S1x && lt_tune().s1_f32 != 0) ? b->S1x : nullptr;
     const unsigned blocks = (unsigned)((n + FD_WAVES - 1) / FD_WAVES + nslab);
     const size_t smem = fd_smem_bytes(F);
     if (b->ldx % 2 == 0 && ((uintptr_t)b->X % 8) == 0)
         hipLaunchKernelGGL((k_s1d_feature_rows<2>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx,
-                           b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs, zstate);
+                           b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs, zstate, s1x);
     else
         hipLaunchKernelGGL((k_s1d_feature_rows<1>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx,
-                           b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs, zstate);
+                           b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs, zstate, s1x);
     LT_CHECK_LAUNCH();
     if (defer) {
         hipLaunchKernelGGL(k_cref_sum, dim3(1), dim3(256), 0, st, nz, H, Hp, b->fd_slabs, b->fd_cref);
         LT_CHECK_LAUNCH();
     }
     b->cref_deferred = defer;
+    b->s1_f32 = s1x != nullptr;
     return LT_OK;
 }
 
@@ -947,6 +956,7 @@ static int compute_s1d(lt_baseline *b, hipStream_t st) {
                                                 "before lt_baseline_enable_fp64)");
     lt_prof_scope prof_(LT_K_FP64_PRODUCT, st);
     b->cref_deferred = false;
+    b->s1_f32 = false;
     if (b->S1d_external) {
         // multi-GPU: S1d arrives by the caller's all-gather of the ranks' row shards (lt_baseline_refresh_rows_fp64)
     } else if (want_feature_rows(b)) {
@@ -984,9 +994,15 @@ static int form_z1d(lt_baseline *b, int32_t *state, hipStream_t st) {
     }
     const unsigned gs = have_long ? (unsigned)((g->p_n_seg + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr))) : 0u;
     const double *crefv = b->cref_deferred ? b->fd_cref : nullptr;      // (deferred cref: S1d holds S1d - cref)
-    LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_>), dim3(g2 + gs), dim3(256), 0, st, n, g->rowptr,
-                                            g->col, g->val, b->S1d, Hp, b->b1p, b->Z1d, (int)gs, g->p_n_seg, g->p_seg_begin,
-                                            g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv));
+    if (b->s1_f32) {
+        LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, float>), dim3(g2 + gs), dim3(256), 0, st, n, g->rowptr,
+                                                g->col, g->val, b->S1x, Hp, b->b1p, b->Z1d, (int)gs, g->p_n_seg, g->p_seg_begin,
+                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv));
+    } else {
+        LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, double>), dim3(g2 + gs), dim3(256), 0, st, n, g->rowptr,
+                                                g->col, g->val, b->S1d, Hp, b->b1p, b->Z1d, (int)gs, g->p_n_seg, g->p_seg_begin,
+                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv));
+    }
     LT_CHECK_LAUNCH();
     if (have_long) {
         const long tot = (long)g->p_n_long * Hp;
@@ -1068,7 +1084,7 @@ int lt_launch_spmm_f64(const lt_graph *g, const double *S, int ld, const float *
     const unsigned g2 = (unsigned)((n + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr)));
     const int have_long = (g->p_n_long > 0 && seg_d) ? 1 : 0;
     const unsigned gs = have_long ? (unsigned)((g->p_n_seg + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr))) : 0u;
-    LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_>), dim3(g2 + gs), dim3(256), 0, st, n, g->rowptr, g->col, g->val, S, ld,
+    LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, double>), dim3(g2 + gs), dim3(256), 0, st, n, g->rowptr, g->col, g->val, S, ld,
                                             biasp, out, (int)gs, g->p_n_seg, g->p_seg_begin, g->p_seg_long, g->p_long_row, seg_d,
                                             (int32_t *)nullptr, (const double *)nullptr, (const double *)nullptr));
     LT_CHECK_LAUNCH();
@@ -1148,6 +1164,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     double *yd = nullptr, *segy = nullptr;
     float *fref = nullptr;
     double *frs = nullptr;
+    float *fs1x = nullptr;
     int *gate = nullptr;
     int32_t *zst = nullptr, *zrw = nullptr, *zct = nullptr;
     hipError_t e = hipMalloc((void **)&z1d, nh);
@@ -1162,6 +1179,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
         if (e == hipSuccess && fd_possible) e = hipMemsetAsync(gate, 0, sizeof(int), st);     // (the slice counter of k_ref_row_product)
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fref, (size_t)(b->F + 64) * sizeof(float));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&frs, n1 * sizeof(double));
+        if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fs1x, n1 * b->Hp * sizeof(float));
     }
     if (alloc_agg) {
         if (e == hipSuccess) e = hipMalloc((void **)&yd, n1 * b->Fp * sizeof(double));
@@ -1173,13 +1191,13 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     if (e == hipSuccess) e = hipMalloc((void **)&zct, sizeof(int32_t));
     if (e != hipSuccess) {   // all or nothing: a retry starts from a clean state, nothing leaks
         (void)hipFree(s1d); (void)hipFree(z1d); (void)hipFree(slabs); (void)hipFree(segd);
-        (void)hipFree(cref); (void)hipFree(fslabs); (void)hipFree(gate); (void)hipFree(fref); (void)hipFree(frs);
+        (void)hipFree(cref); (void)hipFree(fslabs); (void)hipFree(gate); (void)hipFree(fref); (void)hipFree(frs); (void)hipFree(fs1x);
         (void)hipFree(yd); (void)hipFree(segy); (void)hipFree(zst); (void)hipFree(zrw); (void)hipFree(zct);
         if (hint_host) (void)hipHostFree(hint_host);
         return lt_set_error(LT_ERR_HIP, "lt_baseline_enable_fp64: hipMalloc failed: %s", hipGetErrorString(e));
     }
     b->S1d = s1d; b->Z1d = z1d; b->slabs_d = slabs; b->seg_d = segd;
-    b->fd_cref = cref; b->fd_slabs = fslabs; b->fd_gate = gate; b->fd_ref = fref; b->fd_rs = frs;
+    b->fd_cref = cref; b->fd_slabs = fslabs; b->fd_gate = gate; b->fd_ref = fref; b->fd_rs = frs; b->S1x = fs1x;
     if (frs && b->n > 0) {
         hipLaunchKernelGGL(k_row_sums, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, st, b->n, b->g->rowptr, b->g->val, frs);
         LT_CHECK_LAUNCH();
@@ -1268,6 +1286,9 @@ void lt_baseline_free_fp64(lt_baseline *b) {
     (void)hipFree(b->fd_gate);
     (void)hipFree(b->fd_ref);
     (void)hipFree(b->fd_rs);
+    (void)hipFree(b->S1x);
+    b->S1x = nullptr;
+    b->s1_f32 = false;
     b->fd_ref = nullptr;
     b->fd_rs = nullptr;
     b->cref_deferred = false;

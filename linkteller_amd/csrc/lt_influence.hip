@@ -631,7 +631,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
     const float *__restrict__ Sp, float delta, float *__restrict__ S2x, int n_long,
     const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_segptr,
     const float *__restrict__ seg_part, const int2 *__restrict__ item_pr, const double *__restrict__ Spd,
-    const double *__restrict__ crefv) {
+    const double *__restrict__ crefv, const float *__restrict__ S1x) {
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int gl = lane & (LPR - 1);
@@ -660,7 +660,11 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
                     if (DELTA == 2) {   // the probe's S1 row off the fp64 product (the fp32 one is not even computed for this mode)
                         // (aggregate-first route: the probes' own product rows Spd[b], there is no S1d)
                         const double *sp = Spd ? Spd + (size_t)b * Hp + coff : S1d + (size_t)v * Hp + coff;
-                        if (crefv && !Spd)     // deferred cref: S1d holds the rows without the reference vector's product
+                        if (S1x) {             // the feature route's rows in fp32 storage (always with the deferred cref)
+                            const f32x4 t = ld4(S1x + (size_t)v * Hp + coff);
+                            s = f32x4{(float)((double)t[0] + crefv[coff]), (float)((double)t[1] + crefv[coff + 1]),
+                                      (float)((double)t[2] + crefv[coff + 2]), (float)((double)t[3] + crefv[coff + 3])};
+                        } else if (crefv && !Spd)     // deferred cref: S1d holds the rows without the reference vector's product
                             s = f32x4{(float)(sp[0] + crefv[coff]), (float)(sp[1] + crefv[coff + 1]), (float)(sp[2] + crefv[coff + 2]),
                                       (float)(sp[3] + crefv[coff + 3])};
                         else
@@ -1486,7 +1490,8 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, g->tptr,
                                        g->trow, g->tval, b->S1, b->Z1, b->Z1d, b->S1d, Hp, b->b1p, b->W2p, C, probes, nb,
                                        w.off, w.Sp, delta, w.S2x, g->p_n_long, g->p_long_row, g->p_long_segptr,
-                                       b->seg_part, w.item_pr, (const double *)nullptr, (const double *)nullptr))); }
+                                       b->seg_part, w.item_pr, (const double *)nullptr, (const double *)nullptr,
+                                       (const float *)nullptr))); }
                 LT_CHECK_LAUNCH();
                 lt_prof_scope prof_(LT_K_ITEM_B, st);
                 if (long_blocks > 0 && hub_short) {
@@ -1538,7 +1543,8 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                            b->Z1, b->Z1d, b->S1d, Hp, b->b1p, b->W2p, C, probes, nb, w.off,
                                            (const float *)nullptr, delta, w.S2x, 0, (const int32_t *)nullptr,
                                            (const int32_t *)nullptr, (const float *)nullptr, w.item_pr, spd,
-                                           b->cref_deferred ? b->fd_cref : (const double *)nullptr)));
+                                           b->cref_deferred ? b->fd_cref : (const double *)nullptr,
+                                           (b->s1_f32 && !spd) ? b->S1x : (const float *)nullptr)));
                 } else {
                     LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
                         hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, 1>), dim3(LT_ITEM_GRID), dim3(LT_BLOCK), 0,
@@ -1546,7 +1552,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                            b->Z1, b->Z1d, b->S1d, Hp, b->b1p, b->W2p, C, probes, nb, w.off,
                                            (const float *)nullptr, delta, w.S2x, 0, (const int32_t *)nullptr,
                                            (const int32_t *)nullptr, (const float *)nullptr, w.item_pr, (const double *)nullptr,
-                                           (const double *)nullptr)));
+                                           (const double *)nullptr, (const float *)nullptr)));
                 } }
                 LT_CHECK_LAUNCH();
                 lt_prof_scope prof_(LT_K_ITEM_B, st);

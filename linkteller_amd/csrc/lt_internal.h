@@ -81,6 +81,8 @@ struct lt_baseline {
     float *fd_ref = nullptr;    // [F] the reference vector m (majority value of each column over the first rows)
     bool fd_ref_valid = false;
     double *fd_rs = nullptr;    // [n] row sums of A_hat in fp64 (deferred cref: Z1d[r] += rs[r] * cref)
+    float *S1x = nullptr;       // [n, Hp] the feature route's product rows, fp64-accumulated and rounded once to fp32 (s1_f32)
+    mutable bool s1_f32 = false;          // the current product lives in S1x (fp32) instead of S1d
     mutable bool cref_deferred = false;   // S1d currently holds S1d - cref: its readers add fd_cref themselves
     double *fd_cref = nullptr;  // [Hp] its product m W1
     double *fd_slabs = nullptr; // [ceil(F / 64), H] its split-K partials
@@ -131,6 +133,8 @@ struct lt_tuning {
     long long bits_max_bytes;    // SPARSE / DELTA: a bitmap row per probe only while the chunk's rows fit this (default 128 MiB);
                                  // beyond it only the chunk's big probes get rows (LT_BITS_MAX_BYTES)
     int tiled_big;               // 1: the tiled SpMM always uses 64-bit gather offsets (test hook; default: only when S spans >= 4 GiB)
+    int s1_f32;                  // feature-difference route (with defer_cref): 1 the product rows are stored in fp32 (fp64-accumulated,
+                                 // rounded once), 0 in fp64 (LT_S1_F32)
     int defer_cref;              // feature-difference route: 1 the reference vector's product rides in the rows' launch and is added by the
                                  // readers of S1d, 0 it is formed first and added by the rows kernel (LT_DEFER_CREF)
     int z_on_demand;             // fp64 pre-activation rows of the S1d routes: 1 only the rows a call reads, 0 all rows, -1 by the call's

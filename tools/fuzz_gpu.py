@@ -83,13 +83,14 @@ def main():
             for k in knobs:
                 _lib.set_tuning(k, None)
         # the other fp64 route of `delta` (aggregate-first <-> S1d; feature rows <-> matrix cores): fp64 summation order only
-        for k, v in (("aggregate_first", 0), ("feature_delta", int(rng.choice([0, 1]))), ("defer_cref", int(rng.choice([0, 1])))):
+        for k, v in (("aggregate_first", 0), ("feature_delta", int(rng.choice([0, 1]))), ("defer_cref", int(rng.choice([0, 1]))),
+                     ("s1_f32", int(rng.choice([0, 1])))):
             _lib.set_tuning(k, v)
         try:
             base.refresh()
             other = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
         finally:
-            for k in ("aggregate_first", "feature_delta", "defer_cref"):
+            for k in ("aggregate_first", "feature_delta", "defer_cref", "s1_f32"):
                 _lib.set_tuning(k, None)
             base.refresh()
         assert np.abs(other - ref64).max() <= 1e-5 * scale and np.abs(other - res["delta"]).max() <= 1e-6 * scale, it
