@@ -960,9 +960,11 @@ static int compute_s1d(lt_baseline *b, hipStream_t st) {
     if (b->S1d_external) {
         // multi-GPU: S1d arrives by the caller's all-gather of the ranks' row shards (lt_baseline_refresh_rows_fp64)
     } else if (want_feature_rows(b)) {
-        // (writes the pad columns of S1d as zeros itself; cref deferred to the readers unless the SpMM takes the tiled route)
-        const bool tiled = lt_tiled_wanted(b->g, Hp) && (b->g->p_n_long == 0 || b->seg_d);
-        int rc = launch_feature_s1d(b, st, -1, !tiled && lt_tune().defer_cref != 0, b->zstate);
+        // (writes the pad columns of S1d as zeros itself.)  The deferred cref + fp32 storage are for products the caches hold
+        // (a fixed size rule, not the "tiled_min_bytes" knob, so that knob keeps every bit); beyond it the rows carry cref
+        // themselves in fp64 and the SpMM may take the tiled route
+        const bool small = (long long)n * Hp * (long long)sizeof(double) < ((long long)32 << 20);
+        int rc = launch_feature_s1d(b, st, -1, small && lt_tune().defer_cref != 0, b->zstate);
         if (rc) return rc;
     } else {
         if (Hp != H) LT_HIP(hipMemsetAsync(b->S1d, 0, (size_t)n * Hp * sizeof(double), st));
@@ -979,7 +981,7 @@ static int form_z1d(lt_baseline *b, int32_t *state, hipStream_t st) {
     const unsigned g2 = (unsigned)((n + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr)));
     const lt_graph *g = b->g;
     const int have_long = (g->p_n_long > 0 && b->seg_d) ? 1 : 0;
-    if (!state && lt_tiled_wanted(g, Hp) && (g->p_n_long == 0 || b->seg_d)) {
+    if (!state && !b->cref_deferred && lt_tiled_wanted(g, Hp) && (g->p_n_long == 0 || b->seg_d)) {
         // S1d beyond the caches (R-MAT scale 21: 4.3 GB): the column-sliced work-item route of lt_spmm.hip, same chains
         int rc = lt_launch_rows_tiled_f64(g, b->S1d, Hp, Hp, b->b1p, b->Z1d, Hp, b->seg_d, Hp, st);
         if (rc) return rc;
@@ -1029,7 +1031,7 @@ int lt_fp64_prepare_rows(const lt_baseline *cb, const int32_t *off, int nb, cons
     lt_prof_scope prof_(LT_K_FP64_SPMM, st);
     const double avg = g->n > 0 ? (double)g->nnz / (double)g->n : 0.0;
     const int knob = lt_tune().z_on_demand;
-    const bool tiled = lt_tiled_wanted(g, b->Hp) && (g->p_n_long == 0 || b->seg_d);
+    const bool tiled = !b->cref_deferred && lt_tiled_wanted(g, b->Hp) && (g->p_n_long == 0 || b->seg_d);
     const bool ondemand = !tiled && (knob > 0 || (knob < 0 && (double)n_probe_call * avg * 2.0 < (double)g->n));
     if (!ondemand) {
         const int rc = form_z1d(b, nullptr, st);
