@@ -1091,6 +1091,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
 // the only global traffic of an untouched pair).  The touched pairs run row2_dot over the staged row: same chains
 // (entry e -> chain (e - e0) & 7, k-ordered), same butterfly, same tail -- the bits of k_item_stageB.
 #define LT_SB_UNR 4
+#define LT_SB_PASS 2048   // probes per pass of a block (its touched pairs are listed in LDS)
 template <int CP, bool DELTA>
 __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_rows(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
@@ -1111,61 +1112,80 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_rows(
     const int b_begin = part * per, b_end = min(nb, b_begin + per);
     const int32_t *lc = scol - e0;       // row2_dot indexes its arrays with the CSR entry number
     const float *lv = sval - e0;
-    for (int b0 = b_begin + grp; b0 < b_end; b0 += GROUPS * LT_SB_UNR) {
-        int t[LT_SB_UNR];
+    // Two phases per pass of up to LT_SB_PASS probes: (1) every group tests LT_SB_UNR probes at a time against the staged row
+    // (independent bitmap loads) -- untouched pairs get their 0 at once, touched ones go onto a block-wide LDS list; (2) the
+    // groups take the listed pairs round-robin, so the few touched pairs of a block (7 % at twitch size) run side by side
+    // instead of one after the other inside the group that found them.  The list order is arbitrary: pairs are independent.
+    __shared__ int32_t s_list[LT_SB_PASS];
+    __shared__ int32_t s_cnt;
+    for (int p0 = b_begin; p0 < b_end; p0 += LT_SB_PASS) {
+        const int p1 = min(b_end, p0 + LT_SB_PASS);
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        for (int b0 = p0 + grp; b0 < p1; b0 += GROUPS * LT_SB_UNR) {
+            int t[LT_SB_UNR];
 #pragma unroll
-        for (int k = 0; k < LT_SB_UNR; ++k) {
-            const int b = b0 + k * GROUPS;
-            unsigned hit = 0u;
-            if (b < b_end) {
-                const uint2 *mb = bits + (size_t)b * words;
-                for (int e = q; e < d; e += LT_L2_LANES) {
-                    const int c = scol[e];
-                    hit |= (mb[c >> 5].x >> (c & 31)) & 1u;
+            for (int k = 0; k < LT_SB_UNR; ++k) {
+                const int b = b0 + k * GROUPS;
+                unsigned hit = 0u;
+                if (b < p1) {
+                    const uint2 *mb = bits + (size_t)b * words;
+                    for (int e = q; e < d; e += LT_L2_LANES) {
+                        const int c = scol[e];
+                        hit |= (mb[c >> 5].x >> (c & 31)) & 1u;
+                    }
+                }
+                t[k] = (int)hit;
+            }
+#pragma unroll
+            for (int k = 0; k < LT_SB_UNR; ++k)
+#pragma unroll
+                for (int m = LT_L2_LANES / 2; m >= 1; m >>= 1) t[k] |= __shfl_xor(t[k], m, 64);
+            if (q == 0) {
+#pragma unroll
+                for (int k = 0; k < LT_SB_UNR; ++k) {
+                    const int b = b0 + k * GROUPS;
+                    if (b >= p1) continue;
+                    if (t[k]) s_list[atomicAdd(&s_cnt, 1)] = b;
+                    else out[(long)b * ldo + j] = 0.f;
                 }
             }
-            t[k] = (int)hit;
         }
+        __syncthreads();
+        const int cnt = s_cnt;
+        for (int idx = grp; idx < cnt; idx += GROUPS) {
+            const int b = s_list[idx];
+            const uint2 *mb = bits + (size_t)b * words;
+            const float *items = S2x + (size_t)off[b] * C;
+            float acc[CP];
+            float res;
+            if (DELTA) {
+                row2_dot<CP>(lc, lv, e0, e0 + d, q, C,
+                             [&](int c, int) {
+                                 const int p = bits_pos(mb, c);
+                                 return p >= 0 ? items + (size_t)p * C : (const float *)nullptr;
+                             },
+                             acc);
+                float ss = 0.f;
 #pragma unroll
-        for (int k = 0; k < LT_SB_UNR; ++k)
-#pragma unroll
-            for (int m = LT_L2_LANES / 2; m >= 1; m >>= 1) t[k] |= __shfl_xor(t[k], m, 64);
-#pragma unroll
-        for (int k = 0; k < LT_SB_UNR; ++k) {
-            const int b = b0 + k * GROUPS;
-            if (b >= b_end) continue;     // group-uniform
-            float res = 0.f;
-            if (t[k]) {                   // group-uniform
-                const uint2 *mb = bits + (size_t)b * words;
-                const float *items = S2x + (size_t)off[b] * C;
-                float acc[CP];
-                if (DELTA) {
-                    row2_dot<CP>(lc, lv, e0, e0 + d, q, C,
-                                 [&](int c, int) {
-                                     const int p = bits_pos(mb, c);
-                                     return p >= 0 ? items + (size_t)p * C : (const float *)nullptr;
-                                 },
-                                 acc);
-                    float ss = 0.f;
-#pragma unroll
-                    for (int c = 0; c < CP; ++c)
-                        if (c < C) {
-                            const float dd = acc[c] / delta;
-                            ss = fmaf(dd, dd, ss);
-                        }
-                    res = sqrtf(ss);
-                } else {
-                    row2_dot<CP>(lc, lv, e0, e0 + d, q, C,
-                                 [&](int c, int) {
-                                     const int p = bits_pos(mb, c);
-                                     return p >= 0 ? items + (size_t)p * C : S2 + (size_t)c * C;
-                                 },
-                                 acc);
-                    res = diff_norm<CP>(acc, b2, OUT + (size_t)u * C, C, delta);
-                }
+                for (int c = 0; c < CP; ++c)
+                    if (c < C) {
+                        const float dd = acc[c] / delta;
+                        ss = fmaf(dd, dd, ss);
+                    }
+                res = sqrtf(ss);
+            } else {
+                row2_dot<CP>(lc, lv, e0, e0 + d, q, C,
+                             [&](int c, int) {
+                                 const int p = bits_pos(mb, c);
+                                 return p >= 0 ? items + (size_t)p * C : S2 + (size_t)c * C;
+                             },
+                             acc);
+                res = diff_norm<CP>(acc, b2, OUT + (size_t)u * C, C, delta);
             }
             if (q == 0) out[(long)b * ldo + j] = res;
         }
+        __syncthreads();
     }
 }
 
