@@ -631,7 +631,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
     const float *__restrict__ Sp, float delta, float *__restrict__ S2x, int n_long,
     const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_segptr,
     const float *__restrict__ seg_part, const int2 *__restrict__ item_pr, const double *__restrict__ Spd,
-    const double *__restrict__ crefv, const float *__restrict__ S1x, const float *__restrict__ item_a) {
+    const double *__restrict__ crefv, const float *__restrict__ S1x) {
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int gl = lane & (LPR - 1);
@@ -651,11 +651,11 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
             const int2 pr = item_pr[item];
             const int b = pr.x, r = pr.y;
             const int v = probes[b];
+            const int t = tptr[v] + (item - off[b]);
             if (active) {
                 const f32x4 b1v = ld4(b1p + coff);
                 if (DELTA) {
-                    // the item's coefficient A_hat[r, v]: from the item table when k_item_bits left it there
-                    const float arv = item_a ? item_a[item] : tval[tptr[v] + (item - off[b])];
+                    const float arv = tval[t];
                     f32x4 s;
                     if (DELTA == 2) {   // the probe's S1 row off the fp64 product (the fp32 one is not even computed for this mode)
                         // (aggregate-first route: the probes' own product rows Spd[b], there is no S1d)
@@ -1241,7 +1241,6 @@ struct infl_ws {
     double *Spd;           // DELTA, aggregate-first route: fp64 product rows of the chunk's probes [chunk, Hp]
     int32_t *off;          // SPARSE / DELTA: item offsets [chunk + 1]
     int2 *item_pr;         // SPARSE / DELTA: (probe index, row) of every item
-    float *item_a;         // DELTA: A_hat[row, probe node] of every item
     int32_t *pm_cnt, *pm_start, *pm_rank, *pm_list;   // SPARSE / DELTA pair marks: per-node lists of observed nodes (lt_items.cuh)
     unsigned *pm_marks;    // SPARSE / DELTA: one bit per (probe of the chunk, observed node)
     uint2 *big_bits;       // SPARSE / DELTA without `bits`: bitmap rows of the chunk's big probes [LT_BIG_SLOTS][ceil(n / 32)]
@@ -1260,7 +1259,7 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int n_o
     const size_t nseg = long_rows_parallel(b->g, b->Hp) ? (size_t)b->g->p_n_seg : 0;
     if (mode == LT_MODE_FULL) per_probe = (n * C + Hp + splitk) * sizeof(float) + nseg * Hp * sizeof(float) * 9 / 8;
     else if (mode == LT_MODE_SPARSE) per_probe = (maxc * C + Hp + splitk) * sizeof(float) + sizeof(int32_t) + maxc * sizeof(int2);
-    else per_probe = maxc * C * sizeof(float) + sizeof(int32_t) + maxc * (sizeof(int2) + sizeof(float));
+    else per_probe = maxc * C * sizeof(float) + sizeof(int32_t) + maxc * sizeof(int2);
     size_t chunk = chunk_budget() / (per_probe ? per_probe : 1);
     if (chunk < 1) chunk = 1;
     if (chunk > 65534) chunk = 65534;  // grid.y (FULL, narrow kernel: probes + 1)
@@ -1287,7 +1286,6 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int n_o
         w.S2x = (float *)take(chunk * maxc * C * sizeof(float));
         w.off = (int32_t *)take((chunk + 1) * sizeof(int32_t));
         w.item_pr = (int2 *)take(chunk * maxc * sizeof(int2));
-        if (mode == LT_MODE_DELTA) w.item_a = (float *)take(chunk * maxc * sizeof(float));
         const size_t bw = (n + 31) / 32;
         // ("item_bits" = 0 forces the search path a huge graph takes: tests)
         const bool no_bits = lt_tune().item_bits == 0;
@@ -1496,7 +1494,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
             const unsigned *marks = nullptr;
             { lt_prof_scope prof_(LT_K_ITEM_BITS, st);
             hipLaunchKernelGGL(k_item_bits, dim3(nb), dim3(256), 0, st, g->tptr, g->trow, probes, nb, words, w.bits, w.off, w.item_pr,
-                               w.big_bits, w.big_slot, w.big_slot ? w.big_slot + w.chunk : (int32_t *)nullptr, g->tval, w.item_a);
+                               w.big_bits, w.big_slot, w.big_slot ? w.big_slot + w.chunk : (int32_t *)nullptr);
             LT_CHECK_LAUNCH();
             if (use_marks) {
                 LT_HIP(hipMemsetAsync(w.pm_marks, 0, (size_t)((pairs + 31) / 32) * sizeof(unsigned), st));
@@ -1513,7 +1511,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                        g->trow, g->tval, b->S1, b->Z1, b->Z1d, b->S1d, Hp, b->b1p, b->W2p, C, probes, nb,
                                        w.off, w.Sp, delta, w.S2x, g->p_n_long, g->p_long_row, g->p_long_segptr,
                                        b->seg_part, w.item_pr, (const double *)nullptr, (const double *)nullptr,
-                                       (const float *)nullptr, (const float *)nullptr))); }
+                                       (const float *)nullptr))); }
                 LT_CHECK_LAUNCH();
                 lt_prof_scope prof_(LT_K_ITEM_B, st);
                 if (long_blocks > 0 && hub_short) {
@@ -1566,7 +1564,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                            (const float *)nullptr, delta, w.S2x, 0, (const int32_t *)nullptr,
                                            (const int32_t *)nullptr, (const float *)nullptr, w.item_pr, spd,
                                            b->cref_deferred ? b->fd_cref : (const double *)nullptr,
-                                           (b->s1_f32 && !spd) ? b->S1x : (const float *)nullptr, w.item_a)));
+                                           (b->s1_f32 && !spd) ? b->S1x : (const float *)nullptr)));
                 } else {
                     LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
                         hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, 1>), dim3(LT_ITEM_GRID), dim3(LT_BLOCK), 0,
@@ -1574,7 +1572,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                            b->Z1, b->Z1d, b->S1d, Hp, b->b1p, b->W2p, C, probes, nb, w.off,
                                            (const float *)nullptr, delta, w.S2x, 0, (const int32_t *)nullptr,
                                            (const int32_t *)nullptr, (const float *)nullptr, w.item_pr, (const double *)nullptr,
-                                           (const double *)nullptr, (const float *)nullptr, w.item_a)));
+                                           (const double *)nullptr, (const float *)nullptr)));
                 } }
                 LT_CHECK_LAUNCH();
                 lt_prof_scope prof_(LT_K_ITEM_B, st);

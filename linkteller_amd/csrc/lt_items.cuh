@@ -39,11 +39,7 @@ static __global__ __launch_bounds__(256) void k_item_bits(const int32_t *__restr
                                                    const int32_t *__restrict__ probes, int nb, int words,
                                                    uint2 *__restrict__ bits, int32_t *__restrict__ off,
                                                    int2 *__restrict__ item_pr, uint2 *__restrict__ big_bits,
-                                                   int32_t *__restrict__ big_slot, int32_t *__restrict__ big_count,
-                                                   const float *__restrict__ tval = nullptr,
-                                                   float *__restrict__ item_a = nullptr) {
-    // item_a != NULL: the coefficient A_hat[r, v] of every item next to its (probe, row) -- stage A of DELTA then starts
-    // its row loads one round trip after the item table instead of three (probe -> tptr -> tval)
+                                                   int32_t *__restrict__ big_slot, int32_t *__restrict__ big_count) {
     // One block per probe.  It also forms the probe's item offset off[b] = sum of |R_v| over the probes before it
     // (every block sums its own prefix: nb^2 / 2 four-byte loads in all, no scan kernel in front), the last block
     // writes the total off[nb].  bits == NULL: no bitmap (huge graphs); item_pr == NULL: no (probe, row) table.
@@ -88,7 +84,6 @@ static __global__ __launch_bounds__(256) void k_item_bits(const int32_t *__restr
         }
         // item (off[b] + position in R_v) = (probe index, row): stage A reads it instead of searching `off`
         if (items) items[t - t0] = make_int2(b, r);
-        if (item_a) item_a[my_off + (t - t0)] = tval[t];
     }
 }
 // position of column c in R_v from the probe's bitmap row, or -1
