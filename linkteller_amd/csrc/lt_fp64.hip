@@ -396,7 +396,8 @@ __global__ void k_spmm_f64_long(int n_long, const int32_t *__restrict__ long_row
 typedef float f32x2_ __attribute__((ext_vector_type(2)));
 #define FD_CAP 384
 #define FD_WAVES 4
-#define FD_PU 8          // W1 rows in flight per lane while a list is walked (FD_CAP is a multiple)
+#define FD_PU 6          // W1 rows in flight per lane while a list is walked (FD_CAP is a multiple; 8 costs the fifth wave per SIMD)
+#define FD_REF_PAD (16 * 64 * FD_WAVES + 64)   // the staging loop of k_s1d_feature_rows reads the reference vector in whole passes
 #define FD_UN 26         // loads in flight per lane in the row pass (x 128 floats: F <= 3328 is one trip)
 template <int VEC>   // floats per lane and load: 2 when the rows of X are 8-byte aligned, else 1
 __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
@@ -449,25 +450,42 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     const float *xr = X + (long)(live ? i : 0) * ldx;
     constexpr int STEP = 64 * VEC;
     // the first trip's loads of the row go out BEFORE the reference vector is staged: one round trip covers both
+    // Branch-free loads: hipcc turns a load guarded by a branch into "wait for everything, then load", i.e. it SERIALISES the
+    // row's 26 loads (s_waitcnt vmcnt(0) in front of each: the pass took 24 us against 12 us for the same reads issued back
+    // to back, tools/read_lab).  Lanes past the end of the row read the row's last pair instead (valid memory) and are
+    // masked by `j < F` when the values are compared.
     float x[FD_UN][VEC];
+    // The loads are constant offsets from ONE base address (26 individually clamped addresses cost 52 VGPRs and the kernel
+    // its fifth wave per SIMD), so a trip reads FD_UN * STEP floats whatever F is: past the end of the row into the next row
+    // (valid memory, masked by `j < F` later) -- and for the LAST row, which has nothing behind it, the window is shifted
+    // left to END at the row's end (it then starts in the previous row: masked by `j >= 0`).  Rows longer than one trip
+    // send the last row through the piecewise path of the dense rows instead.
+    const bool last_row = i == n - 1;              // wave-uniform (waves past the last row load row 0 unshifted and exit after the barrier)
+    const bool one_trip = F <= FD_UN * STEP;
+    const int shift = (last_row && one_trip) ? FD_UN * STEP - F : 0;    // (even when VEC == 2: F is even then)
     auto load_trip = [&](int j0) {
+        const float *p = ((last_row && !one_trip) ? X : xr) + j0 + lane * VEC - shift;
 #pragma unroll
         for (int u = 0; u < FD_UN; ++u) {
-            const int j = j0 + u * STEP + lane * VEC;
-            // (plain loads: non-temporal ones measured 22 % slower here -- 32.7 against 26.8 us -- the 55 MB of X are served
-            // out of the Infinity Cache from one step to the next)
             if constexpr (VEC == 2) {
-                f32x2_ t = {0.f, 0.f};
-                if (j + 1 < F) t = *reinterpret_cast<const f32x2_ *>(xr + j);
-                else if (j < F) t.x = xr[j];
+                const f32x2_ t = *reinterpret_cast<const f32x2_ *>(p + u * STEP);
                 x[u][0] = t.x; x[u][1] = t.y;
             } else {
-                x[u][0] = j < F ? xr[j] : 0.f;
+                x[u][0] = p[u * STEP];
             }
         }
     };
     load_trip(0);
-    for (int j = tid; j < Fp; j += 64 * FD_WAVES) sref[j] = j < F ? ref[j] : 0.f;
+    for (int j0 = 0; j0 < Fp; j0 += 16 * 64 * FD_WAVES) {       // (16 loads in flight per thread, no branch between them)
+        float r[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) r[u] = ref[j0 + u * 64 * FD_WAVES + tid];   // (ref is allocated FD_REF_PAD floats past F: constant offsets from one address)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int j = j0 + u * 64 * FD_WAVES + tid;
+            if (j < Fp) sref[j] = j < F ? r[u] : 0.f;
+        }
+    }
     __syncthreads();
     if (!live) return;
     double *mv = ldv + wid * FD_CAP;
@@ -480,24 +498,28 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     auto walk = [&](int cnt) {
         const int padded = (cnt + FD_PU - 1) / FD_PU * FD_PU;
         if (lane < padded - cnt) { mj[cnt + lane] = 0; mv[cnt + lane] = 0.0; }      // (d = 0: the term adds exactly nothing)
-        if (own)
+        if (own && vec_ok) {
             for (int e = 0; e < padded; e += FD_PU) {
                 f32x4 w[FD_PU];
                 double d[FD_PU];
 #pragma unroll
-                for (int k = 0; k < FD_PU; ++k) {
-                    const int j = mj[e + k];
+                for (int k = 0; k < FD_PU; ++k) {       // (no branch between the loads: they all go out before the first wait)
                     d[k] = mv[e + k];
-                    if (vec_ok) w[k] = ld4(W1 + (size_t)j * H + c0);
-                    else
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) w[k][t] = c0 + t < H ? W1[(size_t)j * H + c0 + t] : 0.f;
+                    w[k] = ld4(W1 + (size_t)mj[e + k] * H + c0);
                 }
 #pragma unroll
                 for (int k = 0; k < FD_PU; ++k)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) acc[t] = fma(d[k], (double)w[k][t], acc[t]);
             }
+        } else if (own) {
+            for (int e = 0; e < padded; ++e) {
+                const int j = mj[e];
+                const double d = mv[e];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = fma(d, c0 + t < H ? (double)W1[(size_t)j * H + c0 + t] : 0.0, acc[t]);
+            }
+        }
     };
     const unsigned long long lt = (1ull << lane) - 1ull;
     // pass 1 (the common case is all there is); differing columns beyond the list's capacity are only counted
@@ -508,9 +530,9 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
         for (int u = 0; u < FD_UN; ++u) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-                const int j = j0 + u * STEP + lane * VEC + v;
-                const float r = j < F ? sref[j] : 0.f;
-                const bool diff = j < F && x[u][v] != r;
+                const int j = j0 + u * STEP + lane * VEC + v - shift;
+                const float r = (j >= 0 && j < F) ? sref[j] : 0.f;
+                const bool diff = j >= 0 && j < F && x[u][v] != r;
                 const unsigned long long m = __ballot(diff);
                 if (m) {
                     const int pos = total + __popcll(m & lt);
@@ -520,6 +542,8 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
             }
         }
     }
+    const int real_total = total;
+    if (last_row && !one_trip) total = FD_CAP + 1; // (what pass 1 loaded was not this row)
     if (total <= FD_CAP) {
         walk(total);
     } else {
@@ -535,7 +559,7 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
             walk(__popcll(m));
         }
     }
-    if (total > hint_cap && lane == 0) *dense_hint = 1;
+    if (!(last_row && !one_trip) && real_total > hint_cap && lane == 0) *dense_hint = 1;
     if (zstate && lane == 0) zstate[i] = 0;
     if (!own) return;
     f64x4 o;
@@ -925,7 +949,7 @@ static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, b
     float *s1x = (defer && b->S1x && lt_tune().s1_f32 != 0) ? b->S1x : nullptr;
     const unsigned blocks = (unsigned)((n + FD_WAVES - 1) / FD_WAVES + nslab);
     const size_t smem = fd_smem_bytes(F);
-    if (b->ldx % 2 == 0 && ((uintptr_t)b->X % 8) == 0)
+    if (b->ldx % 2 == 0 && F % 2 == 0 && ((uintptr_t)b->X % 8) == 0)
         hipLaunchKernelGGL((k_s1d_feature_rows<2>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx,
                            b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs, zstate, s1x);
     else
@@ -1136,7 +1160,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
         float *fref = nullptr;
         int *gate = nullptr;
         hipError_t e = hipMalloc((void **)&cref, (size_t)b->Hp * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void **)&fref, (size_t)(b->F + 64) * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **)&fref, (size_t)(b->F + FD_REF_PAD) * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&fslabs, (size_t)((b->F + 63) / 64) * b->H * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&gate, sizeof(int));
         if (e == hipSuccess) e = hipMemsetAsync(gate, 0, sizeof(int), st);
@@ -1180,7 +1204,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fslabs, (size_t)((b->F + 63) / 64) * b->H * sizeof(double));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&gate, sizeof(int));
         if (e == hipSuccess && fd_possible) e = hipMemsetAsync(gate, 0, sizeof(int), st);     // (the slice counter of k_ref_row_product)
-        if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fref, (size_t)(b->F + 64) * sizeof(float));
+        if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fref, (size_t)(b->F + FD_REF_PAD) * sizeof(float));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&frs, n1 * sizeof(double));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fs1x, n1 * b->Hp * sizeof(float));
     }

@@ -163,7 +163,9 @@ def test_feature_difference_route_of_the_fp64_product(gpu):
     base = engine.Baseline(hg, xt, *_params(w, gpu)).enable_fp64()
     assert base.fp64_route() == 1
     rng = np.random.RandomState(0)
-    probes, observe = rng.choice(n, 40, replace=False), rng.choice(n, 200, replace=False)
+    # (the last and the first node on both sides: the last row of X is read through a shifted window, lt_fp64.hip)
+    probes = np.concatenate([[n - 1, 0], rng.choice(np.arange(1, n - 1), 38, replace=False)])
+    observe = np.concatenate([[n - 1, 0], rng.choice(np.arange(1, n - 1), 198, replace=False)])
     ref64 = _oracle_matrix(a_hat, x, w, probes, observe, 1e-4, torch.float64)
     got = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
     assert np.abs(got - ref64).max() <= 1e-5 * ref64.max()
