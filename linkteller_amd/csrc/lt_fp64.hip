@@ -456,15 +456,18 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     // masked by `j < F` when the values are compared.
     float x[FD_UN][VEC];
     // The loads are constant offsets from ONE base address (26 individually clamped addresses cost 52 VGPRs and the kernel
-    // its fifth wave per SIMD), so a trip reads FD_UN * STEP floats whatever F is: past the end of the row into the next row
-    // (valid memory, masked by `j < F` later) -- and for the LAST row, which has nothing behind it, the window is shifted
-    // left to END at the row's end (it then starts in the previous row: masked by `j >= 0`).  Rows longer than one trip
-    // send the last row through the piecewise path of the dense rows instead.
-    const bool last_row = i == n - 1;              // wave-uniform (waves past the last row load row 0 unshifted and exit after the barrier)
-    const bool one_trip = F <= FD_UN * STEP;
-    const int shift = (last_row && one_trip) ? FD_UN * STEP - F : 0;    // (even when VEC == 2: F is even then)
+    // its fifth wave per SIMD), so a trip reads T = FD_UN * STEP floats whatever F is: past the end of the row into the
+    // following rows (valid memory, masked by `j < F` later).  Near the END of X there is nothing behind: the window of
+    // such a trip is shifted left so that it ends with the matrix (it then starts in earlier elements: masked by `j >= j0`).
+    // The host takes this route only when X holds at least T floats.
+    constexpr int T = FD_UN * STEP;
+    const long total_floats = (long)(n - 1) * ldx + F;
+    const long off_i = (long)(live ? i : 0) * ldx;
+    int shift = 0;                                  // wave-uniform, of the trip in flight (even when VEC == 2)
     auto load_trip = [&](int j0) {
-        const float *p = ((last_row && !one_trip) ? X : xr) + j0 + lane * VEC - shift;
+        const long over = off_i + j0 + T - total_floats;
+        shift = over > 0 ? (int)over : 0;
+        const float *p = xr + j0 + lane * VEC - shift;
 #pragma unroll
         for (int u = 0; u < FD_UN; ++u) {
             if constexpr (VEC == 2) {
@@ -531,8 +534,8 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 const int j = j0 + u * STEP + lane * VEC + v - shift;
-                const float r = (j >= 0 && j < F) ? sref[j] : 0.f;
-                const bool diff = j >= 0 && j < F && x[u][v] != r;
+                const float r = (j >= j0 && j < F) ? sref[j] : 0.f;
+                const bool diff = j >= j0 && j < F && x[u][v] != r;
                 const unsigned long long m = __ballot(diff);
                 if (m) {
                     const int pos = total + __popcll(m & lt);
@@ -542,8 +545,6 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
             }
         }
     }
-    const int real_total = total;
-    if (last_row && !one_trip) total = FD_CAP + 1; // (what pass 1 loaded was not this row)
     if (total <= FD_CAP) {
         walk(total);
     } else {
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
             walk(__popcll(m));
         }
     }
-    if (!(last_row && !one_trip) && real_total > hint_cap && lane == 0) *dense_hint = 1;
+    if (total > hint_cap && lane == 0) *dense_hint = 1;
     if (zstate && lane == 0) zstate[i] = 0;
     if (!own) return;
     f64x4 o;
@@ -1141,7 +1142,9 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     //   3. else                                                                                   -> the f64 matrix cores
     // Routes 1 / 3 share S1d + the all-rows fp64 SpMM; route 2 has its own buffers.  Small problems get both sets (the
     // knobs may then switch at any time); large ones only the chosen set.
-    const bool fd_possible = b->n >= 2 && fd_smem_bytes(b->F) <= (size_t)60 * 1024 && lt_tune().feature_delta != 0;
+    // (the rows kernel reads X in whole trips of 26 x 128 floats: tiny matrices take the matrix cores)
+    const bool fd_possible = b->n >= 2 && fd_smem_bytes(b->F) <= (size_t)60 * 1024 && lt_tune().feature_delta != 0 &&
+                             (long)(b->n - 1) * b->ldx + b->F >= (long)FD_UN * 128;
     int feat = -1;
     int *hint_host = nullptr, *hint_dev = nullptr;
     if (fd_possible) {
