@@ -72,7 +72,7 @@ def source_signature():
 
 
 def stamped_traffic(kernel_key):
-    """Fallback when the in-run PMC passes are unavailable: profiles/pmc_traffic.json (tools/pmc_traffic.sh), used only
+    """Fallback when the in-run PMC passes are unavailable: profiles/pmc_traffic.json (copied from the in-run passes of a kept bench line), used only
     when it was collected for the kernel sources in the tree."""
     try:
         d = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
