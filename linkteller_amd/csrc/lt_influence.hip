@@ -171,6 +171,8 @@ __device__ __forceinline__ void stageA_epilogue(f32x4 (&acc)[P], int lane, bool 
 #define LT_RING_NB 1   // half-blocks in flight behind the one being consumed (ring = 4*(NB+1) KiB per wave)
 #endif
 #define LT_RING_SLOTS (4 * (LT_RING_NB + 1))
+#define LT_REDO_W 4     // substituted probes of a wave recomputed together
+#define LT_REDO_AH 8    // entries in flight in that recomputation (16 for the single chain of a short row)
 #ifndef LT_RING_ROWS
 #define LT_RING_ROWS 1   // consecutive rows a wave walks (amortises wave launch)
 #endif
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
     const int32_t *__restrict__ probes, int nb, const float *__restrict__ Sp,
     float *__restrict__ S2p, int n_segblocks, const int32_t *__restrict__ seg_long,
     const int32_t *__restrict__ seg_begin, const int32_t *__restrict__ long_row,
-    float *__restrict__ lpart) {
+    float *__restrict__ lpart, unsigned *__restrict__ lhit) {
     static_assert((P * CP) % 4 == 0, "P*CP must be a multiple of 4");
     __shared__ __attribute__((aligned(16))) float ring[LT_RING_SLOTS * 256];
     const int lane = threadIdx.x;
@@ -388,72 +390,120 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
     const unsigned hitmask = (unsigned)hit;   // bit p: probe pb+p sits on one of this row's columns (probe ids sit in lanes < P <= 32)
     // A column of this row is one of my probes (about P*deg/n of the waves): the chains above used the
     // UNSUBSTITUTED S1 row for all P probes -- right for every probe but the one(s) sitting on that column.
-    // The epilogue leaves those out, and the wave recomputes them here, one single-probe chain each (row_dot
-    // + relu_w2_partial + group_sum, the chain every other kernel uses), with its accumulators dead and the
-    // row's S1 lines still warm in L1/L2.  Keeping the select path out of the hot loop is worth 50 VGPRs.
+    // The epilogue leaves those out, and the wave recomputes them below, one single-probe chain each (the chain
+    // every other kernel uses), with its accumulators dead and the row's S1 lines still warm in L1/L2.
+    // Keeping the select path out of the hot loop is worth 50 VGPRs.
     // group 0 also delivers the baseline column: any of its probes that met no substitution
     const int nvalid = min(nb - pb, P);
     const unsigned valid = nvalid >= 32 ? 0xffffffffu : ((1u << nvalid) - 1u);
     const unsigned clean = ~hitmask & valid;
     const int base_p = (pb == 0 && clean != 0u) ? __builtin_ctz(clean) : -1;
     const bool base_redo = pb == 0 && clean == 0u;   // every probe of group 0 sits on this row: recompute it plainly
-    // segment sums go to lpart: slot p < P = probe pb + p, slot P = the unperturbed segment (group 0 only);
-    // uniform slot base + 32-bit lane offset = the saddr store form
+    // segment sums go to lpart; uniform slot base + 32-bit lane offset = the saddr store form
     float *slot_base = segmode ? lpart + ((size_t)(sg * groups + pb / P) * (P + 1)) * Hp : nullptr;
     if constexpr (MODE == 0) {
         stageA_epilogue<CP, P>(acc, lane, active, coff, W2p, C, n, nb, r, pb, S2p, hitmask, base_p);
     } else if constexpr (MODE == 2) {
         stageA_epilogue<CP, P>(tot, lane, active, coff, W2p, C, n, nb, r, pb, S2p, hitmask, base_p);
     } else {
+        // The chains that met no substitution hold the same bits (P recomputations of the unperturbed segment), so ONE of
+        // them is stored -- slot P -- with the mask of the probes that did meet one (their own chains follow below, into
+        // their own slots); k_full_long_combine picks per (segment, probe).  P times less scratch than a slot per probe:
+        // 105 MB -> 3 MB per step on the power-law graph.
+        const int keep = clean != 0u ? __builtin_ctz(clean) : -1;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            if (!((hitmask >> p) & 1u)) {
-                char *sp = reinterpret_cast<char *>(slot_base + (size_t)p * Hp);
-                asm("" : "+s"(sp));
-                *reinterpret_cast<f32x4 *>(sp + lane_off) = acc[p];
-            }
-            if (p == base_p) {
+            if (p == keep) {   // wave-uniform
                 char *sp = reinterpret_cast<char *>(slot_base + (size_t)P * Hp);
                 asm("" : "+s"(sp));
                 *reinterpret_cast<f32x4 *>(sp + lane_off) = acc[p];
             }
         }
+        if (lane == 0) lhit[sg * groups + pb / P] = hitmask & valid;
     }
     if (__builtin_expect(hitmask != 0u || base_redo, 0)) {
-        // the probes that sit on one of the columns walked (and, if no chain of group 0 was clean, the
-        // unperturbed one) get their own single chain: over the row, or over this segment of it
+        // The probes that sit on one of the columns walked (and, if no chain of group 0 was clean, the unperturbed one)
+        // get their own single chain: over the row, or over this segment of it.  On long rows up to LT_REDO_W of them walk together
+        // -- every entry's S1 row is loaded once and serves them all, LT_REDO_AH entries in flight -- because on a hub
+        // segment, where a wave meets 0.9 substitutions on average and some meet five, one latency-bound pass per probe
+        // was the kernel's tail (133 us for a 60 us walk).
+        constexpr int W = MODE == 0 ? 1 : LT_REDO_W, AH = LT_REDO_AH;   // short rows: a wave rarely meets two
         const f32x4 b1r = first_seg ? ld4(b1p + coff) : f32x4{0.f, 0.f, 0.f, 0.f};
         unsigned m = hitmask;
         bool do_base = base_redo;
         while (m || do_base) {
-            int p = -1, v = -1;
-            if (m) {
-                p = __builtin_ctz(m);
-                m &= m - 1;
-                v = probes[pb + p];
-            } else {
-                do_base = false;
+            int pj[W], vj[W];   // probe slot (-1: the unperturbed chain, -2: none) and its node
+            f32x4 own[W], z[W], zt[W];
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                pj[j] = -2;
+                vj[j] = -1;
+                if (m) {
+                    pj[j] = __builtin_ctz(m);
+                    m &= m - 1;
+                    vj[j] = probes[pb + pj[j]];
+                } else if (do_base) {
+                    pj[j] = -1;
+                    do_base = false;
+                }
+                own[j] = ld4(Sp + (size_t)(pb + (pj[j] < 0 ? 0 : pj[j])) * Hp + coff);
             }
             // MODE 0 / 1: e1 - e0 <= LT_ROW_SEG, one segment chain (row_dot of a short row is the same thing);
-            // MODE 2: the whole long row, segment by segment
-            const f32x4 z = MODE == 2
-                ? row_dot(col, val, e0, e1, S1, Hp, coff, true, v, Sp + (size_t)(pb + (p < 0 ? 0 : p)) * Hp, b1r)
-                : seg_chain(col, val, e0, e1, S1, Hp, coff, true, v, Sp + (size_t)(pb + (p < 0 ? 0 : p)) * Hp, b1r);
-            if (segmode) {
-                char *sp = reinterpret_cast<char *>(slot_base + (size_t)(p < 0 ? P : p) * Hp);
-                *reinterpret_cast<f32x4 *>(sp + lane_off) = z;
-            } else {
-                float part[CP];
+            // MODE 2: the whole long row, segment by segment, the sums added in segment order (row_dot)
+            if constexpr (MODE == 0) {
+                zt[0] = e1 > e0 ? seg_chain_clamped<16>(col, val, e0, e1, S1, Hp, coff, vj[0],
+                                                        Sp + (size_t)(pb + (pj[0] < 0 ? 0 : pj[0])) * Hp, b1r)
+                                : b1r;
+            } else
+            for (int ws = e0; ws == e0 || ws < e1; ws += LT_ROW_SEG) {
+                const int we = min(e1, ws + LT_ROW_SEG);
 #pragma unroll
-                for (int c = 0; c < CP; ++c) part[c] = 0.f;
-                if (active) relu_w2_partial<CP>(z, W2p + (size_t)coff * C, C, part);
+                for (int j = 0; j < W; ++j) z[j] = ws == e0 ? b1r : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int e = ws; e < we; e += AH) {
+                    int c[AH];
+                    float a[AH];
+                    f32x4 sv[AH];
 #pragma unroll
-                for (int c = 0; c < CP; ++c) part[c] = group_sum<64>(part[c]);
-                if (lane == 0) {
-                    float *dst = S2p + ((size_t)r * (nb + 1) + (p < 0 ? nb : pb + p)) * C;
+                    for (int k = 0; k < AH; ++k) {
+                        const int ee = min(e + k, we - 1);   // past the end: the last entry again, unused
+                        c[k] = col[ee];
+                        a[k] = val[ee];
+                    }
 #pragma unroll
-                    for (int c = 0; c < CP; ++c)
-                        if (c < C) dst[c] = part[c];
+                    for (int k = 0; k < AH; ++k) sv[k] = ld4(S1 + (size_t)c[k] * Hp + coff);
+#pragma unroll
+                    for (int k = 0; k < AH; ++k) {
+                        if (e + k >= we) break;   // wave-uniform
+#pragma unroll
+                        for (int j = 0; j < W; ++j) z[j] = fma4(a[k], c[k] == vj[j] ? own[j] : sv[k], z[j]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    if (ws == e0) zt[j] = z[j];
+                    else { zt[j].x += z[j].x; zt[j].y += z[j].y; zt[j].z += z[j].z; zt[j].w += z[j].w; }
+                }
+                if (MODE != 2) break;
+            }
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                if (pj[j] == -2) continue;   // wave-uniform
+                if (segmode) {
+                    char *sp = reinterpret_cast<char *>(slot_base + (size_t)(pj[j] < 0 ? P : pj[j]) * Hp);
+                    *reinterpret_cast<f32x4 *>(sp + lane_off) = zt[j];
+                } else {
+                    float part[CP];
+#pragma unroll
+                    for (int c = 0; c < CP; ++c) part[c] = 0.f;
+                    if (active) relu_w2_partial<CP>(zt[j], W2p + (size_t)coff * C, C, part);
+#pragma unroll
+                    for (int c = 0; c < CP; ++c) part[c] = group_sum<64>(part[c]);
+                    if (lane == 0) {
+                        float *dst = S2p + ((size_t)r * (nb + 1) + (pj[j] < 0 ? nb : pb + pj[j])) * C;
+#pragma unroll
+                        for (int c = 0; c < CP; ++c)
+                            if (c < C) dst[c] = part[c];
+                    }
                 }
             }
         }
@@ -473,7 +523,8 @@ __global__ __launch_bounds__(64) void k_full_stageA_lds(
 template <int CP, int P>
 __global__ __launch_bounds__(LT_BLOCK) void k_full_long_combine(
     int Hp, const float *__restrict__ W2p, int C, int nb, int n_long, const int32_t *__restrict__ long_row,
-    const int32_t *__restrict__ long_segptr, const float *__restrict__ lpart, float *__restrict__ S2p) {
+    const int32_t *__restrict__ long_segptr, const float *__restrict__ lpart, const unsigned *__restrict__ lhit,
+    float *__restrict__ S2p) {
     const int lane = threadIdx.x & 63;
     const long wid = ((long)blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
     const int li = (int)(wid / (nb + 1)), b = (int)(wid % (nb + 1));
@@ -484,8 +535,11 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_long_combine(
     const int s0 = long_segptr[li], s1 = long_segptr[li + 1];
     const bool active = 4 * lane < Hp;
     const int coff = active ? 4 * lane : Hp - 4;
+    // slot P of a (segment, group) holds the unperturbed segment sum; a probe that sits on one of the segment's columns
+    // (bit of lhit) has its own
     auto slot = [&](int s) {
-        return *reinterpret_cast<const f32x4 *>(lpart + ((size_t)(s * groups + g) * (P + 1) + sl) * Hp + coff);
+        const int own = (b < nb && ((lhit[s * groups + g] >> sl) & 1u)) ? sl : P;
+        return *reinterpret_cast<const f32x4 *>(lpart + ((size_t)(s * groups + g) * (P + 1) + own) * Hp + coff);
     };
     f32x4 z = slot(s0);
     int s = s0 + 1;
@@ -1116,6 +1170,64 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_rows(
     // (independent bitmap loads) -- untouched pairs get their 0 at once, touched ones go onto a block-wide LDS list; (2) the
     // groups take the listed pairs round-robin, so the few touched pairs of a block (7 % at twitch size) run side by side
     // instead of one after the other inside the group that found them.  The list order is arbitrary: pairs are independent.
+    if constexpr (DELTA) {
+        // DELTA: only the members of R_v in the row contribute, and the bitmap word that answers "is this column a member"
+        // also gives its position in R_v -- so the lane that tests an entry (lane q tests exactly the entries of chain q)
+        // adds the member's term at once: no second phase, no look-up.  Same FMAs in the same per-chain order, then the same
+        // 8-lane butterfly as row2_dot: the bits of k_item_stageB.
+        for (int b0 = b_begin + grp; b0 < b_end; b0 += GROUPS * LT_SB_UNR) {
+            float acc[LT_SB_UNR][CP];
+            int t[LT_SB_UNR];
+#pragma unroll
+            for (int k = 0; k < LT_SB_UNR; ++k) {
+                const int b = b0 + k * GROUPS;
+#pragma unroll
+                for (int c = 0; c < CP; ++c) acc[k][c] = 0.f;
+                t[k] = 0;
+                if (b < b_end) {
+                    const uint2 *mb = bits + (size_t)b * words;
+                    const float *items = S2x + (size_t)off[b] * C;
+                    for (int e = q; e < d; e += LT_L2_LANES) {
+                        const int c = scol[e];
+                        const uint2 w = mb[c >> 5];
+                        const unsigned bit = 1u << (c & 31);
+                        if (w.x & bit) {
+                            const float *it = items + (size_t)(w.y + __popc(w.x & (bit - 1u))) * C;
+                            const float a = sval[e];
+#pragma unroll
+                            for (int cc = 0; cc < CP; ++cc)
+                                if (cc < C) acc[k][cc] = fmaf(a, it[cc], acc[k][cc]);
+                            t[k] = 1;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < LT_SB_UNR; ++k)
+#pragma unroll
+                for (int m = LT_L2_LANES / 2; m >= 1; m >>= 1) t[k] |= __shfl_xor(t[k], m, 64);
+#pragma unroll
+            for (int k = 0; k < LT_SB_UNR; ++k) {
+                const int b = b0 + k * GROUPS;
+                if (b >= b_end) continue;     // group-uniform
+                float res = 0.f;
+                if (t[k]) {                   // group-uniform
+                    float ss = 0.f;
+#pragma unroll
+                    for (int cc = 0; cc < CP; ++cc) {
+                        const float o = group_sum<LT_L2_LANES>(acc[k][cc]);
+                        if (cc < C) {
+                            const float dd = o / delta;
+                            ss = fmaf(dd, dd, ss);
+                        }
+                    }
+                    res = sqrtf(ss);
+                }
+                if (q == 0) out[(long)b * ldo + j] = res;
+            }
+        }
+        return;
+    }
     __shared__ int32_t s_list[LT_SB_PASS];
     __shared__ int32_t s_cnt;
     for (int p0 = b_begin; p0 < b_end; p0 += LT_SB_PASS) {
@@ -1236,6 +1348,7 @@ static int probe_kslice(const lt_baseline *b) {
 struct infl_ws {
     float *Sp, *S2p;       // FULL / SPARSE: S1 rows of the perturbed probes; FULL: per-probe S2
     float *lpart;          // FULL: segment sums of the long rows [segment][group][P + 1][Hp]
+    unsigned *lhit;        // FULL: which probes of a (segment, group) wrote a slot of their own
     float *slabs;          // FULL / SPARSE: split-K partials of the perturbed-row GEMM
     float *S2x;            // SPARSE / DELTA: per-item values
     double *Spd;           // DELTA, aggregate-first route: fp64 product rows of the chunk's probes [chunk, Hp]
@@ -1280,6 +1393,7 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int n_o
         w.S2p = (float *)take((chunk + 1) * n * C * sizeof(float));   // + the baseline column
         // groups * (P + 1) slots per segment: at most ceil(chunk / 8) * 9 (P = 8), or chunk / 32 * 33 + 33
         w.lpart = (float *)take(nseg * (((chunk + 7) / 8) * 9 + 33) * Hp * sizeof(float));
+        w.lhit = (unsigned *)take(nseg * ((chunk + 7) / 8 + 1) * sizeof(unsigned));   // per (segment, group): probes with a slot of their own
     }
     if (mode == LT_MODE_DELTA) w.Spd = (double *)take(chunk * Hp * sizeof(double));   // aggregate-first: X[probes] W1 in fp64
     if (mode != LT_MODE_FULL) {
@@ -1429,25 +1543,27 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
         if (n_segblocks > 0) {                                                                                \
             LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, P_, 1>), dim3(n_segblocks),         \
                                                    dim3(64), 0, ls, LT_RING_ARGS, n_segblocks,                \
-                                                   g->p_seg_long, g->p_seg_begin, g->p_long_row, w.lpart));   \
+                                                   g->p_seg_long, g->p_seg_begin, g->p_long_row, w.lpart,     \
+                                                   w.lhit));                                                  \
             LT_CHECK_LAUNCH();                                                                                \
             LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_long_combine<CP_, P_>),                             \
                                                    dim3((unsigned)(((long)g->p_n_long * (nb + 1) + 3) / 4)),  \
                                                    dim3(LT_BLOCK), 0, ls, Hp, b->W2p, C, nb, g->p_n_long,     \
-                                                   g->p_long_row, g->p_long_segptr, w.lpart, w.S2p));         \
+                                                   g->p_long_row, g->p_long_segptr, w.lpart, w.lhit, w.S2p)); \
             LT_CHECK_LAUNCH();                                                                                \
         }                                                                                                     \
         LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, P_, 0>), gridr, dim3(64), 0, st,        \
                                                LT_RING_ARGS, 0, (const int32_t *)nullptr,                     \
                                                (const int32_t *)nullptr, (const int32_t *)nullptr,            \
-                                               (float *)nullptr));                                            \
+                                               (float *)nullptr, (unsigned *)nullptr));                       \
     } while (0)
 #define LT_LONG_LAUNCH(P_)                                                                                    \
     do {                                                                                                      \
         LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_full_stageA_lds<CP_, P_, 2>),                                \
                                                dim3((unsigned)((long)g->p_n_long * lgroups)), dim3(64), 0,    \
                                                ls, LT_RING_ARGS, 0, (const int32_t *)nullptr,                 \
-                                               (const int32_t *)nullptr, g->p_long_row, (float *)nullptr));   \
+                                               (const int32_t *)nullptr, g->p_long_row, (float *)nullptr,     \
+                                               (unsigned *)nullptr));                                         \
         LT_CHECK_LAUNCH();                                                                                    \
     } while (0)
                 if (g->p_n_long > 0 && !par) {

@@ -121,6 +121,36 @@ __device__ __forceinline__ f32x4 seg_chain(const int32_t *__restrict__ col, cons
     }
     return acc;
 }
+// The same chain with every trip -- the last one too -- issuing AHEAD gathers at once: a trip past the end re-reads the
+// last entry (clamped index, never used) instead of falling back to one gather per round trip.  For callers whose run time
+// IS this chain's latency (FULL stage A recomputing a substituted probe: a d-entry row is ceil(d / AHEAD) round trips
+// instead of d / 4 + d % 4).  e1 > e0; e0, e1 wave-uniform.
+template <int AHEAD>
+__device__ __forceinline__ f32x4 seg_chain_clamped(const int32_t *__restrict__ col, const float *__restrict__ val,
+                                                   int e0, int e1, const float *__restrict__ S, int ld, int coff,
+                                                   int subst_col, const float *__restrict__ subst_row, f32x4 init) {
+    f32x4 acc = init;
+    for (int e = e0; e < e1; e += AHEAD) {
+        int c[AHEAD];
+        float a[AHEAD];
+        f32x4 s[AHEAD];
+#pragma unroll
+        for (int k = 0; k < AHEAD; ++k) {
+            const int ee = min(e + k, e1 - 1);
+            c[k] = col[ee];
+            a[k] = val[ee];
+        }
+#pragma unroll
+        for (int k = 0; k < AHEAD; ++k) {
+            const float *src = (c[k] == subst_col) ? subst_row : S + (size_t)c[k] * ld;
+            s[k] = ld4(src + coff);
+        }
+#pragma unroll
+        for (int k = 0; k < AHEAD; ++k)
+            if (e + k < e1) acc = fma4(a[k], s[k], acc);   // wave-uniform
+    }
+    return acc;
+}
 template <int AHEAD = 4>
 __device__ __forceinline__ f32x4 row_dot(const int32_t *__restrict__ col,
                                          const float *__restrict__ val, int e0, int e1,
