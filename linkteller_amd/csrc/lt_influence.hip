@@ -536,23 +536,34 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_long_combine(
     const bool active = 4 * lane < Hp;
     const int coff = active ? 4 * lane : Hp - 4;
     // slot P of a (segment, group) holds the unperturbed segment sum; a probe that sits on one of the segment's columns
-    // (bit of lhit) has its own
-    auto slot = [&](int s) {
-        const int own = (b < nb && ((lhit[s * groups + g] >> sl) & 1u)) ? sl : P;
-        return *reinterpret_cast<const f32x4 *>(lpart + ((size_t)(s * groups + g) * (P + 1) + own) * Hp + coff);
+    // (bit of lhit) has its own.  The masks of 64 segments are fetched at once, one per lane: `mine` = the segments (bits)
+    // where this wave's probe has a slot of its own.
+    auto masks = [&](int sb) {
+        const int sx = sb + lane;
+        const unsigned m = (b < nb && sx < s1) ? lhit[sx * groups + g] : 0u;
+        return __ballot((m >> (sl & 31)) & 1u);
     };
-    f32x4 z = slot(s0);
-    int s = s0 + 1;
-    for (; s + 8 <= s1; s += 8) {   // 8 segment sums in flight, added in segment order
-        f32x4 t[8];
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int sb = s0; sb < s1; sb += 64) {
+        const unsigned long long mine = masks(sb);
+        const int se = min(s1, sb + 64);
+        auto slot = [&](int s) {
+            const int own = ((mine >> (s - sb)) & 1ull) ? sl : P;
+            return *reinterpret_cast<const f32x4 *>(lpart + ((size_t)(s * groups + g) * (P + 1) + own) * Hp + coff);
+        };
+        int s = sb;
+        if (sb == s0) z = slot(s++);   // the first segment's sum starts the total (it holds the bias)
+        for (; s + 8 <= se; s += 8) {   // 8 segment sums in flight, added in segment order
+            f32x4 t[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = slot(s + k);
+            for (int k = 0; k < 8; ++k) t[k] = slot(s + k);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { z.x += t[k].x; z.y += t[k].y; z.z += t[k].z; z.w += t[k].w; }
-    }
-    for (; s < s1; ++s) {
-        const f32x4 t = slot(s);
-        z.x += t.x; z.y += t.y; z.z += t.z; z.w += t.w;
+            for (int k = 0; k < 8; ++k) { z.x += t[k].x; z.y += t[k].y; z.z += t[k].z; z.w += t[k].w; }
+        }
+        for (; s < se; ++s) {
+            const f32x4 t = slot(s);
+            z.x += t.x; z.y += t.y; z.z += t.z; z.w += t.w;
+        }
     }
     float part[CP];
 #pragma unroll
