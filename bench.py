@@ -383,6 +383,20 @@ def main():
             pending.append(work)
         return full
 
+    def wall_median(fn, steps, blocks=5, warm=3):
+        """Seconds per call of fn: median over `blocks` synchronize-bracketed blocks of `steps` calls (the side legs)."""
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(blocks):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / steps)
+        return float(np.median(ts))
+
     def drain():
         while pending:
             pending.pop().wait()
@@ -572,14 +586,7 @@ def main():
             out_h = torch.empty((a.n_test, a.n_test), dtype=torch.float32, device=dev)
             res_h = {}
             for m in ("delta", "full", "sparse"):
-                for _ in range(2):
-                    base_h.refresh(m); base_h.influence_rows(obs, obs, delta, m, out=out_h)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(10):
-                    base_h.refresh(m); base_h.influence_rows(obs, obs, delta, m, out=out_h)
-                torch.cuda.synchronize()
-                res_h[m] = (time.perf_counter() - t0) / 10
+                res_h[m] = wall_median(lambda: (base_h.refresh(m), base_h.influence_rows(obs, obs, delta, m, out=out_h)), 20)
             extras["workload_2"] = {"workload": f"n_test={a.n_test} {a.workload}-shaped POWER-LAW graph (same N, E; what real MUSAE graphs look like)",
                                     "max_degree": int(np.diff(ah.indptr).max()),
                                     "value": round(a.n_test ** 2 / res_h[a.mode], 1), "unit": "node-pairs/s", "mode": a.mode,
@@ -593,14 +600,7 @@ def main():
             out3 = torch.empty((2000, 2000), dtype=torch.float32, device=dev)
             res3 = {}
             for m in ("delta", "sparse", "full"):
-                for _ in range(2):
-                    base.refresh(m); base.influence_rows(nodes3, nodes3, delta, m, out=out3)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(5):
-                    base.refresh(m); base.influence_rows(nodes3, nodes3, delta, m, out=out3)
-                torch.cuda.synchronize()
-                res3[m] = (time.perf_counter() - t0) / 5
+                res3[m] = wall_median(lambda: (base.refresh(m), base.influence_rows(nodes3, nodes3, delta, m, out=out3)), 10)
             extras["workload_3"] = {"workload": f"n_test=2000 on the same graph, one GPU (BASELINE configs[2] shards it over 8)",
                                     "value": round(2000 ** 2 / res3[a.mode], 1), "unit": "node-pairs/s", "mode": a.mode,
                                     **{f"{m}_ms_per_step": round(res3[m] * 1e3, 4) for m in res3}}
