@@ -825,6 +825,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
 // (e - e0) & 7, k-ordered, non-members skipped in DELTA), same butterfly, same tail: the bits of k_item_stageB.
 #define LT_SBL_CHUNK 1024
 #define LT_SBL_UN 8
+#define LT_SBL_UN_DELTA 32
 #define LT_SBL_NS 8        // light probes: searches in flight per lane
 #define LT_SBL_MC 128      // SPARSE: members of a light probe kept in LDS at a time (> 64 + a search round: see fill)
 template <int CP, bool DELTA, bool SHORT>   // SHORT: the short-side search (without it every probe tests every entry, no member lists in LDS)
@@ -836,18 +837,22 @@ __device__ __forceinline__ void stageB_long_block(
     const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
     const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
     float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words,
-    const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot) {
+    const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot, const int32_t *__restrict__ hub_obs) {
     constexpr int CHUNK = CP <= 2 ? LT_SBL_CHUNK : (CP <= 4 ? LT_SBL_CHUNK / 2 : LT_SBL_CHUNK / 4);   // LDS: <= 16 KB
     constexpr int GROUPS = LT_BLOCK / LT_L2_LANES;
+    // entries of the walk whose membership tests are in flight per lane: DELTA keeps nothing else per entry (no baseline
+    // row), and an observed hub of 1 700 entries is 27 dependent rounds at 8
+    constexpr int UN = DELTA ? LT_SBL_UN_DELTA : LT_SBL_UN;
     __shared__ int sc[CHUNK];
     __shared__ float sv[CHUNK];
     __shared__ float sT[DELTA ? 1 : CHUNK][CP];
     __shared__ int2 smem[(DELTA || !SHORT) ? 1 : GROUPS][(DELTA || !SHORT) ? 1 : LT_SBL_MC];   // SPARSE, light probes: (entry - e0, position in R_v)
     const int pblocks = (nb + GROUPS - 1) / GROUPS;
-    const int j = bid / pblocks;
+    // the launch has blocks for min(n_obs, hub rows of the graph) observed hubs; hub_obs (k_item_bits) lists the ones there are
+    if (bid / pblocks >= hub_obs[0]) return;     // block-uniform exit
+    const int j = hub_obs[1 + bid / pblocks];
     const int u = observe[j];
     const int e0 = rowptr[u], e1 = rowptr[u + 1];
-    if (e1 - e0 <= LT_ROW_SEG) return;           // not a hub: k_item_stageB has it (block-uniform exit)
     const int d = e1 - e0;
     const int tid = threadIdx.x;
     const int q = tid & (LT_L2_LANES - 1);
@@ -870,7 +875,10 @@ __device__ __forceinline__ void stageB_long_block(
     // (group-uniform) per-entry tests cost d / 64 rounds of one load (a miss, ~ 2x an L2 hit) with a bitmap row, of
     // log |R_v| loads without; the search from the R_v side costs |R_v| / (8 NS) rounds of log d loads
     const int lg_d = 32 - __clz(d), lg_c = 32 - __clz(cnt > 1 ? cnt : 1);
-    const bool heavy = live && (!SHORT || (mb ? (long)cnt * lg_d > d : 2L * cnt * lg_d > (long)d * lg_c));
+    // with a bitmap row, in dependent rounds: the walk is d / (8 lanes * UN) of them, the search (lg d + 2) per 64 members
+    const bool heavy = live && (!SHORT || (mb ? (DELTA ? (long)((cnt + 63) / 64) * (lg_d + 2) > (d + LT_L2_LANES * UN - 1) / (LT_L2_LANES * UN)
+                                                       : (long)cnt * lg_d > d)
+                                              : 2L * cnt * lg_d > (long)d * lg_c));
     const bool light = live && !heavy;
     const int32_t *cu = col + e0;
     const int gl0 = (tid & 63) & ~(LT_L2_LANES - 1);    // first lane of the group inside its wave
@@ -965,26 +973,42 @@ __device__ __forceinline__ void stageB_long_block(
             }
             __syncthreads();
             if (!walk) continue;
-            for (int i = q; i < nc; i += LT_L2_LANES * LT_SBL_UN) {
-                int mp[LT_SBL_UN];
-                float a_[LT_SBL_UN], tb[LT_SBL_UN][CP];
+            for (int i = q; i < nc; i += LT_L2_LANES * UN) {
+                int mp[UN];
+                float a_[UN], tb[DELTA ? 1 : UN][CP];
 #pragma unroll
-                for (int k = 0; k < LT_SBL_UN; ++k) {
+                for (int k = 0; k < UN; ++k) {
                     const int ii = i + k * LT_L2_LANES;
                     mp[k] = -1;
                     a_[k] = ii < nc ? sv[ii] : 0.f;
 #pragma unroll
-                    for (int c = 0; c < CP; ++c) tb[k][c] = (!DELTA && ii < nc) ? sT[ii][c] : 0.f;
+                    for (int c = 0; c < CP; ++c)
+                        if (!DELTA) tb[k][c] = ii < nc ? sT[ii][c] : 0.f;
                 }
-                if (heavy) {
+                if (heavy && mb) {
+                    // the membership words of UN entries in flight together: unconditional loads (past the chunk end: its
+                    // last entry again) -- hipcc drains the queue in front of every load it finds behind a branch
+                    uint2 wv[UN];
+                    int cv[UN];
 #pragma unroll
-                    for (int k = 0; k < LT_SBL_UN; ++k) {   // the membership loads of 8 entries in flight together
+                    for (int k = 0; k < UN; ++k) {
+                        cv[k] = sc[min(i + k * LT_L2_LANES, nc - 1)];
+                        wv[k] = mb[cv[k] >> 5];
+                    }
+#pragma unroll
+                    for (int k = 0; k < UN; ++k) {
+                        const unsigned bit = 1u << (cv[k] & 31);
+                        if (i + k * LT_L2_LANES < nc && (wv[k].x & bit)) mp[k] = (int)(wv[k].y + __popc(wv[k].x & (bit - 1u)));
+                    }
+                } else if (heavy) {
+#pragma unroll
+                    for (int k = 0; k < UN; ++k) {
                         const int ii = i + k * LT_L2_LANES;
                         if (ii < nc) mp[k] = pos(sc[ii]);
                     }
                 } else if (!DELTA) {
                     const int base_e = cb - e0 + (i - q);       // the group's next 64 entries start here
-                    const int end_e = base_e + LT_L2_LANES * LT_SBL_UN;
+                    const int end_e = base_e + LT_L2_LANES * UN;
                     if (r_next < cnt && last_e < end_e) {       // the list may end inside them: refill it
                         fill(base_e);
                         mg = 0;
@@ -997,14 +1021,14 @@ __device__ __forceinline__ void stageB_long_block(
                         const int rel = next_e - base_e, p = smem[grp][mg].y;
                         const bool mine = (rel & (LT_L2_LANES - 1)) == q;
 #pragma unroll
-                        for (int k = 0; k < LT_SBL_UN; ++k)
+                        for (int k = 0; k < UN; ++k)
                             if (mine && (rel >> 3) == k) mp[k] = p;
                         ++mg;
                         next_e = mg < nmem ? smem[grp][mg].x : 0x7fffffff;
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < LT_SBL_UN; ++k) {
+                for (int k = 0; k < UN; ++k) {
                     const int ii = i + k * LT_L2_LANES;
                     if (ii >= nc) break;
                     const float a = a_[k];
@@ -1017,7 +1041,7 @@ __device__ __forceinline__ void stageB_long_block(
                     } else if (!DELTA) {
 #pragma unroll
                         for (int c = 0; c < CP; ++c)
-                            if (c < C) acc[c] = fmaf(a, tb[k][c], acc[c]);
+                            if (c < C) acc[c] = fmaf(a, tb[DELTA ? 0 : k][c], acc[c]);
                     }
                 }
             }
@@ -1058,9 +1082,9 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_hubs(
     const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
     const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
     float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words,
-    const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot) {
+    const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot, const int32_t *__restrict__ hub_obs) {
     stageB_long_block<CP, DELTA, SHORT>((int)blockIdx.x, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off, S2x,
-                                        observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot);
+                                        observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot, hub_obs);
 }
 
 // SPARSE / DELTA stage B: 8 lanes per (probe, observed node).
@@ -1074,7 +1098,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
     const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
     float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words, int long_blocks, int skip_long,
     const unsigned *__restrict__ marks, const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot,
-    int hub_short) {
+    int hub_short, const int32_t *__restrict__ hub_obs) {
     // long_blocks > 0 (the graph has hub rows): the first long_blocks blocks serve the observed hubs
     // (stageB_long_block: most of them find a plain row and exit); skip_long: the pairs below leave those rows alone
     // (SPARSE with the short-side search: k_item_stageB_hubs has them, long_blocks = 0 here)
@@ -1082,10 +1106,10 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
         if (hub_short) {
             if constexpr (DELTA)
                 stageB_long_block<CP, DELTA, true>((int)blockIdx.x, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off,
-                                                   S2x, observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot);
+                                                   S2x, observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot, hub_obs);
         } else {
             stageB_long_block<CP, DELTA, false>((int)blockIdx.x, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off,
-                                                S2x, observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot);
+                                                S2x, observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot, hub_obs);
         }
         return;
     }
@@ -1156,6 +1180,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
 // the only global traffic of an untouched pair).  The touched pairs run row2_dot over the staged row: same chains
 // (entry e -> chain (e - e0) & 7, k-ordered), same butterfly, same tail -- the bits of k_item_stageB.
 #define LT_SB_UNR 4
+#define LT_SB_SHORT 32    // rows up to this many entries test their probes one after the other (DELTA)
 #define LT_SB_PASS 2048   // probes per pass of a block (its touched pairs are listed in LDS)
 template <int CP, bool DELTA>
 __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_rows(
@@ -1189,27 +1214,51 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_rows(
         for (int b0 = b_begin + grp; b0 < b_end; b0 += GROUPS * LT_SB_UNR) {
             float acc[LT_SB_UNR][CP];
             int t[LT_SB_UNR];
+            const uint2 *mb[LT_SB_UNR];
+            const float *items[LT_SB_UNR];
 #pragma unroll
             for (int k = 0; k < LT_SB_UNR; ++k) {
-                const int b = b0 + k * GROUPS;
+                const int b = min(b0 + k * GROUPS, b_end - 1);   // past the end: the last probe again, never stored
 #pragma unroll
                 for (int c = 0; c < CP; ++c) acc[k][c] = 0.f;
                 t[k] = 0;
-                if (b < b_end) {
-                    const uint2 *mb = bits + (size_t)b * words;
-                    const float *items = S2x + (size_t)off[b] * C;
+                mb[k] = bits + (size_t)b * words;
+                items[k] = S2x + (size_t)off[b] * C;
+            }
+            if (d <= LT_SB_SHORT) {
+                // short rows (a lane holds one to four entries): one probe after the other, measured faster there
+#pragma unroll
+                for (int k = 0; k < LT_SB_UNR; ++k) {
                     for (int e = q; e < d; e += LT_L2_LANES) {
                         const int c = scol[e];
-                        const uint2 w = mb[c >> 5];
+                        const uint2 w = mb[k][c >> 5];
                         const unsigned bit = 1u << (c & 31);
                         if (w.x & bit) {
-                            const float *it = items + (size_t)(w.y + __popc(w.x & (bit - 1u))) * C;
+                            const float *it = items[k] + (size_t)(w.y + __popc(w.x & (bit - 1u))) * C;
                             const float a = sval[e];
 #pragma unroll
                             for (int cc = 0; cc < CP; ++cc)
                                 if (cc < C) acc[k][cc] = fmaf(a, it[cc], acc[k][cc]);
                             t[k] = 1;
                         }
+                    }
+                }
+            } else
+            for (int e = q; e < d; e += LT_L2_LANES) {
+                const int c = scol[e];
+                const float a = sval[e];
+                const unsigned bit = 1u << (c & 31);
+                uint2 w[LT_SB_UNR];
+#pragma unroll
+                for (int k = 0; k < LT_SB_UNR; ++k) w[k] = mb[k][c >> 5];   // the LT_SB_UNR tests of an entry in flight together
+#pragma unroll
+                for (int k = 0; k < LT_SB_UNR; ++k) {
+                    if (w[k].x & bit) {
+                        const float *it = items[k] + (size_t)(w[k].y + __popc(w[k].x & (bit - 1u))) * C;
+#pragma unroll
+                        for (int cc = 0; cc < CP; ++cc)
+                            if (cc < C) acc[k][cc] = fmaf(a, it[cc], acc[k][cc]);
+                        t[k] = 1;
                     }
                 }
             }
@@ -1360,6 +1409,7 @@ struct infl_ws {
     float *Sp, *S2p;       // FULL / SPARSE: S1 rows of the perturbed probes; FULL: per-probe S2
     float *lpart;          // FULL: segment sums of the long rows [segment][group][P + 1][Hp]
     unsigned *lhit;        // FULL: which probes of a (segment, group) wrote a slot of their own
+    int32_t *hub_obs;      // SPARSE / DELTA: [0] = observed hubs, [1 ...] = their positions in observe_nodes
     float *slabs;          // FULL / SPARSE: split-K partials of the perturbed-row GEMM
     float *S2x;            // SPARSE / DELTA: per-item values
     double *Spd;           // DELTA, aggregate-first route: fp64 product rows of the chunk's probes [chunk, Hp]
@@ -1408,6 +1458,7 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int n_o
     }
     if (mode == LT_MODE_DELTA) w.Spd = (double *)take(chunk * Hp * sizeof(double));   // aggregate-first: X[probes] W1 in fp64
     if (mode != LT_MODE_FULL) {
+        w.hub_obs = (int32_t *)take(((size_t)n_obs + 1) * sizeof(int32_t));   // the observed nodes that are hub rows (k_item_bits)
         w.S2x = (float *)take(chunk * maxc * C * sizeof(float));
         w.off = (int32_t *)take((chunk + 1) * sizeof(int32_t));
         w.item_pr = (int2 *)take(chunk * maxc * sizeof(int2));
@@ -1514,7 +1565,8 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                    nb, n_obs);
         const unsigned gridB = (unsigned)((pairs * LT_L2_LANES + LT_BLOCK - 1) / LT_BLOCK);
         // SPARSE / DELTA on a graph with hub rows: blocks for the observed hubs ride in front of stage B's launch
-        const long long_blocks = (mode != LT_MODE_FULL && g->p_n_long > 0) ? ((nb + 31) / 32) * (long)n_obs : 0;
+        // hub blocks: 32 probes x one observed hub each, for at most as many observed hubs as the graph has hub rows
+        const long long_blocks = (mode != LT_MODE_FULL && g->p_n_long > 0) ? ((nb + 31) / 32) * (long)(n_obs < g->p_n_long ? n_obs : g->p_n_long) : 0;
         LT_REQUIRE(gridB + long_blocks < 2147483647L, "lt_influence_rows: stage-B grid limit");
 
         if (mode != LT_MODE_DELTA) {
@@ -1620,8 +1672,9 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
             if (w.big_slot) LT_HIP(hipMemsetAsync(w.big_slot + w.chunk, 0, sizeof(int32_t), st));
             const unsigned *marks = nullptr;
             { lt_prof_scope prof_(LT_K_ITEM_BITS, st);
-            hipLaunchKernelGGL(k_item_bits, dim3(nb), dim3(256), 0, st, g->tptr, g->trow, probes, nb, words, w.bits, w.off, w.item_pr,
-                               w.big_bits, w.big_slot, w.big_slot ? w.big_slot + w.chunk : (int32_t *)nullptr);
+            hipLaunchKernelGGL(k_item_bits, dim3(nb + (long_blocks > 0 ? 1 : 0)), dim3(256), 0, st, g->tptr, g->trow, probes, nb, words,
+                               w.bits, w.off, w.item_pr, w.big_bits, w.big_slot, w.big_slot ? w.big_slot + w.chunk : (int32_t *)nullptr,
+                               g->rowptr, observe_nodes, n_obs, w.hub_obs);
             LT_CHECK_LAUNCH();
             if (use_marks) {
                 LT_HIP(hipMemsetAsync(w.pm_marks, 0, (size_t)((pairs + 31) / 32) * sizeof(unsigned), st));
@@ -1646,7 +1699,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                            dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
                                                            g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
                                                            nb, w.off, w.S2x, observe_nodes, n_obs, delta,
-                                                           orow, (long)ldo, w.bits, words, w.big_bits, w.big_slot));
+                                                           orow, (long)ldo, w.bits, words, w.big_bits, w.big_slot, w.hub_obs));
                     LT_CHECK_LAUNCH();
                 }
                 const unsigned inl = hub_short ? 0u : (unsigned)long_blocks;   // hub blocks in front of the pair launch
@@ -1656,7 +1709,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                                g->rowptr, g->col, g->val, g->tptr, g->trow, b->S2, C, b->b2,
                                                                b->OUT, probes, nb, w.off, w.S2x, observe_nodes, n_obs, delta,
                                                                orow, (long)ldo, w.bits, words, (int)inl, 1, marks, w.big_bits,
-                                                               w.big_slot, 0));
+                                                               w.big_slot, 0, w.hub_obs));
                         LT_CHECK_LAUNCH();
                     }
                     LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_rows<CP_, false>), dim3((unsigned)((long)n_obs * psplit)),
@@ -1669,7 +1722,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                        g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
                                                        nb, w.off, w.S2x, observe_nodes, n_obs, delta,
                                                        orow, (long)ldo, w.bits, words, (int)inl, long_blocks > 0 ? 1 : 0, marks,
-                                                       w.big_bits, w.big_slot, 0));
+                                                       w.big_bits, w.big_slot, 0, w.hub_obs));
             } else {
                 const double *spd = nullptr;
                 if (b->Z1d && lt_fp64_agg_active(b)) {
@@ -1709,7 +1762,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                                st, g->rowptr, g->col, g->val, g->tptr, g->trow, b->S2, C, b->b2,
                                                                b->OUT, probes, nb, w.off, w.S2x, observe_nodes, n_obs, delta, orow,
                                                                (long)ldo, w.bits, words, (int)long_blocks, 1, marks, w.big_bits,
-                                                               w.big_slot, hub_short ? 1 : 0));
+                                                               w.big_slot, hub_short ? 1 : 0, w.hub_obs));
                         LT_CHECK_LAUNCH();
                     }
                     LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_rows<CP_, true>), dim3((unsigned)((long)n_obs * psplit)),
@@ -1722,7 +1775,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                        g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
                                                        nb, w.off, w.S2x, observe_nodes, n_obs, delta,
                                                        orow, (long)ldo, w.bits, words, (int)long_blocks, long_blocks > 0 ? 1 : 0,
-                                                       marks, w.big_bits, w.big_slot, hub_short ? 1 : 0));
+                                                       marks, w.big_bits, w.big_slot, hub_short ? 1 : 0, w.hub_obs));
             }
             LT_CHECK_LAUNCH();
         }

@@ -39,7 +39,24 @@ static __global__ __launch_bounds__(256) void k_item_bits(const int32_t *__restr
                                                    const int32_t *__restrict__ probes, int nb, int words,
                                                    uint2 *__restrict__ bits, int32_t *__restrict__ off,
                                                    int2 *__restrict__ item_pr, uint2 *__restrict__ big_bits,
-                                                   int32_t *__restrict__ big_slot, int32_t *__restrict__ big_count) {
+                                                   int32_t *__restrict__ big_slot, int32_t *__restrict__ big_count,
+                                                   const int32_t *__restrict__ rowptr = nullptr,
+                                                   const int32_t *__restrict__ observe = nullptr, int n_obs = 0,
+                                                   int32_t *__restrict__ hub_obs = nullptr) {
+    // One block more than probes (hub_obs != NULL): it lists the observed nodes that are hub rows, hub_obs[0] = how many,
+    // hub_obs[1 ...] = their positions j in `observe` (any order) -- stage B launches its hub blocks for those alone.
+    if ((int)blockIdx.x == nb) {
+        __shared__ int32_t s_n;
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        for (int j = threadIdx.x; j < n_obs; j += blockDim.x) {
+            const int u = observe[j];
+            if (rowptr[u + 1] - rowptr[u] > LT_ROW_SEG) hub_obs[1 + atomicAdd(&s_n, 1)] = j;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) hub_obs[0] = s_n;
+        return;
+    }
     // One block per probe.  It also forms the probe's item offset off[b] = sum of |R_v| over the probes before it
     // (every block sums its own prefix: nb^2 / 2 four-byte loads in all, no scan kernel in front), the last block
     // writes the total off[nb].  bits == NULL: no bitmap (huge graphs); item_pr == NULL: no (probe, row) table.
