@@ -399,7 +399,10 @@ typedef float f32x2_ __attribute__((ext_vector_type(2)));
 #define FD_PU 6          // W1 rows in flight per lane while a list is walked (FD_CAP is a multiple; 8 costs the fifth wave per SIMD)
 #define FD_REF_PAD (16 * 64 * FD_WAVES + 64)   // the staging loop of k_s1d_feature_rows reads the reference vector in whole passes
 #define FD_UN 26         // loads in flight per lane in the row pass (x 128 floats: F <= 3328 is one trip)
-template <int VEC>   // floats per lane and load: 2 when the rows of X are 8-byte aligned, else 1
+// VEC: floats per lane and load, 2 when the rows of X are 8-byte aligned, else 1.  ONE: the reference vector is staged in one
+// pass (F <= 16 * 64 * FD_WAVES = 4096) -- no loop then, which hipcc needs to keep the row's loads in flight across the
+// staging (a path through a loop in front of the compare steps makes it wait for everything there).
+template <int VEC, bool ONE>
 __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     int n, int F, int H, int Hp, const float *__restrict__ X, long ldx, const float *__restrict__ ref,
     const float *__restrict__ W1, const double *__restrict__ cref, double *__restrict__ S1d, int hint_cap,
@@ -478,15 +481,31 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
             }
         }
     };
-    load_trip(0);
-    for (int j0 = 0; j0 < Fp; j0 += 16 * 64 * FD_WAVES) {       // (16 loads in flight per thread, no branch between them)
-        float r[16];
+    {
+        float r[16];                                            // (16 loads in flight per thread, no branch between them)
 #pragma unroll
-        for (int u = 0; u < 16; ++u) r[u] = ref[j0 + u * 64 * FD_WAVES + tid];   // (ref is allocated FD_REF_PAD floats past F: constant offsets from one address)
+        for (int u = 0; u < 16; ++u) r[u] = ref[u * 64 * FD_WAVES + tid];   // (ref is allocated FD_REF_PAD floats past F: constant offsets from one address)
+        // The row's loads go out BEHIND the reference vector's (loads return in order): the staging below then waits for
+        // its own 16 alone, the barrier for nothing, and the compare steps start while the row is still arriving.  Issued
+        // in front of them, every wave sat at s_waitcnt vmcnt(0) until its whole row had landed.
+        asm volatile("" ::: "memory");      // (keeps hipcc from hoisting the row's loads back in front)
+        load_trip(0);
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            const int j = j0 + u * 64 * FD_WAVES + tid;
+            const int j = u * 64 * FD_WAVES + tid;
             if (j < Fp) sref[j] = j < F ? r[u] : 0.f;
+        }
+    }
+    if constexpr (!ONE) {
+        for (int j0 = 16 * 64 * FD_WAVES; j0 < Fp; j0 += 16 * 64 * FD_WAVES) {
+            float r[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) r[u] = ref[j0 + u * 64 * FD_WAVES + tid];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int j = j0 + u * 64 * FD_WAVES + tid;
+                if (j < Fp) sref[j] = j < F ? r[u] : 0.f;
+            }
         }
     }
     __syncthreads();
@@ -950,12 +969,15 @@ static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, b
     float *s1x = (defer && b->S1x && lt_tune().s1_f32 != 0) ? b->S1x : nullptr;
     const unsigned blocks = (unsigned)((n + FD_WAVES - 1) / FD_WAVES + nslab);
     const size_t smem = fd_smem_bytes(F);
-    if (b->ldx % 2 == 0 && F % 2 == 0 && ((uintptr_t)b->X % 8) == 0)
-        hipLaunchKernelGGL((k_s1d_feature_rows<2>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx,
-                           b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs, zstate, s1x);
-    else
-        hipLaunchKernelGGL((k_s1d_feature_rows<1>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx,
-                           b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs, zstate, s1x);
+    const bool vec2 = b->ldx % 2 == 0 && F % 2 == 0 && ((uintptr_t)b->X % 8) == 0, one = F <= 16 * 64 * FD_WAVES;
+#define LT_FD_LAUNCH(V_, O_)                                                                                                  \
+    hipLaunchKernelGGL((k_s1d_feature_rows<V_, O_>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx, \
+                       b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs, zstate, s1x)
+    if (vec2 && one) LT_FD_LAUNCH(2, true);
+    else if (vec2) LT_FD_LAUNCH(2, false);
+    else if (one) LT_FD_LAUNCH(1, true);
+    else LT_FD_LAUNCH(1, false);
+#undef LT_FD_LAUNCH
     LT_CHECK_LAUNCH();
     if (defer) {
         hipLaunchKernelGGL(k_cref_sum, dim3(1), dim3(256), 0, st, nz, H, Hp, b->fd_slabs, b->fd_cref);
