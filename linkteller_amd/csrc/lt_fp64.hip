@@ -13,6 +13,7 @@
 #include <type_traits>
 
 #include "lt_rows.cuh"
+#include "lt_items.cuh"
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u_ __attribute__((ext_vector_type(4), aligned(4)));
@@ -282,7 +283,14 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
                                                   const int32_t *__restrict__ seg_long,
                                                   const int32_t *__restrict__ long_row,
                                                   double *__restrict__ seg_out, int32_t *__restrict__ state,
-                                                  const double *__restrict__ rs, const double *__restrict__ crefv) {
+                                                  const double *__restrict__ rs, const double *__restrict__ crefv,
+                                                  const lt_bits_job job = lt_bits_job{}, const int job_first = 0) {
+    // job.nblocks > 0: the blocks from job_first on build the item tables of a probe chunk (k_item_bits' blocks: nothing in
+    // this launch depends on them, and the launch in front of this one that they used to be cost the step 4 us)
+    if (job.nblocks > 0 && (int)blockIdx.x >= job_first) {
+        item_bits_block((int)blockIdx.x - job_first, job);
+        return;
+    }
     // crefv != NULL: S holds the feature rows' products WITHOUT the reference vector's (S1d - cref, lt_fp64 "deferred cref");
     // the row's share rs[r] * cref (rs = the row sum of A_hat) is added with the bias
     // state != NULL (on-demand, lt_fp64_prepare_rows): only the rows marked 2 are formed; a short row is marked 1 (valid) by its
@@ -407,7 +415,7 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     int n, int F, int H, int Hp, const float *__restrict__ X, long ldx, const float *__restrict__ ref,
     const float *__restrict__ W1, const double *__restrict__ cref, double *__restrict__ S1d, int hint_cap,
     int *__restrict__ dense_hint, int nslab, double *__restrict__ slabs, int32_t *__restrict__ zstate,
-    float *__restrict__ S1x) {
+    float *__restrict__ S1x, unsigned *__restrict__ gate, double *__restrict__ cref_out) {
     // zstate != NULL: every row's pre-activation is marked stale here (saves the refresh its memset launch).
     // The first nslab blocks of the launch (deferred cref, nslab > 0) form the K slices of cref = m W1 instead of rows:
     // block z sums slice [64 z, 64 z + 64) for every hidden column (thread (kq, cq): 16 k's x 4 columns, one trip; the four
@@ -440,7 +448,45 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
 #pragma unroll
         for (int t = 0; t < 4; ++t) s_p[kq][(cc + t) & 255] = a[t];
         __syncthreads();
-        for (int c = threadIdx.x; c < H; c += 256) slabs[(size_t)blockIdx.x * H + c] = ((s_p[0][c] + s_p[1][c]) + s_p[2][c]) + s_p[3][c];
+        if (!gate) {
+            for (int c = threadIdx.x; c < H; c += 256) slabs[(size_t)blockIdx.x * H + c] = ((s_p[0][c] + s_p[1][c]) + s_p[2][c]) + s_p[3][c];
+            return;
+        }
+        // gate != NULL: the slab block that finishes last adds the slices (the association of k_cref_sum, whoever comes
+        // last), so cref is there when this launch ends, without a launch of its own.  The slices travel between the blocks
+        // as device-scope atomic stores / loads (they bypass the XCD's L2): a __threadfence() here would write back the whole
+        // L2 while the rows stream through it (measured: +8 us).
+        for (int c = threadIdx.x; c < H; c += 256)
+            __hip_atomic_store(slabs + (size_t)blockIdx.x * H + c, ((s_p[0][c] + s_p[1][c]) + s_p[2][c]) + s_p[3][c], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        __shared__ unsigned s_last;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's stores have left
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(gate, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nslab - 1u ? 1u : 0u;
+        __syncthreads();
+        if (!s_last) return;
+        const int zq = threadIdx.x >> 6;
+        for (int cb = 0; cb < Hp; cb += 64) {
+            const int c = cb + (threadIdx.x & 63);
+            double acc = 0.0;
+            if (c < H)
+                for (int z0 = 0; z0 < nslab; z0 += 32) {
+                    double t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int z = z0 + zq + 4 * u;
+                        t[u] = z < nslab ? __hip_atomic_load(slabs + (size_t)z * H + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += t[u];
+                }
+            __syncthreads();
+            s_p[zq][threadIdx.x & 63] = acc;
+            __syncthreads();
+            if (zq == 0 && c < Hp)
+                cref_out[c] = c < H ? ((s_p[0][threadIdx.x] + s_p[1][threadIdx.x]) + s_p[2][threadIdx.x]) + s_p[3][threadIdx.x] : 0.0;
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(gate, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         return;
     }
     float *sref = reinterpret_cast<float *>(fd_smem);                              // [Fp] the reference vector
@@ -965,6 +1011,7 @@ static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, b
         LT_CHECK_LAUNCH();
     }
     const int nslab = defer ? nz : 0;
+    const bool fused_sum = defer && getenv("LT_X_NOFUSE") == nullptr;
     const double *cref = defer ? (const double *)nullptr : b->fd_cref;
     float *s1x = (defer && b->S1x && lt_tune().s1_f32 != 0) ? b->S1x : nullptr;
     const unsigned blocks = (unsigned)((n + FD_WAVES - 1) / FD_WAVES + nslab);
@@ -972,14 +1019,15 @@ static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, b
     const bool vec2 = b->ldx % 2 == 0 && F % 2 == 0 && ((uintptr_t)b->X % 8) == 0, one = F <= 16 * 64 * FD_WAVES;
 #define LT_FD_LAUNCH(V_, O_)                                                                                                  \
     hipLaunchKernelGGL((k_s1d_feature_rows<V_, O_>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx, \
-                       b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs, zstate, s1x)
+                       b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs, zstate, s1x,           \
+                       fused_sum ? (unsigned *)b->fd_gate : (unsigned *)nullptr, b->fd_cref)
     if (vec2 && one) LT_FD_LAUNCH(2, true);
     else if (vec2) LT_FD_LAUNCH(2, false);
     else if (one) LT_FD_LAUNCH(1, true);
     else LT_FD_LAUNCH(1, false);
 #undef LT_FD_LAUNCH
     LT_CHECK_LAUNCH();
-    if (defer) {
+    if (defer && !fused_sum) {
         hipLaunchKernelGGL(k_cref_sum, dim3(1), dim3(256), 0, st, nz, H, Hp, b->fd_slabs, b->fd_cref);
         LT_CHECK_LAUNCH();
     }
@@ -1023,7 +1071,7 @@ static int compute_s1d(lt_baseline *b, hipStream_t st) {
 }
 
 // Z1d = A_hat S1d + b1: every row (state == NULL) or the rows marked 2 in `state`
-static int form_z1d(lt_baseline *b, int32_t *state, hipStream_t st) {
+static int form_z1d(lt_baseline *b, int32_t *state, hipStream_t st, const lt_bits_job *job = nullptr, bool *job_done = nullptr) {
     const int Hp = b->Hp, n = b->n;
     const int lpr = lt_lpr_for(Hp);
     const unsigned g2 = (unsigned)((n + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr)));
@@ -1044,14 +1092,17 @@ static int form_z1d(lt_baseline *b, int32_t *state, hipStream_t st) {
     }
     const unsigned gs = have_long ? (unsigned)((g->p_n_seg + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr))) : 0u;
     const double *crefv = b->cref_deferred ? b->fd_cref : nullptr;      // (deferred cref: S1d holds S1d - cref)
+    const lt_bits_job jb = (job && !state) ? *job : lt_bits_job{};
+    const unsigned gj = jb.nblocks > 0 ? (unsigned)jb.nblocks : 0u;
+    if (job_done) *job_done = gj > 0;
     if (b->s1_f32) {
-        LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, float>), dim3(g2 + gs), dim3(256), 0, st, n, g->rowptr,
+        LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, float>), dim3(g2 + gs + gj), dim3(256), 0, st, n, g->rowptr,
                                                 g->col, g->val, b->S1x, Hp, b->b1p, b->Z1d, (int)gs, g->p_n_seg, g->p_seg_begin,
-                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv));
+                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv, jb, (int)(g2 + gs)));
     } else {
-        LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, double>), dim3(g2 + gs), dim3(256), 0, st, n, g->rowptr,
+        LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, double>), dim3(g2 + gs + gj), dim3(256), 0, st, n, g->rowptr,
                                                 g->col, g->val, b->S1d, Hp, b->b1p, b->Z1d, (int)gs, g->p_n_seg, g->p_seg_begin,
-                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv));
+                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv, jb, (int)(g2 + gs)));
     }
     LT_CHECK_LAUNCH();
     if (have_long) {
@@ -1072,8 +1123,10 @@ static int form_z1d(lt_baseline *b, int32_t *state, hipStream_t st) {
 // whose items cannot cover much of the graph (n_probe_call * average column length well below n: one rank of many) forms
 // only those rows (k_z_mark + the row kernel restricted to them; rows stay valid for later chunks and calls); otherwise all
 // rows once.  Same chains either way: the bits do not depend on which rows were asked for.
-int lt_fp64_prepare_rows(const lt_baseline *cb, const int32_t *off, int nb, const int2 *item_pr, int n_probe_call, hipStream_t st) {
+int lt_fp64_prepare_rows(const lt_baseline *cb, const int32_t *off, int nb, const int2 *item_pr, int n_probe_call, hipStream_t st,
+                         const lt_bits_job *job, bool *job_done) {
     lt_baseline *b = const_cast<lt_baseline *>(cb);   // cache state only
+    if (job_done) *job_done = false;
     if (b->z_all_valid || b->n == 0) return LT_OK;
     const lt_graph *g = b->g;
     lt_prof_scope prof_(LT_K_FP64_SPMM, st);
@@ -1082,11 +1135,12 @@ int lt_fp64_prepare_rows(const lt_baseline *cb, const int32_t *off, int nb, cons
     const bool tiled = !b->cref_deferred && lt_tiled_wanted(g, b->Hp) && (g->p_n_long == 0 || b->seg_d);
     const bool ondemand = !tiled && (knob > 0 || (knob < 0 && (double)n_probe_call * avg * 2.0 < (double)g->n));
     if (!ondemand) {
-        const int rc = form_z1d(b, nullptr, st);
+        const int rc = form_z1d(b, nullptr, st, job, job_done);
         if (rc) return rc;
         b->z_all_valid = true;
         return LT_OK;
     }
+    if (job) return LT_OK;        // on demand: the marks below read the job's tables -- the caller makes them and calls again
     LT_HIP(hipMemsetAsync(b->zcount, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(k_z_mark, dim3(256), dim3(256), 0, st, off, nb, item_pr, b->zstate, b->zrows, b->zcount);
     LT_CHECK_LAUNCH();

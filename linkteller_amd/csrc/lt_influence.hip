@@ -1671,11 +1671,23 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
             // item offsets, the (probe, row) table of the items and the membership bitmap, one block per probe
             if (w.big_slot) LT_HIP(hipMemsetAsync(w.big_slot + w.chunk, 0, sizeof(int32_t), st));
             const unsigned *marks = nullptr;
+            // DELTA on an S1d route whose pre-activation is still to be formed, all rows at once: the item tables ride in that
+            // launch (lt_fp64_prepare_rows); otherwise -- and always in SPARSE -- a launch of their own
+            bool bits_done = false;
+            const lt_bits_job job = {g->tptr, g->trow, probes, nb, words, w.bits, w.off, w.item_pr, w.big_bits, w.big_slot,
+                                     w.big_slot ? w.big_slot + w.chunk : (int32_t *)nullptr, g->rowptr, observe_nodes, n_obs, w.hub_obs,
+                                     nb + (long_blocks > 0 ? 1 : 0)};
+            if (mode == LT_MODE_DELTA && b->Z1d && !lt_fp64_agg_active(b) && !use_marks) {
+                const int rc = lt_fp64_prepare_rows(b, w.off, nb, w.item_pr, n_probe, st, &job, &bits_done);
+                if (rc) return rc;
+            }
             { lt_prof_scope prof_(LT_K_ITEM_BITS, st);
-            hipLaunchKernelGGL(k_item_bits, dim3(nb + (long_blocks > 0 ? 1 : 0)), dim3(256), 0, st, g->tptr, g->trow, probes, nb, words,
-                               w.bits, w.off, w.item_pr, w.big_bits, w.big_slot, w.big_slot ? w.big_slot + w.chunk : (int32_t *)nullptr,
-                               g->rowptr, observe_nodes, n_obs, w.hub_obs);
-            LT_CHECK_LAUNCH();
+            if (!bits_done) {
+                hipLaunchKernelGGL(k_item_bits, dim3((unsigned)job.nblocks), dim3(256), 0, st, g->tptr, g->trow, probes, nb, words,
+                                   w.bits, w.off, w.item_pr, w.big_bits, w.big_slot, job.big_count,
+                                   g->rowptr, observe_nodes, n_obs, w.hub_obs);
+                LT_CHECK_LAUNCH();
+            }
             if (use_marks) {
                 LT_HIP(hipMemsetAsync(w.pm_marks, 0, (size_t)((pairs + 31) / 32) * sizeof(unsigned), st));
                 hipLaunchKernelGGL(k_pm_mark, dim3(LT_ITEM_GRID), dim3(256), 0, st, w.off, nb, w.item_pr, w.pm_cnt, w.pm_start,

@@ -216,7 +216,25 @@ int lt_launch_gemm_f64_dense(const double *A, long lda, int M, const float *B, l
 int lt_launch_gemm_f64_gather(const float *A, long lda, const int32_t *rows, int M, const float *B, long ldb, int N, int K,
                               double *C, long ldc, hipStream_t st);
 int lt_launch_spmm_f64(const lt_graph *g, const double *S, int ld, const float *biasp, double *out, double *seg_d, hipStream_t st);
-int lt_fp64_prepare_rows(const lt_baseline *b, const int32_t *off, int nb, const int2 *item_pr, int n_probe_call, hipStream_t st);
+// The arguments of k_item_bits (lt_items.cuh) as a value: lt_fp64_prepare_rows can let the item tables of a probe chunk ride
+// in the launch that forms the pre-activation (extra blocks of k_spmm_f64) instead of a launch of their own in front of it.
+struct lt_bits_job {
+    const int32_t *tptr, *trow, *probes;
+    int nb, words;
+    uint2 *bits;
+    int32_t *off;
+    int2 *item_pr;
+    uint2 *big_bits;
+    int32_t *big_slot, *big_count;
+    const int32_t *rowptr, *observe;
+    int n_obs;
+    int32_t *hub_obs;
+    int nblocks;      // nb, + 1 when hub_obs is wanted; 0 = no job
+};
+// job != NULL: *job_done says whether the job went along (it does when every row is formed by one plain launch; the on-demand
+// form needs the tables BEFORE, the caller then launches k_item_bits itself and calls again without a job)
+int lt_fp64_prepare_rows(const lt_baseline *b, const int32_t *off, int nb, const int2 *item_pr, int n_probe_call, hipStream_t st,
+                         const lt_bits_job *job = nullptr, bool *job_done = nullptr);
 int lt_fp64_prepare_items(const lt_baseline *b, const int32_t *off, int nb, const int2 *item_pr, const int32_t *probes,
                           double *Spd, hipStream_t st);
 int lt_launch_rows_tiled_f64(const lt_graph *g, const double *S, int64_t lds, int ncols, const float *bias_after,

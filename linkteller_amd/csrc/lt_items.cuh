@@ -35,17 +35,16 @@ __device__ __forceinline__ int find_row(const int32_t *__restrict__ rows, int cn
 // big_slot[b] (or -1).  Searching such a list once per entry of an observed hub row is what made those pairs slow.
 #define LT_BIG_RV 512
 #define LT_BIG_SLOTS 64
-static __global__ __launch_bounds__(256) void k_item_bits(const int32_t *__restrict__ tptr, const int32_t *__restrict__ trow,
-                                                   const int32_t *__restrict__ probes, int nb, int words,
-                                                   uint2 *__restrict__ bits, int32_t *__restrict__ off,
-                                                   int2 *__restrict__ item_pr, uint2 *__restrict__ big_bits,
-                                                   int32_t *__restrict__ big_slot, int32_t *__restrict__ big_count,
-                                                   const int32_t *__restrict__ rowptr = nullptr,
-                                                   const int32_t *__restrict__ observe = nullptr, int n_obs = 0,
-                                                   int32_t *__restrict__ hub_obs = nullptr) {
+static __device__ __forceinline__ void item_bits_block(const int bid, const int32_t *__restrict__ tptr, const int32_t *__restrict__ trow,
+                                                       const int32_t *__restrict__ probes, int nb, int words,
+                                                       uint2 *__restrict__ bits, int32_t *__restrict__ off,
+                                                       int2 *__restrict__ item_pr, uint2 *__restrict__ big_bits,
+                                                       int32_t *__restrict__ big_slot, int32_t *__restrict__ big_count,
+                                                       const int32_t *__restrict__ rowptr, const int32_t *__restrict__ observe, int n_obs,
+                                                       int32_t *__restrict__ hub_obs) {
     // One block more than probes (hub_obs != NULL): it lists the observed nodes that are hub rows, hub_obs[0] = how many,
     // hub_obs[1 ...] = their positions j in `observe` (any order) -- stage B launches its hub blocks for those alone.
-    if ((int)blockIdx.x == nb) {
+    if (bid == nb) {
         __shared__ int32_t s_n;
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
@@ -62,7 +61,7 @@ static __global__ __launch_bounds__(256) void k_item_bits(const int32_t *__restr
     // writes the total off[nb].  bits == NULL: no bitmap (huge graphs); item_pr == NULL: no (probe, row) table.
     __shared__ int32_t red[4];
     __shared__ int32_t s_slot;
-    const int b = blockIdx.x;
+    const int b = bid;
     const int v = probes[b];
     const int t0 = tptr[v], t1 = tptr[v + 1];
     int part = 0;
@@ -102,6 +101,22 @@ static __global__ __launch_bounds__(256) void k_item_bits(const int32_t *__restr
         // item (off[b] + position in R_v) = (probe index, row): stage A reads it instead of searching `off`
         if (items) items[t - t0] = make_int2(b, r);
     }
+}
+static __global__ __launch_bounds__(256) void k_item_bits(const int32_t *__restrict__ tptr, const int32_t *__restrict__ trow,
+                                                   const int32_t *__restrict__ probes, int nb, int words,
+                                                   uint2 *__restrict__ bits, int32_t *__restrict__ off,
+                                                   int2 *__restrict__ item_pr, uint2 *__restrict__ big_bits,
+                                                   int32_t *__restrict__ big_slot, int32_t *__restrict__ big_count,
+                                                   const int32_t *__restrict__ rowptr = nullptr,
+                                                   const int32_t *__restrict__ observe = nullptr, int n_obs = 0,
+                                                   int32_t *__restrict__ hub_obs = nullptr) {
+    item_bits_block((int)blockIdx.x, tptr, trow, probes, nb, words, bits, off, item_pr, big_bits, big_slot, big_count, rowptr, observe,
+                    n_obs, hub_obs);
+}
+// the same block as part of another launch (256 threads per block)
+static __device__ __forceinline__ void item_bits_block(const int bid, const lt_bits_job &j) {
+    item_bits_block(bid, j.tptr, j.trow, j.probes, j.nb, j.words, j.bits, j.off, j.item_pr, j.big_bits, j.big_slot, j.big_count, j.rowptr,
+                    j.observe, j.n_obs, j.hub_obs);
 }
 // position of column c in R_v from the probe's bitmap row, or -1
 __device__ __forceinline__ int bits_pos(const uint2 *__restrict__ mb, int c) {

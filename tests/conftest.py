@@ -78,7 +78,8 @@ def noise_gate(key, measured, ceiling=RATIO_CEILING):
         return
     table = _ratio_table()
     assert key in table, f"{key}: no recorded value in {RATIO_FILE} (run the GPU suite once with LT_RECORD_RATIOS=1)"
-    assert measured <= table[key] * 1.10 + 1e-9, f"{key}: measured {measured:.4f}, recorded {table[key]:.4f} (+10 % allowed)"
+    # (+ 1e-5: the table is rounded to 6 decimals, and two cases compare two of OUR outputs, ratios of a few 1e-6)
+    assert measured <= table[key] * 1.10 + 1e-5, f"{key}: measured {measured:.6f}, recorded {table[key]:.6f} (+10 % allowed)"
 
 
 def pytest_sessionfinish(session, exitstatus):
