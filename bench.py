@@ -466,6 +466,12 @@ def main():
             per_kernel[k] = {"launches_per_step": round(cnt / a.steps, 2), "us_per_step": round(tot / a.steps * 1e3, 2),
                              "share_of_step": round(tot / a.steps / (elapsed_i / a.steps * 1e3), 3)}
     _lib.lib().lt_profile_enable(0)
+    # what an empty event pair reads on this stream (median of 50): the overhead every HIP-event duration above carries
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
+    for e0, e1 in evs:
+        e0.record(); e1.record()
+    torch.cuda.synchronize()
+    event_pair_us = round(float(np.median([e0.elapsed_time(e1) for e0, e1 in evs])) * 1e3, 2)
     if dom_cnt:      # duration of the dominant class as measured INSIDE the timed region (per step = per launch group)
         per_kernel[dom_name]["us_per_step_instrumented_pass"] = per_kernel[dom_name]["us_per_step"]
         per_kernel[dom_name]["us_per_step"] = round(dom_tot / (a.steps * max(1, a.blocks)) * 1e3, 2)
@@ -708,7 +714,10 @@ def main():
                        "collective_bytes_per_step": coll,
                        "step": "baseline forward of the mode + all probes + norms" + (" + all-gather" if world > 1 else "")},
             "timing": {"blocks": len(block_s), "steps_per_block": a.steps, "reported": "median block",
-                       "block_ms": [round(b * 1e3, 3) for b in block_s]},
+                       "block_ms": [round(b * 1e3, 3) for b in block_s],
+                       "event_pair_overhead_us": event_pair_us,
+                       "event_pair_note": "an EMPTY hipEventRecord pair on the kernels' stream reads this much: the per-class avg_launch_us "
+                                          "figures (HIP events) sit that far above the rocprofv3 kernel durations in profiles/"},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "kernels": per_kernel,
             "kernels_note": f"dominant class ({dom_name}) timed by HIP events inside the timed region; the other rows from an "
                             f"instrumented repeat of the same {a.steps} steps ({round(elapsed_i / a.steps * 1e3, 4)} ms/step)",

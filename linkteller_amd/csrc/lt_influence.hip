@@ -1681,7 +1681,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                 const int rc = lt_fp64_prepare_rows(b, w.off, nb, w.item_pr, n_probe, st, &job, &bits_done);
                 if (rc) return rc;
             }
-            { lt_prof_scope prof_(LT_K_ITEM_BITS, st);
+            { lt_prof_scope prof_(LT_K_ITEM_BITS, st, !bits_done || use_marks);   // (nothing to time when the tables rode along)
             if (!bits_done) {
                 hipLaunchKernelGGL(k_item_bits, dim3((unsigned)job.nblocks), dim3(256), 0, st, g->tptr, g->trow, probes, nb, words,
                                    w.bits, w.off, w.item_pr, w.big_bits, w.big_slot, job.big_count,

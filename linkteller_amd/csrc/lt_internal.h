@@ -178,7 +178,7 @@ void lt_profile_begin(int kernel_id, hipStream_t st);
 void lt_profile_end(int kernel_id, hipStream_t st);
 struct lt_prof_scope {
     int id; hipStream_t st; bool on;
-    lt_prof_scope(int id_, hipStream_t st_) : id(id_), st(st_), on((g_lt_profile_mask >> id_) & 1u) { if (on) lt_profile_begin(id, st); }
+    lt_prof_scope(int id_, hipStream_t st_, bool wanted = true) : id(id_), st(st_), on(wanted && ((g_lt_profile_mask >> id_) & 1u)) { if (on) lt_profile_begin(id, st); }
     ~lt_prof_scope() { if (on) lt_profile_end(id, st); }
 };
 
