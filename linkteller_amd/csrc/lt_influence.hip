@@ -828,7 +828,9 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
 #define LT_SBL_UN_DELTA 32
 #define LT_SBL_NS 8        // light probes: searches in flight per lane
 #define LT_SBL_MC 128      // SPARSE: members of a light probe kept in LDS at a time (> 64 + a search round: see fill)
-template <int CP, bool DELTA, bool SHORT>   // SHORT: the short-side search (without it every probe tests every entry, no member lists in LDS)
+// WIDE (DELTA, calls with a handful of observed hubs): 32 membership tests in flight per lane instead of 8 -- 211 VGPRs, two
+// blocks per CU: right for the 100 hub blocks of a twitch-size call, wrong for the 5000 of BASELINE configs[4] (0.76 -> 1.28 ms)
+template <int CP, bool DELTA, bool SHORT, bool WIDE = false>   // SHORT: the short-side search (without it every probe tests every entry, no member lists in LDS)
 __device__ __forceinline__ void stageB_long_block(
     int bid, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const int32_t *__restrict__ tptr,
@@ -842,7 +844,7 @@ __device__ __forceinline__ void stageB_long_block(
     constexpr int GROUPS = LT_BLOCK / LT_L2_LANES;
     // entries of the walk whose membership tests are in flight per lane: DELTA keeps nothing else per entry (no baseline
     // row), and an observed hub of 1 700 entries is 27 dependent rounds at 8
-    constexpr int UN = DELTA ? LT_SBL_UN_DELTA : LT_SBL_UN;
+    constexpr int UN = (DELTA && WIDE) ? LT_SBL_UN_DELTA : LT_SBL_UN;
     __shared__ int sc[CHUNK];
     __shared__ float sv[CHUNK];
     __shared__ float sT[DELTA ? 1 : CHUNK][CP];
@@ -876,7 +878,7 @@ __device__ __forceinline__ void stageB_long_block(
     // log |R_v| loads without; the search from the R_v side costs |R_v| / (8 NS) rounds of log d loads
     const int lg_d = 32 - __clz(d), lg_c = 32 - __clz(cnt > 1 ? cnt : 1);
     // with a bitmap row, in dependent rounds: the walk is d / (8 lanes * UN) of them, the search (lg d + 2) per 64 members
-    const bool heavy = live && (!SHORT || (mb ? (DELTA ? (long)((cnt + 63) / 64) * (lg_d + 2) > (d + LT_L2_LANES * UN - 1) / (LT_L2_LANES * UN)
+    const bool heavy = live && (!SHORT || (mb ? ((DELTA && WIDE) ? (long)((cnt + 63) / 64) * (lg_d + 2) > (d + LT_L2_LANES * UN - 1) / (LT_L2_LANES * UN)
                                                        : (long)cnt * lg_d > d)
                                               : 2L * cnt * lg_d > (long)d * lg_c));
     const bool light = live && !heavy;
@@ -1073,7 +1075,7 @@ __device__ __forceinline__ void stageB_long_block(
 // The observed hubs of SPARSE in a launch of their own: stageB_long_block's member lists take 48 KB of LDS per block, which
 // as part of k_item_stageB capped every block of that launch -- the pairs too -- at three per CU (28 -> 55 us at twitch
 // size, hubs or not).  DELTA's hub blocks need 8 KB and stay in front of the pair launch.
-template <int CP, bool DELTA, bool SHORT>
+template <int CP, bool DELTA, bool SHORT, bool WIDE = false>
 __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_hubs(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const int32_t *__restrict__ tptr,
@@ -1083,7 +1085,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_hubs(
     const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
     float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words,
     const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot, const int32_t *__restrict__ hub_obs) {
-    stageB_long_block<CP, DELTA, SHORT>((int)blockIdx.x, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off, S2x,
+    stageB_long_block<CP, DELTA, SHORT, WIDE>((int)blockIdx.x, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off, S2x,
                                         observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot, hub_obs);
 }
 
@@ -1102,16 +1104,14 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
     // long_blocks > 0 (the graph has hub rows): the first long_blocks blocks serve the observed hubs
     // (stageB_long_block: most of them find a plain row and exit); skip_long: the pairs below leave those rows alone
     // (SPARSE with the short-side search: k_item_stageB_hubs has them, long_blocks = 0 here)
-    if ((int)blockIdx.x < long_blocks) {
-        if (hub_short) {
-            if constexpr (DELTA)
-                stageB_long_block<CP, DELTA, true>((int)blockIdx.x, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off,
-                                                   S2x, observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot, hub_obs);
-        } else {
+    // (DELTA: always k_item_stageB_hubs -- its hub block keeps 32 membership tests in flight per lane, 211 VGPRs, which as
+    // part of this kernel cost the pairs of a large call their occupancy: 0.88 -> 1.25 ms at BASELINE configs[4])
+    if constexpr (!DELTA) {
+        if ((int)blockIdx.x < long_blocks) {
             stageB_long_block<CP, DELTA, false>((int)blockIdx.x, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off,
                                                 S2x, observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot, hub_obs);
+            return;
         }
-        return;
     }
     const long gid = ((long)(blockIdx.x - long_blocks) * LT_BLOCK + threadIdx.x) / LT_L2_LANES;
     const int q = threadIdx.x & (LT_L2_LANES - 1);
@@ -1768,25 +1768,39 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                 } }
                 LT_CHECK_LAUNCH();
                 lt_prof_scope prof_(LT_K_ITEM_B, st);
-                if (rows_route) {
-                    if (long_blocks > 0) {
-                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, true>), dim3((unsigned)long_blocks), dim3(LT_BLOCK), 0,
-                                                               st, g->rowptr, g->col, g->val, g->tptr, g->trow, b->S2, C, b->b2,
-                                                               b->OUT, probes, nb, w.off, w.S2x, observe_nodes, n_obs, delta, orow,
-                                                               (long)ldo, w.bits, words, (int)long_blocks, 1, marks, w.big_bits,
-                                                               w.big_slot, hub_short ? 1 : 0, w.hub_obs));
-                        LT_CHECK_LAUNCH();
+                if (long_blocks > 0) {   // the observed hubs, a launch of their own
+                    if (rows_route && !hub_short) {      // twitch size: few hub blocks, every probe walks the row
+                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_hubs<CP_, true, false, true>), dim3((unsigned)long_blocks),
+                                                               dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, g->tptr, g->trow,
+                                                               b->S2, C, b->b2, b->OUT, probes, nb, w.off, w.S2x, observe_nodes,
+                                                               n_obs, delta, orow, (long)ldo, w.bits, words, w.big_bits,
+                                                               w.big_slot, w.hub_obs));
+                    } else if (hub_short) {
+                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_hubs<CP_, true, true>), dim3((unsigned)long_blocks),
+                                                               dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, g->tptr, g->trow,
+                                                               b->S2, C, b->b2, b->OUT, probes, nb, w.off, w.S2x, observe_nodes,
+                                                               n_obs, delta, orow, (long)ldo, w.bits, words, w.big_bits,
+                                                               w.big_slot, w.hub_obs));
+                    } else {
+                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_hubs<CP_, true, false>), dim3((unsigned)long_blocks),
+                                                               dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, g->tptr, g->trow,
+                                                               b->S2, C, b->b2, b->OUT, probes, nb, w.off, w.S2x, observe_nodes,
+                                                               n_obs, delta, orow, (long)ldo, w.bits, words, w.big_bits,
+                                                               w.big_slot, w.hub_obs));
                     }
+                    LT_CHECK_LAUNCH();
+                }
+                if (rows_route) {
                     LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_rows<CP_, true>), dim3((unsigned)((long)n_obs * psplit)),
                                                            dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, b->S2, C, b->b2,
                                                            b->OUT, nb, w.off, w.S2x, observe_nodes, n_obs, delta, orow, (long)ldo,
                                                            w.bits, words, psplit));
                 } else
-                LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, true>), dim3(gridB + (unsigned)long_blocks),
+                LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, true>), dim3(gridB),
                                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
                                                        g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
                                                        nb, w.off, w.S2x, observe_nodes, n_obs, delta,
-                                                       orow, (long)ldo, w.bits, words, (int)long_blocks, long_blocks > 0 ? 1 : 0,
+                                                       orow, (long)ldo, w.bits, words, 0, long_blocks > 0 ? 1 : 0,
                                                        marks, w.big_bits, w.big_slot, hub_short ? 1 : 0, w.hub_obs));
             }
             LT_CHECK_LAUNCH();
