@@ -808,6 +808,94 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
     }
 }
 
+// DELTA stage A on the fp64 pre-activation, the form every `delta` call takes (k_item_stageA<.., 2> computes the same values):
+// an item needs (probe node v, row r, A_hat[r, v]) -- one 16-byte pair of loads from the tables k_item_bits left, instead of
+// the chain item_pr -> probes[b] -> tptr[v] -> tval[t] -- then the probe's product row and the row's pre-activation, both
+// addressed from the tables.  TWO items per lane group are in flight (all loads unconditional, indices clamped: hipcc drains
+// the queue in front of a guarded load); W2 and the deferred reference product of the lane's 4 hidden columns stay in
+// registers across the items.  Same operations in the same order as k_item_stageA: the bits are its bits.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+template <int LPR, int CP>
+__global__ __launch_bounds__(LT_BLOCK) void k_item_stageA_d2(
+    const double *__restrict__ Z1d, const double *__restrict__ S1d, const float *__restrict__ S1x,
+    const double *__restrict__ Spd, const double *__restrict__ crefv, int Hp, const float *__restrict__ W2p, int C,
+    int nb, const int32_t *__restrict__ off, float delta, float *__restrict__ S2x, const int2 *__restrict__ item_pr,
+    const int2 *__restrict__ item_va) {
+    constexpr int RPW = 64 / LPR, U = 2;
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & (LPR - 1);
+    const bool active = 4 * gl < Hp;
+    const int coff = active ? 4 * gl : 0;
+    const int total = off[nb];
+    const int wave0 = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
+    const int stride = gridDim.x * (LT_BLOCK / 64) * RPW;
+    float w2[4][CP];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < CP; ++c) w2[k][c] = c < C ? W2p[(size_t)(coff + k) * C + c] : 0.f;
+    double cr[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool add_cref = crefv != nullptr && Spd == nullptr;
+    if (add_cref) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cr[k] = crefv[coff + k];
+    }
+    for (int base = wave0 * RPW; base < total; base += U * stride) {
+        int item[U];
+        int2 pr[U], va[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            item[u] = base + u * stride + lane / LPR;
+            const int ic = min(item[u], total - 1);        // past the end: the last item again, never stored
+            pr[u] = item_pr[ic];
+            va[u] = item_va[ic];
+        }
+        f64x4 z[U], sd[U];
+        f32x4 sx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            z[u] = *reinterpret_cast<const f64x4 *>(Z1d + (size_t)pr[u].y * Hp + coff);
+            if (S1x) sx[u] = ld4(S1x + (size_t)va[u].x * Hp + coff);
+            else sd[u] = *reinterpret_cast<const f64x4 *>(Spd ? Spd + (size_t)pr[u].x * Hp + coff : S1d + (size_t)va[u].x * Hp + coff);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float arv = __int_as_float(va[u].y);
+            float part[CP];
+#pragma unroll
+            for (int c = 0; c < CP; ++c) part[c] = 0.f;
+            if (active) {
+                float dh[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    // the probe's S1 row off the fp64 product (fp32 storage and / or deferred reference product: lt_fp64.hip)
+                    const float sk = S1x ? (float)((double)sx[u][k] + cr[k]) : (add_cref ? (float)(sd[u][k] + cr[k]) : (float)sd[u][k]);
+                    // kink test on the fp64-accumulated pre-activation
+                    const float dz = arv * (delta * sk);
+                    const double zz = z[u][k], z1 = zz + (double)dz;
+                    dh[k] = zz > 0.0 ? (z1 > 0.0 ? dz : (float)(-zz)) : (z1 > 0.0 ? (float)z1 : 0.f);
+                }
+#pragma unroll
+                for (int c = 0; c < CP; ++c)
+                    if (c < C) {
+                        float p = dh[0] * w2[0][c];
+                        p = fmaf(dh[1], w2[1][c], p);
+                        p = fmaf(dh[2], w2[2][c], p);
+                        p = fmaf(dh[3], w2[3][c], p);
+                        part[c] = p;
+                    }
+            }
+#pragma unroll
+            for (int c = 0; c < CP; ++c) part[c] = group_sum<LPR>(part[c]);
+            if (item[u] < total && gl == 0) {
+#pragma unroll
+                for (int c = 0; c < CP; ++c)
+                    if (c < C) S2x[(size_t)item[u] * C + c] = part[c];
+            }
+        }
+    }
+}
+
 // SPARSE / DELTA stage B for an OBSERVED HUB (a row of more than LT_ROW_SEG entries).  A block (the first blocks of
 // k_item_stageB's launch) takes one observed hub and 32 probes, 8 chain lanes per probe.  A pair (hub u, probe v) is
 // affected through the members of row(u) /\ R_v, and which entries those are is found from the SHORT side:
@@ -1415,6 +1503,7 @@ struct infl_ws {
     double *Spd;           // DELTA, aggregate-first route: fp64 product rows of the chunk's probes [chunk, Hp]
     int32_t *off;          // SPARSE / DELTA: item offsets [chunk + 1]
     int2 *item_pr;         // SPARSE / DELTA: (probe index, row) of every item
+    int2 *item_va;         // DELTA: (probe node, A_hat[row, probe node] as bits) of every item
     int32_t *pm_cnt, *pm_start, *pm_rank, *pm_list;   // SPARSE / DELTA pair marks: per-node lists of observed nodes (lt_items.cuh)
     unsigned *pm_marks;    // SPARSE / DELTA: one bit per (probe of the chunk, observed node)
     uint2 *big_bits;       // SPARSE / DELTA without `bits`: bitmap rows of the chunk's big probes [LT_BIG_SLOTS][ceil(n / 32)]
@@ -1462,6 +1551,7 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int n_o
         w.S2x = (float *)take(chunk * maxc * C * sizeof(float));
         w.off = (int32_t *)take((chunk + 1) * sizeof(int32_t));
         w.item_pr = (int2 *)take(chunk * maxc * sizeof(int2));
+        if (mode == LT_MODE_DELTA) w.item_va = (int2 *)take(chunk * maxc * sizeof(int2));
         const size_t bw = (n + 31) / 32;
         // ("item_bits" = 0 forces the search path a huge graph takes: tests)
         const bool no_bits = lt_tune().item_bits == 0;
@@ -1676,7 +1766,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
             bool bits_done = false;
             const lt_bits_job job = {g->tptr, g->trow, probes, nb, words, w.bits, w.off, w.item_pr, w.big_bits, w.big_slot,
                                      w.big_slot ? w.big_slot + w.chunk : (int32_t *)nullptr, g->rowptr, observe_nodes, n_obs, w.hub_obs,
-                                     nb + (long_blocks > 0 ? 1 : 0)};
+                                     nb + (long_blocks > 0 ? 1 : 0), g->tval, w.item_va};
             if (mode == LT_MODE_DELTA && b->Z1d && !lt_fp64_agg_active(b) && !use_marks) {
                 const int rc = lt_fp64_prepare_rows(b, w.off, nb, w.item_pr, n_probe, st, &job, &bits_done);
                 if (rc) return rc;
@@ -1685,7 +1775,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
             if (!bits_done) {
                 hipLaunchKernelGGL(k_item_bits, dim3((unsigned)job.nblocks), dim3(256), 0, st, g->tptr, g->trow, probes, nb, words,
                                    w.bits, w.off, w.item_pr, w.big_bits, w.big_slot, job.big_count,
-                                   g->rowptr, observe_nodes, n_obs, w.hub_obs);
+                                   g->rowptr, observe_nodes, n_obs, w.hub_obs, g->tval, w.item_va);
                 LT_CHECK_LAUNCH();
             }
             if (use_marks) {
@@ -1750,13 +1840,10 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                 { lt_prof_scope prof_(LT_K_ITEM_A, st);
                 if (b->Z1d) {
                     LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
-                        hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, 2>), dim3(LT_ITEM_GRID), dim3(LT_BLOCK), 0,
-                                           st, g->rowptr, g->col, g->val, g->tptr, g->trow, g->tval, b->S1,
-                                           b->Z1, b->Z1d, b->S1d, Hp, b->b1p, b->W2p, C, probes, nb, w.off,
-                                           (const float *)nullptr, delta, w.S2x, 0, (const int32_t *)nullptr,
-                                           (const int32_t *)nullptr, (const float *)nullptr, w.item_pr, spd,
-                                           b->cref_deferred ? b->fd_cref : (const double *)nullptr,
-                                           (b->s1_f32 && !spd) ? b->S1x : (const float *)nullptr)));
+                        hipLaunchKernelGGL((k_item_stageA_d2<LPR_, CP_>), dim3(LT_ITEM_GRID), dim3(LT_BLOCK), 0, st, b->Z1d, b->S1d,
+                                           (b->s1_f32 && !spd) ? b->S1x : (const float *)nullptr, spd,
+                                           b->cref_deferred ? b->fd_cref : (const double *)nullptr, Hp, b->W2p, C, nb, w.off, delta,
+                                           w.S2x, w.item_pr, w.item_va)));
                 } else {
                     LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
                         hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, 1>), dim3(LT_ITEM_GRID), dim3(LT_BLOCK), 0,

@@ -230,6 +230,8 @@ struct lt_bits_job {
     int n_obs;
     int32_t *hub_obs;
     int nblocks;      // nb, + 1 when hub_obs is wanted; 0 = no job
+    const float *tval;      // with item_va: (probe node, A_hat[r, v]) of every item next to (probe index, row)
+    int2 *item_va;
 };
 // job != NULL: *job_done says whether the job went along (it does when every row is formed by one plain launch; the on-demand
 // form needs the tables BEFORE, the caller then launches k_item_bits itself and calls again without a job)

@@ -41,7 +41,8 @@ static __device__ __forceinline__ void item_bits_block(const int bid, const int3
                                                        int2 *__restrict__ item_pr, uint2 *__restrict__ big_bits,
                                                        int32_t *__restrict__ big_slot, int32_t *__restrict__ big_count,
                                                        const int32_t *__restrict__ rowptr, const int32_t *__restrict__ observe, int n_obs,
-                                                       int32_t *__restrict__ hub_obs) {
+                                                       int32_t *__restrict__ hub_obs, const float *__restrict__ tval = nullptr,
+                                                       int2 *__restrict__ item_va = nullptr) {
     // One block more than probes (hub_obs != NULL): it lists the observed nodes that are hub rows, hub_obs[0] = how many,
     // hub_obs[1 ...] = their positions j in `observe` (any order) -- stage B launches its hub blocks for those alone.
     if (bid == nb) {
@@ -100,6 +101,8 @@ static __device__ __forceinline__ void item_bits_block(const int bid, const int3
         }
         // item (off[b] + position in R_v) = (probe index, row): stage A reads it instead of searching `off`
         if (items) items[t - t0] = make_int2(b, r);
+        // ... and (probe node, A_hat[r, v]): DELTA stage A would otherwise chase probes[b] -> tptr[v] -> tval[t] per item
+        if (item_va) item_va[my_off + (t - t0)] = make_int2(v, __float_as_int(tval[t]));
     }
 }
 static __global__ __launch_bounds__(256) void k_item_bits(const int32_t *__restrict__ tptr, const int32_t *__restrict__ trow,
@@ -109,14 +112,15 @@ static __global__ __launch_bounds__(256) void k_item_bits(const int32_t *__restr
                                                    int32_t *__restrict__ big_slot, int32_t *__restrict__ big_count,
                                                    const int32_t *__restrict__ rowptr = nullptr,
                                                    const int32_t *__restrict__ observe = nullptr, int n_obs = 0,
-                                                   int32_t *__restrict__ hub_obs = nullptr) {
+                                                   int32_t *__restrict__ hub_obs = nullptr, const float *__restrict__ tval = nullptr,
+                                                   int2 *__restrict__ item_va = nullptr) {
     item_bits_block((int)blockIdx.x, tptr, trow, probes, nb, words, bits, off, item_pr, big_bits, big_slot, big_count, rowptr, observe,
-                    n_obs, hub_obs);
+                    n_obs, hub_obs, tval, item_va);
 }
 // the same block as part of another launch (256 threads per block)
 static __device__ __forceinline__ void item_bits_block(const int bid, const lt_bits_job &j) {
     item_bits_block(bid, j.tptr, j.trow, j.probes, j.nb, j.words, j.bits, j.off, j.item_pr, j.big_bits, j.big_slot, j.big_count, j.rowptr,
-                    j.observe, j.n_obs, j.hub_obs);
+                    j.observe, j.n_obs, j.hub_obs, j.tval, j.item_va);
 }
 // position of column c in R_v from the probe's bitmap row, or -1
 __device__ __forceinline__ int bits_pos(const uint2 *__restrict__ mb, int c) {

@@ -83,8 +83,9 @@ def main():
             for k in knobs:
                 _lib.set_tuning(k, None)
         # the other fp64 route of `delta` (aggregate-first <-> S1d; feature rows <-> matrix cores): fp64 summation order only
-        for k, v in (("aggregate_first", 0), ("feature_delta", int(rng.choice([0, 1]))), ("defer_cref", int(rng.choice([0, 1]))),
-                     ("s1_f32", int(rng.choice([0, 1])))):
+        route_knobs = (("aggregate_first", 0), ("feature_delta", int(rng.choice([0, 1]))), ("defer_cref", int(rng.choice([0, 1]))),
+                       ("s1_f32", int(rng.choice([0, 1]))))
+        for k, v in route_knobs:
             _lib.set_tuning(k, v)
         try:
             base.refresh()
@@ -93,7 +94,11 @@ def main():
             for k in ("aggregate_first", "feature_delta", "defer_cref", "s1_f32"):
                 _lib.set_tuning(k, None)
             base.refresh()
-        assert np.abs(other - ref64).max() <= 1e-5 * scale and np.abs(other - res["delta"]).max() <= 1e-6 * scale, it
+        # (5e-6 between two routes: the default feature route keeps its product rows rounded once to fp32 -- 6e-8 relative -- and a
+        # hidden unit whose pre-activation sits within dz of zero turns that into an absolute error of its contribution; the worst
+        # seen is 1.4e-6 of the largest score (seed 777, case 7), against 6e-8 for the fp64-stored routes; the gate is 1e-5)
+        assert np.abs(other - ref64).max() <= 1e-5 * scale and np.abs(other - res["delta"]).max() <= 5e-6 * scale, \
+            (it, kind, n, h, c, f, route_knobs, np.abs(other - ref64).max() / scale, np.abs(other - res["delta"]).max() / scale, base.fp64_route())
         logits_ref = O.gcn_forward(torch.from_numpy(x).double(), O.to_torch_sparse(a_hat).double(),
                                    {k: torch.from_numpy(w[k]).double() for k in ("W1", "b1", "W2", "b2")}).numpy()
         tag = f"case {it}: {kind} n={n} H={h} C={c} F={f} {norm} probes={len(probes)} obs={len(observe)} maxdeg={int(np.diff(a_hat.indptr).max())}"
