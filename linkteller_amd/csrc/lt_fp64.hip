@@ -269,9 +269,9 @@ __global__ void k_sum_slabs_f64(const double *__restrict__ slabs, long slab_stri
 // One lane group per row of up to LT_ROW_SEG entries; on a graph with hub rows the first seg_blocks blocks of the
 // launch take one SEGMENT of a long row per lane group instead, raw sum into seg_out[segment] (k_spmm_f64_long adds
 // them in segment order and the bias).  fp64: the cut only decides how a hub row's work is spread.
-// ST = double, or float: the feature route stores its fp64-ACCUMULATED product rounded once to fp32 (S1x: 6e-8 relative, two
-// orders below what the kink test needs, and half the bytes every gather moves -- the 4.5 MB then sit in the L2s); the chains
-// accumulate in fp64 either way.
+// ST = double, or float: the feature route stores its fp64-ACCUMULATED product rounded once to fp32 (S1x: 6e-8 relative, half the
+// bytes every gather moves -- the 4.5 MB then sit in the L2s; a unit within dz of its kink carries that rounding into the result
+// as an absolute error: <= 2e-6 of the largest score in tools/fuzz_gpu.py); the chains accumulate in fp64 either way.
 template <int LPR, typename ST>
 __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restrict__ rowptr,
                                                   const int32_t *__restrict__ col,
