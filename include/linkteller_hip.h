@@ -93,7 +93,8 @@ int lt_device_count(int *count);
  *                         by the rows kernel.  fp64 summation order only, like "feature_delta"
  *   "z_on_demand"         LT_MODE_DELTA on the S1d routes: 1 = the fp64 pre-activation is formed only on the rows a call's items
  *                         read (they stay valid until the next refresh), 0 = on all rows at the first call after a refresh,
- *                         negative = by the call's size (default: on demand when probes x average column length < n / 2)
+ *                         negative = by the call's size (default: on demand when probes x average column length < n / 2 and the
+ *                         whole fp64 SpMM is worth avoiding, nnz x hidden width >= 2.5e8: below that it is a 10 us launch)
  *   "stageb_rows"         SPARSE / DELTA stage B of calls with a membership bitmap and no pair marks: 1 = one block per (observed
  *                         node, slice of the probes), the observed row staged in LDS (default), 0 = one 8-lane group per pair
  *   "aggregate_first"     fp64 pre-activation of LT_MODE_DELTA as Z1d[r] = (A_hat X)[r] W1 + b1, computed only on the rows the

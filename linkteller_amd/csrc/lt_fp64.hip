@@ -1133,7 +1133,10 @@ int lt_fp64_prepare_rows(const lt_baseline *cb, const int32_t *off, int nb, cons
     const double avg = g->n > 0 ? (double)g->nnz / (double)g->n : 0.0;
     const int knob = lt_tune().z_on_demand;
     const bool tiled = !b->cref_deferred && lt_tiled_wanted(g, b->Hp) && (g->p_n_long == 0 || b->seg_d);
-    const bool ondemand = !tiled && (knob > 0 || (knob < 0 && (double)n_probe_call * avg * 2.0 < (double)g->n));
+    // (a graph whose whole fp64 SpMM is a 10 us launch is formed whole: marking the rows costs a memset, k_z_mark and the item
+    // tables' own launch in front of it -- 55 against 50 us for the step one rank of 8 runs at twitch size)
+    const bool ondemand = !tiled && (knob > 0 || (knob < 0 && (double)n_probe_call * avg * 2.0 < (double)g->n &&
+                                                  (double)g->nnz * (double)b->Hp >= 2.5e8));
     if (!ondemand) {
         const int rc = form_z1d(b, nullptr, st, job, job_done);
         if (rc) return rc;
