@@ -419,7 +419,7 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     // zstate != NULL: every row's pre-activation is marked stale here (saves the refresh its memset launch).
     // The first nslab blocks of the launch (deferred cref, nslab > 0) form the K slices of cref = m W1 instead of rows:
     // block z sums slice [64 z, 64 z + 64) for every hidden column (thread (kq, cq): 16 k's x 4 columns, one trip; the four
-    // k-quarters added in order through LDS) into slabs[z]; k_cref_sum adds the slices afterwards, and the rows below are
+    // k-quarters added in order through LDS) into slabs[z]; the last of these blocks adds the slices (below), and the rows are
     // written WITHOUT cref (cref == NULL), which the fp64 SpMM and stage A add where they read them.
     extern __shared__ __attribute__((aligned(16))) unsigned char fd_smem[];
     if ((int)blockIdx.x < nslab) {
@@ -452,8 +452,8 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
             for (int c = threadIdx.x; c < H; c += 256) slabs[(size_t)blockIdx.x * H + c] = ((s_p[0][c] + s_p[1][c]) + s_p[2][c]) + s_p[3][c];
             return;
         }
-        // gate != NULL: the slab block that finishes last adds the slices (the association of k_cref_sum, whoever comes
-        // last), so cref is there when this launch ends, without a launch of its own.  The slices travel between the blocks
+        // gate != NULL: the slab block that finishes last adds the slices (thread (zq, c): slices zq, zq + 4, ... in order, then the
+        // four partial sums in order -- a fixed association whoever comes last), so cref is there when this launch ends, without a launch of its own.  The slices travel between the blocks
         // as device-scope atomic stores / loads (they bypass the XCD's L2): a __threadfence() here would write back the whole
         // L2 while the rows stream through it (measured: +8 us).
         for (int c = threadIdx.x; c < H; c += 256)
@@ -737,31 +737,6 @@ __global__ __launch_bounds__(256) void k_ref_product(int F, int H, int Hp, const
     if (threadIdx.x == 0) *counter = 0;              // ready for the next launch
 }
 
-// cref[c] = sum of the nz slices of slabs in a fixed association (thread (zq, c): slices zq, zq + 4, ..., then the four
-// partial sums in order); one block -- everything it reads was written by the previous launch
-__global__ __launch_bounds__(256) void k_cref_sum(int nz, int H, int Hp, const double *__restrict__ slabs, double *__restrict__ cref) {
-    __shared__ double s_p[4][64];
-    const int zq = threadIdx.x >> 6;
-    for (int cb = 0; cb < Hp; cb += 64) {
-        const int c = cb + (threadIdx.x & 63);
-        double a = 0.0;
-        if (c < H)
-            for (int z0 = 0; z0 < nz; z0 += 64) {
-                double t[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int z = z0 + zq + 4 * u;
-                    t[u] = z < nz ? slabs[(size_t)z * H + c] : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) a += t[u];
-            }
-        __syncthreads();
-        s_p[zq][threadIdx.x & 63] = a;
-        __syncthreads();
-        if (zq == 0 && c < Hp) cref[c] = c < H ? ((s_p[0][threadIdx.x] + s_p[1][threadIdx.x]) + s_p[2][threadIdx.x]) + s_p[3][threadIdx.x] : 0.0;
-    }
-}
 // rs[r] = sum of row r of A_hat, fp64 (entry order)
 __global__ void k_row_sums(int n, const int32_t *__restrict__ rowptr, const float *__restrict__ val, double *__restrict__ rs) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1011,7 +986,6 @@ static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, b
         LT_CHECK_LAUNCH();
     }
     const int nslab = defer ? nz : 0;
-    const bool fused_sum = defer && getenv("LT_X_NOFUSE") == nullptr;
     const double *cref = defer ? (const double *)nullptr : b->fd_cref;
     float *s1x = (defer && b->S1x && lt_tune().s1_f32 != 0) ? b->S1x : nullptr;
     const unsigned blocks = (unsigned)((n + FD_WAVES - 1) / FD_WAVES + nslab);
@@ -1020,17 +994,13 @@ static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, b
 #define LT_FD_LAUNCH(V_, O_)                                                                                                  \
     hipLaunchKernelGGL((k_s1d_feature_rows<V_, O_>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx, \
                        b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs, zstate, s1x,           \
-                       fused_sum ? (unsigned *)b->fd_gate : (unsigned *)nullptr, b->fd_cref)
+                       defer ? (unsigned *)b->fd_gate : (unsigned *)nullptr, b->fd_cref)
     if (vec2 && one) LT_FD_LAUNCH(2, true);
     else if (vec2) LT_FD_LAUNCH(2, false);
     else if (one) LT_FD_LAUNCH(1, true);
     else LT_FD_LAUNCH(1, false);
 #undef LT_FD_LAUNCH
     LT_CHECK_LAUNCH();
-    if (defer && !fused_sum) {
-        hipLaunchKernelGGL(k_cref_sum, dim3(1), dim3(256), 0, st, nz, H, Hp, b->fd_slabs, b->fd_cref);
-        LT_CHECK_LAUNCH();
-    }
     b->cref_deferred = defer;
     b->s1_f32 = s1x != nullptr;
     return LT_OK;
