@@ -498,7 +498,7 @@ def main():
                     "avg_launch_us": us, "units_per_launch": f"per step: X[{rows_x}x{f}] * W1[{f}x{h}] and X'[{n_probe_local} probes] * W1, exact fp32 MFMA"}
         if cls == "fp64_product" and fp64_route == 1:
             alg = n * f * 4 + f * h * 4 + n * hp * 8
-            return {"kernel": "k_s1d_feature_rows (+ k_ref_product: the reference vector's own product)",
+            return {"kernel": "k_s1d_feature_rows (the reference vector's product and its slice sum ride in the same launch)",
                     "bound": "hbm", "achieved": round(alg / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(alg / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": tr, "algorithmic_bytes_per_launch": int(alg), "avg_launch_us": us,
                     "units_per_launch": f"one pass over X[{n}x{f}] fp32 -> S1d = X*W1 [{n}x{h}] fp64 (feature rows as differences to a reference row); "
