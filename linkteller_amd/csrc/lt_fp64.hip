@@ -284,7 +284,12 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
                                                   const int32_t *__restrict__ long_row,
                                                   double *__restrict__ seg_out, int32_t *__restrict__ state,
                                                   const double *__restrict__ rs, const double *__restrict__ crefv,
-                                                  const lt_bits_job job = lt_bits_job{}, const int job_first = 0) {
+                                                  const lt_bits_job job = lt_bits_job{}, const int job_first = 0,
+                                                  float *__restrict__ outf = nullptr) {
+    // outf != NULL: the finished rows go there rounded once to fp32 instead of to `out` (the segment sums stay fp64).  The
+    // kink test of LT_MODE_DELTA reads a pre-activation for its SIGN, the sign of z + dz and, where they differ, its value: a
+    // relative rounding of z (6e-8) moves none of the three by more than 6e-8 of what the exact z gives -- unlike a rounding of
+    // the terms z is summed from.  Half the bytes stage A gathers per item (2 KB -> 1 KB) and this kernel writes.
     // job.nblocks > 0: the blocks from job_first on build the item tables of a probe chunk (k_item_bits' blocks: nothing in
     // this launch depends on them, and the launch in front of this one that they used to be cost the step 4 us)
     if (job.nblocks > 0 && (int)blockIdx.x >= job_first) {
@@ -361,7 +366,8 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[k] += (double)b[k];
     }
-    *reinterpret_cast<f64x4 *>((SEG ? seg_out : out) + (size_t)r * ld + coff) = acc;
+    if (outf && !SEG) *reinterpret_cast<f32x4 *>(outf + (size_t)r * ld + coff) = f32x4{(float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]};
+    else *reinterpret_cast<f64x4 *>((SEG ? seg_out : out) + (size_t)r * ld + coff) = acc;
     if (state && !SEG && coff == 0) state[r] = 1;
 }
 // the hub rows: segment sums added in segment order + the bias (`state`: as in k_spmm_f64; the marked rows are set valid by a
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
 __global__ void k_spmm_f64_long(int n_long, const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_segptr,
                                 const double *__restrict__ part, int ld, const float *__restrict__ b1p,
                                 double *__restrict__ out, int32_t *__restrict__ state, int finish,
-                                const double *__restrict__ rs, const double *__restrict__ crefv) {
+                                const double *__restrict__ rs, const double *__restrict__ crefv, float *__restrict__ outf = nullptr) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (finish) {
         if (i < n_long && state[long_row[i]] == 2) state[long_row[i]] = 1;
@@ -381,7 +387,8 @@ __global__ void k_spmm_f64_long(int n_long, const int32_t *__restrict__ long_row
     double acc = part[(size_t)long_segptr[li] * ld + c];
     for (int sg = long_segptr[li] + 1; sg < long_segptr[li + 1]; ++sg) acc += part[(size_t)sg * ld + c];
     if (crefv) acc = fma(rs[long_row[li]], crefv[c], acc);
-    out[(size_t)long_row[li] * ld + c] = acc + (double)b1p[c];
+    if (outf) outf[(size_t)long_row[li] * ld + c] = (float)(acc + (double)b1p[c]);      // (as k_spmm_f64's outf)
+    else out[(size_t)long_row[li] * ld + c] = acc + (double)b1p[c];
 }
 
 // ---- S1d = X*W1 from the DIFFERENCES of the feature rows to one reference row ---------------------------------------
@@ -1013,6 +1020,7 @@ static int compute_s1d(lt_baseline *b, hipStream_t st) {
     if (b->n == 0) return LT_OK;
     const int Hp = b->Hp, H = b->H, n = b->n;
     b->z_all_valid = false;
+    b->z1x_valid = false;
     // every pre-activation row is stale from here on (the feature-rows kernel resets the words itself)
     const bool feat = !lt_fp64_agg_active(b) && b->S1d && !b->S1d_external && want_feature_rows(b);
     if (!feat) LT_HIP(hipMemsetAsync(b->zstate, 0, (size_t)n * sizeof(int32_t), st));
@@ -1041,12 +1049,14 @@ static int compute_s1d(lt_baseline *b, hipStream_t st) {
 }
 
 // Z1d = A_hat S1d + b1: every row (state == NULL) or the rows marked 2 in `state`
-static int form_z1d(lt_baseline *b, int32_t *state, hipStream_t st, const lt_bits_job *job = nullptr, bool *job_done = nullptr) {
+static int form_z1d(lt_baseline *b, int32_t *state, hipStream_t st, const lt_bits_job *job = nullptr, bool *job_done = nullptr,
+                    bool allow_f32 = false) {
     const int Hp = b->Hp, n = b->n;
     const int lpr = lt_lpr_for(Hp);
     const unsigned g2 = (unsigned)((n + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr)));
     const lt_graph *g = b->g;
     const int have_long = (g->p_n_long > 0 && b->seg_d) ? 1 : 0;
+    b->z1x_valid = false;
     if (!state && !b->cref_deferred && lt_tiled_wanted(g, Hp) && (g->p_n_long == 0 || b->seg_d)) {
         // S1d beyond the caches (R-MAT scale 21: 4.3 GB): the column-sliced work-item route of lt_spmm.hip, same chains
         int rc = lt_launch_rows_tiled_f64(g, b->S1d, Hp, Hp, b->b1p, b->Z1d, Hp, b->seg_d, Hp, st);
@@ -1063,22 +1073,25 @@ static int form_z1d(lt_baseline *b, int32_t *state, hipStream_t st, const lt_bit
     const unsigned gs = have_long ? (unsigned)((g->p_n_seg + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr))) : 0u;
     const double *crefv = b->cref_deferred ? b->fd_cref : nullptr;      // (deferred cref: S1d holds S1d - cref)
     const lt_bits_job jb = (job && !state) ? *job : lt_bits_job{};
+    // all rows of the feature route with fp32 row storage, for LT_MODE_DELTA's stage A alone: the result in fp32 too
+    float *zf = (allow_f32 && !state && b->s1_f32 && b->Z1x && lt_tune().s1_f32 != 0) ? b->Z1x : nullptr;
+    b->z1x_valid = zf != nullptr;
     const unsigned gj = jb.nblocks > 0 ? (unsigned)jb.nblocks : 0u;
     if (job_done) *job_done = gj > 0;
     if (b->s1_f32) {
         LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, float>), dim3(g2 + gs + gj), dim3(256), 0, st, n, g->rowptr,
                                                 g->col, g->val, b->S1x, Hp, b->b1p, b->Z1d, (int)gs, g->p_n_seg, g->p_seg_begin,
-                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv, jb, (int)(g2 + gs)));
+                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv, jb, (int)(g2 + gs), zf));
     } else {
         LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, double>), dim3(g2 + gs + gj), dim3(256), 0, st, n, g->rowptr,
                                                 g->col, g->val, b->S1d, Hp, b->b1p, b->Z1d, (int)gs, g->p_n_seg, g->p_seg_begin,
-                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv, jb, (int)(g2 + gs)));
+                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv, jb, (int)(g2 + gs), zf));
     }
     LT_CHECK_LAUNCH();
     if (have_long) {
         const long tot = (long)g->p_n_long * Hp;
         hipLaunchKernelGGL(k_spmm_f64_long, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, g->p_n_long,
-                           g->p_long_row, g->p_long_segptr, b->seg_d, Hp, b->b1p, b->Z1d, state, 0, b->fd_rs, crefv);
+                           g->p_long_row, g->p_long_segptr, b->seg_d, Hp, b->b1p, b->Z1d, state, 0, b->fd_rs, crefv, zf);
         LT_CHECK_LAUNCH();
         if (state) {
             hipLaunchKernelGGL(k_spmm_f64_long, dim3((unsigned)((g->p_n_long + 255) / 256)), dim3(256), 0, st, g->p_n_long,
@@ -1108,7 +1121,7 @@ int lt_fp64_prepare_rows(const lt_baseline *cb, const int32_t *off, int nb, cons
     const bool ondemand = !tiled && (knob > 0 || (knob < 0 && (double)n_probe_call * avg * 2.0 < (double)g->n &&
                                                   (double)g->nnz * (double)b->Hp >= 2.5e8));
     if (!ondemand) {
-        const int rc = form_z1d(b, nullptr, st, job, job_done);
+        const int rc = form_z1d(b, nullptr, st, job, job_done, true);
         if (rc) return rc;
         b->z_all_valid = true;
         return LT_OK;
@@ -1243,7 +1256,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     double *yd = nullptr, *segy = nullptr;
     float *fref = nullptr;
     double *frs = nullptr;
-    float *fs1x = nullptr;
+    float *fs1x = nullptr, *fz1x = nullptr;
     int *gate = nullptr;
     int32_t *zst = nullptr, *zrw = nullptr, *zct = nullptr;
     hipError_t e = hipMalloc((void **)&z1d, nh);
@@ -1259,6 +1272,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fref, (size_t)(b->F + FD_REF_PAD) * sizeof(float));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&frs, n1 * sizeof(double));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fs1x, n1 * b->Hp * sizeof(float));
+        if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fz1x, n1 * b->Hp * sizeof(float));
     }
     if (alloc_agg) {
         if (e == hipSuccess) e = hipMalloc((void **)&yd, n1 * b->Fp * sizeof(double));
@@ -1270,13 +1284,13 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     if (e == hipSuccess) e = hipMalloc((void **)&zct, sizeof(int32_t));
     if (e != hipSuccess) {   // all or nothing: a retry starts from a clean state, nothing leaks
         (void)hipFree(s1d); (void)hipFree(z1d); (void)hipFree(slabs); (void)hipFree(segd);
-        (void)hipFree(cref); (void)hipFree(fslabs); (void)hipFree(gate); (void)hipFree(fref); (void)hipFree(frs); (void)hipFree(fs1x);
+        (void)hipFree(cref); (void)hipFree(fslabs); (void)hipFree(gate); (void)hipFree(fref); (void)hipFree(frs); (void)hipFree(fs1x); (void)hipFree(fz1x);
         (void)hipFree(yd); (void)hipFree(segy); (void)hipFree(zst); (void)hipFree(zrw); (void)hipFree(zct);
         if (hint_host) (void)hipHostFree(hint_host);
         return lt_set_error(LT_ERR_HIP, "lt_baseline_enable_fp64: hipMalloc failed: %s", hipGetErrorString(e));
     }
     b->S1d = s1d; b->Z1d = z1d; b->slabs_d = slabs; b->seg_d = segd;
-    b->fd_cref = cref; b->fd_slabs = fslabs; b->fd_gate = gate; b->fd_ref = fref; b->fd_rs = frs; b->S1x = fs1x;
+    b->fd_cref = cref; b->fd_slabs = fslabs; b->fd_gate = gate; b->fd_ref = fref; b->fd_rs = frs; b->S1x = fs1x; b->Z1x = fz1x;
     if (frs && b->n > 0) {
         hipLaunchKernelGGL(k_row_sums, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, st, b->n, b->g->rowptr, b->g->val, frs);
         LT_CHECK_LAUNCH();
@@ -1366,7 +1380,9 @@ void lt_baseline_free_fp64(lt_baseline *b) {
     (void)hipFree(b->fd_ref);
     (void)hipFree(b->fd_rs);
     (void)hipFree(b->S1x);
-    b->S1x = nullptr;
+    (void)hipFree(b->Z1x);
+    b->S1x = b->Z1x = nullptr;
+    b->z1x_valid = false;
     b->s1_f32 = false;
     b->fd_ref = nullptr;
     b->fd_rs = nullptr;

@@ -815,12 +815,14 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
 // the queue in front of a guarded load); W2 and the deferred reference product of the lane's 4 hidden columns stay in
 // registers across the items.  Same operations in the same order as k_item_stageA: the bits are its bits.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-template <int LPR, int CP>
+// SX / ZF: the probe's product row from S1x (fp32) / the pre-activation from Z1x (fp32) -- compile-time, so that no load sits
+// behind a branch
+template <int LPR, int CP, bool SX, bool ZF>
 __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA_d2(
     const double *__restrict__ Z1d, const double *__restrict__ S1d, const float *__restrict__ S1x,
     const double *__restrict__ Spd, const double *__restrict__ crefv, int Hp, const float *__restrict__ W2p, int C,
     int nb, const int32_t *__restrict__ off, float delta, float *__restrict__ S2x, const int2 *__restrict__ item_pr,
-    const int2 *__restrict__ item_va) {
+    const int2 *__restrict__ item_va, const float *__restrict__ Z1x) {      // Z1x != NULL: the pre-activation in fp32 (k_spmm_f64)
     constexpr int RPW = 64 / LPR, U = 2;
     const int lane = threadIdx.x & 63;
     const int gl = lane & (LPR - 1);
@@ -854,9 +856,14 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA_d2(
         f32x4 sx[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            z[u] = *reinterpret_cast<const f64x4 *>(Z1d + (size_t)pr[u].y * Hp + coff);
-            if (S1x) sx[u] = ld4(S1x + (size_t)va[u].x * Hp + coff);
-            else sd[u] = *reinterpret_cast<const f64x4 *>(Spd ? Spd + (size_t)pr[u].x * Hp + coff : S1d + (size_t)va[u].x * Hp + coff);
+            if constexpr (ZF) {
+                const f32x4 zf = ld4(Z1x + (size_t)pr[u].y * Hp + coff);
+                z[u] = f64x4{(double)zf[0], (double)zf[1], (double)zf[2], (double)zf[3]};
+            } else {
+                z[u] = *reinterpret_cast<const f64x4 *>(Z1d + (size_t)pr[u].y * Hp + coff);
+            }
+            if constexpr (SX) sx[u] = ld4(S1x + (size_t)va[u].x * Hp + coff);
+            else sd[u] = *reinterpret_cast<const f64x4 *>((Spd ? Spd + (size_t)pr[u].x * Hp : S1d + (size_t)va[u].x * Hp) + coff);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -869,7 +876,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA_d2(
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     // the probe's S1 row off the fp64 product (fp32 storage and / or deferred reference product: lt_fp64.hip)
-                    const float sk = S1x ? (float)((double)sx[u][k] + cr[k]) : (add_cref ? (float)(sd[u][k] + cr[k]) : (float)sd[u][k]);
+                    const float sk = SX ? (float)((double)sx[u][k] + cr[k]) : (add_cref ? (float)(sd[u][k] + cr[k]) : (float)sd[u][k]);
                     // kink test on the fp64-accumulated pre-activation
                     const float dz = arv * (delta * sk);
                     const double zz = z[u][k], z1 = zz + (double)dz;
@@ -1839,11 +1846,17 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                 }
                 { lt_prof_scope prof_(LT_K_ITEM_A, st);
                 if (b->Z1d) {
-                    LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
-                        hipLaunchKernelGGL((k_item_stageA_d2<LPR_, CP_>), dim3(LT_ITEM_GRID), dim3(LT_BLOCK), 0, st, b->Z1d, b->S1d,
-                                           (b->s1_f32 && !spd) ? b->S1x : (const float *)nullptr, spd,
-                                           b->cref_deferred ? b->fd_cref : (const double *)nullptr, Hp, b->W2p, C, nb, w.off, delta,
-                                           w.S2x, w.item_pr, w.item_va)));
+                    const float *sxp = (b->s1_f32 && !spd) ? b->S1x : (const float *)nullptr;
+                    const float *zxp = b->z1x_valid ? b->Z1x : (const float *)nullptr;
+#define LT_D2_LAUNCH(SX_, ZF_)                                                                                                    \
+    LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,                                                                                       \
+        hipLaunchKernelGGL((k_item_stageA_d2<LPR_, CP_, SX_, ZF_>), dim3(LT_ITEM_GRID), dim3(LT_BLOCK), 0, st, b->Z1d, b->S1d, sxp,  \
+                           spd, b->cref_deferred ? b->fd_cref : (const double *)nullptr, Hp, b->W2p, C, nb, w.off, delta, w.S2x,  \
+                           w.item_pr, w.item_va, zxp)))
+                    if (sxp && zxp) { LT_D2_LAUNCH(true, true); }
+                    else if (sxp) { LT_D2_LAUNCH(true, false); }
+                    else { LT_D2_LAUNCH(false, false); }
+#undef LT_D2_LAUNCH
                 } else {
                     LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,
                         hipLaunchKernelGGL((k_item_stageA<LPR_, CP_, 1>), dim3(LT_ITEM_GRID), dim3(LT_BLOCK), 0,
