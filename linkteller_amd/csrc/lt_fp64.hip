@@ -1073,8 +1073,8 @@ static int form_z1d(lt_baseline *b, int32_t *state, hipStream_t st, const lt_bit
     const unsigned gs = have_long ? (unsigned)((g->p_n_seg + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr))) : 0u;
     const double *crefv = b->cref_deferred ? b->fd_cref : nullptr;      // (deferred cref: S1d holds S1d - cref)
     const lt_bits_job jb = (job && !state) ? *job : lt_bits_job{};
-    // all rows of the feature route with fp32 row storage, for LT_MODE_DELTA's stage A alone: the result in fp32 too
-    float *zf = (allow_f32 && !state && b->s1_f32 && b->Z1x && lt_tune().s1_f32 != 0) ? b->Z1x : nullptr;
+    // the feature route with fp32 row storage, for LT_MODE_DELTA's stage A alone: the result in fp32 too
+    float *zf = (allow_f32 && b->s1_f32 && b->Z1x && lt_tune().s1_f32 != 0) ? b->Z1x : nullptr;     // (on demand too: the same bits)
     b->z1x_valid = zf != nullptr;
     const unsigned gj = jb.nblocks > 0 ? (unsigned)jb.nblocks : 0u;
     if (job_done) *job_done = gj > 0;
@@ -1130,7 +1130,7 @@ int lt_fp64_prepare_rows(const lt_baseline *cb, const int32_t *off, int nb, cons
     LT_HIP(hipMemsetAsync(b->zcount, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(k_z_mark, dim3(256), dim3(256), 0, st, off, nb, item_pr, b->zstate, b->zrows, b->zcount);
     LT_CHECK_LAUNCH();
-    return form_z1d(b, b->zstate, st);
+    return form_z1d(b, b->zstate, st, nullptr, nullptr, true);
 }
 
 // ---- pieces the 3-layer model's `delta` (lt_gcn3.hip) builds its fp64 baseline from ------------------------------------
