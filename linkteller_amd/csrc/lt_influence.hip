@@ -876,6 +876,8 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA_d2(
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     // the probe's S1 row off the fp64 product (fp32 storage and / or deferred reference product: lt_fp64.hip)
+                    // (SX: the fp32 part of the stored row is enough here -- s is an fp32 quantity of the algorithm, the bf16
+                    // residual of lt_fp64.hip matters where rows are SUMMED, in the pre-activation)
                     const float sk = SX ? (float)((double)sx[u][k] + cr[k]) : (add_cref ? (float)(sd[u][k] + cr[k]) : (float)sd[u][k]);
                     // kink test on the fp64-accumulated pre-activation
                     const float dz = arv * (delta * sk);
