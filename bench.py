@@ -497,7 +497,7 @@ def main():
                     "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop / sec / 1e12 / FP32_PEAK_TFLOPS, 4), "traffic": tr,
                     "avg_launch_us": us, "units_per_launch": f"per step: X[{rows_x}x{f}] * W1[{f}x{h}] and X'[{n_probe_local} probes] * W1, exact fp32 MFMA"}
         if cls == "fp64_product" and fp64_route == 1:
-            out_b = 8 if os.environ.get("LT_S1_F32") == "0" else 6      # the rows leave as fp32 + a bf16 residual unless s1_f32 = 0
+            out_b = 8 if os.environ.get("LT_S1_F32") == "0" else 4      # the rows leave as 32-bit fixed point unless s1_f32 = 0
             alg = n * f * 4 + f * h * 4 + n * hp * out_b
             return {"kernel": "k_s1d_feature_rows (the reference vector's product and its slice sum ride in the same launch)",
                     "bound": "hbm", "achieved": round(alg / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -84,10 +84,10 @@ int lt_device_count(int *count);
  *                         exact for any X): 0 = never, 1 = always try, negative = when lt_baseline_enable_fp64 found the
  *                         features to be of that kind (default).  The only knob that changes fp64 summation ORDER (the
  *                         results agree to ~1e-16 relative before the final rounding to fp32).
- *   "s1_f32"              feature-difference route with "defer_cref": 1 = the fp64-accumulated product rows are stored as fp32 plus
- *                         a bf16 residual (32 bits of mantissa, 6 bytes; 3/4 of the bytes the fp64 SpMM gathers) and the
- *                         pre-activation in fp32 (default), 0 = both in fp64.  Moves `delta` results by ~1e-7 of the largest score
- *                         (plain fp32 rows, 24 bits, moved them by up to 7e-5: DESIGN.md 5d)
+ *   "s1_f32"              feature-difference route with "defer_cref": 1 = the fp64-accumulated product rows are stored as 32-bit
+ *                         fixed point with one scale per row (31 bits against the row's largest value; half the bytes the fp64
+ *                         SpMM gathers) and the pre-activation in fp32 (default), 0 = both in fp64.  Moves `delta` results by
+ *                         < 1e-6 of the largest score (plain fp32 rows moved them by up to 7e-5: DESIGN.md 5d)
  *   "defer_cref"          feature-difference route: 1 = the reference vector's product m W1 is formed by extra blocks of the rows'
  *                         launch and added by the readers of S1d (the fp64 SpMM, stage A) (default), 0 = formed first and added
  *                         by the rows kernel.  fp64 summation order only, like "feature_delta"

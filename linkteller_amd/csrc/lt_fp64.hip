@@ -269,9 +269,10 @@ __global__ void k_sum_slabs_f64(const double *__restrict__ slabs, long slab_stri
 // One lane group per row of up to LT_ROW_SEG entries; on a graph with hub rows the first seg_blocks blocks of the
 // launch take one SEGMENT of a long row per lane group instead, raw sum into seg_out[segment] (k_spmm_f64_long adds
 // them in segment order and the bias).  fp64: the cut only decides how a hub row's work is spread.
-// ST = double, or float: the feature route stores its fp64-ACCUMULATED product as fp32 + a bf16 residual (S1x + Sl: 32 bits of
-// mantissa, 3/4 of the bytes every gather moves; plain fp32 rows were not enough -- a unit within dz of its kink carries the rounding
-// of the terms into the result as an absolute error, up to 7e-5 of the largest score); the chains accumulate in fp64.
+// ST = double, or "float": the feature route stores its fp64-ACCUMULATED product as 32-bit fixed point with a scale per row (S1x +
+// S1qs: 31 bits against the row's largest value, half the bytes every gather moves; plain fp32 rows were not enough -- a unit within
+// dz of its kink carries the rounding of the terms into the result as an absolute error, up to 7e-5 of the largest score);
+// the chains accumulate in fp64.
 template <int LPR, typename ST>
 __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restrict__ rowptr,
                                                   const int32_t *__restrict__ col,
@@ -285,8 +286,8 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
                                                   double *__restrict__ seg_out, int32_t *__restrict__ state,
                                                   const double *__restrict__ rs, const double *__restrict__ crefv,
                                                   const lt_bits_job job = lt_bits_job{}, const int job_first = 0,
-                                                  float *__restrict__ outf = nullptr, const unsigned short *__restrict__ Sl = nullptr) {
-    // Sl != NULL (ST = float): the bf16 residuals of S, gathered next to it -- a term is (double)S + (double)residual
+                                                  float *__restrict__ outf = nullptr, const double *__restrict__ Sq = nullptr) {
+    // ST = float: S holds int32 fixed point, row c scaled by Sq[c] (k_s1d_feature_rows): a term is A_hat[r, c] * Sq[c] * q
     // outf != NULL: the finished rows go there rounded once to fp32 instead of to `out` (the segment sums stay fp64).  The
     // kink test of LT_MODE_DELTA reads a pre-activation for its SIGN, the sign of z + dz and, where they differ, its value: a
     // relative rounding of z (6e-8) moves none of the three by more than 6e-8 of what the exact z gives -- unlike a rounding of
@@ -325,56 +326,49 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
         if (seg_blocks > 0 && e1 - e > LT_ROW_SEG) return;
     }
     typedef ST sx4 __attribute__((ext_vector_type(4)));
-    constexpr bool RES = sizeof(ST) == 4;        // float rows come with their bf16 residuals (Sl)
-    // value k of a gathered row: the stored element, plus its residual (bf16 k of the 8 bytes gathered next to it)
-    auto term = [](const sx4 &sv, const uint2 &lv, int k) -> double {
-        if constexpr (RES) {
-            const unsigned w = k < 2 ? lv.x : lv.y;
-            return (double)sv[k] + (double)__uint_as_float((k & 1) ? (w & 0xffff0000u) : (w << 16));
-        } else {
-            return (double)sv[k];
-        }
+    constexpr bool QNT = sizeof(ST) == 4;        // "float" rows are int32 fixed point with a scale per row (Sq)
+    typedef int qx4 __attribute__((ext_vector_type(4)));
+    auto term = [](const sx4 &sv, int k) -> double {
+        if constexpr (QNT) return (double)__builtin_bit_cast(qx4, sv)[k];
+        else return (double)sv[k];
     };
     for (; e + 8 <= e1; e += 8) {   // eight gathers in flight (a trip costs one L2 / Infinity-Cache latency); entry order kept
         double a[8];
         sx4 s[8];
-        uint2 l[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+            const int c = col[e + j];
             a[j] = (double)val[e + j];
-            const size_t ro = (size_t)col[e + j] * ld + coff;
-            s[j] = *reinterpret_cast<const sx4 *>(S + ro);
-            if constexpr (RES) l[j] = *reinterpret_cast<const uint2 *>(Sl + ro);
+            if constexpr (QNT) a[j] *= Sq[c];
+            s[j] = *reinterpret_cast<const sx4 *>(S + (size_t)c * ld + coff);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] = fma(a[j], term(s[j], l[j], k), acc[k]);
+            for (int k = 0; k < 4; ++k) acc[k] = fma(a[j], term(s[j], k), acc[k]);
     }
     for (; e + 4 <= e1; e += 4) {
         double a[4];
         sx4 s[4];
-        uint2 l[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            const int c = col[e + j];
             a[j] = (double)val[e + j];
-            const size_t ro = (size_t)col[e + j] * ld + coff;
-            s[j] = *reinterpret_cast<const sx4 *>(S + ro);
-            if constexpr (RES) l[j] = *reinterpret_cast<const uint2 *>(Sl + ro);
+            if constexpr (QNT) a[j] *= Sq[c];
+            s[j] = *reinterpret_cast<const sx4 *>(S + (size_t)c * ld + coff);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] = fma(a[j], term(s[j], l[j], k), acc[k]);
+            for (int k = 0; k < 4; ++k) acc[k] = fma(a[j], term(s[j], k), acc[k]);
     }
     for (; e < e1; ++e) {
-        const double a = (double)val[e];
-        const size_t ro = (size_t)col[e] * ld + coff;
-        const sx4 s = *reinterpret_cast<const sx4 *>(S + ro);
-        uint2 l = make_uint2(0u, 0u);
-        if constexpr (RES) l = *reinterpret_cast<const uint2 *>(Sl + ro);
+        const int c = col[e];
+        double a = (double)val[e];
+        if constexpr (QNT) a *= Sq[c];
+        const sx4 s = *reinterpret_cast<const sx4 *>(S + (size_t)c * ld + coff);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = fma(a, term(s, l, k), acc[k]);
+        for (int k = 0; k < 4; ++k) acc[k] = fma(a, term(s, k), acc[k]);
     }
     if (!SEG) {
         const f32x4 b = ld4(b1p + coff);
@@ -442,7 +436,7 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     int n, int F, int H, int Hp, const float *__restrict__ X, long ldx, const float *__restrict__ ref,
     const float *__restrict__ W1, const double *__restrict__ cref, double *__restrict__ S1d, int hint_cap,
     int *__restrict__ dense_hint, int nslab, double *__restrict__ slabs, int32_t *__restrict__ zstate,
-    float *__restrict__ S1x, unsigned *__restrict__ gate, double *__restrict__ cref_out, unsigned short *__restrict__ S1l) {
+    float *__restrict__ S1x, unsigned *__restrict__ gate, double *__restrict__ cref_out, double *__restrict__ S1qs) {
     // zstate != NULL: every row's pre-activation is marked stale here (saves the refresh its memset launch).
     // The first nslab blocks of the launch (deferred cref, nslab > 0) form the K slices of cref = m W1 instead of rows:
     // block z sums slice [64 z, 64 z + 64) for every hidden column (thread (kq, cq): 16 k's x 4 columns, one trip; the four
@@ -654,25 +648,27 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     }
     if (total > hint_cap && lane == 0) *dense_hint = 1;
     if (zstate && lane == 0) zstate[i] = 0;
-    if (!own) return;
+    if (!own && !S1x) return;
     f64x4 o;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) o[t] = c0 + t < H ? (cref ? cref[c0 + t] + acc[t] : acc[t]) : 0.0;
-    if (S1x) {
-        // fp32 + a bf16 residual: the fp64-accumulated value to 32 bits of mantissa in 6 bytes (plain fp32 storage, 24 bits, reached
-        // the result as up to 7e-5 of the largest score where a hidden unit sat within dz of its kink: tools/fuzz_gpu.py 60 31337)
-        const f32x4 hi = f32x4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
-        *reinterpret_cast<f32x4 *>(S1x + (size_t)i * Hp + c0) = hi;
-        unsigned short lo[4];
+    for (int t = 0; t < 4; ++t) o[t] = (own && c0 + t < H) ? (cref ? cref[c0 + t] + acc[t] : acc[t]) : 0.0;
+    if (S1x) {      // (every lane of the wave is here: the row's largest value is a wave reduction)
+        // 32-bit FIXED POINT with one scale per row: q = round(value / scale), scale = (largest |value| of the row) / 2^31 -- 31 bits
+        // against the row's largest value instead of fp32's 24 against each value, in the same 4 bytes.  What the readers sum is
+        // A_hat[r, c] * value: an ABSOLUTE error per term is what reaches a pre-activation, and plain fp32 rows reached the result
+        // as up to 7e-5 of the largest score where a hidden unit sat within dz of its kink (tools/fuzz_gpu.py 60 31337).
+        double mx = fmax(fmax(fabs(o[0]), fabs(o[1])), fmax(fabs(o[2]), fabs(o[3])));
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            unsigned u = __float_as_uint((float)(o[t] - (double)hi[t]));
-            u += 0x7fffu + ((u >> 16) & 1u);              // round to nearest even on the 16 bits kept
-            lo[t] = (unsigned short)(u >> 16);
-        }
-        *reinterpret_cast<uint2 *>(S1l + (size_t)i * Hp + c0) = make_uint2((unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16));
+        for (int m = 32; m >= 1; m >>= 1) mx = fmax(mx, __shfl_xor(mx, m, 64));
+        const double scale = mx > 0.0 ? mx * (1.0 / 2147483000.0) : 1.0;
+        const double inv = 1.0 / scale;
+        int q[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) q[t] = (int)rint(o[t] * inv);
+        if (own) *reinterpret_cast<int4 *>(S1x + (size_t)i * Hp + c0) = make_int4(q[0], q[1], q[2], q[3]);
+        if (lane == 0) S1qs[i] = scale;
     }
-    else *reinterpret_cast<f64x4 *>(S1d + (size_t)i * Hp + c0) = o;
+    else if (own) *reinterpret_cast<f64x4 *>(S1d + (size_t)i * Hp + c0) = o;
 }
 static size_t fd_smem_bytes(int F) {
     const size_t Fp = (size_t)((F + 1) & ~1);
@@ -1027,14 +1023,14 @@ static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, b
     }
     const int nslab = defer ? nz : 0;
     const double *cref = defer ? (const double *)nullptr : b->fd_cref;
-    float *s1x = (defer && b->S1x && b->S1l && lt_tune().s1_f32 != 0) ? b->S1x : nullptr;
+    float *s1x = (defer && b->S1x && b->S1qs && lt_tune().s1_f32 != 0) ? b->S1x : nullptr;
     const unsigned blocks = (unsigned)((n + FD_WAVES - 1) / FD_WAVES + nslab);
     const size_t smem = fd_smem_bytes(F);
     const bool vec2 = b->ldx % 2 == 0 && F % 2 == 0 && ((uintptr_t)b->X % 8) == 0, one = F <= 16 * 64 * FD_WAVES;
 #define LT_FD_LAUNCH(V_, O_)                                                                                                  \
     hipLaunchKernelGGL((k_s1d_feature_rows<V_, O_>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx, \
                        b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs, zstate, s1x,           \
-                       defer ? (unsigned *)b->fd_gate : (unsigned *)nullptr, b->fd_cref, b->S1l)
+                       defer ? (unsigned *)b->fd_gate : (unsigned *)nullptr, b->fd_cref, b->S1qs)
     if (vec2 && one) LT_FD_LAUNCH(2, true);
     else if (vec2) LT_FD_LAUNCH(2, false);
     else if (one) LT_FD_LAUNCH(1, true);
@@ -1114,7 +1110,7 @@ static int form_z1d(lt_baseline *b, int32_t *state, hipStream_t st, const lt_bit
     if (b->s1_f32) {
         LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, float>), dim3(g2 + gs + gj), dim3(256), 0, st, n, g->rowptr,
                                                 g->col, g->val, b->S1x, Hp, b->b1p, b->Z1d, (int)gs, g->p_n_seg, g->p_seg_begin,
-                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv, jb, (int)(g2 + gs), zf, b->S1l));
+                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv, jb, (int)(g2 + gs), zf, b->S1qs));
     } else {
         LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, double>), dim3(g2 + gs + gj), dim3(256), 0, st, n, g->rowptr,
                                                 g->col, g->val, b->S1d, Hp, b->b1p, b->Z1d, (int)gs, g->p_n_seg, g->p_seg_begin,
@@ -1290,7 +1286,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     float *fref = nullptr;
     double *frs = nullptr;
     float *fs1x = nullptr, *fz1x = nullptr;
-    unsigned short *fs1l = nullptr;
+    double *fs1q = nullptr;
     int *gate = nullptr;
     int32_t *zst = nullptr, *zrw = nullptr, *zct = nullptr;
     hipError_t e = hipMalloc((void **)&z1d, nh);
@@ -1307,7 +1303,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&frs, n1 * sizeof(double));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fs1x, n1 * b->Hp * sizeof(float));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fz1x, n1 * b->Hp * sizeof(float));
-        if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fs1l, n1 * b->Hp * sizeof(unsigned short));
+        if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fs1q, n1 * sizeof(double));
     }
     if (alloc_agg) {
         if (e == hipSuccess) e = hipMalloc((void **)&yd, n1 * b->Fp * sizeof(double));
@@ -1319,13 +1315,13 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     if (e == hipSuccess) e = hipMalloc((void **)&zct, sizeof(int32_t));
     if (e != hipSuccess) {   // all or nothing: a retry starts from a clean state, nothing leaks
         (void)hipFree(s1d); (void)hipFree(z1d); (void)hipFree(slabs); (void)hipFree(segd);
-        (void)hipFree(cref); (void)hipFree(fslabs); (void)hipFree(gate); (void)hipFree(fref); (void)hipFree(frs); (void)hipFree(fs1x); (void)hipFree(fz1x); (void)hipFree(fs1l);
+        (void)hipFree(cref); (void)hipFree(fslabs); (void)hipFree(gate); (void)hipFree(fref); (void)hipFree(frs); (void)hipFree(fs1x); (void)hipFree(fz1x); (void)hipFree(fs1q);
         (void)hipFree(yd); (void)hipFree(segy); (void)hipFree(zst); (void)hipFree(zrw); (void)hipFree(zct);
         if (hint_host) (void)hipHostFree(hint_host);
         return lt_set_error(LT_ERR_HIP, "lt_baseline_enable_fp64: hipMalloc failed: %s", hipGetErrorString(e));
     }
     b->S1d = s1d; b->Z1d = z1d; b->slabs_d = slabs; b->seg_d = segd;
-    b->fd_cref = cref; b->fd_slabs = fslabs; b->fd_gate = gate; b->fd_ref = fref; b->fd_rs = frs; b->S1x = fs1x; b->Z1x = fz1x; b->S1l = fs1l;
+    b->fd_cref = cref; b->fd_slabs = fslabs; b->fd_gate = gate; b->fd_ref = fref; b->fd_rs = frs; b->S1x = fs1x; b->Z1x = fz1x; b->S1qs = fs1q;
     if (frs && b->n > 0) {
         hipLaunchKernelGGL(k_row_sums, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, st, b->n, b->g->rowptr, b->g->val, frs);
         LT_CHECK_LAUNCH();
@@ -1416,9 +1412,9 @@ void lt_baseline_free_fp64(lt_baseline *b) {
     (void)hipFree(b->fd_rs);
     (void)hipFree(b->S1x);
     (void)hipFree(b->Z1x);
-    (void)hipFree(b->S1l);
+    (void)hipFree(b->S1qs);
     b->S1x = b->Z1x = nullptr;
-    b->S1l = nullptr;
+    b->S1qs = nullptr;
     b->z1x_valid = false;
     b->s1_f32 = false;
     b->fd_ref = nullptr;

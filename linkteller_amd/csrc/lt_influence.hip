@@ -725,10 +725,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA(
                     if (DELTA == 2) {   // the probe's S1 row off the fp64 product (the fp32 one is not even computed for this mode)
                         // (aggregate-first route: the probes' own product rows Spd[b], there is no S1d)
                         const double *sp = Spd ? Spd + (size_t)b * Hp + coff : S1d + (size_t)v * Hp + coff;
-                        if (S1x) {             // the feature route's rows in fp32 storage (always with the deferred cref)
-                            const f32x4 t = ld4(S1x + (size_t)v * Hp + coff);
-                            s = f32x4{(float)((double)t[0] + crefv[coff]), (float)((double)t[1] + crefv[coff + 1]),
-                                      (float)((double)t[2] + crefv[coff + 2]), (float)((double)t[3] + crefv[coff + 3])};
+                        if (false) {
                         } else if (crefv && !Spd)     // deferred cref: S1d holds the rows without the reference vector's product
                             s = f32x4{(float)(sp[0] + crefv[coff]), (float)(sp[1] + crefv[coff + 1]), (float)(sp[2] + crefv[coff + 2]),
                                       (float)(sp[3] + crefv[coff + 3])};
@@ -822,7 +819,8 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA_d2(
     const double *__restrict__ Z1d, const double *__restrict__ S1d, const float *__restrict__ S1x,
     const double *__restrict__ Spd, const double *__restrict__ crefv, int Hp, const float *__restrict__ W2p, int C,
     int nb, const int32_t *__restrict__ off, float delta, float *__restrict__ S2x, const int2 *__restrict__ item_pr,
-    const int2 *__restrict__ item_va, const float *__restrict__ Z1x) {      // Z1x != NULL: the pre-activation in fp32 (k_spmm_f64)
+    const int2 *__restrict__ item_va, const float *__restrict__ Z1x,        // Z1x != NULL: the pre-activation in fp32 (k_spmm_f64)
+    const double *__restrict__ S1qs) {                                      // with S1x: the scales of its fixed-point rows (lt_fp64.hip)
     constexpr int RPW = 64 / LPR, U = 2;
     const int lane = threadIdx.x & 63;
     const int gl = lane & (LPR - 1);
@@ -854,6 +852,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA_d2(
         }
         f64x4 z[U], sd[U];
         f32x4 sx[U];
+        double sq[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if constexpr (ZF) {
@@ -862,7 +861,10 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA_d2(
             } else {
                 z[u] = *reinterpret_cast<const f64x4 *>(Z1d + (size_t)pr[u].y * Hp + coff);
             }
-            if constexpr (SX) sx[u] = ld4(S1x + (size_t)va[u].x * Hp + coff);
+            if constexpr (SX) {
+                sx[u] = ld4(S1x + (size_t)va[u].x * Hp + coff);
+                sq[u] = S1qs[va[u].x];
+            }
             else sd[u] = *reinterpret_cast<const f64x4 *>((Spd ? Spd + (size_t)pr[u].x * Hp : S1d + (size_t)va[u].x * Hp) + coff);
         }
 #pragma unroll
@@ -876,9 +878,9 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA_d2(
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     // the probe's S1 row off the fp64 product (fp32 storage and / or deferred reference product: lt_fp64.hip)
-                    // (SX: the fp32 part of the stored row is enough here -- s is an fp32 quantity of the algorithm, the bf16
-                    // residual of lt_fp64.hip matters where rows are SUMMED, in the pre-activation)
-                    const float sk = SX ? (float)((double)sx[u][k] + cr[k]) : (add_cref ? (float)(sd[u][k] + cr[k]) : (float)sd[u][k]);
+                    typedef int qx4 __attribute__((ext_vector_type(4)));
+                    const float sk = SX ? (float)((double)__builtin_bit_cast(qx4, sx[u])[k] * sq[u] + cr[k])
+                                        : (add_cref ? (float)(sd[u][k] + cr[k]) : (float)sd[u][k]);
                     // kink test on the fp64-accumulated pre-activation
                     const float dz = arv * (delta * sk);
                     const double zz = z[u][k], z1 = zz + (double)dz;
@@ -1854,7 +1856,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
     LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,                                                                                       \
         hipLaunchKernelGGL((k_item_stageA_d2<LPR_, CP_, SX_, ZF_>), dim3(LT_ITEM_GRID), dim3(LT_BLOCK), 0, st, b->Z1d, b->S1d, sxp,  \
                            spd, b->cref_deferred ? b->fd_cref : (const double *)nullptr, Hp, b->W2p, C, nb, w.off, delta, w.S2x,  \
-                           w.item_pr, w.item_va, zxp)))
+                           w.item_pr, w.item_va, zxp, b->S1qs)))
                     if (sxp && zxp) { LT_D2_LAUNCH(true, true); }
                     else if (sxp) { LT_D2_LAUNCH(true, false); }
                     else { LT_D2_LAUNCH(false, false); }

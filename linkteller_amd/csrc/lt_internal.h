@@ -107,7 +107,7 @@ struct lt_baseline {
     mutable bool layers_fresh = false;
     mutable bool fp64_fresh = false;
     mutable bool z_all_valid = false;   // every row of Z1d matches S1d (else: zstate per row)
-    unsigned short *S1l = nullptr;      // ... and the bf16 residual of every S1x value (S1d - S1x): 32 bits of mantissa in 6 bytes
+    double *S1qs = nullptr;             // [n] the scale of row i of S1x: that array then holds int32 q with S1d - cref = q * S1qs[i] (see k_spmm_f64)
     float *Z1x = nullptr;               // feature route with fp32 row storage: the pre-activation rounded ONCE to fp32 (see k_spmm_f64)
     mutable bool z1x_valid = false;     // ... is what the last all-rows pass wrote (instead of Z1d)
     // FULL rows on a graph with hub rows: the segment kernel + combine run on `side` next to the plain-row

@@ -96,7 +96,7 @@ def main():
                 _lib.set_tuning(k, None)
             base.refresh()
         # (this check is what caught plain fp32 storage of the feature route's product rows: seed 31337, case 59, 7e-5 of the largest
-        # score; with the bf16 residual the routes agree to ~1e-7)
+        # score; as 32-bit fixed point with a scale per row the routes agree to < 1e-6)
         assert np.abs(other - ref64).max() <= 1e-5 * scale and np.abs(other - res["delta"]).max() <= 2e-6 * scale, \
             (it, kind, n, h, c, f, route_knobs, np.abs(other - ref64).max() / scale, np.abs(other - res["delta"]).max() / scale, base.fp64_route())
         logits_ref = O.gcn_forward(torch.from_numpy(x).double(), O.to_torch_sparse(a_hat).double(),
