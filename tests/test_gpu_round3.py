@@ -509,3 +509,44 @@ def test_full_mode_on_a_hub_of_many_segments(gpu, long_par, p):
         # a 9 500-term fp32 sum in two different orders (128-entry segments here, sequential in torch.spmm): same noise
         # level, not the same draw -- 4x instead of the 2.5x ceiling of the recorded gates
         assert np.abs(f[i] - ref[torch.float64]).max() <= 4.0 * e32, i
+
+
+@pytest.mark.gpu
+def test_delta_with_a_whole_row_of_hidden_units_at_their_kinks(gpu):
+    """The worst case for the storage precision of the fp64 product rows: the bias is chosen so that EVERY hidden unit
+    of one row has a pre-activation of (almost) zero, i.e. every perturbation through that row crosses a ReLU kink and contributes
+    `-z` / `z + dz` -- the place where a rounding of the TERMS z is summed from reaches the result as an absolute error.  Plain fp32
+    rows (the default for most of round 3) gave ~7e-4 of the largest score here; the 32-bit fixed-point rows must stay inside the
+    1e-5 every other `delta` test asserts, fp64 rows (`s1_f32 = 0`) inside 1e-6."""
+    from linkteller_amd import _lib, engine, graph, synth
+    from oracle import linkteller_oracle as O
+    n, h, c, f = 600, 64, 2, 8
+    a_hat = graph.first_order_gcn(synth.powerlaw_graph(n, 3000, seed=3))
+    x = synth.gaussian_features(n, f, seed=5)            # F = 8: the feature-difference route serves it (route 1)
+    w = dict(synth.gcn_weights(f, h, c, seed=7))
+    deg = np.diff(a_hat.indptr)
+    r0 = int(np.argsort(deg)[len(deg) // 2])
+    z0 = (a_hat.astype(np.float64) @ (x.astype(np.float64) @ w["W1"].astype(np.float64)))[r0]
+    w["b1"] = (-z0).astype(np.float32)
+    nb = a_hat[r0].indices
+    probes = np.unique(np.concatenate([nb, [r0]])).astype(np.int32)
+    obs = np.unique(np.concatenate([nb, a_hat[nb[0]].indices])).astype(np.int32)
+    P64 = {k: torch.from_numpy(w[k]).double() for k in ("W1", "b1", "W2", "b2")}
+    adj_o, x64 = O.to_torch_sparse(a_hat).double(), torch.from_numpy(x).double()
+    ref = np.zeros((len(probes), len(obs)))
+    with torch.no_grad():
+        for i, v in enumerate(probes):
+            ref[i] = O.get_gradient_eps_mat(x64, adj_o, P64, int(v), 1e-4)[torch.as_tensor(obs.astype(np.int64))].norm(dim=1).numpy()
+    scale = ref.max()
+    err = {}
+    try:
+        for knob in (1, 0):
+            _lib.set_tuning("s1_f32", knob)
+            base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *_params(w, gpu))
+            got = base.influence_rows(probes, obs, 1e-4, "delta").cpu().numpy().astype(np.float64)
+            assert base.fp64_route() == 1
+            err[knob] = np.abs(got - ref).max() / scale
+    finally:
+        _lib.set_tuning("s1_f32", None)
+    assert err[1] <= 1e-5, err
+    assert err[0] <= 1e-6, err
