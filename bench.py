@@ -108,6 +108,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU reference sample")
     p.add_argument("--no-extras", action="store_true", help="skip other_modes / standalone SpMM legs")
+    p.add_argument("--no-scaling-workloads", action="store_true",
+                   help="skip the strong-scaling legs (n_test=2000 and the R-MAT n_test=4096 build at this rank count)")
     p.add_argument("--spmm-scale", type=int, default=21,
                    help="R-MAT scale of the HBM-resident SpMM leg (BASELINE configs[4]: 21; 0 = skip)")
     p.add_argument("--only-spmm", action="store_true", help="run only the R-MAT SpMM leg")
@@ -227,7 +229,7 @@ def main():
     # HBM traffic of the kernels this line prices, measured now (rank 0 of a 1-GPU run; child processes, so that this
     # process has not touched the GPU when they start)
     pmc, pmc_note = (None, "N > 1: not collected")
-    if world == 1 and not a.pmc_child and not a.only_spmm:
+    if world == 1 and not a.pmc_child and not a.only_spmm and os.environ.get("LT_FORCE_COLLECTIVES") != "1":
         pmc, pmc_note = pmc_inrun(a)
 
     import torch
@@ -242,8 +244,16 @@ def main():
         raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} HIP devices are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # LT_FORCE_COLLECTIVES=1 (linkteller_amd/dist.py): a process group is created even at world size 1 and every collective of
+    # the N > 1 path is issued -- on a one-GPU box RCCL then executes the exact calls an 8-GPU run makes
+    force = os.environ.get("LT_FORCE_COLLECTIVES") == "1" and not a.pmc_child
+    multi = world > 1 or force
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -257,13 +267,30 @@ def main():
             return pmc[cls]["hbm_bytes_per_launch"]
         return stamped_traffic(stamped_key) if stamped_key else None
 
+    rmat_cache = {}
+
+    def rmat_problem(scale):
+        """(A_hat scipy CSR, its device handle, host seconds) of the R-MAT graph of BASELINE configs[4]; built once per process."""
+        if scale not in rmat_cache:
+            t0 = time.perf_counter()
+            big = graph.first_order_gcn(synth.rmat_graph(scale, synth.rmat_draws(scale), seed=42))
+            rmat_cache[scale] = (big, graph.HipGraph(big), time.perf_counter() - t0)
+        return rmat_cache[scale]
+
+    def rmat_baseline(gb, nb_, hcols):
+        """The configs[4] model on the R-MAT graph: F = 256 Gaussian features, H = hcols, C = 2 (kept for the scaling leg)."""
+        key = ("baseline", nb_, hcols)
+        if key not in rmat_cache:
+            xb = torch.from_numpy(synth.gaussian_features(nb_, 256, seed=1)).to(dev)
+            wb = synth.gcn_weights(256, hcols, 2, seed=42)
+            rmat_cache[key] = engine.Baseline(gb, xb, *[torch.from_numpy(wb[k]).to(dev) for k in ("W1", "b1", "W2", "b2")])
+        return rmat_cache[key]
+
     def influence_shard(gb, nb_, scale, hcols):
         """The influence build on the R-MAT graph at the shape ONE of 8 ranks gets in BASELINE configs[4] (n_test = 4096 ->
         512 probes x 4096 observed nodes, F = H = 256): the product's default mode, with and without the loop-invariant
         baseline (X*W1 and the fp64 pre-activation), and the bit-faithful `sparse`."""
-        xb = torch.from_numpy(synth.gaussian_features(nb_, 256, seed=1)).to(dev)
-        wb = synth.gcn_weights(256, hcols, 2, seed=42)
-        bb = engine.Baseline(gb, xb, *[torch.from_numpy(wb[k]).to(dev) for k in ("W1", "b1", "W2", "b2")])
+        bb = rmat_baseline(gb, nb_, hcols)
         rs = np.random.RandomState(42)
         ob = rs.choice(nb_, 4096, replace=False)
         pb = ob[:512]
@@ -285,10 +312,7 @@ def main():
     def spmm_rmat_leg(scale, hcols, reps=10, with_shard=True):
         """Standalone SpMM (lt_spmm_csr_f32) on an R-MAT graph whose S exceeds every cache: the 'SpMM HBM GB/s' half of
         the metric, at BASELINE configs[4] size by default.  Kernel time from HIP events on the launch stream."""
-        t0 = time.perf_counter()
-        big = graph.first_order_gcn(synth.rmat_graph(scale, synth.rmat_draws(scale), seed=42))
-        gb = graph.HipGraph(big)
-        host_s = time.perf_counter() - t0
+        big, gb, host_s = rmat_problem(scale)
         sb = torch.randn((big.shape[0], hcols), device=dev)
         for _ in range(2):
             engine.spmm(gb, sb)
@@ -367,7 +391,7 @@ def main():
         communicator's stream while step k+1 computes (steps are independent; every step's matrix is
         complete before the closing barrier + synchronize)."""
         bs = bs or base
-        if world > 1:
+        if multi:
             # a fresh padded slab per step: the collective of step k may still be reading its slab
             # while step k+1 computes
             slab = torch.empty((per, a.n_test), dtype=torch.float32, device=dev)
@@ -403,9 +427,16 @@ def main():
 
     def barrier():
         drain()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(el):
+        if not multi:
+            return el
+        t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     def timed(mode, steps, warmup, profile_mask=0, blocks=1, bs=None):
         """`blocks` timed blocks of exactly `steps` steps (barrier + synchronize on both sides, MAX over ranks);
@@ -421,12 +452,7 @@ def main():
             for _ in range(steps):
                 full = step(mode, bs)
             barrier()
-            el = time.perf_counter() - t0
-            if world > 1:
-                t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                el = float(t.item())
-            out.append(el)
+            out.append(max_over_ranks(time.perf_counter() - t0))
         return out, full
 
     if a.pmc_child:
@@ -630,6 +656,98 @@ def main():
         if a.spmm_scale:
             extras["roofline_spmm"] = spmm_rmat_leg(a.spmm_scale, h)
 
+    # ---------------- strong-scaling workloads: the configs where sharding matters, at THIS rank count ----------------
+    # One driver command per N then yields the 1/2/4/8 curve of all three: the n_test = 500 build of
+    # `value` is a 65 us job whose pass over X every rank repeats (it cannot scale), n_test = 2000 and the R-MAT shard can.
+    def collective_us(slab_rows, n_cols, reps=20):
+        """The all-gather of row slabs ALONE, at the shape one step sends: HIP events on the compute stream around the
+        blocking all_gather_into_tensor (the stream waits for the communicator's), median."""
+        if not multi:
+            return None
+        slab = torch.zeros((slab_rows, n_cols), dtype=torch.float32, device=dev)
+        ts = []
+        for i in range(reps + 3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            lt_dist.all_gather_rows(slab, world * slab_rows)
+            e1.record()
+            torch.cuda.synchronize()
+            if i >= 3:
+                ts.append(e0.elapsed_time(e1) * 1e3)
+        return round(float(np.median(ts)), 2)
+
+    def sharded_build(bs, nodes_np, mode, steps, blocks=3, warm=2):
+        """(seconds per step, probes per rank): this rank's ceil(n / W) probes x all n observed nodes incl. the loop-invariant
+        baseline of the mode, then the single all-gather -- barrier + synchronize around every block, MAX over ranks."""
+        n_t = len(nodes_np)
+        q0, q1, per_ = lt_dist.shard_bounds(n_t, rank, world)
+        pr = torch.from_numpy(nodes_np[q0:q1].astype(np.int32)).to(dev)
+        ob = torch.from_numpy(nodes_np.astype(np.int32)).to(dev)
+
+        def one():
+            slab = torch.empty((per_, n_t), dtype=torch.float32, device=dev)
+            if q1 - q0 < per_:
+                slab[q1 - q0:].zero_()
+            bs.refresh(mode)
+            bs.influence_rows(pr, ob, delta, mode, out=slab[: q1 - q0])
+            full_, work = lt_dist.all_gather_rows(slab, n_t, async_op=True)
+            if work is not None:
+                pending.append(work)
+            return full_
+        for _ in range(warm):
+            one()
+        ts = []
+        for _ in range(blocks):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one()
+            barrier()
+            ts.append(max_over_ranks(time.perf_counter() - t0) / steps)
+        return float(np.median(ts)), per_
+
+    scaling = None
+    if not a.no_scaling_workloads and (multi or not a.no_extras):
+        scaling = {"note": "strong scaling: the same problem at every rank count, probes sharded contiguously over the ranks, one all-gather "
+                           "of row slabs per step; ms_per_step = loop-invariant baseline of the mode + this rank's probes + the all-gather, "
+                           "MAX over ranks, median block; collective_us = that all-gather alone (HIP events)",
+                   "mode": a.mode, "n_gpus": world}
+        scaling["configs[1]"] = {"workload": f"n_test={a.n_test} (the `value` workload)", "ms_per_step": round(ms_per_step, 4),
+                                 "pairs_per_s": round(value, 1), "probes_per_rank": per, "collective_us": collective_us(per, a.n_test)}
+        if n >= 2000:
+            np.random.seed(42)
+            nodes3 = np.random.choice(np.arange(n), 2000, replace=False)
+            t3, per3 = sharded_build(base, nodes3, a.mode, 10)
+            scaling["configs[2]"] = {"workload": "n_test=2000 on the same graph (BASELINE configs[2])", "ms_per_step": round(t3 * 1e3, 4),
+                                     "pairs_per_s": round(2000 ** 2 / t3, 1), "probes_per_rank": per3, "collective_us": collective_us(per3, 2000)}
+            base.refresh()
+        if a.spmm_scale:
+            big, gb, _ = rmat_problem(a.spmm_scale)
+            bb = rmat_baseline(gb, big.shape[0], h)
+            if a.mode == "delta":
+                bb.enable_fp64()
+            lt_dist.choose_baseline_sharding(bb, mode=a.mode)
+            nodes5 = np.random.RandomState(42).choice(big.shape[0], 4096, replace=False)
+            t5, per5 = sharded_build(bb, nodes5, a.mode, 3, blocks=3, warm=1)
+            scaling["configs[4]"] = {"workload": f"R-MAT scale {a.spmm_scale} (N={big.shape[0]}, nnz={big.nnz}) F=256 H={h} n_test=4096 (BASELINE configs[4])",
+                                     "ms_per_step": round(t5 * 1e3, 3), "pairs_per_s": round(4096 ** 2 / t5, 1), "probes_per_rank": per5,
+                                     "collective_us": collective_us(per5, 4096)}
+            del bb
+        rmat_cache.clear()
+
+    def rccl_info():
+        """Which collective library this process has mapped (/proc/self/maps): the evidence that RCCL itself executed."""
+        libs = set()
+        try:
+            for line in open("/proc/self/maps"):
+                nm = line.rsplit("/", 1)[-1].strip()
+                if "rccl" in nm or "nccl" in nm:
+                    libs.add(nm)
+        except OSError:
+            pass
+        return {"backend": (dist.get_backend() if multi else None), "forced_at_world_size_1": bool(force and world == 1),
+                "librccl_mapped": any("rccl" in x for x in libs), "libs": sorted(libs)}
+
     # ---------------- CPU reference path (oracle), bounded sample, rank 0 / N=1 only -----------
     cpu = None
     parity = None
@@ -687,13 +805,13 @@ def main():
         cpu["max_abs_diff_vs_gpu_rows"] = float(np.abs(cpu32 - full[:done].cpu().numpy().astype(np.float64)).max())
 
     if rank == 0:
-        shard_note = ("single GPU" if world == 1 else
+        shard_note = ("single GPU" if not multi else
                       (("fp64" if a.mode == "delta" else "fp32") + " X*W1 sharded over ranks + all-gather" if baseline_sharded else
                        ("feature-difference fp64 product on every rank (one pass over X)" if (a.mode == "delta" and fp64_route == 1)
                         else "replicated on every rank")))
         hp = (h + 3) // 4 * 4
         coll = 0
-        if world > 1:
+        if multi:
             coll = world * per * a.n_test * 4
             if baseline_sharded:
                 coll += world * lt_dist.shard_bounds(n, rank, world)[2] * hp * (8 if a.mode == "delta" else 4)
@@ -713,7 +831,7 @@ def main():
                                               2: "aggregate-first on the rows the probes reach (k_rows_tiled_xf64 + k_gemm_f64_rows)",
                                               0: "f64 matrix cores (k_gemm_f64acc_128)", -1: "not used"}[fp64_route],
                        "collective_bytes_per_step": coll,
-                       "step": "baseline forward of the mode + all probes + norms" + (" + all-gather" if world > 1 else "")},
+                       "step": "baseline forward of the mode + all probes + norms" + (" + all-gather" if multi else "")},
             "timing": {"blocks": len(block_s), "steps_per_block": a.steps, "reported": "median block",
                        "block_ms": [round(b * 1e3, 3) for b in block_s],
                        "event_pair_overhead_us": event_pair_us,
@@ -727,11 +845,14 @@ def main():
             out["parity_note"] = ("this mode is the reference's fp32 finite difference: its raw AUC can move by 1 / n_edges when a low-score "
                                   "edge quantises to 0 (DESIGN.md section 3); `delta` is the mode that meets north_star's 1e-4")
         out.update(extras)
+        if scaling is not None:
+            out["scaling_workloads"] = scaling
+        out["collectives"] = rccl_info()
         if os.environ.get("LT_BENCH_DUMP"):          # test hook: the matrix of the last timed step
             np.save(os.environ["LT_BENCH_DUMP"], full.cpu().numpy())
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and parity is not None and not parity["ok"]:

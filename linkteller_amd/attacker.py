@@ -171,11 +171,11 @@ class Attacker:
             self._baseline = engine.baseline_for(self.adj, self.features, *[p.to(dev) for p in src])
             self._baseline_key = key
             self._sharding_mode = None
-        refreshed = created and lt_dist.world()[1] == 1           # a new baseline computes everything on first use
+        refreshed = created and not lt_dist.collectives_on()      # a new baseline computes everything on first use
         if getattr(self, "_sharding_mode", None) != mode:
             lt_dist.choose_baseline_sharding(self._baseline, mode=mode)      # (several ranks: ends with a refresh for `mode`)
             self._sharding_mode = mode
-            refreshed = refreshed or lt_dist.world()[1] > 1
+            refreshed = refreshed or lt_dist.collectives_on()
         if not refreshed:
             self._baseline.refresh(mode)
         return self._baseline

@@ -481,7 +481,14 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
             __hip_atomic_store(slabs + (size_t)blockIdx.x * H + c, ((s_p[0][c] + s_p[1][c]) + s_p[2][c]) + s_p[3][c], __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         __shared__ unsigned s_last;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's stores have left
+        // Memory-order argument (MI355X_MICROARCH.md, "Valid forms", sc1 both sides, first table row):
+        //  (1) every byte of a slice is stored `sc1` (write-through, above) and loaded `sc1` (below): no L1 / L2 copy to go stale;
+        //  (2) each storing wave drains ITS stores (s_waitcnt vmcnt(0): they have reached memory, not just left the wave);
+        //  (3) the workgroup barrier puts every wave's drain in front of lane 0's ticket;
+        //  (4) the ticket is an agent-scope atomic whose RETURNED value names the last block, and that block's loads come after
+        //      the barrier its lane 0 joins once the add has returned.  A workgroup-scope fence here emits nothing (the ticket
+        //      could pass a slice still in flight); an agent release would write back the whole L2 under the rows' stream (+8 us).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(gate, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nslab - 1u ? 1u : 0u;
         __syncthreads();

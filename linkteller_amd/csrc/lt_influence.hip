@@ -938,7 +938,7 @@ __device__ __forceinline__ void stageB_long_block(
     const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
     const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
     float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words,
-    const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot, const int32_t *__restrict__ hub_obs) {
+    const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot, const int32_t *__restrict__ hub_obs, int hub_cap) {
     constexpr int CHUNK = CP <= 2 ? LT_SBL_CHUNK : (CP <= 4 ? LT_SBL_CHUNK / 2 : LT_SBL_CHUNK / 4);   // LDS: <= 16 KB
     constexpr int GROUPS = LT_BLOCK / LT_L2_LANES;
     // entries of the walk whose membership tests are in flight per lane: DELTA keeps nothing else per entry (no baseline
@@ -949,9 +949,11 @@ __device__ __forceinline__ void stageB_long_block(
     __shared__ float sT[DELTA ? 1 : CHUNK][CP];
     __shared__ int2 smem[(DELTA || !SHORT) ? 1 : GROUPS][(DELTA || !SHORT) ? 1 : LT_SBL_MC];   // SPARSE, light probes: (entry - e0, position in R_v)
     const int pblocks = (nb + GROUPS - 1) / GROUPS;
-    // the launch has blocks for min(n_obs, hub rows of the graph) observed hubs; hub_obs (k_item_bits) lists the ones there are
-    if (bid / pblocks >= hub_obs[0]) return;     // block-uniform exit
-    const int j = hub_obs[1 + bid / pblocks];
+    // the launch has blocks for hub_cap = min(n_obs, hub rows of the graph) observed hubs; hub_obs (k_item_bits) lists the
+    // positions there are -- MORE than hub_cap when observe_nodes repeats a hub (a star graph observed twice): a block then
+    // serves slot, slot + hub_cap, ... (block-uniform trips; usually one or none)
+    for (int slot = bid / pblocks; slot < hub_obs[0]; slot += hub_cap) {
+    const int j = hub_obs[1 + slot];
     const int u = observe[j];
     const int e0 = rowptr[u], e1 = rowptr[u + 1];
     const int d = e1 - e0;
@@ -1169,6 +1171,8 @@ __device__ __forceinline__ void stageB_long_block(
         }
     }
     if (live && q == 0) out[(long)b * ldo + j] = res;
+    __syncthreads();        // (the next slot restages sc / sv / sT)
+    }
 }
 
 // The observed hubs of SPARSE in a launch of their own: stageB_long_block's member lists take 48 KB of LDS per block, which
@@ -1185,7 +1189,8 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_hubs(
     float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words,
     const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot, const int32_t *__restrict__ hub_obs) {
     stageB_long_block<CP, DELTA, SHORT, WIDE>((int)blockIdx.x, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off, S2x,
-                                        observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot, hub_obs);
+                                        observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot, hub_obs,
+                                        (int)gridDim.x / ((nb + LT_BLOCK / LT_L2_LANES - 1) / (LT_BLOCK / LT_L2_LANES)));
 }
 
 // SPARSE / DELTA stage B: 8 lanes per (probe, observed node).
@@ -1208,7 +1213,8 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
     if constexpr (!DELTA) {
         if ((int)blockIdx.x < long_blocks) {
             stageB_long_block<CP, DELTA, false>((int)blockIdx.x, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off,
-                                                S2x, observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot, hub_obs);
+                                                S2x, observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot, hub_obs,
+                                                long_blocks / ((nb + LT_BLOCK / LT_L2_LANES - 1) / (LT_BLOCK / LT_L2_LANES)));
             return;
         }
     }

@@ -5,6 +5,8 @@ the path.  Works on CPU tensors with ``gloo`` too (that is how the N>1 path is t
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -13,6 +15,19 @@ def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def force_collectives() -> bool:
+    """``LT_FORCE_COLLECTIVES=1`` with an initialised process group: every collective of the path (the all-gather of row
+    slabs, the sharded refresh's all-gather of X W1, the policy's all-reduce) is issued even at world size 1.  A one-GPU box
+    then executes the very calls an 8-GPU run makes -- through RCCL when the backend is ``nccl`` -- instead of the
+    single-process shortcuts (tests/test_gpu_round4.py asserts librccl is mapped)."""
+    return os.environ.get("LT_FORCE_COLLECTIVES") == "1" and dist.is_available() and dist.is_initialized()
+
+
+def collectives_on() -> bool:
+    """True when the N > 1 code path is the one to run: several ranks, or the forcing hook above."""
+    return world()[1] > 1 or force_collectives()
 
 
 def shard_bounds(n_items: int, rank: int, world_size: int):
@@ -29,7 +44,7 @@ def all_gather_rows(local_rows: torch.Tensor, n_total: int, async_op: bool = Fal
     ``async_op=True`` returns ``(tensor, work)``: the collective runs on the communicator's stream and
     the caller's stream is not made to wait (``work.wait()`` before reading the tensor)."""
     rank, ws = world()
-    if ws == 1:
+    if not collectives_on():
         return (local_rows, None) if async_op else local_rows
     _, _, per = shard_bounds(n_total, rank, ws)
     n_obs = local_rows.shape[1]
@@ -73,7 +88,7 @@ def shard_baseline_policy() -> str:
 
 def choose_baseline_sharding(base, trials: int = 5, mode: str = "full") -> bool:
     use = _choose_baseline_sharding(base, trials, mode)
-    if world()[1] > 1:
+    if collectives_on():
         base.refresh(mode)          # whatever was decided: the products the mode reads are current on every rank
     return use
 
@@ -88,19 +103,34 @@ def _choose_baseline_sharding(base, trials, mode) -> bool:
     is on."""
     import time
     rank, ws = world()
+    multi = collectives_on()
     pol = shard_baseline_policy()
     is_delta = mode == "delta"
+    if not getattr(base, "supports_sharding", True):
+        # engine.WideBaseline (layers wider than one pass of the fused kernels): its product is a per-slice loop with no
+        # sharded refresh, and the timing loop below would call modes it may not serve -- replicated on every rank
+        return False
     shard = base.shard_refresh_fp64 if is_delta else base.shard_refresh
     other = base.shard_refresh if is_delta else base.shard_refresh_fp64
     other(False)
-    if is_delta and ws > 1:
+    if is_delta and multi:
         base.enable_fp64()
-        if base.fp64_route() in (1, 2):     # (same features and shapes on every rank -> same answer on every rank)
+        # The route depends on a word of mapped host memory that k_s1d_feature_rows sets asynchronously (rows denser than
+        # its probe saw): read it only once the stream has drained, and let every rank take the SAME branch (the smallest
+        # route any rank reports: 0, the matrix-core product, is always valid) -- ranks that disagree here would sit in
+        # different collectives below.
+        if base.x.is_cuda:
+            torch.cuda.current_stream(base.x.device).synchronize()
+        route = torch.tensor([base.fp64_route()], dtype=torch.int32)
+        if dist.get_backend() != "gloo":
+            route = route.to(base.x.device)
+        dist.all_reduce(route, op=dist.ReduceOp.MIN)
+        if int(route.item()) in (1, 2):
             # 1: the fp64 product is one pass over X; 2: the pre-activation is formed on the rows a rank's own probes reach
             # (aggregate-first, no S1d at all) -- nothing worth exchanging either way
             shard(False)
             return False
-    if ws == 1 or pol == "0":
+    if not multi or pol == "0":
         shard(False)
         return False
     if pol == "1":

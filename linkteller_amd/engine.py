@@ -166,7 +166,7 @@ class Baseline:
         of S1d) instead of recomputing it on every rank.  Bits are those of the replicated product."""
         from . import dist as lt_dist
         rank, world = lt_dist.world()
-        if not enable or world == 1:
+        if not enable or not lt_dist.collectives_on():
             if self._shard64 is not None:
                 _lib.check(_lib.lib().lt_baseline_attach_s1d(self._h, None, 0, _stream()), "lt_baseline_attach_s1d")
                 torch.cuda.current_stream().synchronize()
@@ -190,7 +190,7 @@ class Baseline:
         output) that the library reads in place.  Bits are those of the replicated product."""
         from . import dist as lt_dist
         rank, world = lt_dist.world()
-        if not enable or world == 1:
+        if not enable or not lt_dist.collectives_on():
             self._shard = None
             return self
         b, e, per = lt_dist.shard_bounds(self.n, rank, world)
@@ -256,6 +256,8 @@ class WideBaseline:
         _require_finite(features=self.x, W1=self.w1, b1=self.b1, W2=self.w2, b2=self.b2)
         self._s1 = None
         self._out = None
+
+    supports_sharding = False       # dist.choose_baseline_sharding: replicated on every rank, no timing loop
 
     def refresh(self, mode=None):
         self._s1 = self._out = None

@@ -64,14 +64,21 @@ def init_distributed():
     """One process per GPU (``torchrun --nproc-per-node N -m linkteller_amd.main ...``): pin this rank's device
     BEFORE anything touches the GPU (Worker moves its tensors with ``.cuda()``) and join the process group, so
     that ``Attacker.influence_matrix`` shards the probes (linkteller_amd/dist.py) and only rank 0 writes the
-    result file.  ``LT_DIST_BACKEND`` / ``LT_DIST_DEVICE`` are test hooks (gloo, all ranks on one device).
+    result file.  ``LT_DIST_BACKEND`` / ``LT_DIST_DEVICE`` are test hooks (gloo, all ranks on one device), and so is
+    ``LT_FORCE_COLLECTIVES=1`` (a group and every collective even at world size 1: RCCL on a one-GPU box).
     Returns True when a group was created here (the caller destroys it)."""
     import os
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1 or dist.is_initialized():
+    force = os.environ.get("LT_FORCE_COLLECTIVES") == "1"       # dist.force_collectives(): the N > 1 path at world size 1
+    if (world <= 1 and not force) or dist.is_initialized():
         return False
-    rank = int(os.environ["RANK"])
+    rank = int(os.environ.get("RANK", "0"))
+    if "MASTER_PORT" not in os.environ:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
     local = int(os.environ.get("LT_DIST_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     backend = os.environ.get("LT_DIST_BACKEND", "nccl")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

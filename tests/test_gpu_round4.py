@@ -1,0 +1,250 @@
+"""GPU tests added in round 4: the N > 1 path executed by RCCL itself on one GPU (world size 1, every collective forced),
+an observed hub repeated in observe_nodes, the last-arriver reduction of k_s1d_feature_rows under stress, a wide model on
+two ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(w, dev):
+    return [torch.from_numpy(w[k]).to(dev) for k in ("W1", "b1", "W2", "b2")]
+
+
+def _bench(args, env=None, timeout=1200):
+    e = dict(os.environ, PYTHONPATH=REPO, **(env or {}))
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("mode,extra", [("delta", {}), ("sparse", {"LT_SHARD_BASELINE": "1"}),
+                                        ("delta", {"LT_FEATURE_DELTA": "0", "LT_AGGREGATE_FIRST": "0", "LT_SHARD_BASELINE": "1"})])
+def test_bench_collectives_execute_under_rccl_at_world_size_1(gpu, tmp_path, mode, extra):
+    """LT_FORCE_COLLECTIVES=1: bench.py creates the ``nccl`` process group (device_id=) at world size 1 and issues every
+    collective of the N > 1 path -- the async all_gather_into_tensor of row slabs pipelined across steps, the sharded
+    refresh's all-gather of X W1 (fp32 for `sparse`, fp64 for `delta` on dense routing), the policy's all-reduce, the
+    timing all-reduce, barriers -- on device tensors, so RCCL itself runs them.  The process must have librccl mapped, the
+    line must carry the three strong-scaling workloads with an event-timed collective, and the matrix of the last step
+    must equal the plain one-process run bit for bit."""
+    common = ["--steps", "3", "--warmup", "1", "--blocks", "2", "--no-cpu-baseline", "--no-extras", "--no-pmc", "--mode", mode,
+              "--n-test", "120", "--spmm-scale", "14"]
+    plain = _bench(common, {"LT_BENCH_DUMP": str(tmp_path / "plain.npy"), **extra})
+    forced = _bench(common, {"LT_FORCE_COLLECTIVES": "1", "LT_BENCH_DUMP": str(tmp_path / "forced.npy"), **extra})
+    assert plain["collectives"]["backend"] is None and not plain["collectives"]["forced_at_world_size_1"]
+    col = forced["collectives"]
+    assert col["backend"] == "nccl" and col["forced_at_world_size_1"] and col["librccl_mapped"], col
+    assert forced["n_gpus"] == 1 and forced["config"]["collective_bytes_per_step"] >= 120 * 120 * 4
+    if extra.get("LT_SHARD_BASELINE") == "1":
+        assert "sharded" in forced["config"]["baseline_XW1"], forced["config"]
+    sw = forced["scaling_workloads"]
+    for key, n_t in (("configs[1]", 120), ("configs[2]", 2000), ("configs[4]", 4096)):
+        assert sw[key]["probes_per_rank"] == n_t and sw[key]["ms_per_step"] > 0 and sw[key]["collective_us"] > 0, sw[key]
+    assert "scaling_workloads" not in plain           # (--no-extras at one rank: nothing to shard, the leg is skipped)
+    a, b = np.load(tmp_path / "plain.npy"), np.load(tmp_path / "forced.npy")
+    assert a.shape == (120, 120) and np.array_equal(a, b)
+
+
+def test_attacker_through_rccl_at_world_size_1(gpu, tmp_path):
+    """The product's own N > 1 path (main.init_distributed -> Attacker.influence_matrix -> dist.all_gather_rows, and the
+    sharding policy's collectives) under RCCL at world size 1, in a child process: same matrix as without a group."""
+    code = r'''
+import os, sys, types, argparse
+import numpy as np, torch
+sys.path.insert(0, os.environ["LT_REPO"])
+from linkteller_amd import graph, synth, main as lt_main, dist as lt_dist
+from linkteller_amd.attacker import Attacker
+from linkteller_amd.gcn import GCN
+dev = torch.device("cuda:0")
+n, f, h = 700, 300, 64
+adj = synth.powerlaw_graph(n, 3500, seed=3)
+x = torch.from_numpy(synth.gaussian_features(n, f, seed=4)).to(dev)
+a_hat = graph.first_order_gcn(adj)
+adj_t = graph.sparse_mx_to_torch_sparse_tensor(a_hat).to(dev)
+w = synth.gcn_weights(f, h, 2, seed=5)
+model = GCN(f, h, 2, 0.5)
+model.load_state_dict({"gc1.weight": torch.from_numpy(w["W1"]), "gc1.bias": torch.from_numpy(w["b1"]),
+                       "gc2.weight": torch.from_numpy(w["W2"]), "gc2.bias": torch.from_numpy(w["b2"])})
+model.to(dev).eval()
+wk = types.SimpleNamespace(features_2=x, adj_2=adj_t, adj_ori=adj.tocsr(), n_nodes=n)
+def run():
+    out = {}
+    for mode in ("delta", "sparse"):
+        args = argparse.Namespace(dataset="twitch/ES/RU", sample_type="unbalanced", n_test=90, sample_seed=42, influence=1e-4,
+                                  mode="vanilla-clean", attack_mode="efficient", influence_mode=mode)
+        atk = Attacker(args, model, wk)
+        atk.prepare_test_data()
+        out[mode] = atk.influence_matrix()
+    return out
+plain = run()
+os.environ["LT_FORCE_COLLECTIVES"] = "1"
+os.environ["LT_SHARD_BASELINE"] = "1"
+assert lt_main.init_distributed() is True
+assert lt_dist.force_collectives() and lt_dist.collectives_on() and lt_dist.world() == (0, 1)
+forced = run()
+import torch.distributed as dist
+assert dist.get_backend() == "nccl"
+dist.barrier(); dist.destroy_process_group()
+maps = open("/proc/self/maps").read()
+assert "librccl" in maps, "RCCL not mapped"
+for m in plain:
+    assert plain[m].shape == (90, 90) and np.array_equal(plain[m], forced[m]), m
+print("OK")
+'''
+    e = dict(os.environ, LT_REPO=REPO, PYTHONPATH=REPO)
+    for k in ("LT_FORCE_COLLECTIVES", "RANK", "WORLD_SIZE", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("n_leaves,repeat", [(400, 2), (400, 5), (150, 3)])
+def test_observed_hub_repeated_in_observe_nodes(gpu, n_leaves, repeat):
+    """observe_nodes may repeat a node (the reference indexes grad[test_nodes[j]], attacker.py:229).  A star graph has ONE hub
+    row (> LT_ROW_SEG entries), so stage B launches hub blocks for min(n_obs, 1) observed hub -- and the hub observed
+    `repeat` times fills `repeat` slots of hub_obs: every one of those columns must be written (they were left as
+    torch.empty garbage before the blocks learnt to serve slot + k * hub_cap), equal to each other and to the oracle."""
+    from test_gpu_parity import _oracle_matrix
+    from linkteller_amd import engine, graph, synth
+    n = n_leaves + 1
+    rows = np.concatenate([np.zeros(n_leaves, dtype=np.int64), np.arange(1, n)])
+    cols = np.concatenate([np.arange(1, n), np.zeros(n_leaves, dtype=np.int64)])
+    adj = sp.csr_matrix((np.ones(2 * n_leaves, dtype=np.float32), (rows, cols)), shape=(n, n))
+    a_hat = graph.first_order_gcn(adj)
+    x = synth.twitch_like_features(n, 64, seed=3, density=0.05)
+    w = synth.gcn_weights(64, 32, 2, seed=4)
+    base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *_params(w, gpu))
+    rng = np.random.RandomState(1)
+    leaves = rng.choice(np.arange(1, n), 20, replace=False)
+    observe = np.concatenate([[0], leaves[:7], [0] * (repeat - 1), leaves[7:12]])
+    probes = np.concatenate([[0], leaves[:10], leaves[15:]])
+    ref64 = _oracle_matrix(a_hat, x, w, probes, observe, 1e-4, torch.float64)
+    e32 = np.abs(_oracle_matrix(a_hat, x, w, probes, observe, 1e-4, torch.float32) - ref64).max()
+    hub_cols = np.flatnonzero(observe == 0)
+    assert len(hub_cols) == repeat
+    for mode in ("delta", "sparse", "full"):
+        # poison the output first: an unwritten column keeps the poison
+        out = torch.full((len(probes), len(observe)), float("nan"), dtype=torch.float32, device=gpu)
+        got = base.influence_rows(probes, observe, 1e-4, mode, out=out).cpu().numpy().astype(np.float64)
+        assert np.isfinite(got).all(), (mode, np.argwhere(~np.isfinite(got))[:5])
+        for j in hub_cols[1:]:
+            assert np.array_equal(got[:, j], got[:, hub_cols[0]]), (mode, j)
+        tol = 1e-5 * ref64.max() if mode == "delta" else max(2.0 * e32, 2e-3 * ref64.max())
+        assert np.abs(got - ref64).max() <= tol, (mode, np.abs(got - ref64).max())
+    assert np.array_equal(base.influence_rows(probes, observe, 1e-4, "sparse").cpu().numpy(),
+                          base.influence_rows(probes, observe, 1e-4, "full").cpu().numpy())
+
+
+def test_last_arriver_reduction_under_stress(gpu):
+    """k_s1d_feature_rows' first blocks form the K slices of cref = m W1 and the block that draws the last ticket adds them
+    (lt_fp64.hip: sc1 stores -> per-wave s_waitcnt vmcnt(0) -> barrier -> agent-scope ticket -> sc1 loads).  A slice that
+    the last block reads before it has landed would be the PREVIOUS refresh's -- so W1 alternates between two weight sets
+    from refresh to refresh (a stale slice then belongs to the other set and moves every score), a side stream keeps the
+    memory system busy with copies of uneven size, and 20 000 refreshes must each reproduce the bits of their weight set."""
+    from linkteller_amd import _lib, engine, graph, synth
+    n, f, h = 1200, 3170, 256            # twitch-shaped rows: F = 3170 -> 50 slab blocks in front of the row blocks
+    a_hat = graph.first_order_gcn(synth.powerlaw_graph(n, 6000, seed=2))
+    x = torch.from_numpy(synth.twitch_like_features(n, f, seed=4, density=0.006)).to(gpu)
+    wa, wb = synth.gcn_weights(f, h, 2, seed=5), synth.gcn_weights(f, h, 2, seed=6)
+    W = [torch.from_numpy(wa["W1"]).to(gpu), torch.from_numpy(wb["W1"]).to(gpu)]
+    p = _params(wa, gpu)
+    base = engine.Baseline(graph.HipGraph(a_hat), x, *p).enable_fp64()
+    assert base.fp64_route() == 1
+    rng = np.random.RandomState(0)
+    probes = torch.from_numpy(rng.choice(n, 6, replace=False).astype(np.int32)).to(gpu)
+    observe = torch.from_numpy(rng.choice(n, 64, replace=False).astype(np.int32)).to(gpu)
+
+    def rows():
+        base.refresh("delta")
+        return base.influence_rows(probes, observe, 1e-4, "delta")
+    want = []
+    for k in (0, 1):                      # the expected bits of each weight set, formed on a quiet device ...
+        p[0].copy_(W[k])
+        torch.cuda.synchronize()
+        r = rows().clone()
+        torch.cuda.synchronize()
+        # ... and cross-checked against the route without the in-launch reduction (cref by a launch of its own)
+        _lib.set_tuning("defer_cref", 0)
+        try:
+            early = rows().clone()
+        finally:
+            _lib.set_tuning("defer_cref", None)
+        assert float((early - r).abs().max()) <= 1e-6 * float(r.max())
+        want.append(r)
+    assert float((want[0] - want[1]).abs().max()) > 1e-3 * float(want[0].max())      # the two sets are told apart
+    side = torch.cuda.Stream()
+    junk, junk2 = (torch.empty(64 << 20, dtype=torch.uint8, device=gpu) for _ in range(2))
+    bad = torch.zeros((), dtype=torch.int64, device=gpu)
+    iters = 20000
+    for it in range(iters):
+        k = it & 1
+        if it % 7 == 0:                   # uneven background traffic: copies of varying size on another stream
+            with torch.cuda.stream(side):
+                sz = (1 + (it * 2654435761) % 63) << 20
+                junk2[:sz].copy_(junk[:sz])
+        p[0].copy_(W[k])
+        bad += (rows() != want[k]).any()
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0, f"{int(bad.item())} of {iters} refreshes read a stale slice of cref"
+
+
+def _wide_rank(rank, ws, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    import argparse
+    import types
+    from linkteller_amd import graph, synth
+    from linkteller_amd.attacker import Attacker
+    from linkteller_amd.gcn import GCN
+    dev = torch.device("cuda:0")
+    n, f, h, c = 300, 80, 320, 12          # hidden > 256 and > 8 classes: outside one pass of the fused kernels
+    adj = synth.powerlaw_graph(n, 1400, seed=3)
+    x = torch.from_numpy(synth.gaussian_features(n, f, seed=4)).to(dev)
+    adj_t = graph.sparse_mx_to_torch_sparse_tensor(graph.first_order_gcn(adj)).to(dev)
+    w = synth.gcn_weights(f, h, c, seed=5)
+    model = GCN(f, h, c, 0.5)
+    model.load_state_dict({"gc1.weight": torch.from_numpy(w["W1"]), "gc1.bias": torch.from_numpy(w["b1"]),
+                           "gc2.weight": torch.from_numpy(w["W2"]), "gc2.bias": torch.from_numpy(w["b2"])})
+    model.to(dev).eval()
+    wk = types.SimpleNamespace(features_2=x, adj_2=adj_t, adj_ori=adj.tocsr(), n_nodes=n)
+    args = argparse.Namespace(dataset="twitch/ES/RU", sample_type="unbalanced", n_test=24, sample_seed=42, influence=1e-4,
+                              mode="vanilla-clean", attack_mode="efficient")          # default mode (delta), default policy (auto)
+    atk = Attacker(args, model, wk)
+    atk.prepare_test_data()
+    m = atk.influence_matrix()
+    q.put((rank, m))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_wide_model_on_two_ranks_default_mode(gpu):
+    """a model wider than the fused kernels under the defaults (mode `delta`, LT_SHARD_BASELINE=auto) on two
+    ranks used to die in the sharding policy's timing loop.  Two ranks on one device (gloo hook): both finish, with the
+    same matrix as one process."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_wide_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0].shape == (24, 24) and np.array_equal(res[0], res[1]) and np.isfinite(res[0]).all() and res[0].max() > 0
