@@ -83,6 +83,13 @@ def stamped_traffic(kernel_key):
         return None
 
 
+def flush_c_stdio():
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:      # noqa: BLE001
+        pass
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -258,6 +265,11 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # RCCL prints a version banner through C stdio when its communicator comes up; with stdout redirected that sits in
+        # a buffer until the process exits -- i.e. BEHIND the JSON line.  Bring the communicator up now and flush it out, on
+        # every rank, so that the line rank 0 prints at the end is the last thing on stdout.
+        dist.barrier()
+        flush_c_stdio()
 
     from linkteller_amd import _lib, engine, graph, synth
     from linkteller_amd import dist as lt_dist
@@ -850,11 +862,13 @@ def main():
         out["collectives"] = rccl_info()
         if os.environ.get("LT_BENCH_DUMP"):          # test hook: the matrix of the last timed step
             np.save(os.environ["LT_BENCH_DUMP"], full.cpu().numpy())
-        print(json.dumps(out))
-        sys.stdout.flush()
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+        flush_c_stdio()
+    if rank == 0:
+        print(json.dumps(out))
+        sys.stdout.flush()
     if rank == 0 and parity is not None and not parity["ok"]:
         sys.exit(3)
 

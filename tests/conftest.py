@@ -47,16 +47,17 @@ def gpu():
     return torch.device("cuda:0")
 
 
-# ---- recorded fp32-noise gates -----------------------------------------------------------------------------------
-# `full` / `sparse` evaluate the reference's fp32 finite difference (f(X + d) - f(X)) / 1e-4 itself, so their distance
-# to the fp64 evaluation is rounding noise of the reference's own class -- not a quantity a tolerance can be derived
-# for.  The kernels are deterministic (fixed-order chains, no atomics), so every test case's measured ratio
-# |ours - ref64| / |ref32 - ref64| (and raw AUC / AP deviations) is a constant of the source tree: it is RECORDED in
-# tests/golden/fp32_noise_ratios.json by a GPU run with LT_RECORD_RATIOS=1 (written to gpurun_out/, copied into
-# tests/golden/ by hand) and every later run asserts `measured <= recorded * 1.10` -- plus a hard ceiling no recorded
-# value may exceed.  A missing key fails: new cases must be recorded.
+# ---- fp32-noise gates ------------------------------------------------------------------------------------------------
+# `full` / `sparse` evaluate the reference's fp32 finite difference (f(X + d) - f(X)) / 1e-4 itself, so their distance to the
+# fp64 evaluation is rounding noise of the reference's own class.  The HARD gate is principled: our error, in units of the
+# reference's own fp32 error for the same case, stays below RATIO_CEILING = 2 (two draws from one noise class; BASELINE.md
+# section 3's `err(build) <= err(reference fp32)` itself is asserted on WHOLE matrices of the BASELINE configs, where the
+# maxima are over 1e5 entries and the ratio is stable: tests/test_gpu_round4.py, tests/golden/fp32_whole_matrix.npz).
+# The measured ratios are also kept in tests/golden/fp32_noise_ratios.json (a GPU run with LT_RECORD_RATIOS=1 writes
+# gpurun_out/fp32_noise_ratios.json) -- INFORMATIONAL since round 4: a value that moved by more than 10 % against the record
+# is reported as a warning (a toolchain bump or a legitimate reorder moves them), never a failure.
 RATIO_FILE = os.path.join(GOLDEN, "fp32_noise_ratios.json")
-RATIO_CEILING = 2.5     # sanity cap on any recorded value (measured over all cases: 0.33 .. 2.06; whole-matrix fixtures <= 1.0)
+RATIO_CEILING = 2.0
 _recorded = {}
 
 
@@ -70,16 +71,17 @@ def _ratio_table():
 
 
 def noise_gate(key, measured, ceiling=RATIO_CEILING):
-    """measured = our error expressed in units of the reference's own fp32 error for the same case."""
+    """measured = our error expressed in units of the reference's own fp32 error for the same case (or, with an explicit
+    ceiling, any quantity with a bound of its own)."""
+    import warnings
     measured = float(measured)
-    assert ceiling is None or measured <= ceiling, f"{key}: {measured:.3f} x the reference's own fp32 error (ceiling {ceiling})"
+    assert ceiling is None or measured <= ceiling, f"{key}: {measured:.4f} exceeds its bound {ceiling}"
     if os.environ.get("LT_RECORD_RATIOS"):
         _recorded[key] = round(measured, 6)
         return
-    table = _ratio_table()
-    assert key in table, f"{key}: no recorded value in {RATIO_FILE} (run the GPU suite once with LT_RECORD_RATIOS=1)"
-    # (+ 1e-5: the table is rounded to 6 decimals, and two cases compare two of OUR outputs, ratios of a few 1e-6)
-    assert measured <= table[key] * 1.10 + 1e-5, f"{key}: measured {measured:.6f}, recorded {table[key]:.6f} (+10 % allowed)"
+    rec = _ratio_table().get(key)
+    if rec is not None and measured > rec * 1.10 + 1e-5:
+        warnings.warn(f"{key}: measured {measured:.6f}, recorded {rec:.6f} (informational: inside its bound {ceiling})")
 
 
 def pytest_sessionfinish(session, exitstatus):

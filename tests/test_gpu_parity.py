@@ -96,8 +96,10 @@ def test_influence_matrix(influence_golden, gpu, key):
     def outside(v, a, b):
         lo, hi = min(a, b) - 1e-4, max(a, b) + 1e-4
         return max(0.0, lo - v, v - hi)
-    noise_gate(f"influence.{key}.full_raw_auc_outside_band", outside(got["full"]["auc"], auc32, auc64), ceiling=None)
-    noise_gate(f"influence.{key}.full_raw_ap_outside_band", outside(got["full"]["ap"], ap32, ap64), ceiling=None)
+    # bound: ONE low-score edge quantising to 0 (here or in the reference's fp32 run) moves AUC by at most 1 / n_edges
+    one_edge = 1.0 / max(len(ex), 1) + 1e-4
+    noise_gate(f"influence.{key}.full_raw_auc_outside_band", outside(got["full"]["auc"], auc32, auc64), ceiling=one_edge)
+    noise_gate(f"influence.{key}.full_raw_ap_outside_band", outside(got["full"]["ap"], ap32, ap64), ceiling=one_edge)
     # full / sparse are the fp32 finite difference (f(X + d) - f(X)) / 1e-4 itself: scores are quantised to
     # ulp(logit) / 1e-4 ~ 1e-2, so a pair whose true score is below that can come out exactly 0 -- in the reference's
     # fp32 run as well as here (counted below).  ONE low-score edge falling to zero moves AUC by up to 1 / n_edges
@@ -496,8 +498,9 @@ def test_full_size_twitch(gpu, workload, n_test, served):
     ref32 = _oracle_matrix(a_hat, x, w, nodes[sample], nodes, 1e-4, torch.float32)
     e32 = np.abs(ref32 - ref64).max()
     assert np.abs(res["delta"][sample] - ref64).max() <= 1e-5 * ref64.max()
-    # (max over a 12-row sample on both sides: an extreme-value ratio; recorded per case like every fp32-noise gate)
-    noise_gate(f"fullsize.{workload}.{n_test}.{served}.full", np.abs(res["full"][sample] - ref64).max() / e32)
+    # (max over a 12-row sample on both sides is an extreme-value ratio: only the noise-class bound here; BASELINE.md's
+    # err(build) <= err(reference fp32) is asserted over the WHOLE matrix in tests/test_gpu_round4.py)
+    noise_gate(f"fullsize.{workload}.{n_test}.{served}.full", np.abs(res["full"][sample] - ref64).max() / e32, ceiling=2.5)
     assert np.all(res["full"][sample][ref64 == 0] == 0)
 
 

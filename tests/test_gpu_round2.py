@@ -138,7 +138,8 @@ def test_get_gradient_eps_mat_matches_oracle(gpu, influence_golden):
         noise_gate(f"eps_mat.pl600.v{v}.logit_diff", np.abs(got - ref64).max() / e32)
         assert np.all(got[np.all(ref64 == 0, axis=1)] == 0)          # untouched rows: exactly zero
         rows = atk.baseline().influence_rows([v], np.arange(a.shape[0]), args["influence"], "full").cpu().numpy()[0]
-        noise_gate(f"eps_mat.pl600.v{v}.norm_vs_rows", np.abs(np.linalg.norm(got, axis=1) - rows).max() / e32)
+        # (two of OUR outputs: the row norms of the [N, C] difference against the batched primitive's row -- fp32 rounding of a norm)
+        noise_gate(f"eps_mat.pl600.v{v}.norm_vs_rows", np.abs(np.linalg.norm(got, axis=1) - rows).max() / e32, ceiling=1e-4)
 
 
 def test_integration_md_stub_runs_as_written(gpu, influence_golden, tmp_path):

@@ -507,7 +507,7 @@ def test_full_mode_on_a_hub_of_many_segments(gpu, long_par, p):
             ref[dt] = gm[torch.as_tensor(obs.astype(np.int64))].norm(dim=1).double().numpy()
         e32 = max(np.abs(ref[torch.float32] - ref[torch.float64]).max(), 1e-9)
         # a 9 500-term fp32 sum in two different orders (128-entry segments here, sequential in torch.spmm): same noise
-        # level, not the same draw -- 4x instead of the 2.5x ceiling of the recorded gates
+        # level, not the same draw -- 4x instead of the 2x noise-class bound of conftest.noise_gate
         assert np.abs(f[i] - ref[torch.float64]).max() <= 4.0 * e32, i
 
 

@@ -106,7 +106,8 @@ print("OK")
     for k in ("LT_FORCE_COLLECTIVES", "RANK", "WORLD_SIZE", "MASTER_PORT"):
         e.pop(k, None)
     r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
-    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-3000:] + r.stderr[-3000:]
+    # (RCCL's version banner leaves C stdio at exit, behind the script's last print)
+    assert r.returncode == 0 and "\nOK\n" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
 @pytest.mark.parametrize("n_leaves,repeat", [(400, 2), (400, 5), (150, 3)])
@@ -248,3 +249,40 @@ def test_wide_model_on_two_ranks_default_mode(gpu):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert res[0].shape == (24, 24) and np.array_equal(res[0], res[1]) and np.isfinite(res[0]).all() and res[0].max() > 0
+
+
+@pytest.mark.parametrize("key", ["twitch-ES.64.clean", "twitch-RU.500.clean", "twitch-RU.500.lapgraph", "twitch-RU.2000.clean"])
+def test_fp32_modes_meet_the_reference_noise_over_the_whole_matrix(gpu, key):
+    """``err(build) <= err(reference fp32)``, both against the fp64 evaluation -- on the WHOLE matrix of
+    BASELINE configs[0], [1], [3] and on a 200-row sample of configs[2] (round 3 asserted it on 12-row samples, an
+    extreme-value ratio that read 1.1 .. 2.06).  The right-hand side is the REFERENCE's own fp32 run (attacker.py:100-108 on
+    torch's CPU kernels, one thread), generated in the build container by tests/golden/generate_fp32_noise.py and committed
+    (fp32_whole_matrix.npz: the fp32 scores of every probed row); the fp64 side is oracle.RestrictedOracle, live.
+    Gates: max |full - ref64| <= 1.10 x max |ref32 - ref64| and the same for the root mean square over the 2-hop support."""
+    from conftest import load_golden, noise_gate
+    from linkteller_amd import dp, engine, graph, synth
+    from oracle import linkteller_oracle as O
+    g = load_golden("fp32_whole_matrix.npz")
+    workload, n_test, served = key.rsplit(".", 2)
+    adj, x, w = synth.twitch_like_problem(workload, hidden=256, n_classes=2, seed=0)
+    if served == "lapgraph":
+        adj = dp.perturb_adj(adj, "continuous", 5.0, noise_seed=42)
+    a_hat = graph.first_order_gcn(adj)
+    nodes, rows, ref32 = g[f"{key}.nodes"], g[f"{key}.rows"], g[f"{key}.ref32"].astype(np.float64)
+    assert len(nodes) == int(n_test) and np.array_equal(nodes, np.sort(np.random.RandomState(7).choice(adj.shape[0], int(n_test), replace=False)))
+    ref64 = O.RestrictedOracle(x, a_hat, w).rows(nodes[rows], nodes, 1e-4)
+    support = ref64 != 0
+    e32_max, e32_rms = np.abs(ref32 - ref64).max(), np.sqrt(((ref32 - ref64)[support] ** 2).mean())
+    # the committed statistics are those of the committed rows against THIS fp64 evaluation (pins the live oracle to the generator's)
+    assert abs(e32_max - float(g[f"{key}.e32_max"])) <= 1e-9 and abs(e32_rms - float(g[f"{key}.e32_rms"])) <= 1e-9
+    base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *_params(w, gpu))
+    res = {m: base.influence_rows(nodes[rows], nodes, 1e-4, m).cpu().numpy().astype(np.float64) for m in ("full", "sparse", "delta")}
+    assert np.array_equal(res["full"], res["sparse"])
+    assert np.all(res["full"][~support] == 0) and np.all(res["delta"][~support] == 0)
+    assert np.abs(res["delta"] - ref64).max() <= 1e-5 * ref64.max()
+    d = res["full"] - ref64
+    r_max, r_rms = np.abs(d).max() / e32_max, np.sqrt((d[support] ** 2).mean()) / e32_rms
+    print(f"{key}: rows {len(rows)} x {n_test}; reference fp32 error max {e32_max:.4e} rms {e32_rms:.4e}; "
+          f"full: max ratio {r_max:.4f}, rms ratio {r_rms:.4f}; delta error {np.abs(res['delta'] - ref64).max():.2e}")
+    noise_gate(f"whole.{key}.full_rms", r_rms, ceiling=1.10)
+    noise_gate(f"whole.{key}.full_max", r_max, ceiling=1.10)

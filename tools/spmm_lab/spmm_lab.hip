@@ -180,6 +180,69 @@ __global__ __launch_bounds__(256) void k_spmm_sliced(
     else *reinterpret_cast<f32x4 *>(d) = acc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// GATHER CEILING (round 4): the sliced kernel above with everything but its gathers removed -- the SAME work items in
+// the SAME order, the SAME column stream (col only: 4 B per entry against 4 * GL * 4 B gathered), the same
+// slice = f(XCD) placement and U gathers in flight per lane -- no val stream, no fmaf chain (the loaded words are
+// XOR-folded, one VALU op each, so that the loads stay live), no result rows (one word per item and slice, 1/64 of the
+// real stores).  What it measures is what the memory system delivers for this index stream at this hit distribution:
+// no row-gather SpMM that issues these gathers can run faster, whatever its arithmetic.
+// ------------------------------------------------------------------------------------------------
+template <int GL, int U>
+__global__ __launch_bounds__(256) void k_gather_ceiling(
+    int n_items, const int32_t *__restrict__ w_e0, const int32_t *__restrict__ w_cnt, const int32_t *__restrict__ col,
+    const float *__restrict__ S, int lds, int ncols, unsigned *__restrict__ sink, int ns) {
+    constexpr int GPW = 64 / GL;
+    constexpr int IPB = 4 * GPW;
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int j = lane & (GL - 1);
+    const int xcd = blockIdx.x & 7;
+    const int q = blockIdx.x >> 3;
+    const int xps = 8 / ns;
+    const int slice = xcd % ns;
+    const int chunk = q * xps + xcd / ns;
+    int it = chunk * IPB + wv * GPW + lane / GL;
+    if (GL == 64) it = __builtin_amdgcn_readfirstlane(it);
+    if (it >= n_items) return;
+    const int e0 = w_e0[it], cnt = w_cnt[it];
+    const int coff = slice * 4 * GL + 4 * j;
+    const bool active = coff < ncols;
+    const unsigned rowbytes = (unsigned)lds * 4u;
+    const unsigned loff = (unsigned)coff * 4u;
+    const char *Sb = reinterpret_cast<const char *>(S);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 x = {0u, 0u, 0u, 0u};
+    const int e1 = e0 + cnt;
+    int nxc = 0;
+    if (e0 + j < e1) nxc = __builtin_nontemporal_load(col + e0 + j);
+    for (int eb = e0; eb < e1; eb += GL) {
+        const int me = eb + j;
+        const int myc = nxc;
+        nxc = 0;
+        if (me + GL < e1) nxc = __builtin_nontemporal_load(col + me + GL);
+        const int left = e1 - eb;
+        static_for<GL / U>([&](auto kbt) {
+            constexpr int kb = decltype(kbt)::value * U;
+            if (kb < left) {
+                u32x4 s[U];
+                static_for<U>([&](auto ut) {
+                    constexpr int u = decltype(ut)::value;
+                    constexpr int k = kb + u;
+                    const int c = bcast_c<GL, k>(myc);
+                    s[u] = u32x4{0u, 0u, 0u, 0u};
+                    if (k < left && active) s[u] = *reinterpret_cast<const u32x4 *>(Sb + (size_t)((unsigned)c * rowbytes + loff));
+                });
+                static_for<U>([&](auto ut) {
+                    constexpr int u = decltype(ut)::value;
+                    x ^= s[u];
+                });
+            }
+        });
+    }
+    if (active && j == 0) sink[(size_t)it * ns + slice] = x.x ^ x.y ^ x.z ^ x.w;
+}
+
 // long rows: partials added in segment order
 __global__ void k_combine(int n_long, const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_segptr,
                           const float *__restrict__ partial, int ldp, int ncols, float *__restrict__ out, int ldo) {
@@ -349,7 +412,20 @@ struct Ctx {
     Work work_col;   // segments ordered by first column
     Work work_half;  // ... and dealt so that each of a slice's two XCDs sweeps its own half of the column range
     lt_graph *lg;
+    unsigned *sink;  // [n_items * 8] of the gather ceilings
 };
+
+template <int GL, int U, int ORDER = 2>
+static void run_ceiling(Ctx &c, hipStream_t st) {
+    Work &W = ORDER == 2 ? c.work_half : (ORDER ? c.work_col : c.work);
+    const int ns = c.H / (4 * GL) > 0 ? (c.H + 4 * GL - 1) / (4 * GL) : 1;
+    const int xps = 8 / ns;
+    constexpr int IPB = 4 * (64 / GL);
+    const int chunks = (W.n_items + IPB - 1) / IPB;
+    const int grid = 8 * ((chunks + xps - 1) / xps);
+    hipLaunchKernelGGL((k_gather_ceiling<GL, U>), dim3(grid), dim3(256), 0, st, W.n_items, W.e0, W.cnt, c.col, c.S, c.H, c.H,
+                       c.sink, ns);
+}
 
 template <int GL, int U, bool NT, bool SORTED, int HINT = 0, bool SEQ = false, int HOTSET = 0, int ORDER = 0, bool PF = false>
 static void run_sliced(Ctx &c, hipStream_t st) {
@@ -390,7 +466,9 @@ int main(int argc, char **argv) {
     auto t0 = std::chrono::steady_clock::now();
     // LAB_BANDED=<window>: a graph with locality instead of R-MAT (edge factor = average degree / 2)
     const int banded = getenv("LAB_BANDED") ? atoi(getenv("LAB_BANDED")) : 0;
-    HostCsr g = banded ? make_banded(scale, 2 * ef, banded, 42) : make_rmat(scale, (long)ef << scale, 42);
+    // LAB_DRAWS=<n>: directed R-MAT draws (BASELINE configs[4]: 40000000 at scale 21) instead of edge_factor << scale
+    const long draws = getenv("LAB_DRAWS") ? atol(getenv("LAB_DRAWS")) : ((long)ef << scale);
+    HostCsr g = banded ? make_banded(scale, 2 * ef, banded, 42) : make_rmat(scale, draws, 42);
     const long nnz = (long)g.col.size();
     int maxd = 0;
     for (int r = 0; r < g.n; ++r) maxd = std::max(maxd, g.rowptr[r + 1] - g.rowptr[r]);
@@ -410,6 +488,7 @@ int main(int argc, char **argv) {
     CK(hipMalloc((void **)&c.ref, (size_t)g.n * H * sizeof(float)));
     c.work = build_work(g, H, 128, 0);
     c.work_col = build_work(g, H, 128, 1);
+    CK(hipMalloc((void **)&c.sink, ((size_t)g.col.size() / 8 + (size_t)g.n + 1024) * 8 * sizeof(unsigned)));
     c.work_half = build_work(g, H, 128, 2);   // the library's canonical order: 128-entry segments added in order (lt_rows.cuh row_dot)
     {
         // hot sets by in-degree (= row length: the matrix is symmetric)
@@ -417,6 +496,14 @@ int main(int argc, char **argv) {
         for (int r = 0; r < g.n; ++r) deg[r] = g.rowptr[r + 1] - g.rowptr[r];
         std::vector<int> sorted(deg);
         std::sort(sorted.begin(), sorted.end(), std::greater<int>());
+        // what an LDS-resident hot block could hold (160 KB = 640 pieces of 256 B / 160 whole rows) up to the Infinity Cache
+        for (int k : {160, 640, 2560, 32768, 65536, 131072, 262144, 524288}) {
+            if (k > g.n) break;
+            const int thr = sorted[k - 1];
+            long hot = 0;
+            for (size_t e = 0; e < g.col.size(); ++e) hot += deg[g.col[e]] >= thr;
+            printf("top %7d columns (degree >= %d): %.1f%% of the entries\n", k, thr, 100.0 * hot / g.col.size());
+        }
         const int hs[4] = {8192, 12288, 16384, 24576};
         for (int h = 0; h < 4; ++h) {
             const int thr = sorted[std::min(hs[h], g.n) - 1];   // columns with deg > thr are hot (at most hs[h] of them)
@@ -450,6 +537,17 @@ int main(int argc, char **argv) {
         {"g32_col", run_sliced<32, 8, true, true, 0, false, 0, 1>},
         {"g32_col_pf", run_sliced<32, 8, true, true, 0, false, 0, 1, true>},
         {"g16_col_u4_pf", run_sliced<16, 4, true, true, 0, false, 0, 1, true>},
+        {"g16_half_u16_pf", run_sliced<16, 16, true, true, 0, false, 0, 2, true>},
+        {"g8_half_pf", run_sliced<8, 8, true, true, 0, false, 0, 2, true>},
+        {"g8_col_pf", run_sliced<8, 8, true, true, 0, false, 0, 1, true>},
+        {"g32_half_pf", run_sliced<32, 8, true, true, 0, false, 0, 2, true>},
+        {"ceil16_u8", run_ceiling<16, 8>},
+        {"ceil16_u16", run_ceiling<16, 16>},
+        {"ceil8_u8", run_ceiling<8, 8>},
+        {"ceil32_u8", run_ceiling<32, 8>},
+        {"ceil32_u16", run_ceiling<32, 16>},
+        {"ceil64_u8", run_ceiling<64, 8>},
+        {"ceil16_u8_len", run_ceiling<16, 8, 0>},
     };
     hipStream_t st;
     CK(hipStreamCreate(&st));
@@ -465,7 +563,9 @@ int main(int argc, char **argv) {
         CK(hipGetLastError());
         // correctness: bit-equal to the library kernel
         const char *verdict = "ref";
-        if (!have_ref) {
+        if (!strncmp(v.name, "ceil", 4)) {
+            verdict = "(gathers only)";
+        } else if (!have_ref) {
             CK(hipMemcpy(c.ref, c.out, (size_t)g.n * H * sizeof(float), hipMemcpyDeviceToDevice));
             have_ref = true;
         } else {
