@@ -29,8 +29,9 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 2   /* 2: lt_baseline_refresh launches nothing (lazy recomputation on the first reader's stream); fp64 shard entry points;
-                            profile classes 9-11 */
+#define LT_ABI_VERSION 3   /* 2: lt_baseline_refresh launches nothing (lazy recomputation on the first reader's stream); fp64 shard entry points;
+                            profile classes 9-11.  3: lt_influence_rows_vec + lt_wide_combine (layers wider than one pass of the fused
+                            kernels), lt_spmm_gather_ceiling (measurement support); every version-2 entry point is unchanged */
 
 typedef enum lt_status {
     LT_OK = 0,
@@ -204,6 +205,37 @@ int lt_influence_rows(const lt_baseline *b, const int32_t *probe_nodes, int32_t 
                       const int32_t *observe_nodes, int32_t n_obs, float delta, int32_t mode,
                       float *out, int64_t ldo, void *workspace, size_t workspace_bytes,
                       void *stream);
+
+/* ---- measurement support: the gather ceiling of the tiled SpMM ------------------------------------------------------
+ * The tiled (column-sliced work-item) kernel of lt_spmm_csr_f32 with everything but its gathers removed: the same work
+ * items, order, column stream, slice placement and piece size, `in_flight` (8 = the kernel's own, or 16) gathers per lane;
+ * no values, no arithmetic, no result rows.  Its duration bounds from below ANY row-gather SpMM that issues this index
+ * stream -- what bench.py reports as roofline_spmm.gather_ceiling next to the kernel it bounds.  `sink`: device scratch
+ * of lt_spmm_gather_ceiling_bytes(g) bytes (one word per item and slice keeps the loads alive). */
+size_t lt_spmm_gather_ceiling_bytes(const lt_graph *g);
+int lt_spmm_gather_ceiling(const lt_graph *g, const float *S, int64_t lds, int32_t ncols, int32_t in_flight,
+                           void *sink, size_t sink_bytes, void *stream);
+
+/* ---- layers wider than one pass of the fused kernels (hidden > 256 or > 8 classes) ------------------------------------
+ * The reference has no width limit (gcn/layers.py:14-36, main.py:30 --hidden).  The perturbation's effect on the logits is
+ * a SUM over the hidden units, so a wide model is served slice by slice: for every slice s of <= 256 hidden units and every
+ * slice t of <= 8 classes a baseline on (W1[:, s], b1[s], W2[s, t], b2[t]) and one
+ *   lt_influence_rows_vec   = lt_influence_rows that also writes the pair's difference VECTOR, unscaled:
+ *                             vec[(i * ldo + j) * C_t + c] = (f_s(X + d e_v x_v^T) - f_s(X))[u_j, c]   (LT_MODE_SPARSE: the fp32
+ *                             finite difference of the slice's own forward; LT_MODE_DELTA: the propagated difference; exact zeros
+ *                             outside the probe's 2-hop set in both).  FULL has no vector form (it names SPARSE's bits).
+ * and per class slice one
+ *   lt_wide_combine         d_c = (vec_0 + vec_1 + ... )[c] / delta in slice order, ss = fma(d_c, d_c, ss) in class order on top of
+ *                             the running ss[pair] of the previous class slices (first != 0: start from 0), and on the last class
+ *                             slice (last != 0) ss[pair] <- sqrt(ss[pair]): the influence score of attacker.py:227-229.
+ * vecs: HOST array of n_vec device pointers, each [n_pairs, C] dense.  Launch count per matrix: ~5 per (s, t) + one per t,
+ * independent of n_probe (the round-3 route looped ~5 launches per PROBE). */
+int lt_influence_rows_vec(const lt_baseline *b, const int32_t *probe_nodes, int32_t n_probe,
+                          const int32_t *observe_nodes, int32_t n_obs, float delta, int32_t mode,
+                          float *out, int64_t ldo, float *vec, void *workspace, size_t workspace_bytes,
+                          void *stream);
+int lt_wide_combine(const float *const *vecs, int32_t n_vec, int64_t n_pairs, int32_t C, float delta,
+                    float *ss, int32_t first, int32_t last, void *stream);
 
 /* ---- the same for the 3-layer model (GCN3, gcn/models.py:28-46; --n-layer 3, gcn_trainer.py:81-86) -------------
  *   logits = A (relu(A (relu(A (X W1) + b1) W2) + b2) W3) + b3,   H1, H2 <= 256, C <= 8.

@@ -39,6 +39,8 @@ SIGNATURES = {
     "lt_spmm_csr_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32,
                                   C.c_void_p, C.c_int64, C.c_void_p]),
     "lt_spmm_route": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lt_spmm_gather_ceiling_bytes": (C.c_size_t, [C.c_void_p]),
+    "lt_spmm_gather_ceiling": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "lt_gcn2_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "lt_gcn2_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
@@ -58,6 +60,10 @@ SIGNATURES = {
     "lt_influence_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "lt_influence_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
                                     C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "lt_influence_rows_vec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
+                                        C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "lt_wide_combine": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_int32,
+                                  C.c_int32, C.c_void_p]),
     "lt_baseline3_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                       C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                       C.POINTER(C.c_void_p)]),
@@ -78,7 +84,7 @@ SIGNATURES = {
 }
 KERNEL_IDS = {"gemm": 0, "layer1": 1, "layer2": 2, "perturb": 3, "full_stageA": 4, "full_stageB": 5,
               "item_stageA": 6, "item_stageB": 7, "spmm": 8, "fp64_product": 9, "fp64_spmm": 10, "item_bits": 11}
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def lib():

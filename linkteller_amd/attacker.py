@@ -140,14 +140,7 @@ class Attacker:
         """[len(probe_nodes), len(observe_nodes)] influence rows on the device."""
         if self._is_two_layer():
             mode = self._mode(mode)
-            base = self.baseline(mode)
-            if isinstance(base, engine.WideBaseline) and mode == "delta":
-                # no exact propagation outside the fused widths: say so once instead of silently serving another mode
-                if not getattr(self, "_warned_wide", False):
-                    print("influence-mode 'delta' is not available for layers wider than 256 hidden units / 8 classes: "
-                          "using the reference's fp32 finite difference ('sparse') on the unfused HIP layers")
-                    self._warned_wide = True
-                mode = "sparse"
+            base = self.baseline(mode)      # (engine.WideBaseline beyond 256 hidden units / 8 classes: every mode, slice by slice)
             return base.influence_rows(probe_nodes, observe_nodes, float(self.args.influence), mode)
         if self._is_three_layer():
             # the 3-hop probe primitive: `delta` (default) propagates the perturbation exactly through the three layers,

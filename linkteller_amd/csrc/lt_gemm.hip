@@ -4,6 +4,15 @@
 //
 // v_mfma_f32_32x32x2_f32: f32 in / f32 accumulate; each output element is a k-ordered fmaf
 // chain (no reduced-precision path exists on gfx950), 64 FLOP/clk/SIMD = the fp32 peak.
+//
+// Summation order (round 4): a K slice is summed as chains of LT_GEMM_FOLD = 128 terms, each started from +0, whose sums are
+// added in order ( ((c0 + c1) + c2) + ... ), and the slices of a split-K product are added in slice order as before.  One
+// 3170-term chain per output carries ~sqrt(3170) roundings; torch's CPU sgemm (blocked, vectorised partial sums) carries far
+// fewer, and the finite difference of `full` / `sparse` amplifies that rounding by 1 / delta = 1e4: with plain chains the fp32
+// modes sat at 1.5x (rms) / 2x (max) the REFERENCE's own fp32 error over the whole twitch-ES matrix (BASELINE.md section 3
+// asks <= 1x); folded every 128 terms they sit at its level (tests/test_gpu_round4.py, whole-matrix gate; the CPU
+// experiment behind the choice: NOTES.md).  The fold is 16 v_add per accumulator tile per 64 MFMAs.  Every kernel below
+// folds at the same k (multiples of 128 from the slice start) and once more at the end, so they still give each other's bits.
 // Block = 4 waves as 2x2, each wave owns one 32x32 accumulator tile of a 64x64 block tile;
 // K is walked in 16-deep tiles staged through LDS with a register prefetch of the next tile
 // (one barrier per tile).  A-tile rows are padded to 17 floats: the MFMA A operand is read
@@ -16,6 +25,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#define LT_GEMM_FOLD 128   // terms per inner chain (a multiple of every kernel's k-tile depth)
 #define GM_BM 64
 #define GM_BN 64
 #define GM_BK 16
@@ -94,9 +104,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma(const float *__restrict__
         *reinterpret_cast<f32x4 *>(&Bs[buf][b_row * GM_BN + b_col]) = rb;
     };
 
-    f32x16 acc;
+    f32x16 acc, total;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; total[i] = 0.f; }
 
     const int nk = (ke - kb + GM_BK - 1) / GM_BK;
     load_tiles(kb);
@@ -105,6 +115,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma(const float *__restrict__
 
     const int a_frag = (wr * 32 + (lane & 31)) * GM_LDA + (lane >> 5);
     const int b_frag = (lane >> 5) * GM_BN + wc * 32 + (lane & 31);
+    constexpr int FOLD_TILES = LT_GEMM_FOLD / GM_BK;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tiles(kb + (kt + 1) * GM_BK);
@@ -113,9 +124,16 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma(const float *__restrict__
 #pragma unroll
         for (int kk = 0; kk < GM_BK; kk += 2)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[kk], bs[kk * GM_BN], acc, 0, 0, 0);
+        if ((kt + 1) % FOLD_TILES == 0) {     // LT_GEMM_FOLD terms: the chain's sum joins the total, the next chain starts from +0
+            total += acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        }
         if (kt + 1 < nk) store_tiles(buf ^ 1);
         __syncthreads();
     }
+    total += acc;
+    acc = total;
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int cn = n0 + wc * 32 + (lane & 31);
@@ -213,9 +231,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma_deep(const float *__restr
             *reinterpret_cast<f32x4 *>(&Bs[buf][(t_row + 16 * p) * GM_BN + t_col]) = rb[p];
         }
     };
-    f32x16 acc;
+    f32x16 acc, total;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; total[i] = 0.f; }
+    constexpr int FOLD_TILES = LT_GEMM_FOLD / GD_BK;
     const int a_frag = (wr * 32 + (lane & 31)) * GD_LDA + (lane >> 5);
     const int b_frag = (lane >> 5) * GM_BN + wc * 32 + (lane & 31);
     auto multiply = [&](int buf) {
@@ -237,10 +256,17 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma_deep(const float *__restr
             const int buf = kt & 1;
             if (kt + 1 < nk) load_any(kt + 1);
             multiply(buf);
+            if ((kt + 1) % FOLD_TILES == 0) {     // (the fold of the header comment: same k as the other kernels)
+                total += acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            }
             if (kt + 1 < nk) store_tiles(buf ^ 1);
             __syncthreads();
         }
     }
+    total += acc;
+    acc = total;
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int cn = n0 + wc * 32 + (lane & 31);
 #pragma unroll
@@ -349,13 +375,26 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma_128(const float *__restri
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2], total[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; total[i][j][e] = 0.f; }
+    constexpr int FOLD_TILES = LT_GEMM_FOLD / GL_BK;
+    static_assert((FOLD_TILES & 1) == 0, "the steady-state loop folds after the second tile of a trip");
+    // the fold of the header comment: after tile t with (t + 1) % FOLD_TILES == 0
+    auto fold = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                total[i][j] += acc[i][j];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            }
+    };
 
     const int a_frag = (wr * 64 + (lane & 31)) * GL_LDA + (lane >> 5);
     const int b_frag = (lane >> 5) * GL_BN + wc * 64 + (lane & 31);
@@ -397,6 +436,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma_128(const float *__restri
             constexpr int E = decltype(even_tag)::value;   // kt & 1
             if (kt + 2 < nfull) load_full(std::integral_constant<int, E>{});
             multiply(E);
+            if ((kt + 1) % FOLD_TILES == 0) fold();
             if (kt + 1 < nfull) store_tiles(E ^ 1, std::integral_constant<int, E ^ 1>{});
             __syncthreads();
         };
@@ -410,6 +450,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma_128(const float *__restri
             __syncthreads();
             load_full(S1{});
             multiply(1);
+            if ((kt + 2) % FOLD_TILES == 0) fold();     // (register-only: the counted waits of the loads above are unaffected)
             store_tiles(0, S0{});
             __syncthreads();
         }
@@ -426,6 +467,14 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma_128(const float *__restri
         __syncthreads();
         multiply(0);
     }
+    // (a partial tile is the slice's last: its terms belong to the chain the final fold closes)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            total[i][j] += acc[i][j];
+            acc[i][j] = total[i][j];
+        }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll

@@ -938,7 +938,8 @@ __device__ __forceinline__ void stageB_long_block(
     const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
     const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
     float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words,
-    const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot, const int32_t *__restrict__ hub_obs, int hub_cap) {
+    const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot, const int32_t *__restrict__ hub_obs, int hub_cap,
+    float *__restrict__ vec = nullptr) {
     constexpr int CHUNK = CP <= 2 ? LT_SBL_CHUNK : (CP <= 4 ? LT_SBL_CHUNK / 2 : LT_SBL_CHUNK / 4);   // LDS: <= 16 KB
     constexpr int GROUPS = LT_BLOCK / LT_L2_LANES;
     // entries of the walk whose membership tests are in flight per lane: DELTA keeps nothing else per entry (no baseline
@@ -1170,7 +1171,10 @@ __device__ __forceinline__ void stageB_long_block(
             res = diff_norm<CP>(acc, b2, OUT + (size_t)u * C, C, delta);
         }
     }
-    if (live && q == 0) out[(long)b * ldo + j] = res;
+    if (live && q == 0) {
+        out[(long)b * ldo + j] = res;
+        if (vec) store_diff_vec<CP>(vec, (long)b * ldo + j, C, acc, b2, DELTA ? (const float *)nullptr : OUT + (size_t)u * C, t != 0);
+    }
     __syncthreads();        // (the next slot restages sc / sv / sT)
     }
 }
@@ -1187,10 +1191,11 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_hubs(
     const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
     const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
     float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words,
-    const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot, const int32_t *__restrict__ hub_obs) {
+    const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot, const int32_t *__restrict__ hub_obs,
+    float *__restrict__ vec) {
     stageB_long_block<CP, DELTA, SHORT, WIDE>((int)blockIdx.x, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off, S2x,
                                         observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot, hub_obs,
-                                        (int)gridDim.x / ((nb + LT_BLOCK / LT_L2_LANES - 1) / (LT_BLOCK / LT_L2_LANES)));
+                                        (int)gridDim.x / ((nb + LT_BLOCK / LT_L2_LANES - 1) / (LT_BLOCK / LT_L2_LANES)), vec);
 }
 
 // SPARSE / DELTA stage B: 8 lanes per (probe, observed node).
@@ -1204,7 +1209,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
     const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
     float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words, int long_blocks, int skip_long,
     const unsigned *__restrict__ marks, const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot,
-    int hub_short, const int32_t *__restrict__ hub_obs) {
+    int hub_short, const int32_t *__restrict__ hub_obs, float *__restrict__ vec) {
     // long_blocks > 0 (the graph has hub rows): the first long_blocks blocks serve the observed hubs
     // (stageB_long_block: most of them find a plain row and exit); skip_long: the pairs below leave those rows alone
     // (SPARSE with the short-side search: k_item_stageB_hubs has them, long_blocks = 0 here)
@@ -1214,7 +1219,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
         if ((int)blockIdx.x < long_blocks) {
             stageB_long_block<CP, DELTA, false>((int)blockIdx.x, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off,
                                                 S2x, observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot, hub_obs,
-                                                long_blocks / ((nb + LT_BLOCK / LT_L2_LANES - 1) / (LT_BLOCK / LT_L2_LANES)));
+                                                long_blocks / ((nb + LT_BLOCK / LT_L2_LANES - 1) / (LT_BLOCK / LT_L2_LANES)), vec);
             return;
         }
     }
@@ -1247,8 +1252,8 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
         for (int m = LT_L2_LANES / 2; m >= 1; m >>= 1) t |= __shfl_xor(t, m, 64);
     }
     float res = 0.f;
+    float acc[CP];
     if (t) {  // group-uniform
-        float acc[CP];
         if (DELTA) {
             // d_out[c] = sum over e with col[e] in R_v of val[e] * dS2[item(col[e]), c]
             row2_dot<CP>(col, val, e0, e1, q, C,
@@ -1275,7 +1280,10 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
             res = diff_norm<CP>(acc, b2, OUT + (size_t)u * C, C, delta);
         }
     }
-    if (q == 0) out[(long)b * ldo + j] = res;
+    if (q == 0) {
+        out[(long)b * ldo + j] = res;
+        if (vec) store_diff_vec<CP>(vec, (long)b * ldo + j, C, acc, b2, DELTA ? (const float *)nullptr : OUT + (size_t)u * C, t != 0);
+    }
 }
 
 // SPARSE / DELTA stage B, calls with a bitmap row per probe (twitch size): one block per (observed node, slice of the
@@ -1596,10 +1604,37 @@ extern "C" size_t lt_influence_workspace_bytes(const lt_baseline *b, int32_t n_p
     return carve_infl(nullptr, b, n_probe, n_obs, mode).bytes;
 }
 
+static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes, int32_t n_probe,
+                               const int32_t *observe_nodes, int32_t n_obs, float delta,
+                               int32_t mode, float *out, int64_t ldo, void *workspace,
+                               size_t workspace_bytes, void *stream, float *vec);
+
 extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_nodes, int32_t n_probe,
                                  const int32_t *observe_nodes, int32_t n_obs, float delta,
                                  int32_t mode, float *out, int64_t ldo, void *workspace,
                                  size_t workspace_bytes, void *stream) {
+    return influence_rows_impl(b, probe_nodes, n_probe, observe_nodes, n_obs, delta, mode, out, ldo, workspace, workspace_bytes,
+                               stream, nullptr);
+}
+
+// The same call with the pairs' difference VECTORS next to the norms: vec[(i * ldo + j) * C + c], unscaled (see
+// store_diff_vec in lt_items.cuh).  For models wider than one pass of these kernels the caller runs one such call per slice
+// of the hidden layer (W1[:, s], b1[s], W2[s, t]) and per slice of <= 8 classes and joins them with lt_wide_combine.
+// LT_MODE_SPARSE and LT_MODE_DELTA only (FULL names the same quantity as SPARSE, bit for bit).
+extern "C" int lt_influence_rows_vec(const lt_baseline *b, const int32_t *probe_nodes, int32_t n_probe,
+                                     const int32_t *observe_nodes, int32_t n_obs, float delta,
+                                     int32_t mode, float *out, int64_t ldo, float *vec, void *workspace,
+                                     size_t workspace_bytes, void *stream) {
+    LT_REQUIRE(vec != nullptr, "lt_influence_rows_vec: vec is NULL");
+    LT_REQUIRE(mode == LT_MODE_SPARSE || mode == LT_MODE_DELTA, "lt_influence_rows_vec: mode %d has no vector form (use SPARSE / DELTA)", mode);
+    return influence_rows_impl(b, probe_nodes, n_probe, observe_nodes, n_obs, delta, mode, out, ldo, workspace, workspace_bytes,
+                               stream, vec);
+}
+
+static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes, int32_t n_probe,
+                               const int32_t *observe_nodes, int32_t n_obs, float delta,
+                               int32_t mode, float *out, int64_t ldo, void *workspace,
+                               size_t workspace_bytes, void *stream, float *vec) {
     LT_REQUIRE(b != nullptr, "lt_influence_rows: baseline is NULL");
     LT_REQUIRE(n_probe >= 0 && n_obs >= 0, "lt_influence_rows: negative count");
     LT_REQUIRE(mode >= LT_MODE_FULL && mode <= LT_MODE_DELTA, "lt_influence_rows: unknown mode %d", mode);
@@ -1642,7 +1677,8 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
     const bool hub_short = mode != LT_MODE_FULL && (lt_tune().hub_short_side >= 0 ? lt_tune().hub_short_side != 0 : w.bits == nullptr);
     // stage B per observed row (k_item_stageB_rows) instead of per pair: calls with a bitmap row per probe and no pair marks
     // ("stageb_rows" = 0 keeps the per-pair kernel; results are bit-identical)
-    const bool rows_route = mode != LT_MODE_FULL && w.bits != nullptr && !use_marks && lt_tune().stageb_rows != 0;
+    // (the vector form is written by the per-pair kernel and the hub blocks only)
+    const bool rows_route = mode != LT_MODE_FULL && w.bits != nullptr && !use_marks && lt_tune().stageb_rows != 0 && vec == nullptr;
     // probes of a chunk split over `psplit` blocks per observed node so that the launch fills the chip
     int psplit = 1;
     {
@@ -1665,6 +1701,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
         const int nb = (n_probe - p0) < w.chunk ? (n_probe - p0) : w.chunk;
         const int32_t *probes = probe_nodes + p0;
         float *orow = out + (int64_t)p0 * ldo;
+        float *vrow = vec ? vec + (int64_t)p0 * ldo * b->C : (float *)nullptr;
         const long pairs = (long)nb * n_obs;
         LT_REQUIRE(mode == LT_MODE_FULL || ((pairs * LT_L2_LANES + LT_BLOCK - 1) / LT_BLOCK < 2147483647L &&
                                             ((nb + 31) / 32) * (long)n_obs < 2147483647L),
@@ -1818,7 +1855,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                            dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
                                                            g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
                                                            nb, w.off, w.S2x, observe_nodes, n_obs, delta,
-                                                           orow, (long)ldo, w.bits, words, w.big_bits, w.big_slot, w.hub_obs));
+                                                           orow, (long)ldo, w.bits, words, w.big_bits, w.big_slot, w.hub_obs, vrow));
                     LT_CHECK_LAUNCH();
                 }
                 const unsigned inl = hub_short ? 0u : (unsigned)long_blocks;   // hub blocks in front of the pair launch
@@ -1828,7 +1865,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                                g->rowptr, g->col, g->val, g->tptr, g->trow, b->S2, C, b->b2,
                                                                b->OUT, probes, nb, w.off, w.S2x, observe_nodes, n_obs, delta,
                                                                orow, (long)ldo, w.bits, words, (int)inl, 1, marks, w.big_bits,
-                                                               w.big_slot, 0, w.hub_obs));
+                                                               w.big_slot, 0, w.hub_obs, vrow));
                         LT_CHECK_LAUNCH();
                     }
                     LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_rows<CP_, false>), dim3((unsigned)((long)n_obs * psplit)),
@@ -1841,7 +1878,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                        g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
                                                        nb, w.off, w.S2x, observe_nodes, n_obs, delta,
                                                        orow, (long)ldo, w.bits, words, (int)inl, long_blocks > 0 ? 1 : 0, marks,
-                                                       w.big_bits, w.big_slot, 0, w.hub_obs));
+                                                       w.big_bits, w.big_slot, 0, w.hub_obs, vrow));
             } else {
                 const double *spd = nullptr;
                 if (b->Z1d && lt_fp64_agg_active(b)) {
@@ -1884,19 +1921,19 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                                dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, g->tptr, g->trow,
                                                                b->S2, C, b->b2, b->OUT, probes, nb, w.off, w.S2x, observe_nodes,
                                                                n_obs, delta, orow, (long)ldo, w.bits, words, w.big_bits,
-                                                               w.big_slot, w.hub_obs));
+                                                               w.big_slot, w.hub_obs, vrow));
                     } else if (hub_short) {
                         LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_hubs<CP_, true, true>), dim3((unsigned)long_blocks),
                                                                dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, g->tptr, g->trow,
                                                                b->S2, C, b->b2, b->OUT, probes, nb, w.off, w.S2x, observe_nodes,
                                                                n_obs, delta, orow, (long)ldo, w.bits, words, w.big_bits,
-                                                               w.big_slot, w.hub_obs));
+                                                               w.big_slot, w.hub_obs, vrow));
                     } else {
                         LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_hubs<CP_, true, false>), dim3((unsigned)long_blocks),
                                                                dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, g->tptr, g->trow,
                                                                b->S2, C, b->b2, b->OUT, probes, nb, w.off, w.S2x, observe_nodes,
                                                                n_obs, delta, orow, (long)ldo, w.bits, words, w.big_bits,
-                                                               w.big_slot, w.hub_obs));
+                                                               w.big_slot, w.hub_obs, vrow));
                     }
                     LT_CHECK_LAUNCH();
                 }
@@ -1911,10 +1948,46 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
                                                        g->tptr, g->trow, b->S2, C, b->b2, b->OUT, probes,
                                                        nb, w.off, w.S2x, observe_nodes, n_obs, delta,
                                                        orow, (long)ldo, w.bits, words, 0, long_blocks > 0 ? 1 : 0,
-                                                       marks, w.big_bits, w.big_slot, hub_short ? 1 : 0, w.hub_obs));
+                                                       marks, w.big_bits, w.big_slot, hub_short ? 1 : 0, w.hub_obs, vrow));
             }
             LT_CHECK_LAUNCH();
         }
     }
+    return LT_OK;
+}
+
+// ---- lt_wide_combine: the slices' difference vectors -> scores (include/linkteller_hip.h) ---------------------------------
+#define LT_WIDE_MAX_VEC 32
+struct lt_vec_ptrs { const float *p[LT_WIDE_MAX_VEC]; };
+__global__ __launch_bounds__(256) void k_wide_combine(lt_vec_ptrs v, int n_vec, long n_pairs, int C, float delta,
+                                                      float *__restrict__ ss, int first, int last) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pairs) return;
+    float acc = first ? 0.f : ss[i];
+    for (int c = 0; c < C; ++c) {
+        float d = v.p[0][i * C + c];
+        for (int s = 1; s < n_vec; ++s) d += v.p[s][i * C + c];     // hidden slices in slice order
+        d = d / delta;                                              // attacker.py:105-106
+        acc = fmaf(d, d, acc);
+    }
+    ss[i] = last ? sqrtf(acc) : acc;
+}
+
+extern "C" int lt_wide_combine(const float *const *vecs, int32_t n_vec, int64_t n_pairs, int32_t C, float delta,
+                               float *ss, int32_t first, int32_t last, void *stream) {
+    LT_REQUIRE(vecs != nullptr && ss != nullptr, "lt_wide_combine: NULL pointer");
+    LT_REQUIRE(n_vec >= 1 && n_vec <= LT_WIDE_MAX_VEC, "lt_wide_combine: %d vectors (1 .. %d hidden slices)", n_vec, LT_WIDE_MAX_VEC);
+    LT_REQUIRE(n_pairs >= 0 && C >= 1 && C <= LT_MAX_C, "lt_wide_combine: n_pairs=%lld C=%d", (long long)n_pairs, C);
+    LT_REQUIRE(delta != 0.f && delta == delta, "lt_wide_combine: delta must be a non-zero number");
+    if (n_pairs == 0) return LT_OK;
+    lt_vec_ptrs v = {};
+    for (int s_ = 0; s_ < n_vec; ++s_) {
+        LT_REQUIRE(vecs[s_] != nullptr, "lt_wide_combine: vecs[%d] is NULL", s_);
+        v.p[s_] = vecs[s_];
+    }
+    LT_REQUIRE((n_pairs + 255) / 256 < 2147483647L, "lt_wide_combine: grid limit");
+    hipLaunchKernelGGL(k_wide_combine, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, n_vec,
+                       (long)n_pairs, C, delta, ss, first, last);
+    LT_CHECK_LAUNCH();
     return LT_OK;
 }

@@ -184,6 +184,18 @@ static __global__ __launch_bounds__(256) void k_pm_mark(const int32_t *__restric
 // ------------------------------------------------------------------------------------------------
 // shared tail: finite difference + L2 norm of one observed row          attacker.py:105-106,227-229
 // ------------------------------------------------------------------------------------------------
+// Vector form of the tail, for layers wider than one pass of these kernels (lt_influence_rows_vec): instead of the norm,
+// the C differences of the pair go to vec[pair * C + c] UNSCALED -- SPARSE: (acc + b2) - base, the fp32 finite difference
+// before the division by delta; DELTA (base == NULL): the propagated difference acc itself; an untouched pair: zeros --
+// so that the caller can add the vectors of the hidden-layer slices (lt_wide_combine) before dividing and taking the norm.
+template <int CP>
+__device__ __forceinline__ void store_diff_vec(float *__restrict__ vec, long pair, int C, const float (&acc)[CP],
+                                               const float *__restrict__ b2, const float *__restrict__ base, bool touched) {
+#pragma unroll
+    for (int c = 0; c < CP; ++c)
+        if (c < C) vec[pair * C + c] = !touched ? 0.f : (base ? (acc[c] + b2[c]) - base[c] : acc[c]);
+}
+
 template <int CP>
 __device__ __forceinline__ float diff_norm(const float (&acc)[CP], const float *__restrict__ b2,
                                            const float *__restrict__ base, int C, float delta) {

@@ -372,6 +372,98 @@ int lt_launch_rows_tiled(const lt_graph *g, const float *S, int64_t lds, int nco
 }
 
 // --------------------------------------------------------------------------------------------
+// Measurement support (bench.py `roofline_spmm.gather_ceiling`): k_rows_tiled with everything but its GATHERS removed --
+// the same work items in the same order, the same column stream (col only), the same slice = f(XCD) placement and the
+// same 16-lane x 16-byte pieces, U gathers in flight per lane; no val stream, no fmaf chains (the loaded words are
+// XOR-folded, one VALU op each, so that the loads stay live), no result rows (one word per item and slice).  Its duration
+// is what the memory system needs to deliver THIS index stream at THIS hit distribution: a lower bound for any
+// row-gather SpMM that issues these gathers, whatever its arithmetic (tools/spmm_lab holds the variants that were tried:
+// 8 / 16 / 32 / 64 lanes per item, 8 or 16 gathers in flight).
+// --------------------------------------------------------------------------------------------
+template <int U, bool BIG>
+__global__ __launch_bounds__(LT_BLOCK) void k_rows_tiled_gathers_only(
+    int n_items, const int32_t *__restrict__ w_e0, const int32_t *__restrict__ w_cnt, const int32_t *__restrict__ col,
+    const float *__restrict__ S, long lds, int ncols, unsigned *__restrict__ sink, int ns) {
+    constexpr int GL = LT_TILE_GL;
+    constexpr int GPW = 64 / GL, IPB = (LT_BLOCK / 64) * GPW;
+    const int lane = threadIdx.x & 63;
+    const int j = lane & (GL - 1);
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int xps = 8 / ns;
+    const int slice = xcd % ns;
+    const int it = (q * xps + xcd / ns) * IPB + (threadIdx.x >> 6) * GPW + lane / GL;
+    if (it >= n_items) return;
+    const int e0 = __builtin_nontemporal_load(w_e0 + it);
+    const int cnt = __builtin_nontemporal_load(w_cnt + it);
+    const int coff = slice * 4 * GL + 4 * j;
+    const bool active = coff < ncols;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 x = {0u, 0u, 0u, 0u};
+    const char *Sb = reinterpret_cast<const char *>(S);
+    const size_t rowbytes = (size_t)lds * 4u;
+    const unsigned loff = (unsigned)coff * 4u;
+    const int e1 = e0 + cnt;
+    int nxc = 0;
+    if (e0 + j < e1) nxc = __builtin_nontemporal_load(col + e0 + j);
+    for (int eb = e0; eb < e1; eb += GL) {
+        const int me = eb + j;
+        const int myc = nxc;
+        nxc = 0;
+        if (me + GL < e1) nxc = __builtin_nontemporal_load(col + me + GL);
+        const int left = e1 - eb;
+        static_for<GL / U>([&](auto kbt) {
+            constexpr int kb = decltype(kbt)::value * U;
+            if (kb < left) {
+                u32x4 s[U];
+                static_for<U>([&](auto ut) {
+                    constexpr int u = decltype(ut)::value;
+                    constexpr int k = kb + u;
+                    const int c = row_bcast<k>(myc);
+                    s[u] = u32x4{0u, 0u, 0u, 0u};
+                    if (k < left && active) {
+                        if (BIG) s[u] = *reinterpret_cast<const u32x4 *>(Sb + ((size_t)c * rowbytes + loff));
+                        else s[u] = *reinterpret_cast<const u32x4 *>(Sb + (size_t)((unsigned)c * (unsigned)rowbytes + loff));
+                    }
+                });
+                static_for<U>([&](auto ut) { x ^= s[decltype(ut)::value]; });
+            }
+        });
+    }
+    if (active && j == 0) sink[(size_t)it * ns + slice] = x.x ^ x.y ^ x.z ^ x.w;
+}
+
+extern "C" size_t lt_spmm_gather_ceiling_bytes(const lt_graph *g) {
+    return g ? ((size_t)g->w_n * 4 + 64) * sizeof(unsigned) : 0;
+}
+
+extern "C" int lt_spmm_gather_ceiling(const lt_graph *g, const float *S, int64_t lds, int32_t ncols, int32_t in_flight,
+                                      void *sink, size_t sink_bytes, void *stream) {
+    LT_REQUIRE(g != nullptr && S != nullptr && sink != nullptr, "lt_spmm_gather_ceiling: NULL pointer");
+    LT_REQUIRE(ncols > 0 && ncols % 4 == 0 && ncols <= 4 * LT_TILE_GL * 4 && lds >= ncols,
+               "lt_spmm_gather_ceiling: ncols=%d (a multiple of 4 up to %d, one pass of the tiled kernel)", ncols, 16 * LT_TILE_GL);
+    LT_REQUIRE(in_flight == 8 || in_flight == 16, "lt_spmm_gather_ceiling: in_flight = 8 (the kernel's own) or 16");
+    LT_REQUIRE(sink_bytes >= lt_spmm_gather_ceiling_bytes(g), "lt_spmm_gather_ceiling: sink needs %zu bytes", lt_spmm_gather_ceiling_bytes(g));
+    if (g->w_n == 0) return LT_OK;
+    int ns = (ncols + 4 * LT_TILE_GL - 1) / (4 * LT_TILE_GL);
+    ns = ns <= 1 ? 1 : (ns == 2 ? 2 : 4);
+    const int xps = 8 / ns;
+    constexpr int IPB = (LT_BLOCK / 64) * (64 / LT_TILE_GL);
+    const long chunks = ((long)g->w_n + IPB - 1) / IPB;
+    const long grid = 8 * ((chunks + xps - 1) / xps);
+    LT_REQUIRE(grid < 2147483647L, "lt_spmm_gather_ceiling: grid limit");
+    const bool big = (unsigned long long)g->n * (unsigned long long)lds * 4ull >= (1ull << 32);
+    hipStream_t st = (hipStream_t)stream;
+#define LT_GC_LAUNCH(U_, BIG_)                                                                                          \
+    hipLaunchKernelGGL((k_rows_tiled_gathers_only<U_, BIG_>), dim3((unsigned)grid), dim3(LT_BLOCK), 0, st, g->w_n, g->w_e0, \
+                       g->w_cnt, g->col, S, (long)lds, ncols, (unsigned *)sink, ns)
+    if (in_flight == 8) { if (big) LT_GC_LAUNCH(8, true); else LT_GC_LAUNCH(8, false); }
+    else { if (big) LT_GC_LAUNCH(16, true); else LT_GC_LAUNCH(16, false); }
+#undef LT_GC_LAUNCH
+    LT_CHECK_LAUNCH();
+    return LT_OK;
+}
+
+// --------------------------------------------------------------------------------------------
 // small graphs: one LPR-lane group per row (4 columns per lane), rows of up to LT_ROW_SEG entries
 // --------------------------------------------------------------------------------------------
 template <int LPR>

@@ -235,13 +235,41 @@ class Baseline:
         return out
 
 
+    def influence_rows_vec(self, probes: torch.Tensor, obs: torch.Tensor, delta: float, m: int, out: torch.Tensor,
+                           vec: torch.Tensor) -> torch.Tensor:
+        """lt_influence_rows_vec (a slice of a wide model, ``WideBaseline``): the norms into ``out`` and the pairs' unscaled
+        difference vectors into ``vec`` ([n_probe, n_obs, C] dense in the storage of ``vec``).  Device int32 node tensors."""
+        if m == _lib.MODE_DELTA and not self._fp64:
+            self.enable_fp64()
+        npb, nob = probes.numel(), obs.numel()
+        if vec.numel() < npb * nob * self.c or vec.dtype != torch.float32 or not vec.is_contiguous():
+            raise ValueError("vec must be a contiguous float32 tensor of at least n_probe * n_obs * C elements")
+        key = (npb, nob, m)
+        need = _lib.lib().lt_influence_workspace_bytes(self._h, npb, nob, m)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = _workspace(need, self.x.device)
+            self._ws = {key: ws}
+        _lib.check(_lib.lib().lt_influence_rows_vec(self._h, probes.data_ptr(), npb, obs.data_ptr(), nob, float(delta), m,
+                                                    out.data_ptr(), nob, vec.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+                   "lt_influence_rows_vec")
+        return vec
+
+
 class WideBaseline:
-    """The probe loop for 2-layer models outside what the fused kernels are built for (hidden width > 256 or more than
-    8 classes; the reference has no such limit: gcn/layers.py:30-36, main.py:30).  Same interface as ``Baseline``; every
-    probe runs the reference's own op sequence on the unfused HIP layers -- row v of S1 = X W1 replaced by
-    (x_v + x_v d) W1, then lt_spmm_csr_f32 (column-sliced) / lt_gemm_f32 for the two layers -- and the fp32 finite
-    difference (f(X + d e_v x_v^T) - f(X))[u] / d of attacker.py:100-108.  ~5 launches per probe instead of one call for
-    all probes: the slow, general route (`sparse` / `full` name the same thing here; there is no `delta` propagation)."""
+    """The probe primitive for 2-layer models wider than one pass of the fused kernels (hidden width > 256 or more than 8
+    classes; the reference has no such limit: gcn/layers.py:14-36, main.py:30 --hidden).  Same interface as ``Baseline``.
+
+    A perturbation reaches the logits as a SUM over the hidden units, so the model is served slice by slice: for every slice
+    s of <= 256 hidden units and every slice t of <= 8 classes a ``Baseline`` on (W1[:, s], b1[s], W2[s, t], b2[t]) whose
+    ``lt_influence_rows_vec`` call yields the pairs' difference vectors, and per class slice one ``lt_wide_combine`` that adds
+    the hidden slices' vectors in slice order, divides by delta and accumulates the squared norm over the classes in class
+    order (include/linkteller_hip.h).  All three modes: `sparse` (= `full`: per slice the fp32 finite difference of the
+    slice's own forward, exact zeros outside the 2-hop set) and `delta` (the exact propagation, fp64 kink test per slice).
+    ~5 launches per (s, t) per matrix, independent of the number of probes (round 3 looped ~5 launches per PROBE and had
+    no `delta`).  Cost model: every (s, t) baseline forms its own X W1[:, s] -- the general route, not the fast one."""
+
+    supports_sharding = False       # dist.choose_baseline_sharding: replicated on every rank, no timing loop
 
     def __init__(self, adj, x, w1, b1, w2, b2):
         self.graph: HipGraph = as_hip_graph(adj)
@@ -254,13 +282,36 @@ class WideBaseline:
         if self.graph.device_index != self.x.device.index:
             raise ValueError(f"the graph lives on cuda:{self.graph.device_index}, the features on {self.x.device}")
         _require_finite(features=self.x, W1=self.w1, b1=self.b1, W2=self.w2, b2=self.b2)
-        self._s1 = None
-        self._out = None
+        self.h_slices = [(s0, min(s0 + 256, self.h)) for s0 in range(0, self.h, 256)]
+        self.c_slices = [(t0, min(t0 + 8, self.c)) for t0 in range(0, self.c, 8)]
+        if len(self.h_slices) > 32:
+            raise NotImplementedError(f"hidden width {self.h}: more than 32 slices of 256 (lt_wide_combine)")
+        self._subs = None           # [(s, t)] -> (Baseline, (W1 slice, b1 slice, W2 slice, b2 slice)); built on first use
+        self._logits = None
+        self._fp64 = False
+        self._buf = {}
 
-    supports_sharding = False       # dist.choose_baseline_sharding: replicated on every rank, no timing loop
+    def _build(self):
+        if self._subs is not None:
+            return
+        subs = {}
+        for si, (s0, s1) in enumerate(self.h_slices):
+            for ti, (t0, t1) in enumerate(self.c_slices):
+                parts = (self.w1[:, s0:s1].contiguous(), self.b1[s0:s1].contiguous(),
+                         self.w2[s0:s1, t0:t1].contiguous(), self.b2[t0:t1].contiguous())
+                subs[(si, ti)] = (Baseline(self.graph, self.x, *parts), parts)
+        self._subs = subs
 
     def refresh(self, mode=None):
-        self._s1 = self._out = None
+        """The borrowed inputs changed: the slices are re-cut from them, everything derived is recomputed on next use."""
+        self._logits = None
+        if self._subs is None:
+            return
+        for (si, ti), (sub, (w1s, b1s, w2s, b2s)) in self._subs.items():
+            (s0, s1), (t0, t1) = self.h_slices[si], self.c_slices[ti]
+            w1s.copy_(self.w1[:, s0:s1]); b1s.copy_(self.b1[s0:s1])
+            w2s.copy_(self.w2[s0:s1, t0:t1]); b2s.copy_(self.b2[t0:t1])
+            sub.refresh("sparse" if mode == "full" else mode)
 
     def shard_refresh(self, enable=True):
         return self
@@ -268,31 +319,26 @@ class WideBaseline:
     shard_refresh_fp64 = shard_refresh
 
     def enable_fp64(self):
+        self._fp64 = True
         return self
 
     def fp64_route(self) -> int:
         return -1
 
-    def _rest(self, s1):
-        h1 = spmm(self.graph, s1, self.b1, relu=True)
-        return spmm(self.graph, gemm(h1, self.w2), self.b2)
-
-    def _ensure(self):
-        if self._s1 is None:
-            self._s1 = gemm(self.x, self.w1)
-            self._out = self._rest(self._s1)
-
     def logits(self) -> torch.Tensor:
-        self._ensure()
-        return self._out.clone()
+        """GraphConvolution.forward x 2 on the unfused HIP layers (gcn/layers.py:30-36: any width)."""
+        if self._logits is None:
+            h1 = spmm(self.graph, gemm(self.x, self.w1), self.b1, relu=True)
+            self._logits = spmm(self.graph, gemm(h1, self.w2), self.b2)
+        return self._logits.clone()
 
-    def influence_rows(self, probe_nodes, observe_nodes, delta: float, mode="sparse", out=None) -> torch.Tensor:
-        if mode not in ("sparse", "full", 0, 1, None):
-            raise NotImplementedError("layers wider than 256 hidden units / 8 classes run the reference's fp32 finite difference "
-                                      "('sparse' / 'full') on the unfused HIP layers; there is no 'delta' propagation for them")
+    def influence_rows(self, probe_nodes, observe_nodes, delta: float, mode="delta", out=None) -> torch.Tensor:
+        m = _lib.MODES[mode or "delta"] if isinstance(mode, str) or mode is None else int(mode)
+        if m == _lib.MODE_FULL:
+            m = _lib.MODE_SPARSE            # the same quantity, bit for bit (lt_influence_rows_vec has no FULL form)
         dev = self.x.device
-        probes = _as_nodes(probe_nodes, self.n, dev, "probe_nodes").long()
-        obs = _as_nodes(observe_nodes, self.n, dev, "observe_nodes").long()
+        probes = _as_nodes(probe_nodes, self.n, dev, "probe_nodes")
+        obs = _as_nodes(observe_nodes, self.n, dev, "observe_nodes")
         npb, nob = probes.numel(), obs.numel()
         if out is None:
             out = torch.empty((npb, nob), dtype=torch.float32, device=dev)
@@ -300,16 +346,24 @@ class WideBaseline:
             raise ValueError("out must be a contiguous float32 [n_probe, n_obs] tensor")
         if npb == 0 or nob == 0:
             return out
-        self._ensure()
-        base = self._out[obs]
-        s1p = self._s1.clone()
-        d = float(delta)
-        for i in range(npb):
-            v = int(probes[i])
-            xv = self.x[v]
-            s1p[v] = gemm((xv + xv * d)[None, :].contiguous(), self.w1)[0]      # two roundings, as attacker.py:103,105
-            out[i] = ((self._rest(s1p)[obs] - base) / d).norm(dim=1)
-            s1p[v] = self._s1[v]
+        self._build()
+        key = (npb, nob)
+        if self._buf.get("key") != key:
+            self._buf = {"key": key, "norm": torch.empty((npb, nob), dtype=torch.float32, device=dev),
+                         "vec": [torch.empty((npb, nob, 8), dtype=torch.float32, device=dev) for _ in self.h_slices]}
+        n_s = len(self.h_slices)
+        ptrs = (C.c_void_p * n_s)()
+        for ti, (t0, t1) in enumerate(self.c_slices):
+            ct = t1 - t0
+            for si in range(n_s):
+                sub = self._subs[(si, ti)][0]
+                if m == _lib.MODE_DELTA:
+                    sub.enable_fp64()
+                vec = self._buf["vec"][si]          # used as [npb, nob, ct] dense
+                sub.influence_rows_vec(probes, obs, delta, m, self._buf["norm"], vec)
+                ptrs[si] = vec.data_ptr()
+            _lib.check(_lib.lib().lt_wide_combine(ptrs, n_s, npb * nob, ct, float(delta), out.data_ptr(), int(ti == 0),
+                                                  int(ti == len(self.c_slices) - 1), _stream()), "lt_wide_combine")
         return out
 
 

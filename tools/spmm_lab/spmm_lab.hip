@@ -380,6 +380,21 @@ static Work build_work(const HostCsr &g, int H, int SEG, int ordering) {
             if (sa) return colp[a.e0] < colp[b.e0];
             return (a.cnt + 15) / 16 > (b.cnt + 15) / 16;
         });
+        if (ordering == 3) {
+            // short rows: by length class, then by the column of their first entry (does a sweep help them as it helps the segments?)
+            std::stable_sort(items.begin(), items.end(), [n, colp](const Item &a, const Item &b) {
+                const bool sa = a.dst >= n, sb = b.dst >= n;
+                if (sa != sb) return sa;
+                if (sa) return false;
+                const int ca = (a.cnt + 15) / 16, cb = (b.cnt + 15) / 16;
+                if (ca != cb) return ca > cb;
+                return colp[a.e0 + a.cnt / 2] < colp[b.e0 + b.cnt / 2];     // median column
+            });
+        }
+        if (ordering == 4) {
+            // short rows FIRST (hot columns stay in L2 while nothing sweeps it), the segments after them
+            std::stable_partition(items.begin(), items.end(), [n](const Item &a) { return a.dst < n; });
+        }
         if (ordering == 2) {
             // blocks of 16 items are dealt to a slice's two XCDs alternately (chunk parity): give the even chunks the
             // first half of the column-ordered segments and the odd chunks the second half
@@ -411,13 +426,14 @@ struct Ctx {
     Work work;
     Work work_col;   // segments ordered by first column
     Work work_half;  // ... and dealt so that each of a slice's two XCDs sweeps its own half of the column range
+    Work work_o3, work_o4;   // round-4 orderings (build_work)
     lt_graph *lg;
     unsigned *sink;  // [n_items * 8] of the gather ceilings
 };
 
 template <int GL, int U, int ORDER = 2>
 static void run_ceiling(Ctx &c, hipStream_t st) {
-    Work &W = ORDER == 2 ? c.work_half : (ORDER ? c.work_col : c.work);
+    Work &W = ORDER == 4 ? c.work_o4 : (ORDER == 3 ? c.work_o3 : (ORDER == 2 ? c.work_half : (ORDER ? c.work_col : c.work)));
     const int ns = c.H / (4 * GL) > 0 ? (c.H + 4 * GL - 1) / (4 * GL) : 1;
     const int xps = 8 / ns;
     constexpr int IPB = 4 * (64 / GL);
@@ -489,6 +505,8 @@ int main(int argc, char **argv) {
     c.work = build_work(g, H, 128, 0);
     c.work_col = build_work(g, H, 128, 1);
     CK(hipMalloc((void **)&c.sink, ((size_t)g.col.size() / 8 + (size_t)g.n + 1024) * 8 * sizeof(unsigned)));
+    c.work_o3 = build_work(g, H, 128, 3);
+    c.work_o4 = build_work(g, H, 128, 4);
     c.work_half = build_work(g, H, 128, 2);   // the library's canonical order: 128-entry segments added in order (lt_rows.cuh row_dot)
     {
         // hot sets by in-degree (= row length: the matrix is symmetric)
@@ -548,6 +566,9 @@ int main(int argc, char **argv) {
         {"ceil32_u16", run_ceiling<32, 16>},
         {"ceil64_u8", run_ceiling<64, 8>},
         {"ceil16_u8_len", run_ceiling<16, 8, 0>},
+        {"ceil16_u8_col", run_ceiling<16, 8, 1>},
+        {"ceil16_u8_o3", run_ceiling<16, 8, 3>},
+        {"ceil16_u8_o4", run_ceiling<16, 8, 4>},
     };
     hipStream_t st;
     CK(hipStreamCreate(&st));
@@ -556,7 +577,18 @@ int main(int argc, char **argv) {
     bool have_ref = false;
     std::vector<float> h_ref, h_out;
     for (auto &v : vs) {
-        if (only[0] && !strstr(only, v.name) && strcmp(v.name, "lib") != 0) continue;
+        if (only[0] && strcmp(v.name, "lib") != 0) {
+            // comma-separated tokens; a token selects the variants whose name it is a prefix of
+            bool sel = false;
+            std::string o(only);
+            for (size_t b = 0; b < o.size();) {
+                size_t e = o.find(',', b);
+                if (e == std::string::npos) e = o.size();
+                if (e > b && strncmp(v.name, o.c_str() + b, e - b) == 0) sel = true;
+                b = e + 1;
+            }
+            if (!sel) continue;
+        }
         CK(hipMemsetAsync(c.out, 0xff, (size_t)g.n * H * sizeof(float), st));
         v.fn(c, st);
         CK(hipStreamSynchronize(st));
