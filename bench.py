@@ -321,6 +321,9 @@ def main():
         shard["pairs_per_s_delta_incl_baseline"] = round(512 * 4096 / (shard["delta_incl_baseline_ms"] * 1e-3), 1)
         return shard
 
+    def tiled_route(gb_, hcols):
+        return bool(_lib.lib().lt_spmm_route(gb_.handle, hcols))
+
     def spmm_rmat_leg(scale, hcols, reps=10, with_shard=True):
         """Standalone SpMM (lt_spmm_csr_f32) on an R-MAT graph whose S exceeds every cache: the 'SpMM HBM GB/s' half of
         the metric, at BASELINE configs[4] size by default.  Kernel time from HIP events on the launch stream."""
@@ -339,11 +342,44 @@ def main():
         _lib.lib().lt_profile_enable(0)
         sec = tot / cnt * 1e-3
         byts = spmm_bytes(big.shape[0], big.nnz, hcols)
+        # the gather ceiling (lt_spmm_gather_ceiling): the timed kernel with everything but its gathers removed -- same work
+        # items, order, column stream, slice placement, piece size; then the same with the result rows stored as well
+        ceiling = None
+        if tiled_route(gb, hcols):
+            sink = torch.empty(int(_lib.lib().lt_spmm_gather_ceiling_bytes(gb.handle)), dtype=torch.uint8, device=dev)
+            outc = torch.empty((big.shape[0], hcols), dtype=torch.float32, device=dev)
+
+            def ceiling_ms(in_flight, with_stores, reps_=5):
+                def one():
+                    _lib.check(_lib.lib().lt_spmm_gather_ceiling(gb.handle, sb.data_ptr(), hcols, hcols, in_flight, sink.data_ptr(), sink.numel(),
+                                                                 outc.data_ptr() if with_stores else None, hcols,
+                                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), "lt_spmm_gather_ceiling")
+                one()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps_):
+                    one()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / reps_
+            g_ms = {u: ceiling_ms(u, False) for u in (8, 16)}
+            gs_ms = {u: ceiling_ms(u, True) for u in (8, 16)}
+            best, best_s = min(g_ms.values()), min(gs_ms.values())
+            ceiling = {"gathers_only_ms": round(best, 3), "gathers_plus_result_stores_ms": round(best_s, 3),
+                       "by_gathers_in_flight": {str(u): round(v, 3) for u, v in g_ms.items()},
+                       "kernel_ms": round(sec * 1e3, 3),
+                       "kernel_reaches_of_gather_ceiling": round(best / (sec * 1e3), 4),
+                       "kernel_reaches_of_gather_plus_store_ceiling": round(best_s / (sec * 1e3), 4),
+                       "ceiling_as_frac_of_hbm_roofline": round(byts / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       "note": "k_rows_tiled with its val stream, fmaf chains and result rows removed (XOR-folded loads): what the memory "
+                               "system needs for THIS index stream at THIS hit distribution -- no row-gather SpMM issuing these gathers runs "
+                               "faster; tools/spmm_lab holds the other geometries tried (8 / 32 / 64 lanes per item are all slower)"}
+            del sink, outc
         del sb
         shard = influence_shard(gb, big.shape[0], scale, hcols) if with_shard else None
         tr = traffic_of("spmm", f"spmm_rmat{scale}")
-        tiled = bool(_lib.lib().lt_spmm_route(gb.handle, hcols))          # the route the call actually took
-        return {"influence_shard": shard,
+        tiled = tiled_route(gb, hcols)          # the route the call actually took
+        return {"influence_shard": shard, "gather_ceiling": ceiling,
                 "kernel": ("k_rows_tiled (+ k_spmm_long_combine for the hub rows)" if tiled else "k_spmm_rows (+ k_spmm_segments / k_spmm_long_combine for the hub rows)"),
                 "bound": "hbm",
                 # the HBM-side rate of the bytes the kernel really moves (PMC traffic over the measured duration)

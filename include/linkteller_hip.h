@@ -89,6 +89,9 @@ int lt_device_count(int *count);
  *                         fixed point with one scale per row (31 bits against the row's largest value; half the bytes the fp64
  *                         SpMM gathers) and the pre-activation in fp32 (default), 0 = both in fp64.  Moves `delta` results by
  *                         < 1e-6 of the largest score (plain fp32 rows moved them by up to 7e-5: DESIGN.md 5d)
+ *   "fd_vec4"             feature-difference route: 1 (default) = the rows of X are read with 16-byte loads and compared four columns
+ *                         per step, 0 = the 8- / 4-byte forms of round 3.  NOT bit-identical: the order in which a row's differing
+ *                         columns are listed -- an fp64 summation order -- differs (both within 1e-6 of the fp64 oracle).
  *   "defer_cref"          feature-difference route: 1 = the reference vector's product m W1 is formed by extra blocks of the rows'
  *                         launch and added by the readers of S1d (the fp64 SpMM, stage A) (default), 0 = formed first and added
  *                         by the rows kernel.  fp64 summation order only, like "feature_delta"
@@ -211,10 +214,11 @@ int lt_influence_rows(const lt_baseline *b, const int32_t *probe_nodes, int32_t 
  * items, order, column stream, slice placement and piece size, `in_flight` (8 = the kernel's own, or 16) gathers per lane;
  * no values, no arithmetic, no result rows.  Its duration bounds from below ANY row-gather SpMM that issues this index
  * stream -- what bench.py reports as roofline_spmm.gather_ceiling next to the kernel it bounds.  `sink`: device scratch
- * of lt_spmm_gather_ceiling_bytes(g) bytes (one word per item and slice keeps the loads alive). */
+ * of lt_spmm_gather_ceiling_bytes(g) bytes (one word per item and slice keeps the loads alive).  `out` != NULL ([n, ldo]
+ * fp32): the result rows are stored as the real kernel stores them (their content is meaningless): gathers + result stores. */
 size_t lt_spmm_gather_ceiling_bytes(const lt_graph *g);
 int lt_spmm_gather_ceiling(const lt_graph *g, const float *S, int64_t lds, int32_t ncols, int32_t in_flight,
-                           void *sink, size_t sink_bytes, void *stream);
+                           void *sink, size_t sink_bytes, float *out, int64_t ldo, void *stream);
 
 /* ---- layers wider than one pass of the fused kernels (hidden > 256 or > 8 classes) ------------------------------------
  * The reference has no width limit (gcn/layers.py:14-36, main.py:30 --hidden).  The perturbation's effect on the logits is

@@ -40,7 +40,8 @@ SIGNATURES = {
                                   C.c_void_p, C.c_int64, C.c_void_p]),
     "lt_spmm_route": (C.c_int, [C.c_void_p, C.c_int32]),
     "lt_spmm_gather_ceiling_bytes": (C.c_size_t, [C.c_void_p]),
-    "lt_spmm_gather_ceiling": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "lt_spmm_gather_ceiling": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p,
+                                         C.c_int64, C.c_void_p]),
     "lt_gcn2_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "lt_gcn2_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,

@@ -428,7 +428,10 @@ typedef float f32x2_ __attribute__((ext_vector_type(2)));
 #define FD_PU 6          // W1 rows in flight per lane while a list is walked (FD_CAP is a multiple; 8 costs the fifth wave per SIMD)
 #define FD_REF_PAD (16 * 64 * FD_WAVES + 64)   // the staging loop of k_s1d_feature_rows reads the reference vector in whole passes
 #define FD_UN 26         // loads in flight per lane in the row pass (x 128 floats: F <= 3328 is one trip)
-// VEC: floats per lane and load, 2 when the rows of X are 8-byte aligned, else 1.  ONE: the reference vector is staged in one
+// VEC: floats per lane and load: 4 (round 4: 13 loads of 16 bytes per row trip; rows need no alignment, the loads are declared
+// 4-byte aligned -- and ONE compare step per load: a 16-byte LDS read of the reference vector, four compares, one branch round
+// the appends of the four; with VEC = 2 the row's 52 compare steps were 52 dependent LDS round trips + 52 branches, 6.3 of the
+// kernel's 21 us), 2 when the rows of X are 8-byte aligned, else 1.  ONE: the reference vector is staged in one
 // pass (F <= 16 * 64 * FD_WAVES = 4096) -- no loop then, which hipcc needs to keep the row's loads in flight across the
 // staging (a path through a loop in front of the compare steps makes it wait for everything there).
 template <int VEC, bool ONE>
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
         return;
     }
     float *sref = reinterpret_cast<float *>(fd_smem);                              // [Fp] the reference vector
-    const int Fp = (F + 1) & ~1;
+    const int Fp = (F + 3) & ~3;
     double *ldv = reinterpret_cast<double *>(fd_smem + (((size_t)Fp * 4 + 15) & ~(size_t)15));   // [FD_WAVES][FD_CAP]
     int *lj = reinterpret_cast<int *>(ldv + FD_WAVES * FD_CAP);                    // [FD_WAVES][FD_CAP]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -531,23 +534,29 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     // row's 26 loads (s_waitcnt vmcnt(0) in front of each: the pass took 24 us against 12 us for the same reads issued back
     // to back, tools/read_lab).  Lanes past the end of the row read the row's last pair instead (valid memory) and are
     // masked by `j < F` when the values are compared.
-    float x[FD_UN][VEC];
+    constexpr int UN = VEC == 4 ? FD_UN / 2 : FD_UN;        // loads per trip: the same T floats per trip for VEC = 2 and 4
+    float x[UN][VEC];
     // The loads are constant offsets from ONE base address (26 individually clamped addresses cost 52 VGPRs and the kernel
     // its fifth wave per SIMD), so a trip reads T = FD_UN * STEP floats whatever F is: past the end of the row into the
     // following rows (valid memory, masked by `j < F` later).  Near the END of X there is nothing behind: the window of
     // such a trip is shifted left so that it ends with the matrix (it then starts in earlier elements: masked by `j >= j0`).
     // The host takes this route only when X holds at least T floats.
-    constexpr int T = FD_UN * STEP;
+    constexpr int T = UN * STEP;
     const long total_floats = (long)(n - 1) * ldx + F;
     const long off_i = (long)(live ? i : 0) * ldx;
     int shift = 0;                                  // wave-uniform, of the trip in flight (even when VEC == 2)
     auto load_trip = [&](int j0) {
         const long over = off_i + j0 + T - total_floats;
         shift = over > 0 ? (int)over : 0;
+        if constexpr (VEC == 4) shift = (shift + 3) & ~3;      // (keeps the 16-byte reads of the reference vector aligned)
         const float *p = xr + j0 + lane * VEC - shift;
 #pragma unroll
-        for (int u = 0; u < FD_UN; ++u) {
-            if constexpr (VEC == 2) {
+        for (int u = 0; u < UN; ++u) {
+            if constexpr (VEC == 4) {
+                typedef float f32x4u_ __attribute__((ext_vector_type(4), aligned(4)));
+                const f32x4u_ t = *reinterpret_cast<const f32x4u_ *>(p + u * STEP);
+                x[u][0] = t.x; x[u][1] = t.y; x[u][2] = t.z; x[u][3] = t.w;
+            } else if constexpr (VEC == 2) {
                 const f32x2_ t = *reinterpret_cast<const f32x2_ *>(p + u * STEP);
                 x[u][0] = t.x; x[u][1] = t.y;
             } else {
@@ -620,10 +629,35 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     const unsigned long long lt = (1ull << lane) - 1ull;
     // pass 1 (the common case is all there is); differing columns beyond the list's capacity are only counted
     int total = 0;                                  // wave-uniform: differing columns of the row
-    for (int j0 = 0; j0 < F; j0 += STEP * FD_UN) {
+    for (int j0 = 0; j0 < F; j0 += STEP * UN) {
         if (j0 > 0) load_trip(j0);
+        if constexpr (VEC == 4) {
 #pragma unroll
-        for (int u = 0; u < FD_UN; ++u) {
+            for (int u = 0; u < UN; ++u) {
+                const int jb = j0 + u * STEP + lane * 4 - shift;          // a multiple of 4
+                const f32x4 r = *reinterpret_cast<const f32x4 *>(sref + min(max(jb, 0), Fp - 4));
+                bool d[4];
+                unsigned long long m[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    d[v] = jb + v >= j0 && jb + v < F && x[u][v] != r[v];
+                    m[v] = __ballot(d[v]);
+                }
+                if ((m[0] | m[1]) | (m[2] | m[3])) {        // wave-uniform: two of three steps find nothing at twitch density
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        if (m[v]) {
+                            const int pos = total + __popcll(m[v] & lt);
+                            if (d[v] && pos < FD_CAP) { mj[pos] = jb + v; mv[pos] = (double)x[u][v] - (double)r[v]; }
+                            total += __popcll(m[v]);
+                        }
+                    }
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 const int j = j0 + u * STEP + lane * VEC + v - shift;
@@ -678,7 +712,7 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     else if (own) *reinterpret_cast<f64x4 *>(S1d + (size_t)i * Hp + c0) = o;
 }
 static size_t fd_smem_bytes(int F) {
-    const size_t Fp = (size_t)((F + 1) & ~1);
+    const size_t Fp = (size_t)((F + 3) & ~3);
     const size_t need = ((Fp * 4 + 15) & ~(size_t)15) + (size_t)FD_WAVES * FD_CAP * (sizeof(double) + sizeof(int));
     return need < 8192 ? 8192 : need;      // (the slab blocks of the deferred-cref launch use 4 x 256 doubles of it)
 }
@@ -1034,11 +1068,15 @@ static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, b
     const unsigned blocks = (unsigned)((n + FD_WAVES - 1) / FD_WAVES + nslab);
     const size_t smem = fd_smem_bytes(F);
     const bool vec2 = b->ldx % 2 == 0 && F % 2 == 0 && ((uintptr_t)b->X % 8) == 0, one = F <= 16 * 64 * FD_WAVES;
+    // 16-byte loads (declared 4-byte aligned: any ldx): X must hold a whole trip + the 3 floats the window's shift is rounded up by
+    const bool vec4 = lt_tune().fd_vec4 != 0 && F >= 4 && (long)(n - 1) * b->ldx + F >= (long)(FD_UN / 2) * 256 + 4;
 #define LT_FD_LAUNCH(V_, O_)                                                                                                  \
     hipLaunchKernelGGL((k_s1d_feature_rows<V_, O_>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx, \
                        b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs, zstate, s1x,           \
                        defer ? (unsigned *)b->fd_gate : (unsigned *)nullptr, b->fd_cref, b->S1qs)
-    if (vec2 && one) LT_FD_LAUNCH(2, true);
+    if (vec4 && one) LT_FD_LAUNCH(4, true);
+    else if (vec4) LT_FD_LAUNCH(4, false);
+    else if (vec2 && one) LT_FD_LAUNCH(2, true);
     else if (vec2) LT_FD_LAUNCH(2, false);
     else if (one) LT_FD_LAUNCH(1, true);
     else LT_FD_LAUNCH(1, false);

@@ -383,7 +383,8 @@ int lt_launch_rows_tiled(const lt_graph *g, const float *S, int64_t lds, int nco
 template <int U, bool BIG>
 __global__ __launch_bounds__(LT_BLOCK) void k_rows_tiled_gathers_only(
     int n_items, const int32_t *__restrict__ w_e0, const int32_t *__restrict__ w_cnt, const int32_t *__restrict__ col,
-    const float *__restrict__ S, long lds, int ncols, unsigned *__restrict__ sink, int ns) {
+    const float *__restrict__ S, long lds, int ncols, unsigned *__restrict__ sink, int ns,
+    const int32_t *__restrict__ w_dst, int n, float *__restrict__ out, long ldo) {
     constexpr int GL = LT_TILE_GL;
     constexpr int GPW = 64 / GL, IPB = (LT_BLOCK / 64) * GPW;
     const int lane = threadIdx.x & 63;
@@ -430,6 +431,11 @@ __global__ __launch_bounds__(LT_BLOCK) void k_rows_tiled_gathers_only(
         });
     }
     if (active && j == 0) sink[(size_t)it * ns + slice] = x.x ^ x.y ^ x.z ^ x.w;
+    // out != NULL: the result rows leave as in the real kernel (16 bytes per lane, non-temporal) -- "gathers + result stores"
+    if (out != nullptr && active) {
+        const int dst = __builtin_nontemporal_load(w_dst + it);
+        if (dst < n) __builtin_nontemporal_store(x, reinterpret_cast<u32x4 *>(out + (size_t)dst * ldo + coff));
+    }
 }
 
 extern "C" size_t lt_spmm_gather_ceiling_bytes(const lt_graph *g) {
@@ -437,11 +443,12 @@ extern "C" size_t lt_spmm_gather_ceiling_bytes(const lt_graph *g) {
 }
 
 extern "C" int lt_spmm_gather_ceiling(const lt_graph *g, const float *S, int64_t lds, int32_t ncols, int32_t in_flight,
-                                      void *sink, size_t sink_bytes, void *stream) {
+                                      void *sink, size_t sink_bytes, float *out, int64_t ldo, void *stream) {
     LT_REQUIRE(g != nullptr && S != nullptr && sink != nullptr, "lt_spmm_gather_ceiling: NULL pointer");
     LT_REQUIRE(ncols > 0 && ncols % 4 == 0 && ncols <= 4 * LT_TILE_GL * 4 && lds >= ncols,
                "lt_spmm_gather_ceiling: ncols=%d (a multiple of 4 up to %d, one pass of the tiled kernel)", ncols, 16 * LT_TILE_GL);
     LT_REQUIRE(in_flight == 8 || in_flight == 16, "lt_spmm_gather_ceiling: in_flight = 8 (the kernel's own) or 16");
+    LT_REQUIRE(out == nullptr || (ldo >= ncols && ldo % 4 == 0 && (uintptr_t)out % 16 == 0), "lt_spmm_gather_ceiling: out / ldo");
     LT_REQUIRE(sink_bytes >= lt_spmm_gather_ceiling_bytes(g), "lt_spmm_gather_ceiling: sink needs %zu bytes", lt_spmm_gather_ceiling_bytes(g));
     if (g->w_n == 0) return LT_OK;
     int ns = (ncols + 4 * LT_TILE_GL - 1) / (4 * LT_TILE_GL);
@@ -455,7 +462,7 @@ extern "C" int lt_spmm_gather_ceiling(const lt_graph *g, const float *S, int64_t
     hipStream_t st = (hipStream_t)stream;
 #define LT_GC_LAUNCH(U_, BIG_)                                                                                          \
     hipLaunchKernelGGL((k_rows_tiled_gathers_only<U_, BIG_>), dim3((unsigned)grid), dim3(LT_BLOCK), 0, st, g->w_n, g->w_e0, \
-                       g->w_cnt, g->col, S, (long)lds, ncols, (unsigned *)sink, ns)
+                       g->w_cnt, g->col, S, (long)lds, ncols, (unsigned *)sink, ns, g->w_dst, g->n, out, (long)ldo)
     if (in_flight == 8) { if (big) LT_GC_LAUNCH(8, true); else LT_GC_LAUNCH(8, false); }
     else { if (big) LT_GC_LAUNCH(16, true); else LT_GC_LAUNCH(16, false); }
 #undef LT_GC_LAUNCH

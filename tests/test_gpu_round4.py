@@ -286,3 +286,41 @@ def test_fp32_modes_meet_the_reference_noise_over_the_whole_matrix(gpu, key):
           f"full: max ratio {r_max:.4f}, rms ratio {r_rms:.4f}; delta error {np.abs(res['delta'] - ref64).max():.2e}")
     noise_gate(f"whole.{key}.full_rms", r_rms, ceiling=1.10)
     noise_gate(f"whole.{key}.full_max", r_max, ceiling=1.10)
+
+
+def test_gather_ceiling_entry_point(gpu):
+    """lt_spmm_gather_ceiling (measurement support for bench.py's roofline_spmm.gather_ceiling): runs on the graph's own
+    work items for both depths, with and without the result stores; argument errors come back as statuses."""
+    import ctypes as C
+    from linkteller_amd import _lib, engine, graph, synth
+    a_hat = graph.first_order_gcn(synth.rmat_graph(13, synth.rmat_draws(13), seed=42))
+    hg = graph.HipGraph(a_hat)
+    n, h = a_hat.shape[0], 256
+    s = torch.randn((n, h), device=gpu)
+    L = _lib.lib()
+    need = int(L.lt_spmm_gather_ceiling_bytes(hg.handle))
+    assert need >= a_hat.shape[0] * 4
+    sink = torch.zeros(need, dtype=torch.uint8, device=gpu)
+    out = torch.full((n, h), float("nan"), dtype=torch.float32, device=gpu)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for u in (8, 16):
+        _lib.check(L.lt_spmm_gather_ceiling(hg.handle, s.data_ptr(), h, h, u, sink.data_ptr(), need, None, 0, st))
+        _lib.check(L.lt_spmm_gather_ceiling(hg.handle, s.data_ptr(), h, h, u, sink.data_ptr(), need, out.data_ptr(), h, st))
+    torch.cuda.synchronize()
+    assert int(sink.view(torch.int32).ne(0).sum()) > 0            # the XOR words of the gathered rows landed
+    short = np.diff(a_hat.indptr) <= 128
+    assert not bool(torch.isnan(out[torch.from_numpy(short).to(gpu)]).any())   # every short row's slot was stored
+    assert L.lt_spmm_gather_ceiling(hg.handle, s.data_ptr(), h, h, 12, sink.data_ptr(), need, None, 0, st) == -1
+    assert L.lt_spmm_gather_ceiling(hg.handle, s.data_ptr(), h, h, 8, sink.data_ptr(), need - 64, None, 0, st) == -1
+    # the real kernel still gives the row kernels' bits next to it (sanity that the shared work items were not disturbed)
+    _lib.set_tuning("tiled_min_bytes", 0)
+    try:
+        tiled = engine.spmm(hg, s)
+    finally:
+        _lib.set_tuning("tiled_min_bytes", None)
+    _lib.set_tuning("tiled_min_bytes", 1 << 60)
+    try:
+        rows = engine.spmm(hg, s)
+    finally:
+        _lib.set_tuning("tiled_min_bytes", None)
+    assert torch.equal(tiled, rows)
