@@ -122,7 +122,9 @@ int lt_graph_destroy(lt_graph *g);
 int lt_graph_info(const lt_graph *g, int32_t *n, int64_t *nnz, int32_t *max_row_nnz);
 
 /* ---- dense GEMM C[M,N] = A[M,K] * B[K,N]  (torch.mm at gcn/layers.py:31) ----------------
- * exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): each output is a k-ordered fmaf chain. */
+ * exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): each output is the ordered sum of k-ordered fmaf chains of 128 terms
+ * (one chain per 128 k's, each started from +0: the rounding of a K = 3170 product stays at the level of a blocked CPU
+ * sgemm, which is what keeps the fp32 finite difference of FULL / SPARSE inside the reference's own noise). */
 int lt_gemm_f32(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
                 int32_t M, int32_t N, int32_t K, void *stream);
 

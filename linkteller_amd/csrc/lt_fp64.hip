@@ -548,7 +548,8 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     auto load_trip = [&](int j0) {
         const long over = off_i + j0 + T - total_floats;
         shift = over > 0 ? (int)over : 0;
-        if constexpr (VEC == 4) shift = (shift + 3) & ~3;      // (keeps the 16-byte reads of the reference vector aligned)
+        if constexpr (VEC == 4) shift = __builtin_amdgcn_readfirstlane((shift + 3) & ~3);   // (16-byte aligned reads of the reference
+                                                                                            // vector; a SCALAR for the lane masks below)
         const float *p = xr + j0 + lane * VEC - shift;
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -632,23 +633,31 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     for (int j0 = 0; j0 < F; j0 += STEP * UN) {
         if (j0 > 0) load_trip(j0);
         if constexpr (VEC == 4) {
+            // lanes below `k` (0 .. 64)
+            auto lanes_below = [](int k) -> unsigned long long { return k >= 64 ? ~0ull : (k <= 0 ? 0ull : (1ull << k) - 1ull); };
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const int jb = j0 + u * STEP + lane * 4 - shift;          // a multiple of 4
+                const int base = j0 + u * STEP - shift;                   // wave-uniform; lane l holds columns base + 4 l + v
+                const int jb = base + lane * 4;                           // a multiple of 4
                 const f32x4 r = *reinterpret_cast<const f32x4 *>(sref + min(max(jb, 0), Fp - 4));
-                bool d[4];
                 unsigned long long m[4];
+                if (base >= j0 && base + STEP <= F) {                     // (wave-uniform) every lane holds columns of this row: all
+#pragma unroll                                                            // but the last step of a trip and the shifted windows
+                    for (int v = 0; v < 4; ++v) m[v] = __ballot(x[u][v] != r[v]);   // (one v_cmp: the compare IS the ballot)
+                } else {
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    d[v] = jb + v >= j0 && jb + v < F && x[u][v] != r[v];
-                    m[v] = __ballot(d[v]);
+                    for (int v = 0; v < 4; ++v) {
+                        // which lanes hold a column of THIS trip of THIS row (j0 <= j < F) is scalar arithmetic: a lane range
+                        const unsigned long long valid = lanes_below((F - base - v + 3) >> 2) & ~lanes_below((j0 - base - v + 3) >> 2);
+                        m[v] = __ballot(x[u][v] != r[v]) & valid;
+                    }
                 }
-                if ((m[0] | m[1]) | (m[2] | m[3])) {        // wave-uniform: two of three steps find nothing at twitch density
+                if ((m[0] | m[1]) | (m[2] | m[3])) {        // wave-uniform
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         if (m[v]) {
                             const int pos = total + __popcll(m[v] & lt);
-                            if (d[v] && pos < FD_CAP) { mj[pos] = jb + v; mv[pos] = (double)x[u][v] - (double)r[v]; }
+                            if (((m[v] >> lane) & 1ull) && pos < FD_CAP) { mj[pos] = jb + v; mv[pos] = (double)x[u][v] - (double)r[v]; }
                             total += __popcll(m[v]);
                         }
                     }
