@@ -89,9 +89,6 @@ int lt_device_count(int *count);
  *                         fixed point with one scale per row (31 bits against the row's largest value; half the bytes the fp64
  *                         SpMM gathers) and the pre-activation in fp32 (default), 0 = both in fp64.  Moves `delta` results by
  *                         < 1e-6 of the largest score (plain fp32 rows moved them by up to 7e-5: DESIGN.md 5d)
- *   "fd_vec4"             feature-difference route: 1 (default) = the rows of X are read with 16-byte loads and compared four columns
- *                         per step, 0 = the 8- / 4-byte forms of round 3.  NOT bit-identical: the order in which a row's differing
- *                         columns are listed -- an fp64 summation order -- differs (both within 1e-6 of the fp64 oracle).
  *   "defer_cref"          feature-difference route: 1 = the reference vector's product m W1 is formed by extra blocks of the rows'
  *                         launch and added by the readers of S1d (the fp64 SpMM, stage A) (default), 0 = formed first and added
  *                         by the rows kernel.  fp64 summation order only, like "feature_delta"

@@ -423,15 +423,25 @@ __global__ void k_spmm_f64_long(int n_long, const int32_t *__restrict__ long_row
 //                       sets *dense_hint -- a word of mapped host memory the host looks at before the NEXT refresh to move
 //                       the baseline to the matrix-core product for good.
 typedef float f32x2_ __attribute__((ext_vector_type(2)));
+#ifdef LT_FD_TRACE      // tools/read_lab/feat_lab.hip: phase stamps of every row wave on the constant 100 MHz clock
+__device__ unsigned long long *g_fd_trace = nullptr;
+#define FD_STAMP(k_)                                                                                                   \
+    do {                                                                                                               \
+        if ((threadIdx.x & 63) == 0 && g_fd_trace)                                                                     \
+            g_fd_trace[((size_t)blockIdx.x * FD_WAVES + (threadIdx.x >> 6)) * 8 + (k_)] = wall_clock64();               \
+    } while (0)
+#else
+#define FD_STAMP(k_)
+#endif
 #define FD_CAP 384
 #define FD_WAVES 4
 #define FD_PU 6          // W1 rows in flight per lane while a list is walked (FD_CAP is a multiple; 8 costs the fifth wave per SIMD)
 #define FD_REF_PAD (16 * 64 * FD_WAVES + 64)   // the staging loop of k_s1d_feature_rows reads the reference vector in whole passes
 #define FD_UN 26         // loads in flight per lane in the row pass (x 128 floats: F <= 3328 is one trip)
-// VEC: floats per lane and load: 4 (round 4: 13 loads of 16 bytes per row trip; rows need no alignment, the loads are declared
-// 4-byte aligned -- and ONE compare step per load: a 16-byte LDS read of the reference vector, four compares, one branch round
-// the appends of the four; with VEC = 2 the row's 52 compare steps were 52 dependent LDS round trips + 52 branches, 6.3 of the
-// kernel's 21 us), 2 when the rows of X are 8-byte aligned, else 1.  ONE: the reference vector is staged in one
+// VEC: floats per lane and load, 2 when the rows of X are 8-byte aligned, else 1.  (Round 4 built VEC = 4 -- 13 loads of 16 bytes,
+// ONE compare step per load with scalar lane masks: 9 VALU per step instead of ~60 -- and removed it: 26.0 against 24.3 us by
+// events.  The compare steps are not where the time is: tools/read_lab/feat_lab.hip, profiles/r04_feat_lab_timeline.txt.)
+// ONE: the reference vector is staged in one
 // pass (F <= 16 * 64 * FD_WAVES = 4096) -- no loop then, which hipcc needs to keep the row's loads in flight across the
 // staging (a path through a loop in front of the compare steps makes it wait for everything there).
 template <int VEC, bool ONE>
@@ -520,8 +530,9 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
         if (threadIdx.x == 0) __hip_atomic_store(gate, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         return;
     }
+    FD_STAMP(0);
     float *sref = reinterpret_cast<float *>(fd_smem);                              // [Fp] the reference vector
-    const int Fp = (F + 3) & ~3;
+    const int Fp = (F + 1) & ~1;
     double *ldv = reinterpret_cast<double *>(fd_smem + (((size_t)Fp * 4 + 15) & ~(size_t)15));   // [FD_WAVES][FD_CAP]
     int *lj = reinterpret_cast<int *>(ldv + FD_WAVES * FD_CAP);                    // [FD_WAVES][FD_CAP]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -534,7 +545,7 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     // row's 26 loads (s_waitcnt vmcnt(0) in front of each: the pass took 24 us against 12 us for the same reads issued back
     // to back, tools/read_lab).  Lanes past the end of the row read the row's last pair instead (valid memory) and are
     // masked by `j < F` when the values are compared.
-    constexpr int UN = VEC == 4 ? FD_UN / 2 : FD_UN;        // loads per trip: the same T floats per trip for VEC = 2 and 4
+    constexpr int UN = FD_UN;
     float x[UN][VEC];
     // The loads are constant offsets from ONE base address (26 individually clamped addresses cost 52 VGPRs and the kernel
     // its fifth wave per SIMD), so a trip reads T = FD_UN * STEP floats whatever F is: past the end of the row into the
@@ -548,16 +559,10 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     auto load_trip = [&](int j0) {
         const long over = off_i + j0 + T - total_floats;
         shift = over > 0 ? (int)over : 0;
-        if constexpr (VEC == 4) shift = __builtin_amdgcn_readfirstlane((shift + 3) & ~3);   // (16-byte aligned reads of the reference
-                                                                                            // vector; a SCALAR for the lane masks below)
         const float *p = xr + j0 + lane * VEC - shift;
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            if constexpr (VEC == 4) {
-                typedef float f32x4u_ __attribute__((ext_vector_type(4), aligned(4)));
-                const f32x4u_ t = *reinterpret_cast<const f32x4u_ *>(p + u * STEP);
-                x[u][0] = t.x; x[u][1] = t.y; x[u][2] = t.z; x[u][3] = t.w;
-            } else if constexpr (VEC == 2) {
+            if constexpr (VEC == 2) {
                 const f32x2_ t = *reinterpret_cast<const f32x2_ *>(p + u * STEP);
                 x[u][0] = t.x; x[u][1] = t.y;
             } else {
@@ -593,6 +598,7 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
         }
     }
     __syncthreads();
+    FD_STAMP(1);
     if (!live) return;
     double *mv = ldv + wid * FD_CAP;
     int *mj = lj + wid * FD_CAP;
@@ -632,39 +638,6 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     int total = 0;                                  // wave-uniform: differing columns of the row
     for (int j0 = 0; j0 < F; j0 += STEP * UN) {
         if (j0 > 0) load_trip(j0);
-        if constexpr (VEC == 4) {
-            // lanes below `k` (0 .. 64)
-            auto lanes_below = [](int k) -> unsigned long long { return k >= 64 ? ~0ull : (k <= 0 ? 0ull : (1ull << k) - 1ull); };
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int base = j0 + u * STEP - shift;                   // wave-uniform; lane l holds columns base + 4 l + v
-                const int jb = base + lane * 4;                           // a multiple of 4
-                const f32x4 r = *reinterpret_cast<const f32x4 *>(sref + min(max(jb, 0), Fp - 4));
-                unsigned long long m[4];
-                if (base >= j0 && base + STEP <= F) {                     // (wave-uniform) every lane holds columns of this row: all
-#pragma unroll                                                            // but the last step of a trip and the shifted windows
-                    for (int v = 0; v < 4; ++v) m[v] = __ballot(x[u][v] != r[v]);   // (one v_cmp: the compare IS the ballot)
-                } else {
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        // which lanes hold a column of THIS trip of THIS row (j0 <= j < F) is scalar arithmetic: a lane range
-                        const unsigned long long valid = lanes_below((F - base - v + 3) >> 2) & ~lanes_below((j0 - base - v + 3) >> 2);
-                        m[v] = __ballot(x[u][v] != r[v]) & valid;
-                    }
-                }
-                if ((m[0] | m[1]) | (m[2] | m[3])) {        // wave-uniform
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        if (m[v]) {
-                            const int pos = total + __popcll(m[v] & lt);
-                            if (((m[v] >> lane) & 1ull) && pos < FD_CAP) { mj[pos] = jb + v; mv[pos] = (double)x[u][v] - (double)r[v]; }
-                            total += __popcll(m[v]);
-                        }
-                    }
-                }
-            }
-            continue;
-        }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
 #pragma unroll
@@ -679,8 +652,11 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
                     total += __popcll(m);
                 }
             }
+            if (u == 0) FD_STAMP(2);
+            if (u == UN / 2) FD_STAMP(3);
         }
     }
+    FD_STAMP(4);
     if (total <= FD_CAP) {
         walk(total);
     } else {
@@ -696,6 +672,7 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
             walk(__popcll(m));
         }
     }
+    FD_STAMP(5);
     if (total > hint_cap && lane == 0) *dense_hint = 1;
     if (zstate && lane == 0) zstate[i] = 0;
     if (!own && !S1x) return;
@@ -719,9 +696,10 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
         if (lane == 0) S1qs[i] = scale;
     }
     else if (own) *reinterpret_cast<f64x4 *>(S1d + (size_t)i * Hp + c0) = o;
+    FD_STAMP(6);
 }
 static size_t fd_smem_bytes(int F) {
-    const size_t Fp = (size_t)((F + 3) & ~3);
+    const size_t Fp = (size_t)((F + 1) & ~1);
     const size_t need = ((Fp * 4 + 15) & ~(size_t)15) + (size_t)FD_WAVES * FD_CAP * (sizeof(double) + sizeof(int));
     return need < 8192 ? 8192 : need;      // (the slab blocks of the deferred-cref launch use 4 x 256 doubles of it)
 }
@@ -1077,15 +1055,11 @@ static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, b
     const unsigned blocks = (unsigned)((n + FD_WAVES - 1) / FD_WAVES + nslab);
     const size_t smem = fd_smem_bytes(F);
     const bool vec2 = b->ldx % 2 == 0 && F % 2 == 0 && ((uintptr_t)b->X % 8) == 0, one = F <= 16 * 64 * FD_WAVES;
-    // 16-byte loads (declared 4-byte aligned: any ldx): X must hold a whole trip + the 3 floats the window's shift is rounded up by
-    const bool vec4 = lt_tune().fd_vec4 != 0 && F >= 4 && (long)(n - 1) * b->ldx + F >= (long)(FD_UN / 2) * 256 + 4;
 #define LT_FD_LAUNCH(V_, O_)                                                                                                  \
     hipLaunchKernelGGL((k_s1d_feature_rows<V_, O_>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx, \
                        b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs, zstate, s1x,           \
                        defer ? (unsigned *)b->fd_gate : (unsigned *)nullptr, b->fd_cref, b->S1qs)
-    if (vec4 && one) LT_FD_LAUNCH(4, true);
-    else if (vec4) LT_FD_LAUNCH(4, false);
-    else if (vec2 && one) LT_FD_LAUNCH(2, true);
+    if (vec2 && one) LT_FD_LAUNCH(2, true);
     else if (vec2) LT_FD_LAUNCH(2, false);
     else if (one) LT_FD_LAUNCH(1, true);
     else LT_FD_LAUNCH(1, false);

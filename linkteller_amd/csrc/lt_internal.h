@@ -148,8 +148,6 @@ struct lt_tuning {
                                  // -1 when they do and the features are not sparse differences (LT_AGGREGATE_FIRST)
     int feature_delta;           // fp64 product X*W1 from the feature rows' differences to a reference row: 0 never, 1 always try,
                                  // -1 when the baseline's features were found to be sparse differences (LT_FEATURE_DELTA)
-    int fd_vec4;                 // feature-difference route: 1 the rows are read with 16-byte loads and compared four columns per step
-                                 // (round 4), 0 the 8- / 4-byte forms (LT_FD_VEC4; the list order -- hence the last bits -- differs)
 };
 lt_tuning &lt_tune();
 

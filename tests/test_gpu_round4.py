@@ -326,37 +326,3 @@ def test_gather_ceiling_entry_point(gpu):
     finally:
         _lib.set_tuning("tiled_min_bytes", None)
     assert torch.equal(tiled, rows)
-
-
-@pytest.mark.parametrize("n,f,h", [(900, 700, 102), (1200, 3170, 256), (500, 5000, 64), (600, 3329, 8), (40, 200, 32)])
-def test_feature_rows_with_16_byte_loads(gpu, n, f, h):
-    """k_s1d_feature_rows<4, *> (round 4): the rows of X read with 16-byte loads, four columns compared per step.  Against the
-    8- / 4-byte forms of round 3 (`fd_vec4` = 0) the list of a row's differing columns comes in another order -- an fp64
-    summation order -- so the two agree to rounding, not bit for bit; both within 1e-5 of the fp64 oracle.  Shapes: H that
-    needs padding, the twitch row length (one trip, rows 8- but not 16-byte aligned), F > 4096 (the reference vector staged in
-    several passes, two trips per row, the last rows' window shifted), F = one trip + 1, and an X smaller than one trip
-    (falls back to the narrow forms by itself); first and last nodes probed and observed (the shifted window)."""
-    from test_gpu_parity import _oracle_matrix
-    from linkteller_amd import _lib, engine, graph, synth
-    a_hat = graph.first_order_gcn(synth.powerlaw_graph(n, 4 * n, seed=2))
-    x = synth.twitch_like_features(n, f, seed=4, density=0.02)
-    w = synth.gcn_weights(f, h, 3, seed=5)
-    base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *_params(w, gpu)).enable_fp64()
-    assert base.fp64_route() == 1
-    rng = np.random.RandomState(0)
-    k = min(30, n - 3)
-    probes = np.concatenate([[n - 1, 0, n - 2], rng.choice(np.arange(1, n - 2), k, replace=False)])
-    observe = np.concatenate([[n - 1, 0], rng.choice(np.arange(1, n - 1), min(150, n - 2), replace=False)])
-    ref64 = _oracle_matrix(a_hat, x, w, probes, observe, 1e-4, torch.float64)
-    got4 = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
-    _lib.set_tuning("fd_vec4", 0)
-    try:
-        base.refresh()
-        got2 = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
-    finally:
-        _lib.set_tuning("fd_vec4", None)
-        base.refresh()
-    assert np.abs(got4 - ref64).max() <= 1e-5 * ref64.max(), np.abs(got4 - ref64).max() / ref64.max()
-    assert np.abs(got2 - ref64).max() <= 1e-5 * ref64.max()
-    assert np.abs(got4 - got2).max() <= 1e-6 * ref64.max()
-    assert np.array_equal(base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64), got4)
