@@ -110,17 +110,16 @@ def main():
             print("NOISE?", tag, f"|full-ref64| {ef:.3e}  |ref32-ref64| {e32:.3e}  scale {scale:.3e}  nonzeros {(ref64 > 0).sum()}")
         # absolute floor: an fp32 finite difference carries ~ eps * |logit| / delta = 6e-4 * |logit| of noise whatever
         # the score is; a one-entry sample of the oracle's own noise can be anything
+        # (round 4: the error of ONE entry is a handful of those steps -- one rounding of the difference to the ulp grid at every
+        # CHANGED term of the observed row's sum, NOTES.md -- so the bound allows 8 of them and fails on the first case beyond it;
+        # round 3 allowed 3 steps and tolerated one offending case in 50)
         floor = 6e-4 * max(1.0, float(np.abs(logits_ref).max()))
-        if ef > 2.0 * e32 + 1e-3 * scale + 3.0 * floor:
+        if ef > 2.0 * e32 + 1e-3 * scale + 8.0 * floor:
             k = np.unravel_index(np.abs(res["full"] - ref64).argmax(), ref64.shape)
             print("FAIL", tag, f"|full-ref64| {ef:.3e}  |ref32-ref64| {e32:.3e}  scale {scale:.3e}  floor {floor:.3e}  at {k}: full {res['full'][k]:.6e} "
                   f"delta {res['delta'][k]:.6e} ref64 {ref64[k]:.6e} ref32 {ref32[k]:.6e}; ref32 errors sorted {np.sort(np.abs(ref32 - ref64).ravel())[-4:]}; "
                   f"full errors sorted {np.sort(np.abs(res['full'] - ref64).ravel())[-4:]}")
-            # a noise heuristic on ONE sample of the reference's own fp32 error: an outlier pair now and then is expected (seed
-            # 31337, case 117: one pair of 150 at 5x); more than 1 case in 50 is not
-            noisy += 1
-            if noisy > max(1, cases // 50):
-                raise SystemExit(1)
+            raise SystemExit(1)
         for r in res.values():
             assert np.all(r[ref64 == 0] == 0), tag
         logits = base.logits().cpu().numpy().astype(np.float64)
@@ -129,7 +128,7 @@ def main():
         assert np.abs(logits - rl).max() <= 2e-5 * max(1.0, np.abs(rl).max()), tag
         worst = max(worst, ed)
         print("ok", tag, f"delta err {ed:.1e}")
-    print("all", cases, "cases ok; worst delta error", worst, "; cases whose `full` was noisier than the heuristic allows:", noisy)
+    print("all", cases, "cases ok; worst delta error", worst)
 
 
 if __name__ == "__main__":
