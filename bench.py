@@ -793,8 +793,11 @@ def main():
                     libs.add(nm)
         except OSError:
             pass
+        # (librccl.so is mapped by `import torch.distributed` alone; the `nccl-*` shared-memory segment only exists once a
+        # communicator has been brought up in this process)
         return {"backend": (dist.get_backend() if multi else None), "forced_at_world_size_1": bool(force and world == 1),
-                "librccl_mapped": any("rccl" in x for x in libs), "libs": sorted(libs)}
+                "librccl_mapped": any("rccl" in x for x in libs),
+                "communicator_segment_mapped": any(x.startswith("nccl-") for x in libs), "libs": sorted(libs)}
 
     # ---------------- CPU reference path (oracle), bounded sample, rank 0 / N=1 only -----------
     cpu = None

@@ -89,6 +89,9 @@ int lt_device_count(int *count);
  *                         fixed point with one scale per row (31 bits against the row's largest value; half the bytes the fp64
  *                         SpMM gathers) and the pre-activation in fp32 (default), 0 = both in fp64.  Moves `delta` results by
  *                         < 1e-6 of the largest score (plain fp32 rows moved them by up to 7e-5: DESIGN.md 5d)
+ *   "delta_fused"         LT_MODE_DELTA, calls with a membership-bitmap-sized graph (n <= 65534) without hub rows whose pre-activation is
+ *                         formed on all rows: 1 = stage A and stage B of a probe in ONE block -- its items from the CSC column, their
+ *                         layer-2 inputs and a 16-bit position per node in LDS (default), 0 = the item kernels
  *   "defer_cref"          feature-difference route: 1 = the reference vector's product m W1 is formed by extra blocks of the rows'
  *                         launch and added by the readers of S1d (the fp64 SpMM, stage A) (default), 0 = formed first and added
  *                         by the rows kernel.  fp64 summation order only, like "feature_delta"

@@ -54,6 +54,7 @@ static lt_tuning tuning_defaults() {
     t.z_on_demand = getenv("LT_Z_ON_DEMAND") ? (env_ll("LT_Z_ON_DEMAND", 0) != 0 ? 1 : 0) : -1;
     t.aggregate_first = getenv("LT_AGGREGATE_FIRST") ? (env_ll("LT_AGGREGATE_FIRST", 0) != 0 ? 1 : 0) : -1;
     t.feature_delta = getenv("LT_FEATURE_DELTA") ? (env_ll("LT_FEATURE_DELTA", 0) != 0 ? 1 : 0) : -1;
+    t.delta_fused = env_ll("LT_DELTA_FUSED", 1) != 0 ? 1 : 0;
     return t;
 }
 lt_tuning &lt_tune() {
@@ -86,6 +87,7 @@ extern "C" int lt_set_tuning(const char *key, long long value) {
     else if (!strcmp(key, "tiled_big")) t.tiled_big = reset ? 0 : (value != 0);
     else if (!strcmp(key, "s1_f32")) t.s1_f32 = reset ? d.s1_f32 : (value != 0);
     else if (!strcmp(key, "defer_cref")) t.defer_cref = reset ? d.defer_cref : (value != 0);
+    else if (!strcmp(key, "delta_fused")) t.delta_fused = reset ? d.delta_fused : (value != 0);
     else if (!strcmp(key, "z_on_demand")) t.z_on_demand = reset ? d.z_on_demand : (value < 0 ? -1 : (value != 0));
     else if (!strcmp(key, "stageb_rows")) t.stageb_rows = reset ? d.stageb_rows : (value != 0);
     else if (!strcmp(key, "aggregate_first")) t.aggregate_first = reset ? d.aggregate_first : (value < 0 ? -1 : (value != 0));

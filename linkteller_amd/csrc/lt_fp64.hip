@@ -1163,20 +1163,25 @@ static int form_z1d(lt_baseline *b, int32_t *state, hipStream_t st, const lt_bit
 // whose items cannot cover much of the graph (n_probe_call * average column length well below n: one rank of many) forms
 // only those rows (k_z_mark + the row kernel restricted to them; rows stay valid for later chunks and calls); otherwise all
 // rows once.  Same chains either way: the bits do not depend on which rows were asked for.
-int lt_fp64_prepare_rows(const lt_baseline *cb, const int32_t *off, int nb, const int2 *item_pr, int n_probe_call, hipStream_t st,
-                         const lt_bits_job *job, bool *job_done) {
-    lt_baseline *b = const_cast<lt_baseline *>(cb);   // cache state only
-    if (job_done) *job_done = false;
-    if (b->z_all_valid || b->n == 0) return LT_OK;
+// Would lt_fp64_prepare_rows form the pre-activation only on the rows a call of `n_probe_call` probes reads (true), or on all rows?
+bool lt_fp64_on_demand(const lt_baseline *b, int n_probe_call) {
     const lt_graph *g = b->g;
-    lt_prof_scope prof_(LT_K_FP64_SPMM, st);
     const double avg = g->n > 0 ? (double)g->nnz / (double)g->n : 0.0;
     const int knob = lt_tune().z_on_demand;
     const bool tiled = !b->cref_deferred && lt_tiled_wanted(g, b->Hp) && (g->p_n_long == 0 || b->seg_d);
     // (a graph whose whole fp64 SpMM is a 10 us launch is formed whole: marking the rows costs a memset, k_z_mark and the item
     // tables' own launch in front of it -- 55 against 50 us for the step one rank of 8 runs at twitch size)
-    const bool ondemand = !tiled && (knob > 0 || (knob < 0 && (double)n_probe_call * avg * 2.0 < (double)g->n &&
-                                                  (double)g->nnz * (double)b->Hp >= 2.5e8));
+    return !tiled && (knob > 0 || (knob < 0 && (double)n_probe_call * avg * 2.0 < (double)g->n &&
+                                   (double)g->nnz * (double)b->Hp >= 2.5e8));
+}
+
+int lt_fp64_prepare_rows(const lt_baseline *cb, const int32_t *off, int nb, const int2 *item_pr, int n_probe_call, hipStream_t st,
+                         const lt_bits_job *job, bool *job_done) {
+    lt_baseline *b = const_cast<lt_baseline *>(cb);   // cache state only
+    if (job_done) *job_done = false;
+    if (b->z_all_valid || b->n == 0) return LT_OK;
+    lt_prof_scope prof_(LT_K_FP64_SPMM, st);
+    const bool ondemand = lt_fp64_on_demand(b, n_probe_call);
     if (!ondemand) {
         const int rc = form_z1d(b, nullptr, st, job, job_done, true);
         if (rc) return rc;

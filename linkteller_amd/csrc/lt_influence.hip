@@ -1198,6 +1198,192 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_hubs(
                                         (int)gridDim.x / ((nb + LT_BLOCK / LT_L2_LANES - 1) / (LT_BLOCK / LT_L2_LANES)), vec);
 }
 
+// ---- DELTA at twitch size: stage A and stage B of ONE probe in one block (round 4; "delta_fused") ----------------------------
+// The two kernels above and below cost 12.8 + 13.4 us of a 65 us step (+ a launch gap), both latency-bound passes over
+// cache-resident operands organised by item and by observed row.  Organised by PROBE everything a probe needs fits a block:
+// its items are the CSC column of v (no item tables, no offsets), the C values each item yields go to LDS instead of a global
+// S2x, "is column c a member of R_v, and which item" is ONE 2-byte LDS read (pos[c] = position + 1, n <= 65534) instead of an
+// 8-byte global bitmap word, and the observed rows are walked 8 lanes per row exactly as k_item_stageB does -- lane q owns
+// the entries e0 + q, e0 + q + 8, ... (a k-ordered fmaf chain), the xor 4, 2, 1 butterfly, d / delta, the fmaf sum of squares.
+// Stage A's arithmetic is k_item_stageA_d2's, statement by statement.  So the matrix has the bits of the three-launch route
+// (`delta_fused` = 0; tests/test_gpu_round4.py compares them), for graphs without hub rows and calls with a bitmap-sized n.
+#define LT_DF_ROWS 4      // observed rows in flight per 8-lane group (their loads are unconditional, clamped)
+template <int LPR, int CP, bool SX, bool ZF>
+__global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_block(
+    const double *__restrict__ Z1d, const double *__restrict__ S1d, const float *__restrict__ S1x,
+    const double *__restrict__ crefv, const double *__restrict__ S1qs, const float *__restrict__ Z1x, int Hp,
+    const float *__restrict__ W2p, int C, const int32_t *__restrict__ probes, const int32_t *__restrict__ tptr,
+    const int32_t *__restrict__ trow, const float *__restrict__ tval, const int32_t *__restrict__ rowptr,
+    const int32_t *__restrict__ col, const float *__restrict__ val, const int32_t *__restrict__ observe, int n_obs, int n,
+    float delta, float *__restrict__ out, long ldo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char df_smem[];
+    unsigned short *pos = reinterpret_cast<unsigned short *>(df_smem);                       // [n] position in R_v + 1, or 0
+    float *sS2 = reinterpret_cast<float *>(df_smem + ((((size_t)n + 1) * 2 + 15) & ~(size_t)15));   // [|R_v|][C] the items' layer-2 inputs
+    constexpr int RPW = 64 / LPR, WAVES = LT_BLOCK / 64, U = 2;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int b = blockIdx.x;
+    const int v = probes[b];
+    const int t0 = tptr[v], cnt = tptr[v + 1] - t0;
+    for (int i = tid; i < (n + 1) / 2; i += LT_BLOCK) reinterpret_cast<unsigned *>(pos)[i] = 0u;      // (inside the [n + 1] shorts of `pos`)
+    // ---- stage A: this probe's items (k_item_stageA_d2) ----
+    {
+        const int gl = lane & (LPR - 1);
+        const bool active = 4 * gl < Hp;
+        const int coff = active ? 4 * gl : 0;
+        float w2[4][CP];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int c = 0; c < CP; ++c) w2[k][c] = c < C ? W2p[(size_t)(coff + k) * C + c] : 0.f;
+        // delta * S1[v, coff + k]: the probe's S1 row off the fp64 product (fixed-point rows and / or deferred reference product)
+        float ds[4];
+        {
+            double cr[4] = {0.0, 0.0, 0.0, 0.0};
+            if (crefv != nullptr) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cr[k] = crefv[coff + k];
+            }
+            if constexpr (SX) {
+                typedef int qx4 __attribute__((ext_vector_type(4)));
+                const f32x4 sx = ld4(S1x + (size_t)v * Hp + coff);
+                const double sq = S1qs[v];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ds[k] = delta * (float)((double)__builtin_bit_cast(qx4, sx)[k] * sq + cr[k]);
+            } else {
+                const f64x4 sd = *reinterpret_cast<const f64x4 *>(S1d + (size_t)v * Hp + coff);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ds[k] = delta * (crefv != nullptr ? (float)(sd[k] + cr[k]) : (float)sd[k]);
+            }
+        }
+        const int stride = WAVES * RPW;
+        for (int base = wid * RPW + lane / LPR; base < cnt; base += U * stride) {
+            int it[U], r[U];
+            float arv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                it[u] = base + u * stride;
+                const int ic = min(it[u], cnt - 1);          // past the end: the last item again, never stored
+                r[u] = trow[t0 + ic];
+                arv[u] = tval[t0 + ic];
+            }
+            f64x4 z[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if constexpr (ZF) {
+                    const f32x4 zf = ld4(Z1x + (size_t)r[u] * Hp + coff);
+                    z[u] = f64x4{(double)zf[0], (double)zf[1], (double)zf[2], (double)zf[3]};
+                } else {
+                    z[u] = *reinterpret_cast<const f64x4 *>(Z1d + (size_t)r[u] * Hp + coff);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float part[CP];
+#pragma unroll
+                for (int c = 0; c < CP; ++c) part[c] = 0.f;
+                if (active) {
+                    float dh[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float dz = arv[u] * ds[k];
+                        const double zz = z[u][k], z1 = zz + (double)dz;
+                        dh[k] = zz > 0.0 ? (z1 > 0.0 ? dz : (float)(-zz)) : (z1 > 0.0 ? (float)z1 : 0.f);
+                    }
+#pragma unroll
+                    for (int c = 0; c < CP; ++c)
+                        if (c < C) {
+                            float p = dh[0] * w2[0][c];
+                            p = fmaf(dh[1], w2[1][c], p);
+                            p = fmaf(dh[2], w2[2][c], p);
+                            p = fmaf(dh[3], w2[3][c], p);
+                            part[c] = p;
+                        }
+                }
+#pragma unroll
+                for (int c = 0; c < CP; ++c) part[c] = group_sum<LPR>(part[c]);
+                if (it[u] < cnt && gl == 0) {
+#pragma unroll
+                    for (int c = 0; c < CP; ++c)
+                        if (c < C) sS2[(size_t)it[u] * C + c] = part[c];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < cnt; i += LT_BLOCK) pos[trow[t0 + i]] = (unsigned short)(i + 1);
+    __syncthreads();
+    // ---- stage B: every observed row against this probe (k_item_stageB / k_item_stageB_rows, DELTA) ----
+    const int q = lane & (LT_L2_LANES - 1), grp = tid / LT_L2_LANES;
+    constexpr int GROUPS = LT_BLOCK / LT_L2_LANES;
+    float *orow = out + (long)b * ldo;
+    for (int j0 = grp; j0 < n_obs; j0 += GROUPS * LT_DF_ROWS) {
+        int e0[LT_DF_ROWS], d[LT_DF_ROWS], u_[LT_DF_ROWS];
+        bool mine[LT_DF_ROWS];
+#pragma unroll
+        for (int i = 0; i < LT_DF_ROWS; ++i) u_[i] = observe[min(j0 + i * GROUPS, n_obs - 1)];
+#pragma unroll
+        for (int i = 0; i < LT_DF_ROWS; ++i) {
+            e0[i] = rowptr[u_[i]];
+            d[i] = rowptr[u_[i] + 1] - e0[i];
+            mine[i] = j0 + i * GROUPS < n_obs && d[i] <= LT_ROW_SEG;        // past the end / an observed hub (its own blocks): nothing here
+            if (!mine[i]) d[i] = 0;
+        }
+        int dmax = 0;
+#pragma unroll
+        for (int i = 0; i < LT_DF_ROWS; ++i) dmax = max(dmax, d[i]);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) dmax = max(dmax, __shfl_xor(dmax, m, 64));    // wave-uniform trip count
+        float acc[LT_DF_ROWS][CP];
+        int t[LT_DF_ROWS];
+#pragma unroll
+        for (int i = 0; i < LT_DF_ROWS; ++i) {
+            t[i] = 0;
+#pragma unroll
+            for (int c = 0; c < CP; ++c) acc[i][c] = 0.f;
+        }
+        for (int k = q; k - q < dmax; k += LT_L2_LANES) {
+            int cc[LT_DF_ROWS];
+            float a[LT_DF_ROWS];
+            // unconditional loads (past a row's end: its first entry again -- the CSR arrays are padded -- never used)
+#pragma unroll
+            for (int i = 0; i < LT_DF_ROWS; ++i) {
+                const int e = e0[i] + (k < d[i] ? k : 0);
+                cc[i] = col[e];
+                a[i] = val[e];
+            }
+#pragma unroll
+            for (int i = 0; i < LT_DF_ROWS; ++i) {
+                const int p = (int)pos[min(max(cc[i], 0), n - 1)];
+                if (k < d[i] && p != 0) {
+                    const float *itv = sS2 + (size_t)(p - 1) * C;
+#pragma unroll
+                    for (int c = 0; c < CP; ++c)
+                        if (c < C) acc[i][c] = fmaf(a[i], itv[c], acc[i][c]);
+                    t[i] = 1;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LT_DF_ROWS; ++i)
+#pragma unroll
+            for (int m = LT_L2_LANES / 2; m >= 1; m >>= 1) t[i] |= __shfl_xor(t[i], m, 64);
+#pragma unroll
+        for (int i = 0; i < LT_DF_ROWS; ++i) {
+            const int j = j0 + i * GROUPS;
+            float ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < CP; ++c) {
+                const float o = group_sum<LT_L2_LANES>(acc[i][c]);
+                if (c < C) {
+                    const float dd = o / delta;
+                    ss = fmaf(dd, dd, ss);
+                }
+            }
+            if (mine[i] && q == 0) orow[j] = t[i] ? sqrtf(ss) : 0.f;
+        }
+    }
+}
+
 // SPARSE / DELTA stage B: 8 lanes per (probe, observed node).
 template <int CP, bool DELTA>
 __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
@@ -1817,6 +2003,34 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
             const unsigned *marks = nullptr;
             // DELTA on an S1d route whose pre-activation is still to be formed, all rows at once: the item tables ride in that
             // launch (lt_fp64_prepare_rows); otherwise -- and always in SPARSE -- a launch of their own
+            // DELTA at twitch size, graphs without hub rows: stage A + stage B of a probe in one block (k_delta_probe_block),
+            // no item tables, no bitmap rows -- when the pre-activation is formed on all rows anyway and a position per node
+            // fits LDS as 16 bits ("delta_fused" = 0 keeps the three launches; the matrices are bit-identical)
+            {
+                const size_t df_smem = ((((size_t)n + 1) * 2 + 15) & ~(size_t)15) + (size_t)(g->max_col_nnz > 0 ? g->max_col_nnz : 1) * C * sizeof(float);
+                const bool fused = delta64 && vec == nullptr && lt_tune().delta_fused != 0 && g->p_n_long == 0 && w.bits != nullptr && !use_marks &&
+                                   !lt_fp64_agg_active(b) && n <= 65534 && g->max_col_nnz <= 65534 && df_smem <= (size_t)60 * 1024 &&
+                                   !lt_fp64_on_demand(b, n_probe);
+                if (fused) {
+                    int rc = lt_fp64_prepare_rows(b, nullptr, 0, nullptr, n_probe, st);      // (all rows: no tables needed)
+                    if (rc) return rc;
+                    lt_prof_scope prof_(LT_K_ITEM_B, st);
+                    const float *sxp = b->s1_f32 ? b->S1x : (const float *)nullptr;
+                    const float *zxp = b->z1x_valid ? b->Z1x : (const float *)nullptr;
+                    const double *crp = b->cref_deferred ? b->fd_cref : (const double *)nullptr;
+#define LT_DF_LAUNCH(SX_, ZF_)                                                                                                        \
+    LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,                                                                                           \
+        hipLaunchKernelGGL((k_delta_probe_block<LPR_, CP_, SX_, ZF_>), dim3((unsigned)nb), dim3(LT_BLOCK), df_smem, st, b->Z1d, b->S1d, \
+                           sxp, crp, b->S1qs, zxp, Hp, b->W2p, C, probes, g->tptr, g->trow, g->tval, g->rowptr, g->col, g->val,       \
+                           observe_nodes, n_obs, n, delta, orow, (long)ldo)))
+                    if (sxp && zxp) { LT_DF_LAUNCH(true, true); }
+                    else if (sxp) { LT_DF_LAUNCH(true, false); }
+                    else { LT_DF_LAUNCH(false, false); }
+#undef LT_DF_LAUNCH
+                    LT_CHECK_LAUNCH();
+                    continue;
+                }
+            }
             bool bits_done = false;
             const lt_bits_job job = {g->tptr, g->trow, probes, nb, words, w.bits, w.off, w.item_pr, w.big_bits, w.big_slot,
                                      w.big_slot ? w.big_slot + w.chunk : (int32_t *)nullptr, g->rowptr, observe_nodes, n_obs, w.hub_obs,

@@ -148,6 +148,8 @@ struct lt_tuning {
                                  // -1 when they do and the features are not sparse differences (LT_AGGREGATE_FIRST)
     int feature_delta;           // fp64 product X*W1 from the feature rows' differences to a reference row: 0 never, 1 always try,
                                  // -1 when the baseline's features were found to be sparse differences (LT_FEATURE_DELTA)
+    int delta_fused;             // DELTA at twitch size on graphs without hub rows: 1 stage A + B of a probe in one block
+                                 // (k_delta_probe_block), 0 the item kernels (LT_DELTA_FUSED)
 };
 lt_tuning &lt_tune();
 
@@ -238,6 +240,7 @@ struct lt_bits_job {
 };
 // job != NULL: *job_done says whether the job went along (it does when every row is formed by one plain launch; the on-demand
 // form needs the tables BEFORE, the caller then launches k_item_bits itself and calls again without a job)
+bool lt_fp64_on_demand(const lt_baseline *b, int n_probe_call);
 int lt_fp64_prepare_rows(const lt_baseline *b, const int32_t *off, int nb, const int2 *item_pr, int n_probe_call, hipStream_t st,
                          const lt_bits_job *job = nullptr, bool *job_done = nullptr);
 int lt_fp64_prepare_items(const lt_baseline *b, const int32_t *off, int nb, const int2 *item_pr, const int32_t *probes,

@@ -45,6 +45,7 @@ def test_bench_collectives_execute_under_rccl_at_world_size_1(gpu, tmp_path, mod
     assert plain["collectives"]["backend"] is None and not plain["collectives"]["forced_at_world_size_1"]
     col = forced["collectives"]
     assert col["backend"] == "nccl" and col["forced_at_world_size_1"] and col["librccl_mapped"], col
+    assert col["communicator_segment_mapped"] and not plain["collectives"]["communicator_segment_mapped"], (col, plain["collectives"])
     assert forced["n_gpus"] == 1 and forced["config"]["collective_bytes_per_step"] >= 120 * 120 * 4
     if extra.get("LT_SHARD_BASELINE") == "1":
         assert "sharded" in forced["config"]["baseline_XW1"], forced["config"]
@@ -326,3 +327,56 @@ def test_gather_ceiling_entry_point(gpu):
     finally:
         _lib.set_tuning("tiled_min_bytes", None)
     assert torch.equal(tiled, rows)
+
+
+@pytest.mark.parametrize("h,c,kind", [(256, 2, "er"), (100, 3, "er"), (16, 8, "er"), (132, 1, "iso"), (64, 7, "dup")])
+def test_delta_fused_probe_blocks_keep_every_bit(gpu, h, c, kind):
+    """k_delta_probe_block (round 4, `delta_fused`): stage A and stage B of a probe in one block, items from the CSC column,
+    a 16-bit position per node in LDS.  Graphs without hub rows; the matrix must equal the three-launch route's (`delta_fused`
+    = 0) bit for bit -- widths that need padding and several lane groupings, 1 .. 8 classes, isolated nodes, duplicate probes
+    and observed nodes, observe != probes, a single probe, a multi-chunk call, both storage forms of the product rows (twitch-like
+    and Gaussian features) -- and stay within 1e-5 of the fp64 oracle."""
+    from test_gpu_parity import _oracle_matrix
+    from linkteller_amd import _lib, engine, graph, synth
+    n, f = 700, 96
+    a = synth.erdos_renyi_graph(n, 4200, seed=h + c).tolil()
+    if kind == "iso":
+        for k in (5, 77, 300):
+            a[k, :] = 0
+            a[:, k] = 0
+    a = sp.csr_matrix(a)
+    a.eliminate_zeros()
+    a_hat = graph.first_order_gcn(a)
+    assert np.diff(a_hat.indptr).max() <= 128                     # no hub rows: the fused route applies
+    rng = np.random.RandomState(c)
+    w = synth.gcn_weights(f, h, c, seed=3)
+    for feats in ("twitch", "gauss"):
+        x = synth.twitch_like_features(n, f, seed=2, density=0.05) if feats == "twitch" else synth.gaussian_features(n, f, seed=2)
+        base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *_params(w, gpu)).enable_fp64()
+        probes = rng.choice(n, 75, replace=False)
+        observe = rng.choice(n, 90, replace=False)
+        if kind == "dup":
+            probes[3] = probes[9]
+            observe[5] = observe[6]
+        if kind == "iso":
+            probes[0], observe[0] = 5, 77
+        calls = [(probes, observe), (probes[:1], observe), (probes, probes)]
+        for pr, ob in calls:
+            fused = base.influence_rows(pr, ob, 1e-4, "delta").cpu().numpy()
+            _lib.set_tuning("delta_fused", 0)
+            try:
+                plain = base.influence_rows(pr, ob, 1e-4, "delta").cpu().numpy()
+            finally:
+                _lib.set_tuning("delta_fused", None)
+            assert np.array_equal(fused, plain), (feats, len(pr), np.abs(fused - plain).max())
+        ref64 = _oracle_matrix(a_hat, x, w, probes[:12], observe, 1e-4, torch.float64)
+        got = base.influence_rows(probes[:12], observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
+        assert np.abs(got - ref64).max() <= 1e-5 * ref64.max()
+        assert np.all(got[ref64 == 0] == 0)
+        # several chunks per call
+        _lib.set_tuning("chunk_budget_bytes", 1 << 15)
+        try:
+            chunked = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy()
+        finally:
+            _lib.set_tuning("chunk_budget_bytes", None)
+        assert np.array_equal(chunked, base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy())
