@@ -120,6 +120,7 @@ static void free_graph(lt_graph *g) {
     (void)hipFree(g->tptr);
     (void)hipFree(g->trow);
     (void)hipFree(g->tval);
+    (void)hipFree(g->tpos);
     (void)hipFree(g->w_e0);
     (void)hipFree(g->w_cnt);
     (void)hipFree(g->w_dst);
@@ -149,6 +150,7 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
     std::vector<int32_t> tptr;
     std::unique_ptr<int32_t[]> trow;     // (uninitialised: the threads of the fill touch the pages, not a zeroing pass)
     std::unique_ptr<float[]> tval;
+    std::unique_ptr<int32_t[]> tpos;     // small graphs only (lt_graph::tpos)
     int32_t max_row = 0, max_col = 0;
     int64_t n_local = 0;
     double hot_frac = 1.0;
@@ -242,6 +244,8 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
         tval.reset(new float[(size_t)nnz + 1]);
         int32_t *trow_p = trow.get();
         float *tval_p = tval.get();
+        if (n <= 65534) tpos.reset(new int32_t[(size_t)nnz + 1]);
+        int32_t *tpos_p = tpos.get();
         run([&](unsigned t) {
             int32_t *cur = cnt[t].data();
             for (int32_t r = rb[t]; r < rb[t + 1]; ++r)
@@ -249,6 +253,7 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
                     const int32_t p = cur[col[k]]++;
                     trow_p[p] = r;
                     tval_p[p] = val[k];
+                    if (tpos_p) tpos_p[p] = k - rowptr[r];
                 }
         });
     } catch (const std::bad_alloc &) {
@@ -293,6 +298,11 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
         G_HIP(hipMemcpy(g->val, val, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice));
         G_HIP(hipMemcpy(g->trow, trow.get(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
         G_HIP(hipMemcpy(g->tval, tval.get(), (size_t)nnz * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (tpos) {
+        G_HIP(hipMalloc((void **)&g->tpos, ib));
+        G_HIP(hipMemset(g->tpos, 0, ib));
+        if (nnz > 0) G_HIP(hipMemcpy(g->tpos, tpos.get(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     // segment table of the long rows (LT_ROW_SEG entries per segment)
     {

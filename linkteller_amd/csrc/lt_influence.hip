@@ -1199,33 +1199,102 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_hubs(
 }
 
 // ---- DELTA at twitch size: stage A and stage B of ONE probe in one block (round 4; "delta_fused") ----------------------------
-// The two kernels above and below cost 12.8 + 13.4 us of a 65 us step (+ a launch gap), both latency-bound passes over
-// cache-resident operands organised by item and by observed row.  Organised by PROBE everything a probe needs fits a block:
-// its items are the CSC column of v (no item tables, no offsets), the C values each item yields go to LDS instead of a global
-// S2x, "is column c a member of R_v, and which item" is ONE 2-byte LDS read (pos[c] = position + 1, n <= 65534) instead of an
-// 8-byte global bitmap word, and the observed rows are walked 8 lanes per row exactly as k_item_stageB does -- lane q owns
-// the entries e0 + q, e0 + q + 8, ... (a k-ordered fmaf chain), the xor 4, 2, 1 butterfly, d / delta, the fmaf sum of squares.
-// Stage A's arithmetic is k_item_stageA_d2's, statement by statement.  So the matrix has the bits of the three-launch route
-// (`delta_fused` = 0; tests/test_gpu_round4.py compares them), for graphs without hub rows and calls with a bitmap-sized n.
-#define LT_DF_ROWS 4      // observed rows in flight per 8-lane group (their loads are unconditional, clamped)
+// k_item_stageA_d2 + k_item_stageB_rows cost 12.8 + 13.4 us of a 65 us step: stage B tests every entry of every observed row
+// against every probe -- 4.75 M (probe, entry) tests at n_test = 500 for the 7 % of the pairs a probe touches at all; those
+// tests, not latency or cache lines, are what it costs (a per-probe block that still tested every entry took the same 18 us
+// whether it made 24 or 6 dependent round trips and whether its loads were coalesced: ~20 instructions per test).
+// Here the touched pairs are ENUMERATED from the probe's side instead: the members of R_v are the CSC column of v (the items),
+// the rows that hold member r are the CSC column of r, `obs_mark` says which of those rows are observed (and where), and
+// `tpos` which entry of the row the member is -- ~ |R_v| * average column length = 360 incidences per probe instead of 9 500
+// tests.  Per observed row the incidences are then put in entry order and summed exactly as row2_dot would: entry k feeds
+// chain k & 7, a chain is a k-ordered fmaf sequence from +0, the chains are added by the xor 4, 2, 1 butterfly, then d / delta
+// and the fmaf sum of squares.  Stage A's arithmetic is k_item_stageA_d2's, statement by statement.  So the matrix has the
+// bits of the three-launch route (`delta_fused` = 0; tests/test_gpu_round4.py compares them).  Graphs without hub rows,
+// n <= 65534, column length^2 <= LT_DF_MAXI * 256 incidences per probe, n_obs small enough for the LDS tables below.
+#define LT_DF_U 4          // items in flight per lane group in stage A
+#define LT_DF_MAXI 16      // incidences per thread (registers between the counting and the placing pass)
+struct lt_df_inc { float a; int ik; };      // A_hat[u, r] and (item << 16 | entry position in row u)
 template <int LPR, int CP, bool SX, bool ZF>
 __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_block(
     const double *__restrict__ Z1d, const double *__restrict__ S1d, const float *__restrict__ S1x,
     const double *__restrict__ crefv, const double *__restrict__ S1qs, const float *__restrict__ Z1x, int Hp,
     const float *__restrict__ W2p, int C, const int32_t *__restrict__ probes, const int32_t *__restrict__ tptr,
-    const int32_t *__restrict__ trow, const float *__restrict__ tval, const int32_t *__restrict__ rowptr,
-    const int32_t *__restrict__ col, const float *__restrict__ val, const int32_t *__restrict__ observe, int n_obs, int n,
-    float delta, float *__restrict__ out, long ldo) {
+    const int32_t *__restrict__ trow, const float *__restrict__ tval, const int32_t *__restrict__ tpos,
+    const int32_t *__restrict__ obs_mark, const int32_t *__restrict__ observe, int n_obs,
+    float delta, float *__restrict__ out, long ldo, int maxc, int pool_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char df_smem[];
-    unsigned short *pos = reinterpret_cast<unsigned short *>(df_smem);                       // [n] position in R_v + 1, or 0
-    float *sS2 = reinterpret_cast<float *>(df_smem + ((((size_t)n + 1) * 2 + 15) & ~(size_t)15));   // [|R_v|][C] the items' layer-2 inputs
-    constexpr int RPW = 64 / LPR, WAVES = LT_BLOCK / 64, U = 2;
+    // LDS: pool [pool_cap = min(MAXI * 256, maxc^2)] inc | sS2 [maxc][C] f32 | sR, sC0, sCn, sIo [maxc (+1)] i32 | sAv [maxc] f32 | sCnt, sOff, sRes, sLong [n_obs]
+    lt_df_inc *pool = reinterpret_cast<lt_df_inc *>(df_smem);
+    float *sS2 = reinterpret_cast<float *>(pool + pool_cap);
+    int32_t *sR = reinterpret_cast<int32_t *>(sS2 + (size_t)maxc * C);
+    int32_t *sC0 = sR + maxc, *sCn = sC0 + maxc, *sIo = sCn + maxc;      // column of item i: first CSC entry, length; incidence offset [maxc + 1]
+    float *sAv = reinterpret_cast<float *>(sIo + maxc + 1);
+    int32_t *sCnt = reinterpret_cast<int32_t *>(sAv + maxc), *sOff = sCnt + n_obs;
+    float *sRes = reinterpret_cast<float *>(sOff + n_obs);
+    __shared__ int32_t s_wsum[LT_BLOCK / 64];
+    constexpr int RPW = 64 / LPR, WAVES = LT_BLOCK / 64;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.x;
     const int v = probes[b];
     const int t0 = tptr[v], cnt = tptr[v + 1] - t0;
-    for (int i = tid; i < (n + 1) / 2; i += LT_BLOCK) reinterpret_cast<unsigned *>(pos)[i] = 0u;      // (inside the [n + 1] shorts of `pos`)
-    // ---- stage A: this probe's items (k_item_stageA_d2) ----
+    // where each observed position's result will come from (a repeated node: its first position): needed last, asked first
+    constexpr int JPT = 4;                                    // positions per thread held in registers (n_obs <= JPT * 256: else re-read)
+    int canon[JPT];
+#pragma unroll
+    for (int h = 0; h < JPT; ++h) {
+        const int j = tid + h * LT_BLOCK;
+        canon[h] = j < n_obs ? obs_mark[observe[j]] : 0;
+    }
+    for (int i = tid; i < cnt; i += LT_BLOCK) {
+        const int r = trow[t0 + i];
+        sR[i] = r;
+        sAv[i] = tval[t0 + i];
+        const int c0 = tptr[r];
+        sC0[i] = c0;
+        sCn[i] = tptr[r + 1] - c0;
+    }
+    for (int j = tid; j < n_obs; j += LT_BLOCK) sCnt[j] = 0;
+    __syncthreads();
+    if (wid == 0) {      // exclusive scan of the items' column lengths -> the incidences' numbering (one wave: cnt is a few dozen)
+        int carry = 0;
+        for (int i0 = 0; i0 < cnt; i0 += 64) {
+            const int i = i0 + lane;
+            const int x = i < cnt ? sCn[i] : 0;
+            int inc = x;
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                const int y = __shfl_up(inc, m, 64);
+                if (lane >= m) inc += y;
+            }
+            if (i < cnt) sIo[i] = carry + inc - x;
+            carry += __shfl(inc, 63, 64);
+        }
+        if (lane == 0) sIo[cnt] = carry;
+    }
+    __syncthreads();
+    // the incidences (member r_i of R_v, row u that holds it), numbered item by item: their three loads go out NOW and land
+    // while stage A runs
+    const int T = sIo[cnt];
+    int jx[LT_DF_MAXI], sl[LT_DF_MAXI], ii[LT_DF_MAXI], kp[LT_DF_MAXI];
+    float av[LT_DF_MAXI];
+#pragma unroll
+    for (int m = 0; m < LT_DF_MAXI; ++m) {
+        const int x = tid + m * LT_BLOCK;
+        jx[m] = -1; sl[m] = 0; ii[m] = 0; kp[m] = 0; av[m] = 0.f;
+        if (x < T) {
+            int lo = 0, hi = cnt;                            // the item whose incidence range holds x: last i with sIo[i] <= x
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (sIo[mid] <= x) lo = mid; else hi = mid;
+            }
+            ii[m] = lo;
+            const int t = sC0[lo] + (x - sIo[lo]);
+            jx[m] = trow[t];
+            av[m] = tval[t];
+            kp[m] = tpos[t];
+        }
+    }
+    // ---- stage A: this probe's items (k_item_stageA_d2, statement by statement) ----
     {
         const int gl = lane & (LPR - 1);
         const bool active = 4 * gl < Hp;
@@ -1255,25 +1324,23 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_block(
                 for (int k = 0; k < 4; ++k) ds[k] = delta * (crefv != nullptr ? (float)(sd[k] + cr[k]) : (float)sd[k]);
             }
         }
+        constexpr int U = LT_DF_U;
         const int stride = WAVES * RPW;
         for (int base = wid * RPW + lane / LPR; base < cnt; base += U * stride) {
-            int it[U], r[U];
+            int it[U];
             float arv[U];
+            f64x4 z[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 it[u] = base + u * stride;
                 const int ic = min(it[u], cnt - 1);          // past the end: the last item again, never stored
-                r[u] = trow[t0 + ic];
-                arv[u] = tval[t0 + ic];
-            }
-            f64x4 z[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
+                arv[u] = sAv[ic];
+                const int r = sR[ic];
                 if constexpr (ZF) {
-                    const f32x4 zf = ld4(Z1x + (size_t)r[u] * Hp + coff);
+                    const f32x4 zf = ld4(Z1x + (size_t)r * Hp + coff);
                     z[u] = f64x4{(double)zf[0], (double)zf[1], (double)zf[2], (double)zf[3]};
                 } else {
-                    z[u] = *reinterpret_cast<const f64x4 *>(Z1d + (size_t)r[u] * Hp + coff);
+                    z[u] = *reinterpret_cast<const f64x4 *>(Z1d + (size_t)r * Hp + coff);
                 }
             }
 #pragma unroll
@@ -1310,78 +1377,157 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_block(
         }
     }
     __syncthreads();
-    for (int i = tid; i < cnt; i += LT_BLOCK) pos[trow[t0 + i]] = (unsigned short)(i + 1);
-    __syncthreads();
-    // ---- stage B: every observed row against this probe (k_item_stageB / k_item_stageB_rows, DELTA) ----
-    const int q = lane & (LT_L2_LANES - 1), grp = tid / LT_L2_LANES;
-    constexpr int GROUPS = LT_BLOCK / LT_L2_LANES;
-    float *orow = out + (long)b * ldo;
-    for (int j0 = grp; j0 < n_obs; j0 += GROUPS * LT_DF_ROWS) {
-        int e0[LT_DF_ROWS], d[LT_DF_ROWS], u_[LT_DF_ROWS];
-        bool mine[LT_DF_ROWS];
+    // ---- count the incidences per observed position ----
 #pragma unroll
-        for (int i = 0; i < LT_DF_ROWS; ++i) u_[i] = observe[min(j0 + i * GROUPS, n_obs - 1)];
-#pragma unroll
-        for (int i = 0; i < LT_DF_ROWS; ++i) {
-            e0[i] = rowptr[u_[i]];
-            d[i] = rowptr[u_[i] + 1] - e0[i];
-            mine[i] = j0 + i * GROUPS < n_obs && d[i] <= LT_ROW_SEG;        // past the end / an observed hub (its own blocks): nothing here
-            if (!mine[i]) d[i] = 0;
-        }
-        int dmax = 0;
-#pragma unroll
-        for (int i = 0; i < LT_DF_ROWS; ++i) dmax = max(dmax, d[i]);
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) dmax = max(dmax, __shfl_xor(dmax, m, 64));    // wave-uniform trip count
-        float acc[LT_DF_ROWS][CP];
-        int t[LT_DF_ROWS];
-#pragma unroll
-        for (int i = 0; i < LT_DF_ROWS; ++i) {
-            t[i] = 0;
-#pragma unroll
-            for (int c = 0; c < CP; ++c) acc[i][c] = 0.f;
-        }
-        for (int k = q; k - q < dmax; k += LT_L2_LANES) {
-            int cc[LT_DF_ROWS];
-            float a[LT_DF_ROWS];
-            // unconditional loads (past a row's end: its first entry again -- the CSR arrays are padded -- never used)
-#pragma unroll
-            for (int i = 0; i < LT_DF_ROWS; ++i) {
-                const int e = e0[i] + (k < d[i] ? k : 0);
-                cc[i] = col[e];
-                a[i] = val[e];
-            }
-#pragma unroll
-            for (int i = 0; i < LT_DF_ROWS; ++i) {
-                const int p = (int)pos[min(max(cc[i], 0), n - 1)];
-                if (k < d[i] && p != 0) {
-                    const float *itv = sS2 + (size_t)(p - 1) * C;
-#pragma unroll
-                    for (int c = 0; c < CP; ++c)
-                        if (c < C) acc[i][c] = fmaf(a[i], itv[c], acc[i][c]);
-                    t[i] = 1;
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < LT_DF_ROWS; ++i)
-#pragma unroll
-            for (int m = LT_L2_LANES / 2; m >= 1; m >>= 1) t[i] |= __shfl_xor(t[i], m, 64);
-#pragma unroll
-        for (int i = 0; i < LT_DF_ROWS; ++i) {
-            const int j = j0 + i * GROUPS;
-            float ss = 0.f;
-#pragma unroll
-            for (int c = 0; c < CP; ++c) {
-                const float o = group_sum<LT_L2_LANES>(acc[i][c]);
-                if (c < C) {
-                    const float dd = o / delta;
-                    ss = fmaf(dd, dd, ss);
-                }
-            }
-            if (mine[i] && q == 0) orow[j] = t[i] ? sqrtf(ss) : 0.f;
+    for (int m = 0; m < LT_DF_MAXI; ++m) {
+        const int x = tid + m * LT_BLOCK;
+        if (x < T) {
+            const int j = obs_mark[jx[m]];
+            jx[m] = j < n_obs ? j : -1;
+            if (jx[m] >= 0) sl[m] = atomicAdd(&sCnt[jx[m]], 1);
         }
     }
+    __syncthreads();
+    {   // exclusive scan of the counts over the observed positions (block-wide, 256 at a time)
+        int carry = 0;
+        for (int j0 = 0; j0 < n_obs; j0 += LT_BLOCK) {
+            const int j = j0 + tid;
+            const int x = j < n_obs ? sCnt[j] : 0;
+            int inc = x;
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                const int y = __shfl_up(inc, m, 64);
+                if (lane >= m) inc += y;
+            }
+            if (lane == 63) s_wsum[wid] = inc;
+            __syncthreads();
+            int before = carry;
+            for (int w_ = 0; w_ < wid; ++w_) before += s_wsum[w_];
+            if (j < n_obs) sOff[j] = before + inc - x;
+            carry += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < LT_DF_MAXI; ++m) {
+        if (jx[m] >= 0) {
+            lt_df_inc e;
+            e.a = av[m];
+            e.ik = (ii[m] << 16) | kp[m];
+            pool[sOff[jx[m]] + sl[m]] = e;
+        }
+    }
+    __syncthreads();
+    // ---- per observed position: its incidences in entry order, the 8 chains, the butterfly, the norm ----
+    // Lists of up to 4 incidences (all but one or two per probe) by one thread in registers: a sorting network on the entry
+    // position, then every (entry, chain) pair as a select -- no loop, no LDS in the arithmetic.  Longer lists (the pair
+    // (v, v): row v holds ALL of R_v) are left to a whole wave below.
+    __shared__ int32_t s_nlong;
+    int32_t *sLong = reinterpret_cast<int32_t *>(sRes + n_obs);        // [n_obs] the positions with a long list
+    if (tid == 0) s_nlong = 0;
+    __syncthreads();
+    for (int j = tid; j < n_obs; j += LT_BLOCK) {
+        const int c_ = sCnt[j];
+        if (c_ == 0) { sRes[j] = 0.f; continue; }
+        if (c_ > 4) {
+            sLong[atomicAdd(&s_nlong, 1)] = j;
+            continue;
+        }
+        const lt_df_inc *e = pool + sOff[j];
+        float a[4], tv[4][CP];
+        int k[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const lt_df_inc ex = e[x < c_ ? x : 0];
+            a[x] = ex.a;
+            k[x] = x < c_ ? (ex.ik & 0xffff) : (0x10000 + x);           // absent entries sort behind every real one
+            const float *t = sS2 + (size_t)(ex.ik >> 16) * C;
+#pragma unroll
+            for (int c = 0; c < CP; ++c) tv[x][c] = c < C ? t[c] : 0.f;
+        }
+        auto cswap = [&](int p, int q_) {                               // compare-exchange on the entry position
+            if (k[p] > k[q_]) {
+                const int tk = k[p]; k[p] = k[q_]; k[q_] = tk;
+                const float ta = a[p]; a[p] = a[q_]; a[q_] = ta;
+#pragma unroll
+                for (int c = 0; c < CP; ++c) { const float tt_ = tv[p][c]; tv[p][c] = tv[q_][c]; tv[q_][c] = tt_; }
+            }
+        };
+        cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
+            float ch[LT_L2_LANES];
+#pragma unroll
+            for (int qq = 0; qq < LT_L2_LANES; ++qq) {
+                float acc = 0.f;
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+                    acc = (k[x] < 0x10000 && (k[x] & (LT_L2_LANES - 1)) == qq) ? fmaf(a[x], tv[x][c], acc) : acc;
+                ch[qq] = acc;
+            }
+            // lane 0 of group_sum<8>: x += xor 4; x += xor 2; x += xor 1
+            const float o = ((ch[0] + ch[4]) + (ch[2] + ch[6])) + ((ch[1] + ch[5]) + (ch[3] + ch[7]));
+            if (c < C) {
+                const float dd = o / delta;
+                ss = fmaf(dd, dd, ss);
+            }
+        }
+        sRes[j] = sqrtf(ss);
+    }
+    __syncthreads();
+    // the long lists: one wave each.  Lane l ranks entries l, l + 64, ... by position (every lane reads the whole list), the
+    // list is rewritten in order, then lane (c, qq) = (l >> 3, l & 7) walks it for chain qq of class c and the 8-lane
+    // butterfly is row2_dot's own.
+    {
+        const int nl = s_nlong;
+        for (int s_ = wid; s_ < nl; s_ += WAVES) {                       // (wave-uniform)
+            const int j = sLong[s_];
+            const int c_ = sCnt[j];
+            lt_df_inc *e = pool + sOff[j];
+            lt_df_inc mine[2];
+            int rank[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int x = lane + 64 * h;
+                mine[h] = e[x < c_ ? x : 0];
+                rank[h] = 0;
+            }
+            for (int y = 0; y < c_; ++y) {
+                const int ky = e[y].ik & 0xffff;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) rank[h] += ky < (mine[h].ik & 0xffff) ? 1 : 0;      // (positions inside one row are distinct)
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (lane + 64 * h < c_) e[rank[h]] = mine[h];
+            __builtin_amdgcn_wave_barrier();
+            const int qq = lane & (LT_L2_LANES - 1), c = lane >> 3;
+            float acc = 0.f;
+            if (c < C)
+                for (int y = 0; y < c_; ++y) {
+                    const lt_df_inc ey = e[y];
+                    if ((ey.ik & (LT_L2_LANES - 1)) == qq) acc = fmaf(ey.a, sS2[(size_t)(ey.ik >> 16) * C + c], acc);
+                }
+            const float o = group_sum<LT_L2_LANES>(acc);
+            float ss = 0.f;
+            for (int cc = 0; cc < C; ++cc) {
+                const float oc = __shfl(o, cc * LT_L2_LANES, 64);
+                const float dd = oc / delta;
+                ss = fmaf(dd, dd, ss);
+            }
+            if (lane == 0) sRes[j] = sqrtf(ss);
+        }
+    }
+    __syncthreads();
+    float *orow = out + (long)b * ldo;
+#pragma unroll
+    for (int h = 0; h < JPT; ++h) {
+        const int j = tid + h * LT_BLOCK;
+        if (j < n_obs) orow[j] = sRes[canon[h]];
+    }
+    for (int j = tid + JPT * LT_BLOCK; j < n_obs; j += LT_BLOCK) orow[j] = sRes[obs_mark[observe[j]]];
 }
 
 // SPARSE / DELTA stage B: 8 lanes per (probe, observed node).
@@ -1712,6 +1858,7 @@ struct infl_ws {
     float *slabs;          // FULL / SPARSE: split-K partials of the perturbed-row GEMM
     float *S2x;            // SPARSE / DELTA: per-item values
     double *Spd;           // DELTA, aggregate-first route: fp64 product rows of the chunk's probes [chunk, Hp]
+    int32_t *obs_mark;     // DELTA, fused route: node -> position in the observed list (obs_mark_block)
     int32_t *off;          // SPARSE / DELTA: item offsets [chunk + 1]
     int2 *item_pr;         // SPARSE / DELTA: (probe index, row) of every item
     int2 *item_va;         // DELTA: (probe node, A_hat[row, probe node] as bits) of every item
@@ -1757,6 +1904,8 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int n_o
         w.lhit = (unsigned *)take(nseg * ((chunk + 7) / 8 + 1) * sizeof(unsigned));   // per (segment, group): probes with a slot of their own
     }
     if (mode == LT_MODE_DELTA) w.Spd = (double *)take(chunk * Hp * sizeof(double));   // aggregate-first: X[probes] W1 in fp64
+    if (mode == LT_MODE_DELTA && b->g->tpos != nullptr && b->g->p_n_long == 0)      // k_delta_probe_block: node -> observed position
+        w.obs_mark = (int32_t *)take(n * sizeof(int32_t));
     if (mode != LT_MODE_FULL) {
         w.hub_obs = (int32_t *)take(((size_t)n_obs + 1) * sizeof(int32_t));   // the observed nodes that are hub rows (k_item_bits)
         w.S2x = (float *)take(chunk * maxc * C * sizeof(float));
@@ -2007,13 +2156,29 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
             // no item tables, no bitmap rows -- when the pre-activation is formed on all rows anyway and a position per node
             // fits LDS as 16 bits ("delta_fused" = 0 keeps the three launches; the matrices are bit-identical)
             {
-                const size_t df_smem = ((((size_t)n + 1) * 2 + 15) & ~(size_t)15) + (size_t)(g->max_col_nnz > 0 ? g->max_col_nnz : 1) * C * sizeof(float);
-                const bool fused = delta64 && vec == nullptr && lt_tune().delta_fused != 0 && g->p_n_long == 0 && w.bits != nullptr && !use_marks &&
-                                   !lt_fp64_agg_active(b) && n <= 65534 && g->max_col_nnz <= 65534 && df_smem <= (size_t)60 * 1024 &&
-                                   !lt_fp64_on_demand(b, n_probe);
+                const int df_maxc = g->max_col_nnz > 0 ? g->max_col_nnz : 1;
+                const long df_inc = (long)df_maxc * df_maxc;       // bound on a probe's incidences: |R_v| columns of at most max_col entries
+                const int df_pool = (int)((df_inc < (long)LT_DF_MAXI * LT_BLOCK ? df_inc : (long)LT_DF_MAXI * LT_BLOCK) + 1) & ~1;
+                const size_t df_smem = (size_t)df_pool * sizeof(lt_df_inc) + (size_t)df_maxc * (C + 5) * sizeof(float) + 16 +
+                                       (size_t)4 * n_obs * sizeof(int32_t);
+                const bool fused = delta64 && vec == nullptr && lt_tune().delta_fused != 0 && g->p_n_long == 0 && g->tpos != nullptr &&
+                                   w.bits != nullptr && !use_marks && w.obs_mark != nullptr && !lt_fp64_agg_active(b) && n <= 65534 &&
+                                   df_inc <= (long)LT_DF_MAXI * LT_BLOCK && df_maxc < 32768 &&
+                                   df_smem <= (size_t)64 * 1024 && !lt_fp64_on_demand(b, n_probe);
                 if (fused) {
-                    int rc = lt_fp64_prepare_rows(b, nullptr, 0, nullptr, n_probe, st);      // (all rows: no tables needed)
-                    if (rc) return rc;
+                    // node -> observed position, once per call: as a trailing block of the launch that forms the pre-activation
+                    // when there is one (nothing in it depends on the table), else a launch of its own
+                    if (p0 == 0) {
+                        bool rode = false;
+                        lt_bits_job cj = {};
+                        cj.observe = observe_nodes; cj.n_obs = n_obs; cj.nblocks = 1; cj.obs_mark = w.obs_mark; cj.n_nodes = n;
+                        int rc = lt_fp64_prepare_rows(b, nullptr, 0, nullptr, n_probe, st, &cj, &rode);      // (all rows: no item tables needed)
+                        if (rc) return rc;
+                        if (!rode) {
+                            hipLaunchKernelGGL(k_obs_mark, dim3(1), dim3(256), 0, st, observe_nodes, n_obs, n, w.obs_mark);
+                            LT_CHECK_LAUNCH();
+                        }
+                    }
                     lt_prof_scope prof_(LT_K_ITEM_B, st);
                     const float *sxp = b->s1_f32 ? b->S1x : (const float *)nullptr;
                     const float *zxp = b->z1x_valid ? b->Z1x : (const float *)nullptr;
@@ -2021,8 +2186,8 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
 #define LT_DF_LAUNCH(SX_, ZF_)                                                                                                        \
     LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,                                                                                           \
         hipLaunchKernelGGL((k_delta_probe_block<LPR_, CP_, SX_, ZF_>), dim3((unsigned)nb), dim3(LT_BLOCK), df_smem, st, b->Z1d, b->S1d, \
-                           sxp, crp, b->S1qs, zxp, Hp, b->W2p, C, probes, g->tptr, g->trow, g->tval, g->rowptr, g->col, g->val,       \
-                           observe_nodes, n_obs, n, delta, orow, (long)ldo)))
+                           sxp, crp, b->S1qs, zxp, Hp, b->W2p, C, probes, g->tptr, g->trow, g->tval, g->tpos, w.obs_mark,             \
+                           observe_nodes, n_obs, delta, orow, (long)ldo, df_maxc, df_pool)))
                     if (sxp && zxp) { LT_DF_LAUNCH(true, true); }
                     else if (sxp) { LT_DF_LAUNCH(true, false); }
                     else { LT_DF_LAUNCH(false, false); }

@@ -117,8 +117,22 @@ static __global__ __launch_bounds__(256) void k_item_bits(const int32_t *__restr
     item_bits_block((int)blockIdx.x, tptr, trow, probes, nb, words, bits, off, item_pr, big_bits, big_slot, big_count, rowptr, observe,
                     n_obs, hub_obs, tval, item_va);
 }
+// node -> position in the observed list, for k_delta_probe_block: ONE block clears the table and scatters the list (the
+// smallest j wins where observe repeats a node: the other positions copy its result).  17 KB at twitch size.
+static __device__ __forceinline__ void obs_mark_block(const int32_t *__restrict__ observe, int n_obs, int n, int32_t *__restrict__ obs_mark) {
+    for (int u = threadIdx.x; u < n; u += blockDim.x) obs_mark[u] = LT_NOT_OBSERVED;
+    __syncthreads();
+    for (int j = threadIdx.x; j < n_obs; j += blockDim.x) atomicMin(&obs_mark[observe[j]], j);
+}
+static __global__ __launch_bounds__(256) void k_obs_mark(const int32_t *__restrict__ observe, int n_obs, int n, int32_t *__restrict__ obs_mark) {
+    obs_mark_block(observe, n_obs, n, obs_mark);
+}
 // the same block as part of another launch (256 threads per block)
 static __device__ __forceinline__ void item_bits_block(const int bid, const lt_bits_job &j) {
+    if (j.obs_mark != nullptr) {      // (the job is the observed-position table: one block)
+        if (bid == 0) obs_mark_block(j.observe, j.n_obs, j.n_nodes, j.obs_mark);
+        return;
+    }
     item_bits_block(bid, j.tptr, j.trow, j.probes, j.nb, j.words, j.bits, j.off, j.item_pr, j.big_bits, j.big_slot, j.big_count, j.rowptr,
                     j.observe, j.n_obs, j.hub_obs, j.tval, j.item_va);
 }

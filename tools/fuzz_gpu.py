@@ -91,8 +91,12 @@ def main():
         try:
             base.refresh()
             other = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
+            # on these S1d routes a graph without hub rows takes k_delta_probe_block (round 4): the item kernels give its bits
+            _lib.set_tuning("delta_fused", 0)
+            unfused = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
+            assert np.array_equal(other, unfused), (it, kind, n, h, c, f, route_knobs, "delta_fused")
         finally:
-            for k in ("aggregate_first", "feature_delta", "defer_cref", "s1_f32"):
+            for k in ("aggregate_first", "feature_delta", "defer_cref", "s1_f32", "delta_fused"):
                 _lib.set_tuning(k, None)
             base.refresh()
         # (this check is what caught plain fp32 storage of the feature route's product rows: seed 31337, case 59, 7e-5 of the largest
