@@ -525,7 +525,12 @@ def main():
         tot, cnt = kernel_ms(k)
         first[k] = tot
     dom_name = max(first, key=first.get)
+    # (an event pair costs ~5 us of stream time -- 9 % of a 0.058 ms step: the dominant class is bracketed on every
+    # PROFILE_EVERY-th step of the timed region, its average launch duration is the mean of those samples)
+    PROFILE_EVERY = 5
+    _lib.set_tuning("profile_every", PROFILE_EVERY)
     block_s, full = timed(a.mode, a.steps, 2, profile_mask=1 << _lib.KERNEL_IDS[dom_name], blocks=max(1, a.blocks))
+    _lib.set_tuning("profile_every", None)
     elapsed = float(np.median(block_s))
     ms_per_step = elapsed / a.steps * 1e3
     value = a.n_test * a.n_test * a.steps / elapsed
@@ -548,7 +553,8 @@ def main():
     event_pair_us = round(float(np.median([e0.elapsed_time(e1) for e0, e1 in evs])) * 1e3, 2)
     if dom_cnt:      # duration of the dominant class as measured INSIDE the timed region (per step = per launch group)
         per_kernel[dom_name]["us_per_step_instrumented_pass"] = per_kernel[dom_name]["us_per_step"]
-        per_kernel[dom_name]["us_per_step"] = round(dom_tot / (a.steps * max(1, a.blocks)) * 1e3, 2)
+        per_kernel[dom_name]["us_per_step"] = round(dom_tot / max(dom_cnt, 1) * 1e3, 2)
+        per_kernel[dom_name]["samples_in_timed_region"] = int(dom_cnt)
 
     def roofline_of(cls, us, mode):
         """Roofline object of one kernel class at `us` microseconds per launch group (one per step)."""
@@ -889,7 +895,8 @@ def main():
                        "event_pair_note": "an EMPTY hipEventRecord pair on the kernels' stream reads this much: the per-class avg_launch_us "
                                           "figures (HIP events) sit that far above the rocprofv3 kernel durations in profiles/"},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "kernels": per_kernel,
-            "kernels_note": f"dominant class ({dom_name}) timed by HIP events inside the timed region; the other rows from an "
+            "kernels_note": f"dominant class ({dom_name}) timed by HIP events inside the timed region (every {PROFILE_EVERY}th step: an event pair costs "
+                            f"~5 us of stream time); the other rows from an "
                             f"instrumented repeat of the same {a.steps} steps ({round(elapsed_i / a.steps * 1e3, 4)} ms/step)",
         }
         if a.mode != "delta":

@@ -105,6 +105,7 @@ int lt_device_count(int *count);
  *                         probes of a call reach (no n x F x H product): 0 = never, 1 = whenever the shapes allow (F <= 2 Hp,
  *                         F <= 512; set it before lt_baseline_enable_fp64 allocates), negative = then and when the features
  *                         are not sparse differences (default).  Like "feature_delta" it changes fp64 summation order only.
+ *   "profile_every"       lt_profile_enable brackets every N-th launch group of an enabled class with events (default 1 = all of them)
  *   "probe_kslice"        K-slice of the perturbed-row GEMM; 0 = the slicing of the baseline X*W1 (default: S1'[v] and
  *                         S1[v] then share one summation order, like the reference's two torch.mm calls)
  * value = LT_TUNING_DEFAULT restores the default. */
@@ -290,7 +291,8 @@ int lt_lapgraph_select(int32_t n, const int32_t *lower_rowptr, const int32_t *lo
 /* ---- per-kernel timing (used by bench.py for the roofline object) --------------------------
  * lt_profile_enable(mask): bit k of mask set = launches of kernel class k are bracketed by a pair of
  * hipEvents on the caller's stream (mask 0 = off, -1 = every class; an event pair costs a few
- * microseconds of stream time, so a timed region should enable only what it reports).
+ * microseconds of stream time, so a timed region should enable only what it reports -- and may sample:
+ * lt_set_tuning("profile_every", N) brackets only every N-th launch group of an enabled class).
  * lt_profile_summary synchronises on the recorded events and returns the summed duration and
  * launch count of one kernel class.  No reference counterpart (the reference only
  * has wall-clock prints, attacker.py:213,231). */

@@ -55,6 +55,7 @@ static lt_tuning tuning_defaults() {
     t.aggregate_first = getenv("LT_AGGREGATE_FIRST") ? (env_ll("LT_AGGREGATE_FIRST", 0) != 0 ? 1 : 0) : -1;
     t.feature_delta = getenv("LT_FEATURE_DELTA") ? (env_ll("LT_FEATURE_DELTA", 0) != 0 ? 1 : 0) : -1;
     t.delta_fused = env_ll("LT_DELTA_FUSED", 1) != 0 ? 1 : 0;
+    t.profile_every = 1;
     return t;
 }
 lt_tuning &lt_tune() {
@@ -88,6 +89,7 @@ extern "C" int lt_set_tuning(const char *key, long long value) {
     else if (!strcmp(key, "s1_f32")) t.s1_f32 = reset ? d.s1_f32 : (value != 0);
     else if (!strcmp(key, "defer_cref")) t.defer_cref = reset ? d.defer_cref : (value != 0);
     else if (!strcmp(key, "delta_fused")) t.delta_fused = reset ? d.delta_fused : (value != 0);
+    else if (!strcmp(key, "profile_every")) t.profile_every = reset ? 1 : (value >= 1 ? (int)(value > 1000000 ? 1000000 : value) : 1);
     else if (!strcmp(key, "z_on_demand")) t.z_on_demand = reset ? d.z_on_demand : (value < 0 ? -1 : (value != 0));
     else if (!strcmp(key, "stageb_rows")) t.stageb_rows = reset ? d.stageb_rows : (value != 0);
     else if (!strcmp(key, "aggregate_first")) t.aggregate_first = reset ? d.aggregate_first : (value < 0 ? -1 : (value != 0));
@@ -400,6 +402,7 @@ struct prof_rec { int id; hipEvent_t a, b; };
 std::vector<prof_rec> g_recs;
 std::vector<hipEvent_t> g_free;
 hipEvent_t g_open[LT_K_COUNT];
+unsigned g_tick[LT_K_COUNT];
 hipEvent_t take_event() {
     if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -408,6 +411,10 @@ hipEvent_t take_event() {
 }
 }  // namespace
 
+bool lt_profile_sample(int id) {
+    const unsigned every = (unsigned)lt_tune().profile_every;
+    return every <= 1u || (g_tick[id]++ % every) == 0u;
+}
 void lt_profile_begin(int id, hipStream_t st) {
     hipEvent_t e = take_event();
     (void)hipEventRecord(e, st);
@@ -426,6 +433,7 @@ extern "C" int lt_profile_reset(void) {
 }
 extern "C" int lt_profile_enable(int mask) {
     lt_profile_reset();
+    for (auto &t : g_tick) t = 0;
     g_lt_profile_mask = (unsigned)mask;
     return LT_OK;
 }

@@ -152,6 +152,8 @@ struct lt_tuning {
                                  // -1 when the baseline's features were found to be sparse differences (LT_FEATURE_DELTA)
     int delta_fused;             // DELTA at twitch size on graphs without hub rows: 1 stage A + B of a probe in one block
                                  // (k_delta_probe_block), 0 the item kernels (LT_DELTA_FUSED)
+    int profile_every;           // lt_profile_enable: bracket every N-th scope of an enabled class with events (1 = all; an event pair
+                                 // costs ~5 us of stream time, so a timed region samples)
 };
 lt_tuning &lt_tune();
 
@@ -181,11 +183,13 @@ static inline size_t lt_align_up(size_t x, size_t a) { return (x + a - 1) / a * 
 
 // ---- optional per-kernel event timing (lt_core.hip) ------------------------------------------
 extern unsigned g_lt_profile_mask;
+bool lt_profile_sample(int kernel_id);      // "profile_every" = N: true for every N-th scope of a class (1: all of them)
 void lt_profile_begin(int kernel_id, hipStream_t st);
 void lt_profile_end(int kernel_id, hipStream_t st);
 struct lt_prof_scope {
     int id; hipStream_t st; bool on;
-    lt_prof_scope(int id_, hipStream_t st_, bool wanted = true) : id(id_), st(st_), on(wanted && ((g_lt_profile_mask >> id_) & 1u)) { if (on) lt_profile_begin(id, st); }
+    lt_prof_scope(int id_, hipStream_t st_, bool wanted = true)
+        : id(id_), st(st_), on(wanted && ((g_lt_profile_mask >> id_) & 1u) && lt_profile_sample(id_)) { if (on) lt_profile_begin(id, st); }
     ~lt_prof_scope() { if (on) lt_profile_end(id, st); }
 };
 

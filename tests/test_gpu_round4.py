@@ -380,3 +380,36 @@ def test_delta_fused_probe_blocks_keep_every_bit(gpu, h, c, kind):
         finally:
             _lib.set_tuning("chunk_budget_bytes", None)
         assert np.array_equal(chunked, base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy())
+
+
+def test_delta_fused_on_a_directed_pattern_with_empty_columns_and_many_observed(gpu):
+    """k_delta_probe_block beyond the symmetric case: a DIRECTED adjacency (rows and columns differ: R_v is the column of v, the
+    rows that hold a member are the member's column, `tpos` is the entry's place in its ROW), nodes nobody reads (empty
+    columns: no items) and nobody is read by (empty rows), and more observed positions than a thread keeps canonical indices
+    for (n_obs > 1024, with repeats).  Bits of the item kernels, and the fp64 oracle on a few rows."""
+    from test_gpu_parity import _oracle_matrix
+    from linkteller_amd import _lib, engine, graph, synth
+    n, f, h, c = 2500, 48, 64, 3
+    rng = np.random.RandomState(11)
+    rows = rng.randint(0, n, 30000)
+    cols = rng.randint(0, n, 30000)
+    keep = (rows != cols) & (cols >= 40) & (rows >= 20)            # columns 0..39 stay empty, rows 0..19 too
+    a = sp.csr_matrix((rng.uniform(0.05, 0.3, keep.sum()).astype(np.float32), (rows[keep], cols[keep])), shape=(n, n))
+    a.sum_duplicates()
+    a.sort_indices()
+    assert np.diff(a.indptr).max() <= 128 and np.diff(a.tocsc().indptr).max() <= 60
+    x = synth.gaussian_features(n, f, seed=2)
+    w = synth.gcn_weights(f, h, c, seed=3)
+    base = engine.Baseline(graph.HipGraph(a), torch.from_numpy(x).to(gpu), *_params(w, gpu)).enable_fp64()
+    probes = np.concatenate([[0, 5, 39, 40], rng.choice(n, 60, replace=False)])           # 0, 5, 39: empty columns (no items)
+    observe = np.concatenate([rng.choice(n, 1400, replace=False), [3, 3, 41, 41, 41]])     # 3: an empty row; repeats
+    fused = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy()
+    _lib.set_tuning("delta_fused", 0)
+    try:
+        plain = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy()
+    finally:
+        _lib.set_tuning("delta_fused", None)
+    assert np.array_equal(fused, plain), np.abs(fused - plain).max()
+    assert np.all(fused[:3] == 0) and np.array_equal(fused[:, -1], fused[:, -3]) and fused.max() > 0
+    ref64 = _oracle_matrix(a, x, w, probes[3:9], observe, 1e-4, torch.float64)
+    assert np.abs(fused[3:9].astype(np.float64) - ref64).max() <= 1e-5 * max(ref64.max(), 1e-9)
