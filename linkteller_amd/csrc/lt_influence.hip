@@ -1212,6 +1212,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_hubs(
 // bits of the three-launch route (`delta_fused` = 0; tests/test_gpu_round4.py compares them).  Graphs without hub rows,
 // n <= 65534, column length^2 <= LT_DF_MAXI * 256 incidences per probe, n_obs small enough for the LDS tables below.
 #define LT_DF_U 4          // items in flight per lane group in stage A
+#define LT_DF_LDS_MAX (144 * 1024)   // dynamic LDS the kernel may be given (n_obs up to ~ 7 000 beside a 32 KB pool)
 #define LT_DF_MAXI 16      // incidences per thread (registers between the counting and the placing pass)
 struct lt_df_inc { float a; int ik; };      // A_hat[u, r] and (item << 16 | entry position in row u)
 template <int LPR, int CP, bool SX, bool ZF>
@@ -2164,7 +2165,7 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
                 const bool fused = delta64 && vec == nullptr && lt_tune().delta_fused != 0 && g->p_n_long == 0 && g->tpos != nullptr &&
                                    w.bits != nullptr && !use_marks && w.obs_mark != nullptr && !lt_fp64_agg_active(b) && n <= 65534 &&
                                    df_inc <= (long)LT_DF_MAXI * LT_BLOCK && df_maxc < 32768 &&
-                                   df_smem <= (size_t)64 * 1024 && !lt_fp64_on_demand(b, n_probe);
+                                   df_smem <= (size_t)LT_DF_LDS_MAX && !lt_fp64_on_demand(b, n_probe);
                 if (fused) {
                     // node -> observed position, once per call: as a trailing block of the launch that forms the pre-activation
                     // when there is one (nothing in it depends on the table), else a launch of its own
@@ -2183,7 +2184,16 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
                     const float *sxp = b->s1_f32 ? b->S1x : (const float *)nullptr;
                     const float *zxp = b->z1x_valid ? b->Z1x : (const float *)nullptr;
                     const double *crp = b->cref_deferred ? b->fd_cref : (const double *)nullptr;
+                    // (beyond the default 64 KB of dynamic LDS -- every node observed, `balanced-full` -- the kernel is told once per
+                    // instantiation that it may take most of the CU's 160 KB: one block per CU then, still far fewer operations)
 #define LT_DF_LAUNCH(SX_, ZF_)                                                                                                        \
+    LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp, {                                                                                         \
+        static bool big_lds_ = false;                                                                                                 \
+        if (df_smem > (size_t)64 * 1024 && !big_lds_) {                                                                               \
+            LT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_delta_probe_block<LPR_, CP_, SX_, ZF_>),                     \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LT_DF_LDS_MAX));                                   \
+            big_lds_ = true;                                                                                                          \
+        } });                                                                                                                         \
     LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,                                                                                           \
         hipLaunchKernelGGL((k_delta_probe_block<LPR_, CP_, SX_, ZF_>), dim3((unsigned)nb), dim3(LT_BLOCK), df_smem, st, b->Z1d, b->S1d, \
                            sxp, crp, b->S1qs, zxp, Hp, b->W2p, C, probes, g->tptr, g->trow, g->tval, g->tpos, w.obs_mark,             \

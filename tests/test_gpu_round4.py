@@ -413,3 +413,24 @@ def test_delta_fused_on_a_directed_pattern_with_empty_columns_and_many_observed(
     assert np.all(fused[:3] == 0) and np.array_equal(fused[:, -1], fused[:, -3]) and fused.max() > 0
     ref64 = _oracle_matrix(a, x, w, probes[3:9], observe, 1e-4, torch.float64)
     assert np.abs(fused[3:9].astype(np.float64) - ref64).max() <= 1e-5 * max(ref64.max(), 1e-9)
+
+
+def test_delta_fused_with_every_node_observed(gpu):
+    """`balanced-full` observes every node (attacker.py:250-284): at twitch-RU size the per-position LDS tables of
+    k_delta_probe_block pass the default 64 KB of dynamic LDS and the kernel is given more (hipFuncSetAttribute, one block
+    per CU).  Same bits as the item kernels; the call is chunked as the attack chunks it."""
+    from linkteller_amd import _lib, engine, graph, synth
+    adj, x, w = synth.twitch_like_problem("twitch-RU", hidden=256, n_classes=2, seed=0)
+    a_hat = graph.first_order_gcn(adj)
+    n = adj.shape[0]
+    base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *_params(w, gpu)).enable_fp64()
+    probes = np.random.RandomState(5).choice(n, 300, replace=False)
+    everyone = np.arange(n)
+    fused = base.influence_rows(probes, everyone, 1e-4, "delta").cpu().numpy()
+    _lib.set_tuning("delta_fused", 0)
+    try:
+        plain = base.influence_rows(probes, everyone, 1e-4, "delta").cpu().numpy()
+    finally:
+        _lib.set_tuning("delta_fused", None)
+    assert np.array_equal(fused, plain)
+    assert (fused > 0).sum() > 10 * len(probes) and np.isfinite(fused).all()
