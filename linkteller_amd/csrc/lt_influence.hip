@@ -1531,6 +1531,18 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_block(
     for (int j = tid + JPT * LT_BLOCK; j < n_obs; j += LT_BLOCK) orow[j] = sRes[obs_mark[observe[j]]];
 }
 
+// beyond the default 64 KB of dynamic LDS the kernel is told, once per instantiation, that it may take most of a CU's 160 KB
+template <int LPR, int CP, bool SX, bool ZF>
+static int df_allow_big_lds() {
+    static bool done = false;
+    if (!done) {
+        LT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_delta_probe_block<LPR, CP, SX, ZF>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LT_DF_LDS_MAX));
+        done = true;
+    }
+    return LT_OK;
+}
+
 // SPARSE / DELTA stage B: 8 lanes per (probe, observed node).
 template <int CP, bool DELTA>
 __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
@@ -2187,14 +2199,8 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
                     // (beyond the default 64 KB of dynamic LDS -- every node observed, `balanced-full` -- the kernel is told once per
                     // instantiation that it may take most of the CU's 160 KB: one block per CU then, still far fewer operations)
 #define LT_DF_LAUNCH(SX_, ZF_)                                                                                                        \
-    LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp, {                                                                                         \
-        static bool big_lds_ = false;                                                                                                 \
-        if (df_smem > (size_t)64 * 1024 && !big_lds_) {                                                                               \
-            LT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_delta_probe_block<LPR_, CP_, SX_, ZF_>),                     \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LT_DF_LDS_MAX));                                   \
-            big_lds_ = true;                                                                                                          \
-        } });                                                                                                                         \
     LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,                                                                                           \
+        if (df_smem > (size_t)64 * 1024) { const int rc_ = df_allow_big_lds<LPR_, CP_, SX_, ZF_>(); if (rc_) return rc_; }           \
         hipLaunchKernelGGL((k_delta_probe_block<LPR_, CP_, SX_, ZF_>), dim3((unsigned)nb), dim3(LT_BLOCK), df_smem, st, b->Z1d, b->S1d, \
                            sxp, crp, b->S1qs, zxp, Hp, b->W2p, C, probes, g->tptr, g->trow, g->tval, g->tpos, w.obs_mark,             \
                            observe_nodes, n_obs, delta, orow, (long)ldo, df_maxc, df_pool)))
