@@ -2017,7 +2017,19 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
     // SPARSE / DELTA, large calls: the per-node lists of observed nodes, once per call (lt_items.cuh "pair marks")
     // (with a membership bitmap the per-pair scan is one load per entry and the join pays from ~ 4 M pairs on -- measured
     // at twitch-RU size, tools/marks_ab.py; without one -- large graphs -- it always does)
-    const bool use_marks = mode != LT_MODE_FULL && w.pm_cnt != nullptr &&
+    // DELTA at twitch size, graphs without hub rows: stage A + stage B of a probe in one block (k_delta_probe_block), no item
+    // tables, no bitmap rows, no pair marks -- when the pre-activation is formed on all rows anyway and the block's tables fit
+    // LDS ("delta_fused" = 0 keeps the item kernels; the matrices are bit-identical).  Decided once per call.
+    const int df_maxc = g->max_col_nnz > 0 ? g->max_col_nnz : 1;
+    const long df_inc = (long)df_maxc * df_maxc;       // bound on a probe's incidences: |R_v| columns of at most max_col entries
+    const int df_pool = (int)((df_inc < (long)LT_DF_MAXI * LT_BLOCK ? df_inc : (long)LT_DF_MAXI * LT_BLOCK) + 1) & ~1;
+    const size_t df_smem = (size_t)df_pool * sizeof(lt_df_inc) + (size_t)df_maxc * (C + 5) * sizeof(float) + 16 +
+                           (size_t)4 * n_obs * sizeof(int32_t);
+    const bool fused = delta64 && vec == nullptr && lt_tune().delta_fused != 0 && g->p_n_long == 0 && g->tpos != nullptr &&
+                       w.bits != nullptr && w.obs_mark != nullptr && !lt_fp64_agg_active(b) && n <= 65534 &&
+                       df_inc <= (long)LT_DF_MAXI * LT_BLOCK && df_maxc < 32768 && df_smem <= (size_t)LT_DF_LDS_MAX &&
+                       !lt_fp64_on_demand(b, n_probe);
+    const bool use_marks = !fused && mode != LT_MODE_FULL && w.pm_cnt != nullptr &&
                            (w.bits == nullptr || (long long)(n_probe < w.chunk ? n_probe : w.chunk) * n_obs >= lt_tune().pair_marks);
     // observed hubs (stageB_long_block): members found from the short side, or every entry tested against every probe.
     // With a bitmap row per probe (twitch size) the per-entry test is one cached load and wins; without one it is a search
@@ -2165,19 +2177,7 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
             const unsigned *marks = nullptr;
             // DELTA on an S1d route whose pre-activation is still to be formed, all rows at once: the item tables ride in that
             // launch (lt_fp64_prepare_rows); otherwise -- and always in SPARSE -- a launch of their own
-            // DELTA at twitch size, graphs without hub rows: stage A + stage B of a probe in one block (k_delta_probe_block),
-            // no item tables, no bitmap rows -- when the pre-activation is formed on all rows anyway and a position per node
-            // fits LDS as 16 bits ("delta_fused" = 0 keeps the three launches; the matrices are bit-identical)
             {
-                const int df_maxc = g->max_col_nnz > 0 ? g->max_col_nnz : 1;
-                const long df_inc = (long)df_maxc * df_maxc;       // bound on a probe's incidences: |R_v| columns of at most max_col entries
-                const int df_pool = (int)((df_inc < (long)LT_DF_MAXI * LT_BLOCK ? df_inc : (long)LT_DF_MAXI * LT_BLOCK) + 1) & ~1;
-                const size_t df_smem = (size_t)df_pool * sizeof(lt_df_inc) + (size_t)df_maxc * (C + 5) * sizeof(float) + 16 +
-                                       (size_t)4 * n_obs * sizeof(int32_t);
-                const bool fused = delta64 && vec == nullptr && lt_tune().delta_fused != 0 && g->p_n_long == 0 && g->tpos != nullptr &&
-                                   w.bits != nullptr && !use_marks && w.obs_mark != nullptr && !lt_fp64_agg_active(b) && n <= 65534 &&
-                                   df_inc <= (long)LT_DF_MAXI * LT_BLOCK && df_maxc < 32768 &&
-                                   df_smem <= (size_t)LT_DF_LDS_MAX && !lt_fp64_on_demand(b, n_probe);
                 if (fused) {
                     // node -> observed position, once per call: as a trailing block of the launch that forms the pre-activation
                     // when there is one (nothing in it depends on the table), else a launch of its own
