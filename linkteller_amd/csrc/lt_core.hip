@@ -123,6 +123,8 @@ static void free_graph(lt_graph *g) {
     (void)hipFree(g->trow);
     (void)hipFree(g->tval);
     (void)hipFree(g->tpos);
+    (void)hipFree(g->dl_meta);
+    (void)hipFree(g->dl_rec);
     (void)hipFree(g->w_e0);
     (void)hipFree(g->w_cnt);
     (void)hipFree(g->w_dst);
@@ -132,6 +134,103 @@ static void free_graph(lt_graph *g) {
     (void)hipFree(g->p_seg_begin);
     (void)hipFree(g->p_seg_scratch);
     delete g;
+}
+
+// The fused DELTA route's per-node incidence records (lt_items.cuh "INCIDENCE RECORD"; lt_influence.hip k_delta_probe_finish):
+// for node v, its items (the CSC column of v) and the entries (u, position in row u) that hold an item, grouped by u ascending,
+// a node's entries in entry order.  Sum over the nodes of |R_v| * column lengths entries -- 1.6 M at twitch size, 25 MB; built on
+// the host from the CSC arrays lt_graph_create has in hand.  Only for graphs whose largest record stays small (no hub rows).
+#define LT_DL_MAX_T 4096             // incidences of one node (the finish kernel holds a record in LDS)
+#define LT_DL_MAX_WORDS ((int64_t)64 << 20)   // 256 MB of records
+struct dl_host {
+    std::vector<int32_t> meta, rec;
+    int32_t max_t = 0, max_tu = 0;
+};
+static bool build_delta_records(int32_t n, const int32_t *tptr, const int32_t *trow, const float *tval, const int32_t *tpos,
+                                int32_t max_col, dl_host &out) {
+    if (n < 1 || n > 65534 || max_col >= 32768 || tpos == nullptr) return false;
+    unsigned T = std::thread::hardware_concurrency();
+    if (T < 1) T = 1;
+    if (T > 8) T = 8;
+    if ((int64_t)n < 4096) T = 1;
+    auto run = [&](auto &&fn) {
+        if (T == 1) { fn(0u); return; }
+        struct joiner {
+            std::vector<std::thread> th;
+            ~joiner() { for (auto &x : th) if (x.joinable()) x.join(); }
+        } j;
+        j.th.reserve(T);
+        for (unsigned t = 0; t < T; ++t) j.th.emplace_back(fn, t);
+    };
+    out.meta.assign((size_t)n * 4, 0);
+    std::vector<int> too_big(T, 0);
+    // pass 1: items, incidences and touched nodes of every node
+    run([&](unsigned t) {
+        std::vector<int32_t> stamp((size_t)n, -1);
+        const int32_t v0 = (int32_t)((int64_t)n * t / T), v1 = (int32_t)((int64_t)n * (t + 1) / T);
+        for (int32_t v = v0; v < v1; ++v) {
+            int64_t inc = 0;
+            int32_t touched = 0;
+            for (int32_t i = tptr[v]; i < tptr[v + 1] && inc <= LT_DL_MAX_T; ++i) {
+                const int32_t r = trow[i];
+                inc += tptr[r + 1] - tptr[r];
+                if (inc > LT_DL_MAX_T) break;
+                for (int32_t q = tptr[r]; q < tptr[r + 1]; ++q)
+                    if (stamp[trow[q]] != v) { stamp[trow[q]] = v; ++touched; }
+            }
+            if (inc > LT_DL_MAX_T) { too_big[t] = 1; return; }
+            out.meta[(size_t)v * 4 + 1] = tptr[v + 1] - tptr[v];
+            out.meta[(size_t)v * 4 + 2] = touched;
+            out.meta[(size_t)v * 4 + 3] = (int32_t)inc;
+        }
+    });
+    for (unsigned t = 0; t < T; ++t) if (too_big[t]) return false;
+    int64_t words = 0;
+    for (int32_t v = 0; v < n; ++v) {
+        int32_t *m = &out.meta[(size_t)v * 4];
+        if (words > LT_DL_MAX_WORDS) return false;
+        m[0] = (int32_t)words;
+        words += 2 * ((int64_t)m[1] + m[2] + m[3]);
+        if (m[3] > out.max_t) out.max_t = m[3];
+        if (m[2] > out.max_tu) out.max_tu = m[2];
+    }
+    if (words > LT_DL_MAX_WORDS) return false;
+    out.rec.assign((size_t)words + 4, 0);
+    // pass 2: the records
+    run([&](unsigned t) {
+        struct inc_t { uint32_t key; int32_t ik; float a; };
+        std::vector<inc_t> buf;
+        buf.reserve(LT_DL_MAX_T);
+        const int32_t v0 = (int32_t)((int64_t)n * t / T), v1 = (int32_t)((int64_t)n * (t + 1) / T);
+        for (int32_t v = v0; v < v1; ++v) {
+            const int32_t *m = &out.meta[(size_t)v * 4];
+            int32_t *items = &out.rec[(size_t)m[0]], *list = items + 2 * m[1], *ent = list + 2 * m[2];
+            buf.clear();
+            for (int32_t i = tptr[v]; i < tptr[v + 1]; ++i) {
+                const int32_t r = trow[i], item = i - tptr[v];
+                items[2 * item] = r;
+                memcpy(&items[2 * item + 1], &tval[i], sizeof(float));
+                for (int32_t q = tptr[r]; q < tptr[r + 1]; ++q)
+                    buf.push_back({((uint32_t)trow[q] << 16) | (uint32_t)tpos[q], (item << 16) | tpos[q], tval[q]});
+            }
+            std::sort(buf.begin(), buf.end(), [](const inc_t &x, const inc_t &y) { return x.key < y.key; });
+            int32_t nl = 0;
+            for (size_t e = 0; e < buf.size();) {
+                size_t f = e;
+                const uint32_t u = buf[e].key >> 16;
+                while (f < buf.size() && (buf[f].key >> 16) == u) ++f;
+                list[2 * nl] = (int32_t)u;
+                list[2 * nl + 1] = (int32_t)e | ((int32_t)(f - e) << 16);
+                ++nl;
+                e = f;
+            }
+            for (size_t e = 0; e < buf.size(); ++e) {
+                memcpy(&ent[2 * e], &buf[e].a, sizeof(float));
+                ent[2 * e + 1] = buf[e].ik;
+            }
+        }
+    });
+    return true;
 }
 
 extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, const int32_t *col,
@@ -375,6 +474,22 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
             G_HIP(hipMemcpy(g->w_cnt, tmp.data(), wb, hipMemcpyHostToDevice));
             for (size_t i = 0; i < items.size(); ++i) tmp[i] = items[i].dst;
             G_HIP(hipMemcpy(g->w_dst, tmp.data(), wb, hipMemcpyHostToDevice));
+        }
+    }
+    // the fused DELTA route's per-node records (graphs without hub rows; a failure to build them only means the route is not taken)
+    if (g->p_n_long == 0 && tpos) {
+        try {
+            dl_host dl;
+            if (build_delta_records(n, tptr.data(), trow.get(), tval.get(), tpos.get(), max_col, dl)) {
+                G_HIP(hipMalloc((void **)&g->dl_meta, (size_t)n * sizeof(int4)));
+                G_HIP(hipMalloc((void **)&g->dl_rec, dl.rec.size() * sizeof(int32_t)));
+                G_HIP(hipMemcpy(g->dl_meta, dl.meta.data(), (size_t)n * sizeof(int4), hipMemcpyHostToDevice));
+                G_HIP(hipMemcpy(g->dl_rec, dl.rec.data(), dl.rec.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                g->dl_max_t = dl.max_t;
+                g->dl_max_tu = dl.max_tu;
+            }
+        } catch (const std::bad_alloc &) {
+        } catch (const std::system_error &) {
         }
     }
 #undef G_HIP

@@ -294,9 +294,17 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
     // the terms z is summed from.  Half the bytes stage A gathers per item (2 KB -> 1 KB) and this kernel writes.
     // job.nblocks > 0: the blocks from job_first on build the item tables of a probe chunk (k_item_bits' blocks: nothing in
     // this launch depends on them, and the launch in front of this one that they used to be cost the step 4 us)
-    if (job.nblocks > 0 && (int)blockIdx.x >= job_first) {
-        item_bits_block((int)blockIdx.x - job_first, job);
-        return;
+    // job_first < 0: the job's blocks are the FIRST of the grid instead (a record gather is three dependent round trips: started
+    // last it would finish last)
+    int bx = (int)blockIdx.x;
+    if (job.nblocks > 0) {
+        if (job_first < 0) {
+            if (bx < job.nblocks) { item_bits_block(bx, job); return; }
+            bx -= job.nblocks;
+        } else if (bx >= job_first) {
+            item_bits_block(bx - job_first, job);
+            return;
+        }
     }
     // crefv != NULL: S holds the feature rows' products WITHOUT the reference vector's (S1d - cref, lt_fp64 "deferred cref");
     // the row's share rs[r] * cref (rs = the row sum of A_hat) is added with the bias
@@ -305,8 +313,8 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int gl = lane & (LPR - 1);
-    const bool SEG = (int)blockIdx.x < seg_blocks;      // block-uniform: the first blocks take the segments of the hub rows
-    const int wave = ((SEG ? (int)blockIdx.x : (int)blockIdx.x - seg_blocks) * 256 + threadIdx.x) >> 6;
+    const bool SEG = bx < seg_blocks;      // block-uniform: the first blocks take the segments of the hub rows
+    const int wave = ((SEG ? bx : bx - seg_blocks) * 256 + threadIdx.x) >> 6;
     int r = wave * RPW + lane / LPR;
     if (LPR == 64) r = __builtin_amdgcn_readfirstlane(r);
     if (r >= (SEG ? n_seg : n)) return;
@@ -1138,11 +1146,11 @@ static int form_z1d(lt_baseline *b, int32_t *state, hipStream_t st, const lt_bit
     if (b->s1_f32) {
         LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, float>), dim3(g2 + gs + gj), dim3(256), 0, st, n, g->rowptr,
                                                 g->col, g->val, b->S1x, Hp, b->b1p, b->Z1d, (int)gs, g->p_n_seg, g->p_seg_begin,
-                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv, jb, (int)(g2 + gs), zf, b->S1qs));
+                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv, jb, jb.dl_rec ? -1 : (int)(g2 + gs), zf, b->S1qs));
     } else {
         LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, double>), dim3(g2 + gs + gj), dim3(256), 0, st, n, g->rowptr,
                                                 g->col, g->val, b->S1d, Hp, b->b1p, b->Z1d, (int)gs, g->p_n_seg, g->p_seg_begin,
-                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv, jb, (int)(g2 + gs), zf));
+                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv, jb, jb.dl_rec ? -1 : (int)(g2 + gs), zf));
     }
     LT_CHECK_LAUNCH();
     if (have_long) {

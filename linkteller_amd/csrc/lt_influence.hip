@@ -1203,98 +1203,72 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_hubs(
 // against every probe -- 4.75 M (probe, entry) tests at n_test = 500 for the 7 % of the pairs a probe touches at all; those
 // tests, not latency or cache lines, are what it costs (a per-probe block that still tested every entry took the same 18 us
 // whether it made 24 or 6 dependent round trips and whether its loads were coalesced: ~20 instructions per test).
-// Here the touched pairs are ENUMERATED from the probe's side instead: the members of R_v are the CSC column of v (the items),
-// the rows that hold member r are the CSC column of r, `obs_mark` says which of those rows are observed (and where), and
-// `tpos` which entry of the row the member is -- ~ |R_v| * average column length = 360 incidences per probe instead of 9 500
-// tests.  Per observed row the incidences are then put in entry order and summed exactly as row2_dot would: entry k feeds
-// chain k & 7, a chain is a k-ordered fmaf sequence from +0, the chains are added by the xor 4, 2, 1 butterfly, then d / delta
-// and the fmaf sum of squares.  Stage A's arithmetic is k_item_stageA_d2's, statement by statement.  So the matrix has the
-// bits of the three-launch route (`delta_fused` = 0; tests/test_gpu_round4.py compares them).  Graphs without hub rows,
-// n <= 65534, column length^2 <= LT_DF_MAXI * 256 incidences per probe, n_obs small enough for the LDS tables below.
+// Here the touched pairs are ENUMERATED from the probe's side instead, ~ 360 incidences per probe instead of 9 500 tests, in
+// two halves: the part that depends on the graph alone -- the probe's items and, per touched node, its member entries in
+// entry order -- is a record written by delta_lists_block (lt_items.cuh) as extra blocks of the launch that forms the
+// pre-activation, where it costs nothing; this kernel, one block per probe, runs stage A over the record's items
+// (k_item_stageA_d2's arithmetic, statement by statement) and then, per observed position, finds the node among the probe's
+// touched nodes (a binary search in LDS; a repeated observed node is simply found twice) and sums its entries exactly as
+// row2_dot would: entry k feeds chain k & 7, a chain is a k-ordered fmaf sequence from +0, the chains are added by the xor
+// 4, 2, 1 butterfly, then d / delta and the fmaf sum of squares.  So the matrix has the bits of the three-launch route
+// (`delta_fused` = 0; tests/test_gpu_round4.py compares them).  Graphs without hub rows, n <= 65534, column length^2 <=
+// the largest record within LT_DF_LDS_MAX.
+#ifdef LT_DF_TRACE      // tools/df_trace.py: phase stamps of every wave of k_delta_probe_finish on the constant 100 MHz clock
+#define LT_DF_TRACE_BLOCKS 4096
+__device__ unsigned long long g_df_trace[LT_DF_TRACE_BLOCKS * 4 * 8];
+extern "C" int lt_debug_df_trace(unsigned long long *host_out, int n_words) {
+    LT_HIP(hipDeviceSynchronize());
+    LT_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_df_trace), (size_t)n_words * sizeof(unsigned long long)));
+    return LT_OK;
+}
+#define DF_STAMP(k_)                                                                                                   \
+    do {                                                                                                               \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < LT_DF_TRACE_BLOCKS)                                                \
+            g_df_trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k_)] = wall_clock64();                     \
+    } while (0)
+#else
+#define DF_STAMP(k_)
+#endif
 #define LT_DF_U 4          // items in flight per lane group in stage A
-#define LT_DF_LDS_MAX (144 * 1024)   // dynamic LDS the kernel may be given (n_obs up to ~ 7 000 beside a 32 KB pool)
-#define LT_DF_MAXI 16      // incidences per thread (registers between the counting and the placing pass)
-struct lt_df_inc { float a; int ik; };      // A_hat[u, r] and (item << 16 | entry position in row u)
+#define LT_DF_LDS_MAX (144 * 1024)   // dynamic LDS a kernel of this route may be given
 template <int LPR, int CP, bool SX, bool ZF>
-__global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_block(
+__global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_finish(
     const double *__restrict__ Z1d, const double *__restrict__ S1d, const float *__restrict__ S1x,
     const double *__restrict__ crefv, const double *__restrict__ S1qs, const float *__restrict__ Z1x, int Hp,
-    const float *__restrict__ W2p, int C, const int32_t *__restrict__ probes, const int32_t *__restrict__ tptr,
-    const int32_t *__restrict__ trow, const float *__restrict__ tval, const int32_t *__restrict__ tpos,
-    const int32_t *__restrict__ obs_mark, const int32_t *__restrict__ observe, int n_obs,
-    float delta, float *__restrict__ out, long ldo, int maxc, int pool_cap) {
+    const float *__restrict__ W2p, int C, const int32_t *__restrict__ probes, const int32_t *__restrict__ rec, int rec_words,
+    int maxc, int lcap, int pool_cap, const int32_t *__restrict__ observe, int n_obs,
+    float delta, float *__restrict__ out, long ldo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char df_smem[];
-    // LDS: pool [pool_cap = min(MAXI * 256, maxc^2)] inc | sS2 [maxc][C] f32 | sR, sC0, sCn, sIo [maxc (+1)] i32 | sAv [maxc] f32 | sCnt, sOff, sRes, sLong [n_obs]
-    lt_df_inc *pool = reinterpret_cast<lt_df_inc *>(df_smem);
-    float *sS2 = reinterpret_cast<float *>(pool + pool_cap);
-    int32_t *sR = reinterpret_cast<int32_t *>(sS2 + (size_t)maxc * C);
-    int32_t *sC0 = sR + maxc, *sCn = sC0 + maxc, *sIo = sCn + maxc;      // column of item i: first CSC entry, length; incidence offset [maxc + 1]
-    float *sAv = reinterpret_cast<float *>(sIo + maxc + 1);
-    int32_t *sCnt = reinterpret_cast<int32_t *>(sAv + maxc), *sOff = sCnt + n_obs;
-    float *sRes = reinterpret_cast<float *>(sOff + n_obs);
-    __shared__ int32_t s_wsum[LT_BLOCK / 64];
+    // LDS: sEnt [pool_cap] inc | sList [lcap] (u, start | count << 16) | sS2 [maxc][C] f32 | sLong [pool_cap / 4 + 1]
+    lt_df_inc *sEnt = reinterpret_cast<lt_df_inc *>(df_smem);
+    int2 *sList = reinterpret_cast<int2 *>(sEnt + pool_cap);
+    float *sS2 = reinterpret_cast<float *>(sList + lcap);
+    int32_t *sLong = reinterpret_cast<int32_t *>(sS2 + (size_t)maxc * C);      // the touched nodes with more than 4 member entries
+    __shared__ int32_t s_nlong;
+    if (threadIdx.x == 0) s_nlong = 0;
     constexpr int RPW = 64 / LPR, WAVES = LT_BLOCK / 64;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.x;
+    DF_STAMP(0);
+    const int32_t *R = rec + (size_t)b * rec_words;
+    const int2 *gItems = reinterpret_cast<const int2 *>(R + 4);
+    const int2 *gList = reinterpret_cast<const int2 *>(R + 4 + 2 * maxc);
+    const lt_df_inc *gEnt = reinterpret_cast<const lt_df_inc *>(R + 4 + 2 * maxc + 2 * lcap);
     const int v = probes[b];
-    const int t0 = tptr[v], cnt = tptr[v + 1] - t0;
-    // where each observed position's result will come from (a repeated node: its first position): needed last, asked first
-    constexpr int JPT = 4;                                    // positions per thread held in registers (n_obs <= JPT * 256: else re-read)
-    int canon[JPT];
+    // the observed nodes this thread answers for: needed last, asked first
+    constexpr int JPT = 2;                                    // positions per thread held in registers (beyond: re-read)
+    int obs_u[JPT];
 #pragma unroll
     for (int h = 0; h < JPT; ++h) {
         const int j = tid + h * LT_BLOCK;
-        canon[h] = j < n_obs ? obs_mark[observe[j]] : 0;
+        obs_u[h] = j < n_obs ? observe[j] : 0;
     }
-    for (int i = tid; i < cnt; i += LT_BLOCK) {
-        const int r = trow[t0 + i];
-        sR[i] = r;
-        sAv[i] = tval[t0 + i];
-        const int c0 = tptr[r];
-        sC0[i] = c0;
-        sCn[i] = tptr[r + 1] - c0;
-    }
-    for (int j = tid; j < n_obs; j += LT_BLOCK) sCnt[j] = 0;
-    __syncthreads();
-    if (wid == 0) {      // exclusive scan of the items' column lengths -> the incidences' numbering (one wave: cnt is a few dozen)
-        int carry = 0;
-        for (int i0 = 0; i0 < cnt; i0 += 64) {
-            const int i = i0 + lane;
-            const int x = i < cnt ? sCn[i] : 0;
-            int inc = x;
-#pragma unroll
-            for (int m = 1; m < 64; m <<= 1) {
-                const int y = __shfl_up(inc, m, 64);
-                if (lane >= m) inc += y;
-            }
-            if (i < cnt) sIo[i] = carry + inc - x;
-            carry += __shfl(inc, 63, 64);
-        }
-        if (lane == 0) sIo[cnt] = carry;
-    }
-    __syncthreads();
-    // the incidences (member r_i of R_v, row u that holds it), numbered item by item: their three loads go out NOW and land
-    // while stage A runs
-    const int T = sIo[cnt];
-    int jx[LT_DF_MAXI], sl[LT_DF_MAXI], ii[LT_DF_MAXI], kp[LT_DF_MAXI];
-    float av[LT_DF_MAXI];
-#pragma unroll
-    for (int m = 0; m < LT_DF_MAXI; ++m) {
-        const int x = tid + m * LT_BLOCK;
-        jx[m] = -1; sl[m] = 0; ii[m] = 0; kp[m] = 0; av[m] = 0.f;
-        if (x < T) {
-            int lo = 0, hi = cnt;                            // the item whose incidence range holds x: last i with sIo[i] <= x
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (sIo[mid] <= x) lo = mid; else hi = mid;
-            }
-            ii[m] = lo;
-            const int t = sC0[lo] + (x - sIo[lo]);
-            jx[m] = trow[t];
-            av[m] = tval[t];
-            kp[m] = tpos[t];
-        }
-    }
+    const int4 hdr = *reinterpret_cast<const int4 *>(R);
+    const int cnt = hdr.x, Tu = hdr.y, T = hdr.z;
+    // the record's lists, on their way to LDS while stage A runs (the first two rounds in registers)
+    constexpr int CPR = 2;
+    int2 lreg[CPR];
+    lt_df_inc ereg[CPR];
     // ---- stage A: this probe's items (k_item_stageA_d2, statement by statement) ----
     {
         const int gl = lane & (LPR - 1);
@@ -1327,16 +1301,27 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_block(
         }
         constexpr int U = LT_DF_U;
         const int stride = WAVES * RPW;
-        for (int base = wid * RPW + lane / LPR; base < cnt; base += U * stride) {
+#pragma unroll
+        for (int h = 0; h < CPR; ++h) {
+            const int x = tid + h * LT_BLOCK;
+            lreg[h] = gList[x < Tu ? x : 0];
+            ereg[h] = gEnt[x < T ? x : 0];
+        }
+        // (the first trip's items are asked for before the header is back: the record holds maxc item slots, the unused ones
+        // naming row 0 -- loaded, never stored)
+        int base = wid * RPW + lane / LPR;
+        do {
             int it[U];
-            float arv[U];
-            f64x4 z[U];
+            int2 itm[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 it[u] = base + u * stride;
-                const int ic = min(it[u], cnt - 1);          // past the end: the last item again, never stored
-                arv[u] = sAv[ic];
-                const int r = sR[ic];
+                itm[u] = gItems[min(it[u], maxc - 1)];
+            }
+            f64x4 z[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = itm[u].x;
                 if constexpr (ZF) {
                     const f32x4 zf = ld4(Z1x + (size_t)r * Hp + coff);
                     z[u] = f64x4{(double)zf[0], (double)zf[1], (double)zf[2], (double)zf[3]};
@@ -1346,6 +1331,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_block(
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
+                const float arv = __int_as_float(itm[u].y);
                 float part[CP];
 #pragma unroll
                 for (int c = 0; c < CP; ++c) part[c] = 0.f;
@@ -1353,7 +1339,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_block(
                     float dh[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float dz = arv[u] * ds[k];
+                        const float dz = arv * ds[k];
                         const double zz = z[u][k], z1 = zz + (double)dz;
                         dh[k] = zz > 0.0 ? (z1 > 0.0 ? dz : (float)(-zz)) : (z1 > 0.0 ? (float)z1 : 0.f);
                     }
@@ -1375,86 +1361,76 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_block(
                         if (c < C) sS2[(size_t)it[u] * C + c] = part[c];
                 }
             }
-        }
+            base += U * stride;
+        } while (base < cnt);
     }
-    __syncthreads();
-    // ---- count the incidences per observed position ----
+    DF_STAMP(1);
+    __syncthreads();                                              // (s_nlong = 0 is visible)
+    DF_STAMP(2);
 #pragma unroll
-    for (int m = 0; m < LT_DF_MAXI; ++m) {
-        const int x = tid + m * LT_BLOCK;
-        if (x < T) {
-            const int j = obs_mark[jx[m]];
-            jx[m] = j < n_obs ? j : -1;
-            if (jx[m] >= 0) sl[m] = atomicAdd(&sCnt[jx[m]], 1);
+    for (int h = 0; h < CPR; ++h) {
+        const int x = tid + h * LT_BLOCK;
+        if (x < Tu) {
+            sList[x] = lreg[h];
+            if ((lreg[h].y >> 16) > 4) sLong[atomicAdd(&s_nlong, 1)] = x;
         }
+        if (x < T) sEnt[x] = ereg[h];
     }
+    for (int x = tid + CPR * LT_BLOCK; x < Tu; x += LT_BLOCK) {
+        const int2 le = gList[x];
+        sList[x] = le;
+        if ((le.y >> 16) > 4) sLong[atomicAdd(&s_nlong, 1)] = x;
+    }
+    for (int x = tid + CPR * LT_BLOCK; x < T; x += LT_BLOCK) sEnt[x] = gEnt[x];
     __syncthreads();
-    {   // exclusive scan of the counts over the observed positions (block-wide, 256 at a time)
-        int carry = 0;
-        for (int j0 = 0; j0 < n_obs; j0 += LT_BLOCK) {
-            const int j = j0 + tid;
-            const int x = j < n_obs ? sCnt[j] : 0;
-            int inc = x;
-#pragma unroll
-            for (int m = 1; m < 64; m <<= 1) {
-                const int y = __shfl_up(inc, m, 64);
-                if (lane >= m) inc += y;
+    DF_STAMP(3);
+    // ---- the nodes with more than 4 member entries (row v itself holds ALL of R_v): one wave each; lane (c, qq) =
+    // (l >> 3, l & 7) walks the list for chain qq of class c, the 8-lane butterfly is row2_dot's own.  The result replaces
+    // the list's first entry (.a), where the per-position pass below picks it up.
+    const int nlong = s_nlong;
+    for (int s_ = wid; s_ < nlong; s_ += WAVES) {                    // (wave-uniform)
+        const int pk = sList[sLong[s_]].y, st = pk & 0xffff, c_ = pk >> 16;
+        lt_df_inc *e = sEnt + st;
+        const int qq = lane & (LT_L2_LANES - 1), c = lane >> 3;
+        float acc = 0.f;
+        if (c < C)
+            for (int y = 0; y < c_; ++y) {
+                const lt_df_inc ey = e[y];
+                if ((ey.ik & (LT_L2_LANES - 1)) == qq) acc = fmaf(ey.a, sS2[(size_t)(ey.ik >> 16) * C + c], acc);
             }
-            if (lane == 63) s_wsum[wid] = inc;
-            __syncthreads();
-            int before = carry;
-            for (int w_ = 0; w_ < wid; ++w_) before += s_wsum[w_];
-            if (j < n_obs) sOff[j] = before + inc - x;
-            carry += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-            __syncthreads();
+        const float o = group_sum<LT_L2_LANES>(acc);
+        float ss = 0.f;
+        for (int cc = 0; cc < C; ++cc) {
+            const float oc = __shfl(o, cc * LT_L2_LANES, 64);
+            const float dd = oc / delta;
+            ss = fmaf(dd, dd, ss);
         }
-    }
-#pragma unroll
-    for (int m = 0; m < LT_DF_MAXI; ++m) {
-        if (jx[m] >= 0) {
-            lt_df_inc e;
-            e.a = av[m];
-            e.ik = (ii[m] << 16) | kp[m];
-            pool[sOff[jx[m]] + sl[m]] = e;
-        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) e[0].a = sqrtf(ss);
     }
     __syncthreads();
-    // ---- per observed position: its incidences in entry order, the 8 chains, the butterfly, the norm ----
-    // Lists of up to 4 incidences (all but one or two per probe) by one thread in registers: a sorting network on the entry
-    // position, then every (entry, chain) pair as a select -- no loop, no LDS in the arithmetic.  Longer lists (the pair
-    // (v, v): row v holds ALL of R_v) are left to a whole wave below.
-    __shared__ int32_t s_nlong;
-    int32_t *sLong = reinterpret_cast<int32_t *>(sRes + n_obs);        // [n_obs] the positions with a long list
-    if (tid == 0) s_nlong = 0;
-    __syncthreads();
-    for (int j = tid; j < n_obs; j += LT_BLOCK) {
-        const int c_ = sCnt[j];
-        if (c_ == 0) { sRes[j] = 0.f; continue; }
-        if (c_ > 4) {
-            sLong[atomicAdd(&s_nlong, 1)] = j;
-            continue;
-        }
-        const lt_df_inc *e = pool + sOff[j];
+    DF_STAMP(4);
+    // ---- per observed position: find the node, sum its entries (already in entry order): every (entry, chain) pair as a
+    // select -- no loop, no sorting, nothing but LDS reads in the arithmetic
+    float *orow = out + (long)b * ldo;
+    auto answer = [&](const int u, const int lo) -> float {       // lo: lower bound of u among the touched nodes
+        if (lo >= Tu) return 0.f;
+        const int2 le = sList[lo];
+        if (le.x != u) return 0.f;
+        const int st = le.y & 0xffff, c_ = le.y >> 16;
+        const lt_df_inc *e = sEnt + st;
+        if (c_ > 4) return e[0].a;
         float a[4], tv[4][CP];
         int k[4];
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
             const lt_df_inc ex = e[x < c_ ? x : 0];
             a[x] = ex.a;
-            k[x] = x < c_ ? (ex.ik & 0xffff) : (0x10000 + x);           // absent entries sort behind every real one
+            k[x] = x < c_ ? (ex.ik & (LT_L2_LANES - 1)) : -1;
             const float *t = sS2 + (size_t)(ex.ik >> 16) * C;
 #pragma unroll
             for (int c = 0; c < CP; ++c) tv[x][c] = c < C ? t[c] : 0.f;
         }
-        auto cswap = [&](int p, int q_) {                               // compare-exchange on the entry position
-            if (k[p] > k[q_]) {
-                const int tk = k[p]; k[p] = k[q_]; k[q_] = tk;
-                const float ta = a[p]; a[p] = a[q_]; a[q_] = ta;
-#pragma unroll
-                for (int c = 0; c < CP; ++c) { const float tt_ = tv[p][c]; tv[p][c] = tv[q_][c]; tv[q_][c] = tt_; }
-            }
-        };
-        cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
         float ss = 0.f;
 #pragma unroll
         for (int c = 0; c < CP; ++c) {
@@ -1463,8 +1439,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_block(
             for (int qq = 0; qq < LT_L2_LANES; ++qq) {
                 float acc = 0.f;
 #pragma unroll
-                for (int x = 0; x < 4; ++x)
-                    acc = (k[x] < 0x10000 && (k[x] & (LT_L2_LANES - 1)) == qq) ? fmaf(a[x], tv[x][c], acc) : acc;
+                for (int x = 0; x < 4; ++x) acc = k[x] == qq ? fmaf(a[x], tv[x][c], acc) : acc;
                 ch[qq] = acc;
             }
             // lane 0 of group_sum<8>: x += xor 4; x += xor 2; x += xor 1
@@ -1474,69 +1449,54 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_block(
                 ss = fmaf(dd, dd, ss);
             }
         }
-        sRes[j] = sqrtf(ss);
-    }
-    __syncthreads();
-    // the long lists: one wave each.  Lane l ranks entries l, l + 64, ... by position (every lane reads the whole list), the
-    // list is rewritten in order, then lane (c, qq) = (l >> 3, l & 7) walks it for chain qq of class c and the 8-lane
-    // butterfly is row2_dot's own.
+        return sqrtf(ss);
+    };
+    // (branch-free lower bounds, the thread's JPT positions searched together: a step is one LDS trip for all of them)
+    auto lower = [&](const int (&u)[JPT], int (&pos)[JPT]) {
+#pragma unroll
+        for (int h = 0; h < JPT; ++h) pos[h] = 0;
+        for (int nrem = Tu; nrem > 1;) {
+            const int half = nrem >> 1;
+#pragma unroll
+            for (int h = 0; h < JPT; ++h) pos[h] = sList[pos[h] + half - 1].x < u[h] ? pos[h] + half : pos[h];
+            nrem -= half;
+        }
+#pragma unroll
+        for (int h = 0; h < JPT; ++h)
+            if (Tu > 0 && sList[pos[h]].x < u[h]) ++pos[h];
+    };
     {
-        const int nl = s_nlong;
-        for (int s_ = wid; s_ < nl; s_ += WAVES) {                       // (wave-uniform)
-            const int j = sLong[s_];
-            const int c_ = sCnt[j];
-            lt_df_inc *e = pool + sOff[j];
-            lt_df_inc mine[2];
-            int rank[2];
+        int pos[JPT];
+        lower(obs_u, pos);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int x = lane + 64 * h;
-                mine[h] = e[x < c_ ? x : 0];
-                rank[h] = 0;
-            }
-            for (int y = 0; y < c_; ++y) {
-                const int ky = e[y].ik & 0xffff;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) rank[h] += ky < (mine[h].ik & 0xffff) ? 1 : 0;      // (positions inside one row are distinct)
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                if (lane + 64 * h < c_) e[rank[h]] = mine[h];
-            __builtin_amdgcn_wave_barrier();
-            const int qq = lane & (LT_L2_LANES - 1), c = lane >> 3;
-            float acc = 0.f;
-            if (c < C)
-                for (int y = 0; y < c_; ++y) {
-                    const lt_df_inc ey = e[y];
-                    if ((ey.ik & (LT_L2_LANES - 1)) == qq) acc = fmaf(ey.a, sS2[(size_t)(ey.ik >> 16) * C + c], acc);
-                }
-            const float o = group_sum<LT_L2_LANES>(acc);
-            float ss = 0.f;
-            for (int cc = 0; cc < C; ++cc) {
-                const float oc = __shfl(o, cc * LT_L2_LANES, 64);
-                const float dd = oc / delta;
-                ss = fmaf(dd, dd, ss);
-            }
-            if (lane == 0) sRes[j] = sqrtf(ss);
+        for (int h = 0; h < JPT; ++h) {
+            const int j = tid + h * LT_BLOCK;
+            if (j < n_obs) orow[j] = answer(obs_u[h], pos[h]);
         }
     }
-    __syncthreads();
-    float *orow = out + (long)b * ldo;
+    DF_STAMP(5);
+    for (int j0 = JPT * LT_BLOCK; j0 < n_obs; j0 += JPT * LT_BLOCK) {        // (block-uniform trips)
+        int u[JPT], pos[JPT];
 #pragma unroll
-    for (int h = 0; h < JPT; ++h) {
-        const int j = tid + h * LT_BLOCK;
-        if (j < n_obs) orow[j] = sRes[canon[h]];
+        for (int h = 0; h < JPT; ++h) {
+            const int j = j0 + tid + h * LT_BLOCK;
+            u[h] = j < n_obs ? observe[j] : 0;
+        }
+        lower(u, pos);
+#pragma unroll
+        for (int h = 0; h < JPT; ++h) {
+            const int j = j0 + tid + h * LT_BLOCK;
+            if (j < n_obs) orow[j] = answer(u[h], pos[h]);
+        }
     }
-    for (int j = tid + JPT * LT_BLOCK; j < n_obs; j += LT_BLOCK) orow[j] = sRes[obs_mark[observe[j]]];
 }
 
-// beyond the default 64 KB of dynamic LDS the kernel is told, once per instantiation, that it may take most of a CU's 160 KB
+// beyond the default 64 KB of dynamic LDS a kernel is told, once, that it may take most of a CU's 160 KB
 template <int LPR, int CP, bool SX, bool ZF>
 static int df_allow_big_lds() {
     static bool done = false;
     if (!done) {
-        LT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_delta_probe_block<LPR, CP, SX, ZF>),
+        LT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_delta_probe_finish<LPR, CP, SX, ZF>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LT_DF_LDS_MAX));
         done = true;
     }
@@ -1863,6 +1823,20 @@ static int probe_kslice(const lt_baseline *b) {
     return k > 0 ? (k + 15) / 16 * 16 : lt_gemm_pick_kslice(b->n, b->H, b->F);
 }
 
+// the fused DELTA route's sizes (delta_record_block + k_delta_probe_finish): whether the graph qualifies at all
+struct df_geom { int maxc, pool, lcap, rec_words; size_t finish_smem; bool ok; };
+static df_geom df_geometry(const lt_graph *g, int C) {
+    df_geom d = {};
+    d.maxc = g->max_col_nnz > 0 ? g->max_col_nnz : 1;
+    d.pool = (g->dl_max_t + 2) & ~1;
+    d.lcap = (g->dl_max_tu + 2) & ~1;
+    d.rec_words = lt_dl_rec_words(d.maxc, d.lcap, d.pool);
+    d.finish_smem = (size_t)d.pool * sizeof(lt_df_inc) + (size_t)d.lcap * sizeof(int2) + (size_t)d.maxc * C * sizeof(float) +
+                    ((size_t)d.pool / 4 + 1) * sizeof(int32_t);
+    d.ok = g->dl_meta != nullptr && d.finish_smem <= (size_t)LT_DF_LDS_MAX;
+    return d;
+}
+
 struct infl_ws {
     float *Sp, *S2p;       // FULL / SPARSE: S1 rows of the perturbed probes; FULL: per-probe S2
     float *lpart;          // FULL: segment sums of the long rows [segment][group][P + 1][Hp]
@@ -1871,7 +1845,7 @@ struct infl_ws {
     float *slabs;          // FULL / SPARSE: split-K partials of the perturbed-row GEMM
     float *S2x;            // SPARSE / DELTA: per-item values
     double *Spd;           // DELTA, aggregate-first route: fp64 product rows of the chunk's probes [chunk, Hp]
-    int32_t *obs_mark;     // DELTA, fused route: node -> position in the observed list (obs_mark_block)
+    int32_t *dl_rec;       // DELTA, fused route: the probes' incidence records [chunk][rec_words] (delta_lists_block)
     int32_t *off;          // SPARSE / DELTA: item offsets [chunk + 1]
     int2 *item_pr;         // SPARSE / DELTA: (probe index, row) of every item
     int2 *item_va;         // DELTA: (probe node, A_hat[row, probe node] as bits) of every item
@@ -1917,8 +1891,11 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int n_o
         w.lhit = (unsigned *)take(nseg * ((chunk + 7) / 8 + 1) * sizeof(unsigned));   // per (segment, group): probes with a slot of their own
     }
     if (mode == LT_MODE_DELTA) w.Spd = (double *)take(chunk * Hp * sizeof(double));   // aggregate-first: X[probes] W1 in fp64
-    if (mode == LT_MODE_DELTA && b->g->tpos != nullptr && b->g->p_n_long == 0)      // k_delta_probe_block: node -> observed position
-        w.obs_mark = (int32_t *)take(n * sizeof(int32_t));
+    {   // the fused route's records (k_delta_probe_finish), when the graph qualifies and they stay modest
+        const df_geom dg = df_geometry(b->g, (int)C);
+        if (mode == LT_MODE_DELTA && dg.ok && chunk * (size_t)dg.rec_words * sizeof(int32_t) <= ((size_t)1 << 30))
+            w.dl_rec = (int32_t *)take(chunk * (size_t)dg.rec_words * sizeof(int32_t));
+    }
     if (mode != LT_MODE_FULL) {
         w.hub_obs = (int32_t *)take(((size_t)n_obs + 1) * sizeof(int32_t));   // the observed nodes that are hub rows (k_item_bits)
         w.S2x = (float *)take(chunk * maxc * C * sizeof(float));
@@ -2020,15 +1997,9 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
     // DELTA at twitch size, graphs without hub rows: stage A + stage B of a probe in one block (k_delta_probe_block), no item
     // tables, no bitmap rows, no pair marks -- when the pre-activation is formed on all rows anyway and the block's tables fit
     // LDS ("delta_fused" = 0 keeps the item kernels; the matrices are bit-identical).  Decided once per call.
-    const int df_maxc = g->max_col_nnz > 0 ? g->max_col_nnz : 1;
-    const long df_inc = (long)df_maxc * df_maxc;       // bound on a probe's incidences: |R_v| columns of at most max_col entries
-    const int df_pool = (int)((df_inc < (long)LT_DF_MAXI * LT_BLOCK ? df_inc : (long)LT_DF_MAXI * LT_BLOCK) + 1) & ~1;
-    const size_t df_smem = (size_t)df_pool * sizeof(lt_df_inc) + (size_t)df_maxc * (C + 5) * sizeof(float) + 16 +
-                           (size_t)4 * n_obs * sizeof(int32_t);
-    const bool fused = delta64 && vec == nullptr && lt_tune().delta_fused != 0 && g->p_n_long == 0 && g->tpos != nullptr &&
-                       w.bits != nullptr && w.obs_mark != nullptr && !lt_fp64_agg_active(b) && n <= 65534 &&
-                       df_inc <= (long)LT_DF_MAXI * LT_BLOCK && df_maxc < 32768 && df_smem <= (size_t)LT_DF_LDS_MAX &&
-                       !lt_fp64_on_demand(b, n_probe);
+    const df_geom dg = df_geometry(g, C);
+    const bool fused = delta64 && vec == nullptr && lt_tune().delta_fused != 0 && dg.ok && w.dl_rec != nullptr &&
+                       !lt_fp64_agg_active(b) && !lt_fp64_on_demand(b, n_probe);
     const bool use_marks = !fused && mode != LT_MODE_FULL && w.pm_cnt != nullptr &&
                            (w.bits == nullptr || (long long)(n_probe < w.chunk ? n_probe : w.chunk) * n_obs >= lt_tune().pair_marks);
     // observed hubs (stageB_long_block): members found from the short side, or every entry tested against every probe.
@@ -2179,16 +2150,20 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
             // launch (lt_fp64_prepare_rows); otherwise -- and always in SPARSE -- a launch of their own
             {
                 if (fused) {
-                    // node -> observed position, once per call: as a trailing block of the launch that forms the pre-activation
-                    // when there is one (nothing in it depends on the table), else a launch of its own
-                    if (p0 == 0) {
-                        bool rode = false;
+                    // the records of the chunk's probes: as extra blocks of the launch that forms the pre-activation when there is
+                    // one (nothing in it depends on them, and it hides them), else a launch of their own
+                    {
                         lt_bits_job cj = {};
-                        cj.observe = observe_nodes; cj.n_obs = n_obs; cj.nblocks = 1; cj.obs_mark = w.obs_mark; cj.n_nodes = n;
-                        int rc = lt_fp64_prepare_rows(b, nullptr, 0, nullptr, n_probe, st, &cj, &rode);      // (all rows: no item tables needed)
-                        if (rc) return rc;
+                        cj.probes = probes; cj.nb = nb; cj.nblocks = nb; cj.dl_rec = w.dl_rec; cj.dl_meta = g->dl_meta; cj.dl_src = g->dl_rec;
+                        cj.dl_maxc = dg.maxc; cj.dl_lcap = dg.lcap; cj.dl_rec_words = dg.rec_words;
+                        bool rode = false;
+                        if (p0 == 0) {
+                            int rc = lt_fp64_prepare_rows(b, nullptr, 0, nullptr, n_probe, st, &cj, &rode);      // (all rows: no item tables needed)
+                            if (rc) return rc;
+                        }
                         if (!rode) {
-                            hipLaunchKernelGGL(k_obs_mark, dim3(1), dim3(256), 0, st, observe_nodes, n_obs, n, w.obs_mark);
+                            lt_prof_scope prof_(LT_K_ITEM_BITS, st);
+                            hipLaunchKernelGGL(k_delta_records, dim3((unsigned)nb), dim3(256), 0, st, cj);
                             LT_CHECK_LAUNCH();
                         }
                     }
@@ -2196,14 +2171,13 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
                     const float *sxp = b->s1_f32 ? b->S1x : (const float *)nullptr;
                     const float *zxp = b->z1x_valid ? b->Z1x : (const float *)nullptr;
                     const double *crp = b->cref_deferred ? b->fd_cref : (const double *)nullptr;
-                    // (beyond the default 64 KB of dynamic LDS -- every node observed, `balanced-full` -- the kernel is told once per
-                    // instantiation that it may take most of the CU's 160 KB: one block per CU then, still far fewer operations)
+                    // (beyond the default 64 KB of dynamic LDS the kernel is told once per instantiation that it may take more)
 #define LT_DF_LAUNCH(SX_, ZF_)                                                                                                        \
     LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,                                                                                           \
-        if (df_smem > (size_t)64 * 1024) { const int rc_ = df_allow_big_lds<LPR_, CP_, SX_, ZF_>(); if (rc_) return rc_; }           \
-        hipLaunchKernelGGL((k_delta_probe_block<LPR_, CP_, SX_, ZF_>), dim3((unsigned)nb), dim3(LT_BLOCK), df_smem, st, b->Z1d, b->S1d, \
-                           sxp, crp, b->S1qs, zxp, Hp, b->W2p, C, probes, g->tptr, g->trow, g->tval, g->tpos, w.obs_mark,             \
-                           observe_nodes, n_obs, delta, orow, (long)ldo, df_maxc, df_pool)))
+        if (dg.finish_smem > (size_t)64 * 1024) { const int rc_ = df_allow_big_lds<LPR_, CP_, SX_, ZF_>(); if (rc_) return rc_; }    \
+        hipLaunchKernelGGL((k_delta_probe_finish<LPR_, CP_, SX_, ZF_>), dim3((unsigned)nb), dim3(LT_BLOCK), dg.finish_smem, st,      \
+                           b->Z1d, b->S1d, sxp, crp, b->S1qs, zxp, Hp, b->W2p, C, probes, w.dl_rec, dg.rec_words, dg.maxc, dg.lcap,   \
+                           dg.pool, observe_nodes, n_obs, delta, orow, (long)ldo)))
                     if (sxp && zxp) { LT_DF_LAUNCH(true, true); }
                     else if (sxp) { LT_DF_LAUNCH(true, false); }
                     else { LT_DF_LAUNCH(false, false); }

@@ -26,7 +26,11 @@ struct lt_graph {
     int32_t *trow = nullptr;
     float *tval = nullptr;
     int32_t *tpos = nullptr;   // [nnz] position of the CSC entry inside its ROW (k - rowptr[r]); graphs of up to 65534 nodes only
-                               // (k_delta_probe_block: which of the row's 8 chains a member feeds, and in which order)
+    // the fused DELTA route's per-node incidence records (lt_items.cuh; graphs of up to 65534 nodes without hub rows whose
+    // largest record fits LDS), or NULL
+    int4 *dl_meta = nullptr;      // [n] (offset into dl_rec in words, items, touched nodes, incidences)
+    int32_t *dl_rec = nullptr;
+    int32_t dl_max_t = 0, dl_max_tu = 0;   // largest incidence / touched-node count of a node
     // Long rows (hubs).  A row of more than LT_ROW_SEG entries is summed segment by segment in EVERY kernel
     // (lt_rows.cuh row_dot: 128-entry fmaf chains, their sums added in segment order), which lets any kernel hand
     // the segments of a hub row to separate waves and still produce the same bits: the SpMM / layer-1 segment
@@ -243,12 +247,13 @@ struct lt_bits_job {
     int nblocks;      // nb, + 1 when hub_obs is wanted; 0 = no job
     const float *tval;      // with item_va: (probe node, A_hat[r, v]) of every item next to (probe index, row)
     int2 *item_va;
-    // obs_mark != NULL: the job is ONE block that fills the node -> observed-position table of k_delta_probe_block instead
-    // (lt_items.cuh obs_mark_block): obs_mark[u] = the smallest j with observe[j] == u, or LT_NOT_OBSERVED; uses observe / n_obs
-    int32_t *obs_mark;
-    int n_nodes;
+    // dl_rec != NULL: the job gathers the incidence records of the chunk's probes instead (the fused DELTA route, lt_items.cuh
+    // delta_record_block: one block per probe); uses probes / nb
+    int32_t *dl_rec;
+    const int4 *dl_meta;
+    const int32_t *dl_src;
+    int dl_maxc, dl_lcap, dl_rec_words;
 };
-#define LT_NOT_OBSERVED 0x7fffffff
 // job != NULL: *job_done says whether the job went along (it does when every row is formed by one plain launch; the on-demand
 // form needs the tables BEFORE, the caller then launches k_item_bits itself and calls again without a job)
 bool lt_fp64_on_demand(const lt_baseline *b, int n_probe_call);

@@ -117,20 +117,39 @@ static __global__ __launch_bounds__(256) void k_item_bits(const int32_t *__restr
     item_bits_block((int)blockIdx.x, tptr, trow, probes, nb, words, bits, off, item_pr, big_bits, big_slot, big_count, rowptr, observe,
                     n_obs, hub_obs, tval, item_va);
 }
-// node -> position in the observed list, for k_delta_probe_block: ONE block clears the table and scatters the list (the
-// smallest j wins where observe repeats a node: the other positions copy its result).  17 KB at twitch size.
-static __device__ __forceinline__ void obs_mark_block(const int32_t *__restrict__ observe, int n_obs, int n, int32_t *__restrict__ obs_mark) {
-    for (int u = threadIdx.x; u < n; u += blockDim.x) obs_mark[u] = LT_NOT_OBSERVED;
-    __syncthreads();
-    for (int j = threadIdx.x; j < n_obs; j += blockDim.x) atomicMin(&obs_mark[observe[j]], j);
+// ---- the fused DELTA route, first half: a probe's INCIDENCE RECORD (round 4) -----------------------------------------------
+// Everything about a probe v that depends on the graph alone is a property of NODE v, built once by lt_graph_create
+// (lt_core.hip build_delta_records; lt_graph::dl_meta / dl_rec): the items (members r of R_v = the CSC column of v, with
+// A_hat[r, v]) and, for every node u that holds a member, the entries of row u that are members -- as (A_hat[u, r], item << 16 |
+// entry position in row u), the nodes ascending, a node's entries in entry order:
+//     dl_meta[v] = (offset into dl_rec, items, touched nodes, incidences)
+//     dl_rec + offset: items (r, A_hat[r, v]) [items] | nodes (u, start | count << 16) [touched] | entries [incidences]
+// Per call, the records of the chunk's probes are gathered into one fixed-stride table (probes -> meta -> record: three
+// dependent round trips that the finish kernel then does not make -- a kernel starts with cold caches, a trip is ~ 2 us):
+//     [0] items  [1] touched nodes  [2] incidences  [3] v | items [maxc, the unused slots (0, 0)] | nodes [lcap] | entries [pool]
+// Nothing here reads a layer, so these blocks ride in the launch that forms the pre-activation (k_spmm_f64), which hides them.
+struct lt_df_inc { float a; int ik; };      // A_hat[u, r] and (item << 16 | entry position in row u)
+static inline __host__ __device__ int lt_dl_rec_words(int maxc, int lcap, int pool) { return (4 + 2 * maxc + 2 * lcap + 2 * pool + 3) & ~3; }
+static __device__ __forceinline__ void delta_record_block(const int b, const lt_bits_job &J) {
+    const int tid = threadIdx.x;
+    const int v = J.probes[b];
+    const int4 m = J.dl_meta[v];
+    const int cnt = m.y, Tu = m.z, T = m.w;
+    const int2 *__restrict__ src = reinterpret_cast<const int2 *>(J.dl_src + m.x);
+    int32_t *R = J.dl_rec + (size_t)b * J.dl_rec_words;
+    if (tid == 0) *reinterpret_cast<int4 *>(R) = make_int4(cnt, Tu, T, v);
+    int2 *gi = reinterpret_cast<int2 *>(R + 4);
+    for (int i = tid; i < J.dl_maxc; i += 256) gi[i] = i < cnt ? src[i] : make_int2(0, 0);   // (every slot: the finish kernel loads them unseen)
+    int2 *gl = reinterpret_cast<int2 *>(R + 4 + 2 * J.dl_maxc);
+    for (int i = tid; i < Tu; i += 256) gl[i] = src[cnt + i];
+    int2 *ge = reinterpret_cast<int2 *>(R + 4 + 2 * J.dl_maxc + 2 * J.dl_lcap);
+    for (int i = tid; i < T; i += 256) ge[i] = src[cnt + Tu + i];
 }
-static __global__ __launch_bounds__(256) void k_obs_mark(const int32_t *__restrict__ observe, int n_obs, int n, int32_t *__restrict__ obs_mark) {
-    obs_mark_block(observe, n_obs, n, obs_mark);
-}
+static __global__ __launch_bounds__(256) void k_delta_records(const lt_bits_job job) { delta_record_block((int)blockIdx.x, job); }
 // the same block as part of another launch (256 threads per block)
 static __device__ __forceinline__ void item_bits_block(const int bid, const lt_bits_job &j) {
-    if (j.obs_mark != nullptr) {      // (the job is the observed-position table: one block)
-        if (bid == 0) obs_mark_block(j.observe, j.n_obs, j.n_nodes, j.obs_mark);
+    if (j.dl_rec != nullptr) {
+        delta_record_block(bid, j);
         return;
     }
     item_bits_block(bid, j.tptr, j.trow, j.probes, j.nb, j.words, j.bits, j.off, j.item_pr, j.big_bits, j.big_slot, j.big_count, j.rowptr,
