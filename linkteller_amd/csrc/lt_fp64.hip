@@ -298,11 +298,12 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
     // last it would finish last)
     int bx = (int)blockIdx.x;
     if (job.nblocks > 0) {
+        extern __shared__ __attribute__((aligned(16))) unsigned char spmm_job_smem[];      // (job.smem_bytes: the record gather's list)
         if (job_first < 0) {
-            if (bx < job.nblocks) { item_bits_block(bx, job); return; }
+            if (bx < job.nblocks) { item_bits_block(bx, job, spmm_job_smem); return; }
             bx -= job.nblocks;
         } else if (bx >= job_first) {
-            item_bits_block(bx - job_first, job);
+            item_bits_block(bx - job_first, job, spmm_job_smem);
             return;
         }
     }
@@ -1143,12 +1144,13 @@ static int form_z1d(lt_baseline *b, int32_t *state, hipStream_t st, const lt_bit
     b->z1x_valid = zf != nullptr;
     const unsigned gj = jb.nblocks > 0 ? (unsigned)jb.nblocks : 0u;
     if (job_done) *job_done = gj > 0;
+    const size_t jsm = gj > 0 ? (size_t)jb.smem_bytes : 0;
     if (b->s1_f32) {
-        LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, float>), dim3(g2 + gs + gj), dim3(256), 0, st, n, g->rowptr,
+        LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, float>), dim3(g2 + gs + gj), dim3(256), jsm, st, n, g->rowptr,
                                                 g->col, g->val, b->S1x, Hp, b->b1p, b->Z1d, (int)gs, g->p_n_seg, g->p_seg_begin,
                                                 g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv, jb, jb.dl_rec ? -1 : (int)(g2 + gs), zf, b->S1qs));
     } else {
-        LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, double>), dim3(g2 + gs + gj), dim3(256), 0, st, n, g->rowptr,
+        LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, double>), dim3(g2 + gs + gj), dim3(256), jsm, st, n, g->rowptr,
                                                 g->col, g->val, b->S1d, Hp, b->b1p, b->Z1d, (int)gs, g->p_n_seg, g->p_seg_begin,
                                                 g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv, jb, jb.dl_rec ? -1 : (int)(g2 + gs), zf));
     }

@@ -1203,16 +1203,17 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_hubs(
 // against every probe -- 4.75 M (probe, entry) tests at n_test = 500 for the 7 % of the pairs a probe touches at all; those
 // tests, not latency or cache lines, are what it costs (a per-probe block that still tested every entry took the same 18 us
 // whether it made 24 or 6 dependent round trips and whether its loads were coalesced: ~20 instructions per test).
-// Here the touched pairs are ENUMERATED from the probe's side instead, ~ 360 incidences per probe instead of 9 500 tests, in
-// two halves: the part that depends on the graph alone -- the probe's items and, per touched node, its member entries in
-// entry order -- is a record written by delta_lists_block (lt_items.cuh) as extra blocks of the launch that forms the
-// pre-activation, where it costs nothing; this kernel, one block per probe, runs stage A over the record's items
-// (k_item_stageA_d2's arithmetic, statement by statement) and then, per observed position, finds the node among the probe's
-// touched nodes (a binary search in LDS; a repeated observed node is simply found twice) and sums its entries exactly as
-// row2_dot would: entry k feeds chain k & 7, a chain is a k-ordered fmaf sequence from +0, the chains are added by the xor
-// 4, 2, 1 butterfly, then d / delta and the fmaf sum of squares.  So the matrix has the bits of the three-launch route
-// (`delta_fused` = 0; tests/test_gpu_round4.py compares them).  Graphs without hub rows, n <= 65534, column length^2 <=
-// the largest record within LT_DF_LDS_MAX.
+// Here the touched pairs are ENUMERATED from the probe's side instead, ~ 360 incidences per probe instead of 9 500 tests, and
+// everything about them that does not depend on the layers is ready when this kernel starts: a node's incidence record --
+// its items and, per touched node, the member entries in entry order -- is built with the graph (lt_core.hip
+// build_delta_records), and delta_record_block (lt_items.cuh), riding in the launch that forms the pre-activation, has
+// matched it against the observed list: the table row of probe b names the observed POSITIONS the probe touches and where
+// their entries are.  This kernel, one block per probe, is then two dependent round trips: the table row (items, touched
+// positions), then the items' pre-activation rows with the positions' entries; stage A over the items (k_item_stageA_d2's
+// arithmetic, statement by statement); and per touched position the sum row2_dot would form: entry k feeds chain k & 7, a chain is
+// a k-ordered fmaf sequence from +0, the chains are added by the xor 4, 2, 1 butterfly, then d / delta and the fmaf sum of squares.
+// So the matrix has the bits of the three-launch route (`delta_fused` = 0; tests/test_gpu_round4.py compares them).  Graphs
+// with incidence records: no hub rows, n <= 65534, at most LT_DL_MAX_T incidences per node.
 #ifdef LT_DF_TRACE      // tools/df_trace.py: phase stamps of every wave of k_delta_probe_finish on the constant 100 MHz clock
 #define LT_DF_TRACE_BLOCKS 4096
 __device__ unsigned long long g_df_trace[LT_DF_TRACE_BLOCKS * 4 * 8];
@@ -1230,204 +1231,43 @@ extern "C" int lt_debug_df_trace(unsigned long long *host_out, int n_words) {
 #define DF_STAMP(k_)
 #endif
 #define LT_DF_U 4          // items in flight per lane group in stage A
-#define LT_DF_LDS_MAX (144 * 1024)   // dynamic LDS a kernel of this route may be given
+#define LT_DF_LDS_MAX (144 * 1024)   // dynamic LDS the kernel may be given
 template <int LPR, int CP, bool SX, bool ZF>
 __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_finish(
     const double *__restrict__ Z1d, const double *__restrict__ S1d, const float *__restrict__ S1x,
     const double *__restrict__ crefv, const double *__restrict__ S1qs, const float *__restrict__ Z1x, int Hp,
-    const float *__restrict__ W2p, int C, const int32_t *__restrict__ probes, const int32_t *__restrict__ rec, int rec_words,
-    int maxc, int lcap, int pool_cap, const int32_t *__restrict__ observe, int n_obs,
-    float delta, float *__restrict__ out, long ldo) {
+    const float *__restrict__ W2p, int C, const int32_t *__restrict__ rec, int rec_words, int maxc,
+    const int32_t *__restrict__ dl_src, int n_obs, float delta, float *__restrict__ out, long ldo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char df_smem[];
-    // LDS: sEnt [pool_cap] inc | sList [lcap] (u, start | count << 16) | sS2 [maxc][C] f32 | sLong [pool_cap / 4 + 1]
-    lt_df_inc *sEnt = reinterpret_cast<lt_df_inc *>(df_smem);
-    int2 *sList = reinterpret_cast<int2 *>(sEnt + pool_cap);
-    float *sS2 = reinterpret_cast<float *>(sList + lcap);
-    int32_t *sLong = reinterpret_cast<int32_t *>(sS2 + (size_t)maxc * C);      // the touched nodes with more than 4 member entries
-    __shared__ int32_t s_nlong;
-    if (threadIdx.x == 0) s_nlong = 0;
+    float *sS2 = reinterpret_cast<float *>(df_smem);             // [maxc][C] the items' layer-2 differences
     constexpr int RPW = 64 / LPR, WAVES = LT_BLOCK / 64;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.x;
     DF_STAMP(0);
     const int32_t *R = rec + (size_t)b * rec_words;
     const int2 *gItems = reinterpret_cast<const int2 *>(R + 4);
-    const int2 *gList = reinterpret_cast<const int2 *>(R + 4 + 2 * maxc);
-    const lt_df_inc *gEnt = reinterpret_cast<const lt_df_inc *>(R + 4 + 2 * maxc + 2 * lcap);
-    const int v = probes[b];
-    // the observed nodes this thread answers for: needed last, asked first
-    constexpr int JPT = 2;                                    // positions per thread held in registers (beyond: re-read)
-    int obs_u[JPT];
-#pragma unroll
-    for (int h = 0; h < JPT; ++h) {
-        const int j = tid + h * LT_BLOCK;
-        obs_u[h] = j < n_obs ? observe[j] : 0;
-    }
+    const int2 *gTp = reinterpret_cast<const int2 *>(R + 4 + 2 * maxc);
+    // ---- round trip 1: the header, and unseen (their counts are in it) the items, this thread's touched positions, this
+    // wave's long position
     const int4 hdr = *reinterpret_cast<const int4 *>(R);
-    const int cnt = hdr.x, Tu = hdr.y, T = hdr.z;
-    // the record's lists, on their way to LDS while stage A runs (the first two rounds in registers)
-    constexpr int CPR = 2;
-    int2 lreg[CPR];
-    lt_df_inc ereg[CPR];
-    // ---- stage A: this probe's items (k_item_stageA_d2, statement by statement) ----
-    {
-        const int gl = lane & (LPR - 1);
-        const bool active = 4 * gl < Hp;
-        const int coff = active ? 4 * gl : 0;
-        float w2[4][CP];
+    constexpr int TPR = 2;                                    // short positions per thread held in registers (beyond: a later trip)
+    int2 tp[TPR];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int c = 0; c < CP; ++c) w2[k][c] = c < C ? W2p[(size_t)(coff + k) * C + c] : 0.f;
-        // delta * S1[v, coff + k]: the probe's S1 row off the fp64 product (fixed-point rows and / or deferred reference product)
-        float ds[4];
-        {
-            double cr[4] = {0.0, 0.0, 0.0, 0.0};
-            if (crefv != nullptr) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) cr[k] = crefv[coff + k];
-            }
-            if constexpr (SX) {
-                typedef int qx4 __attribute__((ext_vector_type(4)));
-                const f32x4 sx = ld4(S1x + (size_t)v * Hp + coff);
-                const double sq = S1qs[v];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) ds[k] = delta * (float)((double)__builtin_bit_cast(qx4, sx)[k] * sq + cr[k]);
-            } else {
-                const f64x4 sd = *reinterpret_cast<const f64x4 *>(S1d + (size_t)v * Hp + coff);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) ds[k] = delta * (crefv != nullptr ? (float)(sd[k] + cr[k]) : (float)sd[k]);
-            }
-        }
-        constexpr int U = LT_DF_U;
-        const int stride = WAVES * RPW;
-#pragma unroll
-        for (int h = 0; h < CPR; ++h) {
-            const int x = tid + h * LT_BLOCK;
-            lreg[h] = gList[x < Tu ? x : 0];
-            ereg[h] = gEnt[x < T ? x : 0];
-        }
-        // (the first trip's items are asked for before the header is back: the record holds maxc item slots, the unused ones
-        // naming row 0 -- loaded, never stored)
-        int base = wid * RPW + lane / LPR;
-        do {
-            int it[U];
-            int2 itm[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                it[u] = base + u * stride;
-                itm[u] = gItems[min(it[u], maxc - 1)];
-            }
-            f64x4 z[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int r = itm[u].x;
-                if constexpr (ZF) {
-                    const f32x4 zf = ld4(Z1x + (size_t)r * Hp + coff);
-                    z[u] = f64x4{(double)zf[0], (double)zf[1], (double)zf[2], (double)zf[3]};
-                } else {
-                    z[u] = *reinterpret_cast<const f64x4 *>(Z1d + (size_t)r * Hp + coff);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float arv = __int_as_float(itm[u].y);
-                float part[CP];
-#pragma unroll
-                for (int c = 0; c < CP; ++c) part[c] = 0.f;
-                if (active) {
-                    float dh[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float dz = arv * ds[k];
-                        const double zz = z[u][k], z1 = zz + (double)dz;
-                        dh[k] = zz > 0.0 ? (z1 > 0.0 ? dz : (float)(-zz)) : (z1 > 0.0 ? (float)z1 : 0.f);
-                    }
-#pragma unroll
-                    for (int c = 0; c < CP; ++c)
-                        if (c < C) {
-                            float p = dh[0] * w2[0][c];
-                            p = fmaf(dh[1], w2[1][c], p);
-                            p = fmaf(dh[2], w2[2][c], p);
-                            p = fmaf(dh[3], w2[3][c], p);
-                            part[c] = p;
-                        }
-                }
-#pragma unroll
-                for (int c = 0; c < CP; ++c) part[c] = group_sum<LPR>(part[c]);
-                if (it[u] < cnt && gl == 0) {
-#pragma unroll
-                    for (int c = 0; c < CP; ++c)
-                        if (c < C) sS2[(size_t)it[u] * C + c] = part[c];
-                }
-            }
-            base += U * stride;
-        } while (base < cnt);
-    }
-    DF_STAMP(1);
-    __syncthreads();                                              // (s_nlong = 0 is visible)
-    DF_STAMP(2);
-#pragma unroll
-    for (int h = 0; h < CPR; ++h) {
-        const int x = tid + h * LT_BLOCK;
-        if (x < Tu) {
-            sList[x] = lreg[h];
-            if ((lreg[h].y >> 16) > 4) sLong[atomicAdd(&s_nlong, 1)] = x;
-        }
-        if (x < T) sEnt[x] = ereg[h];
-    }
-    for (int x = tid + CPR * LT_BLOCK; x < Tu; x += LT_BLOCK) {
-        const int2 le = gList[x];
-        sList[x] = le;
-        if ((le.y >> 16) > 4) sLong[atomicAdd(&s_nlong, 1)] = x;
-    }
-    for (int x = tid + CPR * LT_BLOCK; x < T; x += LT_BLOCK) sEnt[x] = gEnt[x];
-    __syncthreads();
-    DF_STAMP(3);
-    // ---- the nodes with more than 4 member entries (row v itself holds ALL of R_v): one wave each; lane (c, qq) =
-    // (l >> 3, l & 7) walks the list for chain qq of class c, the 8-lane butterfly is row2_dot's own.  The result replaces
-    // the list's first entry (.a), where the per-position pass below picks it up.
-    const int nlong = s_nlong;
-    for (int s_ = wid; s_ < nlong; s_ += WAVES) {                    // (wave-uniform)
-        const int pk = sList[sLong[s_]].y, st = pk & 0xffff, c_ = pk >> 16;
-        lt_df_inc *e = sEnt + st;
-        const int qq = lane & (LT_L2_LANES - 1), c = lane >> 3;
-        float acc = 0.f;
-        if (c < C)
-            for (int y = 0; y < c_; ++y) {
-                const lt_df_inc ey = e[y];
-                if ((ey.ik & (LT_L2_LANES - 1)) == qq) acc = fmaf(ey.a, sS2[(size_t)(ey.ik >> 16) * C + c], acc);
-            }
-        const float o = group_sum<LT_L2_LANES>(acc);
-        float ss = 0.f;
-        for (int cc = 0; cc < C; ++cc) {
-            const float oc = __shfl(o, cc * LT_L2_LANES, 64);
-            const float dd = oc / delta;
-            ss = fmaf(dd, dd, ss);
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) e[0].a = sqrtf(ss);
-    }
-    __syncthreads();
-    DF_STAMP(4);
-    // ---- per observed position: find the node, sum its entries (already in entry order): every (entry, chain) pair as a
-    // select -- no loop, no sorting, nothing but LDS reads in the arithmetic
+    for (int h = 0; h < TPR; ++h) tp[h] = gTp[min(tid + h * LT_BLOCK, n_obs - 1)];
+    int2 ltp = gTp[max(n_obs - 1 - wid, 0)];
     float *orow = out + (long)b * ldo;
-    auto answer = [&](const int u, const int lo) -> float {       // lo: lower bound of u among the touched nodes
-        if (lo >= Tu) return 0.f;
-        const int2 le = sList[lo];
-        if (le.x != u) return 0.f;
-        const int st = le.y & 0xffff, c_ = le.y >> 16;
-        const lt_df_inc *e = sEnt + st;
-        if (c_ > 4) return e[0].a;
+    for (int j = tid; j < n_obs; j += LT_BLOCK) orow[j] = 0.f;    // (the barrier below orders these before the positions' results)
+    const int cnt = hdr.x, n_short = hdr.y & 0xffff, n_long = (int)((unsigned)hdr.y >> 16), v = hdr.z;
+    const lt_df_inc *ent = reinterpret_cast<const lt_df_inc *>(dl_src + hdr.w);
+    // per touched position: up to 4 entries by one thread (a select per (entry, chain) pair, nothing but registers)
+    auto short_answer = [&](const lt_df_inc (&e)[4], const int c_) -> float {
         float a[4], tv[4][CP];
         int k[4];
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-            const lt_df_inc ex = e[x < c_ ? x : 0];
-            a[x] = ex.a;
-            k[x] = x < c_ ? (ex.ik & (LT_L2_LANES - 1)) : -1;
-            const float *t = sS2 + (size_t)(ex.ik >> 16) * C;
+            a[x] = e[x].a;
+            k[x] = x < c_ ? (e[x].ik & (LT_L2_LANES - 1)) : -1;
+            const float *t = sS2 + (size_t)(e[x].ik >> 16) * C;
 #pragma unroll
             for (int c = 0; c < CP; ++c) tv[x][c] = c < C ? t[c] : 0.f;
         }
@@ -1451,44 +1291,202 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_finish(
         }
         return sqrtf(ss);
     };
-    // (branch-free lower bounds, the thread's JPT positions searched together: a step is one LDS trip for all of them)
-    auto lower = [&](const int (&u)[JPT], int (&pos)[JPT]) {
-#pragma unroll
-        for (int h = 0; h < JPT; ++h) pos[h] = 0;
-        for (int nrem = Tu; nrem > 1;) {
-            const int half = nrem >> 1;
-#pragma unroll
-            for (int h = 0; h < JPT; ++h) pos[h] = sList[pos[h] + half - 1].x < u[h] ? pos[h] + half : pos[h];
-            nrem -= half;
-        }
-#pragma unroll
-        for (int h = 0; h < JPT; ++h)
-            if (Tu > 0 && sList[pos[h]].x < u[h]) ++pos[h];
+    // a position of more than 4 entries by a wave: lane y holds entry y (64 at a time), the wave walks them in order handing
+    // each to lane (c, qq) = (l >> 3, l & 7) of its chain; the 8-lane butterfly is row2_dot's own
+    auto long_first = [&](const int2 lt_, const int y0) -> lt_df_inc {      // (the loads: before stage A, for the wave's first position)
+        const int st = lt_.y & 0xffff, c_ = lt_.y >> 16;
+        return ent[st + min(y0 + lane, c_ - 1)];
     };
-    {
-        int pos[JPT];
-        lower(obs_u, pos);
+    auto long_answer = [&](const int2 lt_, lt_df_inc mine) {
+        const int st = lt_.y & 0xffff, c_ = lt_.y >> 16;
+        const int qq = lane & (LT_L2_LANES - 1), cl = lane >> 3;
+        float acc = 0.f;
+        for (int y0 = 0; y0 < c_; y0 += 64) {
+            if (y0 > 0) mine = ent[st + min(y0 + lane, c_ - 1)];
+            float tv[CP];
 #pragma unroll
-        for (int h = 0; h < JPT; ++h) {
-            const int j = tid + h * LT_BLOCK;
-            if (j < n_obs) orow[j] = answer(obs_u[h], pos[h]);
+            for (int c = 0; c < CP; ++c) tv[c] = c < C ? sS2[(size_t)(mine.ik >> 16) * C + c] : 0.f;
+            const int qm = mine.ik & (LT_L2_LANES - 1);
+            const bool valid = y0 + lane < c_;
+            // the entries of this lane's chain, as a lane mask: walked in ascending order (a chain has ~ count / 8 of them)
+            unsigned long long mk = 0ull;
+#pragma unroll
+            for (int q_ = 0; q_ < LT_L2_LANES; ++q_) {
+                const unsigned long long bq = __ballot(valid && qm == q_);
+                mk = qq == q_ ? bq : mk;
+            }
+            if (cl >= C) mk = 0ull;
+            while (__ballot(mk != 0ull)) {                        // (wave-uniform trips: every lane stays a readable source)
+                const bool on = mk != 0ull;
+                const int y = on ? __ffsll((long long)mk) - 1 : 0;
+                mk &= mk - 1ull;                                  // (0 stays 0)
+                const float ay = __shfl(mine.a, y, 64);
+                float ty = 0.f;
+#pragma unroll
+                for (int c = 0; c < CP; ++c) {
+                    const float tc = __shfl(tv[c], y, 64);
+                    ty = cl == c ? tc : ty;
+                }
+                acc = on ? fmaf(ay, ty, acc) : acc;
+            }
         }
+        const float o = group_sum<LT_L2_LANES>(acc);
+        float ss = 0.f;
+        for (int cc = 0; cc < C; ++cc) {
+            const float oc = __shfl(o, cc * LT_L2_LANES, 64);
+            const float dd = oc / delta;
+            ss = fmaf(dd, dd, ss);
+        }
+        if (lane == 0) orow[lt_.x] = sqrtf(ss);
+    };
+    lt_df_inc te[TPR][4];
+    lt_df_inc lmine = {0.f, 0};
+    // ---- stage A: this probe's items (k_item_stageA_d2, statement by statement) ----
+    {
+        const int gl = lane & (LPR - 1);
+        const bool active = 4 * gl < Hp;
+        const int coff = active ? 4 * gl : 0;
+        float w2[4][CP];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int c = 0; c < CP; ++c) w2[k][c] = c < C ? W2p[(size_t)(coff + k) * C + c] : 0.f;
+        constexpr int U = LT_DF_U;      // (wider first trips -- 8, 12 items per lane group -- measured slower: 5.3 -> 8.1 us to the barrier)
+        const int stride = WAVES * RPW;
+        // (the first trip's items were asked for before the header was back: the table row holds maxc item slots, the unused
+        // ones naming row 0 -- loaded, never stored)
+        int base = wid * RPW + lane / LPR;
+        int2 itm0[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) itm0[u] = gItems[min(base + u * stride, maxc - 1)];
+        // ---- round trip 2 (with the items' rows below): the probe's S1 row, the positions' entries
+        // delta * S1[v, coff + k]: the probe's S1 row off the fp64 product (fixed-point rows and / or deferred reference product)
+        float ds[4];
+        {
+            double cr[4] = {0.0, 0.0, 0.0, 0.0};
+            if (crefv != nullptr) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cr[k] = crefv[coff + k];
+            }
+            if constexpr (SX) {
+                typedef int qx4 __attribute__((ext_vector_type(4)));
+                const f32x4 sx = ld4(S1x + (size_t)v * Hp + coff);
+                const double sq = S1qs[v];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ds[k] = delta * (float)((double)__builtin_bit_cast(qx4, sx)[k] * sq + cr[k]);
+            } else {
+                const f64x4 sd = *reinterpret_cast<const f64x4 *>(S1d + (size_t)v * Hp + coff);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ds[k] = delta * (crefv != nullptr ? (float)(sd[k] + cr[k]) : (float)sd[k]);
+            }
+        }
+        bool first = true;
+        do {
+            int it[U];
+            int2 itm[U];
+            typename std::conditional<ZF, f32x4, f64x4>::type z[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                it[u] = base + u * stride;
+                itm[u] = itm0[u];
+                const int r = itm[u].x;
+                // (a slot without an item: every lane asks for the row's first 16 bytes -- one cache line instead of a row; a
+                // branch around the load would make hipcc drain the queue in front of it, one round trip per item)
+                const int co = it[u] < cnt ? coff : 0;
+                if constexpr (ZF) z[u] = ld4(Z1x + (size_t)r * Hp + co);
+                else z[u] = *reinterpret_cast<const f64x4 *>(Z1d + (size_t)r * Hp + co);
+            }
+            // (a probe of more items than one trip takes: the next trip's items travel with this trip's rows)
+#pragma unroll
+            for (int u = 0; u < U; ++u) itm0[u] = gItems[min(it[u] + U * stride, maxc - 1)];
+            if (first) {
+#pragma unroll
+                for (int h = 0; h < TPR; ++h) {
+                    const int st = tp[h].y & 0xffff, c_ = tp[h].y >> 16;
+                    const bool have = tid + h * LT_BLOCK < n_short;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) te[h][x] = ent[have ? st + min(x, c_ - 1) : 0];
+                }
+                if (wid < n_long) lmine = long_first(ltp, 0);
+            }
+            first = false;
+            // four items at a time: their lane-group sums run the butterfly in lockstep (one item after the other, each of its
+            // steps waited for the one before: 6 dependent LDS-crossbar trips per item at LPR = 64); the addends of a sum and
+            // their order are group_sum's
+            constexpr int Q = 4;
+            static_assert(U % Q == 0, "stage A works in quads");
+#pragma unroll
+            for (int u0 = 0; u0 < U; u0 += Q) {
+                if (__ballot(it[u0] < cnt) == 0ull) break;            // (wave-uniform; the later slots are further out still)
+                float part[Q][CP];
+#pragma unroll
+                for (int uu = 0; uu < Q; ++uu) {
+                    const int u = u0 + uu;
+                    const float arv = __int_as_float(itm[u].y);
+#pragma unroll
+                    for (int c = 0; c < CP; ++c) part[uu][c] = 0.f;
+                    if (active) {
+                        float dh[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float dz = arv * ds[k];
+                            const double zz = (double)z[u][k], z1 = zz + (double)dz;
+                            dh[k] = zz > 0.0 ? (z1 > 0.0 ? dz : (float)(-zz)) : (z1 > 0.0 ? (float)z1 : 0.f);
+                        }
+#pragma unroll
+                        for (int c = 0; c < CP; ++c)
+                            if (c < C) {
+                                float p = dh[0] * w2[0][c];
+                                p = fmaf(dh[1], w2[1][c], p);
+                                p = fmaf(dh[2], w2[2][c], p);
+                                p = fmaf(dh[3], w2[3][c], p);
+                                part[uu][c] = p;
+                            }
+                    }
+                }
+#pragma unroll
+                for (int m = LPR / 2; m >= 1; m >>= 1)
+#pragma unroll
+                    for (int uu = 0; uu < Q; ++uu)
+#pragma unroll
+                        for (int c = 0; c < CP; ++c) part[uu][c] += __shfl_xor(part[uu][c], m, 64);
+#pragma unroll
+                for (int uu = 0; uu < Q; ++uu) {
+                    const int u = u0 + uu;
+                    if (it[u] < cnt && gl == 0) {
+#pragma unroll
+                        for (int c = 0; c < CP; ++c)
+                            if (c < C) sS2[(size_t)it[u] * C + c] = part[uu][c];
+                    }
+                }
+            }
+            base += U * stride;
+        } while (base < cnt);
+    }
+    DF_STAMP(1);
+    __syncthreads();
+    DF_STAMP(2);
+    // ---- the touched positions ----
+#pragma unroll
+    for (int h = 0; h < TPR; ++h)
+        if (tid + h * LT_BLOCK < n_short) orow[tp[h].x] = short_answer(te[h], tp[h].y >> 16);
+    DF_STAMP(3);
+    if (wid < n_long) long_answer(ltp, lmine);
+    DF_STAMP(4);
+    // (beyond the registers: a trip of their own each)
+    for (int x = tid + TPR * LT_BLOCK; x < n_short; x += LT_BLOCK) {
+        const int2 t_ = gTp[x];
+        const int st = t_.y & 0xffff, c_ = t_.y >> 16;
+        lt_df_inc e[4];
+#pragma unroll
+        for (int y = 0; y < 4; ++y) e[y] = ent[st + min(y, c_ - 1)];
+        orow[t_.x] = short_answer(e, c_);
+    }
+    for (int s_ = wid + WAVES; s_ < n_long; s_ += WAVES) {          // (wave-uniform)
+        const int2 t_ = gTp[n_obs - 1 - s_];
+        long_answer(t_, long_first(t_, 0));
     }
     DF_STAMP(5);
-    for (int j0 = JPT * LT_BLOCK; j0 < n_obs; j0 += JPT * LT_BLOCK) {        // (block-uniform trips)
-        int u[JPT], pos[JPT];
-#pragma unroll
-        for (int h = 0; h < JPT; ++h) {
-            const int j = j0 + tid + h * LT_BLOCK;
-            u[h] = j < n_obs ? observe[j] : 0;
-        }
-        lower(u, pos);
-#pragma unroll
-        for (int h = 0; h < JPT; ++h) {
-            const int j = j0 + tid + h * LT_BLOCK;
-            if (j < n_obs) orow[j] = answer(u[h], pos[h]);
-        }
-    }
 }
 
 // beyond the default 64 KB of dynamic LDS a kernel is told, once, that it may take most of a CU's 160 KB
@@ -1824,16 +1822,14 @@ static int probe_kslice(const lt_baseline *b) {
 }
 
 // the fused DELTA route's sizes (delta_record_block + k_delta_probe_finish): whether the graph qualifies at all
-struct df_geom { int maxc, pool, lcap, rec_words; size_t finish_smem; bool ok; };
-static df_geom df_geometry(const lt_graph *g, int C) {
+struct df_geom { int maxc, rec_words; size_t record_smem, finish_smem; bool ok; };
+static df_geom df_geometry(const lt_graph *g, int C, int n_obs) {
     df_geom d = {};
     d.maxc = g->max_col_nnz > 0 ? g->max_col_nnz : 1;
-    d.pool = (g->dl_max_t + 2) & ~1;
-    d.lcap = (g->dl_max_tu + 2) & ~1;
-    d.rec_words = lt_dl_rec_words(d.maxc, d.lcap, d.pool);
-    d.finish_smem = (size_t)d.pool * sizeof(lt_df_inc) + (size_t)d.lcap * sizeof(int2) + (size_t)d.maxc * C * sizeof(float) +
-                    ((size_t)d.pool / 4 + 1) * sizeof(int32_t);
-    d.ok = g->dl_meta != nullptr && d.finish_smem <= (size_t)LT_DF_LDS_MAX;
+    d.rec_words = lt_dl_rec_words(d.maxc, n_obs);
+    d.record_smem = ((size_t)g->dl_max_tu + 1) * sizeof(int2);
+    d.finish_smem = (size_t)d.maxc * C * sizeof(float) + 16;
+    d.ok = g->dl_meta != nullptr && n_obs >= 1 && n_obs <= 65534 && d.finish_smem <= (size_t)LT_DF_LDS_MAX;
     return d;
 }
 
@@ -1892,7 +1888,7 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int n_o
     }
     if (mode == LT_MODE_DELTA) w.Spd = (double *)take(chunk * Hp * sizeof(double));   // aggregate-first: X[probes] W1 in fp64
     {   // the fused route's records (k_delta_probe_finish), when the graph qualifies and they stay modest
-        const df_geom dg = df_geometry(b->g, (int)C);
+        const df_geom dg = df_geometry(b->g, (int)C, n_obs);
         if (mode == LT_MODE_DELTA && dg.ok && chunk * (size_t)dg.rec_words * sizeof(int32_t) <= ((size_t)1 << 30))
             w.dl_rec = (int32_t *)take(chunk * (size_t)dg.rec_words * sizeof(int32_t));
     }
@@ -1997,7 +1993,7 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
     // DELTA at twitch size, graphs without hub rows: stage A + stage B of a probe in one block (k_delta_probe_block), no item
     // tables, no bitmap rows, no pair marks -- when the pre-activation is formed on all rows anyway and the block's tables fit
     // LDS ("delta_fused" = 0 keeps the item kernels; the matrices are bit-identical).  Decided once per call.
-    const df_geom dg = df_geometry(g, C);
+    const df_geom dg = df_geometry(g, C, n_obs);
     const bool fused = delta64 && vec == nullptr && lt_tune().delta_fused != 0 && dg.ok && w.dl_rec != nullptr &&
                        !lt_fp64_agg_active(b) && !lt_fp64_on_demand(b, n_probe);
     const bool use_marks = !fused && mode != LT_MODE_FULL && w.pm_cnt != nullptr &&
@@ -2155,7 +2151,8 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
                     {
                         lt_bits_job cj = {};
                         cj.probes = probes; cj.nb = nb; cj.nblocks = nb; cj.dl_rec = w.dl_rec; cj.dl_meta = g->dl_meta; cj.dl_src = g->dl_rec;
-                        cj.dl_maxc = dg.maxc; cj.dl_lcap = dg.lcap; cj.dl_rec_words = dg.rec_words;
+                        cj.dl_maxc = dg.maxc; cj.dl_rec_words = dg.rec_words; cj.observe = observe_nodes; cj.n_obs = n_obs;
+                        cj.smem_bytes = (unsigned)dg.record_smem;
                         bool rode = false;
                         if (p0 == 0) {
                             int rc = lt_fp64_prepare_rows(b, nullptr, 0, nullptr, n_probe, st, &cj, &rode);      // (all rows: no item tables needed)
@@ -2163,7 +2160,7 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
                         }
                         if (!rode) {
                             lt_prof_scope prof_(LT_K_ITEM_BITS, st);
-                            hipLaunchKernelGGL(k_delta_records, dim3((unsigned)nb), dim3(256), 0, st, cj);
+                            hipLaunchKernelGGL(k_delta_records, dim3((unsigned)nb), dim3(256), dg.record_smem, st, cj);
                             LT_CHECK_LAUNCH();
                         }
                     }
@@ -2176,8 +2173,8 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
     LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,                                                                                           \
         if (dg.finish_smem > (size_t)64 * 1024) { const int rc_ = df_allow_big_lds<LPR_, CP_, SX_, ZF_>(); if (rc_) return rc_; }    \
         hipLaunchKernelGGL((k_delta_probe_finish<LPR_, CP_, SX_, ZF_>), dim3((unsigned)nb), dim3(LT_BLOCK), dg.finish_smem, st,      \
-                           b->Z1d, b->S1d, sxp, crp, b->S1qs, zxp, Hp, b->W2p, C, probes, w.dl_rec, dg.rec_words, dg.maxc, dg.lcap,   \
-                           dg.pool, observe_nodes, n_obs, delta, orow, (long)ldo)))
+                           b->Z1d, b->S1d, sxp, crp, b->S1qs, zxp, Hp, b->W2p, C, w.dl_rec, dg.rec_words, dg.maxc, g->dl_rec,        \
+                           n_obs, delta, orow, (long)ldo)))
                     if (sxp && zxp) { LT_DF_LAUNCH(true, true); }
                     else if (sxp) { LT_DF_LAUNCH(true, false); }
                     else { LT_DF_LAUNCH(false, false); }

@@ -252,7 +252,8 @@ struct lt_bits_job {
     int32_t *dl_rec;
     const int4 *dl_meta;
     const int32_t *dl_src;
-    int dl_maxc, dl_lcap, dl_rec_words;
+    int dl_maxc, dl_rec_words;
+    unsigned smem_bytes;    // dynamic LDS the job's blocks need (the launch that carries them must be given it)
 };
 // job != NULL: *job_done says whether the job went along (it does when every row is formed by one plain launch; the on-demand
 // form needs the tables BEFORE, the caller then launches k_item_bits itself and calls again without a job)

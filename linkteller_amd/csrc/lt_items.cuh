@@ -124,32 +124,72 @@ static __global__ __launch_bounds__(256) void k_item_bits(const int32_t *__restr
 // entry position in row u), the nodes ascending, a node's entries in entry order:
 //     dl_meta[v] = (offset into dl_rec, items, touched nodes, incidences)
 //     dl_rec + offset: items (r, A_hat[r, v]) [items] | nodes (u, start | count << 16) [touched] | entries [incidences]
-// Per call, the records of the chunk's probes are gathered into one fixed-stride table (probes -> meta -> record: three
-// dependent round trips that the finish kernel then does not make -- a kernel starts with cold caches, a trip is ~ 2 us):
-//     [0] items  [1] touched nodes  [2] incidences  [3] v | items [maxc, the unused slots (0, 0)] | nodes [lcap] | entries [pool]
+// Per call and probe, delta_record_block resolves the record against the observed list -- for each observed position, is its
+// node among the probe's touched nodes (a binary search in LDS), and where are its entries -- and writes what the finish
+// kernel needs as one small table row (probes -> meta -> record -> search: dependent round trips and LDS passes the finish
+// kernel then does not make; a kernel starts with cold caches, a trip is ~ 2 us):
+//     [0] items  [1] short | long << 16 touched POSITIONS  [2] v  [3] offset of the node's entries in dl_rec
+//     | items [maxc, the unused slots repeat the first] | touched positions (j, start | count << 16) [n_obs]: those of up to 4 entries from
+//     the front, the longer ones (row v itself holds ALL of R_v) from the back, in no particular order
 // Nothing here reads a layer, so these blocks ride in the launch that forms the pre-activation (k_spmm_f64), which hides them.
 struct lt_df_inc { float a; int ik; };      // A_hat[u, r] and (item << 16 | entry position in row u)
-static inline __host__ __device__ int lt_dl_rec_words(int maxc, int lcap, int pool) { return (4 + 2 * maxc + 2 * lcap + 2 * pool + 3) & ~3; }
-static __device__ __forceinline__ void delta_record_block(const int b, const lt_bits_job &J) {
+static inline __host__ __device__ int lt_dl_rec_words(int maxc, int n_obs) { return (4 + 2 * maxc + 2 * n_obs + 3) & ~3; }
+static __device__ __forceinline__ void delta_record_block(const int b, const lt_bits_job &J, unsigned char *smem) {
+    int2 *sL = reinterpret_cast<int2 *>(smem);                  // [lcap] the probe's touched nodes (u, start | count << 16), u ascending
+    __shared__ int32_t s_ntp, s_nlp;
     const int tid = threadIdx.x;
     const int v = J.probes[b];
     const int4 m = J.dl_meta[v];
-    const int cnt = m.y, Tu = m.z, T = m.w;
+    const int cnt = m.y, Tu = m.z;
     const int2 *__restrict__ src = reinterpret_cast<const int2 *>(J.dl_src + m.x);
     int32_t *R = J.dl_rec + (size_t)b * J.dl_rec_words;
-    if (tid == 0) *reinterpret_cast<int4 *>(R) = make_int4(cnt, Tu, T, v);
+    if (tid == 0) { s_ntp = 0; s_nlp = 0; }
     int2 *gi = reinterpret_cast<int2 *>(R + 4);
-    for (int i = tid; i < J.dl_maxc; i += 256) gi[i] = i < cnt ? src[i] : make_int2(0, 0);   // (every slot: the finish kernel loads them unseen)
-    int2 *gl = reinterpret_cast<int2 *>(R + 4 + 2 * J.dl_maxc);
-    for (int i = tid; i < Tu; i += 256) gl[i] = src[cnt + i];
-    int2 *ge = reinterpret_cast<int2 *>(R + 4 + 2 * J.dl_maxc + 2 * J.dl_lcap);
-    for (int i = tid; i < T; i += 256) ge[i] = src[cnt + Tu + i];
+    // (every slot: the finish kernel loads them unseen -- and the rows they name; an unused slot repeats the probe's first item,
+    // a row the block reads anyway.  Row 0 for all of them made every block of the launch hammer the same cache lines.)
+    for (int i = tid; i < J.dl_maxc; i += 256) gi[i] = i < cnt ? src[i] : (cnt > 0 ? src[0] : make_int2(0, 0));
+    for (int i = tid; i < Tu; i += 256) sL[i] = src[cnt + i];
+    __syncthreads();
+    int2 *gtp = reinterpret_cast<int2 *>(R + 4 + 2 * J.dl_maxc);
+    constexpr int JP = 2;                                        // positions searched together (a step is one LDS trip for both)
+    for (int j0 = 0; j0 < J.n_obs; j0 += JP * 256) {             // (block-uniform trips)
+        int u[JP], pos[JP];
+#pragma unroll
+        for (int h = 0; h < JP; ++h) {
+            const int j = j0 + tid + h * 256;
+            u[h] = j < J.n_obs ? J.observe[j] : -1;
+            pos[h] = 0;
+        }
+        for (int nrem = Tu; nrem > 1;) {                         // branch-free lower bound
+            const int half = nrem >> 1;
+#pragma unroll
+            for (int h = 0; h < JP; ++h) pos[h] = sL[pos[h] + half - 1].x < u[h] ? pos[h] + half : pos[h];
+            nrem -= half;
+        }
+#pragma unroll
+        for (int h = 0; h < JP; ++h) {
+            const int j = j0 + tid + h * 256;
+            if (Tu > 0 && sL[pos[h]].x < u[h]) ++pos[h];
+            if (j < J.n_obs && pos[h] < Tu) {
+                const int2 le = sL[pos[h]];
+                if (le.x == u[h]) {
+                    if ((le.y >> 16) > 4) gtp[J.n_obs - 1 - atomicAdd(&s_nlp, 1)] = make_int2(j, le.y);
+                    else gtp[atomicAdd(&s_ntp, 1)] = make_int2(j, le.y);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) *reinterpret_cast<int4 *>(R) = make_int4(cnt, s_ntp | (s_nlp << 16), v, m.x + 2 * (cnt + Tu));
 }
-static __global__ __launch_bounds__(256) void k_delta_records(const lt_bits_job job) { delta_record_block((int)blockIdx.x, job); }
+static __global__ __launch_bounds__(256) void k_delta_records(const lt_bits_job job) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dr_smem[];
+    delta_record_block((int)blockIdx.x, job, dr_smem);
+}
 // the same block as part of another launch (256 threads per block)
-static __device__ __forceinline__ void item_bits_block(const int bid, const lt_bits_job &j) {
-    if (j.dl_rec != nullptr) {
-        delta_record_block(bid, j);
+static __device__ __forceinline__ void item_bits_block(const int bid, const lt_bits_job &j, unsigned char *smem = nullptr) {
+    if (j.dl_rec != nullptr) {      // (`smem`: the launch's dynamic LDS, j.smem_bytes)
+        delta_record_block(bid, j, smem);
         return;
     }
     item_bits_block(bid, j.tptr, j.trow, j.probes, j.nb, j.words, j.bits, j.off, j.item_pr, j.big_bits, j.big_slot, j.big_count, j.rowptr,

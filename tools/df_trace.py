@@ -38,7 +38,7 @@ def main():
     assert h.lt_debug_df_trace(buf.ctypes.data, buf.size) == 0
     t = buf.reshape(nb, 4, 8).astype(np.float64) * 0.01      # 100 MHz -> us
     t0 = t[:, :, 0].min()
-    names = ["entry", "stage A done", "sync", "lists in LDS", "long lists done", "positions answered"]
+    names = ["entry", "stage A done", "barrier passed", "short positions done", "long position done", "end"]
     for k, nm in enumerate(names):
         x_ = (t[:, :, k] - t0).ravel()
         print(f"{nm:22s} first {x_.min():6.2f}  median {np.median(x_):6.2f}  p90 {np.percentile(x_, 90):6.2f}  last {x_.max():6.2f}")
