@@ -48,14 +48,14 @@ FP64_MFMA_PEAK_TFLOPS = 78.6
 KERNEL_CLASS = (("k_s1d_feature_rows", "fp64_product"), ("k_ref_product", "fp64_product"), ("k_ref_vector", "fp64_product"), ("k_gemm_f64", "fp64_product"),
                 ("k_sum_slabs_f64", "fp64_product"), ("k_spmm_f64", "fp64_spmm"), ("k_rows_tiled_f64", "fp64_spmm"),
                 ("k_rows_tiled_xf64", "fp64_spmm"), ("k_z_mark", "fp64_spmm"), ("k_y_long", "fp64_spmm"),
-                ("k_item_bits", "item_bits"), ("k_pm_", "item_bits"), ("k_obs_mark", "item_bits"), ("k_item_stageA", "item_stageA"),
-                ("k_delta_probe_block", "item_stageB"), ("k_rows_tiled_gathers_only", "gather_ceiling"),
+                ("k_item_bits", "item_bits"), ("k_pm_", "item_bits"), ("k_delta_records", "item_bits"), ("k_item_stageA", "item_stageA"),
+                ("k_delta_probe_finish", "item_stageB"), ("k_rows_tiled_gathers_only", "gather_ceiling"),
                 ("k_item_stageB", "item_stageB"), ("k_full_stageA", "full_stageA"), ("k_full_long_combine", "full_stageA"),
                 ("k_full_stageB", "full_stageB"), ("k_gemm_f32_mfma", "gemm"), ("k_sum_slabs", "gemm"),
                 ("k_rows_tiled", "spmm"), ("k_spmm_long_combine", "spmm"), ("k_spmm_rows", "spmm"), ("k_spmm_seg", "spmm"))
 PRIMARY = {"fp64_product": ("k_s1d_feature_rows", "k_gemm_f64acc_128", "k_gemm_f64acc", "k_gemm_f64_rows<double>"),
            "fp64_spmm": ("k_spmm_f64<", "k_rows_tiled_f64", "k_rows_tiled_xf64"),
-           "item_bits": ("k_item_bits",), "item_stageA": ("k_item_stageA",), "item_stageB": ("k_delta_probe_block", "k_item_stageB<", "k_item_stageB_rows"),
+           "item_bits": ("k_item_bits",), "item_stageA": ("k_item_stageA",), "item_stageB": ("k_delta_probe_finish", "k_item_stageB<", "k_item_stageB_rows"),
            "full_stageA": ("k_full_stageA_lds<2, 32, 0>", "k_full_stageA_lds", "k_full_stageA"), "full_stageB": ("k_full_stageB",),
            "gemm": ("k_gemm_f32_mfma_128",), "spmm": ("k_rows_tiled<", "k_spmm_rows")}
 
@@ -607,7 +607,7 @@ def main():
         if cls == "item_stageB":
             obs_entries = int(np.diff(a_hat.indptr)[test_nodes].sum())
             alg = n_probe_local * a.n_test * 4 + items_local * c * 4 + obs_entries * 8
-            return {"kernel": "k_delta_probe_block (stage A + B of a probe in one block; graphs with hub rows: k_item_stageB_rows / _hubs)",
+            return {"kernel": "k_delta_probe_finish (stage A + B of a probe in one block, from its incidence record; graphs with hub rows: k_item_stageB_rows / _hubs)",
                     "bound": "hbm", "achieved": round(alg / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(alg / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": tr, "algorithmic_bytes_per_launch": int(alg), "avg_launch_us": us,
                     "units_per_launch": f"{n_probe_local} x {a.n_test} (probe, observed) pairs: the observed rows' CSR once, the items' layer-2 inputs once, "

@@ -331,8 +331,8 @@ def test_gather_ceiling_entry_point(gpu):
 
 @pytest.mark.parametrize("h,c,kind", [(256, 2, "er"), (100, 3, "er"), (16, 8, "er"), (132, 1, "iso"), (64, 7, "dup")])
 def test_delta_fused_probe_blocks_keep_every_bit(gpu, h, c, kind):
-    """k_delta_probe_block (round 4, `delta_fused`): stage A and stage B of a probe in one block, items from the CSC column,
-    a 16-bit position per node in LDS.  Graphs without hub rows; the matrix must equal the three-launch route's (`delta_fused`
+    """k_delta_probe_finish (round 4, `delta_fused`): stage A and stage B of a probe in one block, from the probe node's
+    incidence record (built with the graph) matched against the observed list by delta_record_block.  Graphs without hub rows; the matrix must equal the three-launch route's (`delta_fused`
     = 0) bit for bit -- widths that need padding and several lane groupings, 1 .. 8 classes, isolated nodes, duplicate probes
     and observed nodes, observe != probes, a single probe, a multi-chunk call, both storage forms of the product rows (twitch-like
     and Gaussian features) -- and stay within 1e-5 of the fp64 oracle."""
@@ -383,7 +383,7 @@ def test_delta_fused_probe_blocks_keep_every_bit(gpu, h, c, kind):
 
 
 def test_delta_fused_on_a_directed_pattern_with_empty_columns_and_many_observed(gpu):
-    """k_delta_probe_block beyond the symmetric case: a DIRECTED adjacency (rows and columns differ: R_v is the column of v, the
+    """k_delta_probe_finish beyond the symmetric case: a DIRECTED adjacency (rows and columns differ: R_v is the column of v, the
     rows that hold a member are the member's column, `tpos` is the entry's place in its ROW), nodes nobody reads (empty
     columns: no items) and nobody is read by (empty rows), and more observed positions than a thread keeps canonical indices
     for (n_obs > 1024, with repeats).  Bits of the item kernels, and the fp64 oracle on a few rows."""
@@ -416,9 +416,10 @@ def test_delta_fused_on_a_directed_pattern_with_empty_columns_and_many_observed(
 
 
 def test_delta_fused_with_every_node_observed(gpu):
-    """`balanced-full` observes every node (attacker.py:250-284): at twitch-RU size the per-position LDS tables of
-    k_delta_probe_block pass the default 64 KB of dynamic LDS and the kernel is given more (hipFuncSetAttribute, one block
-    per CU).  Same bits as the item kernels; the call is chunked as the attack chunks it."""
+    """`balanced-full` observes every node (attacker.py:250-284): every touched node of a probe is then a touched position
+    (n_obs = 4385 positions per table row, several search trips per thread in delta_record_block, touched positions beyond the
+    two a thread of k_delta_probe_finish holds in registers).  Same bits as the item kernels; the call is chunked as the attack
+    chunks it."""
     from linkteller_amd import _lib, engine, graph, synth
     adj, x, w = synth.twitch_like_problem("twitch-RU", hidden=256, n_classes=2, seed=0)
     a_hat = graph.first_order_gcn(adj)

@@ -1,4 +1,4 @@
-"""`balanced-full` shape at twitch-RU size (1024 probes x every node observed): k_delta_probe_block (large dynamic LDS) against the
+"""`balanced-full` shape at twitch-RU size (1024 probes x every node observed): k_delta_probe_finish against the
 item kernels.  python tools/balanced_full_time.py"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -91,7 +91,7 @@ def main():
         try:
             base.refresh()
             other = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
-            # on these S1d routes a graph without hub rows takes k_delta_probe_block (round 4): the item kernels give its bits
+            # on these S1d routes a graph without hub rows takes k_delta_probe_finish (round 4): the item kernels give its bits
             _lib.set_tuning("delta_fused", 0)
             unfused = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
             assert np.array_equal(other, unfused), (it, kind, n, h, c, f, route_knobs, "delta_fused")
