@@ -89,9 +89,10 @@ int lt_device_count(int *count);
  *                         fixed point with one scale per row (31 bits against the row's largest value; half the bytes the fp64
  *                         SpMM gathers) and the pre-activation in fp32 (default), 0 = both in fp64.  Moves `delta` results by
  *                         < 1e-6 of the largest score (plain fp32 rows moved them by up to 7e-5: DESIGN.md 5d)
- *   "delta_fused"         LT_MODE_DELTA, calls with a membership-bitmap-sized graph (n <= 65534) without hub rows whose pre-activation is
- *                         formed on all rows: 1 = stage A and stage B of a probe in ONE block -- its items from the CSC column, their
- *                         layer-2 inputs and a 16-bit position per node in LDS (default), 0 = the item kernels
+ *   "delta_fused"         LT_MODE_DELTA on a graph with incidence records (lt_graph_create builds them for graphs of n <= 65534 nodes
+ *                         without hub rows), calls whose pre-activation is formed on all rows: 1 = stage A and stage B of a probe in
+ *                         ONE block, from the probe node's record matched against the observed list inside the pre-activation's
+ *                         launch (default), 0 = the item kernels.  Bit-identical
  *   "defer_cref"          feature-difference route: 1 = the reference vector's product m W1 is formed by extra blocks of the rows'
  *                         launch and added by the readers of S1d (the fp64 SpMM, stage A) (default), 0 = formed first and added
  *                         by the rows kernel.  fp64 summation order only, like "feature_delta"
@@ -116,7 +117,10 @@ int lt_set_tuning(const char *key, long long value);
  * Stands in for utils/load.py:552-559 (sparse_mx_to_torch_sparse_tensor) + the .cuda() at
  * worker.py:665-678: takes the normalised adjacency A_hat as HOST CSR (int32 indices,
  * fp32 values, columns strictly increasing inside each row), validates it, and uploads it
- * to the current device together with its transpose (CSC) used by the sparse/delta modes. */
+ * to the current device together with its transpose (CSC) used by the sparse/delta modes.
+ * Graphs of up to 65534 nodes without hub rows (rows of more than 128 entries) also get their per-node incidence records
+ * (LT_MODE_DELTA's fused route, "delta_fused"): sum over the nodes of |column| x the columns' lengths entries of 8 bytes,
+ * built on the host in this call (twitch-RU: 1.5 M entries, 25 MB); skipped when a node has more than 4096 or they pass 256 MB. */
 int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, const int32_t *col,
                     const float *val, lt_graph **out);
 int lt_graph_destroy(lt_graph *g);
