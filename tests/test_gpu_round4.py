@@ -435,3 +435,51 @@ def test_delta_fused_with_every_node_observed(gpu):
         _lib.set_tuning("delta_fused", None)
     assert np.array_equal(fused, plain)
     assert (fused > 0).sum() > 10 * len(probes) and np.isfinite(fused).all()
+
+
+def test_delta_fused_long_lists_and_huge_observed_lists(gpu):
+    """The record route beyond its common case: a 14-clique (every pair inside it shares 14 entries: 14 long positions per probe,
+    more than the four waves of a block take in their first trip), a star of 110 leaves whose centre's own list has 111 entries
+    (two 64-entry trips of the wave that owns it; the row stays under the 128 entries of a hub), every node observed three times
+    over (more touched positions than a thread's registers hold, repeated long positions), and an observed list of more than
+    65534 positions, which the record route leaves to the item kernels.  Same bits as `delta_fused` = 0, and the fp64 oracle."""
+    from test_gpu_parity import _oracle_matrix
+    from linkteller_amd import _lib, engine, graph, synth
+    n, f, h, c = 900, 80, 96, 3
+    a = synth.erdos_renyi_graph(n, 3600, seed=11).tolil()
+    clique = np.arange(100, 114)
+    for u in clique:
+        for v_ in clique:
+            if u != v_:
+                a[u, v_] = 1
+    centre, leaves = 300, np.arange(400, 510)
+    for u in leaves:
+        a[centre, u] = 1
+        a[u, centre] = 1
+    a = sp.csr_matrix(a)
+    a_hat = graph.first_order_gcn(a)
+    assert np.diff(a_hat.indptr).max() <= 128 and np.diff(a_hat.indptr)[centre] >= 111
+    x = synth.twitch_like_features(n, f, seed=5, density=0.05)
+    w = synth.gcn_weights(f, h, c, seed=4)
+    base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *_params(w, gpu)).enable_fp64()
+    probes = np.concatenate([clique[:6], [centre], leaves[:5], np.random.RandomState(2).choice(n, 40, replace=False)])
+    everyone3 = np.tile(np.arange(n), 3)
+
+    def both(pr, ob):
+        fused = base.influence_rows(pr, ob, 1e-4, "delta").cpu().numpy()
+        _lib.set_tuning("delta_fused", 0)
+        try:
+            plain = base.influence_rows(pr, ob, 1e-4, "delta").cpu().numpy()
+        finally:
+            _lib.set_tuning("delta_fused", None)
+        assert np.array_equal(fused, plain), np.abs(fused - plain).max()
+        return fused
+    got = both(probes, everyone3)
+    assert np.array_equal(got[:, :n], got[:, n:2 * n]) and np.array_equal(got[:, :n], got[:, 2 * n:])
+    ref64 = _oracle_matrix(a_hat, x, w, probes[:9], np.arange(n), 1e-4, torch.float64)
+    assert np.abs(got[:9, :n].astype(np.float64) - ref64).max() <= 1e-5 * ref64.max()
+    assert np.all(got[:9, :n][ref64 == 0] == 0)
+    # more observed positions than the table row's 16-bit counts take: the item kernels serve the call
+    huge = np.tile(np.arange(n), 73)[:65600]
+    wide = both(probes[:7], huge)
+    assert np.array_equal(wide[:, :n], got[:7, :n])
