@@ -1240,7 +1240,10 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_finish(
     const int32_t *__restrict__ dl_src, int n_obs, float delta, float *__restrict__ out, long ldo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char df_smem[];
     float *sS2 = reinterpret_cast<float *>(df_smem);             // [maxc][C] the items' layer-2 differences
-    constexpr int RPW = 64 / LPR, WAVES = LT_BLOCK / 64;
+    // (launched with 256, 128 or 64 threads: a call of more probes than the chip holds 4-wave blocks for -- ~ 90 VGPRs, 5 waves per
+    // SIMD, 1280 blocks -- takes narrower blocks, so that its probes still wait for their round trips side by side)
+    constexpr int RPW = 64 / LPR;
+    const int NT = (int)blockDim.x, WAVES = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.x;
     DF_STAMP(0);
@@ -1253,10 +1256,10 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_finish(
     constexpr int TPR = 2;                                    // short positions per thread held in registers (beyond: a later trip)
     int2 tp[TPR];
 #pragma unroll
-    for (int h = 0; h < TPR; ++h) tp[h] = gTp[min(tid + h * LT_BLOCK, n_obs - 1)];
+    for (int h = 0; h < TPR; ++h) tp[h] = gTp[min(tid + h * NT, n_obs - 1)];
     int2 ltp = gTp[max(n_obs - 1 - wid, 0)];
     float *orow = out + (long)b * ldo;
-    for (int j = tid; j < n_obs; j += LT_BLOCK) orow[j] = 0.f;    // (the barrier below orders these before the positions' results)
+    for (int j = tid; j < n_obs; j += NT) orow[j] = 0.f;    // (the barrier below orders these before the positions' results)
     const int cnt = hdr.x, n_short = hdr.y & 0xffff, n_long = (int)((unsigned)hdr.y >> 16), v = hdr.z;
     const lt_df_inc *ent = reinterpret_cast<const lt_df_inc *>(dl_src + hdr.w);
     // per touched position: up to 4 entries by one thread (a select per (entry, chain) pair, nothing but registers)
@@ -1403,7 +1406,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_finish(
 #pragma unroll
                 for (int h = 0; h < TPR; ++h) {
                     const int st = tp[h].y & 0xffff, c_ = tp[h].y >> 16;
-                    const bool have = tid + h * LT_BLOCK < n_short;
+                    const bool have = tid + h * NT < n_short;
 #pragma unroll
                     for (int x = 0; x < 4; ++x) te[h][x] = ent[have ? st + min(x, c_ - 1) : 0];
                 }
@@ -1469,12 +1472,12 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_finish(
     // ---- the touched positions ----
 #pragma unroll
     for (int h = 0; h < TPR; ++h)
-        if (tid + h * LT_BLOCK < n_short) orow[tp[h].x] = short_answer(te[h], tp[h].y >> 16);
+        if (tid + h * NT < n_short) orow[tp[h].x] = short_answer(te[h], tp[h].y >> 16);
     DF_STAMP(3);
     if (wid < n_long) long_answer(ltp, lmine);
     DF_STAMP(4);
     // (beyond the registers: a trip of their own each)
-    for (int x = tid + TPR * LT_BLOCK; x < n_short; x += LT_BLOCK) {
+    for (int x = tid + TPR * NT; x < n_short; x += NT) {
         const int2 t_ = gTp[x];
         const int st = t_.y & 0xffff, c_ = t_.y >> 16;
         lt_df_inc e[4];
@@ -2192,10 +2195,11 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
                     const float *zxp = b->z1x_valid ? b->Z1x : (const float *)nullptr;
                     const double *crp = b->cref_deferred ? b->fd_cref : (const double *)nullptr;
                     // (beyond the default 64 KB of dynamic LDS the kernel is told once per instantiation that it may take more)
+                    const unsigned df_threads = nb > 2560 ? 64u : (nb > 1280 ? 128u : (unsigned)LT_BLOCK);
 #define LT_DF_LAUNCH(SX_, ZF_)                                                                                                        \
     LT_DISPATCH_LPR(lpr, LT_DISPATCH_CP(cp,                                                                                           \
         if (dg.finish_smem > (size_t)64 * 1024) { const int rc_ = df_allow_big_lds<LPR_, CP_, SX_, ZF_>(); if (rc_) return rc_; }    \
-        hipLaunchKernelGGL((k_delta_probe_finish<LPR_, CP_, SX_, ZF_>), dim3((unsigned)nb), dim3(LT_BLOCK), dg.finish_smem, st,      \
+        hipLaunchKernelGGL((k_delta_probe_finish<LPR_, CP_, SX_, ZF_>), dim3((unsigned)nb), dim3(df_threads), dg.finish_smem, st,      \
                            b->Z1d, b->S1d, sxp, crp, b->S1qs, zxp, Hp, b->W2p, C, w.dl_rec, dg.rec_words, dg.maxc, g->dl_rec,        \
                            n_obs, delta, orow, (long)ldo)))
                     if (sxp && zxp) { LT_DF_LAUNCH(true, true); }

@@ -479,6 +479,12 @@ def test_delta_fused_long_lists_and_huge_observed_lists(gpu):
     ref64 = _oracle_matrix(a_hat, x, w, probes[:9], np.arange(n), 1e-4, torch.float64)
     assert np.abs(got[:9, :n].astype(np.float64) - ref64).max() <= 1e-5 * ref64.max()
     assert np.all(got[:9, :n][ref64 == 0] == 0)
+    # calls of more probes than the chip holds 4-wave blocks for take 2-wave (> 1280 probes) and 1-wave (> 2560) blocks
+    many = np.resize(np.concatenate([probes, np.arange(n)]), 2700)
+    obs64 = np.concatenate([clique, [centre], leaves[:9], np.arange(40)])
+    for count in (1500, 2700):
+        rows = both(many[:count], obs64)
+        assert np.array_equal(rows[:len(probes)], got[:, obs64])
     # more observed positions than the table row's 16-bit counts take: the item kernels serve the call
     huge = np.tile(np.arange(n), 73)[:65600]
     wide = both(probes[:7], huge)
