@@ -1485,9 +1485,20 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_finish(
         for (int y = 0; y < 4; ++y) e[y] = ent[st + min(y, c_ - 1)];
         orow[t_.x] = short_answer(e, c_);
     }
-    for (int s_ = wid + WAVES; s_ < n_long; s_ += WAVES) {          // (wave-uniform)
-        const int2 t_ = gTp[n_obs - 1 - s_];
-        long_answer(t_, long_first(t_, 0));
+    // (the wave's further long positions: the table entry two ahead and the list entries one ahead are on their way while a
+    // position is summed -- a clique of 40 among the probes is 40 long positions per member, 10 per wave; loads unconditional,
+    // past the end the last position again)
+    if (wid + WAVES < n_long) {                                     // (wave-uniform)
+        int s_ = wid + WAVES;
+        int2 tA = gTp[n_obs - 1 - s_];
+        int2 tB = gTp[n_obs - 1 - min(s_ + WAVES, n_long - 1)];
+        lt_df_inc eA = long_first(tA, 0);
+        for (; s_ < n_long; s_ += WAVES) {
+            const int2 tC = gTp[n_obs - 1 - min(s_ + 2 * WAVES, n_long - 1)];
+            const lt_df_inc eB = long_first(tB, 0);
+            long_answer(tA, eA);
+            tA = tB; eA = eB; tB = tC;
+        }
     }
     DF_STAMP(5);
 }
@@ -1855,7 +1866,8 @@ static df_geom df_geometry(const lt_graph *g, int C, int n_obs) {
     d.rec_words = lt_dl_rec_words(d.maxc, n_obs);
     d.record_smem = ((size_t)g->dl_max_tu + 1) * sizeof(int2);
     d.finish_smem = (size_t)d.maxc * C * sizeof(float) + 16;
-    d.ok = g->dl_meta != nullptr && n_obs >= 1 && n_obs <= 65534 && d.finish_smem <= (size_t)LT_DF_LDS_MAX;
+    d.ok = g->dl_meta != nullptr && n_obs >= 1 && n_obs <= 65534 && d.finish_smem <= (size_t)LT_DF_LDS_MAX &&
+           d.record_smem <= (size_t)64 * 1024;
     return d;
 }
 
@@ -2181,7 +2193,10 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
                         cj.smem_bytes = (unsigned)dg.record_smem;
                         bool rode = false;
                         if (p0 == 0) {
-                            int rc = lt_fp64_prepare_rows(b, nullptr, 0, nullptr, n_probe, st, &cj, &rode);      // (all rows: no item tables needed)
+                            // (a launch's dynamic LDS is given to ALL its blocks: beyond 16 KB of node list the records get a launch
+                            // of their own rather than cost the row blocks their occupancy)
+                            const bool ride = dg.record_smem <= (size_t)16 * 1024;
+                            int rc = lt_fp64_prepare_rows(b, nullptr, 0, nullptr, n_probe, st, ride ? &cj : nullptr, ride ? &rode : nullptr);
                             if (rc) return rc;
                         }
                         if (!rode) {

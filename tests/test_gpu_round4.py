@@ -16,6 +16,37 @@ from conftest import REPO
 pytestmark = pytest.mark.gpu
 
 
+def _s1d_baseline(a_hat, x, w, gpu):
+    """A `delta` baseline on one of the routes that form the product rows S1d (0 / 1): small shapes would otherwise go
+    aggregate-first (route 2), whose pre-activation is formed on demand -- not the record route's case."""
+    from linkteller_amd import _lib, engine, graph
+    _lib.set_tuning("aggregate_first", 0)
+    try:
+        base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *_params(w, gpu)).enable_fp64()
+    finally:
+        _lib.set_tuning("aggregate_first", None)
+    assert base.fp64_route() in (0, 1)
+    return base
+
+
+def _item_stage_a_launches(fn):
+    """Launches of the item kernels' stage A (k_item_stageA*) while fn runs: 0 <=> a `delta` call took the record route."""
+    import ctypes as C
+    from linkteller_amd import _lib
+    h = _lib.lib()
+    h.lt_profile_reset()
+    h.lt_profile_enable(1 << _lib.KERNEL_IDS["item_stageA"])
+    try:
+        fn()
+        torch.cuda.synchronize()
+        tot, cnt = C.c_double(), C.c_int64()
+        _lib.check(h.lt_profile_summary(_lib.KERNEL_IDS["item_stageA"], C.byref(tot), C.byref(cnt)))
+    finally:
+        h.lt_profile_enable(0)
+        h.lt_profile_reset()
+    return cnt.value
+
+
 def _params(w, dev):
     return [torch.from_numpy(w[k]).to(dev) for k in ("W1", "b1", "W2", "b2")]
 
@@ -352,7 +383,7 @@ def test_delta_fused_probe_blocks_keep_every_bit(gpu, h, c, kind):
     w = synth.gcn_weights(f, h, c, seed=3)
     for feats in ("twitch", "gauss"):
         x = synth.twitch_like_features(n, f, seed=2, density=0.05) if feats == "twitch" else synth.gaussian_features(n, f, seed=2)
-        base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *_params(w, gpu)).enable_fp64()
+        base = _s1d_baseline(a_hat, x, w, gpu)
         probes = rng.choice(n, 75, replace=False)
         observe = rng.choice(n, 90, replace=False)
         if kind == "dup":
@@ -361,6 +392,9 @@ def test_delta_fused_probe_blocks_keep_every_bit(gpu, h, c, kind):
         if kind == "iso":
             probes[0], observe[0] = 5, 77
         calls = [(probes, observe), (probes[:1], observe), (probes, probes)]
+        # the record route is what the first call of each pair below takes (aggregate-first, which small wide-layer shapes
+        # would otherwise choose, forms the pre-activation on demand: not this route's case)
+        assert _item_stage_a_launches(lambda: base.influence_rows(probes, observe, 1e-4, "delta")) == 0
         for pr, ob in calls:
             fused = base.influence_rows(pr, ob, 1e-4, "delta").cpu().numpy()
             _lib.set_tuning("delta_fused", 0)
@@ -400,9 +434,10 @@ def test_delta_fused_on_a_directed_pattern_with_empty_columns_and_many_observed(
     assert np.diff(a.indptr).max() <= 128 and np.diff(a.tocsc().indptr).max() <= 60
     x = synth.gaussian_features(n, f, seed=2)
     w = synth.gcn_weights(f, h, c, seed=3)
-    base = engine.Baseline(graph.HipGraph(a), torch.from_numpy(x).to(gpu), *_params(w, gpu)).enable_fp64()
+    base = _s1d_baseline(a, x, w, gpu)
     probes = np.concatenate([[0, 5, 39, 40], rng.choice(n, 60, replace=False)])           # 0, 5, 39: empty columns (no items)
     observe = np.concatenate([rng.choice(n, 1400, replace=False), [3, 3, 41, 41, 41]])     # 3: an empty row; repeats
+    assert _item_stage_a_launches(lambda: base.influence_rows(probes, observe, 1e-4, "delta")) == 0       # the record route
     fused = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy()
     _lib.set_tuning("delta_fused", 0)
     try:
@@ -424,9 +459,10 @@ def test_delta_fused_with_every_node_observed(gpu):
     adj, x, w = synth.twitch_like_problem("twitch-RU", hidden=256, n_classes=2, seed=0)
     a_hat = graph.first_order_gcn(adj)
     n = adj.shape[0]
-    base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *_params(w, gpu)).enable_fp64()
+    base = _s1d_baseline(a_hat, x, w, gpu)
     probes = np.random.RandomState(5).choice(n, 300, replace=False)
     everyone = np.arange(n)
+    assert _item_stage_a_launches(lambda: base.influence_rows(probes, everyone, 1e-4, "delta")) == 0     # the record route
     fused = base.influence_rows(probes, everyone, 1e-4, "delta").cpu().numpy()
     _lib.set_tuning("delta_fused", 0)
     try:
@@ -461,7 +497,7 @@ def test_delta_fused_long_lists_and_huge_observed_lists(gpu):
     assert np.diff(a_hat.indptr).max() <= 128 and np.diff(a_hat.indptr)[centre] >= 111
     x = synth.twitch_like_features(n, f, seed=5, density=0.05)
     w = synth.gcn_weights(f, h, c, seed=4)
-    base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *_params(w, gpu)).enable_fp64()
+    base = _s1d_baseline(a_hat, x, w, gpu)
     probes = np.concatenate([clique[:6], [centre], leaves[:5], np.random.RandomState(2).choice(n, 40, replace=False)])
     everyone3 = np.tile(np.arange(n), 3)
 
@@ -474,6 +510,7 @@ def test_delta_fused_long_lists_and_huge_observed_lists(gpu):
             _lib.set_tuning("delta_fused", None)
         assert np.array_equal(fused, plain), np.abs(fused - plain).max()
         return fused
+    assert _item_stage_a_launches(lambda: base.influence_rows(probes, everyone3, 1e-4, "delta")) == 0    # the record route
     got = both(probes, everyone3)
     assert np.array_equal(got[:, :n], got[:, n:2 * n]) and np.array_equal(got[:, :n], got[:, 2 * n:])
     ref64 = _oracle_matrix(a_hat, x, w, probes[:9], np.arange(n), 1e-4, torch.float64)
@@ -487,5 +524,48 @@ def test_delta_fused_long_lists_and_huge_observed_lists(gpu):
         assert np.array_equal(rows[:len(probes)], got[:, obs64])
     # more observed positions than the table row's 16-bit counts take: the item kernels serve the call
     huge = np.tile(np.arange(n), 73)[:65600]
+    assert _item_stage_a_launches(lambda: base.influence_rows(probes[:7], huge, 1e-4, "delta")) > 0       # the item kernels
     wide = both(probes[:7], huge)
     assert np.array_equal(wide[:, :n], got[:7, :n])
+
+
+def test_delta_fused_on_dense_clusters(gpu):
+    """Records near the cap of 2048 incidences per node: a 38-clique inside a sparse graph (each member: ~ 1 800 incidences,
+    every pair inside the clique a 38-entry list, 38 long positions per probe: the waves of a block take them in turn, the
+    next one's loads in flight) and two 24-cliques sharing 8 nodes (lists of mixed lengths).  Same bits as the item kernels,
+    within 1e-5 of the fp64 oracle.  (A 72-clique passes the cap: no records, the item kernels serve both calls.)"""
+    from test_gpu_parity import _oracle_matrix
+    from linkteller_amd import _lib, engine, graph, synth
+    n, f, h, c = 2600, 64, 128, 2
+    for size in (38, 72):
+        a = synth.erdos_renyi_graph(n, 9000, seed=21).tolil()
+
+        def clique(nodes):
+            for u in nodes:
+                for v_ in nodes:
+                    if u != v_:
+                        a[u, v_] = 1
+        big = np.arange(500, 500 + size)
+        clique(big)
+        clique(np.arange(900, 924))
+        clique(np.arange(916, 940))
+        a_hat = graph.first_order_gcn(sp.csr_matrix(a))
+        assert np.diff(a_hat.indptr).max() <= 128
+        x = synth.twitch_like_features(n, f, seed=6, density=0.05)
+        w = synth.gcn_weights(f, h, c, seed=8)
+        base = _s1d_baseline(a_hat, x, w, gpu)
+        rng = np.random.RandomState(3)
+        probes = np.concatenate([big[:5], [905, 935, 960], rng.choice(n, 30, replace=False)])
+        observe = np.concatenate([big, np.arange(900, 940), rng.choice(n, 200, replace=False)])
+        launches = _item_stage_a_launches(lambda: base.influence_rows(probes, observe, 1e-4, "delta"))
+        assert (launches == 0) == (size == 38), (size, launches)          # 38: the record route; 72: beyond the cap
+        fused = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy()
+        _lib.set_tuning("delta_fused", 0)
+        try:
+            plain = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy()
+        finally:
+            _lib.set_tuning("delta_fused", None)
+        assert np.array_equal(fused, plain), (size, np.abs(fused - plain).max())
+        ref64 = _oracle_matrix(a_hat, x, w, probes[:8], observe, 1e-4, torch.float64)
+        assert np.abs(fused[:8].astype(np.float64) - ref64).max() <= 1e-5 * ref64.max()
+        assert np.all(fused[:8][ref64 == 0] == 0)
