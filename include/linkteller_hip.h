@@ -120,7 +120,7 @@ int lt_set_tuning(const char *key, long long value);
  * to the current device together with its transpose (CSC) used by the sparse/delta modes.
  * Graphs of up to 65534 nodes without hub rows (rows of more than 128 entries) also get their per-node incidence records
  * (LT_MODE_DELTA's fused route, "delta_fused"): sum over the nodes of |column| x the columns' lengths entries of 8 bytes,
- * built on the host in this call (twitch-RU: 1.5 M entries, 25 MB); skipped when a node has more than 2048 (dense clusters: the item kernels are faster there) or they pass 256 MB. */
+ * built on the host in this call (twitch-RU: 1.5 M entries, 25 MB); skipped when a node has more than 4096 (dense clusters: the item kernels are faster there) or they pass 256 MB. */
 int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, const int32_t *col,
                     const float *val, lt_graph **out);
 int lt_graph_destroy(lt_graph *g);

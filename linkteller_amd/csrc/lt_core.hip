@@ -140,10 +140,10 @@ static void free_graph(lt_graph *g) {
 // for node v, its items (the CSC column of v) and the entries (u, position in row u) that hold an item, grouped by u ascending,
 // a node's entries in entry order.  Sum over the nodes of |R_v| * column lengths entries -- 1.6 M at twitch size, 25 MB; built on
 // the host from the CSC arrays lt_graph_create has in hand.  Only for graphs whose largest record stays small (no hub rows).
-#define LT_DL_MAX_T 2048             // incidences of one node: where the route still wins.  A k-clique among the probes is k long
-                                     // positions per member, summed by the four waves of its block in turn (tools/clique_time.py,
-                                     // record route against the item kernels per step: k = 10: 32.9 / 40.9 us, 20: 37.1 / 43.3,
-                                     // 40 (~ 1 900 incidences): 50.1 / 46.0, 56: 60.9 / 50.6)
+#define LT_DL_MAX_T 4096             // incidences of one node: where the route still wins.  A k-clique among the probes is k long
+                                     // positions per member (tools/clique_time.py, record route against the item kernels per step:
+                                     // k = 10: 32.5 / 40.7 us, 20: 34.4 / 43.2, 40: 42.9 / 46.2, 56 (~ 3 600 incidences): 49.0 / 50.5,
+                                     // 72 (5 700: lists of two 64-entry stretches): 58.3 / 52.6)
 #define LT_DL_MAX_WORDS ((int64_t)64 << 20)   // 256 MB of records
 struct dl_host {
     std::vector<int32_t> meta, rec;

@@ -1485,19 +1485,58 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_finish(
         for (int y = 0; y < 4; ++y) e[y] = ent[st + min(y, c_ - 1)];
         orow[t_.x] = short_answer(e, c_);
     }
-    // (the wave's further long positions: the table entry two ahead and the list entries one ahead are on their way while a
-    // position is summed -- a clique of 40 among the probes is 40 long positions per member, 10 per wave; loads unconditional,
-    // past the end the last position again)
-    if (wid + WAVES < n_long) {                                     // (wave-uniform)
-        int s_ = wid + WAVES;
-        int2 tA = gTp[n_obs - 1 - s_];
-        int2 tB = gTp[n_obs - 1 - min(s_ + WAVES, n_long - 1)];
-        lt_df_inc eA = long_first(tA, 0);
-        for (; s_ < n_long; s_ += WAVES) {
-            const int2 tC = gTp[n_obs - 1 - min(s_ + 2 * WAVES, n_long - 1)];
-            const lt_df_inc eB = long_first(tB, 0);
-            long_answer(tA, eA);
-            tA = tB; eA = eB; tB = tC;
+    // The long positions beyond each wave's first (a clique of k nodes among the probes is k of them per member): 8 lanes per
+    // position, 8 positions per wave side by side.  Lane q of a group holds entries q, q + 8, ... of a 64-entry stretch and the
+    // group walks the stretch in entry order, every entry handed round by an 8-lane shuffle to the lane of its chain: the
+    // addends and their order are long_answer's (chain k & 7, entry order), the butterfly and the tail row2_dot's.
+    // (one wave per position, as above, is ~ 1 us each: 56 of them took a block 14 us.)
+    {
+        const int q = lane & (LT_L2_LANES - 1);
+        const int NG = NT / LT_L2_LANES;                            // groups per block
+        // (wave-uniform trips: the groups of a wave whose position is past the end ride along unpredicated, stores excepted)
+        for (int s0 = WAVES + wid * (64 / LT_L2_LANES); s0 < n_long; s0 += NG) {
+            const int s_ = s0 + lane / LT_L2_LANES;
+            const bool have = s_ < n_long;
+            const int2 t_ = gTp[n_obs - 1 - min(s_, n_long - 1)];
+            const int st = t_.y & 0xffff, c_ = have ? (t_.y >> 16) : 0;
+            float acc[CP];
+#pragma unroll
+            for (int c = 0; c < CP; ++c) acc[c] = 0.f;
+            for (int y0 = 0; __ballot(y0 < c_) != 0ull; y0 += 64) {
+                lt_df_inc e[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) e[m] = ent[st + min(y0 + q + 8 * m, max(c_ - 1, 0))];
+                float tv[8][CP];
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+#pragma unroll
+                    for (int c = 0; c < CP; ++c) tv[m][c] = c < C ? sS2[(size_t)(e[m].ik >> 16) * C + c] : 0.f;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    if (__ballot(y0 + 8 * m < c_) == 0ull) break;          // (wave-uniform)
+#pragma unroll
+                    for (int src = 0; src < LT_L2_LANES; ++src) {
+                        const float a_ = __shfl(e[m].a, src, LT_L2_LANES);
+                        const int k_ = __shfl(e[m].ik, src, LT_L2_LANES);
+                        const bool mine_ = y0 + 8 * m + src < c_ && (k_ & (LT_L2_LANES - 1)) == q;
+#pragma unroll
+                        for (int c = 0; c < CP; ++c) {
+                            const float t = __shfl(tv[m][c], src, LT_L2_LANES);
+                            acc[c] = mine_ ? fmaf(a_, t, acc[c]) : acc[c];
+                        }
+                    }
+                }
+            }
+            float ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < CP; ++c) {
+                const float o = group_sum<LT_L2_LANES>(acc[c]);
+                if (c < C) {
+                    const float dd = o / delta;
+                    ss = fmaf(dd, dd, ss);
+                }
+            }
+            if (have && q == 0) orow[t_.x] = sqrtf(ss);
         }
     }
     DF_STAMP(5);

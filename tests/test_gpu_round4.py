@@ -530,9 +530,9 @@ def test_delta_fused_long_lists_and_huge_observed_lists(gpu):
 
 
 def test_delta_fused_on_dense_clusters(gpu):
-    """Records near the cap of 2048 incidences per node: a 38-clique inside a sparse graph (each member: ~ 1 800 incidences,
-    every pair inside the clique a 38-entry list, 38 long positions per probe: the waves of a block take them in turn, the
-    next one's loads in flight) and two 24-cliques sharing 8 nodes (lists of mixed lengths).  Same bits as the item kernels,
+    """Records of thousands of incidences per node (the cap is 4096): a 38-clique inside a sparse graph (each member: ~ 1 800
+    incidences, every pair inside the clique a 38-entry list, 38 long positions per probe: one per wave first, then eight per
+    wave side by side) and two 24-cliques sharing 8 nodes (lists of mixed lengths).  Same bits as the item kernels,
     within 1e-5 of the fp64 oracle.  (A 72-clique passes the cap: no records, the item kernels serve both calls.)"""
     from test_gpu_parity import _oracle_matrix
     from linkteller_amd import _lib, engine, graph, synth
