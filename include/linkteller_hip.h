@@ -125,6 +125,14 @@ int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, const int32_t
                     const float *val, lt_graph **out);
 int lt_graph_destroy(lt_graph *g);
 int lt_graph_info(const lt_graph *g, int32_t *n, int64_t *nnz, int32_t *max_row_nnz);
+/* Host only (no device call): the incidence records lt_graph_create would build for this CSR -- what tests/test_records.py pins
+ * against a plain restatement.  meta [4 n]: per node (offset into rec in 32-bit words, items, touched nodes, incidences);
+ * rec (may be NULL: sizes only): per node its items (row r, A_hat[r, v] as bits), then the touched nodes (u, first entry |
+ * entries << 16), u ascending, then the entries (A_hat[u, r] as bits, item << 16 | position in row u) node by node in entry
+ * order.  *rec_words: the words the records take.  LT_ERR_UNSUPPORTED when the graph gets none (hub rows, more than 65534
+ * nodes, a node beyond the incidence cap, more than 256 MB), LT_ERR_WORKSPACE when rec_capacity (words) is too small. */
+int lt_graph_records_host(int32_t n, int64_t nnz, const int32_t *rowptr, const int32_t *col, const float *val,
+                          int32_t *meta, int32_t *rec, int64_t rec_capacity, int64_t *rec_words);
 
 /* ---- dense GEMM C[M,N] = A[M,K] * B[K,N]  (torch.mm at gcn/layers.py:31) ----------------
  * exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): each output is the ordered sum of k-ordered fmaf chains of 128 terms

@@ -34,6 +34,8 @@ SIGNATURES = {
     "lt_graph_destroy": (C.c_int, [C.c_void_p]),
     "lt_graph_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                 C.POINTER(C.c_int32)]),
+    "lt_graph_records_host": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int64, C.POINTER(C.c_int64)]),
     "lt_gemm_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                               C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "lt_spmm_csr_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32,

@@ -505,6 +505,58 @@ extern "C" int lt_graph_destroy(lt_graph *g) {
     return LT_OK;
 }
 
+// Host only: the incidence records of a CSR, as lt_graph_create would build them (tests/test_records.py).  The transpose is
+// formed here by a plain counting pass (lt_graph_create's threaded one is validated against the same CSR on the device side).
+extern "C" int lt_graph_records_host(int32_t n, int64_t nnz, const int32_t *rowptr, const int32_t *col, const float *val,
+                                     int32_t *meta, int32_t *rec, int64_t rec_capacity, int64_t *rec_words) {
+    LT_REQUIRE(n >= 1 && nnz >= 0 && rowptr && (nnz == 0 || (col && val)) && meta && rec_words,
+               "lt_graph_records_host: n=%d nnz=%lld or a NULL argument", n, (long long)nnz);
+    LT_REQUIRE(rowptr[0] == 0 && (int64_t)rowptr[n] == nnz, "lt_graph_records_host: rowptr[0] / rowptr[n] do not frame %lld entries",
+               (long long)nnz);
+    try {
+        std::vector<int32_t> tptr((size_t)n + 1, 0), trow((size_t)nnz + 1), tpos((size_t)nnz + 1);
+        std::vector<float> tval((size_t)nnz + 1);
+        int32_t max_row = 0, max_col = 0;
+        for (int32_t r = 0; r < n; ++r) {
+            LT_REQUIRE(rowptr[r + 1] >= rowptr[r], "lt_graph_records_host: rowptr is not monotone at row %d", r);
+            max_row = std::max(max_row, rowptr[r + 1] - rowptr[r]);
+            for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+                LT_REQUIRE(col[k] >= 0 && col[k] < n, "lt_graph_records_host: column %d out of range in row %d", col[k], r);
+                ++tptr[(size_t)col[k] + 1];
+            }
+        }
+        for (int32_t c = 0; c < n; ++c) {
+            max_col = std::max(max_col, tptr[(size_t)c + 1]);
+            tptr[(size_t)c + 1] += tptr[c];
+        }
+        std::vector<int32_t> cur(tptr.begin(), tptr.end() - 1);
+        for (int32_t r = 0; r < n; ++r)
+            for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+                const int32_t p = cur[col[k]]++;
+                trow[p] = r;
+                tval[p] = val[k];
+                tpos[p] = k - rowptr[r];
+            }
+        dl_host dl;
+        if (max_row > LT_ROW_SEG || !build_delta_records(n, tptr.data(), trow.data(), tval.data(), tpos.data(), max_col, dl))
+            return lt_set_error(LT_ERR_UNSUPPORTED, "lt_graph_records_host: this graph gets no incidence records");
+        const int64_t words = (int64_t)dl.rec.size() - 4;          // (the builder pads its buffer by 4 words)
+        *rec_words = words;
+        memcpy(meta, dl.meta.data(), (size_t)n * 4 * sizeof(int32_t));
+        if (rec) {
+            if (rec_capacity < words)
+                return lt_set_error(LT_ERR_WORKSPACE, "lt_graph_records_host: %lld words given, %lld needed", (long long)rec_capacity,
+                                    (long long)words);
+            memcpy(rec, dl.rec.data(), (size_t)words * sizeof(int32_t));
+        }
+    } catch (const std::bad_alloc &) {
+        return lt_set_error(LT_ERR_NOMEM, "lt_graph_records_host: host allocation failed");
+    } catch (const std::system_error &) {
+        return lt_set_error(LT_ERR_NOMEM, "lt_graph_records_host: could not start the host threads");
+    }
+    return LT_OK;
+}
+
 extern "C" int lt_graph_info(const lt_graph *g, int32_t *n, int64_t *nnz, int32_t *max_row_nnz) {
     LT_REQUIRE(g != nullptr, "lt_graph_info: graph is NULL");
     if (n) *n = g->n;
