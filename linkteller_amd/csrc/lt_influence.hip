@@ -1657,10 +1657,27 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_rows(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ S2, int C, const float *__restrict__ b2, const float *__restrict__ OUT, int nb,
     const int32_t *__restrict__ off, const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs,
-    float delta, float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words, int psplit) {
+    float delta, float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words, int psplit,
+    int long_blocks = 0, const int32_t *__restrict__ tptr = nullptr, const int32_t *__restrict__ trow = nullptr,
+    const int32_t *__restrict__ probes = nullptr, const int32_t *__restrict__ hub_obs = nullptr) {
+    // DELTA, long_blocks > 0 (a graph with hub rows): the FIRST long_blocks blocks serve the observed hubs (stageB_long_block, every
+    // probe walking the staged row through its bitmap: 76 VGPRs against this kernel's 90, 8 KB of LDS) -- the two kernels are
+    // independent and each is one generation of latency-bound blocks: side by side in one launch, not one after the other
+    // (15.0 + 19.7 us at twitch size with a power-law graph; a second stream for the hubs cost more than it hid)
+    int bx = (int)blockIdx.x;
+    if constexpr (DELTA) {
+        if (bx < long_blocks) {
+            stageB_long_block<CP, true, false, false>(bx, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off, S2x, observe,
+                                                      n_obs, delta, out, ldo, bits, words, (const uint2 *)nullptr,
+                                                      (const int32_t *)nullptr, hub_obs,
+                                                      long_blocks / ((nb + LT_BLOCK / LT_L2_LANES - 1) / (LT_BLOCK / LT_L2_LANES)));
+            return;
+        }
+        bx -= long_blocks;
+    }
     __shared__ int32_t scol[LT_ROW_SEG];
     __shared__ float sval[LT_ROW_SEG];
-    const int j = (int)blockIdx.x / psplit, part = (int)blockIdx.x % psplit;
+    const int j = bx / psplit, part = bx % psplit;
     const int u = observe[j];
     const int e0 = rowptr[u], d = rowptr[u + 1] - e0;
     if (d > LT_ROW_SEG) return;          // an observed hub: stageB_long_block (the hub blocks of k_item_stageB's launch)
@@ -2362,8 +2379,11 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
                 } }
                 LT_CHECK_LAUNCH();
                 lt_prof_scope prof_(LT_K_ITEM_B, st);
-                if (long_blocks > 0) {   // the observed hubs, a launch of their own
-                    if (rows_route && !hub_short) {      // twitch size: few hub blocks, every probe walks the row
+                // twitch size (a bitmap row per probe, every probe walks the hub's row): the hub blocks ride in front of the per-row
+                // kernel's launch
+                const bool hubs_ride = long_blocks > 0 && rows_route && !hub_short && w.bits != nullptr && vrow == nullptr;
+                if (long_blocks > 0 && !hubs_ride) {   // the observed hubs, a launch of their own
+                    if (rows_route && !hub_short) {
                         LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_hubs<CP_, true, false, true>), dim3((unsigned)long_blocks),
                                                                dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, g->tptr, g->trow,
                                                                b->S2, C, b->b2, b->OUT, probes, nb, w.off, w.S2x, observe_nodes,
@@ -2385,10 +2405,12 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
                     LT_CHECK_LAUNCH();
                 }
                 if (rows_route) {
-                    LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_rows<CP_, true>), dim3((unsigned)((long)n_obs * psplit)),
+                    const long hb = hubs_ride ? long_blocks : 0;
+                    LT_REQUIRE((long)n_obs * psplit + hb < 2147483647L, "lt_influence_rows: stage-B grid limit");
+                    LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_rows<CP_, true>), dim3((unsigned)((long)n_obs * psplit + hb)),
                                                            dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, b->S2, C, b->b2,
                                                            b->OUT, nb, w.off, w.S2x, observe_nodes, n_obs, delta, orow, (long)ldo,
-                                                           w.bits, words, psplit));
+                                                           w.bits, words, psplit, (int)hb, g->tptr, g->trow, probes, w.hub_obs));
                 } else
                 LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, true>), dim3(gridB),
                                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
