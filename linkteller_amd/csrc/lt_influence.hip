@@ -927,8 +927,9 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageA_d2(
 #define LT_SBL_UN_DELTA 32
 #define LT_SBL_NS 8        // light probes: searches in flight per lane
 #define LT_SBL_MC 128      // SPARSE: members of a light probe kept in LDS at a time (> 64 + a search round: see fill)
-// WIDE (DELTA, calls with a handful of observed hubs): 32 membership tests in flight per lane instead of 8 -- 211 VGPRs, two
-// blocks per CU: right for the 100 hub blocks of a twitch-size call, wrong for the 5000 of BASELINE configs[4] (0.76 -> 1.28 ms)
+// WIDE (DELTA): 32 membership tests in flight per lane instead of 8 -- 211 VGPRs.  Not launched any more: at twitch size the plain
+// form is as fast (14.2 vs 15.0 us) and, at 76 VGPRs, rides in front of k_item_stageB_rows' launch; at BASELINE configs[4] (5000 hub
+// blocks) the wide form was slower (0.76 -> 1.28 ms)
 template <int CP, bool DELTA, bool SHORT, bool WIDE = false>   // SHORT: the short-side search (without it every probe tests every entry, no member lists in LDS)
 __device__ __forceinline__ void stageB_long_block(
     int bid, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
@@ -2383,13 +2384,7 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
                 // kernel's launch
                 const bool hubs_ride = long_blocks > 0 && rows_route && !hub_short && w.bits != nullptr && vrow == nullptr;
                 if (long_blocks > 0 && !hubs_ride) {   // the observed hubs, a launch of their own
-                    if (rows_route && !hub_short) {
-                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_hubs<CP_, true, false, true>), dim3((unsigned)long_blocks),
-                                                               dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, g->tptr, g->trow,
-                                                               b->S2, C, b->b2, b->OUT, probes, nb, w.off, w.S2x, observe_nodes,
-                                                               n_obs, delta, orow, (long)ldo, w.bits, words, w.big_bits,
-                                                               w.big_slot, w.hub_obs, vrow));
-                    } else if (hub_short) {
+                    if (hub_short) {
                         LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_hubs<CP_, true, true>), dim3((unsigned)long_blocks),
                                                                dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, g->tptr, g->trow,
                                                                b->S2, C, b->b2, b->OUT, probes, nb, w.off, w.S2x, observe_nodes,
