@@ -123,6 +123,7 @@ static void free_graph(lt_graph *g) {
     (void)hipFree(g->trow);
     (void)hipFree(g->tval);
     (void)hipFree(g->tpos);
+    (void)hipFree(g->cv);
     (void)hipFree(g->dl_meta);
     (void)hipFree(g->dl_rec);
     (void)hipFree(g->w_e0);
@@ -134,6 +135,11 @@ static void free_graph(lt_graph *g) {
     (void)hipFree(g->p_seg_begin);
     (void)hipFree(g->p_seg_scratch);
     delete g;
+}
+
+static __global__ void k_interleave_cv(const int32_t *__restrict__ col, const float *__restrict__ val, long long total, int2 *__restrict__ cv) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) cv[i] = make_int2(col[i], __float_as_int(val[i]));
 }
 
 // The fused DELTA route's per-node incidence records (lt_items.cuh "INCIDENCE RECORD"; lt_influence.hip k_delta_probe_finish):
@@ -477,6 +483,18 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
             G_HIP(hipMemcpy(g->w_cnt, tmp.data(), wb, hipMemcpyHostToDevice));
             for (size_t i = 0; i < items.size(); ++i) tmp[i] = items[i].dst;
             G_HIP(hipMemcpy(g->w_dst, tmp.data(), wb, hipMemcpyHostToDevice));
+        }
+    }
+    // (col, val) interleaved for the tiled SpMM, on the graphs that take it (a failure to allocate only means the kernel reads the two streams)
+    if (lt_tiled_wanted(g, 256) && nnz > 0) {
+        int2 *cv = nullptr;
+        if (hipMalloc((void **)&cv, ((size_t)nnz + LT_CSR_PAD) * sizeof(int2)) == hipSuccess) {
+            hipLaunchKernelGGL(k_interleave_cv, dim3((unsigned)(((size_t)nnz + LT_CSR_PAD + 255) / 256)), dim3(256), 0, 0, g->col, g->val,
+                               (long long)nnz + LT_CSR_PAD, cv);
+            if (hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess) g->cv = cv;
+            else (void)hipFree(cv);
+        } else {
+            (void)hipGetLastError();
         }
     }
     // the fused DELTA route's per-node records (graphs without hub rows; a failure to build them only means the route is not taken)

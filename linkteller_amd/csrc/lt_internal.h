@@ -25,6 +25,8 @@ struct lt_graph {
     int32_t *tptr = nullptr;
     int32_t *trow = nullptr;
     float *tval = nullptr;
+    int2 *cv = nullptr;        // [nnz + pad] (col, val bits) interleaved, graphs that take the tiled SpMM (lt_tiled_wanted at 256 columns): one
+                               // request per entry for k_rows_tiled instead of two
     int32_t *tpos = nullptr;   // [nnz] position of the CSC entry inside its ROW (k - rowptr[r]); graphs of up to 65534 nodes only
     // the fused DELTA route's per-node incidence records (lt_items.cuh; graphs of up to 65534 nodes without hub rows whose
     // largest record fits LDS), or NULL

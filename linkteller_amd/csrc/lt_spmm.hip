@@ -41,6 +41,22 @@ __device__ __forceinline__ int row_bcast(int x) {
 }
 
 // BIG: S spans 4 GiB or more (byte offsets of a gathered row no longer fit 32 bits)
+// (col, val) of entry e: from the interleaved stream lt_graph::cv when the graph has one -- ONE 8-byte request per entry instead
+// of two of 4: the value stream beside the column stream cost k_rows_tiled 0.5 of 8.8 ms on the R-MAT graph of BASELINE configs[4],
+// as instructions and requests, not as bytes -- else from the two arrays
+__device__ __forceinline__ void tiled_entry(const int2 *__restrict__ cv, const int32_t *__restrict__ col, const float *__restrict__ val,
+                                            int e, int &c, float &a) {
+    if (cv) {
+        typedef int i32x2 __attribute__((ext_vector_type(2)));
+        const i32x2 p_ = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(cv) + e);
+        c = p_.x;
+        a = __int_as_float(p_.y);
+    } else {
+        c = __builtin_nontemporal_load(col + e);
+        a = __builtin_nontemporal_load(val + e);
+    }
+}
+
 template <bool BIG>
 __global__ __launch_bounds__(LT_BLOCK) void k_rows_tiled(
     int n_items, const int32_t *__restrict__ w_e0, const int32_t *__restrict__ w_cnt,
@@ -49,7 +65,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_rows_tiled(
     const float *__restrict__ bias_after, int relu, float *__restrict__ out, long ldo,
     float *__restrict__ seg_out, long ld_seg, const int32_t *__restrict__ seg_begin,
     const int32_t *__restrict__ seg_long, const int32_t *__restrict__ long_row,
-    const int32_t *__restrict__ rowptr, int ns) {
+    const int32_t *__restrict__ rowptr, int ns, const int2 *__restrict__ cv) {
     constexpr int GL = LT_TILE_GL, U = LT_TILE_U;
     constexpr int GPW = 64 / GL, IPB = (LT_BLOCK / 64) * GPW;
     const int lane = threadIdx.x & 63;
@@ -67,7 +83,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_rows_tiled(
     const bool active = coff < ncols;
     // a chain starts from `init` (the layer-1 bias) on a short row and on the FIRST segment of a long row
     bool first = true;
-    if (dst >= n) {
+    if (init != nullptr && dst >= n) {      // (only a chain that starts from `init` asks: four dependent loads per segment otherwise for nothing)
         const int sg = dst - n;
         first = seg_begin[sg] == rowptr[long_row[seg_long[sg]]];
     }
@@ -80,20 +96,14 @@ __global__ __launch_bounds__(LT_BLOCK) void k_rows_tiled(
     // (col, val) of the NEXT 16-entry block are requested before the gathers of the current one go out
     int nxc = 0;
     float nxa = 0.f;
-    if (e0 + j < e1) {
-        nxc = __builtin_nontemporal_load(col + e0 + j);
-        nxa = __builtin_nontemporal_load(val + e0 + j);
-    }
+    if (e0 + j < e1) tiled_entry(cv, col, val, e0 + j, nxc, nxa);
     for (int eb = e0; eb < e1; eb += GL) {
         const int me = eb + j;
         const int myc = nxc;
         const float mya = nxa;
         nxc = 0;
         nxa = 0.f;
-        if (me + GL < e1) {
-            nxc = __builtin_nontemporal_load(col + me + GL);
-            nxa = __builtin_nontemporal_load(val + me + GL);
-        }
+        if (me + GL < e1) tiled_entry(cv, col, val, me + GL, nxc, nxa);
         const int left = e1 - eb;
         static_for<GL / U>([&](auto kbt) {
             constexpr int kb = decltype(kbt)::value * U;
@@ -145,7 +155,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_rows_tiled_f64(
     int n_items, const int32_t *__restrict__ w_e0, const int32_t *__restrict__ w_cnt,
     const int32_t *__restrict__ w_dst, int n, const int32_t *__restrict__ col, const float *__restrict__ val,
     const double *__restrict__ S, long lds, int ncols, const float *__restrict__ bias_after,
-    double *__restrict__ out, long ldo, double *__restrict__ seg_out, long ld_seg, int ns) {
+    double *__restrict__ out, long ldo, double *__restrict__ seg_out, long ld_seg, int ns, const int2 *__restrict__ cv) {
     constexpr int GL = LT_TILE_GL, U = LT_TILE_U;
     constexpr int GPW = 64 / GL, IPB = (LT_BLOCK / 64) * GPW;
     const int lane = threadIdx.x & 63;
@@ -167,20 +177,14 @@ __global__ __launch_bounds__(LT_BLOCK) void k_rows_tiled_f64(
     const int e1 = e0 + cnt;
     int nxc = 0;
     float nxa = 0.f;
-    if (e0 + j < e1) {
-        nxc = __builtin_nontemporal_load(col + e0 + j);
-        nxa = __builtin_nontemporal_load(val + e0 + j);
-    }
+    if (e0 + j < e1) tiled_entry(cv, col, val, e0 + j, nxc, nxa);
     for (int eb = e0; eb < e1; eb += GL) {
         const int me = eb + j;
         const int myc = nxc;
         const float mya = nxa;
         nxc = 0;
         nxa = 0.f;
-        if (me + GL < e1) {
-            nxc = __builtin_nontemporal_load(col + me + GL);
-            nxa = __builtin_nontemporal_load(val + me + GL);
-        }
+        if (me + GL < e1) tiled_entry(cv, col, val, me + GL, nxc, nxa);
         const int left = e1 - eb;
         static_for<GL / U>([&](auto kbt) {
             constexpr int kb = decltype(kbt)::value * U;
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_rows_tiled_xf64(
     const int32_t *__restrict__ w_dst, int n, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ X, long ldx, int ncols, double *__restrict__ out, long ldo, double *__restrict__ seg_out,
     long ld_seg, const int32_t *__restrict__ seg_long, const int32_t *__restrict__ long_row,
-    const int32_t *__restrict__ state, int ns) {
+    const int32_t *__restrict__ state, int ns, const int2 *__restrict__ cv) {
     constexpr int GL = LT_TILE_GL, U = LT_TILE_U;
     constexpr int GPW = 64 / GL, IPB = (LT_BLOCK / 64) * GPW;
     const int lane = threadIdx.x & 63;
@@ -249,20 +253,14 @@ __global__ __launch_bounds__(LT_BLOCK) void k_rows_tiled_xf64(
     const int e1 = e0 + cnt;
     int nxc = 0;
     float nxa = 0.f;
-    if (e0 + j < e1) {
-        nxc = __builtin_nontemporal_load(col + e0 + j);
-        nxa = __builtin_nontemporal_load(val + e0 + j);
-    }
+    if (e0 + j < e1) tiled_entry(cv, col, val, e0 + j, nxc, nxa);
     for (int eb = e0; eb < e1; eb += GL) {
         const int me = eb + j;
         const int myc = nxc;
         const float mya = nxa;
         nxc = 0;
         nxa = 0.f;
-        if (me + GL < e1) {
-            nxc = __builtin_nontemporal_load(col + me + GL);
-            nxa = __builtin_nontemporal_load(val + me + GL);
-        }
+        if (me + GL < e1) tiled_entry(cv, col, val, me + GL, nxc, nxa);
         const int left = e1 - eb;
         static_for<GL / U>([&](auto kbt) {
             constexpr int kb = decltype(kbt)::value * U;
@@ -311,7 +309,7 @@ int lt_launch_rows_tiled_xf64(const lt_graph *g, const float *X, int64_t ldx, in
     LT_REQUIRE(grid < 2147483647L, "tiled aggregate-first SpMM: grid limit");
     hipLaunchKernelGGL(k_rows_tiled_xf64, dim3((unsigned)grid), dim3(LT_BLOCK), 0, st, g->w_n, g->w_e0, g->w_cnt, g->w_dst,
                        g->n, g->col, g->val, X, (long)ldx, ncols, out, (long)ldo, seg_out, (long)ld_seg, g->p_seg_long,
-                       g->p_long_row, state, ns);
+                       g->p_long_row, state, ns, g->cv);
     LT_CHECK_LAUNCH();
     return LT_OK;
 }
@@ -328,7 +326,7 @@ int lt_launch_rows_tiled_f64(const lt_graph *g, const double *S, int64_t lds, in
     const long grid = 8 * ((chunks + xps - 1) / xps);
     LT_REQUIRE(grid < 2147483647L, "tiled fp64 SpMM: grid limit");
     hipLaunchKernelGGL(k_rows_tiled_f64, dim3((unsigned)grid), dim3(LT_BLOCK), 0, st, g->w_n, g->w_e0, g->w_cnt, g->w_dst,
-                       g->n, g->col, g->val, S, (long)lds, ncols, bias_after, out, (long)ldo, seg_out, (long)ld_seg, ns);
+                       g->n, g->col, g->val, S, (long)lds, ncols, bias_after, out, (long)ldo, seg_out, (long)ld_seg, ns, g->cv);
     LT_CHECK_LAUNCH();
     return LT_OK;
 }
@@ -362,11 +360,11 @@ int lt_launch_rows_tiled(const lt_graph *g, const float *S, int64_t lds, int nco
     if (big)
         hipLaunchKernelGGL(k_rows_tiled<true>, dim3((unsigned)grid), dim3(LT_BLOCK), 0, st, g->w_n, g->w_e0, g->w_cnt, g->w_dst,
                            g->n, g->col, g->val, S, (long)lds, ncols, init, bias_after, relu, out, (long)ldo, seg_out,
-                           (long)ld_seg, g->p_seg_begin, g->p_seg_long, g->p_long_row, g->rowptr, ns);
+                           (long)ld_seg, g->p_seg_begin, g->p_seg_long, g->p_long_row, g->rowptr, ns, g->cv);
     else
         hipLaunchKernelGGL(k_rows_tiled<false>, dim3((unsigned)grid), dim3(LT_BLOCK), 0, st, g->w_n, g->w_e0, g->w_cnt, g->w_dst,
                            g->n, g->col, g->val, S, (long)lds, ncols, init, bias_after, relu, out, (long)ldo, seg_out,
-                           (long)ld_seg, g->p_seg_begin, g->p_seg_long, g->p_long_row, g->rowptr, ns);
+                           (long)ld_seg, g->p_seg_begin, g->p_seg_long, g->p_long_row, g->rowptr, ns, g->cv);
     LT_CHECK_LAUNCH();
     return LT_OK;
 }
