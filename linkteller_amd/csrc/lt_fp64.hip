@@ -294,8 +294,8 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
     // the terms z is summed from.  Half the bytes stage A gathers per item (2 KB -> 1 KB) and this kernel writes.
     // job.nblocks > 0: the blocks from job_first on build the item tables of a probe chunk (k_item_bits' blocks: nothing in
     // this launch depends on them, and the launch in front of this one that they used to be cost the step 4 us)
-    // job_first < 0: the job's blocks are the FIRST of the grid instead (a record gather is three dependent round trips: started
-    // last it would finish last)
+    // job_first < 0: the job's blocks are the FIRST of the grid instead (for a job whose blocks outlast a block of rows; the record
+    // gather -- 4.5 us on its own -- is better off last: 11.1 against 11.5 us for the launch at twitch size)
     int bx = (int)blockIdx.x;
     if (job.nblocks > 0) {
         extern __shared__ __attribute__((aligned(16))) unsigned char spmm_job_smem[];      // (job.smem_bytes: the record gather's list)
@@ -1148,11 +1148,11 @@ static int form_z1d(lt_baseline *b, int32_t *state, hipStream_t st, const lt_bit
     if (b->s1_f32) {
         LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, float>), dim3(g2 + gs + gj), dim3(256), jsm, st, n, g->rowptr,
                                                 g->col, g->val, b->S1x, Hp, b->b1p, b->Z1d, (int)gs, g->p_n_seg, g->p_seg_begin,
-                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv, jb, jb.dl_rec ? -1 : (int)(g2 + gs), zf, b->S1qs));
+                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv, jb, (int)(g2 + gs), zf, b->S1qs));
     } else {
         LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, double>), dim3(g2 + gs + gj), dim3(256), jsm, st, n, g->rowptr,
                                                 g->col, g->val, b->S1d, Hp, b->b1p, b->Z1d, (int)gs, g->p_n_seg, g->p_seg_begin,
-                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv, jb, jb.dl_rec ? -1 : (int)(g2 + gs), zf));
+                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv, jb, (int)(g2 + gs), zf));
     }
     LT_CHECK_LAUNCH();
     if (have_long) {
