@@ -121,6 +121,7 @@ def parse():
     p.add_argument("--spmm-scale", type=int, default=21,
                    help="R-MAT scale of the HBM-resident SpMM leg (BASELINE configs[4]: 21; 0 = skip)")
     p.add_argument("--only-spmm", action="store_true", help="run only the R-MAT SpMM leg")
+    p.add_argument("--no-api-wall", action="store_true", help="skip the drop-in API leg (Attacker.influence_matrix wall time)")
     p.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes (roofline.traffic)")
     p.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return p.parse_args()
@@ -218,6 +219,14 @@ def kernel_ms(name):
     return tot.value, cnt.value
 
 
+def profiled_calls():
+    """Calls of the probe primitive sampled by the profile since lt_profile_enable (lt_profile_calls)."""
+    from linkteller_amd import _lib
+    c = C.c_int64(0)
+    _lib.check(_lib.lib().lt_profile_calls(C.byref(c)))
+    return c.value
+
+
 def spmm_bytes(n, nnz, h, elem=4):
     """int32 CSR + fp32 values, S read once, result written once."""
     return nnz * 8 + (n + 1) * 4 + 2 * n * h * elem
@@ -259,6 +268,8 @@ def main():
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
+            if world > 1:      # every rank would pick a different port and the rendezvous would hang until the store timeout
+                raise SystemExit("WORLD_SIZE > 1 but MASTER_PORT is not set (launch through torchrun or `bench.py --gpus N`)")
             with socket.socket() as s_:
                 s_.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
@@ -536,6 +547,9 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     value = a.n_test * a.n_test * a.steps / elapsed
     dom_tot, dom_cnt = kernel_ms(dom_name)
+    # "profile_every" samples whole calls (= steps here): the class's time per step is its total over the SAMPLED STEPS,
+    # however many scopes it opens in a step (chunked calls, the three sites of the fp64 product)
+    dom_steps = profiled_calls()
 
     elapsed_i, _ = timed(a.mode, a.steps, 0, profile_mask=-1)
     elapsed_i = elapsed_i[0]
@@ -554,8 +568,9 @@ def main():
     event_pair_us = round(float(np.median([e0.elapsed_time(e1) for e0, e1 in evs])) * 1e3, 2)
     if dom_cnt:      # duration of the dominant class as measured INSIDE the timed region (per step = per launch group)
         per_kernel[dom_name]["us_per_step_instrumented_pass"] = per_kernel[dom_name]["us_per_step"]
-        per_kernel[dom_name]["us_per_step"] = round(dom_tot / max(dom_cnt, 1) * 1e3, 2)
-        per_kernel[dom_name]["samples_in_timed_region"] = int(dom_cnt)
+        per_kernel[dom_name]["us_per_step"] = round(dom_tot / max(dom_steps, 1) * 1e3, 2)
+        per_kernel[dom_name]["samples_in_timed_region"] = int(dom_steps)
+        per_kernel[dom_name]["scopes_in_those_samples"] = int(dom_cnt)
 
     def roofline_of(cls, us, mode):
         """Roofline object of one kernel class at `us` microseconds per launch group (one per step)."""
@@ -621,6 +636,83 @@ def main():
                                        if kk in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us")}
                                    for k, v in per_kernel.items()}
 
+    # ---------------- the drop-in API: the region the reference itself times --------------------------------------------
+    # attacker.py:213 -> 231 ("time for predicting edges"): from the call to influence_val on the HOST as float64.  Here that is
+    # Attacker.influence_matrix(): one state_dict walk, the cached device node lists, refresh + lt_influence_rows, ONE export
+    # launch that widens on the device and writes into pinned host memory (lt_export_rows_f64), one stream wait.
+    api = None
+    if rank == 0 and world == 1 and not a.no_api_wall and not a.powerlaw:
+        import argparse as _ap
+        import types as _types
+        from linkteller_amd.attacker import Attacker
+        from linkteller_amd.gcn import GCN
+        model = GCN(f, h, c, 0.5)
+        model.load_state_dict({"gc1.weight": torch.from_numpy(w["W1"]), "gc1.bias": torch.from_numpy(w["b1"]),
+                               "gc2.weight": torch.from_numpy(w["W2"]), "gc2.bias": torch.from_numpy(w["b2"])})
+        model.to(dev).eval()
+        adj_t = graph.sparse_mx_to_torch_sparse_tensor(a_hat).to(dev)
+        wk = _types.SimpleNamespace(features_2=x, adj_2=adj_t, adj_ori=adj.tocsr(), n_nodes=n)
+        args_ = _ap.Namespace(dataset="twitch/RU", sample_type="unbalanced", n_test=a.n_test, sample_seed=42, influence=delta,
+                              mode="vanilla-clean", attack_mode="efficient", influence_mode=a.mode)
+        atk = Attacker(args_, model, wk)
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            atk.prepare_test_data()
+        for _ in range(5):
+            m_api = atk.influence_matrix()
+        ts = []
+        for _ in range(40):
+            t0 = time.perf_counter()
+            m_api = atk.influence_matrix()
+            ts.append(time.perf_counter() - t0)
+        api_s = float(np.median(ts))
+        same_nodes = bool(np.array_equal(np.asarray(atk.test_nodes), test_nodes))
+        # the export alone (HIP events on the launch stream), and the copy engine's plain fp32 D2H for comparison
+        pin64 = torch.empty((a.n_test, a.n_test), dtype=torch.float64, pin_memory=True)
+        pin32 = torch.empty((a.n_test, a.n_test), dtype=torch.float32, pin_memory=True)
+
+        def ev_median(fn, reps=30):
+            out_ = []
+            for i in range(reps + 3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); fn(); e1.record()
+                torch.cuda.synchronize()
+                if i >= 3:
+                    out_.append(e0.elapsed_time(e1) * 1e3)
+            return round(float(np.median(out_)), 2)
+        st_ = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        d2h_us = ev_median(lambda: _lib.check(_lib.lib().lt_export_rows_f64(full.data_ptr(), a.n_test, a.n_test, a.n_test, pin64.data_ptr(),
+                                                                           a.n_test, st_)))
+        d2h_copy_us = ev_median(lambda: pin32.copy_(full, non_blocking=True))
+        # the headline step with the matrix brought to the host every step (same blocks, same median)
+        def step_to_host():
+            return engine.export_rows_f64(step(a.mode))
+        bl = []
+        for _ in range(3):
+            step_to_host()
+        for _ in range(max(1, a.blocks)):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                step_to_host()
+            barrier()
+            bl.append(time.perf_counter() - t0)
+        sth = float(np.median(bl)) / a.steps
+        api = {"what": "Attacker.influence_matrix(): the region the reference times at attacker.py:213->231 (`time for predicting edges`), "
+                       "influence_val on the host as float64; median of 40 calls after 5",
+               "api_wall_ms": round(api_s * 1e3, 4), "value_host": round(a.n_test ** 2 / api_s, 1), "unit": "node-pairs/s",
+               "api_wall_min_ms": round(float(np.min(ts)) * 1e3, 4), "api_wall_p90_ms": round(float(np.percentile(ts, 90)) * 1e3, 4),
+               "d2h_us": d2h_us, "d2h_bytes": a.n_test * a.n_test * 8,
+               "d2h_note": "lt_export_rows_f64: one launch widens fp32 -> fp64 on the device and writes into pinned host memory over PCIe "
+                           "(HIP events around the launch)",
+               "d2h_copy_engine_fp32_us": d2h_copy_us,
+               "ms_per_step_to_host": round(sth * 1e3, 4), "value_step_to_host": round(a.n_test ** 2 / sth, 1),
+               "step_to_host_note": "the headline step + the export + the stream wait, every step (the step of `value` ends on the device)",
+               "matrix_equals_step": bool(same_nodes and np.array_equal(m_api, full.cpu().numpy().astype(np.float64))),
+               "same_test_nodes_as_step": same_nodes}
+        del pin64, pin32, atk, model
+
     extras = {}
     mats = {}
     if rank == 0 and not a.no_extras and world == 1:
@@ -682,6 +774,48 @@ def main():
                                     "ms_per_step": round(res_h[a.mode] * 1e3, 4),
                                     **{f"{m}_ms_per_step": round(res_h[m] * 1e3, 4) for m in res_h if m != a.mode}}
             del base_h, out_h
+        # BASELINE configs[3]: the same model served on the LapGraph-perturbed graph (eps = 5, noise_seed = 42; worker.py:281-335):
+        # the graph the DP defence publishes is sparse (~E edges, heavy-tailed), the ground truth stays the clean adj_ori
+        if not a.powerlaw:
+            import contextlib
+            import io
+            from linkteller_amd import dp as lt_dp
+            buf_ = io.StringIO()
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(buf_):
+                n_l, noise_l, keep_l = lt_dp._lapgraph_inputs(adj, 5.0, 42, "laplace", 1e-5)
+            t_draw = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            top_dev = lt_dp._lapgraph_select_hip(adj, noise_l, keep_l)
+            torch.cuda.synchronize()
+            t_dev = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            noise_h = noise_l * np.tri(n_l, n_l, k=-1, dtype=bool)
+            import scipy.sparse as _sp
+            cells_h = np.asarray(_sp.tril(adj, k=-1) + noise_h).ravel()
+            top_host = np.argpartition(cells_h, -keep_l)[-keep_l:]
+            t_host = time.perf_counter() - t0
+            same_cells = bool(np.array_equal(np.sort(top_dev), np.sort(top_host)))
+            del noise_l, noise_h, cells_h
+            mat_l = _sp.csr_matrix((np.ones(keep_l, dtype=np.int32), (top_dev // n_l, top_dev % n_l)), shape=(n_l, n_l))
+            adj_l = ((mat_l + mat_l.T) > 0).astype(np.float32).tocsr()
+            al = graph.first_order_gcn(adj_l)
+            base_l = engine.Baseline(graph.HipGraph(al), x, *params)
+            out_l = torch.empty((a.n_test, a.n_test), dtype=torch.float32, device=dev)
+            res_l = {}
+            for m in ("delta", "sparse", "full"):
+                res_l[m] = wall_median(lambda: (base_l.refresh(m), base_l.influence_rows(obs, obs, delta, m, out=out_l)), 20)
+            extras["workload_4"] = {"workload": f"n_test={a.n_test} on the LapGraph-served graph (eps=5, noise_seed=42; BASELINE configs[3]): "
+                                                f"{int(adj_l.nnz // 2)} edges kept of {int(adj.nnz // 2)}, max degree {int(np.diff(al.indptr).max())}",
+                                    "value": round(a.n_test ** 2 / res_l[a.mode], 1), "unit": "node-pairs/s", "mode": a.mode,
+                                    "ms_per_step": round(res_l[a.mode] * 1e3, 4),
+                                    **{f"{m}_ms_per_step": round(res_l[m] * 1e3, 4) for m in res_l if m != a.mode},
+                                    "lapgraph_select": {"device_s": round(t_dev, 4), "host_argpartition_s": round(t_host, 4),
+                                                        "numpy_laplace_draw_s": round(t_draw, 4), "same_cells": same_cells,
+                                                        "note": "lt_lapgraph_select (upload of the N x N float64 noise + add + 8-pass radix select + "
+                                                                "index read-back) against the reference's host path (tril + add + argpartition); "
+                                                                "the seeded numpy draw is common to both"}}
+            del base_l, out_l
         # BASELINE configs[2] on ONE GPU (the config itself shards n_test = 2000 over 8): the same graph, 2000 probes x 2000 observed
         if a.n_test != 2000 and n >= 2000:
             np.random.seed(42)
@@ -904,6 +1038,9 @@ def main():
         if a.mode != "delta":
             out["parity_note"] = ("this mode is the reference's fp32 finite difference: its raw AUC can move by 1 / n_edges when a low-score "
                                   "edge quantises to 0 (DESIGN.md section 3); `delta` is the mode that meets north_star's 1e-4")
+        if api is not None:
+            out["api_wall"] = api
+            out["value_host"] = api["value_host"]
         out.update(extras)
         if scaling is not None:
             out["scaling_workloads"] = scaling

@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 3   /* 2: lt_baseline_refresh launches nothing (lazy recomputation on the first reader's stream); fp64 shard entry points;
+#define LT_ABI_VERSION 4   /* 4: lt_export_rows_f64 (the matrix leaves the device once, as float64), node ids checked on the device
+                            (LT_ERR_INDEX, lt_node_check), lt_profile_calls; every version-3 entry point is unchanged.  2: lt_baseline_refresh launches nothing (lazy recomputation on the first reader's stream); fp64 shard entry points;
                             profile classes 9-11.  3: lt_influence_rows_vec + lt_wide_combine (layers wider than one pass of the fused
                             kernels), lt_spmm_gather_ceiling (measurement support); every version-2 entry point is unchanged */
 
@@ -39,7 +40,8 @@ typedef enum lt_status {
     LT_ERR_HIP = -2,         /* a HIP runtime call failed (message has the HIP error) */
     LT_ERR_UNSUPPORTED = -3, /* shape outside what the kernels are built for          */
     LT_ERR_WORKSPACE = -4,   /* caller workspace too small / misaligned               */
-    LT_ERR_NOMEM = -5
+    LT_ERR_NOMEM = -5,
+    LT_ERR_INDEX = -6        /* a node id of an EARLIER call's device lists was out of range (see lt_node_check) */
 } lt_status;
 
 /* how lt_influence_rows evaluates a probe (all three give the reference's quantity
@@ -224,6 +226,24 @@ int lt_influence_rows(const lt_baseline *b, const int32_t *probe_nodes, int32_t 
                       float *out, int64_t ldo, void *workspace, size_t workspace_bytes,
                       void *stream);
 
+/* Node ids arrive as DEVICE lists, which the host side of this ABI cannot read: the first kernel of a call that touches a list
+ * checks every id against [0, n) -- where the reference raises IndexError at grad_mat[test_nodes[j]] / features[v]
+ * (attacker.py:103, 226-229) -- replaces an id out of range by node 0 for the rest of the call (no out-of-bounds access;
+ * the rows / columns of such ids are meaningless) and raises a flag in mapped host memory.  The flag is reported
+ *   - by lt_node_check: *bad_probe / *bad_observe (may be NULL) = 1 when a list of a call whose kernels have COMPLETED held such
+ *     an id (call it after synchronising the stream); clears the flag; returns LT_ERR_INDEX when either is set;
+ *   - by the next lt_influence_rows / _vec / lt_influence3_rows* call that finds it set: LT_ERR_INDEX, nothing enqueued. */
+int lt_node_check(int32_t *bad_probe, int32_t *bad_observe);
+
+/* ---- the finished rows, once, as float64 ------------------------------------------------------------------------------
+ * Stands in for influence_val = np.zeros((n_test, n_test)) (float64, attacker.py:216) and the n_test^2 `.norm().item()` host
+ * round trips that fill it (attacker.py:227-229): dst[i * ldd + j] = (double)src[i * lds + j] by one launch.  src: device
+ * [rows, lds] fp32 (what lt_influence_rows wrote).  dst: device memory, or PINNED host memory (hipHostMalloc /
+ * hipHostRegister, e.g. a torch tensor with pin_memory=True): the kernel then writes over PCIe through the buffer's
+ * device-side alias -- no staging copy, no second operation on the stream; the bytes are valid on the host once the stream has
+ * drained.  Pageable host pointers are refused (LT_ERR_INVALID). */
+int lt_export_rows_f64(const float *src, int64_t lds, int32_t rows, int32_t cols, double *dst, int64_t ldd, void *stream);
+
 /* ---- measurement support: the gather ceiling of the tiled SpMM ------------------------------------------------------
  * The tiled (column-sliced work-item) kernel of lt_spmm_csr_f32 with everything but its gathers removed: the same work
  * items, order, column stream, slice placement and piece size, `in_flight` (8 = the kernel's own, or 16) gathers per lane;
@@ -326,6 +346,9 @@ typedef enum lt_kernel_id {
 int lt_profile_enable(int mask);
 int lt_profile_reset(void);
 int lt_profile_summary(int kernel_id, double *total_ms, int64_t *launches);
+/* "profile_every" = N samples whole CALLS of lt_influence_rows* (every scope of a sampled call is bracketed, none of the others):
+ * the number of calls sampled since lt_profile_enable -- a class's time per call = its total / this, however many scopes it opens */
+int lt_profile_calls(int64_t *calls_sampled);
 
 #ifdef __cplusplus
 }

@@ -81,13 +81,16 @@ SIGNATURES = {
     "lt_baseline3_enable_fp64": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lt_influence3_rows_mode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p,
                                          C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "lt_node_check": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "lt_export_rows_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "lt_profile_calls": (C.c_int, [C.POINTER(C.c_int64)]),
     "lt_profile_enable": (C.c_int, [C.c_int]),
     "lt_profile_reset": (C.c_int, []),
     "lt_profile_summary": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 KERNEL_IDS = {"gemm": 0, "layer1": 1, "layer2": 2, "perturb": 3, "full_stageA": 4, "full_stageB": 5,
               "item_stageA": 6, "item_stageB": 7, "spmm": 8, "fp64_product": 9, "fp64_spmm": 10, "item_bits": 11}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def lib():
@@ -111,9 +114,14 @@ def lib():
     return _lib
 
 
+LT_ERR_INDEX = -6
+
+
 def check(status: int, what: str = ""):
     if status != LT_OK:
         msg = lib().lt_last_error().decode("utf-8", "replace")
+        if status == LT_ERR_INDEX:      # the reference raises IndexError at grad_mat[test_nodes[j]] (attacker.py:226-229)
+            raise IndexError(f"{what or 'liblinkteller_hip'}: {msg}")
         raise LinkTellerHipError(f"{what or 'liblinkteller_hip'} failed with status {status}: {msg}")
 
 

@@ -583,6 +583,100 @@ extern "C" int lt_graph_info(const lt_graph *g, int32_t *n, int64_t *nnz, int32_
     return LT_OK;
 }
 
+// ---- node ids out of range: the flag words the kernels raise (include/linkteller_hip.h, lt_node_check) -------------------------
+// Two words of mapped host memory per process (portable: every device writes through its own alias): [0] a probe list,
+// [1] an observed list held an id outside [0, n).
+namespace {
+int32_t *g_node_err_host = nullptr;
+bool g_node_err_tried = false;
+}
+int32_t *lt_node_err_dev() {
+    if (!g_node_err_tried) {
+        g_node_err_tried = true;
+        if (hipHostMalloc((void **)&g_node_err_host, 2 * sizeof(int32_t), hipHostMallocMapped | hipHostMallocPortable) == hipSuccess)
+            g_node_err_host[0] = g_node_err_host[1] = 0;
+        else { g_node_err_host = nullptr; (void)hipGetLastError(); }
+    }
+    if (!g_node_err_host) return nullptr;
+    int32_t *dev = nullptr;
+    if (hipHostGetDevicePointer((void **)&dev, g_node_err_host, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return dev;
+}
+extern "C" int lt_node_check(int32_t *bad_probe, int32_t *bad_observe) {
+    int p = 0, o = 0;
+    if (g_node_err_host) {
+        volatile int32_t *w = g_node_err_host;
+        p = w[0] != 0; o = w[1] != 0;
+        w[0] = 0; w[1] = 0;
+    }
+    if (bad_probe) *bad_probe = p;
+    if (bad_observe) *bad_observe = o;
+    if (p || o)
+        return lt_set_error(LT_ERR_INDEX, "node id out of range in the %s of an earlier call (its rows are meaningless)",
+                            p && o ? "probe and observed lists" : (p ? "probe list" : "observed list"));
+    return LT_OK;
+}
+// (what the probe primitives call on entry: a flag raised by an earlier call's kernels is reported now, nothing is enqueued)
+int lt_node_err_pending() {
+    if (!g_node_err_host) return LT_OK;
+    volatile int32_t *w = g_node_err_host;
+    if (w[0] == 0 && w[1] == 0) return LT_OK;
+    return lt_node_check(nullptr, nullptr);
+}
+
+// ---- lt_export_rows_f64: the finished rows -> float64, straight into host memory ------------------------------------------
+// The reference fills influence_val (np.zeros -> float64, attacker.py:216) with n_test^2 `.norm().item()` round trips
+// (attacker.py:227-229).  Here the matrix leaves the device ONCE, already widened: one lane reads two scores and stores two
+// doubles, a wave instruction writes 1 KiB of contiguous bytes -- into device memory, or over PCIe into pinned host memory
+// (hipHostMalloc / hipHostRegister: the kernel writes through the device-side alias of the buffer, no staging copy, no
+// second launch; the bytes are the caller's once the stream has drained).
+static __global__ __launch_bounds__(256) void k_export_rows_f64(const float *__restrict__ src, long lds, int rows, int cols,
+                                                                 double *__restrict__ dst, long ldd) {
+    const int half = (cols + 1) >> 1;
+    const long total = (long)rows * half;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long)gridDim.x * 256) {
+        const int r = (int)(k / half), c = (int)(k % half) * 2;
+        const float *s = src + r * lds + c;
+        double *d = dst + r * ldd + c;
+        if (c + 1 < cols) {
+            const float a = s[0], b = s[1];
+            if ((reinterpret_cast<uintptr_t>(d) & 15) == 0) *reinterpret_cast<double2 *>(d) = make_double2((double)a, (double)b);
+            else { d[0] = (double)a; d[1] = (double)b; }
+        } else d[0] = (double)s[0];
+    }
+}
+
+extern "C" int lt_export_rows_f64(const float *src, int64_t lds, int32_t rows, int32_t cols, double *dst, int64_t ldd,
+                                  void *stream) {
+    LT_REQUIRE(rows >= 0 && cols >= 0, "lt_export_rows_f64: negative shape");
+    if (rows == 0 || cols == 0) return LT_OK;
+    LT_REQUIRE(src && dst, "lt_export_rows_f64: NULL pointer");
+    LT_REQUIRE(lds >= cols && ldd >= cols, "lt_export_rows_f64: leading dimension smaller than the row");
+    // dst may be host memory: only pinned (device-mapped) memory can be written by a kernel -- resolve its device-side alias
+    // and refuse pageable pointers instead of faulting
+    hipPointerAttribute_t at;
+    hipError_t e = hipPointerGetAttributes(&at, dst);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return lt_set_error(LT_ERR_INVALID, "lt_export_rows_f64: dst is neither device memory nor pinned host memory (%s)",
+                            hipGetErrorString(e));
+    }
+    double *d = dst;
+    if (at.type == hipMemoryTypeHost) {
+        LT_REQUIRE(at.devicePointer != nullptr, "lt_export_rows_f64: pinned dst has no device-side alias");
+        d = (double *)at.devicePointer;
+    } else if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged) {
+        return lt_set_error(LT_ERR_INVALID, "lt_export_rows_f64: dst is pageable host memory (pin it: hipHostMalloc / hipHostRegister)");
+    }
+    const long total = (long)rows * ((cols + 1) / 2);
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_export_rows_f64, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (long)lds, rows, cols, d,
+                       (long)ldd);
+    LT_CHECK_LAUNCH();
+    return LT_OK;
+}
+
 // ---- per-kernel event timing ------------------------------------------------------------------
 unsigned g_lt_profile_mask = 0;   // bit k set: kernel class k is bracketed by events
 namespace {
@@ -591,6 +685,13 @@ std::vector<prof_rec> g_recs;
 std::vector<hipEvent_t> g_free;
 hipEvent_t g_open[LT_K_COUNT];
 unsigned g_tick[LT_K_COUNT];
+// "profile_every" samples whole CALLS of the probe primitive, not single scopes: a class that opens several scopes per call (a
+// chunked call, the three sites of the fp64 product) would otherwise alias to one of them; scopes outside any call keep a
+// tick per class
+int g_call_depth = 0;
+bool g_call_sampled = true;
+unsigned g_call_tick = 0;
+int64_t g_calls_sampled = 0;
 hipEvent_t take_event() {
     if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -600,9 +701,17 @@ hipEvent_t take_event() {
 }  // namespace
 
 bool lt_profile_sample(int id) {
+    if (g_call_depth > 0) return g_call_sampled;
     const unsigned every = (unsigned)lt_tune().profile_every;
     return every <= 1u || (g_tick[id]++ % every) == 0u;
 }
+void lt_profile_call_begin() {
+    if (g_call_depth++ > 0 || !g_lt_profile_mask) return;
+    const unsigned every = (unsigned)lt_tune().profile_every;
+    g_call_sampled = every <= 1u || (g_call_tick++ % every) == 0u;
+    if (g_call_sampled) ++g_calls_sampled;
+}
+void lt_profile_call_end() { if (g_call_depth > 0) --g_call_depth; }
 void lt_profile_begin(int id, hipStream_t st) {
     hipEvent_t e = take_event();
     (void)hipEventRecord(e, st);
@@ -622,7 +731,13 @@ extern "C" int lt_profile_reset(void) {
 extern "C" int lt_profile_enable(int mask) {
     lt_profile_reset();
     for (auto &t : g_tick) t = 0;
+    g_call_tick = 0;
+    g_calls_sampled = 0;
     g_lt_profile_mask = (unsigned)mask;
+    return LT_OK;
+}
+extern "C" int lt_profile_calls(int64_t *calls_sampled) {
+    if (calls_sampled) *calls_sampled = g_calls_sampled;
     return LT_OK;
 }
 extern "C" int lt_profile_summary(int kernel_id, double *total_ms, int64_t *launches) {

@@ -513,13 +513,14 @@ struct infl3_ws {
     uint2 *bits1;
     uint32_t *bits2;
     int2 *items2;
+    int32_t *probes_s, *obs_s;    // the call's lists, every id checked against [0, n) (lt_items.cuh k_check_nodes)
     size_t bytes;
     int chunk;
 };
 
 static int probe_kslice3(const lt_baseline3 *b) { return lt_gemm_pick_kslice(b->n, b->H1, b->F); }
 
-static infl3_ws carve3(void *base, const lt_baseline3 *b, int n_probe) {
+static infl3_ws carve3(void *base, const lt_baseline3 *b, int n_probe, int n_obs) {
     infl3_ws w = {};
     const size_t n = (size_t)b->n, C = (size_t)b->C, Hp1 = (size_t)b->Hp1, Hp2 = (size_t)b->Hp2;
     const size_t maxc = (size_t)(b->g->max_col_nnz > 0 ? b->g->max_col_nnz : 1);
@@ -550,14 +551,15 @@ static infl3_ws carve3(void *base, const lt_baseline3 *b, int n_probe) {
     w.bits2 = (uint32_t *)take(chunk * words * sizeof(uint32_t));
     w.items2 = (int2 *)take(chunk * n * sizeof(int2));
     w.S3x = (float *)take(chunk * n * C * sizeof(float));
+    w.probes_s = (int32_t *)take((size_t)(n_probe > 0 ? n_probe : 1) * sizeof(int32_t));
+    w.obs_s = (int32_t *)take((size_t)(n_obs > 0 ? n_obs : 1) * sizeof(int32_t));
     w.bytes = offb;
     return w;
 }
 
 extern "C" size_t lt_influence3_workspace_bytes(const lt_baseline3 *b, int32_t n_probe, int32_t n_obs) {
-    (void)n_obs;
-    if (!b || n_probe < 0) return 0;
-    return carve3(nullptr, b, n_probe).bytes;
+    if (!b || n_probe < 0 || n_obs < 0) return 0;
+    return carve3(nullptr, b, n_probe, n_obs).bytes;
 }
 
 extern "C" int lt_influence3_rows(const lt_baseline3 *b, const int32_t *probe_nodes, int32_t n_probe,
@@ -571,6 +573,7 @@ extern "C" int lt_influence3_rows_mode(const lt_baseline3 *b, const int32_t *pro
                                        const int32_t *observe_nodes, int32_t n_obs, float delta, int32_t mode, float *out,
                                        int64_t ldo, void *workspace, size_t workspace_bytes, void *stream) {
     LT_REQUIRE(b != nullptr, "lt_influence3_rows: baseline is NULL");
+    lt_prof_call prof_call_;
     LT_REQUIRE(mode == LT_MODE_SPARSE || mode == LT_MODE_FULL || mode == LT_MODE_DELTA, "lt_influence3_rows_mode: unknown mode %d", mode);
     const bool exact = mode == LT_MODE_DELTA;
     LT_REQUIRE(!exact || b->Z2d != nullptr, "lt_influence3_rows_mode: LT_MODE_DELTA needs lt_baseline3_enable_fp64");
@@ -580,13 +583,22 @@ extern "C" int lt_influence3_rows_mode(const lt_baseline3 *b, const int32_t *pro
     LT_REQUIRE(probe_nodes && observe_nodes && out, "lt_influence3_rows: NULL pointer");
     LT_REQUIRE(ldo >= n_obs, "lt_influence3_rows: ldo=%lld < n_obs=%d", (long long)ldo, n_obs);
     LT_REQUIRE(b->n > 0, "lt_influence3_rows: empty graph");
+    { const int rc = lt_node_err_pending(); if (rc) return rc; }     // an earlier call's list held an id out of range
     const size_t need = lt_influence3_workspace_bytes(b, n_probe, n_obs);
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace % 256))
         return lt_set_error(LT_ERR_WORKSPACE, "lt_influence3_rows: workspace needs %zu bytes, 256-byte aligned", need);
     hipStream_t st = (hipStream_t)stream;
     const lt_graph *g = b->g;
-    const infl3_ws w = carve3(workspace, b, n_probe);
+    const infl3_ws w = carve3(workspace, b, n_probe, n_obs);
     const int n = b->n, C = b->C, Hp1 = b->Hp1, Hp2 = b->Hp2, cp = lt_cp_for(C);
+    {   // node ids: both lists checked into the workspace (the first reader is a GEMM that gathers X[probes])
+        const long tot = (long)n_probe + n_obs;
+        hipLaunchKernelGGL(k_check_nodes, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, probe_nodes, n_probe, observe_nodes,
+                           n_obs, n, w.probes_s, w.obs_s, lt_node_err_dev());
+        LT_CHECK_LAUNCH();
+        probe_nodes = w.probes_s;
+        observe_nodes = w.obs_s;
+    }
     const int lpr1 = lt_lpr_for(Hp1), lpr2 = lt_lpr_for(Hp2);
     const int words = (n + 31) / 32;
     const long maxc = g->max_col_nnz > 0 ? g->max_col_nnz : 1;

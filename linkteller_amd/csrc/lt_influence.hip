@@ -1945,6 +1945,7 @@ struct infl_ws {
     uint2 *big_bits;       // SPARSE / DELTA without `bits`: bitmap rows of the chunk's big probes [LT_BIG_SLOTS][ceil(n / 32)]
     int32_t *big_slot;     // [chunk + 1] slot of each probe (-1: none) + the slot counter
     uint2 *bits;           // SPARSE / DELTA: membership bitmap + positions of R_v per probe [chunk][ceil(n / 32)], or NULL (huge graphs)
+    int32_t *probes_s, *obs_s;   // the call's lists with every id checked against [0, n) (lt_items.cuh checked_node) [n_probe] / [n_obs]
     size_t bytes;
     int chunk;
 };
@@ -1971,6 +1972,8 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int n_o
         offb += lt_align_up(bytes ? bytes : 1, 256);
         return q;
     };
+    w.probes_s = (int32_t *)take((size_t)(n_probe > 0 ? n_probe : 1) * sizeof(int32_t));
+    w.obs_s = (int32_t *)take((size_t)(n_obs > 0 ? n_obs : 1) * sizeof(int32_t));
     if (mode == LT_MODE_FULL || mode == LT_MODE_SPARSE) {
         w.Sp = (float *)take(chunk * Hp * sizeof(float));
         w.slabs = (float *)take(lt_gemm_splitk_slab_bytes((int)chunk, b->H, b->F, probe_kslice(b)));
@@ -2051,6 +2054,7 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
                                const int32_t *observe_nodes, int32_t n_obs, float delta,
                                int32_t mode, float *out, int64_t ldo, void *workspace,
                                size_t workspace_bytes, void *stream, float *vec) {
+    lt_prof_call prof_call_;
     LT_REQUIRE(b != nullptr, "lt_influence_rows: baseline is NULL");
     LT_REQUIRE(n_probe >= 0 && n_obs >= 0, "lt_influence_rows: negative count");
     LT_REQUIRE(mode >= LT_MODE_FULL && mode <= LT_MODE_DELTA, "lt_influence_rows: unknown mode %d", mode);
@@ -2059,6 +2063,7 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
     LT_REQUIRE(probe_nodes && observe_nodes && out, "lt_influence_rows: NULL pointer");
     LT_REQUIRE(ldo >= n_obs, "lt_influence_rows: ldo=%lld < n_obs=%d", (long long)ldo, n_obs);
     LT_REQUIRE(b->n > 0, "lt_influence_rows: empty graph");
+    { const int rc = lt_node_err_pending(); if (rc) return rc; }     // an earlier call's list held an id out of range
     const size_t need = lt_influence_workspace_bytes(b, n_probe, n_obs, mode);
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace % 256))
         return lt_set_error(LT_ERR_WORKSPACE, "lt_influence_rows: workspace needs %zu bytes, 256-byte aligned", need);
@@ -2106,6 +2111,20 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
     {
         const int chunk_nb = n_probe < w.chunk ? n_probe : w.chunk;
         while ((long)n_obs * psplit < 2048 && psplit * 32 * LT_SB_UNR < chunk_nb) psplit *= 2;
+    }
+    // Node ids (lt_items.cuh checked_node): DELTA calls without pair marks check their lists in the first blocks that read them
+    // (the record blocks / k_item_bits -- both usually ride in the pre-activation's launch: no launch, no round trip added);
+    // every other call -- FULL / SPARSE start with a GEMM that gathers X[probes], pair marks with the observed rows -- by a
+    // launch of its own, ~2 us in front of steps of 0.15 ms and more.  Behind the check every kernel reads the checked lists.
+    int32_t *const node_err = lt_node_err_dev();
+    const bool inline_check = mode == LT_MODE_DELTA && !use_marks;
+    if (!inline_check) {
+        const long tot = (long)n_probe + n_obs;
+        hipLaunchKernelGGL(k_check_nodes, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, probe_nodes, n_probe, observe_nodes,
+                           n_obs, n, w.probes_s, w.obs_s, node_err);
+        LT_CHECK_LAUNCH();
+        probe_nodes = w.probes_s;
+        observe_nodes = w.obs_s;
     }
     if (use_marks) {
         LT_REQUIRE((long)n_obs * LT_ROW_SEG / 256 + 1 < 2147483647L, "lt_influence_rows: n_obs=%d exceeds the grid limit", n_obs);
@@ -2247,6 +2266,7 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
                         lt_bits_job cj = {};
                         cj.probes = probes; cj.nb = nb; cj.nblocks = nb; cj.dl_rec = w.dl_rec; cj.dl_meta = g->dl_meta; cj.dl_src = g->dl_rec;
                         cj.dl_maxc = dg.maxc; cj.dl_rec_words = dg.rec_words; cj.observe = observe_nodes; cj.n_obs = n_obs;
+                        cj.n = n; cj.err = node_err;
                         cj.smem_bytes = (unsigned)dg.record_smem;
                         bool rode = false;
                         if (p0 == 0) {
@@ -2283,9 +2303,13 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
                 }
             }
             bool bits_done = false;
-            const lt_bits_job job = {g->tptr, g->trow, probes, nb, words, w.bits, w.off, w.item_pr, w.big_bits, w.big_slot,
-                                     w.big_slot ? w.big_slot + w.chunk : (int32_t *)nullptr, g->rowptr, observe_nodes, n_obs, w.hub_obs,
-                                     nb + (long_blocks > 0 ? 1 : 0), g->tval, w.item_va};
+            lt_bits_job job = {g->tptr, g->trow, probes, nb, words, w.bits, w.off, w.item_pr, w.big_bits, w.big_slot,
+                               w.big_slot ? w.big_slot + w.chunk : (int32_t *)nullptr, g->rowptr, observe_nodes, n_obs,
+                               long_blocks > 0 ? w.hub_obs : (int32_t *)nullptr, nb + (long_blocks > 0 ? 1 : 0), g->tval, w.item_va};
+            if (inline_check) {      // these blocks are the first to read the lists: they check them, the kernels behind read the copies
+                job.n = n; job.err = node_err; job.probes_s = w.probes_s + p0; job.obs_s = w.obs_s;
+                job.nblocks = nb + 1;
+            }
             if (mode == LT_MODE_DELTA && b->Z1d && !lt_fp64_agg_active(b) && !use_marks) {
                 const int rc = lt_fp64_prepare_rows(b, w.off, nb, w.item_pr, n_probe, st, &job, &bits_done);
                 if (rc) return rc;
@@ -2294,8 +2318,13 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
             if (!bits_done) {
                 hipLaunchKernelGGL(k_item_bits, dim3((unsigned)job.nblocks), dim3(256), 0, st, g->tptr, g->trow, probes, nb, words,
                                    w.bits, w.off, w.item_pr, w.big_bits, w.big_slot, job.big_count,
-                                   g->rowptr, observe_nodes, n_obs, w.hub_obs, g->tval, w.item_va);
+                                   g->rowptr, observe_nodes, n_obs, job.hub_obs, g->tval, w.item_va, job.n, job.err, job.probes_s,
+                                   job.obs_s);
                 LT_CHECK_LAUNCH();
+            }
+            if (inline_check) {      // from here on: the checked lists
+                probes = w.probes_s + p0;
+                observe_nodes = w.obs_s;
             }
             if (use_marks) {
                 LT_HIP(hipMemsetAsync(w.pm_marks, 0, (size_t)((pairs + 31) / 32) * sizeof(unsigned), st));

@@ -190,6 +190,9 @@ static inline size_t lt_align_up(size_t x, size_t a) { return (x + a - 1) / a * 
 // ---- optional per-kernel event timing (lt_core.hip) ------------------------------------------
 extern unsigned g_lt_profile_mask;
 bool lt_profile_sample(int kernel_id);      // "profile_every" = N: true for every N-th scope of a class (1: all of them)
+void lt_profile_call_begin();                // entry / exit of a probe-primitive call: "profile_every" samples whole calls
+void lt_profile_call_end();
+struct lt_prof_call { lt_prof_call() { lt_profile_call_begin(); } ~lt_prof_call() { lt_profile_call_end(); } };
 void lt_profile_begin(int kernel_id, hipStream_t st);
 void lt_profile_end(int kernel_id, hipStream_t st);
 struct lt_prof_scope {
@@ -198,6 +201,11 @@ struct lt_prof_scope {
         : id(id_), st(st_), on(wanted && ((g_lt_profile_mask >> id_) & 1u) && lt_profile_sample(id_)) { if (on) lt_profile_begin(id, st); }
     ~lt_prof_scope() { if (on) lt_profile_end(id, st); }
 };
+
+// node ids out of range (lt_core.hip): the device-side alias of the two mapped flag words (NULL: unavailable -- ids are still
+// clamped), and the entry check of the probe primitives (LT_ERR_INDEX when an earlier call raised a flag)
+int32_t *lt_node_err_dev();
+int lt_node_err_pending();
 
 int lt_baseline_refresh_fp64(lt_baseline *b, hipStream_t st);
 // what a call needs of the baseline, recomputed here if lt_baseline_refresh marked it stale: need_fp32 = S1 and the
@@ -255,6 +263,11 @@ struct lt_bits_job {
     const int4 *dl_meta;
     const int32_t *dl_src;
     int dl_maxc, dl_rec_words;
+    // node-id check (lt_items.cuh): ids outside [0, n) are replaced by 0 and flagged in err[0] (probes) / err[1] (observed); the
+    // item-table form also writes the checked lists to probes_s [nb] / obs_s [n_obs] for the kernels behind it (NULL: lists
+    // already checked).  n == 0: no check (the 3-layer path checks up front)
+    int n;
+    int32_t *err, *probes_s, *obs_s;
     unsigned smem_bytes;    // dynamic LDS the job's blocks need (the launch that carries them must be given it)
 };
 // job != NULL: *job_done says whether the job went along (it does when every row is formed by one plain launch; the on-demand

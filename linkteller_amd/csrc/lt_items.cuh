@@ -25,6 +25,25 @@ __device__ __forceinline__ int find_row(const int32_t *__restrict__ rows, int cn
 }
 
 
+// ---- node ids out of range (include/linkteller_hip.h, lt_node_check) ----------------------------------------------------
+// The lists are device memory the host side of the ABI cannot read; the reference raises IndexError (attacker.py:103, 226-229).
+// The first kernel of a call that reads a list checks it: an id outside [0, n) becomes node 0 (no out-of-bounds access behind
+// it) and raises err[which] in mapped host memory (a plain store: the flag only ever goes 0 -> 1 between two host reads).
+__device__ __forceinline__ int checked_node(int v, int n, int32_t *__restrict__ err, int which) {
+    if ((unsigned)v < (unsigned)n) return v;
+    if (err) err[which] = 1;
+    return 0;
+}
+// calls whose first reader is not one of the two blocks below (FULL / SPARSE: the perturbed-row GEMM gathers X[probes]; pair
+// marks; the 3-layer path): both lists checked into the call's workspace by a launch of its own
+static __global__ __launch_bounds__(256) void k_check_nodes(const int32_t *__restrict__ probes, int np, const int32_t *__restrict__ obs,
+                                                            int no, int n, int32_t *__restrict__ probes_s, int32_t *__restrict__ obs_s,
+                                                            int32_t *__restrict__ err) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < np) probes_s[i] = checked_node(probes[i], n, err, 0);
+    else if (i - np < no) obs_s[i - np] = checked_node(obs[i - np], n, err, 1);
+}
+
 // bits[b][r >> 5] = { mask, base }: bit (r & 31) of mask = 1  <=>  r in R_v of probe b, and base = the position in
 // R_v (the ascending CSC list of column v) of the lowest member of this word, so that ONE 8-byte load tells stage B
 // both whether an entry of an observed row is affected by the probe and which item replaces it:
@@ -42,19 +61,24 @@ static __device__ __forceinline__ void item_bits_block(const int bid, const int3
                                                        int32_t *__restrict__ big_slot, int32_t *__restrict__ big_count,
                                                        const int32_t *__restrict__ rowptr, const int32_t *__restrict__ observe, int n_obs,
                                                        int32_t *__restrict__ hub_obs, const float *__restrict__ tval = nullptr,
-                                                       int2 *__restrict__ item_va = nullptr) {
-    // One block more than probes (hub_obs != NULL): it lists the observed nodes that are hub rows, hub_obs[0] = how many,
-    // hub_obs[1 ...] = their positions j in `observe` (any order) -- stage B launches its hub blocks for those alone.
+                                                       int2 *__restrict__ item_va = nullptr, int n_check = 0,
+                                                       int32_t *__restrict__ err = nullptr, int32_t *__restrict__ probes_s = nullptr,
+                                                       int32_t *__restrict__ obs_s = nullptr) {
+    // One block more than probes (hub_obs != NULL or obs_s != NULL): it lists the observed nodes that are hub rows, hub_obs[0] =
+    // how many, hub_obs[1 ...] = their positions j in `observe` (any order) -- stage B launches its hub blocks for those alone --
+    // and writes the checked observed list (obs_s) for the kernels behind this one.
     if (bid == nb) {
         __shared__ int32_t s_n;
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
         for (int j = threadIdx.x; j < n_obs; j += blockDim.x) {
-            const int u = observe[j];
-            if (rowptr[u + 1] - rowptr[u] > LT_ROW_SEG) hub_obs[1 + atomicAdd(&s_n, 1)] = j;
+            int u = observe[j];
+            if (n_check > 0) u = checked_node(u, n_check, err, 1);
+            if (obs_s) obs_s[j] = u;
+            if (hub_obs && rowptr[u + 1] - rowptr[u] > LT_ROW_SEG) hub_obs[1 + atomicAdd(&s_n, 1)] = j;
         }
         __syncthreads();
-        if (threadIdx.x == 0) hub_obs[0] = s_n;
+        if (threadIdx.x == 0 && hub_obs) hub_obs[0] = s_n;
         return;
     }
     // One block per probe.  It also forms the probe's item offset off[b] = sum of |R_v| over the probes before it
@@ -63,11 +87,14 @@ static __device__ __forceinline__ void item_bits_block(const int bid, const int3
     __shared__ int32_t red[4];
     __shared__ int32_t s_slot;
     const int b = bid;
-    const int v = probes[b];
+    int v = probes[b];
+    if (n_check > 0) v = checked_node(v, n_check, err, 0);
+    if (probes_s && threadIdx.x == 0) probes_s[b] = v;
     const int t0 = tptr[v], t1 = tptr[v + 1];
     int part = 0;
     for (int i = threadIdx.x; i < b; i += blockDim.x) {
-        const int vi = probes[i];
+        int vi = probes[i];
+        if (n_check > 0) vi = checked_node(vi, n_check, nullptr, 0);
         part += tptr[vi + 1] - tptr[vi];
     }
 #pragma unroll
@@ -113,9 +140,11 @@ static __global__ __launch_bounds__(256) void k_item_bits(const int32_t *__restr
                                                    const int32_t *__restrict__ rowptr = nullptr,
                                                    const int32_t *__restrict__ observe = nullptr, int n_obs = 0,
                                                    int32_t *__restrict__ hub_obs = nullptr, const float *__restrict__ tval = nullptr,
-                                                   int2 *__restrict__ item_va = nullptr) {
+                                                   int2 *__restrict__ item_va = nullptr, int n_check = 0,
+                                                   int32_t *__restrict__ err = nullptr, int32_t *__restrict__ probes_s = nullptr,
+                                                   int32_t *__restrict__ obs_s = nullptr) {
     item_bits_block((int)blockIdx.x, tptr, trow, probes, nb, words, bits, off, item_pr, big_bits, big_slot, big_count, rowptr, observe,
-                    n_obs, hub_obs, tval, item_va);
+                    n_obs, hub_obs, tval, item_va, n_check, err, probes_s, obs_s);
 }
 // ---- the fused DELTA route, first half: a probe's INCIDENCE RECORD (round 4) -----------------------------------------------
 // Everything about a probe v that depends on the graph alone is a property of NODE v, built once by lt_graph_create
@@ -138,7 +167,9 @@ static __device__ __forceinline__ void delta_record_block(const int b, const lt_
     int2 *sL = reinterpret_cast<int2 *>(smem);                  // [lcap] the probe's touched nodes (u, start | count << 16), u ascending
     __shared__ int32_t s_ntp, s_nlp;
     const int tid = threadIdx.x;
-    const int v = J.probes[b];
+    // (the finish kernel reads the probe's node from this block's table row and never the observed list: checking here covers
+    // the whole route)
+    const int v = J.n > 0 ? checked_node(J.probes[b], J.n, J.err, 0) : J.probes[b];
     const int4 m = J.dl_meta[v];
     const int cnt = m.y, Tu = m.z;
     const int2 *__restrict__ src = reinterpret_cast<const int2 *>(J.dl_src + m.x);
@@ -158,6 +189,7 @@ static __device__ __forceinline__ void delta_record_block(const int b, const lt_
         for (int h = 0; h < JP; ++h) {
             const int j = j0 + tid + h * 256;
             u[h] = j < J.n_obs ? J.observe[j] : -1;
+            if (b == 0 && j < J.n_obs && J.n > 0) (void)checked_node(u[h], J.n, J.err, 1);   // (an id out of range is found nowhere)
             pos[h] = 0;
         }
         for (int nrem = Tu; nrem > 1;) {                         // branch-free lower bound
@@ -193,7 +225,7 @@ static __device__ __forceinline__ void item_bits_block(const int bid, const lt_b
         return;
     }
     item_bits_block(bid, j.tptr, j.trow, j.probes, j.nb, j.words, j.bits, j.off, j.item_pr, j.big_bits, j.big_slot, j.big_count, j.rowptr,
-                    j.observe, j.n_obs, j.hub_obs, j.tval, j.item_va);
+                    j.observe, j.n_obs, j.hub_obs, j.tval, j.item_va, j.n, j.err, j.probes_s, j.obs_s);
 }
 // position of column c in R_v from the probe's bitmap row, or -1
 __device__ __forceinline__ int bits_pos(const uint2 *__restrict__ mb, int c) {

@@ -446,9 +446,35 @@ class Baseline3:
         return out
 
 
+def export_rows_f64(rows: torch.Tensor):
+    """The finished rows as a float64 numpy array on the host (the reference's ``influence_val = np.zeros(...)`` filled by
+    n_test**2 ``.item()`` round trips, attacker.py:216-229) -- ONE launch that widens on the device and writes straight into
+    pinned host memory over PCIe (lt_export_rows_f64), one wait.  The array owns a block of torch's pinned-memory cache
+    (recycled when the array is released: a fresh result per call costs no allocation).  Ends with the device-side node-id
+    check of everything the stream has run (IndexError, as the reference raises)."""
+    if rows.dim() != 2 or rows.dtype != torch.float32 or not rows.is_cuda:
+        raise TypeError("rows must be a 2-d float32 CUDA tensor")
+    r, c = rows.shape
+    host = torch.empty((r, c), dtype=torch.float64, pin_memory=True)
+    if rows.stride(1) != 1:
+        rows = rows.contiguous()
+    stream = torch.cuda.current_stream(rows.device)
+    _lib.check(_lib.lib().lt_export_rows_f64(rows.data_ptr(), rows.stride(0) if r > 1 else max(c, 1), r, c, host.data_ptr(), max(c, 1),
+                                             C.c_void_p(stream.cuda_stream)), "lt_export_rows_f64")
+    stream.synchronize()
+    node_check()
+    return host.numpy()
+
+
+def node_check():
+    """Raise IndexError when a probe / observed list of a COMPLETED call held a node id outside [0, n) (lt_node_check: the
+    lists are device memory, so the kernels check them; call after synchronising)."""
+    _lib.check(_lib.lib().lt_node_check(None, None), "lt_node_check")
+
+
 def _as_nodes(nodes, n, device, name) -> torch.Tensor:
     if isinstance(nodes, torch.Tensor) and nodes.is_cuda and nodes.dtype == torch.int32:
-        return nodes.contiguous()          # trusted fast path (already validated by the caller)
+        return nodes.contiguous()          # fast path: the ids are checked on the device (lt_node_check / LT_ERR_INDEX)
     t = torch.as_tensor(nodes).to(torch.int64).reshape(-1).cpu()
     if t.numel() and (int(t.min()) < 0 or int(t.max()) >= n):
         raise IndexError(f"{name} out of range [0, {n})")

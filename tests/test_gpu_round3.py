@@ -514,7 +514,8 @@ def test_full_mode_on_a_hub_of_many_segments(gpu, long_par, p):
     assert np.isfinite(f).all() and f.max() > 0 and (f[:, 0] > 0).sum() > 50      # the hub sees every probe (some of the fp32 differences round to 0)
     adj_o = O.to_torch_sparse(a_hat)
     ours, theirs = [], []
-    for i in (0, 31, 69, 85):
+    checked = (0, 7, 15, 23, 31, 39, 47, 55, 63, 69, 77, 85)
+    for i in checked:
         ref = {}
         for dt in (torch.float32, torch.float64):
             P = {k: torch.from_numpy(w[k]).to(dt) for k in ("W1", "b1", "W2", "b2")}
@@ -528,9 +529,16 @@ def test_full_mode_on_a_hub_of_many_segments(gpu, long_par, p):
     # such steps on either side (round 3 compared row by row at 4x and passed by the luck of the draw: with the bits of the
     # round-4 GEMM row 31 read 0.0345 against a reference error of 0.0032 on that row and 0.01 .. 0.03 on its neighbours) --
     # so: the worst of the checked rows against the reference's worst of the same rows, 4x
-    e32 = max(max(theirs), 1e-9)
-    print(f"hub rows: |full - ref64| per checked row {np.round(ours, 5)}, reference fp32 {np.round(theirs, 5)}")
-    assert max(ours) <= 4.0 * e32, (ours, theirs)
+    # (round 5, ADVICE r4: a row-by-row bound again, so that one bad row cannot hide behind its neighbours -- against the row's own
+    # reference error or the reference's rms error over the twelve checked rows, whichever is larger: the noise floor of the case --
+    # and the rms of our errors against the rms of the reference's, 2x: two draws from one noise class)
+    ours, theirs = np.asarray(ours), np.asarray(theirs)
+    rms_o, rms_t = float(np.sqrt((ours ** 2).mean())), float(np.sqrt((theirs ** 2).mean()))
+    print(f"hub rows: |full - ref64| per checked row {np.round(ours, 5)}, reference fp32 {np.round(theirs, 5)}, rms {rms_o:.5f} / {rms_t:.5f}")
+    assert ours.max() <= 4.0 * max(theirs.max(), 1e-9), (ours, theirs)
+    for i, o, t in zip(checked, ours, theirs):
+        assert o <= 4.0 * max(t, rms_t), (i, o, t, rms_t)
+    assert rms_o <= 2.0 * rms_t, (rms_o, rms_t)
 
 
 @pytest.mark.gpu
