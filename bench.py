@@ -66,7 +66,6 @@ def source_signature():
     import hashlib
     h = hashlib.sha256()
     for fn in sorted(glob.glob(os.path.join(REPO, "linkteller_amd", "csrc", "*.hip")) +
-                     glob.glob(os.path.join(REPO, "linkteller_amd", "csrc", "*.cuh")) +
                      glob.glob(os.path.join(REPO, "linkteller_amd", "csrc", "*.h"))):
         h.update(open(fn, "rb").read())
     return h.hexdigest()[:16]

@@ -142,7 +142,7 @@ static __global__ void k_interleave_cv(const int32_t *__restrict__ col, const fl
     if (i < total) cv[i] = make_int2(col[i], __float_as_int(val[i]));
 }
 
-// The fused DELTA route's per-node incidence records (lt_items.cuh "INCIDENCE RECORD"; lt_influence.hip k_delta_probe_finish):
+// The fused DELTA route's per-node incidence records (lt_items.hip.h "INCIDENCE RECORD"; lt_influence.hip k_delta_probe_finish):
 // for node v, its items (the CSC column of v) and the entries (u, position in row u) that hold an item, grouped by u ascending,
 // a node's entries in entry order.  Sum over the nodes of |R_v| * column lengths entries -- 1.6 M at twitch size, 25 MB; built on
 // the host from the CSC arrays lt_graph_create has in hand.  Only for graphs whose largest record stays small (no hub rows).

@@ -4,7 +4,7 @@
 //   attacker.py:106.
 #include <new>
 
-#include "lt_rows.cuh"
+#include "lt_rows.hip.h"
 
 #define LT_BLOCK 256
 

@@ -12,8 +12,8 @@
 #include <new>
 #include <type_traits>
 
-#include "lt_rows.cuh"
-#include "lt_items.cuh"
+#include "lt_rows.hip.h"
+#include "lt_items.hip.h"
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u_ __attribute__((ext_vector_type(4), aligned(4)));

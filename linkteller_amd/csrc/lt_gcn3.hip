@@ -18,7 +18,7 @@
 // and rows it can reach carry only the perturbation and fp32 rounding -- the reference's noise class.
 #include <new>
 
-#include "lt_items.cuh"
+#include "lt_items.hip.h"
 
 #define LT_BLOCK 256
 #define LT3_GRID 2048
@@ -513,7 +513,7 @@ struct infl3_ws {
     uint2 *bits1;
     uint32_t *bits2;
     int2 *items2;
-    int32_t *probes_s, *obs_s;    // the call's lists, every id checked against [0, n) (lt_items.cuh k_check_nodes)
+    int32_t *probes_s, *obs_s;    // the call's lists, every id checked against [0, n) (lt_items.hip.h k_check_nodes)
     size_t bytes;
     int chunk;
 };

@@ -21,9 +21,9 @@
 
 #include <type_traits>
 
-#include "lt_rows.cuh"
-#include "lt_lanes.cuh"
-#include "lt_items.cuh"
+#include "lt_rows.hip.h"
+#include "lt_lanes.hip.h"
+#include "lt_items.hip.h"
 
 #define LT_BLOCK 256
 #define LT_CHUNK_BUDGET ((size_t)1 << 30)  // bytes of per-probe scratch per chunk
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_full_stageA(
 //  * substituting the probe's own row is rare: the hot loop only asks "does this column equal one of my
 //    P probes" (one vector compare per entry, probe ids sit one per lane, the answer is a wave mask in
 //    SGPRs); the probes that were hit are recomputed after the epilogue, one single-probe chain each;
-//  * the P*C (probe, class) partial sums are reduced together (lt_lanes.cuh): the xor 32,16,8,4,2,1
+//  * the P*C (probe, class) partial sums are reduced together (lt_lanes.hip.h): the xor 32,16,8,4,2,1
 //    butterfly of group_sum<64> with the live registers halving at every stage -- same pairings,
 //    fp add commutes, so the bits equal the baseline kernel's -- and leave in one coalesced store.
 // ------------------------------------------------------------------------------------------------
@@ -139,7 +139,7 @@ __device__ __forceinline__ void stageA_epilogue(f32x4 (&acc)[P], int lane, bool 
             }
         }
     }
-    // 64-lane totals of all P*CP values (lt_lanes.cuh): in batches of up to 64 values, lane l ends with
+    // 64-lane totals of all P*CP values (lt_lanes.hip.h): in batches of up to 64 values, lane l ends with
     // the total of value q = batch * VB + (l >> log2(64 / VB)) = (probe q / CP, class q % CP), so one
     // batch leaves in one coalesced store of S2p[row][pb + p][c]
     constexpr int V = P * CP, VB = V < 64 ? V : 64;
@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_hubs(
 // Here the touched pairs are ENUMERATED from the probe's side instead, ~ 360 incidences per probe instead of 9 500 tests, and
 // everything about them that does not depend on the layers is ready when this kernel starts: a node's incidence record --
 // its items and, per touched node, the member entries in entry order -- is built with the graph (lt_core.hip
-// build_delta_records), and delta_record_block (lt_items.cuh), riding in the launch that forms the pre-activation, has
+// build_delta_records), and delta_record_block (lt_items.hip.h), riding in the launch that forms the pre-activation, has
 // matched it against the observed list: the table row of probe b names the observed POSITIONS the probe touches and where
 // their entries are.  This kernel, one block per probe, is then two dependent round trips: the table row (items, touched
 // positions), then the items' pre-activation rows with the positions' entries; stage A over the items (k_item_stageA_d2's
@@ -1940,12 +1940,12 @@ struct infl_ws {
     int32_t *off;          // SPARSE / DELTA: item offsets [chunk + 1]
     int2 *item_pr;         // SPARSE / DELTA: (probe index, row) of every item
     int2 *item_va;         // DELTA: (probe node, A_hat[row, probe node] as bits) of every item
-    int32_t *pm_cnt, *pm_start, *pm_rank, *pm_list;   // SPARSE / DELTA pair marks: per-node lists of observed nodes (lt_items.cuh)
+    int32_t *pm_cnt, *pm_start, *pm_rank, *pm_list;   // SPARSE / DELTA pair marks: per-node lists of observed nodes (lt_items.hip.h)
     unsigned *pm_marks;    // SPARSE / DELTA: one bit per (probe of the chunk, observed node)
     uint2 *big_bits;       // SPARSE / DELTA without `bits`: bitmap rows of the chunk's big probes [LT_BIG_SLOTS][ceil(n / 32)]
     int32_t *big_slot;     // [chunk + 1] slot of each probe (-1: none) + the slot counter
     uint2 *bits;           // SPARSE / DELTA: membership bitmap + positions of R_v per probe [chunk][ceil(n / 32)], or NULL (huge graphs)
-    int32_t *probes_s, *obs_s;   // the call's lists with every id checked against [0, n) (lt_items.cuh checked_node) [n_probe] / [n_obs]
+    int32_t *probes_s, *obs_s;   // the call's lists with every id checked against [0, n) (lt_items.hip.h checked_node) [n_probe] / [n_obs]
     size_t bytes;
     int chunk;
 };
@@ -2037,7 +2037,7 @@ extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_node
 }
 
 // The same call with the pairs' difference VECTORS next to the norms: vec[(i * ldo + j) * C + c], unscaled (see
-// store_diff_vec in lt_items.cuh).  For models wider than one pass of these kernels the caller runs one such call per slice
+// store_diff_vec in lt_items.hip.h).  For models wider than one pass of these kernels the caller runs one such call per slice
 // of the hidden layer (W1[:, s], b1[s], W2[s, t]) and per slice of <= 8 classes and joins them with lt_wide_combine.
 // LT_MODE_SPARSE and LT_MODE_DELTA only (FULL names the same quantity as SPARSE, bit for bit).
 extern "C" int lt_influence_rows_vec(const lt_baseline *b, const int32_t *probe_nodes, int32_t n_probe,
@@ -2087,7 +2087,7 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
         if (rc) return rc;
     }
 
-    // SPARSE / DELTA, large calls: the per-node lists of observed nodes, once per call (lt_items.cuh "pair marks")
+    // SPARSE / DELTA, large calls: the per-node lists of observed nodes, once per call (lt_items.hip.h "pair marks")
     // (with a membership bitmap the per-pair scan is one load per entry and the join pays from ~ 4 M pairs on -- measured
     // at twitch-RU size, tools/marks_ab.py; without one -- large graphs -- it always does)
     // DELTA at twitch size, graphs without hub rows: stage A + stage B of a probe in one block (k_delta_probe_block), no item
@@ -2112,7 +2112,7 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
         const int chunk_nb = n_probe < w.chunk ? n_probe : w.chunk;
         while ((long)n_obs * psplit < 2048 && psplit * 32 * LT_SB_UNR < chunk_nb) psplit *= 2;
     }
-    // Node ids (lt_items.cuh checked_node): DELTA calls without pair marks check their lists in the first blocks that read them
+    // Node ids (lt_items.hip.h checked_node): DELTA calls without pair marks check their lists in the first blocks that read them
     // (the record blocks / k_item_bits -- both usually ride in the pre-activation's launch: no launch, no round trip added);
     // every other call -- FULL / SPARSE start with a GEMM that gathers X[probes], pair marks with the observed rows -- by a
     // launch of its own, ~2 us in front of steps of 0.15 ms and more.  Behind the check every kernel reads the checked lists.

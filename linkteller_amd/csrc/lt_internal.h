@@ -28,13 +28,13 @@ struct lt_graph {
     int2 *cv = nullptr;        // [nnz + pad] (col, val bits) interleaved, graphs that take the tiled SpMM (lt_tiled_wanted at 256 columns): one
                                // request per entry for k_rows_tiled instead of two
     int32_t *tpos = nullptr;   // [nnz] position of the CSC entry inside its ROW (k - rowptr[r]); graphs of up to 65534 nodes only
-    // the fused DELTA route's per-node incidence records (lt_items.cuh; graphs of up to 65534 nodes without hub rows whose
+    // the fused DELTA route's per-node incidence records (lt_items.hip.h; graphs of up to 65534 nodes without hub rows whose
     // largest record fits LDS), or NULL
     int4 *dl_meta = nullptr;      // [n] (offset into dl_rec in words, items, touched nodes, incidences)
     int32_t *dl_rec = nullptr;
     int32_t dl_max_t = 0, dl_max_tu = 0;   // largest incidence / touched-node count of a node
     // Long rows (hubs).  A row of more than LT_ROW_SEG entries is summed segment by segment in EVERY kernel
-    // (lt_rows.cuh row_dot: 128-entry fmaf chains, their sums added in segment order), which lets any kernel hand
+    // (lt_rows.hip.h row_dot: 128-entry fmaf chains, their sums added in segment order), which lets any kernel hand
     // the segments of a hub row to separate waves and still produce the same bits: the SpMM / layer-1 segment
     // kernels, FULL stage A (k_full_stageA_lds segment mode + k_full_long_combine).
     int32_t p_n_long = 0, p_n_seg = 0;
@@ -241,7 +241,7 @@ int lt_launch_gemm_f64_dense(const double *A, long lda, int M, const float *B, l
 int lt_launch_gemm_f64_gather(const float *A, long lda, const int32_t *rows, int M, const float *B, long ldb, int N, int K,
                               double *C, long ldc, hipStream_t st);
 int lt_launch_spmm_f64(const lt_graph *g, const double *S, int ld, const float *biasp, double *out, double *seg_d, hipStream_t st);
-// The arguments of k_item_bits (lt_items.cuh) as a value: lt_fp64_prepare_rows can let the item tables of a probe chunk ride
+// The arguments of k_item_bits (lt_items.hip.h) as a value: lt_fp64_prepare_rows can let the item tables of a probe chunk ride
 // in the launch that forms the pre-activation (extra blocks of k_spmm_f64) instead of a launch of their own in front of it.
 struct lt_bits_job {
     const int32_t *tptr, *trow, *probes;
@@ -257,13 +257,13 @@ struct lt_bits_job {
     int nblocks;      // nb, + 1 when hub_obs is wanted; 0 = no job
     const float *tval;      // with item_va: (probe node, A_hat[r, v]) of every item next to (probe index, row)
     int2 *item_va;
-    // dl_rec != NULL: the job gathers the incidence records of the chunk's probes instead (the fused DELTA route, lt_items.cuh
+    // dl_rec != NULL: the job gathers the incidence records of the chunk's probes instead (the fused DELTA route, lt_items.hip.h
     // delta_record_block: one block per probe); uses probes / nb
     int32_t *dl_rec;
     const int4 *dl_meta;
     const int32_t *dl_src;
     int dl_maxc, dl_rec_words;
-    // node-id check (lt_items.cuh): ids outside [0, n) are replaced by 0 and flagged in err[0] (probes) / err[1] (observed); the
+    // node-id check (lt_items.hip.h): ids outside [0, n) are replaced by 0 and flagged in err[0] (probes) / err[1] (observed); the
     // item-table form also writes the checked lists to probes_s [nb] / obs_s [n_obs] for the kernels behind it (NULL: lists
     // already checked).  n == 0: no check (the 3-layer path checks up front)
     int n;

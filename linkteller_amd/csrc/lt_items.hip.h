@@ -1,7 +1,7 @@
 // Item-list helpers shared by the SPARSE / DELTA probe kernels (lt_influence.hip) and the 3-layer path (lt_gcn3.hip):
 // per-probe offsets into item lists, the membership bitmap with positions, the finite-difference tail.
 #pragma once
-#include "lt_rows.cuh"
+#include "lt_rows.hip.h"
 
 __device__ __forceinline__ int find_probe(const int32_t *__restrict__ off, int nb, int item) {
     int lo = 0, hi = nb;  // off[lo] <= item < off[hi]

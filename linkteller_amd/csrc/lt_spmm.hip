@@ -1,7 +1,7 @@
 // SpMM  out = A_hat * S (+ bias)(ReLU)                       torch.spmm + bias, gcn/layers.py:32-36
 //
 // Two routes, same arithmetic (a row is a k-ordered fmaf chain per output column; a row of more than
-// LT_ROW_SEG entries is the ordered sum of its 128-entry segment chains -- lt_rows.cuh):
+// LT_ROW_SEG entries is the ordered sum of its 128-entry segment chains -- lt_rows.hip.h):
 //
 //  * small graphs (S fits the caches: twitch): k_spmm_rows, one lane group per row, the whole row of S per gather;
 //    launch-bound, nothing to tile.
@@ -21,7 +21,7 @@
 //    round by DPP row broadcasts; results leave with non-temporal stores.
 #include <type_traits>
 
-#include "lt_rows.cuh"
+#include "lt_rows.hip.h"
 
 #define LT_BLOCK 256
 #define LT_TILE_GL 16    // lanes per item: 16 lanes x float4 = 64 columns

@@ -296,6 +296,7 @@ def test_cli_two_ranks_write_one_result_file(gpu, tmp_path):
     assert np.array_equal(np.asarray(files[1]["result"]["pred"]), np.asarray(files[2]["result"]["pred"]))
 
 
+@pytest.mark.slow      # 150 s (host graph build + fp64 oracle rows): LT_RUN_SLOW=1 / tools/round_artifacts.sh; default set: test_rmat_shape_scaled_config5
 def test_rmat_scale21_config5_full_size(gpu):
     """BASELINE configs[4] at its full size on ONE GPU: R-MAT scale 21 (2 097 152 nodes, 40 M directed draws -> nnz(A_hat)
     ~ 78 M, hub rows of 10^5 entries), F = H = 256, C = 2.  Size-independent properties -- `sparse` == `full` bit for
@@ -529,7 +530,7 @@ def test_auc_ap_at_config1_size(gpu):
 @pytest.mark.parametrize("family", ["powerlaw", "er", "directed"])
 def test_pair_marks_route_keeps_every_bit(gpu, family):
     """Large SPARSE / DELTA calls find the affected (probe, observed) pairs through a join over the middle nodes
-    (`pair_marks`, lt_items.cuh) instead of a membership scan per pair.  Forced on (0) and off (-1) on small graphs
+    (`pair_marks`, lt_items.hip.h) instead of a membership scan per pair.  Forced on (0) and off (-1) on small graphs
     -- hub rows on both sides, a non-symmetric pattern, several probe chunks, with and without the membership
     bitmap, duplicated observed nodes -- the matrices must agree bit for bit, and `sparse` must still equal `full`."""
     import scipy.sparse as sp

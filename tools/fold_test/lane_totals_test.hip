@@ -1,11 +1,11 @@
-// Checks lt_lanes.cuh against group_sum<64> bit for bit on the GPU:  hipcc --offload-arch=gfx950 -ffp-contract=off
+// Checks lt_lanes.hip.h against group_sum<64> bit for bit on the GPU:  hipcc --offload-arch=gfx950 -ffp-contract=off
 //   -I include -I linkteller_amd/csrc tools/fold_test/lane_totals_test.hip -o /tmp/lane_totals_test && /tmp/lane_totals_test
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
 #include <vector>
-#include "lt_rows.cuh"
-#include "lt_lanes.cuh"
+#include "lt_rows.hip.h"
+#include "lt_lanes.hip.h"
 
 template <int V>
 __global__ void k_test(const float *in, float *ref, float *got, int *owner) {

@@ -243,6 +243,121 @@ __global__ __launch_bounds__(256) void k_gather_ceiling(
     if (active && j == 0) sink[(size_t)it * ns + slice] = x.x ^ x.y ^ x.z ^ x.w;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Round 5: EIGHT column slices of 128 B -- one per XCD, so that an XCD's 4 MiB L2 holds twice the rows
+// of S (32 768 slices instead of 16 384) -- gathered as 16 lanes x 8 B, so that an item costs the instruction count of the
+// 4-slice kernel (the round-4 attempt at narrower slices used 8 lanes x 16 B: twice the items per wave-instruction's bytes).
+// Same work items, order, prefetched (col, val) stream and fmaf chains as k_spmm_sliced<16, U, .., PF = true>.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int U>
+__global__ __launch_bounds__(256) void k_spmm_sliced8(
+    int n_items, const int32_t *__restrict__ w_e0, const int32_t *__restrict__ w_cnt,
+    const int32_t *__restrict__ w_dst, int n, const int32_t *__restrict__ col, const float *__restrict__ val,
+    const float *__restrict__ S, int lds, int ncols, float *__restrict__ out, int ldo,
+    float *__restrict__ partial, int ldp) {
+    constexpr int GL = 16, GPW = 4, IPB = 16;
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int j = lane & (GL - 1);
+    const int slice = blockIdx.x & 7;           // slice = XCD
+    const int chunk = blockIdx.x >> 3;
+    const int it = chunk * IPB + wv * GPW + lane / GL;
+    if (it >= n_items) return;
+    const int e0 = w_e0[it], cnt = w_cnt[it], dst = w_dst[it];
+    const int coff = slice * 2 * GL + 2 * j;
+    const bool active = coff < ncols;
+    const unsigned rowbytes = (unsigned)lds * 4u;
+    const unsigned loff = (unsigned)coff * 4u;
+    const char *Sb = reinterpret_cast<const char *>(S);
+    f32x2 acc = {0.f, 0.f};
+    const int e1 = e0 + cnt;
+    int nxc = 0;
+    float nxa = 0.f;
+    if (e0 + j < e1) { nxc = __builtin_nontemporal_load(col + e0 + j); nxa = __builtin_nontemporal_load(val + e0 + j); }
+    for (int eb = e0; eb < e1; eb += GL) {
+        const int me = eb + j;
+        const int myc = nxc;
+        const float mya = nxa;
+        nxc = 0; nxa = 0.f;
+        if (me + GL < e1) { nxc = __builtin_nontemporal_load(col + me + GL); nxa = __builtin_nontemporal_load(val + me + GL); }
+        const int left = e1 - eb;
+        static_for<GL / U>([&](auto kbt) {
+            constexpr int kb = decltype(kbt)::value * U;
+            if (kb < left) {
+                f32x2 s[U];
+                float a[U];
+                static_for<U>([&](auto ut) {
+                    constexpr int u = decltype(ut)::value;
+                    constexpr int k = kb + u;
+                    const int c = bcast_c<GL, k>(myc);
+                    a[u] = __builtin_bit_cast(float, bcast_c<GL, k>(__builtin_bit_cast(int, mya)));
+                    s[u] = f32x2{0.f, 0.f};
+                    if (k < left && active) s[u] = *reinterpret_cast<const f32x2 *>(Sb + (size_t)((unsigned)c * rowbytes + loff));
+                });
+                static_for<U>([&](auto ut) {
+                    constexpr int u = decltype(ut)::value;
+                    if (kb + u < left) { acc.x = fmaf(a[u], s[u].x, acc.x); acc.y = fmaf(a[u], s[u].y, acc.y); }
+                });
+            }
+        });
+    }
+    if (!active) return;
+    float *d = dst < n ? out + (size_t)dst * ldo + coff : partial + (size_t)(dst - n) * ldp + coff;
+    __builtin_nontemporal_store(acc, reinterpret_cast<f32x2 *>(d));
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void k_gather_ceiling8(
+    int n_items, const int32_t *__restrict__ w_e0, const int32_t *__restrict__ w_cnt, const int32_t *__restrict__ col,
+    const float *__restrict__ S, int lds, int ncols, unsigned *__restrict__ sink) {
+    constexpr int GL = 16, GPW = 4, IPB = 16;
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int j = lane & (GL - 1);
+    const int slice = blockIdx.x & 7;
+    const int chunk = blockIdx.x >> 3;
+    const int it = chunk * IPB + wv * GPW + lane / GL;
+    if (it >= n_items) return;
+    const int e0 = w_e0[it], cnt = w_cnt[it];
+    const int coff = slice * 2 * GL + 2 * j;
+    const bool active = coff < ncols;
+    const unsigned rowbytes = (unsigned)lds * 4u;
+    const unsigned loff = (unsigned)coff * 4u;
+    const char *Sb = reinterpret_cast<const char *>(S);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 x = {0u, 0u};
+    const int e1 = e0 + cnt;
+    int nxc = 0;
+    if (e0 + j < e1) nxc = __builtin_nontemporal_load(col + e0 + j);
+    for (int eb = e0; eb < e1; eb += GL) {
+        const int me = eb + j;
+        const int myc = nxc;
+        nxc = 0;
+        if (me + GL < e1) nxc = __builtin_nontemporal_load(col + me + GL);
+        const int left = e1 - eb;
+        static_for<GL / U>([&](auto kbt) {
+            constexpr int kb = decltype(kbt)::value * U;
+            if (kb < left) {
+                u32x2 s[U];
+                static_for<U>([&](auto ut) {
+                    constexpr int u = decltype(ut)::value;
+                    constexpr int k = kb + u;
+                    const int c = bcast_c<GL, k>(myc);
+                    s[u] = u32x2{0u, 0u};
+                    if (k < left && active) s[u] = *reinterpret_cast<const u32x2 *>(Sb + (size_t)((unsigned)c * rowbytes + loff));
+                });
+                static_for<U>([&](auto ut) {
+                    constexpr int u = decltype(ut)::value;
+                    x ^= s[u];
+                });
+            }
+        });
+    }
+    if (active && j == 0) sink[(size_t)it * 8 + slice] = x.x ^ x.y;
+}
+
 // long rows: partials added in segment order
 __global__ void k_combine(int n_long, const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_segptr,
                           const float *__restrict__ partial, int ldp, int ncols, float *__restrict__ out, int ldo) {
@@ -462,6 +577,27 @@ static void run_sliced(Ctx &c, hipStream_t st) {
     }
 }
 
+
+template <int U, int ORDER = 2>
+static void run_sliced8(Ctx &c, hipStream_t st) {
+    Work &W = ORDER == 2 ? c.work_half : (ORDER ? c.work_col : c.work);
+    if (c.H > 256) { fprintf(stderr, "sliced8: H <= 256\n"); exit(1); }
+    const int chunks = (W.n_items + 15) / 16;
+    hipLaunchKernelGGL((k_spmm_sliced8<U>), dim3(8 * chunks), dim3(256), 0, st, W.n_items, W.e0, W.cnt, W.dst, c.g->n, c.col, c.val,
+                       c.S, c.H, c.H, c.out, c.H, W.partial, c.H);
+    if (W.n_long > 0) {
+        const int tot = W.n_long * c.H;
+        hipLaunchKernelGGL(k_combine, dim3((tot + 255) / 256), dim3(256), 0, st, W.n_long, W.long_row, W.long_segptr, W.partial, c.H,
+                           c.H, c.out, c.H);
+    }
+}
+template <int U, int ORDER = 2>
+static void run_ceiling8(Ctx &c, hipStream_t st) {
+    Work &W = ORDER == 2 ? c.work_half : (ORDER ? c.work_col : c.work);
+    const int chunks = (W.n_items + 15) / 16;
+    hipLaunchKernelGGL((k_gather_ceiling8<U>), dim3(8 * chunks), dim3(256), 0, st, W.n_items, W.e0, W.cnt, c.col, c.S, c.H, c.H, c.sink);
+}
+
 static void run_lib(Ctx &c, hipStream_t st) {
     if (lt_spmm_csr_f32(c.lg, c.S, c.H, c.H, nullptr, 0, c.out, c.H, st) != LT_OK) {
         fprintf(stderr, "lt_spmm_csr_f32: %s\n", lt_last_error());
@@ -507,7 +643,7 @@ int main(int argc, char **argv) {
     CK(hipMalloc((void **)&c.sink, ((size_t)g.col.size() / 8 + (size_t)g.n + 1024) * 8 * sizeof(unsigned)));
     c.work_o3 = build_work(g, H, 128, 3);
     c.work_o4 = build_work(g, H, 128, 4);
-    c.work_half = build_work(g, H, 128, 2);   // the library's canonical order: 128-entry segments added in order (lt_rows.cuh row_dot)
+    c.work_half = build_work(g, H, 128, 2);   // the library's canonical order: 128-entry segments added in order (lt_rows.hip.h row_dot)
     {
         // hot sets by in-degree (= row length: the matrix is symmetric)
         std::vector<int> deg((size_t)g.n);
@@ -559,6 +695,11 @@ int main(int argc, char **argv) {
         {"g8_half_pf", run_sliced<8, 8, true, true, 0, false, 0, 2, true>},
         {"g8_col_pf", run_sliced<8, 8, true, true, 0, false, 0, 1, true>},
         {"g32_half_pf", run_sliced<32, 8, true, true, 0, false, 0, 2, true>},
+        {"w8_half_u8", run_sliced8<8, 2>},
+        {"w8_half_u16", run_sliced8<16, 2>},
+        {"w8_col_u8", run_sliced8<8, 1>},
+        {"ceilw8_u8", run_ceiling8<8>},
+        {"ceilw8_u16", run_ceiling8<16>},
         {"ceil16_u8", run_ceiling<16, 8>},
         {"ceil16_u16", run_ceiling<16, 16>},
         {"ceil8_u8", run_ceiling<8, 8>},
@@ -595,7 +736,7 @@ int main(int argc, char **argv) {
         CK(hipGetLastError());
         // correctness: bit-equal to the library kernel
         const char *verdict = "ref";
-        if (!strncmp(v.name, "ceil", 4)) {
+        if (!strncmp(v.name, "ceil", 4)) {      // (also ceilw8_*)
             verdict = "(gathers only)";
         } else if (!have_ref) {
             CK(hipMemcpy(c.ref, c.out, (size_t)g.n * H * sizeof(float), hipMemcpyDeviceToDevice));
