@@ -169,24 +169,28 @@ def pmc_inrun(a):
     acc = {}
     t0 = time.time()
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(root, ctr)
-            cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+        # (third pass, round 5: the L2's own hit / miss counts -- what the SpMM's gather-ceiling argument rests on)
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum TCC_MISS_sum"):
+            out = os.path.join(root, ctr.replace(" ", "+"))
+            cmd = ["rocprofv3", "--pmc", *ctr.split(), "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
                    "--pmc-child", "--mode", a.mode, "--workload", a.workload, "--n-test", str(a.n_test), "--hidden", str(a.hidden),
                    "--classes", str(a.classes), "--spmm-scale", str(0 if a.no_extras else a.spmm_scale)] + (["--powerlaw"] if a.powerlaw else [])
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                timeout=420)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
+                if ctr.startswith("TCC_"):      # the hit / miss pass is an extra: the traffic figures stand without it
+                    continue
                 return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode})"
             for fn in files:
                 for row in csv.DictReader(open(fn)):
                     name = row["Kernel_Name"].replace("void ", "").strip()
-                    if row["Counter_Name"] != ctr:
+                    cn = row["Counter_Name"]
+                    if cn not in ctr.split():
                         continue
-                    d = acc.setdefault(name, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "n": {}})
-                    d[ctr] += float(row["Counter_Value"])
-                    d["n"][ctr] = d["n"].get(ctr, 0) + 1
+                    d = acc.setdefault(name, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "TCC_HIT_sum": 0.0, "TCC_MISS_sum": 0.0, "n": {}})
+                    d[cn] += float(row["Counter_Value"])
+                    d["n"][cn] = d["n"].get(cn, 0) + 1
     except Exception as e:      # noqa: BLE001 -- a profiler hiccup must not cost the benchmark line
         return None, f"in-run PMC passes failed: {type(e).__name__}: {e}"
     finally:
@@ -196,9 +200,12 @@ def pmc_inrun(a):
         cls = next((c for pre, c in KERNEL_CLASS if name.startswith(pre)), None)
         if cls is None:
             continue
-        k = classes.setdefault(cls, {"bytes": 0.0, "primary": 0, "kernels": {}})
+        k = classes.setdefault(cls, {"bytes": 0.0, "primary": 0, "kernels": {}, "hit": 0.0, "miss": 0.0, "fetch": 0.0})
         byts = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
         k["bytes"] += byts
+        k["hit"] += d["TCC_HIT_sum"]
+        k["miss"] += d["TCC_MISS_sum"]
+        k["fetch"] += 2.0 * d["FETCH_SIZE"] * 1024.0
         nd = max(d["n"].values()) if d["n"] else 0
         k["kernels"][name.split("(")[0][:60]] = {"dispatches": nd, "hbm_bytes_per_dispatch": int(byts / max(nd, 1))}
     for cls, k in classes.items():       # launches of the class = dispatches of its primary kernel
@@ -208,7 +215,9 @@ def pmc_inrun(a):
                 k["primary"] = n
                 break
         k["hbm_bytes_per_launch"] = int(k["bytes"] / k["primary"]) if k["primary"] else None
-    return classes, f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate child runs of this command, {time.time() - t0:.0f} s"
+        k["read_bytes_per_launch"] = int(k["fetch"] / k["primary"]) if k["primary"] else None
+        k["l2_hit_frac"] = round(k["hit"] / (k["hit"] + k["miss"]), 4) if (k["hit"] + k["miss"]) > 0 else None
+    return classes, f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum + TCC_MISS_sum, separate child runs of this command, {time.time() - t0:.0f} s"
 
 
 def kernel_ms(name):
@@ -343,6 +352,11 @@ def main():
         for _ in range(2):
             engine.spmm(gb, sb)
         if a.pmc_child:
+            if tiled_route(gb, hcols):      # the gather-ceiling kernel too: its L2 hit fraction next to the real kernel's
+                sink = torch.empty(int(_lib.lib().lt_spmm_gather_ceiling_bytes(gb.handle)), dtype=torch.uint8, device=dev)
+                for _ in range(2):
+                    _lib.check(_lib.lib().lt_spmm_gather_ceiling(gb.handle, sb.data_ptr(), hcols, hcols, 8, sink.data_ptr(), sink.numel(), None,
+                                                                 hcols, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "lt_spmm_gather_ceiling")
             torch.cuda.synchronize()
             return None
         _lib.lib().lt_profile_enable(1 << _lib.KERNEL_IDS["spmm"])
@@ -390,6 +404,9 @@ def main():
         shard = influence_shard(gb, big.shape[0], scale, hcols) if with_shard else None
         tr = traffic_of("spmm", f"spmm_rmat{scale}")
         tiled = tiled_route(gb, hcols)          # the route the call actually took
+        pm_s = (pmc or {}).get("spmm", {})
+        pm_c = (pmc or {}).get("gather_ceiling", {})
+        rd = pm_s.get("read_bytes_per_launch")
         return {"influence_shard": shard, "gather_ceiling": ceiling,
                 "kernel": ("k_rows_tiled (+ k_spmm_long_combine for the hub rows)" if tiled else "k_spmm_rows (+ k_spmm_segments / k_spmm_long_combine for the hub rows)"),
                 "bound": "hbm",
@@ -399,6 +416,12 @@ def main():
                 "achieved": round(byts / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(byts / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": tr,
                 "traffic_over_algorithmic": round(tr / byts, 2) if tr else None,
+                # counters instead of a host-side histogram (round 5): the L2's hit fraction over the launch, the bytes it asked the
+                # memory side for (TCC_EA0_RDREQ x 128 B = 2 x FETCH_SIZE: Infinity Cache AND HBM -- the L2's counters cannot tell the two
+                # apart, "DRAM" in their names is the memory controller's side of the fabric) and that read rate
+                "l2_hit_frac": pm_s.get("l2_hit_frac"), "l2_hit_frac_gather_ceiling_kernel": pm_c.get("l2_hit_frac"),
+                "dram_bytes": rd, "dram_bytes_note": "memory-side read bytes per launch (Infinity Cache + HBM, not separable from the L2)",
+                "dram_read_GBps": round(rd / sec / 1e9, 1) if rd else None,
                 "algorithmic_bytes_per_launch": int(byts), "avg_launch_us": round(sec * 1e6, 1),
                 "units_per_launch": f"one SpMM A_hat[{big.shape[0]}^2, nnz={big.nnz}] x S[{big.shape[0]}x{hcols}] fp32 "
                                     f"(R-MAT scale {scale}, max row {int(np.diff(big.indptr).max())})",

@@ -907,8 +907,19 @@ static __global__ void k_y_long(int n_long, const int32_t *__restrict__ long_row
     const int li = (int)(i / ld), c = (int)(i % ld);
     const int r = long_row[li];
     if (zstate[r] != 2) return;
-    double acc = part[(size_t)long_segptr[li] * ld + c];
-    for (int sg = long_segptr[li] + 1; sg < long_segptr[li + 1]; ++sg) acc += part[(size_t)sg * ld + c];
+    // (segment order, as everywhere; eight loads in flight -- one dependent load per segment made a 900-segment hub row the
+    // whole launch: 0.26 ms at BASELINE configs[4])
+    const int s0 = long_segptr[li], s1 = long_segptr[li + 1];
+    double acc = part[(size_t)s0 * ld + c];
+    int sg = s0 + 1;
+    for (; sg + 8 <= s1; sg += 8) {
+        double v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = part[(size_t)(sg + t) * ld + c];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc += v[t];
+    }
+    for (; sg < s1; ++sg) acc += part[(size_t)sg * ld + c];
     Y[(size_t)r * ld + c] = acc;
 }
 
@@ -1008,7 +1019,7 @@ int lt_fp64_prepare_items(const lt_baseline *b, const int32_t *off, int nb, cons
     LT_HIP(hipMemsetAsync(b->zcount, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(k_z_mark, dim3(1024), dim3(256), 0, st, off, nb, item_pr, b->zstate, b->zrows, b->zcount);
     LT_CHECK_LAUNCH();
-    int rc = lt_launch_rows_tiled_xf64(g, b->X, b->ldx, F, b->Yd, Fp, b->seg_y, Fp, b->zstate, st);
+    int rc = lt_launch_rows_tiled_xf64(g, b->X, b->ldx, F, b->Yd, Fp, b->seg_y, Fp, b->zstate, b->zitems, b->zicount, st);
     if (rc) return rc;
     if (g->p_n_long > 0) {
         const long tot = (long)g->p_n_long * Fp;
@@ -1331,7 +1342,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     float *fs1x = nullptr, *fz1x = nullptr;
     double *fs1q = nullptr;
     int *gate = nullptr;
-    int32_t *zst = nullptr, *zrw = nullptr, *zct = nullptr;
+    int32_t *zst = nullptr, *zrw = nullptr, *zct = nullptr, *zit = nullptr, *zic = nullptr;
     hipError_t e = hipMalloc((void **)&z1d, nh);
     if (e == hipSuccess) e = hipMemsetAsync(z1d, 0, nh, st);      // (pad columns stay zero on every route)
     if (alloc_s1d) {
@@ -1351,6 +1362,8 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     if (alloc_agg) {
         if (e == hipSuccess) e = hipMalloc((void **)&yd, n1 * b->Fp * sizeof(double));
         if (e == hipSuccess && b->g->p_n_seg > 0) e = hipMalloc((void **)&segy, (size_t)b->g->p_n_seg * b->Fp * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&zit, (size_t)(b->g->w_n > 0 ? b->g->w_n : 1) * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&zic, sizeof(int32_t));
     }
     // per-row validity of Z1d (every route): rows are formed for all, or on demand for the rows a call reads
     if (e == hipSuccess) e = hipMalloc((void **)&zst, n1 * sizeof(int32_t));
@@ -1359,7 +1372,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     if (e != hipSuccess) {   // all or nothing: a retry starts from a clean state, nothing leaks
         (void)hipFree(s1d); (void)hipFree(z1d); (void)hipFree(slabs); (void)hipFree(segd);
         (void)hipFree(cref); (void)hipFree(fslabs); (void)hipFree(gate); (void)hipFree(fref); (void)hipFree(frs); (void)hipFree(fs1x); (void)hipFree(fz1x); (void)hipFree(fs1q);
-        (void)hipFree(yd); (void)hipFree(segy); (void)hipFree(zst); (void)hipFree(zrw); (void)hipFree(zct);
+        (void)hipFree(yd); (void)hipFree(segy); (void)hipFree(zst); (void)hipFree(zrw); (void)hipFree(zct); (void)hipFree(zit); (void)hipFree(zic);
         if (hint_host) (void)hipHostFree(hint_host);
         return lt_set_error(LT_ERR_HIP, "lt_baseline_enable_fp64: hipMalloc failed: %s", hipGetErrorString(e));
     }
@@ -1371,7 +1384,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     }
     b->fd_hint_host = hint_host; b->fd_hint_dev = hint_dev;
     if (!cref && hint_host) { (void)hipHostFree(hint_host); b->fd_hint_host = b->fd_hint_dev = nullptr; }
-    b->Yd = yd; b->seg_y = segy; b->zstate = zst; b->zrows = zrw; b->zcount = zct;
+    b->Yd = yd; b->seg_y = segy; b->zstate = zst; b->zrows = zrw; b->zcount = zct; b->zitems = zit; b->zicount = zic;
     b->S1d_owned = true; b->S1d_external = false; b->feat_sparse = feat; b->agg_default = agg_chosen;
     int rc = lt_baseline_ensure_padding(b, st);   // (the padded bias the fp64 SpMM adds)
     if (rc) return rc;
@@ -1471,6 +1484,9 @@ void lt_baseline_free_fp64(lt_baseline *b) {
     (void)hipFree(b->zstate);
     (void)hipFree(b->zrows);
     (void)hipFree(b->zcount);
+    (void)hipFree(b->zitems);
+    (void)hipFree(b->zicount);
+    b->zitems = b->zicount = nullptr;
     b->S1d = b->Z1d = b->slabs_d = b->seg_d = b->fd_cref = b->fd_slabs = b->Yd = b->seg_y = nullptr;
     b->fd_gate = nullptr;
     b->zstate = b->zrows = b->zcount = nullptr;

@@ -950,6 +950,15 @@ __device__ __forceinline__ void stageB_long_block(
     __shared__ float sv[CHUNK];
     __shared__ float sT[DELTA ? 1 : CHUNK][CP];
     __shared__ int2 smem[(DELTA || !SHORT) ? 1 : GROUPS][(DELTA || !SHORT) ? 1 : LT_SBL_MC];   // SPARSE, light probes: (entry - e0, position in R_v)
+    // DELTA, heavy probes with a bitmap row (round 5): the WHOLE block finds the members of a chunk (4 entries per thread, compacted in
+    // entry order), the probe's 8 chain lanes then add them in that order -- 8 lanes testing every entry themselves made the pair
+    // (a probed hub, the 49 489-entry observed hub) of BASELINE configs[4] 773 dependent rounds: 0.7 ms, the whole launch
+    // (SHORT only: without the short-side search every probe walks the row -- the twitch-size launch, where the plain walk wins)
+    constexpr bool COOP = DELTA && SHORT;
+    __shared__ int2 s_mem[COOP ? CHUNK : 1];                   // (entry in the chunk, position in R_v) of the members, ascending
+    __shared__ const uint2 *s_mb[COOP ? GROUPS : 1];
+    __shared__ int s_wc[COOP ? (CHUNK / LT_BLOCK) * (LT_BLOCK / 64) : 1];
+    __shared__ unsigned s_hmask;
     const int pblocks = (nb + GROUPS - 1) / GROUPS;
     // the launch has blocks for hub_cap = min(n_obs, hub rows of the graph) observed hubs; hub_obs (k_item_bits) lists the
     // positions there are -- MORE than hub_cap when observe_nodes repeats a hub (a star graph observed twice): a block then
@@ -985,6 +994,12 @@ __device__ __forceinline__ void stageB_long_block(
                                                        : (long)cnt * lg_d > d)
                                               : 2L * cnt * lg_d > (long)d * lg_c));
     const bool light = live && !heavy;
+    const bool coop = COOP && heavy && mb != nullptr;           // (group-uniform)
+    if (COOP) {
+        if (tid == 0) s_hmask = 0u;
+        __syncthreads();
+        if (coop && q == 0) { atomicOr(&s_hmask, 1u << grp); s_mb[grp] = mb; }
+    }
     const int32_t *cu = col + e0;
     const int gl0 = (tid & 63) & ~(LT_L2_LANES - 1);    // first lane of the group inside its wave
     int nmem = 0;       // SPARSE: members in the list (group-uniform)
@@ -1077,7 +1092,66 @@ __device__ __forceinline__ void stageB_long_block(
                 }
             }
             __syncthreads();
-            if (!walk) continue;
+            if constexpr (COOP) {
+                constexpr int SL = CHUNK / LT_BLOCK, NW = LT_BLOCK / 64;
+                for (unsigned hm = s_hmask; hm != 0u; hm &= hm - 1u) {          // (block-uniform)
+                    const int g = __ffs((int)hm) - 1;
+                    const uint2 *mbg = s_mb[g];
+                    uint2 wv[SL];
+                    int cc[SL];
+#pragma unroll
+                    for (int k = 0; k < SL; ++k) {                              // unconditional loads (past the end: the last entry again)
+                        cc[k] = sc[min(k * LT_BLOCK + tid, nc - 1)];
+                        wv[k] = mbg[cc[k] >> 5];
+                    }
+                    unsigned long long bm[SL];
+                    bool mem[SL];
+#pragma unroll
+                    for (int k = 0; k < SL; ++k) {
+                        mem[k] = k * LT_BLOCK + tid < nc && (wv[k].x & (1u << (cc[k] & 31))) != 0u;
+                        bm[k] = __ballot(mem[k]);
+                        if ((tid & 63) == 0) s_wc[k * NW + (tid >> 6)] = __popcll(bm[k]);
+                    }
+                    __syncthreads();
+                    int nm = 0;
+#pragma unroll
+                    for (int k = 0; k < SL; ++k) {
+                        int before = 0;
+#pragma unroll
+                        for (int w_ = 0; w_ < NW; ++w_) {
+                            const int cw = s_wc[k * NW + w_];
+                            before += w_ < (tid >> 6) ? cw : 0;
+                            nm += cw;
+                        }
+                        if (mem[k]) {
+                            const unsigned bit = 1u << (cc[k] & 31);
+                            int slot = before + __popcll(bm[k] & ((1ull << (tid & 63)) - 1ull));
+#pragma unroll
+                            for (int k2 = 0; k2 < SL; ++k2)
+                                if (k2 < k)
+#pragma unroll
+                                    for (int w_ = 0; w_ < NW; ++w_) slot += s_wc[k2 * NW + w_];
+                            s_mem[slot] = make_int2(k * LT_BLOCK + tid, (int)(wv[k].y + __popc(wv[k].x & (bit - 1u))));
+                        }
+                    }
+                    __syncthreads();
+                    if (grp == g) {                                            // the probe's own lanes: chain (entry & 7), entry order
+                        for (int m = 0; m < nm; ++m) {
+                            const int2 me_ = s_mem[m];
+                            touch = true;
+                            if ((me_.x & (LT_L2_LANES - 1)) == q) {
+                                const float a = sv[me_.x];
+                                const float *t = items + (size_t)me_.y * C;
+#pragma unroll
+                                for (int c = 0; c < CP; ++c)
+                                    if (c < C) acc[c] = fmaf(a, t[c], acc[c]);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            if (!walk || coop) continue;
             for (int i = q; i < nc; i += LT_L2_LANES * UN) {
                 int mp[UN];
                 float a_[UN], tb[DELTA ? 1 : UN][CP];

@@ -107,6 +107,8 @@ struct lt_baseline {
     int32_t *zstate = nullptr;  // [n] 0: Z1d row not computed since the last refresh, 2: wanted by the chunk in flight, 1: valid
     int32_t *zrows = nullptr;   // [n] the rows marked 2 by the chunk in flight
     int32_t *zcount = nullptr;  // [1] their number
+    int32_t *zitems = nullptr;  // [g->w_n] aggregate-first route: the work items of the rows marked 2, compacted (k_z_items)
+    int32_t *zicount = nullptr; // [1] their number
     // lt_baseline_refresh recomputes S1 and marks what depends on it stale; Z1 / S2 / OUT (and Z1d) are
     // recomputed by the first call that reads them (logits, SPARSE / DELTA rows) -- FULL rows never do: their
     // stage A yields the baseline S2 as a by-product and stage B forms the baseline logits itself.
@@ -231,7 +233,8 @@ int lt_launch_rows_tiled(const lt_graph *g, const float *S, int64_t lds, int nco
                          int64_t ld_seg, hipStream_t st);
 // fp64 twin (S, out, seg_out double; chains from zero, + bias_after on short rows): the pre-activation of LT_MODE_DELTA
 int lt_launch_rows_tiled_xf64(const lt_graph *g, const float *X, int64_t ldx, int ncols, double *out, int64_t ldo,
-                              double *seg_out, int64_t ld_seg, const int32_t *state, hipStream_t st);
+                              double *seg_out, int64_t ld_seg, const int32_t *state, int32_t *zitems, int32_t *zicount,
+                              hipStream_t st);
 // aggregate-first route active for this baseline right now?  lt_fp64_prepare_items: per probe chunk of an LT_MODE_DELTA call,
 // the fp64 pre-activation rows the chunk's items read (Z1d) and the probes' own fp64 product rows Spd[nb, Hp]
 bool lt_fp64_agg_active(const lt_baseline *b);

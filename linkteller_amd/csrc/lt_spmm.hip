@@ -224,92 +224,131 @@ __global__ __launch_bounds__(LT_BLOCK) void k_rows_tiled_f64(
 // The same work-item kernel for the AGGREGATE-FIRST route of the fp64 pre-activation (lt_fp64.hip): the gathered matrix
 // is the fp32 FEATURE matrix X (4 columns = 16 bytes per lane, 64-column slices), the chains accumulate in fp64 and only
 // the items of rows marked `state[row] == 2` (rows a probe of this call reaches and that hold no valid pre-activation
-// yet) run at all; the others return at once.  Y[row, :] = sum_e val[e] * X[col[e], :], chains from zero, no bias.
+// yet) run.  Y[row, :] = sum_e val[e] * X[col[e], :], chains from zero, no bias.
+// Round 5: the marked items are COMPACTED first (k_z_items: their indices into the work-item list, in list order block by
+// block, the count on the device) and this kernel walks that list with a fixed grid.  Before, every item of the graph got a
+// lane group that looked its row up and returned -- at BASELINE configs[4] 2.5 M items x 4 slices for 190 K marked ones, and the
+// marked ones sat one or two to a wave with the other lane groups idle: the gathers of a 512-probe call ran at 11 TB/s of a
+// possible ~17 (L2-resident hub columns).
 typedef double f64x4s __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_z_items(int n_items, const int32_t *__restrict__ w_dst, int n,
+                                                 const int32_t *__restrict__ seg_long, const int32_t *__restrict__ long_row,
+                                                 const int32_t *__restrict__ state, int32_t *__restrict__ zitems,
+                                                 int32_t *__restrict__ zicount) {
+    __shared__ int32_t s_cnt[4], s_base;
+    const int it = blockIdx.x * 256 + threadIdx.x;
+    bool on = false;
+    if (it < n_items) {
+        const int dst = __builtin_nontemporal_load(w_dst + it);
+        const int row = dst < n ? dst : long_row[seg_long[dst - n]];
+        on = state[row] == 2;
+    }
+    const unsigned long long mk = __ballot(on);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wid] = __popcll(mk);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        s_base = tot ? atomicAdd(zicount, tot) : 0;
+    }
+    __syncthreads();
+    if (on) {
+        int before = __popcll(mk & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wid; ++w) before += s_cnt[w];
+        zitems[s_base + before] = it;
+    }
+}
 __global__ __launch_bounds__(LT_BLOCK) void k_rows_tiled_xf64(
-    int n_items, const int32_t *__restrict__ w_e0, const int32_t *__restrict__ w_cnt,
-    const int32_t *__restrict__ w_dst, int n, const int32_t *__restrict__ col, const float *__restrict__ val,
-    const float *__restrict__ X, long ldx, int ncols, double *__restrict__ out, long ldo, double *__restrict__ seg_out,
-    long ld_seg, const int32_t *__restrict__ seg_long, const int32_t *__restrict__ long_row,
-    const int32_t *__restrict__ state, int ns, const int2 *__restrict__ cv) {
+    const int32_t *__restrict__ zitems, const int32_t *__restrict__ zicount, const int32_t *__restrict__ w_e0,
+    const int32_t *__restrict__ w_cnt, const int32_t *__restrict__ w_dst, int n, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const float *__restrict__ X, long ldx, int ncols, double *__restrict__ out, long ldo,
+    double *__restrict__ seg_out, long ld_seg, int ns, const int2 *__restrict__ cv) {
     constexpr int GL = LT_TILE_GL, U = LT_TILE_U;
     constexpr int GPW = 64 / GL, IPB = (LT_BLOCK / 64) * GPW;
     const int lane = threadIdx.x & 63;
     const int j = lane & (GL - 1);
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, nq = gridDim.x >> 3;
     const int xps = 8 / ns;
     const int slice = xcd % ns;
-    const int it = (q * xps + xcd / ns) * IPB + (threadIdx.x >> 6) * GPW + lane / GL;
-    if (it >= n_items) return;
-    const int dst = __builtin_nontemporal_load(w_dst + it);
-    const int row = dst < n ? dst : long_row[seg_long[dst - n]];
-    if (state[row] != 2) return;
-    const int e0 = __builtin_nontemporal_load(w_e0 + it);
-    const int cnt = __builtin_nontemporal_load(w_cnt + it);
+    const int total = *zicount;
     const int coff = slice * 4 * GL + 4 * j;
     const bool active = coff < ncols;
     const bool vec = coff + 3 < ncols && (ldx & 3) == 0;      // 16-byte gathers when the rows of X allow them
-    f64x4s acc = {0.0, 0.0, 0.0, 0.0};
-    const int e1 = e0 + cnt;
-    int nxc = 0;
-    float nxa = 0.f;
-    if (e0 + j < e1) tiled_entry(cv, col, val, e0 + j, nxc, nxa);
-    for (int eb = e0; eb < e1; eb += GL) {
-        const int me = eb + j;
-        const int myc = nxc;
-        const float mya = nxa;
-        nxc = 0;
-        nxa = 0.f;
-        if (me + GL < e1) tiled_entry(cv, col, val, me + GL, nxc, nxa);
-        const int left = e1 - eb;
-        static_for<GL / U>([&](auto kbt) {
-            constexpr int kb = decltype(kbt)::value * U;
-            if (kb < left) {
-                f32x4 s[U];
-                double a[U];
-                static_for<U>([&](auto ut) {
-                    constexpr int u = decltype(ut)::value;
-                    constexpr int k = kb + u;
-                    const int c = row_bcast<k>(myc);
-                    a[u] = (double)__builtin_bit_cast(float, row_bcast<k>(__builtin_bit_cast(int, mya)));
-                    s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (k < left && active) {
-                        const float *p = X + ((size_t)c * (size_t)ldx + coff);
-                        if (vec) s[u] = *reinterpret_cast<const f32x4 *>(p);
-                        else
+    for (long chunk = (long)q * xps + xcd / ns; chunk * IPB < total; chunk += (long)nq * xps) {
+        const int k = (int)chunk * IPB + (threadIdx.x >> 6) * GPW + lane / GL;
+        if (k >= total) continue;
+        const int it = zitems[k];
+        const int dst = __builtin_nontemporal_load(w_dst + it);
+        const int e0 = __builtin_nontemporal_load(w_e0 + it);
+        const int cnt = __builtin_nontemporal_load(w_cnt + it);
+        f64x4s acc = {0.0, 0.0, 0.0, 0.0};
+        const int e1 = e0 + cnt;
+        int nxc = 0;
+        float nxa = 0.f;
+        if (e0 + j < e1) tiled_entry(cv, col, val, e0 + j, nxc, nxa);
+        for (int eb = e0; eb < e1; eb += GL) {
+            const int me = eb + j;
+            const int myc = nxc;
+            const float mya = nxa;
+            nxc = 0;
+            nxa = 0.f;
+            if (me + GL < e1) tiled_entry(cv, col, val, me + GL, nxc, nxa);
+            const int left = e1 - eb;
+            static_for<GL / U>([&](auto kbt) {
+                constexpr int kb = decltype(kbt)::value * U;
+                if (kb < left) {
+                    f32x4 s[U];
+                    double a[U];
+                    static_for<U>([&](auto ut) {
+                        constexpr int u = decltype(ut)::value;
+                        constexpr int kk = kb + u;
+                        const int c = row_bcast<kk>(myc);
+                        a[u] = (double)__builtin_bit_cast(float, row_bcast<kk>(__builtin_bit_cast(int, mya)));
+                        s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (kk < left && active) {
+                            const float *p = X + ((size_t)c * (size_t)ldx + coff);
+                            if (vec) s[u] = *reinterpret_cast<const f32x4 *>(p);
+                            else
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) if (coff + t < ncols) s[u][t] = p[t];
-                    }
-                });
-                static_for<U>([&](auto ut) {
-                    constexpr int u = decltype(ut)::value;
-                    if (kb + u < left) {
+                                for (int t = 0; t < 4; ++t) if (coff + t < ncols) s[u][t] = p[t];
+                        }
+                    });
+                    static_for<U>([&](auto ut) {
+                        constexpr int u = decltype(ut)::value;
+                        if (kb + u < left) {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) acc[t] = fma(a[u], (double)s[u][t], acc[t]);
-                    }
-                });
-            }
-        });
+                            for (int t = 0; t < 4; ++t) acc[t] = fma(a[u], (double)s[u][t], acc[t]);
+                        }
+                    });
+                }
+            });
+        }
+        if (!active) continue;
+        double *d = dst < n ? out + (size_t)dst * ldo + coff : seg_out + (size_t)(dst - n) * ld_seg + coff;
+        __builtin_nontemporal_store(acc, reinterpret_cast<f64x4s *>(d));     // (ldo / ld_seg are multiples of 4: 32-byte aligned)
     }
-    if (!active) return;
-    double *d = dst < n ? out + (size_t)dst * ldo + coff : seg_out + (size_t)(dst - n) * ld_seg + coff;
-    __builtin_nontemporal_store(acc, reinterpret_cast<f64x4s *>(d));     // (ldo / ld_seg are multiples of 4: 32-byte aligned)
 }
 
+// zitems: [g->w_n] scratch for the compacted list, zicount: its device counter (zeroed here)
 int lt_launch_rows_tiled_xf64(const lt_graph *g, const float *X, int64_t ldx, int ncols, double *out, int64_t ldo,
-                              double *seg_out, int64_t ld_seg, const int32_t *state, hipStream_t st) {
+                              double *seg_out, int64_t ld_seg, const int32_t *state, int32_t *zitems, int32_t *zicount,
+                              hipStream_t st) {
     if (g->w_n == 0) return LT_OK;
     int ns = (ncols + 4 * LT_TILE_GL - 1) / (4 * LT_TILE_GL);   // 64-column slices: 1, 2, 4, 8
     ns = ns <= 1 ? 1 : (ns == 2 ? 2 : (ns <= 4 ? 4 : 8));
     LT_REQUIRE(ncols <= 4 * LT_TILE_GL * 8 && ldo % 4 == 0 && ld_seg % 4 == 0, "tiled aggregate-first SpMM: ncols=%d", ncols);
+    LT_HIP(hipMemsetAsync(zicount, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_z_items, dim3((unsigned)((g->w_n + 255) / 256)), dim3(256), 0, st, g->w_n, g->w_dst, g->n, g->p_seg_long,
+                       g->p_long_row, state, zitems, zicount);
+    LT_CHECK_LAUNCH();
+    // a fixed grid walks the list (its length stays on the device): as many blocks as the chip holds at once, or the graph needs
     const int xps = 8 / ns;
     constexpr int IPB = (LT_BLOCK / 64) * (64 / LT_TILE_GL);
     const long chunks = ((long)g->w_n + IPB - 1) / IPB;
-    const long grid = 8 * ((chunks + xps - 1) / xps);
-    LT_REQUIRE(grid < 2147483647L, "tiled aggregate-first SpMM: grid limit");
-    hipLaunchKernelGGL(k_rows_tiled_xf64, dim3((unsigned)grid), dim3(LT_BLOCK), 0, st, g->w_n, g->w_e0, g->w_cnt, g->w_dst,
-                       g->n, g->col, g->val, X, (long)ldx, ncols, out, (long)ldo, seg_out, (long)ld_seg, g->p_seg_long,
-                       g->p_long_row, state, ns, g->cv);
+    long grid = 8 * ((chunks + xps - 1) / xps);
+    if (grid > 8 * 512) grid = 8 * 512;
+    hipLaunchKernelGGL(k_rows_tiled_xf64, dim3((unsigned)grid), dim3(LT_BLOCK), 0, st, zitems, zicount, g->w_e0, g->w_cnt, g->w_dst,
+                       g->n, g->col, g->val, X, (long)ldx, ncols, out, (long)ldo, seg_out, (long)ld_seg, ns, g->cv);
     LT_CHECK_LAUNCH();
     return LT_OK;
 }

@@ -479,6 +479,9 @@ def test_gcn3_delta_mode_against_the_fp64_oracle(gpu, h1, h2, c, hub, features):
     assert np.abs(got2 - ref2).max() <= 1e-5 * ref2.max()
 
 
+_HUB_REF = {}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("long_par,p", [(1, 32), (1, 16), (0, 16)])
 def test_full_mode_on_a_hub_of_many_segments(gpu, long_par, p):
@@ -516,36 +519,33 @@ def test_full_mode_on_a_hub_of_many_segments(gpu, long_par, p):
         _lib.set_tuning("long_par", None)
     assert np.array_equal(f, s_)
     assert np.isfinite(f).all() and f.max() > 0 and (f[:, 0] > 0).sum() > 50      # the hub sees every probe (some of the fp32 differences round to 0)
-    adj_o = O.to_torch_sparse(a_hat)
-    ours, theirs = [], []
-    checked = (0, 7, 15, 23, 31, 39, 47, 55, 63, 69, 77, 85)
-    for i in checked:
-        ref = {}
+    # the reference path on ALL 100 probe rows, fp32 and fp64 (once: the three parametrisations produce the same bits)
+    if "ref" not in _HUB_REF:
+        adj_o = O.to_torch_sparse(a_hat)
         for dt in (torch.float32, torch.float64):
             P = {k: torch.from_numpy(w[k]).to(dt) for k in ("W1", "b1", "W2", "b2")}
+            out = np.zeros((len(probes), len(obs)))
             with torch.no_grad():
-                gm = O.get_gradient_eps_mat(torch.from_numpy(x).to(dt), adj_o.to(dt), P, int(probes[i]), 1e-4)
-            ref[dt] = gm[torch.as_tensor(obs.astype(np.int64))].norm(dim=1).double().numpy()
-        theirs.append(np.abs(ref[torch.float32] - ref[torch.float64]).max())
-        ours.append(np.abs(f[i] - ref[torch.float64]).max())
-    # a 9 500-term fp32 sum in two different orders (128-entry segments here, sequential in torch.spmm): same noise level, not
-    # the same draw.  The hub's score is quantised to ulp(logit) / 1e-4 (a few 1e-3 here), and ONE row's error is a handful of
-    # such steps on either side (round 3 compared row by row at 4x and passed by the luck of the draw: with the bits of the
-    # round-4 GEMM row 31 read 0.0345 against a reference error of 0.0032 on that row and 0.01 .. 0.03 on its neighbours) --
-    # so: the worst of the checked rows against the reference's worst of the same rows, 4x
-    # (round 5, ADVICE r4: a row-by-row bound again, so that one bad row cannot hide behind its neighbours -- against the row's own
-    # reference error or the reference's rms error over the twelve checked rows, whichever is larger: the noise floor of the case --
-    # and the rms of our errors against the rms of the reference's, 2x: two draws from one noise class)
-    ours, theirs = np.asarray(ours), np.asarray(theirs)
+                for i, v in enumerate(probes):
+                    gm = O.get_gradient_eps_mat(torch.from_numpy(x).to(dt), adj_o.to(dt), P, int(v), 1e-4)
+                    out[i] = gm[torch.as_tensor(obs.astype(np.int64))].norm(dim=1).double().numpy()
+            _HUB_REF[dt] = out
+        _HUB_REF["ref"] = True
+    ref64, ref32 = _HUB_REF[torch.float64], _HUB_REF[torch.float32]
+    ours = np.abs(f.astype(np.float64) - ref64).max(axis=1)
+    theirs = np.abs(ref32 - ref64).max(axis=1)
+    # A 9 500-term fp32 sum in two different orders (8 strided chains of 128-entry segments here, sequential in torch.spmm): the
+    # pair (probe, hub) carries the hub's ulp-quantised logit difference / 1e-4 -- a few 1e-3 per ulp -- in both.  Measured over the
+    # 100 rows (round 5, tools/hub_noise.py): row maxima rms 0.0273 against the reference's 0.0145 (1.9x: at the hub column our
+    # noise is twice the reference's, on every other column 0.8x of it), largest row 0.067 against 0.060.  Gates (a
+    # row-by-row bound again, so that no row hides behind its neighbours): every row within 4x its own reference error or 5x the
+    # reference's rms, the rms of the row maxima within 2x the reference's, the worst row within 2x the reference's worst.
     rms_o, rms_t = float(np.sqrt((ours ** 2).mean())), float(np.sqrt((theirs ** 2).mean()))
-    print(f"hub rows: |full - ref64| per checked row {np.round(ours, 5)}, reference fp32 {np.round(theirs, 5)}, rms {rms_o:.5f} / {rms_t:.5f}")
-    assert ours.max() <= 4.0 * max(theirs.max(), 1e-9), (ours, theirs)
-    for i, o, t in zip(checked, ours, theirs):
-        assert o <= 4.0 * max(t, rms_t), (i, o, t, rms_t)
-    # (measured in round 5 over these twelve rows: 0.0205 against 0.0100 -- the pair (probe, hub) is the hub's own ulp-quantised
-    # pre-activation change entering with weight A_hat[0, 0] = 1, in two different summation orders; tools/hub_noise.py holds the
-    # same comparison over all 100 probe rows)
-    assert rms_o <= 2.5 * rms_t, (rms_o, rms_t)
+    print(f"hub rows: |full - ref64| row maxima rms {rms_o:.5f} max {ours.max():.5f}; reference fp32 rms {rms_t:.5f} max {theirs.max():.5f}")
+    for i, (o, t) in enumerate(zip(ours, theirs)):
+        assert o <= max(4.0 * t, 5.0 * rms_t), (i, o, t, rms_t)
+    assert rms_o <= 2.0 * rms_t, (rms_o, rms_t)
+    assert ours.max() <= 2.0 * theirs.max(), (ours.max(), theirs.max())
 
 
 @pytest.mark.gpu
