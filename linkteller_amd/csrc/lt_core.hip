@@ -502,12 +502,20 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
         try {
             dl_host dl;
             if (build_delta_records(n, tptr.data(), trow.get(), tval.get(), tpos.get(), max_col, dl)) {
-                G_HIP(hipMalloc((void **)&g->dl_meta, (size_t)n * sizeof(int4)));
-                G_HIP(hipMalloc((void **)&g->dl_rec, dl.rec.size() * sizeof(int32_t)));
-                G_HIP(hipMemcpy(g->dl_meta, dl.meta.data(), (size_t)n * sizeof(int4), hipMemcpyHostToDevice));
-                G_HIP(hipMemcpy(g->dl_rec, dl.rec.data(), dl.rec.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-                g->dl_max_t = dl.max_t;
-                g->dl_max_tu = dl.max_tu;
+                // (not G_HIP: device memory that does not suffice for the records must not fail the whole create -- the buffers
+                // are released, the error cleared and the graph simply has no records: the item kernels serve it)
+                hipError_t e = hipMalloc((void **)&g->dl_meta, (size_t)n * sizeof(int4));
+                if (e == hipSuccess) e = hipMalloc((void **)&g->dl_rec, dl.rec.size() * sizeof(int32_t));
+                if (e == hipSuccess) e = hipMemcpy(g->dl_meta, dl.meta.data(), (size_t)n * sizeof(int4), hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemcpy(g->dl_rec, dl.rec.data(), dl.rec.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+                if (e == hipSuccess) {
+                    g->dl_max_t = dl.max_t;
+                    g->dl_max_tu = dl.max_tu;
+                } else {
+                    (void)hipGetLastError();
+                    (void)hipFree(g->dl_meta); (void)hipFree(g->dl_rec);
+                    g->dl_meta = nullptr; g->dl_rec = nullptr;
+                }
             }
         } catch (const std::bad_alloc &) {
         } catch (const std::system_error &) {

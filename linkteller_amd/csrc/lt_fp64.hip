@@ -444,7 +444,8 @@ __device__ unsigned long long *g_fd_trace = nullptr;
 #endif
 #define FD_CAP 384
 #define FD_WAVES 4
-#define FD_PU 6          // W1 rows in flight per lane while a list is walked (FD_CAP is a multiple; 8 costs the fifth wave per SIMD)
+#define FD_PU 6          // W1 rows in flight per lane while a list is walked (FD_CAP is a multiple; 8 costs the fifth wave per SIMD: 110 VGPRs
+                         // against 90 -- ~10 per row in flight, address pair + data + index -- and 12 the fourth: 138; round 5 re-measured)
 #define FD_REF_PAD (16 * 64 * FD_WAVES + 64)   // the staging loop of k_s1d_feature_rows reads the reference vector in whole passes
 #define FD_UN 26         // loads in flight per lane in the row pass (x 128 floats: F <= 3328 is one trip)
 // VEC: floats per lane and load, 2 when the rows of X are 8-byte aligned, else 1.  (Round 4 built VEC = 4 -- 13 loads of 16 bytes,
@@ -503,6 +504,12 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
             __hip_atomic_store(slabs + (size_t)blockIdx.x * H + c, ((s_p[0][c] + s_p[1][c]) + s_p[2][c]) + s_p[3][c], __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         __shared__ unsigned s_last;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "this hand-off is written against gfx950's memory system (sc1 write-through stores / sc1 loads, vmcnt counting stores): on another target give the ticket __ATOMIC_RELEASE and the slab loads __ATOMIC_ACQUIRE at agent scope"
+#endif
+        // (Under the HIP memory model relaxed atomics + s_waitcnt are a data race; what makes it correct is the ISA-level argument
+        // below, which is why the translation unit refuses to build for any other target, and why tests/test_gpu_round4.py runs
+        // 20 000 refreshes of it against alternating weights under uneven background traffic.)
         // Memory-order argument (MI355X_MICROARCH.md, "Valid forms", sc1 both sides, first table row):
         //  (1) every byte of a slice is stored `sc1` (write-through, above) and loaded `sc1` (below): no L1 / L2 copy to go stale;
         //  (2) each storing wave drains ITS stores (s_waitcnt vmcnt(0): they have reached memory, not just left the wave);
@@ -1362,7 +1369,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     if (alloc_agg) {
         if (e == hipSuccess) e = hipMalloc((void **)&yd, n1 * b->Fp * sizeof(double));
         if (e == hipSuccess && b->g->p_n_seg > 0) e = hipMalloc((void **)&segy, (size_t)b->g->p_n_seg * b->Fp * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void **)&zit, (size_t)(b->g->w_n > 0 ? b->g->w_n : 1) * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&zit, lt_xf64_scratch_words(b->g) * sizeof(int32_t));
         if (e == hipSuccess) e = hipMalloc((void **)&zic, sizeof(int32_t));
     }
     // per-row validity of Z1d (every route): rows are formed for all, or on demand for the rows a call reads

@@ -948,7 +948,7 @@ __device__ __forceinline__ void stageB_long_block(
     constexpr int UN = (DELTA && WIDE) ? LT_SBL_UN_DELTA : LT_SBL_UN;
     __shared__ int sc[CHUNK];
     __shared__ float sv[CHUNK];
-    __shared__ float sT[DELTA ? 1 : CHUNK][CP];
+    __shared__ float sT[(DELTA && !(DELTA && SHORT)) ? 1 : CHUNK][CP];     // SPARSE: the baseline rows of the chunk; DELTA + SHORT: the members' item rows (below)
     __shared__ int2 smem[(DELTA || !SHORT) ? 1 : GROUPS][(DELTA || !SHORT) ? 1 : LT_SBL_MC];   // SPARSE, light probes: (entry - e0, position in R_v)
     // DELTA, heavy probes with a bitmap row (round 5): the WHOLE block finds the members of a chunk (4 entries per thread, compacted in
     // entry order), the probe's 8 chain lanes then add them in that order -- 8 lanes testing every entry themselves made the pair
@@ -957,6 +957,7 @@ __device__ __forceinline__ void stageB_long_block(
     constexpr bool COOP = DELTA && SHORT;
     __shared__ int2 s_mem[COOP ? CHUNK : 1];                   // (entry in the chunk, position in R_v) of the members, ascending
     __shared__ const uint2 *s_mb[COOP ? GROUPS : 1];
+    __shared__ const float *s_items[COOP ? GROUPS : 1];
     __shared__ int s_wc[COOP ? (CHUNK / LT_BLOCK) * (LT_BLOCK / 64) : 1];
     __shared__ unsigned s_hmask;
     const int pblocks = (nb + GROUPS - 1) / GROUPS;
@@ -990,17 +991,29 @@ __device__ __forceinline__ void stageB_long_block(
     // log |R_v| loads without; the search from the R_v side costs |R_v| / (8 NS) rounds of log d loads
     const int lg_d = 32 - __clz(d), lg_c = 32 - __clz(cnt > 1 ? cnt : 1);
     // with a bitmap row, in dependent rounds: the walk is d / (8 lanes * UN) of them, the search (lg d + 2) per 64 members
-    const bool heavy = live && (!SHORT || (mb ? ((DELTA && WIDE) ? (long)((cnt + 63) / 64) * (lg_d + 2) > (d + LT_L2_LANES * UN - 1) / (LT_L2_LANES * UN)
-                                                       : (long)cnt * lg_d > d)
+    // COOP (the whole block finds a heavy probe's members, below): a pass over the row costs ~1.5 us per 1024 entries whatever the
+    // probe, the search from the R_v side (cnt / 64) rounds of lg d DEPENDENT loads (~0.7 us each) -- the walk wins from
+    // cnt lg d > d / 8 on (BASELINE configs[4]: probes of 2 442 and 2 314 neighbours against the 49 489-entry observed hub counted as
+    // light under the old rule, 39 rounds x 16 steps each: 0.7 ms, the whole launch)
+    const bool heavy = live && (!SHORT || (mb ? (COOP ? 8L * cnt * lg_d > d
+                                                      : ((DELTA && WIDE) ? (long)((cnt + 63) / 64) * (lg_d + 2) > (d + LT_L2_LANES * UN - 1) / (LT_L2_LANES * UN)
+                                                                         : (long)cnt * lg_d > d))
                                               : 2L * cnt * lg_d > (long)d * lg_c));
     const bool light = live && !heavy;
     const bool coop = COOP && heavy && mb != nullptr;           // (group-uniform)
     if (COOP) {
         if (tid == 0) s_hmask = 0u;
         __syncthreads();
-        if (coop && q == 0) { atomicOr(&s_hmask, 1u << grp); s_mb[grp] = mb; }
+        if (coop && q == 0) { atomicOr(&s_hmask, 1u << grp); s_mb[grp] = mb; s_items[grp] = items; }
     }
     const int32_t *cu = col + e0;
+    int samp_sh = 0, n_samp = 0;
+    if constexpr (COOP) {       // the search sample of this observed hub (block-uniform; sc is restaged by the walk afterwards)
+        while ((d >> samp_sh) > CHUNK) ++samp_sh;
+        n_samp = d >> samp_sh;
+        for (int i = tid; i < n_samp; i += LT_BLOCK) sc[i] = cu[((i + 1) << samp_sh) - 1];
+        __syncthreads();
+    }
     const int gl0 = (tid & 63) & ~(LT_L2_LANES - 1);    // first lane of the group inside its wave
     int nmem = 0;       // SPARSE: members in the list (group-uniform)
     int r_next = 0;     // next position of R_v to look up (group-uniform)
@@ -1014,6 +1027,34 @@ __device__ __forceinline__ void stageB_long_block(
             key[k] = idx < cnt ? rv[idx] : 0x7fffffff;
             base[k] = 0;
         }
+        if constexpr (COOP) {
+            // two levels (round 5): the last column of every 2^samp_sh-entry stretch of the row sits in LDS (sc, staged once per
+            // observed hub below) -- the upper levels of every search cost LDS trips, only the last samp_sh steps dependent
+            // global loads (49 489 entries: 10 + 6 instead of 16; a row of up to CHUNK entries is searched in LDS alone)
+            for (int nrem = n_samp; nrem > 1;) {
+                const int half = nrem >> 1;
+#pragma unroll
+                for (int k = 0; k < LT_SBL_NS; ++k) base[k] = sc[base[k] + half - 1] < key[k] ? base[k] + half : base[k];
+                nrem -= half;
+            }
+#pragma unroll
+            for (int k = 0; k < LT_SBL_NS; ++k) {
+                if (n_samp > 0 && sc[base[k]] < key[k]) ++base[k];
+                base[k] <<= samp_sh;                       // first entry of the stretch that holds the lower bound (or d)
+            }
+            for (int nrem = 1 << samp_sh; nrem > 1;) {     // (a stretch cut short by the row's end: entries past it read as the last)
+                const int half = nrem >> 1;
+#pragma unroll
+                for (int k = 0; k < LT_SBL_NS; ++k) base[k] = cu[min(base[k] + half - 1, d - 1)] < key[k] ? base[k] + half : base[k];
+                nrem -= half;
+            }
+#pragma unroll
+            for (int k = 0; k < LT_SBL_NS; ++k) {
+                const int cb_ = cu[min(base[k], d - 1)];
+                if (base[k] < d && cb_ < key[k]) ++base[k];
+                fe[k] = (base[k] < d && cu[min(base[k], d - 1)] == key[k]) ? base[k] : -1;
+            }
+        } else {
         // branch-free lower bound over cu[0, d): LT_SBL_NS independent searches per lane, one load each per step
         for (int nrem = d; nrem > 1;) {
             const int half = nrem >> 1;
@@ -1025,6 +1066,7 @@ __device__ __forceinline__ void stageB_long_block(
         for (int k = 0; k < LT_SBL_NS; ++k) {
             if (cu[base[k]] < key[k]) ++base[k];
             fe[k] = (base[k] < d && cu[base[k]] == key[k]) ? base[k] : -1;
+        }
         }
 #pragma unroll
         for (int k = 0; k < LT_SBL_NS; ++k)
@@ -1135,16 +1177,46 @@ __device__ __forceinline__ void stageB_long_block(
                         }
                     }
                     __syncthreads();
-                    if (grp == g) {                                            // the probe's own lanes: chain (entry & 7), entry order
-                        for (int m = 0; m < nm; ++m) {
-                            const int2 me_ = s_mem[m];
-                            touch = true;
-                            if ((me_.x & (LT_L2_LANES - 1)) == q) {
-                                const float a = sv[me_.x];
-                                const float *t = items + (size_t)me_.y * C;
+                    // the members' item rows, fetched by the whole block in one trip (one dependent global load per member in the
+                    // chain lanes' loop made a pair of 1 000 common neighbours a millisecond)
+                    {
+                        const float *itg = s_items[g];
+                        for (int m = tid; m < nm; m += LT_BLOCK) {
+                            const float *t = itg + (size_t)s_mem[m].y * C;
+#pragma unroll
+                            for (int c = 0; c < CP; ++c) sT[m][c] = c < C ? t[c] : 0.f;
+                        }
+                    }
+                    __syncthreads();
+                    if (grp == g && nm > 0) {                                  // the probe's own lanes: chain (entry & 7), entry order
+                        touch = true;
+                        int m = 0;
+                        for (; m + 4 <= nm; m += 4) {
+                            int ex[4];
+                            float a4[4], t4[4][CP];
+#pragma unroll
+                            for (int x = 0; x < 4; ++x) ex[x] = s_mem[m + x].x;
+#pragma unroll
+                            for (int x = 0; x < 4; ++x) {
+                                a4[x] = sv[ex[x]];
+#pragma unroll
+                                for (int c = 0; c < CP; ++c) t4[x][c] = sT[m + x][c];
+                            }
+#pragma unroll
+                            for (int x = 0; x < 4; ++x)
+                                if ((ex[x] & (LT_L2_LANES - 1)) == q) {
+#pragma unroll
+                                    for (int c = 0; c < CP; ++c)
+                                        if (c < C) acc[c] = fmaf(a4[x], t4[x][c], acc[c]);
+                                }
+                        }
+                        for (; m < nm; ++m) {
+                            const int ex = s_mem[m].x;
+                            if ((ex & (LT_L2_LANES - 1)) == q) {
+                                const float a = sv[ex];
 #pragma unroll
                                 for (int c = 0; c < CP; ++c)
-                                    if (c < C) acc[c] = fmaf(a, t[c], acc[c]);
+                                    if (c < C) acc[c] = fmaf(a, sT[m][c], acc[c]);
                             }
                         }
                     }
@@ -1620,11 +1692,14 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_finish(
 // beyond the default 64 KB of dynamic LDS a kernel is told, once, that it may take most of a CU's 160 KB
 template <int LPR, int CP, bool SX, bool ZF>
 static int df_allow_big_lds() {
-    static bool done = false;
-    if (!done) {
+    // (the attribute belongs to the device's copy of the code object: remembered per device, not per process)
+    static unsigned long long done = 0ull;
+    int dev = 0;
+    LT_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !((done >> dev) & 1ull)) {
         LT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_delta_probe_finish<LPR, CP, SX, ZF>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LT_DF_LDS_MAX));
-        done = true;
+        if (dev >= 0 && dev < 64) done |= 1ull << dev;
     }
     return LT_OK;
 }

@@ -107,7 +107,7 @@ struct lt_baseline {
     int32_t *zstate = nullptr;  // [n] 0: Z1d row not computed since the last refresh, 2: wanted by the chunk in flight, 1: valid
     int32_t *zrows = nullptr;   // [n] the rows marked 2 by the chunk in flight
     int32_t *zcount = nullptr;  // [1] their number
-    int32_t *zitems = nullptr;  // [g->w_n] aggregate-first route: the work items of the rows marked 2, compacted (k_z_items)
+    int32_t *zitems = nullptr;  // [lt_xf64_scratch_words] aggregate-first route: the work items of the rows marked 2, compacted in list order
     int32_t *zicount = nullptr; // [1] their number
     // lt_baseline_refresh recomputes S1 and marks what depends on it stale; Z1 / S2 / OUT (and Z1d) are
     // recomputed by the first call that reads them (logits, SPARSE / DELTA rows) -- FULL rows never do: their
@@ -232,6 +232,7 @@ int lt_launch_rows_tiled(const lt_graph *g, const float *S, int64_t lds, int nco
                          const float *bias_after, int relu, float *out, int64_t ldo, float *seg_out,
                          int64_t ld_seg, hipStream_t st);
 // fp64 twin (S, out, seg_out double; chains from zero, + bias_after on short rows): the pre-activation of LT_MODE_DELTA
+size_t lt_xf64_scratch_words(const lt_graph *g);      // int32 words of the `zitems` scratch below
 int lt_launch_rows_tiled_xf64(const lt_graph *g, const float *X, int64_t ldx, int ncols, double *out, int64_t ldo,
                               double *seg_out, int64_t ld_seg, const int32_t *state, int32_t *zitems, int32_t *zicount,
                               hipStream_t st);

@@ -255,14 +255,33 @@ static __global__ __launch_bounds__(256) void k_pm_lists(const int32_t *__restri
                                                          int32_t *__restrict__ cursor) {
     const long k = (long)blockIdx.x * 256 + threadIdx.x;
     const int j = (int)(k / LT_ROW_SEG), i = (int)(k % LT_ROW_SEG);
-    if (j >= n_obs) return;
-    const int u = observe[j];
-    const int e0 = rowptr[u], d = rowptr[u + 1] - e0;
-    if (d > LT_ROW_SEG || i >= d) return;
-    const int r = col[e0 + i];
-    if (PHASE == 0) rank[k] = atomicAdd(&cnt[r], 1);
-    else if (PHASE == 1) { if (rank[k] == 0) start[r] = atomicAdd(cursor, cnt[r]); }
-    else list[start[r] + rank[k]] = j;
+    bool on = j < n_obs;
+    int r = 0;
+    if (on) {
+        const int u = observe[j];
+        const int e0 = rowptr[u], d = rowptr[u + 1] - e0;
+        on = d <= LT_ROW_SEG && i < d;
+        if (on) r = col[e0 + i];
+    }
+    if (PHASE == 0) { if (on) rank[k] = atomicAdd(&cnt[r], 1); }
+    else if (PHASE == 1) {
+        // one slice of `list` per node: the slices' places come off ONE cursor -- a wave sums its claims (inclusive scan) and asks
+        // once (round 5: one atomic per node on that single word was 50 us of serialised adds at BASELINE configs[4])
+        const bool claim = on && rank[k] == 0;
+        const int mine = claim ? cnt[r] : 0;
+        int incl = mine;
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const int t = __shfl_up(incl, m, 64);
+            if (lane >= m) incl += t;
+        }
+        const int total = __shfl(incl, 63, 64);
+        int base = 0;
+        if (lane == 63 && total > 0) base = atomicAdd(cursor, total);
+        base = __shfl(base, 63, 64);
+        if (claim) start[r] = base + incl - mine;
+    } else if (on) list[start[r] + rank[k]] = j;
 }
 
 // 8 lanes per item: the item's list of observed nodes is a contiguous slice

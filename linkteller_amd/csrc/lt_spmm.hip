@@ -19,6 +19,7 @@
 //        different hub rows that cross the same columns meet in L2.
 //    (col, val) stream in with non-temporal loads, one coalesced 16-entry block per lane group, and are handed
 //    round by DPP row broadcasts; results leave with non-temporal stores.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "lt_rows.hip.h"
@@ -225,17 +226,20 @@ __global__ __launch_bounds__(LT_BLOCK) void k_rows_tiled_f64(
 // is the fp32 FEATURE matrix X (4 columns = 16 bytes per lane, 64-column slices), the chains accumulate in fp64 and only
 // the items of rows marked `state[row] == 2` (rows a probe of this call reaches and that hold no valid pre-activation
 // yet) run.  Y[row, :] = sum_e val[e] * X[col[e], :], chains from zero, no bias.
-// Round 5: the marked items are COMPACTED first (k_z_items: their indices into the work-item list, in list order block by
+// Round 5: the marked items are COMPACTED first (k_z_flags / k_z_scan / k_z_scatter: their indices into the work-item list, in list order block by
 // block, the count on the device) and this kernel walks that list with a fixed grid.  Before, every item of the graph got a
 // lane group that looked its row up and returned -- at BASELINE configs[4] 2.5 M items x 4 slices for 190 K marked ones, and the
 // marked ones sat one or two to a wave with the other lane groups idle: the gathers of a 512-probe call ran at 11 TB/s of a
 // possible ~17 (L2-resident hub columns).
 typedef double f64x4s __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_z_items(int n_items, const int32_t *__restrict__ w_dst, int n,
+// (the list keeps the ORDER of the work-item list -- segments by first column: waves that run together gather from one sliding
+// window of X -- so it is built in three small steps, flags + block counts / scan of the counts / scatter, and not with one atomic
+// cursor: blocks claim a cursor in completion order, which shuffled the list across ~ 500 K items and cost the gathers a fifth)
+__global__ __launch_bounds__(256) void k_z_flags(int n_items, const int32_t *__restrict__ w_dst, int n,
                                                  const int32_t *__restrict__ seg_long, const int32_t *__restrict__ long_row,
-                                                 const int32_t *__restrict__ state, int32_t *__restrict__ zitems,
-                                                 int32_t *__restrict__ zicount) {
-    __shared__ int32_t s_cnt[4], s_base;
+                                                 const int32_t *__restrict__ state, unsigned long long *__restrict__ masks,
+                                                 int32_t *__restrict__ bcnt) {
+    __shared__ int32_t s_cnt[4];
     const int it = blockIdx.x * 256 + threadIdx.x;
     bool on = false;
     if (it < n_items) {
@@ -245,18 +249,47 @@ __global__ __launch_bounds__(256) void k_z_items(int n_items, const int32_t *__r
     }
     const unsigned long long mk = __ballot(on);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (lane == 0) s_cnt[wid] = __popcll(mk);
+    if (lane == 0) { masks[(size_t)blockIdx.x * 4 + wid] = mk; s_cnt[wid] = __popcll(mk); }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        s_base = tot ? atomicAdd(zicount, tot) : 0;
-    }
+    if (threadIdx.x == 0) bcnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+// exclusive scan of the block counts (one block walks them in tiles of 1024), the total -> *zicount
+__global__ __launch_bounds__(1024) void k_z_scan(int nb, int32_t *__restrict__ bcnt, int32_t *__restrict__ zicount) {
+    __shared__ int32_t s_w[16];
+    __shared__ int32_t s_carry;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
-    if (on) {
-        int before = __popcll(mk & ((1ull << lane) - 1ull));
-        for (int w = 0; w < wid; ++w) before += s_cnt[w];
-        zitems[s_base + before] = it;
+    for (int t0 = 0; t0 < nb; t0 += 1024) {
+        const int i = t0 + threadIdx.x;
+        const int v = i < nb ? bcnt[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const int t = __shfl_up(incl, m, 64);
+            if (lane >= m) incl += t;
+        }
+        if (lane == 63) s_w[wid] = incl;
+        __syncthreads();
+        int before = s_carry;
+        for (int w = 0; w < wid; ++w) before += s_w[w];
+        if (i < nb) bcnt[i] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = before + incl;
+        __syncthreads();
     }
+    if (threadIdx.x == 0) *zicount = s_carry;
+}
+__global__ __launch_bounds__(256) void k_z_scatter(int n_items, const unsigned long long *__restrict__ masks,
+                                                   const int32_t *__restrict__ boff, int32_t *__restrict__ zitems) {
+    const int it = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned long long *mb = masks + (size_t)blockIdx.x * 4;
+    const unsigned long long mk = mb[wid];
+    if (!((mk >> lane) & 1ull) || it >= n_items) return;
+    int before = __popcll(mk & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wid; ++w) before += __popcll(mb[w]);
+    zitems[boff[blockIdx.x] + before] = it;
 }
 __global__ __launch_bounds__(LT_BLOCK) void k_rows_tiled_xf64(
     const int32_t *__restrict__ zitems, const int32_t *__restrict__ zicount, const int32_t *__restrict__ w_e0,
@@ -329,7 +362,11 @@ __global__ __launch_bounds__(LT_BLOCK) void k_rows_tiled_xf64(
     }
 }
 
-// zitems: [g->w_n] scratch for the compacted list, zicount: its device counter (zeroed here)
+// zitems: scratch of lt_xf64_scratch_words(g) int32 words for the compacted list and its construction, zicount: its device counter
+size_t lt_xf64_scratch_words(const lt_graph *g) {
+    const size_t nbz = ((size_t)(g->w_n > 0 ? g->w_n : 1) + 255) / 256;
+    return (size_t)lt_round_up(g->w_n > 0 ? g->w_n : 1, 4) + nbz * 8 + nbz + 16;      // list | 4 x 8-byte masks per block | block counts
+}
 int lt_launch_rows_tiled_xf64(const lt_graph *g, const float *X, int64_t ldx, int ncols, double *out, int64_t ldo,
                               double *seg_out, int64_t ld_seg, const int32_t *state, int32_t *zitems, int32_t *zicount,
                               hipStream_t st) {
@@ -337,16 +374,25 @@ int lt_launch_rows_tiled_xf64(const lt_graph *g, const float *X, int64_t ldx, in
     int ns = (ncols + 4 * LT_TILE_GL - 1) / (4 * LT_TILE_GL);   // 64-column slices: 1, 2, 4, 8
     ns = ns <= 1 ? 1 : (ns == 2 ? 2 : (ns <= 4 ? 4 : 8));
     LT_REQUIRE(ncols <= 4 * LT_TILE_GL * 8 && ldo % 4 == 0 && ld_seg % 4 == 0, "tiled aggregate-first SpMM: ncols=%d", ncols);
-    LT_HIP(hipMemsetAsync(zicount, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_z_items, dim3((unsigned)((g->w_n + 255) / 256)), dim3(256), 0, st, g->w_n, g->w_dst, g->n, g->p_seg_long,
-                       g->p_long_row, state, zitems, zicount);
+    // zitems doubles as the scratch of the compaction: [0, w_n) the list, behind it the flag masks and the block counts
+    const int nbz = (g->w_n + 255) / 256;
+    unsigned long long *masks = reinterpret_cast<unsigned long long *>(zitems + lt_round_up(g->w_n, 4));
+    int32_t *bcnt = reinterpret_cast<int32_t *>(masks + (size_t)nbz * 4);
+    hipLaunchKernelGGL(k_z_flags, dim3((unsigned)nbz), dim3(256), 0, st, g->w_n, g->w_dst, g->n, g->p_seg_long, g->p_long_row, state,
+                       masks, bcnt);
+    hipLaunchKernelGGL(k_z_scan, dim3(1), dim3(1024), 0, st, nbz, bcnt, zicount);
+    hipLaunchKernelGGL(k_z_scatter, dim3((unsigned)nbz), dim3(256), 0, st, g->w_n, masks, bcnt, zitems);
     LT_CHECK_LAUNCH();
     // a fixed grid walks the list (its length stays on the device): as many blocks as the chip holds at once, or the graph needs
     const int xps = 8 / ns;
     constexpr int IPB = (LT_BLOCK / 64) * (64 / LT_TILE_GL);
     const long chunks = ((long)g->w_n + IPB - 1) / IPB;
     long grid = 8 * ((chunks + xps - 1) / xps);
-    if (grid > 8 * 512) grid = 8 * 512;
+    // (how many blocks walk the list at once matters -- more gathers in flight than the L2s hold windows for cost more than idle
+    // CUs do.  BASELINE configs[4], 190 K marked items, per call incl. the rest of the baseline and the 0.76 ms of the probes:
+    // 32 blocks per XCD 4.43 ms, 48: 3.66, 64: 3.07, 96: 3.00, 128: 3.18, 512: 3.33; profiles/r05_xf64_sweep.txt)
+    static const long cap = [] { const char *e = getenv("LT_XF64_BLOCKS"); const long v = e ? atol(e) : 0; return v > 0 ? v : 96L; }();
+    if (grid > 8 * cap) grid = 8 * cap;
     hipLaunchKernelGGL(k_rows_tiled_xf64, dim3((unsigned)grid), dim3(LT_BLOCK), 0, st, zitems, zicount, g->w_e0, g->w_cnt, g->w_dst,
                        g->n, g->col, g->val, X, (long)ldx, ncols, out, (long)ldo, seg_out, (long)ld_seg, ns, g->cv);
     LT_CHECK_LAUNCH();
@@ -396,12 +442,15 @@ int lt_launch_rows_tiled(const lt_graph *g, const float *S, int64_t lds, int nco
     const long grid = 8 * ((chunks + xps - 1) / xps);
     LT_REQUIRE(grid < 2147483647L, "tiled SpMM: grid limit");
     const bool big = lt_tune().tiled_big != 0 || (unsigned long long)g->n * (unsigned long long)lds * 4ull >= (1ull << 32);
+    // LT_TILED_LDS (experiment hook): dynamic LDS nobody uses, to cap the blocks a CU holds at once (40 KB: 4, 53 KB: 3) -- does the
+    // SpMM, like the aggregate-first gathers, run better with fewer gathers in flight than the chip can hold?
+    static const unsigned occ_lds = [] { const char *e = getenv("LT_TILED_LDS"); const long v = e ? atol(e) : 0; return (unsigned)(v > 0 && v <= 65536 ? v : 0); }();
     if (big)
-        hipLaunchKernelGGL(k_rows_tiled<true>, dim3((unsigned)grid), dim3(LT_BLOCK), 0, st, g->w_n, g->w_e0, g->w_cnt, g->w_dst,
+        hipLaunchKernelGGL(k_rows_tiled<true>, dim3((unsigned)grid), dim3(LT_BLOCK), occ_lds, st, g->w_n, g->w_e0, g->w_cnt, g->w_dst,
                            g->n, g->col, g->val, S, (long)lds, ncols, init, bias_after, relu, out, (long)ldo, seg_out,
                            (long)ld_seg, g->p_seg_begin, g->p_seg_long, g->p_long_row, g->rowptr, ns, g->cv);
     else
-        hipLaunchKernelGGL(k_rows_tiled<false>, dim3((unsigned)grid), dim3(LT_BLOCK), 0, st, g->w_n, g->w_e0, g->w_cnt, g->w_dst,
+        hipLaunchKernelGGL(k_rows_tiled<false>, dim3((unsigned)grid), dim3(LT_BLOCK), occ_lds, st, g->w_n, g->w_e0, g->w_cnt, g->w_dst,
                            g->n, g->col, g->val, S, (long)lds, ncols, init, bias_after, relu, out, (long)ldo, seg_out,
                            (long)ld_seg, g->p_seg_begin, g->p_seg_long, g->p_long_row, g->rowptr, ns, g->cv);
     LT_CHECK_LAUNCH();

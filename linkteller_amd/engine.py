@@ -270,6 +270,7 @@ class WideBaseline:
     no `delta`).  Cost model: every (s, t) baseline forms its own X W1[:, s] -- the general route, not the fast one."""
 
     supports_sharding = False       # dist.choose_baseline_sharding: replicated on every rank, no timing loop
+    VEC_BUDGET_BYTES = 256 << 20    # difference vectors of one probe chunk, all hidden slices together
 
     def __init__(self, adj, x, w1, b1, w2, b2):
         self.graph: HipGraph = as_hip_graph(adj)
@@ -347,23 +348,30 @@ class WideBaseline:
         if npb == 0 or nob == 0:
             return out
         self._build()
-        key = (npb, nob)
-        if self._buf.get("key") != key:
-            self._buf = {"key": key, "norm": torch.empty((npb, nob), dtype=torch.float32, device=dev),
-                         "vec": [torch.empty((npb, nob, 8), dtype=torch.float32, device=dev) for _ in self.h_slices]}
         n_s = len(self.h_slices)
+        # probes in chunks: the slices' difference vectors ([chunk, n_obs, 8] fp32 per hidden slice) stay within a fixed budget
+        # (unchunked they took n_slices x n_probe x n_obs x 32 bytes -- 16 GB at 4096^2 pairs and 32 slices)
+        chunk = max(1, min(npb, self.VEC_BUDGET_BYTES // (n_s * nob * 8 * 4)))
+        key = (chunk, nob)
+        if self._buf.get("key") != key:
+            self._buf = {"key": key, "norm": torch.empty((chunk, nob), dtype=torch.float32, device=dev),
+                         "vec": [torch.empty((chunk, nob, 8), dtype=torch.float32, device=dev) for _ in self.h_slices]}
         ptrs = (C.c_void_p * n_s)()
-        for ti, (t0, t1) in enumerate(self.c_slices):
-            ct = t1 - t0
-            for si in range(n_s):
-                sub = self._subs[(si, ti)][0]
-                if m == _lib.MODE_DELTA:
-                    sub.enable_fp64()
-                vec = self._buf["vec"][si]          # used as [npb, nob, ct] dense
-                sub.influence_rows_vec(probes, obs, delta, m, self._buf["norm"], vec)
-                ptrs[si] = vec.data_ptr()
-            _lib.check(_lib.lib().lt_wide_combine(ptrs, n_s, npb * nob, ct, float(delta), out.data_ptr(), int(ti == 0),
-                                                  int(ti == len(self.c_slices) - 1), _stream()), "lt_wide_combine")
+        for p0 in range(0, npb, chunk):
+            pc = probes[p0:p0 + chunk]
+            nb = pc.numel()
+            orow = out[p0:p0 + nb]
+            for ti, (t0, t1) in enumerate(self.c_slices):
+                ct = t1 - t0
+                for si in range(n_s):
+                    sub = self._subs[(si, ti)][0]
+                    if m == _lib.MODE_DELTA:
+                        sub.enable_fp64()
+                    vec = self._buf["vec"][si]          # used as [nb, nob, ct] dense
+                    sub.influence_rows_vec(pc, obs, delta, m, self._buf["norm"], vec)
+                    ptrs[si] = vec.data_ptr()
+                _lib.check(_lib.lib().lt_wide_combine(ptrs, n_s, nb * nob, ct, float(delta), orow.data_ptr(), int(ti == 0),
+                                                      int(ti == len(self.c_slices) - 1), _stream()), "lt_wide_combine")
         return out
 
 

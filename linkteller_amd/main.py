@@ -75,6 +75,9 @@ def init_distributed():
         return False
     rank = int(os.environ.get("RANK", "0"))
     if "MASTER_PORT" not in os.environ:
+        if world > 1:      # (a port invented per rank would differ on every rank: the rendezvous would hang until the store timeout)
+            raise RuntimeError("WORLD_SIZE > 1 but MASTER_PORT is not set: launch the ranks with torchrun "
+                               "(python -m torch.distributed.run --nproc-per-node N -m linkteller_amd.main ...)")
         import socket
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))

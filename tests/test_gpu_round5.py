@@ -170,3 +170,23 @@ def test_api_out_of_range_test_node_raises_index_error(gpu):
     atk.test_nodes[5] = 700
     with pytest.raises(IndexError):
         atk.influence_matrix()
+
+
+@pytest.mark.parametrize("mode", ["delta", "sparse"])
+def test_wide_baseline_probe_chunks_keep_every_bit(gpu, mode, monkeypatch):
+    """engine.WideBaseline serves the probes in chunks so that the slices' difference vectors stay inside a fixed budget
+    (ADVICE r4); a budget of a few probes per chunk must give the bits of one chunk."""
+    from linkteller_amd import engine, graph, synth
+    n, f, h, c = 300, 80, 320, 12
+    a_hat = graph.first_order_gcn(synth.powerlaw_graph(n, 1400, seed=3))
+    x = torch.from_numpy(synth.gaussian_features(n, f, seed=4)).to(gpu)
+    w = synth.gcn_weights(f, h, c, seed=5)
+    rng = np.random.RandomState(1)
+    probes, obs = rng.choice(n, 37, replace=False), rng.choice(n, 50, replace=False)
+    base = engine.baseline_for(graph.HipGraph(a_hat), x, *_params(w, gpu))
+    assert isinstance(base, engine.WideBaseline)
+    whole = base.influence_rows(probes, obs, 1e-4, mode).clone()
+    monkeypatch.setattr(engine.WideBaseline, "VEC_BUDGET_BYTES", 2 * 50 * 8 * 4 * 5)      # 5 probes per chunk (2 hidden slices)
+    base2 = engine.baseline_for(graph.HipGraph(a_hat), x, *_params(w, gpu))
+    chunked = base2.influence_rows(probes, obs, 1e-4, mode)
+    assert base2._buf["key"][0] == 5 and torch.equal(chunked, whole)
