@@ -923,6 +923,13 @@ def main():
         scaling = {"note": "strong scaling: the same problem at every rank count, probes sharded contiguously over the ranks, one all-gather "
                            "of row slabs per step; ms_per_step = loop-invariant baseline of the mode + this rank's probes + the all-gather, "
                            "MAX over ranks, median block; collective_us = that all-gather alone (HIP events)",
+                   "expectation": "configs[1] / [2] in the default mode CANNOT scale, by construction, and a first real N > 1 run must not be read as "
+                                  "a regression: the step is a ~45 us job of which ~33 us is the loop-invariant baseline every rank repeats (one pass "
+                                  "over X + the pre-activation) and the rest one latency-bound block per probe.  One-GPU emulation of one rank's step "
+                                  "(tools/shard_step_time.py, profiles/r04_shard_step.txt, before any collective): n_test = 500: 44.5 us at 1 rank -> "
+                                  "39.9 / 39.3 / 39.5 at 2 / 4 / 8 ranks (1.13x); n_test = 2000: 67.7 -> 51.1 / 45.8 / 41.0 (1.65x); the all-gather "
+                                  "adds 26-38 us (measured under RCCL at world size 1).  configs[4] is the config where sharding pays: one rank's "
+                                  "512 x 4096 share of the R-MAT build is roofline_spmm.influence_shard (3.0 ms against 23.5 for all 4096 probes on one GPU)",
                    "mode": a.mode, "n_gpus": world}
         scaling["configs[1]"] = {"workload": f"n_test={a.n_test} (the `value` workload)", "ms_per_step": round(ms_per_step, 4),
                                  "pairs_per_s": round(value, 1), "probes_per_rank": per, "collective_us": collective_us(per, a.n_test)}

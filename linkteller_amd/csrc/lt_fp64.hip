@@ -341,6 +341,25 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
         if constexpr (QNT) return (double)__builtin_bit_cast(qx4, sv)[k];
         else return (double)sv[k];
     };
+    if constexpr (QNT) {
+        // sixteen in flight for the 16-byte fixed-point rows (round 5): a row or segment of 128 entries is 8 dependent trips instead
+        // of 16 -- on a graph with rows of 64 .. 128 entries those lane groups are the launch (19 us against 11 for the same graph
+        // size without them); the fma chain stays in entry order: same bits
+        for (; e + 16 <= e1; e += 16) {
+            double a[16];
+            sx4 s[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int c = col[e + j];
+                a[j] = (double)val[e + j] * Sq[c];
+                s[j] = *reinterpret_cast<const sx4 *>(S + (size_t)c * ld + coff);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] = fma(a[j], term(s[j], k), acc[k]);
+        }
+    }
     for (; e + 8 <= e1; e += 8) {   // eight gathers in flight (a trip costs one L2 / Infinity-Cache latency); entry order kept
         double a[8];
         sx4 s[8];
@@ -407,8 +426,24 @@ __global__ void k_spmm_f64_long(int n_long, const int32_t *__restrict__ long_row
     if (i >= (long)n_long * ld) return;
     const int li = (int)(i / ld), c = (int)(i % ld);
     if (state && state[long_row[li]] != 2) return;
-    double acc = part[(size_t)long_segptr[li] * ld + c];
-    for (int sg = long_segptr[li] + 1; sg < long_segptr[li + 1]; ++sg) acc += part[(size_t)sg * ld + c];
+    // (segment order; eight loads in flight -- as k_y_long: one dependent load per segment was most of this launch's 5 us)
+    const int s0 = long_segptr[li], s1 = long_segptr[li + 1];
+    double acc = part[(size_t)s0 * ld + c];
+    int sg = s0 + 1;
+    for (; sg + 8 <= s1; sg += 8) {
+        double v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = part[(size_t)(sg + t) * ld + c];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc += v[t];
+    }
+    if (sg < s1) {      // (the tail in one trip too: loads past the row's last segment read the last again and are not added)
+        double v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = part[(size_t)min(sg + t, s1 - 1) * ld + c];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) if (sg + t < s1) acc += v[t];
+    }
     if (crefv) acc = fma(rs[long_row[li]], crefv[c], acc);
     if (outf) outf[(size_t)long_row[li] * ld + c] = (float)(acc + (double)b1p[c]);      // (as k_spmm_f64's outf)
     else out[(size_t)long_row[li] * ld + c] = acc + (double)b1p[c];

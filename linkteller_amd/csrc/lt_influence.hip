@@ -991,11 +991,14 @@ __device__ __forceinline__ void stageB_long_block(
     // log |R_v| loads without; the search from the R_v side costs |R_v| / (8 NS) rounds of log d loads
     const int lg_d = 32 - __clz(d), lg_c = 32 - __clz(cnt > 1 ? cnt : 1);
     // with a bitmap row, in dependent rounds: the walk is d / (8 lanes * UN) of them, the search (lg d + 2) per 64 members
-    // COOP (the whole block finds a heavy probe's members, below): a pass over the row costs ~1.5 us per 1024 entries whatever the
-    // probe, the search from the R_v side (cnt / 64) rounds of lg d DEPENDENT loads (~0.7 us each) -- the walk wins from
-    // cnt lg d > d / 8 on (BASELINE configs[4]: probes of 2 442 and 2 314 neighbours against the 49 489-entry observed hub counted as
-    // light under the old rule, 39 rounds x 16 steps each: 0.7 ms, the whole launch)
-    const bool heavy = live && (!SHORT || (mb ? (COOP ? 8L * cnt * lg_d > d
+    // COOP (the whole block finds a heavy probe's members, below): a pass over the row costs ~2 us per CHUNK entries whatever the
+    // probe; the search from the R_v side costs, per round of 64 members, lg(sample) LDS steps (~0.3 us together) and samp_sh
+    // DEPENDENT global loads (~0.7 us each) -- a row of up to CHUNK entries sits in LDS whole and is never worth a pass.
+    // (BASELINE configs[4]: probes of 2 442 and 2 314 neighbours against the 49 489-entry observed hub counted as light under the
+    // round-4 rule "cnt lg d > d": 39 rounds x 16 global steps each, 0.7 ms, the whole launch)
+    int samp_sh = 0;
+    if constexpr (COOP) { while ((d >> samp_sh) > CHUNK) ++samp_sh; }
+    const bool heavy = live && (!SHORT || (mb ? (COOP ? (long)((cnt + 63) / 64) * (3 + 7 * samp_sh) > 20L * ((d + CHUNK - 1) / CHUNK)
                                                       : ((DELTA && WIDE) ? (long)((cnt + 63) / 64) * (lg_d + 2) > (d + LT_L2_LANES * UN - 1) / (LT_L2_LANES * UN)
                                                                          : (long)cnt * lg_d > d))
                                               : 2L * cnt * lg_d > (long)d * lg_c));
@@ -1007,9 +1010,8 @@ __device__ __forceinline__ void stageB_long_block(
         if (coop && q == 0) { atomicOr(&s_hmask, 1u << grp); s_mb[grp] = mb; s_items[grp] = items; }
     }
     const int32_t *cu = col + e0;
-    int samp_sh = 0, n_samp = 0;
+    int n_samp = 0;
     if constexpr (COOP) {       // the search sample of this observed hub (block-uniform; sc is restaged by the walk afterwards)
-        while ((d >> samp_sh) > CHUNK) ++samp_sh;
         n_samp = d >> samp_sh;
         for (int i = tid; i < n_samp; i += LT_BLOCK) sc[i] = cu[((i + 1) << samp_sh) - 1];
         __syncthreads();
@@ -2459,16 +2461,17 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
                 job.n = n; job.err = node_err; job.probes_s = w.probes_s + p0; job.obs_s = w.obs_s;
                 job.nblocks = nb + 1;
             }
+            job.smem_bytes = (w.bits || w.big_bits) ? lt_item_bits_smem(words) : 0u;      // the bitmap row built in LDS when it fits
             if (mode == LT_MODE_DELTA && b->Z1d && !lt_fp64_agg_active(b) && !use_marks) {
                 const int rc = lt_fp64_prepare_rows(b, w.off, nb, w.item_pr, n_probe, st, &job, &bits_done);
                 if (rc) return rc;
             }
             { lt_prof_scope prof_(LT_K_ITEM_BITS, st, !bits_done || use_marks);   // (nothing to time when the tables rode along)
             if (!bits_done) {
-                hipLaunchKernelGGL(k_item_bits, dim3((unsigned)job.nblocks), dim3(256), 0, st, g->tptr, g->trow, probes, nb, words,
+                hipLaunchKernelGGL(k_item_bits, dim3((unsigned)job.nblocks), dim3(256), job.smem_bytes, st, g->tptr, g->trow, probes, nb, words,
                                    w.bits, w.off, w.item_pr, w.big_bits, w.big_slot, job.big_count,
                                    g->rowptr, observe_nodes, n_obs, job.hub_obs, g->tval, w.item_va, job.n, job.err, job.probes_s,
-                                   job.obs_s);
+                                   job.obs_s, job.smem_bytes ? words : 0);
                 LT_CHECK_LAUNCH();
             }
             if (inline_check) {      // from here on: the checked lists

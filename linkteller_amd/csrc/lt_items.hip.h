@@ -63,7 +63,10 @@ static __device__ __forceinline__ void item_bits_block(const int bid, const int3
                                                        int32_t *__restrict__ hub_obs, const float *__restrict__ tval = nullptr,
                                                        int2 *__restrict__ item_va = nullptr, int n_check = 0,
                                                        int32_t *__restrict__ err = nullptr, int32_t *__restrict__ probes_s = nullptr,
-                                                       int32_t *__restrict__ obs_s = nullptr) {
+                                                       int32_t *__restrict__ obs_s = nullptr, uint2 *lds_row = nullptr) {
+    // lds_row != NULL (the launch's dynamic LDS, >= words * 8 bytes: graphs whose bitmap row fits LT_IB_LDS_BYTES): the probe's bitmap
+    // row is built in LDS and written out once -- two GLOBAL atomics per item made a probed hub's block (1 749 items on the
+    // power-law co-headline graph) the long pole of the launch that carries these blocks (round 5)
     // One block more than probes (hub_obs != NULL or obs_s != NULL): it lists the observed nodes that are hub rows, hub_obs[0] =
     // how many, hub_obs[1 ...] = their positions j in `observe` (any order) -- stage B launches its hub blocks for those alone --
     // and writes the checked observed list (obs_s) for the kernels behind this one.
@@ -110,7 +113,8 @@ static __device__ __forceinline__ void item_bits_block(const int bid, const int3
         if (big_slot) big_slot[b] = slot;
     }
     __syncthreads();
-    uint2 *mine = bits ? bits + (size_t)b * words : (s_slot >= 0 ? big_bits + (size_t)s_slot * words : nullptr);
+    uint2 *const mine_g = bits ? bits + (size_t)b * words : (s_slot >= 0 ? big_bits + (size_t)s_slot * words : nullptr);
+    uint2 *mine = (mine_g && lds_row) ? lds_row : mine_g;
     if (mine)
         for (int i = threadIdx.x; i < words; i += blockDim.x) mine[i] = make_uint2(0u, 0xffffffffu);
     __syncthreads();
@@ -131,7 +135,13 @@ static __device__ __forceinline__ void item_bits_block(const int bid, const int3
         // ... and (probe node, A_hat[r, v]): DELTA stage A would otherwise chase probes[b] -> tptr[v] -> tval[t] per item
         if (item_va) item_va[my_off + (t - t0)] = make_int2(v, __float_as_int(tval[t]));
     }
+    if (mine_g && mine != mine_g) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < words; i += blockDim.x) mine_g[i] = mine[i];
+    }
 }
+#define LT_IB_LDS_BYTES (16 * 1024)      // bitmap rows of up to this many bytes (n <= 65536 nodes) are built in LDS
+static inline unsigned lt_item_bits_smem(int words) { return (size_t)words * sizeof(uint2) <= LT_IB_LDS_BYTES ? (unsigned)(words * sizeof(uint2)) : 0u; }
 static __global__ __launch_bounds__(256) void k_item_bits(const int32_t *__restrict__ tptr, const int32_t *__restrict__ trow,
                                                    const int32_t *__restrict__ probes, int nb, int words,
                                                    uint2 *__restrict__ bits, int32_t *__restrict__ off,
@@ -142,9 +152,11 @@ static __global__ __launch_bounds__(256) void k_item_bits(const int32_t *__restr
                                                    int32_t *__restrict__ hub_obs = nullptr, const float *__restrict__ tval = nullptr,
                                                    int2 *__restrict__ item_va = nullptr, int n_check = 0,
                                                    int32_t *__restrict__ err = nullptr, int32_t *__restrict__ probes_s = nullptr,
-                                                   int32_t *__restrict__ obs_s = nullptr) {
+                                                   int32_t *__restrict__ obs_s = nullptr, int lds_words = 0) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ib_smem[];      // (lds_words * 8 bytes when the bitmap row fits)
     item_bits_block((int)blockIdx.x, tptr, trow, probes, nb, words, bits, off, item_pr, big_bits, big_slot, big_count, rowptr, observe,
-                    n_obs, hub_obs, tval, item_va, n_check, err, probes_s, obs_s);
+                    n_obs, hub_obs, tval, item_va, n_check, err, probes_s, obs_s,
+                    lds_words >= words ? reinterpret_cast<uint2 *>(ib_smem) : (uint2 *)nullptr);
 }
 // ---- the fused DELTA route, first half: a probe's INCIDENCE RECORD (round 4) -----------------------------------------------
 // Everything about a probe v that depends on the graph alone is a property of NODE v, built once by lt_graph_create
@@ -225,7 +237,8 @@ static __device__ __forceinline__ void item_bits_block(const int bid, const lt_b
         return;
     }
     item_bits_block(bid, j.tptr, j.trow, j.probes, j.nb, j.words, j.bits, j.off, j.item_pr, j.big_bits, j.big_slot, j.big_count, j.rowptr,
-                    j.observe, j.n_obs, j.hub_obs, j.tval, j.item_va, j.n, j.err, j.probes_s, j.obs_s);
+                    j.observe, j.n_obs, j.hub_obs, j.tval, j.item_va, j.n, j.err, j.probes_s, j.obs_s,
+                    (smem && j.smem_bytes >= (unsigned)j.words * sizeof(uint2) && j.smem_bytes > 0) ? reinterpret_cast<uint2 *>(smem) : (uint2 *)nullptr);
 }
 // position of column c in R_v from the probe's bitmap row, or -1
 __device__ __forceinline__ int bits_pos(const uint2 *__restrict__ mb, int c) {
