@@ -959,7 +959,9 @@ __device__ __forceinline__ void stageB_long_block(
     __shared__ const uint2 *s_mb[COOP ? GROUPS : 1];
     __shared__ const float *s_items[COOP ? GROUPS : 1];
     __shared__ int s_wc[COOP ? (CHUNK / LT_BLOCK) * (LT_BLOCK / 64) : 1];
-    __shared__ unsigned s_hmask;
+    __shared__ unsigned s_hmask, s_bmask;
+    __shared__ const int32_t *s_rv[COOP ? GROUPS : 1];
+    __shared__ int s_cnt[COOP ? GROUPS : 1];
     const int pblocks = (nb + GROUPS - 1) / GROUPS;
     // the launch has blocks for hub_cap = min(n_obs, hub rows of the graph) observed hubs; hub_obs (k_item_bits) lists the
     // positions there are -- MORE than hub_cap when observe_nodes repeats a hub (a star graph observed twice): a block then
@@ -1002,12 +1004,33 @@ __device__ __forceinline__ void stageB_long_block(
                                                       : ((DELTA && WIDE) ? (long)((cnt + 63) / 64) * (lg_d + 2) > (d + LT_L2_LANES * UN - 1) / (LT_L2_LANES * UN)
                                                                          : (long)cnt * lg_d > d))
                                               : 2L * cnt * lg_d > (long)d * lg_c));
-    const bool light = live && !heavy;
-    const bool coop = COOP && heavy && mb != nullptr;           // (group-uniform)
+    // COOP, a third way (round 5): the WHOLE BLOCK searches a big probe's R_v in the row -- CHUNK members per pass, a handful of
+    // two-level searches per thread in flight, the finds compacted in R_v (= entry) order and added by the probe's chain lanes.
+    // What a round of the probe's own 8-lane search costs is its dependent trips under a chip full of such blocks, ~10 us whatever
+    // the row (tools/stageb_lab2.py, BASELINE configs[4]: the eight probes of 714 .. 2 442 neighbours against the 138 observed hubs
+    // of under 1 000 entries -- rows that sit in LDS whole -- were 0.68 of the launch's 0.78 ms, 12 .. 39 rounds each; against the
+    // 49 489-entry hub 39 rounds x 16 global steps, 0.7 ms); a block pass over CHUNK members ~20 us, one big probe after the other; a
+    // pass over the row (needs a bitmap row) ~5 us per CHUNK entries.  So: up to four rounds a probe searches for itself (the 32
+    // probes of a block side by side), beyond that the cheaper of the two block forms.
+    bool bsearch = false;
+    bool heavy_ = heavy;
+    if constexpr (COOP) {
+        if (live) {
+            if ((cnt + 63) / 64 > 4) {
+                const long c_block = (long)((cnt + CHUNK - 1) / CHUNK) * (20 + 7 * samp_sh);
+                const long c_walk = mb ? 5L * ((d + CHUNK - 1) / CHUNK) : (1L << 40);
+                bsearch = c_block <= c_walk;
+                heavy_ = !bsearch;            // (mb != NULL then: the walk was the cheaper one)
+            } else heavy_ = false;
+        }
+    }
+    const bool light = live && !heavy_ && !bsearch;
+    const bool coop = COOP && heavy_ && mb != nullptr;          // (group-uniform)
     if (COOP) {
-        if (tid == 0) s_hmask = 0u;
+        if (tid == 0) { s_hmask = 0u; s_bmask = 0u; }
         __syncthreads();
         if (coop && q == 0) { atomicOr(&s_hmask, 1u << grp); s_mb[grp] = mb; s_items[grp] = items; }
+        if (bsearch && q == 0) { atomicOr(&s_bmask, 1u << grp); s_rv[grp] = rv; s_cnt[grp] = cnt; s_items[grp] = items; }
     }
     const int32_t *cu = col + e0;
     int n_samp = 0;
@@ -1050,11 +1073,16 @@ __device__ __forceinline__ void stageB_long_block(
                 for (int k = 0; k < LT_SBL_NS; ++k) base[k] = cu[min(base[k] + half - 1, d - 1)] < key[k] ? base[k] + half : base[k];
                 nrem -= half;
             }
+            if (samp_sh == 0) {         // the row sits in LDS whole: no global trip at all
 #pragma unroll
-            for (int k = 0; k < LT_SBL_NS; ++k) {
-                const int cb_ = cu[min(base[k], d - 1)];
-                if (base[k] < d && cb_ < key[k]) ++base[k];
-                fe[k] = (base[k] < d && cu[min(base[k], d - 1)] == key[k]) ? base[k] : -1;
+                for (int k = 0; k < LT_SBL_NS; ++k) fe[k] = (base[k] < d && sc[min(base[k], d - 1)] == key[k]) ? base[k] : -1;
+            } else {
+#pragma unroll
+                for (int k = 0; k < LT_SBL_NS; ++k) {
+                    const int cb_ = cu[min(base[k], d - 1)];
+                    if (base[k] < d && cb_ < key[k]) ++base[k];
+                    fe[k] = (base[k] < d && cu[min(base[k], d - 1)] == key[k]) ? base[k] : -1;
+                }
             }
         } else {
         // branch-free lower bound over cu[0, d): LT_SBL_NS independent searches per lane, one load each per step
@@ -1115,8 +1143,117 @@ __device__ __forceinline__ void stageB_long_block(
         if (DELTA) while (r_next < cnt) search_round();
         else fill(0);
     }
+    // ---- big probes searched by the whole block (the sample is still in sc; sv / sT / s_mem are free until the walk) ----------
+    if constexpr (COOP) {
+        constexpr int SL = CHUNK / LT_BLOCK, NW = LT_BLOCK / 64;
+        __syncthreads();                                        // (the groups' own searches are done: s_bmask, s_rv, s_cnt are set)
+        for (unsigned bm_ = s_bmask; bm_ != 0u; bm_ &= bm_ - 1u) {              // (block-uniform)
+            const int g = __ffs((int)bm_) - 1;
+            const int32_t *rvg = s_rv[g];
+            const int cg = s_cnt[g];
+            const float *itg = s_items[g];
+            for (int p0_ = 0; p0_ < cg; p0_ += CHUNK) {
+                int key[SL], base[SL], fe[SL];
+#pragma unroll
+                for (int k = 0; k < SL; ++k) {
+                    const int idx = p0_ + k * LT_BLOCK + tid;
+                    key[k] = idx < cg ? rvg[idx] : 0x7fffffff;
+                    base[k] = 0;
+                }
+                for (int nrem = n_samp; nrem > 1;) {
+                    const int half = nrem >> 1;
+#pragma unroll
+                    for (int k = 0; k < SL; ++k) base[k] = sc[base[k] + half - 1] < key[k] ? base[k] + half : base[k];
+                    nrem -= half;
+                }
+#pragma unroll
+                for (int k = 0; k < SL; ++k) {
+                    if (n_samp > 0 && sc[base[k]] < key[k]) ++base[k];
+                    base[k] <<= samp_sh;
+                }
+                for (int nrem = 1 << samp_sh; nrem > 1;) {
+                    const int half = nrem >> 1;
+#pragma unroll
+                    for (int k = 0; k < SL; ++k) base[k] = cu[min(base[k] + half - 1, d - 1)] < key[k] ? base[k] + half : base[k];
+                    nrem -= half;
+                }
+                unsigned long long bmk[SL];
+#pragma unroll
+                for (int k = 0; k < SL; ++k) {
+                    if (samp_sh == 0) {
+                        fe[k] = (base[k] < d && sc[min(base[k], d - 1)] == key[k]) ? base[k] : -1;
+                    } else {
+                        const int cb_ = cu[min(base[k], d - 1)];
+                        if (base[k] < d && cb_ < key[k]) ++base[k];
+                        fe[k] = (base[k] < d && cu[min(base[k], d - 1)] == key[k]) ? base[k] : -1;
+                    }
+                    bmk[k] = __ballot(fe[k] >= 0);
+                    if ((tid & 63) == 0) s_wc[k * NW + (tid >> 6)] = __popcll(bmk[k]);
+                }
+                __syncthreads();
+                int nm = 0;
+#pragma unroll
+                for (int k = 0; k < SL; ++k) {
+                    int before = 0;
+#pragma unroll
+                    for (int w_ = 0; w_ < NW; ++w_) {
+                        const int cw = s_wc[k * NW + w_];
+                        before += w_ < (tid >> 6) ? cw : 0;
+                        nm += cw;
+                    }
+                    if (fe[k] >= 0) {
+                        int slot = before + __popcll(bmk[k] & ((1ull << (tid & 63)) - 1ull));
+#pragma unroll
+                        for (int k2 = 0; k2 < SL; ++k2)
+                            if (k2 < k)
+#pragma unroll
+                                for (int w_ = 0; w_ < NW; ++w_) slot += s_wc[k2 * NW + w_];
+                        s_mem[slot] = make_int2(fe[k], p0_ + k * LT_BLOCK + tid);     // (entry, position in R_v): ascending in both
+                    }
+                }
+                __syncthreads();
+                for (int m = tid; m < nm; m += LT_BLOCK) {      // the members' values and item rows, one trip for the block
+                    const int2 me_ = s_mem[m];
+                    sv[m] = val[e0 + me_.x];
+                    const float *t = itg + (size_t)me_.y * C;
+#pragma unroll
+                    for (int c = 0; c < CP; ++c) sT[m][c] = c < C ? t[c] : 0.f;
+                }
+                __syncthreads();
+                if (grp == g && nm > 0) {                       // the probe's own lanes: chain (entry & 7), entry order
+                    touch = true;
+                    int m = 0;
+                    for (; m + 8 <= nm; m += 8) {
+                        int ex[8];
+                        float a8[8], t8[8][CP];
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) {
+                            ex[x] = s_mem[m + x].x;
+                            a8[x] = sv[m + x];
+#pragma unroll
+                            for (int c = 0; c < CP; ++c) t8[x][c] = sT[m + x][c];
+                        }
+#pragma unroll
+                        for (int x = 0; x < 8; ++x)
+                            if ((ex[x] & (LT_L2_LANES - 1)) == q) {
+#pragma unroll
+                                for (int c = 0; c < CP; ++c)
+                                    if (c < C) acc[c] = fmaf(a8[x], t8[x][c], acc[c]);
+                            }
+                    }
+                    for (; m < nm; ++m)
+                        if ((s_mem[m].x & (LT_L2_LANES - 1)) == q) {
+#pragma unroll
+                            for (int c = 0; c < CP; ++c)
+                                if (c < C) acc[c] = fmaf(sv[m], sT[m][c], acc[c]);
+                        }
+                }
+                __syncthreads();
+            }
+        }
+    }
     // ---- the walk: heavy probes test every entry, SPARSE light probes with members re-sum the row against their list
-    const bool walk = live && (heavy || (!DELTA && nmem > 0));
+    const bool walk = live && (heavy_ || (!DELTA && nmem > 0));
     if (__syncthreads_or(walk ? 1 : 0)) {
         // SPARSE light (all group-uniform): mg = first listed member not yet behind the group, next_e = its entry,
         // last_e = the entry of the last listed member
@@ -1238,7 +1375,7 @@ __device__ __forceinline__ void stageB_long_block(
                     for (int c = 0; c < CP; ++c)
                         if (!DELTA) tb[k][c] = ii < nc ? sT[ii][c] : 0.f;
                 }
-                if (heavy && mb) {
+                if (heavy_ && mb) {
                     // the membership words of UN entries in flight together: unconditional loads (past the chunk end: its
                     // last entry again) -- hipcc drains the queue in front of every load it finds behind a branch
                     uint2 wv[UN];
@@ -1253,7 +1390,7 @@ __device__ __forceinline__ void stageB_long_block(
                         const unsigned bit = 1u << (cv[k] & 31);
                         if (i + k * LT_L2_LANES < nc && (wv[k].x & bit)) mp[k] = (int)(wv[k].y + __popc(wv[k].x & (bit - 1u)));
                     }
-                } else if (heavy) {
+                } else if (heavy_) {
 #pragma unroll
                     for (int k = 0; k < UN; ++k) {
                         const int ii = i + k * LT_L2_LANES;

@@ -479,9 +479,6 @@ def test_gcn3_delta_mode_against_the_fp64_oracle(gpu, h1, h2, c, hub, features):
     assert np.abs(got2 - ref2).max() <= 1e-5 * ref2.max()
 
 
-_HUB_REF = {}
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("long_par,p", [(1, 32), (1, 16), (0, 16)])
 def test_full_mode_on_a_hub_of_many_segments(gpu, long_par, p):
@@ -519,27 +516,20 @@ def test_full_mode_on_a_hub_of_many_segments(gpu, long_par, p):
         _lib.set_tuning("long_par", None)
     assert np.array_equal(f, s_)
     assert np.isfinite(f).all() and f.max() > 0 and (f[:, 0] > 0).sum() > 50      # the hub sees every probe (some of the fp32 differences round to 0)
-    # the reference path on ALL 100 probe rows, fp32 and fp64 (once: the three parametrisations produce the same bits)
-    if "ref" not in _HUB_REF:
-        adj_o = O.to_torch_sparse(a_hat)
-        for dt in (torch.float32, torch.float64):
-            P = {k: torch.from_numpy(w[k]).to(dt) for k in ("W1", "b1", "W2", "b2")}
-            out = np.zeros((len(probes), len(obs)))
-            with torch.no_grad():
-                for i, v in enumerate(probes):
-                    gm = O.get_gradient_eps_mat(torch.from_numpy(x).to(dt), adj_o.to(dt), P, int(v), 1e-4)
-                    out[i] = gm[torch.as_tensor(obs.astype(np.int64))].norm(dim=1).double().numpy()
-            _HUB_REF[dt] = out
-        _HUB_REF["ref"] = True
-    ref64, ref32 = _HUB_REF[torch.float64], _HUB_REF[torch.float32]
+    # the REFERENCE's own fp32 scores and the fp64 evaluation on all 100 probe rows: tests/golden/hub_noise.npz (generated from the
+    # imported reference by tests/golden/generate_hub_noise.py -- its get_gradient_eps_mat on torch's CPU kernels, one thread)
+    from conftest import load_golden
+    hg = load_golden("hub_noise.npz")
+    assert np.array_equal(hg["probes"], probes) and np.array_equal(hg["obs"], obs)
+    ref64, ref32 = hg["ref64"], hg["ref32"].astype(np.float64)
     ours = np.abs(f.astype(np.float64) - ref64).max(axis=1)
     theirs = np.abs(ref32 - ref64).max(axis=1)
-    # A 9 500-term fp32 sum in two different orders (8 strided chains of 128-entry segments here, sequential in torch.spmm): the
-    # pair (probe, hub) carries the hub's ulp-quantised logit difference / 1e-4 -- a few 1e-3 per ulp -- in both.  Measured over the
-    # 100 rows (round 5, tools/hub_noise.py): row maxima rms 0.0273 against the reference's 0.0145 (1.9x: at the hub column our
-    # noise is twice the reference's, on every other column 0.8x of it), largest row 0.067 against 0.060.  Gates (a
-    # row-by-row bound again, so that no row hides behind its neighbours): every row within 4x its own reference error or 5x the
-    # reference's rms, the rms of the row maxima within 2x the reference's, the worst row within 2x the reference's worst.
+    # A 9 500-term fp32 sum in two different orders (8 strided chains here, sequential in torch.spmm): the pair (probe, hub) carries
+    # the hub's ulp-quantised logit difference / 1e-4 -- a few 1e-3 per ulp -- in both, and the reference's own figure moves with
+    # the host it runs on (row maxima rms 0.0210 on the build container's Xeon, 0.0145 on the GPU box's EPYC for the oracle's port).
+    # Measured (round 5, tools/hub_noise.py): ours 0.0273, worst row 0.067 against 0.055.  Gates (row by row again, so
+    # that no row hides behind its neighbours): every row within 4x its own reference error or 5x the reference's rms, the rms of the
+    # row maxima within 2x the reference's, the worst row within 2x the reference's worst.
     rms_o, rms_t = float(np.sqrt((ours ** 2).mean())), float(np.sqrt((theirs ** 2).mean()))
     print(f"hub rows: |full - ref64| row maxima rms {rms_o:.5f} max {ours.max():.5f}; reference fp32 rms {rms_t:.5f} max {theirs.max():.5f}")
     for i, (o, t) in enumerate(zip(ours, theirs)):

@@ -27,14 +27,25 @@ def kernel_ms(name):
     tot, cnt = C.c_double(0), C.c_int64(0)
     _lib.check(_lib.lib().lt_profile_summary(_lib.KERNEL_IDS[name], C.byref(tot), C.byref(cnt)))
     return tot.value / max(cnt.value, 1)
-sets = {"all hubs": hub_idx, "no hubs": np.array([], int), "top 1 only": order[:1], "top 8 only": order[:8], "all but top 8": order[8:],
+small_h = hub_idx[deg[obs_all][hub_idx] < 1000]
+sets = {"20 small hubs": small_h[:20], "60 small hubs": small_h[:60], "all hubs": hub_idx, "no hubs": np.array([], int), "top 1 only": order[:1], "top 8 only": order[:8], "all but top 8": order[8:],
         "hubs of < 1000 entries": hub_idx[deg[obs_all][hub_idx] < 1000]}
-for mode in ("delta", "sparse"):
+for mode in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("delta", "sparse")):
     for name, keep in sets.items():
         o = variant(keep)
         base.influence_rows(probes, o, 1e-4, mode); torch.cuda.synchronize()
         _lib.lib().lt_profile_reset(); _lib.lib().lt_profile_enable(0x1ff)
         for _ in range(3): base.influence_rows(probes, o, 1e-4, mode)
         torch.cuda.synchronize()
+        if name == "hubs of < 1000 entries":      # the same without the eight biggest probes
+            pr2 = probes[np.argsort(deg[probes])[:-8]]
+            base.influence_rows(pr2, o, 1e-4, mode); torch.cuda.synchronize()
+            _lib.lib().lt_profile_reset(); _lib.lib().lt_profile_enable(0x1ff)
+            for _ in range(3): base.influence_rows(pr2, o, 1e-4, mode)
+            torch.cuda.synchronize()
+            print(f'{mode:6s} {name:24s} WITHOUT the 8 biggest probes: stage B {kernel_ms("item_stageB"):.3f} ms')
+            _lib.lib().lt_profile_reset(); _lib.lib().lt_profile_enable(0x1ff)
+            for _ in range(3): base.influence_rows(probes, o, 1e-4, mode)
+            torch.cuda.synchronize()
         print(f'{mode:6s} {name:24s} ({len(keep):3d} hubs, {int(deg[obs_all][keep].sum()) if len(keep) else 0:7d} entries): stage B {kernel_ms("item_stageB"):.3f} ms')
         _lib.lib().lt_profile_enable(0)
