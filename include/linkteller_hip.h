@@ -95,6 +95,9 @@ int lt_device_count(int *count);
  *                         without hub rows), calls whose pre-activation is formed on all rows: 1 = stage A and stage B of a probe in
  *                         ONE block, from the probe node's record matched against the observed list inside the pre-activation's
  *                         launch (default), 0 = the item kernels.  Bit-identical
+ *   "records_early"       "delta_fused" route: 1 = the record blocks of a call's first probe chunk ride in the launch that forms the fp64
+ *                         product rows whenever that launch runs (a refreshed baseline on the feature-difference route: CU slots to
+ *                         spare, seven times the duration) (default), 0 = in the pre-activation's launch.  Bit-identical
  *   "defer_cref"          feature-difference route: 1 = the reference vector's product m W1 is formed by extra blocks of the rows'
  *                         launch and added by the readers of S1d (the fp64 SpMM, stage A) (default), 0 = formed first and added
  *                         by the rows kernel.  fp64 summation order only, like "feature_delta"

@@ -55,6 +55,7 @@ static lt_tuning tuning_defaults() {
     t.aggregate_first = getenv("LT_AGGREGATE_FIRST") ? (env_ll("LT_AGGREGATE_FIRST", 0) != 0 ? 1 : 0) : -1;
     t.feature_delta = getenv("LT_FEATURE_DELTA") ? (env_ll("LT_FEATURE_DELTA", 0) != 0 ? 1 : 0) : -1;
     t.delta_fused = env_ll("LT_DELTA_FUSED", 1) != 0 ? 1 : 0;
+    t.records_early = env_ll("LT_RECORDS_EARLY", 1) != 0 ? 1 : 0;
     t.profile_every = 1;
     return t;
 }
@@ -89,6 +90,7 @@ extern "C" int lt_set_tuning(const char *key, long long value) {
     else if (!strcmp(key, "s1_f32")) t.s1_f32 = reset ? d.s1_f32 : (value != 0);
     else if (!strcmp(key, "defer_cref")) t.defer_cref = reset ? d.defer_cref : (value != 0);
     else if (!strcmp(key, "delta_fused")) t.delta_fused = reset ? d.delta_fused : (value != 0);
+    else if (!strcmp(key, "records_early")) t.records_early = reset ? d.records_early : (value != 0);
     else if (!strcmp(key, "profile_every")) t.profile_every = reset ? 1 : (value >= 1 ? (int)(value > 1000000 ? 1000000 : value) : 1);
     else if (!strcmp(key, "z_on_demand")) t.z_on_demand = reset ? d.z_on_demand : (value < 0 ? -1 : (value != 0));
     else if (!strcmp(key, "stageb_rows")) t.stageb_rows = reset ? d.stageb_rows : (value != 0);

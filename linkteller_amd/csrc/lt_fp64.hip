@@ -494,13 +494,21 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     int n, int F, int H, int Hp, const float *__restrict__ X, long ldx, const float *__restrict__ ref,
     const float *__restrict__ W1, const double *__restrict__ cref, double *__restrict__ S1d, int hint_cap,
     int *__restrict__ dense_hint, int nslab, double *__restrict__ slabs, int32_t *__restrict__ zstate,
-    float *__restrict__ S1x, unsigned *__restrict__ gate, double *__restrict__ cref_out, double *__restrict__ S1qs) {
+    float *__restrict__ S1x, unsigned *__restrict__ gate, double *__restrict__ cref_out, double *__restrict__ S1qs,
+    const lt_bits_job job = lt_bits_job{}, const int job_first = 0) {
+    // job.nblocks > 0 (round 5): the blocks from job_first on -- BEHIND the rows in dispatch order, into the CU slots the rows leave
+    // free -- are a probe chunk's record blocks (lt_items.hip.h delta_record_block: nothing in them reads a layer).  They used to ride
+    // in the launch that forms the pre-activation and cost it 1.5 us; this launch is seven times longer and bound by the pass over X.
     // zstate != NULL: every row's pre-activation is marked stale here (saves the refresh its memset launch).
     // The first nslab blocks of the launch (deferred cref, nslab > 0) form the K slices of cref = m W1 instead of rows:
     // block z sums slice [64 z, 64 z + 64) for every hidden column (thread (kq, cq): 16 k's x 4 columns, one trip; the four
     // k-quarters added in order through LDS) into slabs[z]; the last of these blocks adds the slices (below), and the rows are
     // written WITHOUT cref (cref == NULL), which the fp64 SpMM and stage A add where they read them.
     extern __shared__ __attribute__((aligned(16))) unsigned char fd_smem[];
+    if (job.nblocks > 0 && (int)blockIdx.x >= job_first) {
+        item_bits_block((int)blockIdx.x - job_first, job, fd_smem);
+        return;
+    }
     if ((int)blockIdx.x < nslab) {
         double (*s_p)[256] = reinterpret_cast<double (*)[256]>(fd_smem);           // [4][256] (H <= 256, H % 4 == 0)
         const int k0 = blockIdx.x * 64, k1 = min(F, k0 + 64);
@@ -1094,6 +1102,13 @@ static bool want_feature_rows(const lt_baseline *cb) {
     return knob == 0 ? false : (knob > 0 ? true : b->feat_sparse != 0);
 }
 
+// A probe chunk's record blocks may ride in the rows' launch (influence_rows_impl offers them before it asks for the baseline's
+// fp64 parts; whether they went along is read back afterwards -- the launch only happens when the product is stale)
+static thread_local const lt_bits_job *g_offered_job = nullptr;
+static thread_local bool g_offered_rode = false;
+void lt_fp64_offer_job(const lt_bits_job *job) { g_offered_job = job; g_offered_rode = false; }
+bool lt_fp64_offer_taken() { const bool r = g_offered_rode; g_offered_job = nullptr; g_offered_rode = false; return r; }
+
 static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, bool defer = false, int32_t *zstate = nullptr) {
     // (fp32 storage of the fp64-accumulated rows goes with the deferred cref: the small-graph route whose readers know about both)
     const int Hp = b->Hp, H = b->H, n = n_rows < 0 ? b->n : n_rows, F = b->F;
@@ -1114,13 +1129,21 @@ static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, b
     const int nslab = defer ? nz : 0;
     const double *cref = defer ? (const double *)nullptr : b->fd_cref;
     float *s1x = (defer && b->S1x && b->S1qs && lt_tune().s1_f32 != 0) ? b->S1x : nullptr;
-    const unsigned blocks = (unsigned)((n + FD_WAVES - 1) / FD_WAVES + nslab);
+    unsigned blocks = (unsigned)((n + FD_WAVES - 1) / FD_WAVES + nslab);
     const size_t smem = fd_smem_bytes(F);
+    lt_bits_job jb = lt_bits_job{};
+    const int job_first = (int)blocks;
+    if (g_offered_job && n_rows < 0 && g_offered_job->nblocks > 0 && g_offered_job->dl_rec != nullptr && g_offered_job->smem_bytes <= smem &&
+        lt_tune().records_early != 0) {
+        jb = *g_offered_job;
+        blocks += (unsigned)jb.nblocks;
+        g_offered_rode = true;
+    }
     const bool vec2 = b->ldx % 2 == 0 && F % 2 == 0 && ((uintptr_t)b->X % 8) == 0, one = F <= 16 * 64 * FD_WAVES;
 #define LT_FD_LAUNCH(V_, O_)                                                                                                  \
     hipLaunchKernelGGL((k_s1d_feature_rows<V_, O_>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx, \
                        b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs, zstate, s1x,           \
-                       defer ? (unsigned *)b->fd_gate : (unsigned *)nullptr, b->fd_cref, b->S1qs)
+                       defer ? (unsigned *)b->fd_gate : (unsigned *)nullptr, b->fd_cref, b->S1qs, jb, job_first)
     if (vec2 && one) LT_FD_LAUNCH(2, true);
     else if (vec2) LT_FD_LAUNCH(2, false);
     else if (one) LT_FD_LAUNCH(1, true);

@@ -2367,13 +2367,6 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
     // fp64 pre-activation enabled nothing in fp32 at all -- the probe's own S1 row is read off the fp64 product --
     // and without it S1 and the fp32 layers
     const bool delta64 = mode == LT_MODE_DELTA && b->Z1d != nullptr;
-    {
-        int rc = lt_baseline_ensure_padding(b, st);
-        if (rc) return rc;
-        if (mode == LT_MODE_FULL) rc = lt_baseline_ensure_s1(b, st);
-        else rc = lt_baseline_ensure_layers(b, mode == LT_MODE_DELTA, st, !delta64);
-        if (rc) return rc;
-    }
 
     // SPARSE / DELTA, large calls: the per-node lists of observed nodes, once per call (lt_items.hip.h "pair marks")
     // (with a membership bitmap the per-pair scan is one load per entry and the join pays from ~ 4 M pairs on -- measured
@@ -2399,6 +2392,26 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
     {
         const int chunk_nb = n_probe < w.chunk ? n_probe : w.chunk;
         while ((long)n_obs * psplit < 2048 && psplit * 32 * LT_SB_UNR < chunk_nb) psplit *= 2;
+    }
+    // What the mode reads of the baseline, recomputed now if lt_baseline_refresh marked it stale.  The fused route OFFERS the record
+    // blocks of its first chunk to the launch that forms the fp64 product rows, should that launch happen (a refreshed baseline on
+    // the feature-rows route): nothing in them reads a layer, and that launch has CU slots to spare.
+    lt_bits_job cj0 = {};
+    bool recs_rode = false;
+    {
+        int32_t *const node_err0 = lt_node_err_dev();
+        const bool offer = fused && dg.record_smem <= (size_t)16 * 1024;
+        if (offer) {
+            const int nb0 = n_probe < w.chunk ? n_probe : w.chunk;
+            cj0.probes = probe_nodes; cj0.nb = nb0; cj0.nblocks = nb0; cj0.dl_rec = w.dl_rec; cj0.dl_meta = g->dl_meta; cj0.dl_src = g->dl_rec;
+            cj0.dl_maxc = dg.maxc; cj0.dl_rec_words = dg.rec_words; cj0.observe = observe_nodes; cj0.n_obs = n_obs;
+            cj0.n = n; cj0.err = node_err0; cj0.smem_bytes = (unsigned)dg.record_smem;
+            lt_fp64_offer_job(&cj0);
+        }
+        int rc = lt_baseline_ensure_padding(b, st);
+        if (!rc) rc = mode == LT_MODE_FULL ? lt_baseline_ensure_s1(b, st) : lt_baseline_ensure_layers(b, mode == LT_MODE_DELTA, st, !delta64);
+        if (offer) recs_rode = lt_fp64_offer_taken();
+        if (rc) return rc;
     }
     // Node ids (lt_items.hip.h checked_node): DELTA calls without pair marks check their lists in the first blocks that read them
     // (the record blocks / k_item_bits -- both usually ride in the pre-activation's launch: no launch, no round trip added);
@@ -2556,8 +2569,11 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
                         cj.dl_maxc = dg.maxc; cj.dl_rec_words = dg.rec_words; cj.observe = observe_nodes; cj.n_obs = n_obs;
                         cj.n = n; cj.err = node_err;
                         cj.smem_bytes = (unsigned)dg.record_smem;
-                        bool rode = false;
-                        if (p0 == 0) {
+                        bool rode = p0 == 0 && recs_rode;      // (chunk 0's records went along with the product rows' launch)
+                        if (p0 == 0 && recs_rode) {
+                            int rc = lt_fp64_prepare_rows(b, nullptr, 0, nullptr, n_probe, st, nullptr, nullptr);
+                            if (rc) return rc;
+                        } else if (p0 == 0) {
                             // (a launch's dynamic LDS is given to ALL its blocks: beyond 16 KB of node list the records get a launch
                             // of their own rather than cost the row blocks their occupancy)
                             const bool ride = dg.record_smem <= (size_t)16 * 1024;

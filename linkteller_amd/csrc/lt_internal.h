@@ -160,6 +160,8 @@ struct lt_tuning {
                                  // -1 when the baseline's features were found to be sparse differences (LT_FEATURE_DELTA)
     int delta_fused;             // DELTA at twitch size on graphs without hub rows: 1 stage A + B of a probe in one block
                                  // (k_delta_probe_block), 0 the item kernels (LT_DELTA_FUSED)
+    int records_early;           // DELTA fused route: 1 the first chunk's record blocks ride in the product rows' launch when it runs (default),
+                                 // 0 in the pre-activation's launch as in round 4 (LT_RECORDS_EARLY)
     int profile_every;           // lt_profile_enable: bracket every N-th scope of an enabled class with events (1 = all; an event pair
                                  // costs ~5 us of stream time, so a timed region samples)
 };
@@ -277,6 +279,10 @@ struct lt_bits_job {
 // job != NULL: *job_done says whether the job went along (it does when every row is formed by one plain launch; the on-demand
 // form needs the tables BEFORE, the caller then launches k_item_bits itself and calls again without a job)
 bool lt_fp64_on_demand(const lt_baseline *b, int n_probe_call);
+// the record blocks of a call's first probe chunk offered to the launch that forms the fp64 product rows (k_s1d_feature_rows), should
+// the baseline have to run it: lt_fp64_offer_job before lt_baseline_ensure_layers, lt_fp64_offer_taken after (true: they went along)
+void lt_fp64_offer_job(const lt_bits_job *job);
+bool lt_fp64_offer_taken();
 int lt_fp64_prepare_rows(const lt_baseline *b, const int32_t *off, int nb, const int2 *item_pr, int n_probe_call, hipStream_t st,
                          const lt_bits_job *job = nullptr, bool *job_done = nullptr);
 int lt_fp64_prepare_items(const lt_baseline *b, const int32_t *off, int nb, const int2 *item_pr, const int32_t *probes,
