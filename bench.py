@@ -926,10 +926,12 @@ def main():
                    "expectation": "configs[1] / [2] in the default mode CANNOT scale, by construction, and a first real N > 1 run must not be read as "
                                   "a regression: the step is a ~45 us job of which ~33 us is the loop-invariant baseline every rank repeats (one pass "
                                   "over X + the pre-activation) and the rest one latency-bound block per probe.  One-GPU emulation of one rank's step "
-                                  "(tools/shard_step_time.py, profiles/r04_shard_step.txt, before any collective): n_test = 500: 44.5 us at 1 rank -> "
-                                  "39.9 / 39.3 / 39.5 at 2 / 4 / 8 ranks (1.13x); n_test = 2000: 67.7 -> 51.1 / 45.8 / 41.0 (1.65x); the all-gather "
+                                  "(tools/shard_step_time.py, profiles/r05_shard_step.txt, before any collective): n_test = 500: 44.5 us at 1 rank -> "
+                                  "40.8 / 40.9 / 39.9 at 2 / 4 / 8 ranks (1.1x); n_test = 2000: 66.8 -> 54.1 / 48.8 / 43.7 (1.5x); the all-gather "
                                   "adds 26-38 us (measured under RCCL at world size 1).  configs[4] is the config where sharding pays: one rank's "
-                                  "512 x 4096 share of the R-MAT build is roofline_spmm.influence_shard (3.0 ms against 23.5 for all 4096 probes on one GPU)",
+                                  "512 x 4096 share of the R-MAT build is roofline_spmm.influence_shard (2.8-2.9 ms against 14.0 for all 4096 probes "
+                                  "on one GPU = 4.9x before the collective; the 3 800 hub rows every rank's probes reach are 84 % of a rank's "
+                                  "loop-invariant part and are replicated: DESIGN.md section 7 sizes sharding them)",
                    "mode": a.mode, "n_gpus": world}
         scaling["configs[1]"] = {"workload": f"n_test={a.n_test} (the `value` workload)", "ms_per_step": round(ms_per_step, 4),
                                  "pairs_per_s": round(value, 1), "probes_per_rank": per, "collective_us": collective_us(per, a.n_test)}
