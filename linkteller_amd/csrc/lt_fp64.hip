@@ -497,7 +497,7 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     float *__restrict__ S1x, unsigned *__restrict__ gate, double *__restrict__ cref_out, double *__restrict__ S1qs,
     const lt_bits_job job = lt_bits_job{}, const int job_first = 0) {
     // job.nblocks > 0 (round 5): the blocks from job_first on -- BEHIND the rows in dispatch order, into the CU slots the rows leave
-    // free -- are a probe chunk's record blocks (lt_items.hip.h delta_record_block: nothing in them reads a layer).  They used to ride
+    // free -- are a probe chunk's record blocks or item-table blocks (lt_items.hip.h: nothing in them reads a layer).  They used to ride
     // in the launch that forms the pre-activation and cost it 1.5 us; this launch is seven times longer and bound by the pass over X.
     // zstate != NULL: every row's pre-activation is marked stale here (saves the refresh its memset launch).
     // The first nslab blocks of the launch (deferred cref, nslab > 0) form the K slices of cref = m W1 instead of rows:
@@ -1133,8 +1133,7 @@ static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, b
     const size_t smem = fd_smem_bytes(F);
     lt_bits_job jb = lt_bits_job{};
     const int job_first = (int)blocks;
-    if (g_offered_job && n_rows < 0 && g_offered_job->nblocks > 0 && g_offered_job->dl_rec != nullptr && g_offered_job->smem_bytes <= smem &&
-        lt_tune().records_early != 0) {
+    if (g_offered_job && n_rows < 0 && g_offered_job->nblocks > 0 && g_offered_job->smem_bytes <= smem && lt_tune().records_early != 0) {
         jb = *g_offered_job;
         blocks += (unsigned)jb.nblocks;
         g_offered_rode = true;

@@ -2397,7 +2397,7 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
     // blocks of its first chunk to the launch that forms the fp64 product rows, should that launch happen (a refreshed baseline on
     // the feature-rows route): nothing in them reads a layer, and that launch has CU slots to spare.
     lt_bits_job cj0 = {};
-    bool recs_rode = false;
+    bool recs_rode = false, items_rode = false;
     {
         int32_t *const node_err0 = lt_node_err_dev();
         const bool offer = fused && dg.record_smem <= (size_t)16 * 1024;
@@ -2408,9 +2408,22 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
             cj0.n = n; cj0.err = node_err0; cj0.smem_bytes = (unsigned)dg.record_smem;
             lt_fp64_offer_job(&cj0);
         }
+        // ... and the item route of a graph with per-probe bitmap rows its first chunk's item tables (k_item_bits' blocks), the same way
+        const bool offer_items = !fused && delta64 && !use_marks && w.bits != nullptr && !lt_fp64_agg_active(b);
+        if (offer_items) {
+            const int nb0 = n_probe < w.chunk ? n_probe : w.chunk;
+            const bool hubs0 = g->p_n_long > 0;
+            cj0 = lt_bits_job{g->tptr, g->trow, probe_nodes, nb0, (n + 31) / 32, w.bits, w.off, w.item_pr, w.big_bits, w.big_slot,
+                              (int32_t *)nullptr, g->rowptr, observe_nodes, n_obs, hubs0 ? w.hub_obs : (int32_t *)nullptr, nb0 + 1, g->tval,
+                              w.item_va};
+            cj0.n = n; cj0.err = node_err0; cj0.probes_s = w.probes_s; cj0.obs_s = w.obs_s;      // (DELTA without pair marks: the inline check)
+            cj0.smem_bytes = lt_item_bits_smem((n + 31) / 32);
+            lt_fp64_offer_job(&cj0);
+        }
         int rc = lt_baseline_ensure_padding(b, st);
         if (!rc) rc = mode == LT_MODE_FULL ? lt_baseline_ensure_s1(b, st) : lt_baseline_ensure_layers(b, mode == LT_MODE_DELTA, st, !delta64);
         if (offer) recs_rode = lt_fp64_offer_taken();
+        else if (offer_items) items_rode = lt_fp64_offer_taken();
         if (rc) return rc;
     }
     // Node ids (lt_items.hip.h checked_node): DELTA calls without pair marks check their lists in the first blocks that read them
@@ -2615,7 +2628,8 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
                 job.nblocks = nb + 1;
             }
             job.smem_bytes = (w.bits || w.big_bits) ? lt_item_bits_smem(words) : 0u;      // the bitmap row built in LDS when it fits
-            if (mode == LT_MODE_DELTA && b->Z1d && !lt_fp64_agg_active(b) && !use_marks) {
+            if (p0 == 0 && items_rode) bits_done = true;      // (chunk 0's tables went along with the product rows' launch)
+            else if (mode == LT_MODE_DELTA && b->Z1d && !lt_fp64_agg_active(b) && !use_marks) {
                 const int rc = lt_fp64_prepare_rows(b, w.off, nb, w.item_pr, n_probe, st, &job, &bits_done);
                 if (rc) return rc;
             }

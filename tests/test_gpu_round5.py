@@ -190,3 +190,51 @@ def test_wide_baseline_probe_chunks_keep_every_bit(gpu, mode, monkeypatch):
     base2 = engine.baseline_for(graph.HipGraph(a_hat), x, *_params(w, gpu))
     chunked = base2.influence_rows(probes, obs, 1e-4, mode)
     assert base2._buf["key"][0] == 5 and torch.equal(chunked, whole)
+
+
+@pytest.mark.parametrize("bits", ["per-probe", "big-probes-only"])
+def test_observed_hub_search_forms_keep_every_bit(gpu, bits):
+    """The observed-hub blocks of large calls choose per (probe, hub) pair between the probe's own two-level search (up to four
+    rounds), the whole block searching the probe's R_v, and the whole block passing over the row through a bitmap (round 5,
+    DESIGN 5.2b).  A power-law graph whose biggest hubs are BOTH probed and observed, next to hubs of under and over 1024 entries
+    (rows that sit in LDS whole / sampled rows), drives all three; with the short-side forms forced on (`hub_short_side` = 1) and
+    off the matrices must be equal bit for bit, in `delta` and in `sparse`, with a bitmap row per probe and with rows for the big
+    probes only -- and `delta` must meet the fp64 oracle."""
+    from linkteller_amd import _lib, engine, graph, synth
+    from oracle import linkteller_oracle as O
+    n = 12000
+    a_hat = graph.first_order_gcn(synth.powerlaw_graph(n, 90000, seed=11, exponent=1.7))
+    deg = np.diff(a_hat.indptr)
+    order = np.argsort(-deg)
+    assert deg[order[0]] > 2048 and (deg > 1024).sum() >= 2 and ((deg > 128) & (deg <= 1024)).sum() >= 10
+    f, h, c = 48, 64, 2
+    x = synth.gaussian_features(n, f, seed=3)
+    w = synth.gcn_weights(f, h, c, seed=4)
+    rng = np.random.RandomState(2)
+    mid = np.flatnonzero((deg > 128) & (deg <= 1024))
+    probes = np.concatenate([order[:5], rng.choice(mid, 6, replace=False), rng.choice(n, 120, replace=False)])
+    obs = np.concatenate([order[:4], rng.choice(mid, 12, replace=False), rng.choice(n, 300, replace=False)])
+    assert (deg[probes] > 256).sum() >= 5                      # probes the block searches for (more than four rounds of their own)
+    base = engine.Baseline(graph.HipGraph(a_hat), torch.from_numpy(x).to(gpu), *_params(w, gpu))
+    knobs = ("hub_short_side", "bits_max_bytes", "pair_marks")
+    try:
+        _lib.set_tuning("pair_marks", -1)
+        _lib.set_tuning("bits_max_bytes", (1 << 27) if bits == "per-probe" else 1)
+        got = {}
+        for short in (0, 1):
+            _lib.set_tuning("hub_short_side", short)
+            for m in ("delta", "sparse"):
+                got[(short, m)] = base.influence_rows(probes, obs, 1e-4, m).clone()
+        for m in ("delta", "sparse"):
+            assert torch.equal(got[(0, m)], got[(1, m)]), (bits, m, float((got[(0, m)] - got[(1, m)]).abs().max()))
+    finally:
+        for k in knobs:
+            _lib.set_tuning(k, None)
+    # the fp64 oracle on the hub probes' rows
+    P64 = {k: torch.from_numpy(w[k]).double() for k in ("W1", "b1", "W2", "b2")}
+    adj_o, x64 = O.to_torch_sparse(a_hat).double(), torch.from_numpy(x).double()
+    d = got[(1, "delta")].cpu().numpy().astype(np.float64)
+    with torch.no_grad():
+        for i in (0, 1, 4, 7, 20):
+            r64 = O.get_gradient_eps_mat(x64, adj_o, P64, int(probes[i]), 1e-4)[torch.as_tensor(obs.astype(np.int64))].norm(dim=1).numpy()
+            assert np.abs(d[i] - r64).max() <= 1e-5 * max(r64.max(), 1e-6), (i, np.abs(d[i] - r64).max(), r64.max())
