@@ -540,6 +540,7 @@ extern "C" int lt_baseline_create(const lt_graph *g, const float *X, int64_t ldx
     if (rc) return rc;
     LT_REQUIRE(X && W1 && b1 && W2 && b2, "lt_baseline_create: NULL tensor pointer");
     LT_REQUIRE(ldx >= F, "lt_baseline_create: ldx=%lld < F=%d", (long long)ldx, F);
+    (void)lt_node_err_dev();      // the mapped flag words of the node-id check exist before any call that may be captured into a hipGraph
     lt_baseline *b = new (std::nothrow) lt_baseline();
     if (!b) return lt_set_error(LT_ERR_NOMEM, "lt_baseline_create: out of host memory");
     b->g = g; b->n = g->n; b->F = F; b->H = H; b->C = C; b->Hp = lt_round_up(H, 4);

@@ -415,6 +415,7 @@ extern "C" int lt_baseline3_create(const lt_graph *g, const float *X, int64_t ld
                             LT_MAX_H, LT_MAX_C);
     LT_REQUIRE(X && W1 && b1 && W2 && b2 && W3 && b3, "lt_baseline3_create: NULL tensor pointer");
     LT_REQUIRE(ldx >= F, "lt_baseline3_create: ldx=%lld < F=%d", (long long)ldx, F);
+    (void)lt_node_err_dev();      // (allocated outside any stream capture)
     lt_baseline3 *b = new (std::nothrow) lt_baseline3();
     if (!b) return lt_set_error(LT_ERR_NOMEM, "lt_baseline3_create: out of host memory");
     b->g = g; b->n = g->n; b->F = F; b->H1 = H1; b->H2 = H2; b->C = C;
