@@ -136,6 +136,10 @@ static void free_graph(lt_graph *g) {
     (void)hipFree(g->p_seg_long);
     (void)hipFree(g->p_seg_begin);
     (void)hipFree(g->p_seg_scratch);
+    (void)hipFree(g->q_long_row);
+    (void)hipFree(g->q_long_segptr);
+    (void)hipFree(g->q_seg_long);
+    (void)hipFree(g->q_seg_begin);
     delete g;
 }
 
@@ -441,6 +445,31 @@ extern "C" int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, co
             G_HIP(hipMemcpy(g->p_seg_long, slong.data(), slong.size() * sizeof(int32_t), hipMemcpyHostToDevice));
             G_HIP(hipMemcpy(g->p_seg_begin, sbeg.data(), sbeg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
             G_HIP(hipMalloc((void **)&g->p_seg_scratch, (size_t)g->p_n_seg * LT_MAX_H * sizeof(float)));
+        }
+        {   // the fp64 row kernel's own segment table (lt_internal.h: LT_F64_LONG / LT_F64_SEG)
+            std::vector<int32_t> qrow, qptr(1, 0), qlong, qbeg;
+            for (int32_t r = 0; r < n; ++r) {
+                if (rowptr[r + 1] - rowptr[r] <= LT_F64_LONG) continue;
+                const int32_t li = (int32_t)qrow.size();
+                qrow.push_back(r);
+                for (int32_t b_ = rowptr[r]; b_ < rowptr[r + 1]; b_ += LT_F64_SEG) {
+                    qlong.push_back(li);
+                    qbeg.push_back(b_);
+                }
+                qptr.push_back((int32_t)qbeg.size());
+            }
+            g->q_n_long = (int32_t)qrow.size();
+            g->q_n_seg = (int32_t)qbeg.size();
+            if (g->q_n_long > 0) {
+                G_HIP(hipMalloc((void **)&g->q_long_row, qrow.size() * sizeof(int32_t)));
+                G_HIP(hipMalloc((void **)&g->q_long_segptr, qptr.size() * sizeof(int32_t)));
+                G_HIP(hipMalloc((void **)&g->q_seg_long, qlong.size() * sizeof(int32_t)));
+                G_HIP(hipMalloc((void **)&g->q_seg_begin, qbeg.size() * sizeof(int32_t)));
+                G_HIP(hipMemcpy(g->q_long_row, qrow.data(), qrow.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                G_HIP(hipMemcpy(g->q_long_segptr, qptr.data(), qptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                G_HIP(hipMemcpy(g->q_seg_long, qlong.data(), qlong.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                G_HIP(hipMemcpy(g->q_seg_begin, qbeg.data(), qbeg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            }
         }
         // work items of the tiled SpMM: segments by first column, then short rows by length class (16 entries)
         struct item { int32_t e0, cnt, dst; };

@@ -265,6 +265,50 @@ __global__ void k_sum_slabs_f64(const double *__restrict__ slabs, long slab_stri
     C[(i / N) * ldc + (i % N)] = acc;
 }
 
+// The same sum, the rows leaving as 32-bit FIXED POINT with one scale per row (the storage of the feature-difference route,
+// k_s1d_feature_rows: q = round(value / scale), scale = row max / 2^31): one wave per row, a lane per 4 columns (H <= 256).
+// Round 5: the matrix-core route stores its product rows like that too -- half the bytes the fp64 SpMM gathers and stage A reads.
+__global__ __launch_bounds__(256) void k_sum_slabs_f64_q(const double *__restrict__ slabs, long slab_stride, int splits, int M, int N,
+                                                         int Hp, float *__restrict__ S1x, double *__restrict__ S1qs) {
+    const int row = (int)(((long)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int c0 = 4 * lane;
+    double o[4] = {0.0, 0.0, 0.0, 0.0};
+    if (c0 < N) {       // (N % 4 == 0: 32-byte loads, every slab's in flight before the first add; slab order as k_sum_slabs_f64)
+        const double *p = slabs + (long)row * N + c0;
+        f64x4 acc = *reinterpret_cast<const f64x4 *>(p);
+        int z = 1;
+        for (; z + 4 <= splits; z += 4) {
+            f64x4 v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const f64x4 *>(p + (long)(z + t) * slab_stride);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] += v[t][k];
+        }
+        for (; z < splits; ++z) {
+            const f64x4 v = *reinterpret_cast<const f64x4 *>(p + (long)z * slab_stride);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += v[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = acc[k];
+    }
+    double mx = fmax(fmax(fabs(o[0]), fabs(o[1])), fmax(fabs(o[2]), fabs(o[3])));
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mx = fmax(mx, __shfl_xor(mx, m, 64));
+    const double scale = mx > 0.0 ? mx * (1.0 / 2147483000.0) : 1.0;
+    const double inv = 1.0 / scale;
+    if (c0 < Hp) {
+        int q[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) q[t] = (int)rint(o[t] * inv);
+        *reinterpret_cast<int4 *>(S1x + (size_t)row * Hp + c0) = make_int4(q[0], q[1], q[2], q[3]);
+    }
+    if (lane == 0) S1qs[row] = scale;
+}
+
 // Z1d[r, :] = sum_e val[e] * S1d[col[e], :] + b1     (fp64 fma chain in CSR order, 4 columns per lane)
 // One lane group per row of up to LT_ROW_SEG entries; on a graph with hub rows the first seg_blocks blocks of the
 // launch take one SEGMENT of a long row per lane group instead, raw sum into seg_out[segment] (k_spmm_f64_long adds
@@ -286,7 +330,10 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
                                                   double *__restrict__ seg_out, int32_t *__restrict__ state,
                                                   const double *__restrict__ rs, const double *__restrict__ crefv,
                                                   const lt_bits_job job = lt_bits_job{}, const int job_first = 0,
-                                                  float *__restrict__ outf = nullptr, const double *__restrict__ Sq = nullptr) {
+                                                  float *__restrict__ outf = nullptr, const double *__restrict__ Sq = nullptr,
+                                                  const int seg_len = LT_F64_SEG, const int long_thr = LT_F64_LONG) {
+    // (seg_len / long_thr: the cut of the segment tables the caller passes -- the graph's fp64 tables: rows of more than long_thr
+    // entries in seg_len-entry segments)
     // ST = float: S holds int32 fixed point, row c scaled by Sq[c] (k_s1d_feature_rows): a term is A_hat[r, c] * Sq[c] * q
     // outf != NULL: the finished rows go there rounded once to fp32 instead of to `out` (the segment sums stay fp64).  The
     // kink test of LT_MODE_DELTA reads a pre-activation for its SIGN, the sign of z + dz and, where they differ, its value: a
@@ -327,12 +374,12 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
         const int lr = long_row[seg_long[r]];
         if (state && state[lr] != 2) return;
         e = seg_begin[r];
-        e1 = min(e + LT_ROW_SEG, rowptr[lr + 1]);
+        e1 = min(e + seg_len, rowptr[lr + 1]);
     } else {
         if (state && state[r] != 2) return;
         e = rowptr[r];
         e1 = rowptr[r + 1];
-        if (seg_blocks > 0 && e1 - e > LT_ROW_SEG) return;
+        if (seg_blocks > 0 && e1 - e > long_thr) return;
     }
     typedef ST sx4 __attribute__((ext_vector_type(4)));
     constexpr bool QNT = sizeof(ST) == 4;        // "float" rows are int32 fixed point with a scale per row (Sq)
@@ -375,6 +422,8 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc[k] = fma(a[j], term(s[j], k), acc[k]);
     }
+    // (round 5 tried the tail as one masked batch of 8, and batches of 8 with the next (col, val) prefetched: both SLOWER -- 12.7 ->
+    // 13.6 us for the launch at twitch size: the redundant gathers of the masked slots cost more than the trips they save)
     for (; e + 4 <= e1; e += 4) {
         double a[4];
         sx4 s[4];
@@ -901,7 +950,12 @@ static int fp64_kslice(int n, int H, int F) {
 }
 
 // The dense product S1d = X*W1 on the f64 matrix cores: rows [r0, r1) into dst[(r1 - r0), ldd].
-static int launch_dense_s1d(lt_baseline *b, int r0, int r1, double *dst, long ldd_out, hipStream_t st) {
+// quant: the whole product (r0 = 0, r1 = n) leaves as fixed-point rows in b->S1x / b->S1qs instead of dst (needs the split-K form)
+static bool dense_quant_possible(const lt_baseline *b) {
+    const int kslice = fp64_kslice(b->n, b->H, b->F);
+    return (b->F + kslice - 1) / kslice > 1 && b->H <= 256 && b->H % 4 == 0 && b->S1x && b->S1qs && b->slabs_d;
+}
+static int launch_dense_s1d(lt_baseline *b, int r0, int r1, double *dst, long ldd_out, hipStream_t st, bool quant = false) {
     const int H = b->H, n = b->n, F = b->F, m = r1 - r0;
     if (m <= 0) return LT_OK;
     // the K slicing is that of the FULL product whatever the row range: a row has the same bits whichever rank computed it
@@ -920,7 +974,11 @@ static int launch_dense_s1d(lt_baseline *b, int r0, int r1, double *dst, long ld
         hipLaunchKernelGGL(k_gemm_f64acc, grid, dim3(256), 0, st, A, (long)b->ldx, b->W1, (long)H, out, ldd, m, H, F,
                            splits > 1 ? kslice : (F > 0 ? F : 1), stride);
     LT_CHECK_LAUNCH();
-    if (splits > 1) {
+    if (splits > 1 && quant) {
+        hipLaunchKernelGGL(k_sum_slabs_f64_q, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, b->slabs_d, (long)m * H, splits, m, H, b->Hp,
+                           b->S1x, b->S1qs);
+        LT_CHECK_LAUNCH();
+    } else if (splits > 1) {
         const long tot = (long)m * H;
         hipLaunchKernelGGL(k_sum_slabs_f64, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, b->slabs_d,
                            tot, splits, tot, H, dst, ldd_out);
@@ -1182,9 +1240,14 @@ static int compute_s1d(lt_baseline *b, hipStream_t st) {
         int rc = launch_feature_s1d(b, st, -1, small && lt_tune().defer_cref != 0, b->zstate);
         if (rc) return rc;
     } else {
-        if (Hp != H) LT_HIP(hipMemsetAsync(b->S1d, 0, (size_t)n * Hp * sizeof(double), st));
-        int rc = launch_dense_s1d(b, 0, n, b->S1d, (long)Hp, st);
+        // the matrix-core product; rows the caches hold leave as 32-bit fixed point (round 5: the storage form of the feature route:
+        // "s1_f32" = 0 keeps them fp64)
+        const bool small = (long long)n * Hp * (long long)sizeof(double) < ((long long)32 << 20);
+        const bool quant = small && lt_tune().s1_f32 != 0 && dense_quant_possible(b);
+        if (!quant && Hp != H) LT_HIP(hipMemsetAsync(b->S1d, 0, (size_t)n * Hp * sizeof(double), st));
+        int rc = launch_dense_s1d(b, 0, n, b->S1d, (long)Hp, st, quant);
         if (rc) return rc;
+        b->s1_f32 = quant;
     }
     return LT_OK;
 }
@@ -1196,13 +1259,13 @@ static int form_z1d(lt_baseline *b, int32_t *state, hipStream_t st, const lt_bit
     const int lpr = lt_lpr_for(Hp);
     const unsigned g2 = (unsigned)((n + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr)));
     const lt_graph *g = b->g;
-    const int have_long = (g->p_n_long > 0 && b->seg_d) ? 1 : 0;
+    const int have_long = (g->q_n_long > 0 && b->seg_d) ? 1 : 0;     // (the row kernel's own cut: lt_graph::q_*)
     b->z1x_valid = false;
-    if (!state && !b->cref_deferred && lt_tiled_wanted(g, Hp) && (g->p_n_long == 0 || b->seg_d)) {
+    if (!state && !b->cref_deferred && !b->s1_f32 && lt_tiled_wanted(g, Hp) && (g->p_n_long == 0 || b->seg_d)) {      // (fixed-point rows: the row kernel reads them)
         // S1d beyond the caches (R-MAT scale 21: 4.3 GB): the column-sliced work-item route of lt_spmm.hip, same chains
         int rc = lt_launch_rows_tiled_f64(g, b->S1d, Hp, Hp, b->b1p, b->Z1d, Hp, b->seg_d, Hp, st);
         if (rc) return rc;
-        if (have_long) {
+        if (g->p_n_long > 0 && b->seg_d) {      // (the work items carry the 128-entry segments of lt_graph::p_*)
             const long tot = (long)g->p_n_long * Hp;
             hipLaunchKernelGGL(k_spmm_f64_long, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, g->p_n_long,
                                g->p_long_row, g->p_long_segptr, b->seg_d, Hp, b->b1p, b->Z1d, (int32_t *)nullptr, 0,
@@ -1211,7 +1274,7 @@ static int form_z1d(lt_baseline *b, int32_t *state, hipStream_t st, const lt_bit
         }
         return LT_OK;
     }
-    const unsigned gs = have_long ? (unsigned)((g->p_n_seg + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr))) : 0u;
+    const unsigned gs = have_long ? (unsigned)((g->q_n_seg + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr))) : 0u;
     const double *crefv = b->cref_deferred ? b->fd_cref : nullptr;      // (deferred cref: S1d holds S1d - cref)
     const lt_bits_job jb = (job && !state) ? *job : lt_bits_job{};
     // the feature route with fp32 row storage, for LT_MODE_DELTA's stage A alone: the result in fp32 too
@@ -1222,22 +1285,22 @@ static int form_z1d(lt_baseline *b, int32_t *state, hipStream_t st, const lt_bit
     const size_t jsm = gj > 0 ? (size_t)jb.smem_bytes : 0;
     if (b->s1_f32) {
         LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, float>), dim3(g2 + gs + gj), dim3(256), jsm, st, n, g->rowptr,
-                                                g->col, g->val, b->S1x, Hp, b->b1p, b->Z1d, (int)gs, g->p_n_seg, g->p_seg_begin,
-                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv, jb, (int)(g2 + gs), zf, b->S1qs));
+                                                g->col, g->val, b->S1x, Hp, b->b1p, b->Z1d, (int)gs, g->q_n_seg, g->q_seg_begin,
+                                                g->q_seg_long, g->q_long_row, b->seg_d, state, b->fd_rs, crefv, jb, (int)(g2 + gs), zf, b->S1qs));
     } else {
         LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, double>), dim3(g2 + gs + gj), dim3(256), jsm, st, n, g->rowptr,
-                                                g->col, g->val, b->S1d, Hp, b->b1p, b->Z1d, (int)gs, g->p_n_seg, g->p_seg_begin,
-                                                g->p_seg_long, g->p_long_row, b->seg_d, state, b->fd_rs, crefv, jb, (int)(g2 + gs), zf));
+                                                g->col, g->val, b->S1d, Hp, b->b1p, b->Z1d, (int)gs, g->q_n_seg, g->q_seg_begin,
+                                                g->q_seg_long, g->q_long_row, b->seg_d, state, b->fd_rs, crefv, jb, (int)(g2 + gs), zf));
     }
     LT_CHECK_LAUNCH();
     if (have_long) {
-        const long tot = (long)g->p_n_long * Hp;
-        hipLaunchKernelGGL(k_spmm_f64_long, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, g->p_n_long,
-                           g->p_long_row, g->p_long_segptr, b->seg_d, Hp, b->b1p, b->Z1d, state, 0, b->fd_rs, crefv, zf);
+        const long tot = (long)g->q_n_long * Hp;
+        hipLaunchKernelGGL(k_spmm_f64_long, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, g->q_n_long,
+                           g->q_long_row, g->q_long_segptr, b->seg_d, Hp, b->b1p, b->Z1d, state, 0, b->fd_rs, crefv, zf);
         LT_CHECK_LAUNCH();
         if (state) {
-            hipLaunchKernelGGL(k_spmm_f64_long, dim3((unsigned)((g->p_n_long + 255) / 256)), dim3(256), 0, st, g->p_n_long,
-                               g->p_long_row, g->p_long_segptr, b->seg_d, Hp, b->b1p, b->Z1d, state, 1, b->fd_rs, crefv);
+            hipLaunchKernelGGL(k_spmm_f64_long, dim3((unsigned)((g->q_n_long + 255) / 256)), dim3(256), 0, st, g->q_n_long,
+                               g->q_long_row, g->q_long_segptr, b->seg_d, Hp, b->b1p, b->Z1d, state, 1, b->fd_rs, crefv);
             LT_CHECK_LAUNCH();
         }
     }
@@ -1253,7 +1316,7 @@ bool lt_fp64_on_demand(const lt_baseline *b, int n_probe_call) {
     const lt_graph *g = b->g;
     const double avg = g->n > 0 ? (double)g->nnz / (double)g->n : 0.0;
     const int knob = lt_tune().z_on_demand;
-    const bool tiled = !b->cref_deferred && lt_tiled_wanted(g, b->Hp) && (g->p_n_long == 0 || b->seg_d);
+    const bool tiled = !b->cref_deferred && !b->s1_f32 && lt_tiled_wanted(g, b->Hp) && (g->p_n_long == 0 || b->seg_d);
     // (a graph whose whole fp64 SpMM is a 10 us launch is formed whole: marking the rows costs a memset, k_z_mark and the item
     // tables' own launch in front of it -- 55 against 50 us for the step one rank of 8 runs at twitch size)
     return !tiled && (knob > 0 || (knob < 0 && (double)n_probe_call * avg * 2.0 < (double)g->n &&
@@ -1312,23 +1375,23 @@ int lt_launch_gemm_f64_gather(const float *A, long lda, const int32_t *rows, int
     LT_CHECK_LAUNCH();
     return LT_OK;
 }
-// out[n, ld] = A_hat * S + bias (all rows, fp64 chains; seg_d: [g->p_n_seg, ld] scratch for the hub rows, may be NULL
+// out[n, ld] = A_hat * S + bias (all rows, fp64 chains; seg_d: [lt_f64_seg_rows(g), ld] scratch for the hub rows, may be NULL
 // when the graph has none)
 int lt_launch_spmm_f64(const lt_graph *g, const double *S, int ld, const float *biasp, double *out, double *seg_d, hipStream_t st) {
     const int n = g->n;
     if (n == 0) return LT_OK;
     const int lpr = lt_lpr_for(ld);
     const unsigned g2 = (unsigned)((n + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr)));
-    const int have_long = (g->p_n_long > 0 && seg_d) ? 1 : 0;
-    const unsigned gs = have_long ? (unsigned)((g->p_n_seg + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr))) : 0u;
+    const int have_long = (g->q_n_long > 0 && seg_d) ? 1 : 0;
+    const unsigned gs = have_long ? (unsigned)((g->q_n_seg + (4 * (64 / lpr)) - 1) / (4 * (64 / lpr))) : 0u;
     LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, double>), dim3(g2 + gs), dim3(256), 0, st, n, g->rowptr, g->col, g->val, S, ld,
-                                            biasp, out, (int)gs, g->p_n_seg, g->p_seg_begin, g->p_seg_long, g->p_long_row, seg_d,
+                                            biasp, out, (int)gs, g->q_n_seg, g->q_seg_begin, g->q_seg_long, g->q_long_row, seg_d,
                                             (int32_t *)nullptr, (const double *)nullptr, (const double *)nullptr));
     LT_CHECK_LAUNCH();
     if (have_long) {
-        const long tot = (long)g->p_n_long * ld;
-        hipLaunchKernelGGL(k_spmm_f64_long, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, g->p_n_long, g->p_long_row,
-                           g->p_long_segptr, seg_d, ld, biasp, out, (int32_t *)nullptr, 0, (const double *)nullptr, (const double *)nullptr);
+        const long tot = (long)g->q_n_long * ld;
+        hipLaunchKernelGGL(k_spmm_f64_long, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, g->q_n_long, g->q_long_row,
+                           g->q_long_segptr, seg_d, ld, biasp, out, (int32_t *)nullptr, 0, (const double *)nullptr, (const double *)nullptr);
         LT_CHECK_LAUNCH();
     }
     return LT_OK;
@@ -1411,7 +1474,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     if (e == hipSuccess) e = hipMemsetAsync(z1d, 0, nh, st);      // (pad columns stay zero on every route)
     if (alloc_s1d) {
         if (e == hipSuccess) e = hipMalloc((void **)&s1d, nh);
-        if (e == hipSuccess && b->g->p_n_seg > 0) e = hipMalloc((void **)&segd, (size_t)b->g->p_n_seg * b->Hp * sizeof(double));
+        if (e == hipSuccess && lt_f64_seg_rows(b->g) > 0) e = hipMalloc((void **)&segd, (size_t)lt_f64_seg_rows(b->g) * b->Hp * sizeof(double));
         if (e == hipSuccess && splits > 1) e = hipMalloc((void **)&slabs, (size_t)splits * n1 * b->H * sizeof(double));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&cref, (size_t)b->Hp * sizeof(double));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fslabs, (size_t)((b->F + 63) / 64) * b->H * sizeof(double));

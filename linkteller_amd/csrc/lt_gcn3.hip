@@ -44,7 +44,7 @@ struct lt_baseline3 {
     lt_baseline *l1 = nullptr;
     double *S2d = nullptr;      // [n, Hp2]  relu(Z1d) W2
     double *Z2d = nullptr;      // [n, Hp2]  A S2d + b2
-    double *seg2d = nullptr;    // [g->p_n_seg, Hp2]
+    double *seg2d = nullptr;    // [lt_f64_seg_rows(g), Hp2]
     bool fp64_fresh = false;
 };
 
@@ -483,7 +483,7 @@ extern "C" int lt_baseline3_enable_fp64(lt_baseline3 *b, void *stream) {
     hipError_t e = hipMalloc((void **)&s2d, n1 * b->Hp2 * sizeof(double));
     if (e == hipSuccess) e = hipMemsetAsync(s2d, 0, n1 * b->Hp2 * sizeof(double), (hipStream_t)stream);   // pad columns stay zero
     if (e == hipSuccess) e = hipMalloc((void **)&z2d, n1 * b->Hp2 * sizeof(double));
-    if (e == hipSuccess && b->g->p_n_seg > 0) e = hipMalloc((void **)&seg, (size_t)b->g->p_n_seg * b->Hp2 * sizeof(double));
+    if (e == hipSuccess && lt_f64_seg_rows(b->g) > 0) e = hipMalloc((void **)&seg, (size_t)lt_f64_seg_rows(b->g) * b->Hp2 * sizeof(double));
     if (e != hipSuccess) {
         (void)hipFree(s2d); (void)hipFree(z2d); (void)hipFree(seg); (void)lt_baseline_destroy(l1);
         return lt_set_error(LT_ERR_HIP, "lt_baseline3_enable_fp64: hipMalloc failed: %s", hipGetErrorString(e));

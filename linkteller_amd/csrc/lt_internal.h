@@ -43,6 +43,12 @@ struct lt_graph {
     int32_t *p_seg_long = nullptr;     // [p_n_seg]      index into p_long_row
     int32_t *p_seg_begin = nullptr;    // [p_n_seg]      first CSR entry of the segment
     float *p_seg_scratch = nullptr;    // [p_n_seg, LT_MAX_H] segment sums (standalone SpMM, lt_gcn2_forward; one stream at a time)
+    // The fp64 row kernel's own cut (k_spmm_f64, round 5): rows of more than LT_F64_LONG entries as LT_F64_SEG-entry segments.  An
+    // fp64 sum may be associated freely (the routes agree to ~1e-16), and a lane group walks its entries 16 at a time: the rows of
+    // 64 .. 128 entries of a power-law graph were 4 .. 8 dependent trips each and the launch's longest path (23.4 -> 18.1 us on the
+    // co-headline graph with 32-entry pieces).  Same four arrays as above; the fp32 kernels never see them.
+    int32_t q_n_long = 0, q_n_seg = 0;
+    int32_t *q_long_row = nullptr, *q_long_segptr = nullptr, *q_seg_long = nullptr, *q_seg_begin = nullptr;
     // Work items of the tiled SpMM (lt_spmm.hip), built for every graph: one item per row of up to LT_ROW_SEG entries
     // and one per segment of a long row.  Order: the segments first, by the column their first entry reads (waves
     // that run at the same time then gather from one sliding window of S), then the short rows, longest first.
@@ -54,6 +60,9 @@ struct lt_graph {
 #define LT_HOT_COLUMNS 16384   // one XCD L2 (4 MiB) holds this many 256-byte row slices
 #define LT_LOCAL_WINDOW 8192   // |col - row| up to this counts as a local entry (8192 rows x 1 KiB = two XCD L2s)
 #define LT_ROW_SEG 128   // layer-1 chains: entries per segment (rows up to this length are one plain chain)
+#define LT_F64_LONG 64   // k_spmm_f64: rows of more entries than this are cut ...
+#define LT_F64_SEG 32    // ... into segments of this many (fp64 chains only)
+static inline int lt_f64_seg_rows(const lt_graph *g) { return g->p_n_seg > g->q_n_seg ? g->p_n_seg : g->q_n_seg; }   // rows of an fp64 segment scratch
 #define LT_CSR_PAD 16   // zero entries appended to col/val
 
 struct lt_baseline {
