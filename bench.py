@@ -18,6 +18,10 @@ Timing: W warm-up steps, then ``--blocks`` (default 5) timed blocks of EXACTLY K
 barrier + torch.cuda.synchronize() on both sides and reduced with MAX over ranks; ``value`` / ``ms_per_step`` are the
 MEDIAN block ("median of >= 5"), all block times are in the line.
 
+Next to ``value`` (whose step ends on the device) the line carries ``api_wall``: the drop-in API itself -- ``Attacker.influence_matrix()``
+on the same workload, i.e. the region the reference times at attacker.py:213->231, with ``influence_val`` on the HOST as float64
+(``value_host``, ``d2h_us``, ``ms_per_step_to_host``).
+
 ``value`` is measured in ``--mode delta`` (default): the mode whose scores, AUC and AP meet north_star's 1e-4 against the
 reference.  `full` (every probe a full perturbed forward, the reference's fp32 finite difference)
 and `sparse` (bit-identical to it) are reported next to it under ``other_modes`` and never substituted for it; the line

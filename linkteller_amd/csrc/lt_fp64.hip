@@ -309,6 +309,33 @@ __global__ __launch_bounds__(256) void k_sum_slabs_f64_q(const double *__restric
     if (lane == 0) S1qs[row] = scale;
 }
 
+// The same storage from finished fp64 rows (S[M, ld], pad columns zero): the product of ONE K slice, and the rows the ranks'
+// all-gather rebuilt (multi-GPU) -- the same value gives the same words, so sharded and single-GPU runs keep every bit.
+__global__ __launch_bounds__(256) void k_quant_rows_f64(const double *__restrict__ S, long ld, int M, int N, int Hp,
+                                                        float *__restrict__ S1x, double *__restrict__ S1qs) {
+    const int row = (int)(((long)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int c0 = 4 * lane;
+    double o[4] = {0.0, 0.0, 0.0, 0.0};
+    if (c0 < N) {
+        const f64x4 v = *reinterpret_cast<const f64x4 *>(S + (long)row * ld + c0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = v[k];
+    }
+    double mx = fmax(fmax(fabs(o[0]), fabs(o[1])), fmax(fabs(o[2]), fabs(o[3])));
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mx = fmax(mx, __shfl_xor(mx, m, 64));
+    const double scale = mx > 0.0 ? mx * (1.0 / 2147483000.0) : 1.0;
+    const double inv = 1.0 / scale;
+    if (c0 < Hp) {
+        int q[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) q[t] = (int)rint(o[t] * inv);
+        *reinterpret_cast<int4 *>(S1x + (size_t)row * Hp + c0) = make_int4(q[0], q[1], q[2], q[3]);
+    }
+    if (lane == 0) S1qs[row] = scale;
+}
+
 // Z1d[r, :] = sum_e val[e] * S1d[col[e], :] + b1     (fp64 fma chain in CSR order, 4 columns per lane)
 // One lane group per row of up to LT_ROW_SEG entries; on a graph with hub rows the first seg_blocks blocks of the
 // launch take one SEGMENT of a long row per lane group instead, raw sum into seg_out[segment] (k_spmm_f64_long adds
@@ -951,9 +978,17 @@ static int fp64_kslice(int n, int H, int F) {
 
 // The dense product S1d = X*W1 on the f64 matrix cores: rows [r0, r1) into dst[(r1 - r0), ldd].
 // quant: the whole product (r0 = 0, r1 = n) leaves as fixed-point rows in b->S1x / b->S1qs instead of dst (needs the split-K form)
+// (a rule of the SHAPES and the "s1_f32" knob only: every rank of a sharded run and a single-GPU run decide alike)
+static bool dense_quant_shapes(const lt_baseline *b) {
+    return (long long)b->n * b->Hp * (long long)sizeof(double) < ((long long)32 << 20) && b->H <= 256 && b->H % 4 == 0;
+}
 static bool dense_quant_possible(const lt_baseline *b) {
-    const int kslice = fp64_kslice(b->n, b->H, b->F);
-    return (b->F + kslice - 1) / kslice > 1 && b->H <= 256 && b->H % 4 == 0 && b->S1x && b->S1qs && b->slabs_d;
+    return dense_quant_shapes(b) && lt_tune().s1_f32 != 0 && b->S1x && b->S1qs;
+}
+static int quant_rows(lt_baseline *b, const double *S, hipStream_t st) {
+    hipLaunchKernelGGL(k_quant_rows_f64, dim3((unsigned)((b->n + 3) / 4)), dim3(256), 0, st, S, (long)b->Hp, b->n, b->H, b->Hp, b->S1x, b->S1qs);
+    LT_CHECK_LAUNCH();
+    return LT_OK;
 }
 static int launch_dense_s1d(lt_baseline *b, int r0, int r1, double *dst, long ldd_out, hipStream_t st, bool quant = false) {
     const int H = b->H, n = b->n, F = b->F, m = r1 - r0;
@@ -974,7 +1009,7 @@ static int launch_dense_s1d(lt_baseline *b, int r0, int r1, double *dst, long ld
         hipLaunchKernelGGL(k_gemm_f64acc, grid, dim3(256), 0, st, A, (long)b->ldx, b->W1, (long)H, out, ldd, m, H, F,
                            splits > 1 ? kslice : (F > 0 ? F : 1), stride);
     LT_CHECK_LAUNCH();
-    if (splits > 1 && quant) {
+    if (splits > 1 && quant && b->slabs_d) {
         hipLaunchKernelGGL(k_sum_slabs_f64_q, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, b->slabs_d, (long)m * H, splits, m, H, b->Hp,
                            b->S1x, b->S1qs);
         LT_CHECK_LAUNCH();
@@ -983,6 +1018,8 @@ static int launch_dense_s1d(lt_baseline *b, int r0, int r1, double *dst, long ld
         hipLaunchKernelGGL(k_sum_slabs_f64, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, b->slabs_d,
                            tot, splits, tot, H, dst, ldd_out);
         LT_CHECK_LAUNCH();
+    } else if (quant) {       // one K slice: the rows are in dst already
+        return quant_rows(b, dst, st);
     }
     return LT_OK;
 }
@@ -1231,7 +1268,13 @@ static int compute_s1d(lt_baseline *b, hipStream_t st) {
     b->cref_deferred = false;
     b->s1_f32 = false;
     if (b->S1d_external) {
-        // multi-GPU: S1d arrives by the caller's all-gather of the ranks' row shards (lt_baseline_refresh_rows_fp64)
+        // multi-GPU: S1d arrives by the caller's all-gather of the ranks' row shards (lt_baseline_refresh_rows_fp64); the rows
+        // take the storage form the single-GPU product would have (the same fp64 values -> the same fixed-point words)
+        if (dense_quant_possible(b)) {
+            int rc = quant_rows(b, b->S1d, st);
+            if (rc) return rc;
+            b->s1_f32 = true;
+        }
     } else if (want_feature_rows(b)) {
         // (writes the pad columns of S1d as zeros itself.)  The deferred cref + fp32 storage are for products the caches hold
         // (a fixed size rule, not the "tiled_min_bytes" knob, so that knob keeps every bit); beyond it the rows carry cref
@@ -1242,9 +1285,9 @@ static int compute_s1d(lt_baseline *b, hipStream_t st) {
     } else {
         // the matrix-core product; rows the caches hold leave as 32-bit fixed point (round 5: the storage form of the feature route:
         // "s1_f32" = 0 keeps them fp64)
-        const bool small = (long long)n * Hp * (long long)sizeof(double) < ((long long)32 << 20);
-        const bool quant = small && lt_tune().s1_f32 != 0 && dense_quant_possible(b);
-        if (!quant && Hp != H) LT_HIP(hipMemsetAsync(b->S1d, 0, (size_t)n * Hp * sizeof(double), st));
+        const bool quant = dense_quant_possible(b);
+        const int ks1 = fp64_kslice(n, H, b->F);
+        if ((!quant || (b->F + ks1 - 1) / ks1 <= 1) && Hp != H) LT_HIP(hipMemsetAsync(b->S1d, 0, (size_t)n * Hp * sizeof(double), st));
         int rc = launch_dense_s1d(b, 0, n, b->S1d, (long)Hp, st, quant);
         if (rc) return rc;
         b->s1_f32 = quant;
@@ -1482,9 +1525,10 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
         if (e == hipSuccess && fd_possible) e = hipMemsetAsync(gate, 0, sizeof(int), st);     // (the slice counter of k_ref_row_product)
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fref, (size_t)(b->F + FD_REF_PAD) * sizeof(float));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&frs, n1 * sizeof(double));
-        if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fs1x, n1 * b->Hp * sizeof(float));
-        if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fz1x, n1 * b->Hp * sizeof(float));
-        if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fs1q, n1 * sizeof(double));
+        const bool fixed = fd_possible || dense_quant_shapes(b);     // (the fixed-point rows: feature route, or a small dense product)
+        if (e == hipSuccess && fixed) e = hipMalloc((void **)&fs1x, n1 * b->Hp * sizeof(float));
+        if (e == hipSuccess && fixed) e = hipMalloc((void **)&fz1x, n1 * b->Hp * sizeof(float));
+        if (e == hipSuccess && fixed) e = hipMalloc((void **)&fs1q, n1 * sizeof(double));
     }
     if (alloc_agg) {
         if (e == hipSuccess) e = hipMalloc((void **)&yd, n1 * b->Fp * sizeof(double));

@@ -161,3 +161,34 @@ def test_baseline_attacks_host_math(monkeypatch, tmp_path):
     ref = np.concatenate([g["bf.baseline.norm_exist"], g["bf.baseline.norm_nonexist"]])
     got = np.asarray(torch.load(str(g["bf.baseline.filename"]), weights_only=False)["result"]["pred"])
     assert np.abs(got - ref).max() <= 2e-6
+
+
+def test_attacker_walk_cache_follows_the_model():
+    """Attacker._walk skips state_dict() while the model's parameters are the objects and storages of the last walk (round 5): an
+    in-place update keeps the cache (the baseline's refresh re-reads the borrowed tensors), a replaced parameter, a replaced
+    model and a model whose state_dict keys are not attribute paths walk again."""
+    import torch
+    from linkteller_amd.attacker import Attacker
+    from linkteller_amd.gcn import GCN, GCN3
+    a = Attacker.__new__(Attacker)
+    a.model = GCN(30, 16, 2, 0.5)
+    kind, sd = a._walk()
+    assert kind == "gcn2" and a._walk()[1] is sd                     # cached
+    with torch.no_grad():
+        a.model.gc2.weight.mul_(2)
+    assert a._walk()[1] is sd and torch.equal(sd["gc2.weight"], a.model.gc2.weight)
+    a.model.gc2.weight = torch.nn.Parameter(torch.zeros(16, 2))
+    kind2, sd2 = a._walk()
+    assert sd2 is not sd and sd2["gc2.weight"].data_ptr() == a.model.gc2.weight.data_ptr()
+    a.model = GCN3(30, 16, 8, 2, 0.5)
+    assert a._walk()[0] == "gcn3"
+
+    class Odd(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(3))
+
+        def state_dict(self, *a_, **k_):
+            return {"gc1.weight": self.w.detach()}
+    a.model = Odd()
+    assert a._walk()[0] == "generic" and a._walk_cache is None
