@@ -292,18 +292,20 @@ __global__ __launch_bounds__(512) void k_gemm_i8split3(const float *__restrict__
     {
         const float *xrow = X + (size_t)min(m0 + a_row, m - 1) * ldx;
         unsigned mx = 0;
-        for (int sb = st0; sb < st1; sb += 8) {
+        for (int sb = st0; sb < st1; sb += 8) {       // (no branch per element: indices clamped into the row, the surplus masked)
             float v[8][4];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int k = min(sb + u, st1 - 1) * I8_KS + a_k4;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[u][q] = k + q < F ? xrow[k + q] : 0.f;
+                for (int q = 0; q < 4; ++q) v[u][q] = xrow[min(k + q, F - 1)];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 8; ++u) {
+                const int k = min(sb + u, st1 - 1) * I8_KS + a_k4;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) mx = max(mx, __float_as_uint(v[u][q]) & 0x7fffffffu);
+                for (int q = 0; q < 4; ++q) mx = max(mx, k + q < F ? __float_as_uint(v[u][q]) & 0x7fffffffu : 0u);
+            }
         }
         mx = max(mx, (unsigned)__shfl_xor((int)mx, 1, 64));
         mx = max(mx, (unsigned)__shfl_xor((int)mx, 2, 64));
@@ -335,13 +337,27 @@ __global__ __launch_bounds__(512) void k_gemm_i8split3(const float *__restrict__
         }
     };
     (void)g_x;
-    auto convert = [&](int st) {          // raw X tile of step st -> digit planes As[st & 1]
-        float4 v = *reinterpret_cast<const float4 *>(raw + (st % 3) * I8_RAW_BYTES + a_row * 128 + (tid & 7) * 16);
-        const int k = st * I8_KS + a_k4;
-        if (k + 3 >= F) {        // the piece that straddles the end of a row (last step only): its DMA source was clamped
-            const float *xr = X + (size_t)min(m0 + a_row, m - 1) * ldx;
-            v.x = k < F ? xr[k] : 0.f; v.y = k + 1 < F ? xr[k + 1] : 0.f; v.z = k + 2 < F ? xr[k + 2] : 0.f; v.w = 0.f;
+    float4 v_tail = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        const float *xr = X + (size_t)min(m0 + a_row, m - 1) * ldx;
+        const int kt = (F / 4) * 4;               // the first k of the piece that straddles the row's end (none if F % 4 == 0)
+        if (kt < F && (kt & (I8_KS - 1)) == a_k4) {
+            v_tail.x = xr[kt];
+            if (kt + 1 < F) v_tail.y = xr[kt + 1];
+            if (kt + 2 < F) v_tail.z = xr[kt + 2];
         }
+    }
+    const unsigned lds_base = (unsigned)(size_t)i8_lds;          // LDS byte address of the dynamic block
+    auto convert = [&](int st) {          // raw X tile of step st -> digit planes As[st & 1]
+        // (every read of LDS that a DMA wrote is inline asm: hipcc otherwise drains vmcnt(0) in front of it -- it cannot tell which
+        //  bytes the loads in flight will write -- and the prefetch is gone; the waits and barriers below order them)
+        float4 v;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                     : "=v"(v)
+                     : "v"(lds_base + (unsigned)((st % 3) * I8_RAW_BYTES + a_row * 128 + (tid & 7) * 16))
+                     : "memory");
+        const int k = st * I8_KS + a_k4;
+        if (k + 3 >= F) v = v_tail;      // the piece that straddles the end of a row (its DMA source was clamped): read before the loop
         unsigned w[4], top[4], o[4];
         top[0] = i8_digits5(k < F ? v.x : 0.f, a_sc, w[0]);
         top[1] = i8_digits5(k + 1 < F ? v.y : 0.f, a_sc, w[1]);
@@ -382,17 +398,31 @@ __global__ __launch_bounds__(512) void k_gemm_i8split3(const float *__restrict__
         if (VAR != 2) { if (it + 2 < nst) issue_b(st + 2); }
         if (VAR != 4) { if (it + 1 < nst) convert(st + 1); }
         if (VAR != 1) {
-            const unsigned char *a = As + (st & 1) * I8_A3_BYTES + a_off;
-            const unsigned char *bq = Bs + (st % 3) * I8_B3_BYTES + b_off;
+            const unsigned a_addr = lds_base + (unsigned)(3 * I8_RAW_BYTES + 3 * I8_B3_BYTES + (st & 1) * I8_A3_BYTES + a_off);
+            const unsigned b_addr = lds_base + (unsigned)(3 * I8_RAW_BYTES + (st % 3) * I8_B3_BYTES + b_off);
             i32x4 av[I8_XD], bv[2][I8_WD];
-#pragma unroll
-            for (int d = 0; d < I8_XD; ++d) av[d] = *reinterpret_cast<const i32x4 *>(a + d * (I8_BM * I8_KS));
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int d = 0; d < I8_WD; ++d) bv[t][d] = *reinterpret_cast<const i32x4 *>(bq + d * (256 * I8_KS) + t * 32 * 16);
+            asm volatile("ds_read_b128 %0, %13\n\t"
+                         "ds_read_b128 %5, %14\n\t"
+                         "ds_read_b128 %1, %13 offset:2048\n\t"
+                         "ds_read_b128 %6, %14 offset:8192\n\t"
+                         "ds_read_b128 %2, %13 offset:4096\n\t"
+                         "ds_read_b128 %7, %14 offset:16384\n\t"
+                         "ds_read_b128 %3, %13 offset:6144\n\t"
+                         "ds_read_b128 %8, %14 offset:24576\n\t"
+                         "ds_read_b128 %4, %13 offset:8192\n\t"
+                         "ds_read_b128 %9, %14 offset:512\n\t"
+                         "ds_read_b128 %10, %14 offset:8704\n\t"
+                         "ds_read_b128 %11, %14 offset:16896\n\t"
+                         "ds_read_b128 %12, %14 offset:25088\n\t"
+                         "s_waitcnt lgkmcnt(4)"
+                         : "=&v"(av[0]), "=&v"(av[1]), "=&v"(av[2]), "=&v"(av[3]), "=&v"(av[4]), "=&v"(bv[0][0]), "=&v"(bv[0][1]),
+                           "=&v"(bv[0][2]), "=&v"(bv[0][3]), "=&v"(bv[1][0]), "=&v"(bv[1][1]), "=&v"(bv[1][2]), "=&v"(bv[1][3])
+                         : "v"(a_addr), "v"(b_addr)
+                         : "memory");
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
+                if (t == 1)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[1][0]), "+v"(bv[1][1]), "+v"(bv[1][2]), "+v"(bv[1][3])::"memory");
 #pragma unroll
                 for (int i = 0; i < I8_XD; ++i)
 #pragma unroll
