@@ -621,9 +621,13 @@ def main():
         if cls == "fp64_product" and fp64_route == 1:
             out_b = 8 if os.environ.get("LT_S1_F32") == "0" else 4      # the rows leave as 32-bit fixed point unless s1_f32 = 0
             alg = n * f * 4 + f * h * 4 + n * hp * out_b
+            rec = os.environ.get("LT_RECORDS_EARLY", "1") != "0" and mode == "delta"
             return {"kernel": "k_s1d_feature_rows (the reference vector's product and its slice sum ride in the same launch)",
                     "bound": "hbm", "achieved": round(alg / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(alg / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": tr, "algorithmic_bytes_per_launch": int(alg), "avg_launch_us": us,
+                    **({"also_in_this_launch": "the record blocks of the call's probe chunk (round 5, `records_early`: they left the "
+                                               "pre-activation's launch, the step lost 0.7 us; this launch alone reads 21.4 us = 0.37 "
+                                               "without them, profiles/r04_step_kernel_stats.csv)"} if rec else {}),
                     "units_per_launch": f"one pass over X[{n}x{f}] fp32 -> S1d = X*W1 [{n}x{h}], fp64-accumulated (feature rows as differences to a "
                                         f"reference row); bytes = N*F*4 + F*H*4 + N*H*{out_b}"}
         if cls == "fp64_product":
