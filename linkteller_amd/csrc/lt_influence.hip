@@ -2002,23 +2002,27 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_rows(
                 items[k] = S2x + (size_t)off[b] * C;
             }
             if (d <= LT_SB_SHORT) {
-                // short rows (a lane holds one to four entries): one probe after the other, measured faster there (the batched
-                // form below on them too: 19.8 -> 27.6 us on the power-law graph)
+                // short rows (a lane holds one to four entries): entry by entry (the batched form below on them too: 19.8 -> 27.6 us on
+                // the power-law graph)
+                // (round 5: the membership words of the group's LT_SB_UNR probes for an entry go out TOGETHER -- one trip instead of one
+                // per probe: 0.0735 -> 0.0719 ms for the power-law step; the members' items stay behind their branch, they are rare.  Per
+                // probe the entries come in the same order: same bits.  The lane's up to four entries in one trip as well: slower, 0.081.)
+                for (int e = q; e < d; e += LT_L2_LANES) {
+                    const int c = scol[e];
+                    const unsigned bit = 1u << (c & 31);
+                    const float a = sval[e];
+                    uint2 w[LT_SB_UNR];
 #pragma unroll
-                for (int k = 0; k < LT_SB_UNR; ++k) {
-                    for (int e = q; e < d; e += LT_L2_LANES) {
-                        const int c = scol[e];
-                        const uint2 w = mb[k][c >> 5];
-                        const unsigned bit = 1u << (c & 31);
-                        if (w.x & bit) {
-                            const float *it = items[k] + (size_t)(w.y + __popc(w.x & (bit - 1u))) * C;
-                            const float a = sval[e];
+                    for (int k = 0; k < LT_SB_UNR; ++k) w[k] = mb[k][c >> 5];
+#pragma unroll
+                    for (int k = 0; k < LT_SB_UNR; ++k)
+                        if (w[k].x & bit) {
+                            const float *it = items[k] + (size_t)(w[k].y + __popc(w[k].x & (bit - 1u))) * C;
 #pragma unroll
                             for (int cc = 0; cc < CP; ++cc)
                                 if (cc < C) acc[k][cc] = fmaf(a, it[cc], acc[k][cc]);
                             t[k] = 1;
                         }
-                    }
                 }
             } else {
                 // longer rows (a lane holds up to 16 entries of its chain): LT_SB_EB of them x LT_SB_UNR probes per trip -- all
