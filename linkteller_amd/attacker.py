@@ -138,11 +138,23 @@ class Attacker:
                 h = engine.spmm(g, engine.gemm(h, w), b, relu=li < len(layers) - 1)
             return h
 
+        def ids(nodes, what):
+            # node lists arrive as numpy / lists (direct callers) or as the cached int32 device lists of _device_nodes
+            # (influence_matrix); out-of-range ids raise IndexError as the reference's features[v] does (attacker.py:103)
+            if isinstance(nodes, torch.Tensor):
+                t = nodes.to(device=x.device, dtype=torch.long)
+            else:
+                t = torch.as_tensor(np.asarray(nodes, dtype=np.int64), device=x.device)
+            if t.numel() and (int(t.min()) < 0 or int(t.max()) >= int(x.shape[0])):
+                raise IndexError(f"{what}: node id out of range for {int(x.shape[0])} nodes")
+            return t
+
         s1 = engine.gemm(x, layers[0][0])
-        obs = torch.as_tensor(np.asarray(observe_nodes, dtype=np.int64), device=x.device)
+        obs = ids(observe_nodes, "observe_nodes")
+        probe_ids = ids(probe_nodes, "probe_nodes").tolist()
         base = rest(s1)[obs]
-        rows = torch.empty((len(probe_nodes), obs.numel()), dtype=torch.float32, device=x.device)
-        for i, v in enumerate(np.asarray(probe_nodes, dtype=np.int64)):
+        rows = torch.empty((len(probe_ids), obs.numel()), dtype=torch.float32, device=x.device)
+        for i, v in enumerate(probe_ids):
             xv = x[v]
             s1p = s1.clone()
             s1p[v] = engine.gemm((xv + xv * delta)[None, :].contiguous(), layers[0][0])[0]

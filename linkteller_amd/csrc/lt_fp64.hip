@@ -842,6 +842,44 @@ static size_t fd_smem_bytes(int F) {
 // cnt row gathers per node, the matrix cores F * H at ~10 x the rate
 static int fd_hint_cap(int F) { const int c = F / 16; return c < 8 ? 8 : (c > FD_CAP ? FD_CAP : c); }
 
+#include "lt_feature_ring.hip.h"
+// the slabs of m W1: ceil(F / 64) K slices of k_s1d_feature_rows, or FR_SLABS x 256 of the ring kernel
+static size_t fd_slab_doubles(int F, int H) {
+    const size_t a = (size_t)((F + 63) / 64) * H, r = (size_t)FR_SLABS * 256;
+    return a > r ? a : r;
+}
+static int fd_cu_count() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        int c = 0;
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+        cus[dev] = c;
+    }
+    return cus[dev];
+}
+// Whether the persistent ring form serves this product (else the row-per-wave kernel): rows 8-byte aligned, four hidden columns per
+// lane, a row's chunks + the reference vector + the lists inside one CU's LDS, enough rows to give every CU's waves one
+static bool fd_ring_ok(const lt_baseline *b, int n) {
+    const int knob = lt_tune().feature_ring;
+    if (knob == 0) return false;
+    const int nch = fr_chunks(b->F);
+    return b->H % 4 == 0 && b->H <= 256 && b->Hp == b->H && b->ldx % 2 == 0 && ((uintptr_t)b->X % 8) == 0 && nch >= 4 && nch <= 15 &&
+           fr_smem_bytes(nch) <= (size_t)FR_LDS_MAX && n >= (knob > 0 ? 2 : lt_tune().feature_ring_min_rows) && b->ldx >= 260;
+}
+static int fd_ring_allow_lds() {
+    static unsigned long long done = 0ull;
+    int dev = 0;
+    LT_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !((done >> dev) & 1ull)) {
+        LT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_s1d_feature_ring<13>), hipFuncAttributeMaxDynamicSharedMemorySize, FR_LDS_MAX));
+        LT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_s1d_feature_ring<0>), hipFuncAttributeMaxDynamicSharedMemorySize, FR_LDS_MAX));
+        if (dev >= 0 && dev < 64) done |= 1ull << dev;
+    }
+    return LT_OK;
+}
+
 // The reference vector m[k] = the more frequent of (min, max) of X[0 .. rows, k] over the first rows <= 64 rows: the
 // majority value of a two-valued column.  Computed ONCE (lt_baseline_enable_fp64): any m is a correct reference, so a
 // later change of X costs speed at worst (and the dense hint then retires the route).
@@ -1221,9 +1259,33 @@ static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, b
                            b->fd_cref, (unsigned *)b->fd_gate);
         LT_CHECK_LAUNCH();
     }
-    const int nslab = defer ? nz : 0;
     const double *cref = defer ? (const double *)nullptr : b->fd_cref;
     float *s1x = (defer && b->S1x && b->S1qs && lt_tune().s1_f32 != 0) ? b->S1x : nullptr;
+    if (fd_ring_ok(b, n)) {
+        // the persistent ring form (lt_feature_ring.hip.h): one workgroup per CU; a probe chunk's record blocks cannot ride here (the
+        // workgroups take the CU's whole LDS) -- they go with the pre-activation's launch as with "records_early" = 0
+        int rc = fd_ring_allow_lds();
+        if (rc) return rc;
+        const int nch = fr_chunks(F), G = fd_cu_count();
+        const int nsl = defer ? (FR_SLABS < G ? FR_SLABS : G) : 0;
+        // weights of the row ranges: w_all per workgroup, less the bytes of a slab's K range of W1 in units of a workgroup's rows
+        const double row_bytes = (double)n * F * 4.0 / G, slab_bytes = nsl ? (double)F * H * 4.0 / nsl : 0.0;
+        const int w_all = 1024;
+        int w_cut = row_bytes > 0.0 ? (int)(w_all * slab_bytes / (row_bytes + slab_bytes * nsl / G) + 0.5) : 0;
+        if (w_cut > w_all / 2) w_cut = w_all / 2;
+#define LT_FR_LAUNCH(N_)                                                                                                      \
+    hipLaunchKernelGGL(k_s1d_feature_ring<N_>, dim3((unsigned)G), dim3(64 * FR_WAVES), fr_smem_bytes(nch), st, n, F, H, b->X, (long)b->ldx, \
+                       b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F) < FR_USE ? fd_hint_cap(F) : FR_USE, b->fd_hint_dev, nsl, b->fd_slabs,  \
+                       zstate, s1x, defer ? (unsigned *)b->fd_gate : (unsigned *)nullptr, b->fd_cref, b->S1qs, nch, w_all, w_cut)
+        if (nch == 13) LT_FR_LAUNCH(13);       // (F = 3170, utils/load.py:56: the twitch loader's width)
+        else LT_FR_LAUNCH(0);
+#undef LT_FR_LAUNCH
+        LT_CHECK_LAUNCH();
+        b->cref_deferred = defer;
+        b->s1_f32 = s1x != nullptr;
+        return LT_OK;
+    }
+    const int nslab = defer ? nz : 0;
     unsigned blocks = (unsigned)((n + FD_WAVES - 1) / FD_WAVES + nslab);
     const size_t smem = fd_smem_bytes(F);
     lt_bits_job jb = lt_bits_job{};
@@ -1479,7 +1541,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
         int *gate = nullptr;
         hipError_t e = hipMalloc((void **)&cref, (size_t)b->Hp * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&fref, (size_t)(b->F + FD_REF_PAD) * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void **)&fslabs, (size_t)((b->F + 63) / 64) * b->H * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&fslabs, fd_slab_doubles(b->F, b->H) * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&gate, sizeof(int));
         if (e == hipSuccess) e = hipMemsetAsync(gate, 0, sizeof(int), st);
         if (e == hipSuccess) e = hipMalloc((void **)&s1d, (size_t)n_probe * b->Hp * sizeof(double));
@@ -1520,7 +1582,7 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
         if (e == hipSuccess && lt_f64_seg_rows(b->g) > 0) e = hipMalloc((void **)&segd, (size_t)lt_f64_seg_rows(b->g) * b->Hp * sizeof(double));
         if (e == hipSuccess && splits > 1) e = hipMalloc((void **)&slabs, (size_t)splits * n1 * b->H * sizeof(double));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&cref, (size_t)b->Hp * sizeof(double));
-        if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fslabs, (size_t)((b->F + 63) / 64) * b->H * sizeof(double));
+        if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fslabs, fd_slab_doubles(b->F, b->H) * sizeof(double));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&gate, sizeof(int));
         if (e == hipSuccess && fd_possible) e = hipMemsetAsync(gate, 0, sizeof(int), st);     // (the slice counter of k_ref_row_product)
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fref, (size_t)(b->F + FD_REF_PAD) * sizeof(float));

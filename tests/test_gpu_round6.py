@@ -1,0 +1,86 @@
+"""Round-6 GPU tests: the generic (> 3 layers / wide GCN3) path through the drop-in API, the ring form of the product rows,
+the hub-row sharding of large calls."""
+import argparse
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, csr_from
+
+pytestmark = pytest.mark.gpu
+
+
+def _stack_reference(adj_hat, x, layers, probes, observe, delta):
+    """attacker.py:100-108, 220-229 for a GraphConvolution stack of any depth, in fp64 (gcn/layers.py:30-36 per layer,
+    relu between the layers as gcn/models.py:19-24, 39-45 place it)."""
+    import scipy.sparse as sp
+    a = sp.csr_matrix(adj_hat).astype(np.float64)
+
+    def forward(xx):
+        h = xx
+        for li, (w, b) in enumerate(layers):
+            h = a @ (h @ w) + b
+            if li < len(layers) - 1:
+                h = np.maximum(h, 0.0)
+        return h
+
+    base = forward(x)
+    out = np.zeros((len(probes), len(observe)))
+    for i, v in enumerate(probes):
+        xp = x.copy()
+        xp[v] = x[v] + x[v] * delta
+        out[i] = np.linalg.norm(((forward(xp) - base) / delta)[observe], axis=1)
+    return out
+
+
+def test_generic_stack_through_influence_matrix(gpu):
+    """Attacker.influence_matrix() hands _rows() the cached int32 DEVICE node lists; a model on the generic
+    path (four layers here) reached _rows_generic with them and np.asarray raised.  The API result must equal the direct
+    numpy-list call bit for bit and sit in the fp32 finite difference's noise class of the fp64 evaluation."""
+    from linkteller_amd import graph
+    from linkteller_amd.attacker import Attacker
+    from linkteller_amd.gcn import GraphConvolution
+
+    g = np.load(os.path.join(GOLDEN, "next_rows.npz"), allow_pickle=False)
+    a = csr_from(g, "adj")
+    x = torch.from_numpy(g["x"]).to(gpu)
+    adj_hat = graph.first_order_gcn(a)
+    adj_t = graph.sparse_mx_to_torch_sparse_tensor(adj_hat).to(gpu)
+    w = types.SimpleNamespace(features_2=x, adj_2=adj_t, adj_ori=a, n_nodes=a.shape[0])
+
+    class Stack4(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(5)
+            self.gc1 = GraphConvolution(x.shape[1], 24)
+            self.gc2 = GraphConvolution(24, 16)
+            self.gc3 = GraphConvolution(16, 12)
+            self.gc4 = GraphConvolution(12, 3)
+
+        def forward(self, xx, adj):
+            h = self.gc1(xx, adj, relu=True)
+            h = self.gc2(h, adj, relu=True)
+            h = self.gc3(h, adj, relu=True)
+            return self.gc4(h, adj)
+
+    model = Stack4().to(gpu).eval()
+    args = argparse.Namespace(dataset="twitch/ES/RU", sample_type="unbalanced", n_test=16, sample_seed=42,
+                              influence=1e-4, mode="vanilla-clean", attack_mode="efficient")
+    atk = Attacker(args, model, w)
+    atk.prepare_test_data()
+    assert atk._walk()[0] == "generic"
+    got = atk.influence_matrix()                      # device node lists -> _rows -> _rows_generic
+    nodes = np.asarray(atk.test_nodes, dtype=np.int64)
+    direct = atk._rows_generic(nodes, nodes).cpu().numpy().astype(np.float64)
+    assert got.dtype == np.float64 and got.shape == (16, 16)
+    assert np.array_equal(got, direct)
+    layers = [(getattr(model, f"gc{i}").weight.detach().cpu().numpy().astype(np.float64),
+               getattr(model, f"gc{i}").bias.detach().cpu().numpy().astype(np.float64)) for i in (1, 2, 3, 4)]
+    ref = _stack_reference(adj_hat, g["x"].astype(np.float64), layers, nodes, nodes, 1e-4)
+    # fp32 finite difference at delta = 1e-4: absolute noise ~ ulp(logit) / 1e-4, a few 1e-3 of the largest score
+    assert np.abs(got - ref).max() <= 3e-2 * ref.max(), np.abs(got - ref).max() / ref.max()
+    with pytest.raises(IndexError):
+        atk._rows_generic(np.array([0, a.shape[0]]), nodes)
