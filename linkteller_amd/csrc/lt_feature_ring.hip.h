@@ -46,6 +46,36 @@ __device__ __forceinline__ void fr_wait_dyn(int n) {
 
 typedef __attribute__((address_space(3))) void *fr_lds_ptr_t;
 
+// max over the wave's 64 lanes (DPP inside a row of 16, the four rows by v_readlane): ~12 VALU instead of six ds_bpermute round trips
+__device__ __forceinline__ unsigned fr_wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));      // quad_perm [1,0,3,2]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));      // quad_perm [2,3,0,1]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));     // row_half_mirror
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true));     // row_mirror
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
+}
+// the largest of 64 non-negative finite doubles, exactly (their bit patterns order as integers: high words first, then the low
+// words of the lanes that hold the largest high word)
+__device__ __forceinline__ double fr_wave_max_nonneg(double v) {
+    const unsigned hi = (unsigned)__double2hiint(v), lo = (unsigned)__double2loint(v);
+    const unsigned mh = fr_wave_max_u32(hi);
+    const unsigned ml = fr_wave_max_u32(hi == mh ? lo : 0u);
+    return __hiloint2double((int)mh, (int)ml);
+}
+
+#ifdef LT_FR_TRACE      // tools/read_lab/ring_lab.hip: stamps of every wave's rows on the constant 100 MHz clock
+__device__ unsigned long long *g_fr_trace = nullptr;
+#define FR_STAMP(k_)                                                                                                   \
+    do {                                                                                                               \
+        if (lane == 0 && g_fr_trace && fr_slot < 4)                                                                    \
+            g_fr_trace[(((size_t)blockIdx.x * FR_WAVES + wid) * 4 + fr_slot) * 8 + (k_)] = wall_clock64();             \
+    } while (0)
+#else
+#define FR_STAMP(k_)
+#endif
+
 // NCHT: the chunks of a row at compile time (the counted wait is an immediate), 0 = any (a branch per wait)
 template <int NCHT>
 __global__ __launch_bounds__(64 * FR_WAVES) void k_s1d_feature_ring(
@@ -77,12 +107,20 @@ __global__ __launch_bounds__(64 * FR_WAVES) void k_s1d_feature_ring(
     auto issue = [&](int row, int u) {
         const char *rp = reinterpret_cast<const char *>(X + (long)row * ldx);
         const char *cb = rp - (reinterpret_cast<uintptr_t>(rp) & 15) + (size_t)u * 1024;
-        unsigned off = lane_off;
-        // the last row's chunks may reach past the matrix: a lane whose 16 bytes lie wholly behind it reads the chunk's first
-        // 16 instead (its columns are >= F: masked when compared); a window that only straddles the end stays inside its own
-        // 16-byte unit (same page)
-        if (row == n - 1) off = (cb + lane_off < x_end) ? lane_off : 0u;
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(cb + off), (fr_lds_ptr_t)(ring + u * 256), 16, 0, 0);
+        if (row == n - 1) {
+            // the last row's chunks may reach past the matrix: a lane whose 16 bytes lie wholly behind it reads the chunk's first
+            // 16 instead (its columns are >= F: masked when compared); a window that only straddles the end stays inside its own
+            // 16-byte unit (same page)
+            const unsigned off = (cb + lane_off < x_end) ? lane_off : 0u;
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(cb + off), (fr_lds_ptr_t)(ring + u * 256), 16, 0, 0);
+        } else {
+            // uniform chunk base + 32-bit lane offset: the saddr form of global_load_lds, no VALU (the two empty asm statements keep
+            // hipcc from re-associating the address into a 64-bit VALU add per chunk: k_full_stageA_lds)
+            unsigned off = lane_off;
+            asm("" : "+s"(cb));
+            asm("" : "+v"(off));
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(cb + off), (fr_lds_ptr_t)(ring + u * 256), 16, 0, 0);
+        }
     };
     int cur = rb0 + wid < rb1 ? rb0 + wid : -1;          // wave-uniform: the row being worked on; the first one is static
     if (cur >= 0)
@@ -199,6 +237,189 @@ __global__ __launch_bounds__(64 * FR_WAVES) void k_s1d_feature_ring(
         return row < rb1 ? row : -1;
     };
     int nxt = claim();
+    [[maybe_unused]] int fr_slot = 0;
+    // fixed-point words / fp64 values of a finished row, and the store of them
+    auto finish_row = [&](const double (&acc)[4], int (&q)[4], double &scale, f64x4 &o) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] = own ? (cref ? crefv[t] + acc[t] : acc[t]) : 0.0;
+        if (S1x) {      // 32-bit fixed point with one scale per row (k_s1d_feature_rows: the same words for the same fp64 values)
+            const double mx = fr_wave_max_nonneg(fmax(fmax(fabs(o[0]), fabs(o[1])), fmax(fabs(o[2]), fabs(o[3]))));
+            scale = mx > 0.0 ? mx * (1.0 / 2147483000.0) : 1.0;
+            const double inv = 1.0 / scale;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) q[t] = (int)rint(o[t] * inv);
+        }
+    };
+    auto store_row = [&](int row, const int (&q)[4], double scale, const f64x4 &o) {
+        if (S1x) {
+            if (own) *reinterpret_cast<int4 *>(S1x + (size_t)row * H + c0) = make_int4(q[0], q[1], q[2], q[3]);
+            if (lane == 0) S1qs[row] = scale;
+        } else if (own) {
+            *reinterpret_cast<f64x4 *>(S1d + (size_t)row * H + c0) = o;
+        }
+        if (zstate && lane == 0) zstate[row] = 0;
+    };
+    if constexpr (NCHT > 0) {
+        // ---- whole rows at a time.  What a wave does per row is a chain of dependent instructions with one other wave on its SIMD to
+        // hide behind (a dependent VALU -> SALU -> branch hop is ~10-20 cycles here: the row-per-wave kernel's 52 ballot steps cost
+        // 3.6 us of a wave's row, tools/read_lab/ring_lab timeline), so the row is made of FEW instructions:
+        //   1. the row's chunks and the reference values go to registers in one burst of LDS reads; one bit per value says
+        //      whether it differs (xor, min, shift-or: plain VALU, four independent accumulators);
+        //   2. the lane's three lowest flagged values are read again from LDS in ONE trip (a register array cannot be indexed
+        //      by a lane's own bit number) and appended level by level -- order (level, lane), a function of the data alone;
+        //      lanes with more take a loop;
+        //   3. the W1 rows of the list are asked for (inline asm, no padding), the next row's DMAs go out BEHIND them -- loads
+        //      return in order, so the walk's hand-counted wait leaves those NCHT DMAs in flight -- then the fp64 sums;
+        //   4. the finished words are stored one row later: the drain at the top of a row never waits for a store.
+        int prow = -1, pq[4] = {0, 0, 0, 0};
+        double pscale = 1.0;
+        f64x4 po = {0.0, 0.0, 0.0, 0.0};
+        while (cur >= 0) {
+            const char *rp = reinterpret_cast<const char *>(X + (long)cur * ldx);
+            const int shift = (int)((reinterpret_cast<uintptr_t>(rp) & 15) >> 2);
+            FR_STAMP(0);
+            fr_wait<0>();                                             // the row has landed (nothing younger than its DMAs is in flight)
+            FR_STAMP(1);
+            const int jb0 = 4 * lane - shift;                         // column of the lane's first value of chunk 0
+            unsigned fl[4] = {0u, 0u, 0u, 0u};                        // bit (4 u + v) & 31 of fl[u / 8 * 2 + (v & 1)... ] -- see `word`
+            {
+                f32x4 xv[NCHT];
+                f32x2_ r01[NCHT], r23[NCHT];
+#pragma unroll
+                for (int u = 0; u < NCHT; ++u) {
+                    xv[u] = *reinterpret_cast<const f32x4 *>(ring + u * 256 + 4 * lane);
+                    r01[u] = *reinterpret_cast<const f32x2_ *>(sref + u * 256 + jb0 + 2);
+                    r23[u] = *reinterpret_cast<const f32x2_ *>(sref + u * 256 + jb0 + 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < NCHT; ++u) {
+                    const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+                    const float rr[4] = {r01[u].x, r01[u].y, r23[u].x, r23[u].y};
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        // (bitwise: +0 against -0 is listed with a difference of exactly zero; NaNs are refused at baseline creation)
+                        unsigned t = min(__float_as_uint(xs[v]) ^ __float_as_uint(rr[v]), 1u);
+                        // chunks 1 .. NCHT - 3 lie inside the row for every F with NCHT chunks; the others are masked by column
+                        if (u == 0 || u >= NCHT - 2) t = (unsigned)(u * 256 + jb0 + v) < (unsigned)F ? t : 0u;
+                        const int bit = 4 * u + v;                    // flags word bit / 32, two accumulators per word (v & 1)
+                        fl[(bit >> 5) * 2 + (v & 1)] |= t << (bit & 31);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long flags = ((unsigned long long)(fl[2] | fl[3]) << 32) | (unsigned long long)(fl[0] | fl[1]);
+            // levels 0 .. 2 in one LDS trip
+            int total = 0;
+            {
+                int jq[3];
+                float xq[3], rq[3];
+                bool has[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    has[t] = flags != 0ull;
+                    const int bit = has[t] ? __ffsll((long long)flags) - 1 : 0;
+                    flags &= flags - 1ull;                            // (0 stays 0)
+                    const int u = bit >> 2, v = bit & 3;
+                    jq[t] = u * 256 + jb0 + v;
+                    xq[t] = ring[u * 256 + 4 * lane + v];
+                    rq[t] = sref[max(jq[t], 0) + 2];
+                }
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const unsigned long long m = __ballot(has[t]);
+                    const int pos = total + __popcll(m & lt);
+                    if (has[t] && pos < FR_USE) { mj[pos] = jq[t]; mv[pos] = (double)xq[t] - (double)rq[t]; }
+                    total += __popcll(m);
+                }
+            }
+            while (__ballot(flags != 0ull)) {                         // lanes with more than three (a handful of rows)
+                const bool has = flags != 0ull;
+                const unsigned long long m = __ballot(has);
+                if (has) {
+                    const int bit = __ffsll((long long)flags) - 1;
+                    flags &= flags - 1ull;
+                    const int u = bit >> 2, v = bit & 3, j = u * 256 + jb0 + v;
+                    const float xq = ring[u * 256 + 4 * lane + v], rq = sref[j + 2];
+                    const int pos = total + __popcll(m & lt);
+                    if (pos < FR_USE) { mj[pos] = j; mv[pos] = (double)xq - (double)rq; }
+                }
+                total += __popcll(m);
+            }
+            if (prow >= 0) store_row(prow, pq, pscale, po);           // (a row late: see 4.)
+            FR_STAMP(2);
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            const unsigned c0b = own ? 16u * (unsigned)lane : 0u;     // byte offset of the lane's columns in a W1 row
+            // entries [e, e + cnt), cnt <= FR_P: their W1 rows asked for (inline asm: with an LDS-DMA in flight hipcc (ROCm 7.2) puts
+            // s_waitcnt vmcnt(0) in front of the first use of any ordinary load's result -- that would drain the DMAs issued just
+            // behind them), (dma) the next row's DMAs, the hand-counted wait -- exactly the NCHT DMAs are younger than the last
+            // load; "memory" clobbers keep every other memory operation outside, an extra one would only make the wait stricter --
+            // then the sums in list order
+            auto batch = [&](int e, int cnt, bool dma) {
+                f32x4 w[FR_P];
+#pragma unroll
+                for (int k = 0; k < FR_P; ++k) {
+                    if (k < cnt) {
+                        const char *p = reinterpret_cast<const char *>(W1) + (size_t)(unsigned)mj[e + k] * (unsigned)(4 * H) + c0b;
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w[k]) : "v"(p) : "memory");
+                    }
+                }
+                if (dma) {
+#pragma unroll
+                    for (int u = 0; u < NCHT; ++u) issue(nxt, u);
+                    fr_wait<NCHT>();
+                } else {
+                    fr_wait<0>();
+                }
+#pragma unroll
+                for (int k = 0; k < FR_P; ++k) {
+                    if (k < cnt) {
+                        asm volatile("" : "+v"(w[k]));               // (the value exists from here on)
+                        const double d = mv[e + k];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc[t] = fma(d, (double)w[k][t], acc[t]);
+                    }
+                }
+            };
+            auto walk = [&](int cnt, bool first) {
+                first = first && nxt >= 0;                            // (whether the next row's DMAs are still to be issued)
+                for (int e = 0; e < cnt; e += FR_P) { batch(e, min(cnt - e, FR_P), first); first = false; }
+                if (first) {                                          // (an empty list)
+#pragma unroll
+                    for (int u = 0; u < NCHT; ++u) issue(nxt, u);
+                }
+            };
+            if (total <= FR_USE) {
+                walk(total, true);
+            } else {
+                // a dense row (see the chunk-wise form below)
+                if (nxt >= 0) {
+#pragma unroll
+                    for (int u = 0; u < NCHT; ++u) issue(nxt, u);
+                }
+                const float *xr = X + (long)cur * ldx;
+                for (int j0 = 0; j0 < F; j0 += 64) {
+                    const int j = j0 + lane;
+                    const float xs = j < F ? xr[j] : 0.f;
+                    const float r = j < F ? sref[j + 2] : 0.f;
+                    const bool diff = j < F && xs != r;
+                    const unsigned long long m = __ballot(diff);
+                    if (diff) { const int pos = __popcll(m & lt); mj[pos] = j; mv[pos] = (double)xs - (double)r; }
+                    walk(__popcll(m), false);
+                }
+            }
+            FR_STAMP(3);
+            if (total > hint_cap && lane == 0) *dense_hint = 1;
+            finish_row(acc, pq, pscale, po);
+            prow = cur;
+            FR_STAMP(4);
+            ++fr_slot;
+            cur = nxt;
+            if (cur >= 0) nxt = claim();
+        }
+        if (prow >= 0) store_row(prow, pq, pscale, po);
+        return;
+    }
     while (cur >= 0) {
         const char *rp = reinterpret_cast<const char *>(X + (long)cur * ldx);
         const int shift = (int)((reinterpret_cast<uintptr_t>(rp) & 15) >> 2);         // floats between the chunk's start and the row's
@@ -272,27 +493,12 @@ __global__ __launch_bounds__(64 * FR_WAVES) void k_s1d_feature_ring(
             }
         }
         if (total > hint_cap && lane == 0) *dense_hint = 1;
-        if (zstate && lane == 0) zstate[cur] = 0;
-        f64x4 o;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) o[t] = own ? crefv[t] + acc[t] : 0.0;
-        if (!cref) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) o[t] = own ? acc[t] : 0.0;
-        }
-        if (S1x) {      // 32-bit fixed point with one scale per row (k_s1d_feature_rows: same words for the same fp64 values)
-            double mx = fmax(fmax(fabs(o[0]), fabs(o[1])), fmax(fabs(o[2]), fabs(o[3])));
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) mx = fmax(mx, __shfl_xor(mx, m, 64));
-            const double scale = mx > 0.0 ? mx * (1.0 / 2147483000.0) : 1.0;
-            const double inv = 1.0 / scale;
-            int q[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) q[t] = (int)rint(o[t] * inv);
-            if (own) *reinterpret_cast<int4 *>(S1x + (size_t)cur * H + c0) = make_int4(q[0], q[1], q[2], q[3]);
-            if (lane == 0) S1qs[cur] = scale;
-        } else if (own) {
-            *reinterpret_cast<f64x4 *>(S1d + (size_t)cur * H + c0) = o;
+        {
+            int q[4] = {0, 0, 0, 0};
+            double scale = 1.0;
+            f64x4 o;
+            finish_row(acc, q, scale, o);
+            store_row(cur, q, scale, o);
         }
         cur = nxt;
         if (cur >= 0) nxt = claim();

@@ -5,6 +5,7 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -Iinclude -Ilinkteller_amd/csrc -c tools/read_lab/ring_lab.hip -o /tmp/ring_lab.o && \
 //   (cd linkteller_amd/csrc && hipcc --offload-arch=gfx950 /tmp/ring_lab.o lt_core.o lt_gemm.o lt_spmm.o lt_forward.o lt_influence.o lt_gcn3.o lt_dp.o -o ../../tools/read_lab/ring_lab)
 //   tools/read_lab/ring_lab [n F H density special]
+#define LT_FR_TRACE
 #include "../../linkteller_amd/csrc/lt_fp64.hip"
 #include <algorithm>
 #include <cmath>
@@ -171,6 +172,54 @@ int main(int argc, char **argv) {
         launch_ring(n, F, H, b, defer);
         fetch(defer, r2);
         std::printf("  ring kernel run twice: %s\n", r2 == r ? "same bits" : "BITS DIFFER");
+    }
+    {   // timeline of the ring kernel (deferred form): stamps 0 row begun, 1 landed, 2 list made, 3 walked, 4 finished; per wave and row slot
+        const size_t nw = (size_t)g_cus * FR_WAVES;
+        unsigned long long *trace;
+        hipMalloc(&trace, nw * 32 * 8);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_fr_trace), &trace, sizeof(trace));
+        std::vector<unsigned long long> h(nw * 32);
+        for (int rep = 0; rep < 3; ++rep) {
+            hipMemset(trace, 0, nw * 32 * 8);
+            hipDeviceSynchronize();
+            launch_ring(n, F, H, b, true);
+            hipDeviceSynchronize();
+        }
+        hipMemcpy(h.data(), trace, h.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (size_t i = 0; i < h.size(); ++i) if (h[i]) { t0 = std::min(t0, h[i]); t1 = std::max(t1, h[i]); }
+        std::printf("ring timeline: first stamp -> last stamp %.2f us\n", (t1 - t0) * 0.01);
+        const char *nm[5] = {"row begun", "landed", "list made", "walked", "finished"};
+        for (int slot = 0; slot < 4; ++slot) {
+            for (int k = 0; k < 5; ++k) {
+                std::vector<double> v;
+                for (size_t w = 0; w < nw; ++w) if (h[(w * 4 + slot) * 8 + k]) v.push_back((h[(w * 4 + slot) * 8 + k] - t0) * 0.01);
+                if (v.empty()) continue;
+                std::sort(v.begin(), v.end());
+                const size_t m = v.size();
+                std::printf("   row %d of a wave, %-10s (%5zu waves) us since first stamp: min %5.2f p10 %5.2f p50 %5.2f p90 %5.2f max %5.2f\n", slot, nm[k], m,
+                            v[0], v[m / 10], v[m / 2], v[9 * m / 10], v[m - 1]);
+            }
+        }
+        {   // when does a workgroup begin, and when is it done
+            std::vector<std::pair<double, int>> st;
+            std::vector<double> en;
+            for (int bk = 0; bk < g_cus; ++bk) {
+                unsigned long long a = ~0ull, z = 0;
+                for (int w = 0; w < FR_WAVES; ++w)
+                    for (int slot = 0; slot < 4; ++slot)
+                        for (int k = 0; k < 5; ++k) { const unsigned long long t = h[(((size_t)bk * FR_WAVES + w) * 4 + slot) * 8 + k]; if (t) { a = std::min(a, t); z = std::max(z, t); } }
+                if (z) { st.push_back({(a - t0) * 0.01, bk}); en.push_back((z - t0) * 0.01); }
+            }
+            std::sort(st.begin(), st.end());
+            std::sort(en.begin(), en.end());
+            std::printf("   workgroup begins: p50 %.2f p75 %.2f p90 %.2f p95 %.2f max %.2f us; ends: p10 %.2f p50 %.2f p90 %.2f max %.2f us; the 12 latest to begin:", st[st.size() / 2].first,
+                        st[3 * st.size() / 4].first, st[9 * st.size() / 10].first, st[95 * st.size() / 100].first, st.back().first, en[en.size() / 10], en[en.size() / 2], en[9 * en.size() / 10], en.back());
+            for (size_t i = st.size() - 12; i < st.size(); ++i) std::printf(" %d@%.1f", st[i].second, st[i].first);
+            std::printf("\n");
+        }
+        trace = nullptr;
+        hipMemcpyToSymbol(HIP_SYMBOL(g_fr_trace), &trace, sizeof(trace));
     }
     time_it("k_s1d_feature_rows<2> (deferred, fixed point)", [&] { launch_old(n, F, H, b, true); });
     time_it("k_s1d_feature_ring    (deferred, fixed point)", [&] { launch_ring(n, F, H, b, true); });
