@@ -565,27 +565,12 @@ __device__ unsigned long long *g_fd_trace = nullptr;
 // ONE: the reference vector is staged in one
 // pass (F <= 16 * 64 * FD_WAVES = 4096) -- no loop then, which hipcc needs to keep the row's loads in flight across the
 // staging (a path through a loop in front of the compare steps makes it wait for everything there).
-template <int VEC, bool ONE>
-__global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
-    int n, int F, int H, int Hp, const float *__restrict__ X, long ldx, const float *__restrict__ ref,
-    const float *__restrict__ W1, const double *__restrict__ cref, double *__restrict__ S1d, int hint_cap,
-    int *__restrict__ dense_hint, int nslab, double *__restrict__ slabs, int32_t *__restrict__ zstate,
-    float *__restrict__ S1x, unsigned *__restrict__ gate, double *__restrict__ cref_out, double *__restrict__ S1qs,
-    const lt_bits_job job = lt_bits_job{}, const int job_first = 0) {
-    // job.nblocks > 0 (round 5): the blocks from job_first on -- BEHIND the rows in dispatch order, into the CU slots the rows leave
-    // free -- are a probe chunk's record blocks or item-table blocks (lt_items.hip.h: nothing in them reads a layer).  They used to ride
-    // in the launch that forms the pre-activation and cost it 1.5 us; this launch is seven times longer and bound by the pass over X.
-    // zstate != NULL: every row's pre-activation is marked stale here (saves the refresh its memset launch).
-    // The first nslab blocks of the launch (deferred cref, nslab > 0) form the K slices of cref = m W1 instead of rows:
-    // block z sums slice [64 z, 64 z + 64) for every hidden column (thread (kq, cq): 16 k's x 4 columns, one trip; the four
-    // k-quarters added in order through LDS) into slabs[z]; the last of these blocks adds the slices (below), and the rows are
-    // written WITHOUT cref (cref == NULL), which the fp64 SpMM and stage A add where they read them.
-    extern __shared__ __attribute__((aligned(16))) unsigned char fd_smem[];
-    if (job.nblocks > 0 && (int)blockIdx.x >= job_first) {
-        item_bits_block((int)blockIdx.x - job_first, job, fd_smem);
-        return;
-    }
-    if ((int)blockIdx.x < nslab) {
+// One K slice of cref = m W1 (deferred form) by a 256-thread block: block z sums slice [64 z, 64 z + 64) for every hidden column (thread
+// (kq, cq): 16 k's x 4 columns, one trip; the four k-quarters added in order through LDS) into slabs[z]; with a gate the block that
+// finishes last adds the slices.  Shared by k_s1d_feature_rows and k_s1d_feature_ring (their first nslab blocks): the same bits.
+__device__ __forceinline__ void fd_slab_block(unsigned char *fd_smem, int nslab, int F, int H, int Hp, const float *__restrict__ ref,
+                                              const float *__restrict__ W1, double *__restrict__ slabs, unsigned *__restrict__ gate,
+                                              double *__restrict__ cref_out) {
         double (*s_p)[256] = reinterpret_cast<double (*)[256]>(fd_smem);           // [4][256] (H <= 256, H % 4 == 0)
         const int k0 = blockIdx.x * 64, k1 = min(F, k0 + 64);
         const int kq = threadIdx.x >> 6, cq = threadIdx.x & 63, cc = 4 * cq;
@@ -622,7 +607,7 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
         for (int c = threadIdx.x; c < H; c += 256)
             __hip_atomic_store(slabs + (size_t)blockIdx.x * H + c, ((s_p[0][c] + s_p[1][c]) + s_p[2][c]) + s_p[3][c], __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-        __shared__ unsigned s_last;
+        unsigned &s_last = *reinterpret_cast<unsigned *>(fd_smem + 4 * 256 * sizeof(double));      // (behind s_p: fd_smem_bytes / fr_smem_bytes leave room)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "this hand-off is written against gfx950's memory system (sc1 write-through stores / sc1 loads, vmcnt counting stores): on another target give the ticket __ATOMIC_RELEASE and the slab loads __ATOMIC_ACQUIRE at agent scope"
 #endif
@@ -663,6 +648,30 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
                 cref_out[c] = c < H ? ((s_p[0][threadIdx.x] + s_p[1][threadIdx.x]) + s_p[2][threadIdx.x]) + s_p[3][threadIdx.x] : 0.0;
         }
         if (threadIdx.x == 0) __hip_atomic_store(gate, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        return;
+    }
+template <int VEC, bool ONE>
+__global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
+    int n, int F, int H, int Hp, const float *__restrict__ X, long ldx, const float *__restrict__ ref,
+    const float *__restrict__ W1, const double *__restrict__ cref, double *__restrict__ S1d, int hint_cap,
+    int *__restrict__ dense_hint, int nslab, double *__restrict__ slabs, int32_t *__restrict__ zstate,
+    float *__restrict__ S1x, unsigned *__restrict__ gate, double *__restrict__ cref_out, double *__restrict__ S1qs,
+    const lt_bits_job job = lt_bits_job{}, const int job_first = 0) {
+    // job.nblocks > 0 (round 5): the blocks from job_first on -- BEHIND the rows in dispatch order, into the CU slots the rows leave
+    // free -- are a probe chunk's record blocks or item-table blocks (lt_items.hip.h: nothing in them reads a layer).  They used to ride
+    // in the launch that forms the pre-activation and cost it 1.5 us; this launch is seven times longer and bound by the pass over X.
+    // zstate != NULL: every row's pre-activation is marked stale here (saves the refresh its memset launch).
+    // The first nslab blocks of the launch (deferred cref, nslab > 0) form the K slices of cref = m W1 instead of rows:
+    // block z sums slice [64 z, 64 z + 64) for every hidden column (thread (kq, cq): 16 k's x 4 columns, one trip; the four
+    // k-quarters added in order through LDS) into slabs[z]; the last of these blocks adds the slices (below), and the rows are
+    // written WITHOUT cref (cref == NULL), which the fp64 SpMM and stage A add where they read them.
+    extern __shared__ __attribute__((aligned(16))) unsigned char fd_smem[];
+    if (job.nblocks > 0 && (int)blockIdx.x >= job_first) {
+        item_bits_block((int)blockIdx.x - job_first, job, fd_smem);
+        return;
+    }
+    if ((int)blockIdx.x < nslab) {
+        fd_slab_block(fd_smem, nslab, F, H, Hp, ref, W1, slabs, gate, cref_out);
         return;
     }
     FD_STAMP(0);
@@ -836,18 +845,14 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
 static size_t fd_smem_bytes(int F) {
     const size_t Fp = (size_t)((F + 1) & ~1);
     const size_t need = ((Fp * 4 + 15) & ~(size_t)15) + (size_t)FD_WAVES * FD_CAP * (sizeof(double) + sizeof(int));
-    return need < 8192 ? 8192 : need;      // (the slab blocks of the deferred-cref launch use 4 x 256 doubles of it)
+    return need < 8192 + 16 ? 8192 + 16 : need;      // (the slab blocks of the deferred-cref launch use 4 x 256 doubles + a word of it)
 }
 // rows with more differing columns than this are "dense" for the route decision: the list walk costs ~ cnt * H fp64 FMAs and
 // cnt row gathers per node, the matrix cores F * H at ~10 x the rate
 static int fd_hint_cap(int F) { const int c = F / 16; return c < 8 ? 8 : (c > FD_CAP ? FD_CAP : c); }
 
 #include "lt_feature_ring.hip.h"
-// the slabs of m W1: ceil(F / 64) K slices of k_s1d_feature_rows, or FR_SLABS x 256 of the ring kernel
-static size_t fd_slab_doubles(int F, int H) {
-    const size_t a = (size_t)((F + 63) / 64) * H, r = (size_t)FR_SLABS * 256;
-    return a > r ? a : r;
-}
+static size_t fd_slab_doubles(int F, int H) { return (size_t)((F + 63) / 64) * H; }      // the K slices of m W1
 static int fd_cu_count() {
     static int cus[64] = {0};
     int dev = 0;
@@ -860,21 +865,28 @@ static int fd_cu_count() {
     return cus[dev];
 }
 // Whether the persistent ring form serves this product (else the row-per-wave kernel): rows 8-byte aligned, four hidden columns per
-// lane, a row's chunks + the reference vector + the lists inside one CU's LDS, enough rows to give every CU's waves one
+// lane, 9 .. 13 chunks of 1 KiB per row (two workgroups' rings + reference vector + lists inside one CU's LDS), enough rows
 static bool fd_ring_ok(const lt_baseline *b, int n) {
     const int knob = lt_tune().feature_ring;
     if (knob == 0) return false;
     const int nch = fr_chunks(b->F);
-    return b->H % 4 == 0 && b->H <= 256 && b->Hp == b->H && b->ldx % 2 == 0 && ((uintptr_t)b->X % 8) == 0 && nch >= 4 && nch <= 15 &&
-           fr_smem_bytes(nch) <= (size_t)FR_LDS_MAX && n >= (knob > 0 ? 2 : lt_tune().feature_ring_min_rows) && b->ldx >= 260;
+    return b->H % 4 == 0 && b->H <= 256 && b->Hp == b->H && b->ldx % 2 == 0 && ((uintptr_t)b->X % 8) == 0 && nch >= FR_NCH_MIN &&
+           nch <= FR_NCH_MAX && fr_smem_bytes(nch) <= (size_t)FR_LDS_MAX && n >= (knob > 0 ? 2 : lt_tune().feature_ring_min_rows) &&
+           b->ldx >= 260;
+}
+// every block resident from the start (two per CU); the first nsl of them form a slice of m W1 before they take rows
+static unsigned fd_ring_grid(int n, int nsl) {
+    const int cap = 2 * fd_cu_count(), want = nsl + (n + FR_WAVES - 1) / FR_WAVES;
+    return (unsigned)(want < cap ? want : (cap > nsl ? cap : nsl + 1));
 }
 static int fd_ring_allow_lds() {
     static unsigned long long done = 0ull;
     int dev = 0;
     LT_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !((done >> dev) & 1ull)) {
-        LT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_s1d_feature_ring<13>), hipFuncAttributeMaxDynamicSharedMemorySize, FR_LDS_MAX));
-        LT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_s1d_feature_ring<0>), hipFuncAttributeMaxDynamicSharedMemorySize, FR_LDS_MAX));
+#define LT_FR_ATTR(N_) LT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_s1d_feature_ring<N_>), hipFuncAttributeMaxDynamicSharedMemorySize, FR_LDS_MAX))
+        LT_FR_ATTR(9); LT_FR_ATTR(10); LT_FR_ATTR(11); LT_FR_ATTR(12); LT_FR_ATTR(13);
+#undef LT_FR_ATTR
         if (dev >= 0 && dev < 64) done |= 1ull << dev;
     }
     return LT_OK;
@@ -1262,23 +1274,26 @@ static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, b
     const double *cref = defer ? (const double *)nullptr : b->fd_cref;
     float *s1x = (defer && b->S1x && b->S1qs && lt_tune().s1_f32 != 0) ? b->S1x : nullptr;
     if (fd_ring_ok(b, n)) {
-        // the persistent ring form (lt_feature_ring.hip.h): one workgroup per CU; a probe chunk's record blocks cannot ride here (the
-        // workgroups take the CU's whole LDS) -- they go with the pre-activation's launch as with "records_early" = 0
+        // the persistent ring form (lt_feature_ring.hip.h): the slab blocks in front, then two workgroups per CU; a probe chunk's
+        // record blocks do not ride here (the workgroups take the CU's LDS between them) -- they go with the pre-activation's
+        // launch as with "records_early" = 0
         int rc = fd_ring_allow_lds();
         if (rc) return rc;
-        const int nch = fr_chunks(F), G = fd_cu_count();
-        const int nsl = defer ? (FR_SLABS < G ? FR_SLABS : G) : 0;
-        // weights of the row ranges: w_all per workgroup, less the bytes of a slab's K range of W1 in units of a workgroup's rows
-        const double row_bytes = (double)n * F * 4.0 / G, slab_bytes = nsl ? (double)F * H * 4.0 / nsl : 0.0;
-        const int w_all = 1024;
-        int w_cut = row_bytes > 0.0 ? (int)(w_all * slab_bytes / (row_bytes + slab_bytes * nsl / G) + 0.5) : 0;
-        if (w_cut > w_all / 2) w_cut = w_all / 2;
+        const int nch = fr_chunks(F), nsl = defer ? nz : 0;
+        const unsigned grid = fd_ring_grid(n, nsl);
 #define LT_FR_LAUNCH(N_)                                                                                                      \
-    hipLaunchKernelGGL(k_s1d_feature_ring<N_>, dim3((unsigned)G), dim3(64 * FR_WAVES), fr_smem_bytes(nch), st, n, F, H, b->X, (long)b->ldx, \
-                       b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F) < FR_USE ? fd_hint_cap(F) : FR_USE, b->fd_hint_dev, nsl, b->fd_slabs,  \
-                       zstate, s1x, defer ? (unsigned *)b->fd_gate : (unsigned *)nullptr, b->fd_cref, b->S1qs, nch, w_all, w_cut)
-        if (nch == 13) LT_FR_LAUNCH(13);       // (F = 3170, utils/load.py:56: the twitch loader's width)
-        else LT_FR_LAUNCH(0);
+    hipLaunchKernelGGL(k_s1d_feature_ring<N_>, dim3(grid), dim3(64 * FR_WAVES), fr_smem_bytes(nch), st, n, F, H, b->X, (long)b->ldx,   \
+                       b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F) < FR_CAP ? fd_hint_cap(F) : FR_CAP, b->fd_hint_dev, nsl, b->fd_slabs, \
+                       zstate, s1x, (unsigned *)b->fd_gate, b->fd_cref, b->S1qs, parity)
+        const int parity = b->fd_ring_parity;
+        b->fd_ring_parity ^= 1;
+        switch (nch) {
+        case 9: LT_FR_LAUNCH(9); break;
+        case 10: LT_FR_LAUNCH(10); break;
+        case 11: LT_FR_LAUNCH(11); break;
+        case 12: LT_FR_LAUNCH(12); break;
+        default: LT_FR_LAUNCH(13); break;      // (F = 3170, utils/load.py:56: the twitch loader's width)
+        }
 #undef LT_FR_LAUNCH
         LT_CHECK_LAUNCH();
         b->cref_deferred = defer;
@@ -1542,8 +1557,8 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
         hipError_t e = hipMalloc((void **)&cref, (size_t)b->Hp * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&fref, (size_t)(b->F + FD_REF_PAD) * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&fslabs, fd_slab_doubles(b->F, b->H) * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void **)&gate, sizeof(int));
-        if (e == hipSuccess) e = hipMemsetAsync(gate, 0, sizeof(int), st);
+        if (e == hipSuccess) e = hipMalloc((void **)&gate, FR_GATE_WORDS * sizeof(int));
+        if (e == hipSuccess) e = hipMemsetAsync(gate, 0, FR_GATE_WORDS * sizeof(int), st);
         if (e == hipSuccess) e = hipMalloc((void **)&s1d, (size_t)n_probe * b->Hp * sizeof(double));
         if (e == hipSuccess) {
             b->fd_cref = cref; b->fd_slabs = fslabs; b->fd_gate = gate; b->S1d = s1d; b->fd_ref = fref;
@@ -1583,8 +1598,8 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
         if (e == hipSuccess && splits > 1) e = hipMalloc((void **)&slabs, (size_t)splits * n1 * b->H * sizeof(double));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&cref, (size_t)b->Hp * sizeof(double));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fslabs, fd_slab_doubles(b->F, b->H) * sizeof(double));
-        if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&gate, sizeof(int));
-        if (e == hipSuccess && fd_possible) e = hipMemsetAsync(gate, 0, sizeof(int), st);     // (the slice counter of k_ref_row_product)
+        if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&gate, FR_GATE_WORDS * sizeof(int));
+        if (e == hipSuccess && fd_possible) e = hipMemsetAsync(gate, 0, FR_GATE_WORDS * sizeof(int), st);     // (the slice counter of k_ref_row_product)
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fref, (size_t)(b->F + FD_REF_PAD) * sizeof(float));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&frs, n1 * sizeof(double));
         const bool fixed = fd_possible || dense_quant_shapes(b);     // (the fixed-point rows: feature route, or a small dense product)

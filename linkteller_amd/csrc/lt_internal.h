@@ -103,7 +103,8 @@ struct lt_baseline {
     mutable bool cref_deferred = false;   // S1d currently holds S1d - cref: its readers add fd_cref themselves
     double *fd_cref = nullptr;  // [Hp] its product m W1
     double *fd_slabs = nullptr; // [ceil(F / 64), H] its split-K partials
-    int *fd_gate = nullptr;     // device word: the slice counter of k_ref_row_product
+    int *fd_gate = nullptr;     // device words: the slice counter of k_ref_row_product; the ring kernel's row counters (FR_GATE_WORDS)
+    int fd_ring_parity = 0;     // which of the two counter sets the next launch of k_s1d_feature_ring uses
     int *fd_hint_host = nullptr, *fd_hint_dev = nullptr;   // mapped host word the feature kernel sets when it meets dense rows
     int feat_sparse = -1;       // what the probe at lt_baseline_enable_fp64 found: 1 sparse differences, 0 dense, -1 not probed
     // aggregate-first route of the fp64 pre-activation (lt_fp64.hip): Z1d[r] = (A_hat X)[r] W1 + b1 on the rows a call's

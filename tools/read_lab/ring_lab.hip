@@ -28,21 +28,28 @@ static void launch_old(int n, int F, int H, const Bufs &b, bool defer) {
                        defer ? b.gate : (unsigned *)nullptr, b.cref, b.S1qs);
 }
 static int g_cus = 256;
+static int g_nsl = 0;
+static int ring_rowblocks(int n) { return (int)fd_ring_grid(n, g_nsl); }      // (all blocks: the slab blocks take rows too)
 static void launch_ring(int n, int F, int H, const Bufs &b, bool defer) {
-    const int nch = fr_chunks(F), G = g_cus;
-    const int nsl = defer ? (FR_SLABS < G ? FR_SLABS : G) : 0;
-    const double row_bytes = (double)n * F * 4.0 / G, slab_bytes = nsl ? (double)F * H * 4.0 / nsl : 0.0;
-    const int w_all = 1024;
-    int w_cut = row_bytes > 0.0 ? (int)(w_all * slab_bytes / (row_bytes + slab_bytes * nsl / G) + 0.5) : 0;
-    if (w_cut > w_all / 2) w_cut = w_all / 2;
-    if (nch == 13)
-        hipLaunchKernelGGL(k_s1d_feature_ring<13>, dim3((unsigned)G), dim3(64 * FR_WAVES), fr_smem_bytes(nch), 0, n, F, H, b.X, (long)F, b.ref, b.W1,
-                           defer ? (const double *)nullptr : b.cref, b.S1d, fd_hint_cap(F) < FR_USE ? fd_hint_cap(F) : FR_USE, b.hint, nsl, b.slabs, b.zstate,
-                           defer ? b.S1x : (float *)nullptr, defer ? b.gate : (unsigned *)nullptr, b.cref, b.S1qs, nch, w_all, w_cut);
-    else
-        hipLaunchKernelGGL(k_s1d_feature_ring<0>, dim3((unsigned)G), dim3(64 * FR_WAVES), fr_smem_bytes(nch), 0, n, F, H, b.X, (long)F, b.ref, b.W1,
-                           defer ? (const double *)nullptr : b.cref, b.S1d, fd_hint_cap(F) < FR_USE ? fd_hint_cap(F) : FR_USE, b.hint, nsl, b.slabs, b.zstate,
-                           defer ? b.S1x : (float *)nullptr, defer ? b.gate : (unsigned *)nullptr, b.cref, b.S1qs, nch, w_all, w_cut);
+    const int nch = fr_chunks(F), nsl = defer ? (F + 63) / 64 : 0;
+    g_nsl = nsl;
+    static int g_parity = 0;
+    const int parity = g_parity;
+    g_parity ^= 1;
+    const unsigned grid = fd_ring_grid(n, nsl);
+#define LAB_FR(N_)                                                                                                             \
+    hipLaunchKernelGGL(k_s1d_feature_ring<N_>, dim3(grid), dim3(64 * FR_WAVES), fr_smem_bytes(nch), 0, n, F, H, b.X, (long)F, b.ref, b.W1,  \
+                       defer ? (const double *)nullptr : b.cref, b.S1d, fd_hint_cap(F) < FR_CAP ? fd_hint_cap(F) : FR_CAP, b.hint, nsl, b.slabs,  \
+                       b.zstate, defer ? b.S1x : (float *)nullptr, b.gate, b.cref, b.S1qs, parity)
+    switch (nch) {
+    case 9: LAB_FR(9); break;
+    case 10: LAB_FR(10); break;
+    case 11: LAB_FR(11); break;
+    case 12: LAB_FR(12); break;
+    case 13: LAB_FR(13); break;
+    default: std::printf("no ring kernel for %d chunks per row\n", nch); exit(2);
+    }
+#undef LAB_FR
 }
 
 template <class L>
@@ -97,12 +104,11 @@ int main(int argc, char **argv) {
     hipMalloc(&b.X, hx.size() * 4); hipMalloc(&b.ref, href.size() * 4); hipMalloc(&b.W1, hw.size() * 4);
     hipMalloc(&b.S1x, (size_t)n * H * 4); hipMalloc(&b.S1d, (size_t)n * H * 8); hipMalloc(&b.slabs, fd_slab_doubles(F, H) * 8);
     hipMalloc(&b.cref, (size_t)H * 8); hipMalloc(&b.S1qs, (size_t)n * 8); hipMalloc(&b.hint, 4); hipMalloc(&b.zstate, (size_t)n * 4);
-    hipMalloc(&b.gate, 4); hipMemset(b.gate, 0, 4); hipMemset(b.hint, 0, 4);
+    hipMalloc(&b.gate, FR_GATE_WORDS * 4); hipMemset(b.gate, 0, FR_GATE_WORDS * 4); hipMemset(b.hint, 0, 4);
     hipMemcpy(b.X, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(b.ref, href.data(), href.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(b.W1, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_s1d_feature_ring<13>), hipFuncAttributeMaxDynamicSharedMemorySize, FR_LDS_MAX);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_s1d_feature_ring<0>), hipFuncAttributeMaxDynamicSharedMemorySize, FR_LDS_MAX);
+    if (fd_ring_allow_lds() != LT_OK) { std::printf("hipFuncSetAttribute failed\n"); return 1; }
 
     // host reference: full fp64 rows (exact products, fp64 sum in column order)
     const int nchk = std::min(n, 64);
@@ -174,13 +180,13 @@ int main(int argc, char **argv) {
         std::printf("  ring kernel run twice: %s\n", r2 == r ? "same bits" : "BITS DIFFER");
     }
     {   // timeline of the ring kernel (deferred form): stamps 0 row begun, 1 landed, 2 list made, 3 walked, 4 finished; per wave and row slot
-        const size_t nw = (size_t)g_cus * FR_WAVES;
+        const size_t nw = (size_t)ring_rowblocks(n) * FR_WAVES;
         unsigned long long *trace;
-        hipMalloc(&trace, nw * 32 * 8);
+        hipMalloc(&trace, nw * FR_SLOTS * 8 * 8);
         hipMemcpyToSymbol(HIP_SYMBOL(g_fr_trace), &trace, sizeof(trace));
-        std::vector<unsigned long long> h(nw * 32);
+        std::vector<unsigned long long> h(nw * FR_SLOTS * 8);
         for (int rep = 0; rep < 3; ++rep) {
-            hipMemset(trace, 0, nw * 32 * 8);
+            hipMemset(trace, 0, nw * FR_SLOTS * 8 * 8);
             hipDeviceSynchronize();
             launch_ring(n, F, H, b, true);
             hipDeviceSynchronize();
@@ -190,10 +196,10 @@ int main(int argc, char **argv) {
         for (size_t i = 0; i < h.size(); ++i) if (h[i]) { t0 = std::min(t0, h[i]); t1 = std::max(t1, h[i]); }
         std::printf("ring timeline: first stamp -> last stamp %.2f us\n", (t1 - t0) * 0.01);
         const char *nm[5] = {"row begun", "landed", "list made", "walked", "finished"};
-        for (int slot = 0; slot < 4; ++slot) {
+        for (int slot = 0; slot < FR_SLOTS; ++slot) {
             for (int k = 0; k < 5; ++k) {
                 std::vector<double> v;
-                for (size_t w = 0; w < nw; ++w) if (h[(w * 4 + slot) * 8 + k]) v.push_back((h[(w * 4 + slot) * 8 + k] - t0) * 0.01);
+                for (size_t w = 0; w < nw; ++w) if (h[(w * FR_SLOTS + slot) * 8 + k]) v.push_back((h[(w * FR_SLOTS + slot) * 8 + k] - t0) * 0.01);
                 if (v.empty()) continue;
                 std::sort(v.begin(), v.end());
                 const size_t m = v.size();
@@ -204,11 +210,11 @@ int main(int argc, char **argv) {
         {   // when does a workgroup begin, and when is it done
             std::vector<std::pair<double, int>> st;
             std::vector<double> en;
-            for (int bk = 0; bk < g_cus; ++bk) {
+            for (int bk = 0; bk < ring_rowblocks(n); ++bk) {
                 unsigned long long a = ~0ull, z = 0;
                 for (int w = 0; w < FR_WAVES; ++w)
-                    for (int slot = 0; slot < 4; ++slot)
-                        for (int k = 0; k < 5; ++k) { const unsigned long long t = h[(((size_t)bk * FR_WAVES + w) * 4 + slot) * 8 + k]; if (t) { a = std::min(a, t); z = std::max(z, t); } }
+                    for (int slot = 0; slot < FR_SLOTS; ++slot)
+                        for (int k = 0; k < 5; ++k) { const unsigned long long t = h[(((size_t)bk * FR_WAVES + w) * FR_SLOTS + slot) * 8 + k]; if (t) { a = std::min(a, t); z = std::max(z, t); } }
                 if (z) { st.push_back({(a - t0) * 0.01, bk}); en.push_back((z - t0) * 0.01); }
             }
             std::sort(st.begin(), st.end());
