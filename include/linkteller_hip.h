@@ -98,12 +98,16 @@ int lt_device_count(int *count);
  *   "records_early"       "delta_fused" route: 1 = the record blocks of a call's first probe chunk ride in the launch that forms the fp64
  *                         product rows whenever that launch runs (a refreshed baseline on the feature-difference route: CU slots to
  *                         spare, seven times the duration) (default), 0 = in the pre-activation's launch.  Bit-identical
- *   "feature_ring"        feature-difference route: the product rows by the persistent LDS-ring kernel (one workgroup per CU, a row in
- *                         flight by LDS-DMA ahead of the row a wave compares; rows 8-byte aligned, H % 4 == 0, 1022 <= F <= 3838):
- *                         0 = never (one wave per row), 1 = whenever the shapes allow, negative = when they do and the matrix has
- *                         at least "feature_ring_min_rows" rows (default).  fp64 summation order only, like "feature_delta"; a
- *                         probe chunk's record blocks then ride in the pre-activation's launch ("records_early" has no effect)
+ *   "feature_ring"        feature-difference route: the product rows by the persistent LDS-ring kernel (two workgroups per CU, a row in
+ *                         flight by LDS-DMA ahead of the row a wave works on, rows claimed from counters; rows 8-byte aligned,
+ *                         H % 4 == 0, 2046 <= F <= 3326): 0 = never (one wave per row; default -- the ring form measured 25.6 us
+ *                         against 22.0 at twitch size, profiles/r06_ring_lab.txt), 1 = whenever the shapes allow, negative = when
+ *                         they do and the matrix has at least "feature_ring_min_rows" rows.  fp64 summation order only (as with
+ *                         the "feature_delta" knob); a probe chunk's record blocks then ride in the pre-activation's launch
  *   "feature_ring_min_rows"   see "feature_ring" (default 1024, >= 2)
+ *   "feature_flags"       feature-difference route, one wave per row: 1 = a row's differing columns are found as flag bits (plain VALU)
+ *                         and listed level by level, 0 = by a ballot per value as in round 5 (default: the two measure alike and
+ *                         this one keeps round 5's bits).  Changes the order of a row's list: fp64 summation order only
  *   "defer_cref"          feature-difference route: 1 = the reference vector's product m W1 is formed by extra blocks of the rows'
  *                         launch and added by the readers of S1d (the fp64 SpMM, stage A) (default), 0 = formed first and added
  *                         by the rows kernel.  fp64 summation order only, like "feature_delta"

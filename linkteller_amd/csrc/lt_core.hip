@@ -56,7 +56,8 @@ static lt_tuning tuning_defaults() {
     t.feature_delta = getenv("LT_FEATURE_DELTA") ? (env_ll("LT_FEATURE_DELTA", 0) != 0 ? 1 : 0) : -1;
     t.delta_fused = env_ll("LT_DELTA_FUSED", 1) != 0 ? 1 : 0;
     t.records_early = env_ll("LT_RECORDS_EARLY", 1) != 0 ? 1 : 0;
-    t.feature_ring = getenv("LT_FEATURE_RING") ? (env_ll("LT_FEATURE_RING", 0) != 0 ? 1 : 0) : -1;
+    t.feature_ring = env_ll("LT_FEATURE_RING", 0) != 0 ? (env_ll("LT_FEATURE_RING", 0) < 0 ? -1 : 1) : 0;
+    t.feature_flags = env_ll("LT_FEATURE_FLAGS", 0) != 0 ? 1 : 0;
     const long long frm = env_ll("LT_FEATURE_RING_MIN_ROWS", 1024);
     t.feature_ring_min_rows = frm > 2 ? (int)(frm > (1 << 30) ? (1 << 30) : frm) : 2;
     t.profile_every = 1;
@@ -100,6 +101,7 @@ extern "C" int lt_set_tuning(const char *key, long long value) {
     else if (!strcmp(key, "aggregate_first")) t.aggregate_first = reset ? d.aggregate_first : (value < 0 ? -1 : (value != 0));
     else if (!strcmp(key, "feature_delta")) t.feature_delta = reset ? d.feature_delta : (value < 0 ? -1 : (value != 0));
     else if (!strcmp(key, "feature_ring")) t.feature_ring = reset ? d.feature_ring : (value < 0 ? -1 : (value != 0));
+    else if (!strcmp(key, "feature_flags")) t.feature_flags = reset ? d.feature_flags : (value != 0);
     else if (!strcmp(key, "feature_ring_min_rows")) {
         LT_REQUIRE(reset || value >= 2, "lt_set_tuning: feature_ring_min_rows must be >= 2");
         t.feature_ring_min_rows = reset ? d.feature_ring_min_rows : (int)(value > (1 << 30) ? (1 << 30) : value);

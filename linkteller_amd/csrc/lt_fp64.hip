@@ -656,7 +656,7 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     const float *__restrict__ W1, const double *__restrict__ cref, double *__restrict__ S1d, int hint_cap,
     int *__restrict__ dense_hint, int nslab, double *__restrict__ slabs, int32_t *__restrict__ zstate,
     float *__restrict__ S1x, unsigned *__restrict__ gate, double *__restrict__ cref_out, double *__restrict__ S1qs,
-    const lt_bits_job job = lt_bits_job{}, const int job_first = 0) {
+    const lt_bits_job job = lt_bits_job{}, const int job_first = 0, const int flag_bits = 0) {
     // job.nblocks > 0 (round 5): the blocks from job_first on -- BEHIND the rows in dispatch order, into the CU slots the rows leave
     // free -- are a probe chunk's record blocks or item-table blocks (lt_items.hip.h: nothing in them reads a layer).  They used to ride
     // in the launch that forms the pre-activation and cost it 1.5 us; this launch is seven times longer and bound by the pass over X.
@@ -780,7 +780,66 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     const unsigned long long lt = (1ull << lane) - 1ull;
     // pass 1 (the common case is all there is); differing columns beyond the list's capacity are only counted
     int total = 0;                                  // wave-uniform: differing columns of the row
-    for (int j0 = 0; j0 < F; j0 += STEP * UN) {
+    bool listed = false;
+    if constexpr (VEC == 2) {
+        if (flag_bits && F <= T && shift == 0) {
+            // (round 6) the 52 ballot steps as plain VALU: one bit per value (xor, min, shift-or into four accumulators), then the
+            // flagged values appended level by level -- the lane's three lowest in one trip, read again from the row (an L2 hit; a
+            // register array cannot be indexed by a lane's own bit number) -- order (level, lane).  A ballot + scalar branch per
+            // value is ~10 dependent VALU -> SALU hops of 10-20 cycles each (tools/read_lab/ring_lab: 3.6 us of a wave's row).
+            unsigned fl[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const f32x2_ r2 = *reinterpret_cast<const f32x2_ *>(sref + u * STEP + 2 * lane);
+                const float rr[2] = {r2.x, r2.y};
+                const bool inside = (u + 1) * STEP <= F;          // (wave-uniform)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    unsigned t = min(__float_as_uint(x[u][v]) ^ __float_as_uint(rr[v]), 1u);
+                    if (!inside) t = u * STEP + 2 * lane + v < F ? t : 0u;
+                    const int bit = 2 * u + v;
+                    fl[(bit >> 5) * 2 + v] |= t << (bit & 31);
+                }
+            }
+            unsigned long long flags = ((unsigned long long)(fl[2] | fl[3]) << 32) | (unsigned long long)(fl[0] | fl[1]);
+            {
+                int jq[3];
+                float xq[3], rq[3];
+                bool has[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    has[t] = flags != 0ull;
+                    const int bit = has[t] ? __ffsll((long long)flags) - 1 : 0;
+                    flags &= flags - 1ull;
+                    jq[t] = (bit >> 1) * STEP + 2 * lane + (bit & 1);
+                    xq[t] = xr[min(jq[t], F - 1)];
+                    rq[t] = sref[jq[t]];
+                }
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const unsigned long long m = __ballot(has[t]);
+                    const int pos = total + __popcll(m & lt);
+                    if (has[t] && pos < FD_CAP) { mj[pos] = jq[t]; mv[pos] = (double)xq[t] - (double)rq[t]; }
+                    total += __popcll(m);
+                }
+            }
+            while (__ballot(flags != 0ull)) {
+                const bool has = flags != 0ull;
+                const unsigned long long m = __ballot(has);
+                if (has) {
+                    const int bit = __ffsll((long long)flags) - 1;
+                    flags &= flags - 1ull;
+                    const int j = (bit >> 1) * STEP + 2 * lane + (bit & 1);
+                    const float xq = xr[j], rq = sref[j];
+                    const int pos = total + __popcll(m & lt);
+                    if (pos < FD_CAP) { mj[pos] = j; mv[pos] = (double)xq - (double)rq; }
+                }
+                total += __popcll(m);
+            }
+            listed = true;
+        }
+    }
+    for (int j0 = 0; j0 < F && !listed; j0 += STEP * UN) {
         if (j0 > 0) load_trip(j0);
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -1314,7 +1373,7 @@ static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, b
 #define LT_FD_LAUNCH(V_, O_)                                                                                                  \
     hipLaunchKernelGGL((k_s1d_feature_rows<V_, O_>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx, \
                        b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs, zstate, s1x,           \
-                       defer ? (unsigned *)b->fd_gate : (unsigned *)nullptr, b->fd_cref, b->S1qs, jb, job_first)
+                       defer ? (unsigned *)b->fd_gate : (unsigned *)nullptr, b->fd_cref, b->S1qs, jb, job_first, lt_tune().feature_flags)
     if (vec2 && one) LT_FD_LAUNCH(2, true);
     else if (vec2) LT_FD_LAUNCH(2, false);
     else if (one) LT_FD_LAUNCH(1, true);

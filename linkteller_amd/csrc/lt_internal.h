@@ -172,8 +172,11 @@ struct lt_tuning {
                                  // (k_delta_probe_block), 0 the item kernels (LT_DELTA_FUSED)
     int records_early;           // DELTA fused route: 1 the first chunk's record blocks ride in the product rows' launch when it runs (default),
                                  // 0 in the pre-activation's launch as in round 4 (LT_RECORDS_EARLY)
-    int feature_ring;            // feature-difference route: the persistent LDS-ring form of the rows kernel (lt_feature_ring.hip.h): 0 never,
-                                 // 1 whenever the shapes allow, -1 (default) when they do and there are >= feature_ring_min_rows rows (LT_FEATURE_RING)
+    int feature_ring;            // feature-difference route: the persistent LDS-ring form of the rows kernel (lt_feature_ring.hip.h): 0 never
+                                 // (default: it measured 25.6 us against 22.0 at twitch size, profiles/r06_ring_lab.txt), 1 whenever the shapes
+                                 // allow, -1 when they do and there are >= feature_ring_min_rows rows (LT_FEATURE_RING)
+    int feature_flags;           // the row-per-wave kernel lists a row's differing columns from flag bits (1) or by a ballot per value (0, default:
+                                 // 22.4 against 22.5 us, and the ballot form keeps round 5's bits) (LT_FEATURE_FLAGS)
     int feature_ring_min_rows;   // (LT_FEATURE_RING_MIN_ROWS, default 1024: below it the CUs' waves have no row each)
     int profile_every;           // lt_profile_enable: bracket every N-th scope of an enabled class with events (1 = all; an event pair
                                  // costs ~5 us of stream time, so a timed region samples)

@@ -84,3 +84,58 @@ def test_generic_stack_through_influence_matrix(gpu):
     assert np.abs(got - ref).max() <= 3e-2 * ref.max(), np.abs(got - ref).max() / ref.max()
     with pytest.raises(IndexError):
         atk._rows_generic(np.array([0, a.shape[0]]), nodes)
+
+
+def _params(w, dev):
+    return [torch.from_numpy(w[k]).to(dev) for k in ("W1", "b1", "W2", "b2")]
+
+
+@pytest.mark.parametrize("f,h,hub", [(3170, 256, False), (2300, 64, False), (3170, 128, True)])
+def test_ring_and_flag_forms_of_the_product_rows(gpu, f, h, hub):
+    """k_s1d_feature_ring (persistent LDS-ring form, "feature_ring") and the flag-bit list of k_s1d_feature_rows ("feature_flags")
+    against the default form of the feature-difference product: `delta` within 1e-5 of the fp64 oracle on every form, the
+    forms within 1e-6 of the largest score of each other (they differ in fp64 summation order only), repeatable bit for bit,
+    dense rows among the sparse ones served (and the route retired by the hint), the record route / the item kernels behind it."""
+    from test_gpu_parity import _oracle_matrix
+    from linkteller_amd import _lib, engine, graph, synth
+    n = 1300
+    adj = synth.powerlaw_graph(n, 6000, seed=3) if hub else synth.erdos_renyi_graph(n, 5000, seed=3)
+    a_hat = graph.first_order_gcn(adj)
+    x = synth.twitch_like_features(n, f, seed=6, density=0.006)
+    x[5, ::7] = 3.25                      # a row with ~450 differing columns: beyond a wave's list (the piecewise path), sets the hint
+    x[n - 1, f - 1] = 2.5                 # the last value of the matrix; the first one
+    x[0, 0] = -1.5
+    w = synth.gcn_weights(f, h, 2, seed=7)
+    hg = graph.HipGraph(a_hat)
+    xt = torch.from_numpy(x).to(gpu)
+    rng = np.random.RandomState(1)
+    probes = np.concatenate([[n - 1, 0, 5], rng.choice(np.arange(6, n - 1), 29, replace=False)])
+    observe = np.concatenate([[n - 1, 0, 5], rng.choice(np.arange(6, n - 1), 150, replace=False)])
+    ref64 = _oracle_matrix(a_hat, x, w, probes[:8], observe, 1e-4, torch.float64)
+
+    def run(**knobs):
+        for k, v in knobs.items():
+            _lib.set_tuning(k, v)
+        try:
+            base = engine.Baseline(hg, xt, *_params(w, gpu))
+            _lib.set_tuning("feature_delta", 1)          # (the dense row would retire the route at the probe of enable_fp64)
+            base.enable_fp64()
+            assert base.fp64_route() == 1
+            a = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
+            base.refresh()
+            b = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
+            assert np.array_equal(a, b)                  # a refresh re-forms the rows: the same bits (claimed rows, any wave)
+            return a
+        finally:
+            for k in list(knobs) + ["feature_delta"]:
+                _lib.set_tuning(k, None)
+
+    plain = run()
+    ring = run(feature_ring=1)
+    flags = run(feature_flags=1)
+    both = run(feature_ring=1, defer_cref=0)
+    top = ref64.max()
+    for name, got in (("plain", plain), ("ring", ring), ("flags", flags), ("ring, cref first", both)):
+        assert np.abs(got[:8] - ref64).max() <= 1e-5 * top, name
+        assert np.abs(got - plain).max() <= 1e-6 * top, name
+        assert np.all(got[:8][ref64 == 0] == 0), name

@@ -20,12 +20,13 @@ struct Bufs {
     unsigned *gate;
 };
 
+static int g_flags = 0;
 static void launch_old(int n, int F, int H, const Bufs &b, bool defer) {
     const int nslab = defer ? (F + 63) / 64 : 0;
     const unsigned blocks = (unsigned)((n + FD_WAVES - 1) / FD_WAVES + nslab);
     hipLaunchKernelGGL((k_s1d_feature_rows<2, true>), dim3(blocks), dim3(64 * FD_WAVES), fd_smem_bytes(F), 0, n, F, H, H, b.X, (long)F, b.ref, b.W1,
                        defer ? (const double *)nullptr : b.cref, b.S1d, fd_hint_cap(F), b.hint, nslab, b.slabs, b.zstate, defer ? b.S1x : (float *)nullptr,
-                       defer ? b.gate : (unsigned *)nullptr, b.cref, b.S1qs);
+                       defer ? b.gate : (unsigned *)nullptr, b.cref, b.S1qs, lt_bits_job{}, 0, g_flags);
 }
 static int g_cus = 256;
 static int g_nsl = 0;
@@ -228,6 +229,15 @@ int main(int argc, char **argv) {
         hipMemcpyToSymbol(HIP_SYMBOL(g_fr_trace), &trace, sizeof(trace));
     }
     time_it("k_s1d_feature_rows<2> (deferred, fixed point)", [&] { launch_old(n, F, H, b, true); });
+    {   // the flag-bit form of the row-per-wave kernel against its ballot form
+        std::vector<double> a0, a1;
+        g_flags = 0; launch_old(n, F, H, b, true); fetch(true, a0);
+        g_flags = 1; launch_old(n, F, H, b, true); fetch(true, a1);
+        check("rows kernel, flag bits", a1);
+        cmp("rows kernel: flag bits - ballots", a1, a0);
+        time_it("k_s1d_feature_rows<2> flag bits (deferred)", [&] { launch_old(n, F, H, b, true); });
+        g_flags = 0;
+    }
     time_it("k_s1d_feature_ring    (deferred, fixed point)", [&] { launch_ring(n, F, H, b, true); });
     time_it("k_s1d_feature_rows<2> (cref in the rows, fp64)", [&] { launch_old(n, F, H, b, false); });
     time_it("k_s1d_feature_ring    (cref in the rows, fp64)", [&] { launch_ring(n, F, H, b, false); });
