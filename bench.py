@@ -9,8 +9,10 @@ starts N fresh child processes itself -- BEFORE anything here touches the GPU --
 127.0.0.1, and exits with their status.
 
 One *step* = one complete influence-matrix build for the workload: the loop-invariant baseline forward of the mode, then
-every probe and the n_test x n_test influence norms (``lt_influence_rows``), plus -- for N > 1 -- the single all-gather of
-row slabs.  Nothing is cached across steps.  Probes are sharded over ranks; the problem (n_test = 500 on the twitch-RU-shaped
+every probe and the n_test x n_test influence norms, plus -- for N > 1 -- the single all-gather of row slabs, ENDING with
+``influence_val`` on the host as float64 (``lt_influence_rows_f64``): the region the reference itself times
+(attacker.py:213->231; round 6 -- up to round 5 the step of ``value`` ended on the device: that figure stays in the line as
+``value_device``).  Nothing is cached across steps.  Probes are sharded over ranks; the problem (n_test = 500 on the twitch-RU-shaped
 graph) is fixed, so this is STRONG scaling, as the BASELINE.json metric ("n_test=500 at 1/2/4/8 GPU") is.  Inputs are
 synthetic (no dataset on the box) and resident in HBM before timing.
 
@@ -18,9 +20,9 @@ Timing: W warm-up steps, then ``--blocks`` (default 5) timed blocks of EXACTLY K
 barrier + torch.cuda.synchronize() on both sides and reduced with MAX over ranks; ``value`` / ``ms_per_step`` are the
 MEDIAN block ("median of >= 5"), all block times are in the line.
 
-Next to ``value`` (whose step ends on the device) the line carries ``api_wall``: the drop-in API itself -- ``Attacker.influence_matrix()``
-on the same workload, i.e. the region the reference times at attacker.py:213->231, with ``influence_val`` on the HOST as float64
-(``value_host``, ``d2h_us``, ``ms_per_step_to_host``).
+Next to ``value`` the line carries ``api_wall``: the drop-in API itself -- ``Attacker.influence_matrix()`` on the same workload
+(the same region plus the Python surface: state_dict walk, cached node lists) -- ``value_host``, ``d2h_us``,
+``ms_per_step_export_launch`` (round 5's host path: an export launch behind the step).
 
 ``value`` is measured in ``--mode delta`` (default): the mode whose scores, AUC and AP meet north_star's 1e-4 against the
 reference.  `full` (every probe a full perturbed forward, the reference's fp32 finite difference)
@@ -541,6 +543,32 @@ def main():
             out.append(max_over_ranks(time.perf_counter() - t0))
         return out, full
 
+    def step_to_host(mode, bs=None):
+        """One influence-matrix build that ends where the reference's timed region ends (attacker.py:213 -> 231): influence_val as
+        float64 on the HOST.  One rank: ONE library call forms the rows and lands them in pinned host memory
+        (lt_influence_rows_f64), one stream wait.  Several ranks: the step above (rows + all-gather), then the export launch."""
+        bs = bs or base
+        if multi or not hasattr(bs, "influence_matrix_host"):
+            full_ = step(mode, bs)
+            drain()
+            return engine.export_rows_f64(full_)
+        bs.refresh(mode)
+        return bs.influence_matrix_host(probes, obs, delta, mode)
+
+    def timed_host(mode, steps, warmup, blocks=1, bs=None):
+        for _ in range(warmup):
+            step_to_host(mode, bs)
+        out = []
+        m = None
+        for _ in range(blocks):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                m = step_to_host(mode, bs)
+            barrier()
+            out.append(max_over_ranks(time.perf_counter() - t0))
+        return out, m
+
     if a.pmc_child:
         # the kernels of the value mode and of `full`, a few launches each, for the counter passes
         for m in dict.fromkeys((a.mode, "full")):
@@ -569,9 +597,16 @@ def main():
     _lib.set_tuning("profile_every", PROFILE_EVERY)
     block_s, full = timed(a.mode, a.steps, 2, profile_mask=1 << _lib.KERNEL_IDS[dom_name], blocks=max(1, a.blocks))
     _lib.set_tuning("profile_every", None)
-    elapsed = float(np.median(block_s))
+    elapsed_dev = float(np.median(block_s))
+    ms_per_step_dev = elapsed_dev / a.steps * 1e3
+    value_dev = a.n_test * a.n_test * a.steps / elapsed_dev
+    # THE headline: the same K steps, each ending with influence_val on the host as float64 -- the region the reference times
+    # (attacker.py:213 -> 231).  The device-resident figure above stays in the line as `value_device`.
+    block_h, m_host = timed_host(a.mode, a.steps, 3, blocks=max(1, a.blocks))
+    elapsed = float(np.median(block_h))
     ms_per_step = elapsed / a.steps * 1e3
     value = a.n_test * a.n_test * a.steps / elapsed
+    host_equals_device = bool(m_host is not None and np.array_equal(m_host, full.cpu().numpy().astype(np.float64)))
     dom_tot, dom_cnt = kernel_ms(dom_name)
     # "profile_every" samples whole calls (= steps here): the class's time per step is its total over the SAMPLED STEPS,
     # however many scopes it opens in a step (chunked calls, the three sites of the fp64 product)
@@ -715,17 +750,17 @@ def main():
         d2h_us = ev_median(lambda: _lib.check(_lib.lib().lt_export_rows_f64(full.data_ptr(), a.n_test, a.n_test, a.n_test, pin64.data_ptr(),
                                                                            a.n_test, st_)))
         d2h_copy_us = ev_median(lambda: pin32.copy_(full, non_blocking=True))
-        # the headline step with the matrix brought to the host every step (same blocks, same median)
-        def step_to_host():
+        # the round-5 form of the host-landed step for comparison: rows on the device, then the export launch, then the wait
+        def step_export():
             return engine.export_rows_f64(step(a.mode))
         bl = []
         for _ in range(3):
-            step_to_host()
+            step_export()
         for _ in range(max(1, a.blocks)):
             barrier()
             t0 = time.perf_counter()
             for _ in range(a.steps):
-                step_to_host()
+                step_export()
             barrier()
             bl.append(time.perf_counter() - t0)
         sth = float(np.median(bl)) / a.steps
@@ -737,8 +772,9 @@ def main():
                "d2h_note": "lt_export_rows_f64: one launch widens fp32 -> fp64 on the device and writes into pinned host memory over PCIe "
                            "(HIP events around the launch)",
                "d2h_copy_engine_fp32_us": d2h_copy_us,
-               "ms_per_step_to_host": round(sth * 1e3, 4), "value_step_to_host": round(a.n_test ** 2 / sth, 1),
-               "step_to_host_note": "the headline step + the export + the stream wait, every step (the step of `value` ends on the device)",
+               "ms_per_step_export_launch": round(sth * 1e3, 4),
+               "export_launch_note": "the device-resident step + lt_export_rows_f64 as a launch of its own + the stream wait (round 5's host "
+                                     "path); `value` takes lt_influence_rows_f64, whose probe blocks write their own rows to the host",
                "matrix_equals_step": bool(same_nodes and np.array_equal(m_api, full.cpu().numpy().astype(np.float64))),
                "same_test_nodes_as_step": same_nodes}
         del pin64, pin32, atk, model
@@ -1051,6 +1087,11 @@ def main():
             "metric": "influence-matrix node-pairs/sec", "value": round(value, 1), "unit": "node-pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "value_note": "a step ends with influence_val on the HOST as float64 -- the region the reference times (attacker.py:213 -> 231, "
+                          "SURVEY 8(d)); inputs (graph, features, weights, node lists) resident in HBM",
+            "value_device": round(value_dev, 1), "ms_per_step_device": round(ms_per_step_dev, 4),
+            "value_device_note": "the same K steps ending with the fp32 matrix in HBM (what `value` was up to round 5)",
+            "host_matrix_equals_device_matrix": host_equals_device,
             "dtype": "f64" if a.mode == "delta" else "f32",
             "data": "synthetic",
             "config": {"workload": f"n_test={a.n_test} {a.workload}-shaped {'PL' if a.powerlaw else 'ER'} N={n} E={adj.nnz // 2} F={f} H={h} C={c} "
@@ -1063,9 +1104,13 @@ def main():
                                               2: "aggregate-first on the rows the probes reach (k_rows_tiled_xf64 + k_gemm_f64_rows)",
                                               0: "f64 matrix cores (k_gemm_f64acc_128)", -1: "not used"}[fp64_route],
                        "collective_bytes_per_step": coll,
-                       "step": "baseline forward of the mode + all probes + norms" + (" + all-gather" if multi else "")},
-            "timing": {"blocks": len(block_s), "steps_per_block": a.steps, "reported": "median block",
-                       "block_ms": [round(b * 1e3, 3) for b in block_s],
+                       "step": "baseline forward of the mode + all probes + norms" + (" + all-gather" if multi else "") +
+                               " + the matrix as float64 on the host",
+                       "host_path": ("lt_influence_rows_f64: the probes' blocks write their rows into pinned host memory (no export launch)"
+                                     if (not multi and a.mode == "delta") else "lt_export_rows_f64 behind the last kernel")},
+            "timing": {"blocks": len(block_h), "steps_per_block": a.steps, "reported": "median block",
+                       "block_ms": [round(b * 1e3, 3) for b in block_h],
+                       "device_block_ms": [round(b * 1e3, 3) for b in block_s],
                        "event_pair_overhead_us": event_pair_us,
                        "event_pair_note": "an EMPTY hipEventRecord pair on the kernels' stream reads this much: the per-class avg_launch_us "
                                           "figures (HIP events) sit that far above the rocprofv3 kernel durations in profiles/"},

@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 4   /* 4: lt_export_rows_f64 (the matrix leaves the device once, as float64), node ids checked on the device
+#define LT_ABI_VERSION 5   /* 5: lt_influence_rows_f64 (the probes' blocks write the float64 matrix themselves); every version-4 entry point is
+                            unchanged.  4: lt_export_rows_f64 (the matrix leaves the device once, as float64), node ids checked on the device
                             (LT_ERR_INDEX, lt_node_check), lt_profile_calls; every version-3 entry point is unchanged.  2: lt_baseline_refresh launches nothing (lazy recomputation on the first reader's stream); fp64 shard entry points;
                             profile classes 9-11.  3: lt_influence_rows_vec + lt_wide_combine (layers wider than one pass of the fused
                             kernels), lt_spmm_gather_ceiling (measurement support); every version-2 entry point is unchanged */
@@ -256,6 +257,16 @@ int lt_node_check(int32_t *bad_probe, int32_t *bad_observe);
  * device-side alias -- no staging copy, no second operation on the stream; the bytes are valid on the host once the stream has
  * drained.  Pageable host pointers are refused (LT_ERR_INVALID). */
 int lt_export_rows_f64(const float *src, int64_t lds, int32_t rows, int32_t cols, double *dst, int64_t ldd, void *stream);
+
+/* lt_influence_rows and lt_export_rows_f64 in ONE call: out ([n_probe, ldo] fp32, device) is written as by lt_influence_rows, and
+ * dst[i * ldd + j] = (double)out[i * ldo + j] -- the reference's influence_val (attacker.py:216, 227-229) -- in device memory or
+ * PINNED host memory (as lt_export_rows_f64).  On the fused LT_MODE_DELTA route (graphs with incidence records) every probe's
+ * block widens its own finished row into dst, so the rows cross PCIe while the other probes still compute and no export launch
+ * follows; every other route ends with the launch lt_export_rows_f64 makes.  Same values as the two calls, bit for bit. */
+int lt_influence_rows_f64(const lt_baseline *b, const int32_t *probe_nodes, int32_t n_probe,
+                          const int32_t *observe_nodes, int32_t n_obs, float delta, int32_t mode,
+                          float *out, int64_t ldo, double *dst, int64_t ldd, void *workspace, size_t workspace_bytes,
+                          void *stream);
 
 /* ---- measurement support: the gather ceiling of the tiled SpMM ------------------------------------------------------
  * The tiled (column-sliced work-item) kernel of lt_spmm_csr_f32 with everything but its gathers removed: the same work

@@ -63,6 +63,8 @@ SIGNATURES = {
     "lt_influence_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "lt_influence_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
                                     C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "lt_influence_rows_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
+                                        C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "lt_influence_rows_vec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
                                         C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "lt_wide_combine": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_int32,
@@ -90,7 +92,7 @@ SIGNATURES = {
 }
 KERNEL_IDS = {"gemm": 0, "layer1": 1, "layer2": 2, "perturb": 3, "full_stageA": 4, "full_stageB": 5,
               "item_stageA": 6, "item_stageB": 7, "spmm": 8, "fp64_product": 9, "fp64_spmm": 10, "item_bits": 11}
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def lib():

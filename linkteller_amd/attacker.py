@@ -255,6 +255,14 @@ class Attacker:
         rank, ws = lt_dist.world()
         b, e, _ = lt_dist.shard_bounds(len(nodes), rank, ws)
         probes, observed = self._device_nodes(nodes, b, e)
+        if ws == 1 and not lt_dist.collectives_on() and self.features.is_cuda:
+            # one rank: the library call that forms the rows also lands them on the host as float64 (lt_influence_rows_f64)
+            kind, sd = self._walk()
+            if kind == "gcn2":
+                m = self._mode(mode)
+                base = self.baseline(m, sd)
+                if isinstance(base, engine.Baseline):
+                    return base.influence_matrix_host(probes, observed, float(self.args.influence), m)
         local = self._rows(probes, observed, mode)
         full = lt_dist.all_gather_rows(local, len(nodes))
         if full.is_cuda:

@@ -694,35 +694,44 @@ static __global__ __launch_bounds__(256) void k_export_rows_f64(const float *__r
     }
 }
 
+// dst may be host memory: only pinned (device-mapped) memory can be written by a kernel -- resolve its device-side alias and
+// refuse pageable pointers instead of faulting
+int lt_export_resolve(double *dst, double **dev, const char *who) {
+    hipPointerAttribute_t at;
+    hipError_t e = hipPointerGetAttributes(&at, dst);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return lt_set_error(LT_ERR_INVALID, "%s: dst is neither device memory nor pinned host memory (%s)", who, hipGetErrorString(e));
+    }
+    *dev = dst;
+    if (at.type == hipMemoryTypeHost) {
+        LT_REQUIRE(at.devicePointer != nullptr, "%s: pinned dst has no device-side alias", who);
+        *dev = (double *)at.devicePointer;
+    } else if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged) {
+        return lt_set_error(LT_ERR_INVALID, "%s: dst is pageable host memory (pin it: hipHostMalloc / hipHostRegister)", who);
+    }
+    return LT_OK;
+}
+int lt_export_rows_dev(const float *src, int64_t lds, int32_t rows, int32_t cols, double *d, int64_t ldd, hipStream_t stream) {
+    const long total = (long)rows * ((cols + 1) / 2);
+    if (total <= 0) return LT_OK;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_export_rows_f64, dim3((unsigned)blocks), dim3(256), 0, stream, src, (long)lds, rows, cols, d, (long)ldd);
+    LT_CHECK_LAUNCH();
+    return LT_OK;
+}
+
 extern "C" int lt_export_rows_f64(const float *src, int64_t lds, int32_t rows, int32_t cols, double *dst, int64_t ldd,
                                   void *stream) {
     LT_REQUIRE(rows >= 0 && cols >= 0, "lt_export_rows_f64: negative shape");
     if (rows == 0 || cols == 0) return LT_OK;
     LT_REQUIRE(src && dst, "lt_export_rows_f64: NULL pointer");
     LT_REQUIRE(lds >= cols && ldd >= cols, "lt_export_rows_f64: leading dimension smaller than the row");
-    // dst may be host memory: only pinned (device-mapped) memory can be written by a kernel -- resolve its device-side alias
-    // and refuse pageable pointers instead of faulting
-    hipPointerAttribute_t at;
-    hipError_t e = hipPointerGetAttributes(&at, dst);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        return lt_set_error(LT_ERR_INVALID, "lt_export_rows_f64: dst is neither device memory nor pinned host memory (%s)",
-                            hipGetErrorString(e));
-    }
-    double *d = dst;
-    if (at.type == hipMemoryTypeHost) {
-        LT_REQUIRE(at.devicePointer != nullptr, "lt_export_rows_f64: pinned dst has no device-side alias");
-        d = (double *)at.devicePointer;
-    } else if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged) {
-        return lt_set_error(LT_ERR_INVALID, "lt_export_rows_f64: dst is pageable host memory (pin it: hipHostMalloc / hipHostRegister)");
-    }
-    const long total = (long)rows * ((cols + 1) / 2);
-    long blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_export_rows_f64, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (long)lds, rows, cols, d,
-                       (long)ldd);
-    LT_CHECK_LAUNCH();
-    return LT_OK;
+    double *d = nullptr;
+    const int rc = lt_export_resolve(dst, &d, "lt_export_rows_f64");
+    if (rc) return rc;
+    return lt_export_rows_dev(src, lds, rows, cols, d, ldd, (hipStream_t)stream);
 }
 
 // ---- per-kernel event timing ------------------------------------------------------------------

@@ -1523,7 +1523,8 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_finish(
     const double *__restrict__ Z1d, const double *__restrict__ S1d, const float *__restrict__ S1x,
     const double *__restrict__ crefv, const double *__restrict__ S1qs, const float *__restrict__ Z1x, int Hp,
     const float *__restrict__ W2p, int C, const int32_t *__restrict__ rec, int rec_words, int maxc,
-    const int32_t *__restrict__ dl_src, int n_obs, float delta, float *__restrict__ out, long ldo) {
+    const int32_t *__restrict__ dl_src, int n_obs, float delta, float *__restrict__ out, long ldo,
+    double *__restrict__ out64 = nullptr, long ld64 = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char df_smem[];
     float *sS2 = reinterpret_cast<float *>(df_smem);             // [maxc][C] the items' layer-2 differences
     // (launched with 256, 128 or 64 threads: a call of more probes than the chip holds 4-wave blocks for -- ~ 90 VGPRs, 5 waves per
@@ -1826,6 +1827,25 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_finish(
         }
     }
     DF_STAMP(5);
+    // out64 != NULL (lt_influence_rows_f64): the block widens its own finished row into the caller's float64 matrix -- pinned host
+    // memory through its device-side alias: the rows cross PCIe while the other probes' blocks still compute, instead of in a
+    // launch of their own behind this one (lt_export_rows_f64).  The barrier drains every wave's stores (hipcc emits vmcnt(0) in
+    // front of it); the row is read back past this CU's L1 (an earlier call's export may have left lines of it there).
+    if (out64) {
+        __syncthreads();
+        double *drow = out64 + (long)b * ld64;
+        const bool pair_ok = (reinterpret_cast<uintptr_t>(drow) & 15) == 0;
+        const int half = (n_obs + 1) >> 1;
+        for (int k = tid; k < half; k += NT) {
+            const int c = 2 * k;
+            const float v0 = __builtin_nontemporal_load(orow + c);
+            if (c + 1 < n_obs) {
+                const float v1 = __builtin_nontemporal_load(orow + c + 1);
+                if (pair_ok) *reinterpret_cast<double2 *>(drow + c) = make_double2((double)v0, (double)v1);
+                else { drow[c] = (double)v0; drow[c + 1] = (double)v1; }
+            } else drow[c] = (double)v0;
+        }
+    }
 }
 
 // beyond the default 64 KB of dynamic LDS a kernel is told, once, that it may take most of a CU's 160 KB
@@ -2318,7 +2338,24 @@ extern "C" size_t lt_influence_workspace_bytes(const lt_baseline *b, int32_t n_p
 static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes, int32_t n_probe,
                                const int32_t *observe_nodes, int32_t n_obs, float delta,
                                int32_t mode, float *out, int64_t ldo, void *workspace,
-                               size_t workspace_bytes, void *stream, float *vec);
+                               size_t workspace_bytes, void *stream, float *vec, double *dst64 = nullptr, int64_t ldd = 0);
+
+// lt_influence_rows + the finished rows as float64 in dst (device memory, or pinned host memory: the reference's influence_val,
+// attacker.py:216-229): the fused DELTA route's blocks write their own rows there, every other route ends with the launch of
+// lt_export_rows_f64.
+extern "C" int lt_influence_rows_f64(const lt_baseline *b, const int32_t *probe_nodes, int32_t n_probe,
+                                     const int32_t *observe_nodes, int32_t n_obs, float delta, int32_t mode, float *out,
+                                     int64_t ldo, double *dst, int64_t ldd, void *workspace, size_t workspace_bytes, void *stream) {
+    LT_REQUIRE(dst != nullptr || n_probe == 0 || n_obs == 0, "lt_influence_rows_f64: dst is NULL");
+    LT_REQUIRE(ldd >= n_obs, "lt_influence_rows_f64: ldd smaller than the row");
+    double *dev = nullptr;
+    if (n_probe > 0 && n_obs > 0) {
+        const int rc = lt_export_resolve(dst, &dev, "lt_influence_rows_f64");
+        if (rc) return rc;
+    }
+    return influence_rows_impl(b, probe_nodes, n_probe, observe_nodes, n_obs, delta, mode, out, ldo, workspace, workspace_bytes,
+                               stream, nullptr, dev, ldd);
+}
 
 extern "C" int lt_influence_rows(const lt_baseline *b, const int32_t *probe_nodes, int32_t n_probe,
                                  const int32_t *observe_nodes, int32_t n_obs, float delta,
@@ -2345,8 +2382,9 @@ extern "C" int lt_influence_rows_vec(const lt_baseline *b, const int32_t *probe_
 static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes, int32_t n_probe,
                                const int32_t *observe_nodes, int32_t n_obs, float delta,
                                int32_t mode, float *out, int64_t ldo, void *workspace,
-                               size_t workspace_bytes, void *stream, float *vec) {
+                               size_t workspace_bytes, void *stream, float *vec, double *dst64, int64_t ldd) {
     lt_prof_call prof_call_;
+    int32_t exported_rows = 0;      // (dst64) rows the fused route's blocks wrote themselves: the chunks are in probe order
     LT_REQUIRE(b != nullptr, "lt_influence_rows: baseline is NULL");
     LT_REQUIRE(n_probe >= 0 && n_obs >= 0, "lt_influence_rows: negative count");
     LT_REQUIRE(mode >= LT_MODE_FULL && mode <= LT_MODE_DELTA, "lt_influence_rows: unknown mode %d", mode);
@@ -2614,7 +2652,9 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
         if (dg.finish_smem > (size_t)64 * 1024) { const int rc_ = df_allow_big_lds<LPR_, CP_, SX_, ZF_>(); if (rc_) return rc_; }    \
         hipLaunchKernelGGL((k_delta_probe_finish<LPR_, CP_, SX_, ZF_>), dim3((unsigned)nb), dim3(df_threads), dg.finish_smem, st,      \
                            b->Z1d, b->S1d, sxp, crp, b->S1qs, zxp, Hp, b->W2p, C, w.dl_rec, dg.rec_words, dg.maxc, g->dl_rec,        \
-                           n_obs, delta, orow, (long)ldo)))
+                           n_obs, delta, orow, (long)ldo, drow64, (long)ldd)))
+                    double *const drow64 = (dst64 && exported_rows == p0) ? dst64 + (int64_t)p0 * ldd : (double *)nullptr;
+                    if (drow64) exported_rows = p0 + nb;
                     if (sxp && zxp) { LT_DF_LAUNCH(true, true); }
                     else if (sxp) { LT_DF_LAUNCH(true, false); }
                     else { LT_DF_LAUNCH(false, false); }
@@ -2769,6 +2809,9 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
             LT_CHECK_LAUNCH();
         }
     }
+    if (dst64 && exported_rows < n_probe && n_obs > 0)      // (the rows no block exported itself: one launch behind the last kernel)
+        return lt_export_rows_dev(out + (int64_t)exported_rows * ldo, ldo, n_probe - exported_rows, n_obs,
+                                  dst64 + (int64_t)exported_rows * ldd, ldd, (hipStream_t)stream);
     return LT_OK;
 }
 

@@ -182,6 +182,9 @@ struct lt_tuning {
                                  // costs ~5 us of stream time, so a timed region samples)
 };
 lt_tuning &lt_tune();
+// the float64 export (lt_core.hip): a dst pointer's device-side alias (pinned host memory) / itself (device memory); the launch
+int lt_export_resolve(double *dst, double **dev, const char *who);
+int lt_export_rows_dev(const float *src, int64_t lds, int32_t rows, int32_t cols, double *dst_dev, int64_t ldd, hipStream_t stream);
 
 #define LT_HIP(call)                                                                       \
     do {                                                                                   \

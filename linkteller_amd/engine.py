@@ -119,6 +119,7 @@ class Baseline:
         self._h = h
         self._finalizer = weakref.finalize(self, _lib.lib().lt_baseline_destroy, h)
         self._ws = {}
+        self._host_scratch = {}
         self._fp64 = False
         self._shard = None          # (row_begin, row_end, per) while the sharded refresh of the fp32 product is on
         self._s1_full = None        # torch-owned S1 storage once attached (kept alive for the handle's lifetime)
@@ -217,8 +218,9 @@ class Baseline:
         _lib.check(_lib.lib().lt_baseline_logits(self._h, out.data_ptr(), _stream()), "lt_baseline_logits")
         return out
 
-    def influence_rows(self, probe_nodes, observe_nodes, delta: float, mode="full", out=None) -> torch.Tensor:
-        """[n_probe, n_obs] fp32 on the device: ||(f(X + delta e_v x_v^T) - f(X))[u]||_2 / delta."""
+    def influence_rows(self, probe_nodes, observe_nodes, delta: float, mode="full", out=None, host=None) -> torch.Tensor:
+        """[n_probe, n_obs] fp32 on the device: ||(f(X + delta e_v x_v^T) - f(X))[u]||_2 / delta.  ``host``: a pinned (or
+        device) float64 [n_probe, n_obs] tensor that receives the same matrix widened (valid once the stream has drained)."""
         dev = self.x.device
         probes = _as_nodes(probe_nodes, self.n, dev, "probe_nodes")
         obs = _as_nodes(observe_nodes, self.n, dev, "observe_nodes")
@@ -237,10 +239,38 @@ class Baseline:
         if ws is None or ws.numel() < need:
             ws = _workspace(need, dev)
             self._ws = {key: ws}   # keep only the latest: sizes repeat across steps
+        if host is not None:
+            # lt_influence_rows_f64: the float64 matrix is written as part of the same call (the fused `delta` route's blocks
+            # export their own rows; other routes end with the export launch)
+            _lib.check(_lib.lib().lt_influence_rows_f64(self._h, probes.data_ptr(), npb, obs.data_ptr(), nob, float(delta), m,
+                                                        out.data_ptr(), nob, host.data_ptr(), max(nob, 1), ws.data_ptr(),
+                                                        ws.numel(), _stream()), "lt_influence_rows_f64")
+            return out
         _lib.check(_lib.lib().lt_influence_rows(self._h, probes.data_ptr(), npb, obs.data_ptr(), nob,
                                                 float(delta), m, out.data_ptr(), nob, ws.data_ptr(),
                                                 ws.numel(), _stream()), "lt_influence_rows")
         return out
+
+    def influence_matrix_host(self, probe_nodes, observe_nodes, delta: float, mode="delta"):
+        """[n_probe, n_obs] float64 on the HOST (the reference's ``influence_val``, attacker.py:216-229) by ONE library call:
+        the rows are formed and land in pinned host memory (a block of torch's pinned-memory cache, owned by the returned
+        array) without an export launch of their own where the route allows; one stream wait; then the device-side node-id
+        check (IndexError, as the reference raises)."""
+        dev = self.x.device
+        probes = _as_nodes(probe_nodes, self.n, dev, "probe_nodes")
+        obs = _as_nodes(observe_nodes, self.n, dev, "observe_nodes")
+        npb, nob = probes.numel(), obs.numel()
+        host = torch.empty((npb, nob), dtype=torch.float64, pin_memory=True)
+        key = ("scratch", npb, nob)
+        out = self._host_scratch.get(key)
+        if out is None:
+            out = torch.empty((npb, nob), dtype=torch.float32, device=dev)
+            self._host_scratch = {key: out}
+        if npb and nob:
+            self.influence_rows(probes, obs, delta, mode, out=out, host=host)
+            torch.cuda.current_stream(dev).synchronize()
+            node_check()
+        return host.numpy()
 
 
     def influence_rows_vec(self, probes: torch.Tensor, obs: torch.Tensor, delta: float, m: int, out: torch.Tensor,

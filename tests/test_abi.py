@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lt):
         assert hasattr(handle, n), f"{n} declared in the header but not exported"
         assert n in lt.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(lt.SIGNATURES) == names
-    assert handle.lt_abi_version() == lt.ABI_VERSION == 4
+    assert handle.lt_abi_version() == lt.ABI_VERSION == 5
 
 
 def test_no_gpu_means_loud_failure_not_fallback(lt):

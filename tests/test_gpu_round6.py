@@ -139,3 +139,42 @@ def test_ring_and_flag_forms_of_the_product_rows(gpu, f, h, hub):
         assert np.abs(got[:8] - ref64).max() <= 1e-5 * top, name
         assert np.abs(got - plain).max() <= 1e-6 * top, name
         assert np.all(got[:8][ref64 == 0] == 0), name
+
+
+@pytest.mark.parametrize("graph_kind,mode", [("er", "delta"), ("er", "sparse"), ("pl", "delta"), ("er", "full")])
+def test_influence_rows_f64_equals_rows_plus_export(gpu, graph_kind, mode):
+    """lt_influence_rows_f64 (the probes' blocks of the fused `delta` route write their own float64 rows into pinned host memory;
+    every other route ends with the export launch) gives the bits of lt_influence_rows + lt_export_rows_f64 -- rows of an odd
+    and an even width (16-byte and 8-byte host stores), several probe chunks, device and pinned destinations, and through
+    Attacker.influence_matrix()."""
+    from linkteller_amd import _lib, engine, graph, synth
+    n, f, h = 700, 96, 64
+    adj = synth.erdos_renyi_graph(n, 3000, seed=1) if graph_kind == "er" else synth.powerlaw_graph(n, 3000, seed=1)
+    hg = graph.HipGraph(graph.first_order_gcn(adj))
+    x = torch.from_numpy(synth.twitch_like_features(n, f, seed=2, density=0.05)).to(gpu)
+    w = synth.gcn_weights(f, h, 2, seed=3)
+    base = engine.Baseline(hg, x, *_params(w, gpu))
+    rng = np.random.RandomState(4)
+    for n_probe, n_obs in ((40, 57), (64, 64), (1, 3)):
+        probes = rng.choice(n, n_probe, replace=False)
+        obs = rng.choice(n, n_obs, replace=False)
+        want = engine.export_rows_f64(base.influence_rows(probes, obs, 1e-4, mode))
+        got = base.influence_matrix_host(probes, obs, 1e-4, mode)
+        assert got.dtype == np.float64 and got.shape == (n_probe, n_obs)
+        assert np.array_equal(got, want)
+        dev64 = torch.full((n_probe, n_obs), -1.0, dtype=torch.float64, device=gpu)
+        base.influence_rows(probes, obs, 1e-4, mode, host=dev64)
+        assert np.array_equal(dev64.cpu().numpy(), want)
+    # several probe chunks (a small scratch budget): the chunks' blocks write disjoint row ranges
+    probes = rng.choice(n, 300, replace=False)
+    obs = rng.choice(n, 301, replace=False)
+    want = engine.export_rows_f64(base.influence_rows(probes, obs, 1e-4, mode))
+    _lib.set_tuning("chunk_budget_bytes", 1 << 20)
+    try:
+        got = base.influence_matrix_host(probes, obs, 1e-4, mode)
+    finally:
+        _lib.set_tuning("chunk_budget_bytes", None)
+    assert np.array_equal(got, want)
+    with pytest.raises(IndexError):
+        base.influence_matrix_host(torch.tensor([0, n], dtype=torch.int32, device=gpu), obs, 1e-4, mode)
+    engine.node_check()
