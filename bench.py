@@ -469,16 +469,20 @@ def main():
     obs = torch.from_numpy(test_nodes.astype(np.int32)).to(dev)
     local = torch.empty((b1_ - b0, a.n_test), dtype=torch.float32, device=dev)
     delta = 1e-4
-    n_probe_local = b1_ - b0
-    items_local = int(a_hat.tocsc()[:, test_nodes[b0:b1_]].nnz)      # sum over this rank's probes of |R_v|
-
     pending = []
+    probe_sharded = multi          # decided below (LT_SHARD_PROBES=auto: sharded + all-gather against every rank building all rows)
 
     def step(mode, bs=None):
         """One influence-matrix build.  For N > 1 the all-gather of step k is left in flight on the
         communicator's stream while step k+1 computes (steps are independent; every step's matrix is
         complete before the closing barrier + synchronize)."""
         bs = bs or base
+        if multi and not probe_sharded:
+            # the probe dimension is not worth sharding for this workload (decided once, the same on every rank): every rank
+            # builds all rows, no collective
+            bs.refresh(mode)
+            bs.influence_rows(obs, obs, delta, mode, out=local_all)
+            return local_all
         if multi:
             # a fresh padded slab per step: the collective of step k may still be reading its slab
             # while step k+1 computes
@@ -494,6 +498,10 @@ def main():
         if work is not None:
             pending.append(work)
         return full
+
+    def probe_sharded_set(v):
+        nonlocal probe_sharded
+        probe_sharded = v
 
     def wall_median(fn, steps, blocks=5, warm=3):
         """Seconds per call of fn: median over `blocks` synchronize-bracketed blocks of `steps` calls (the side legs)."""
@@ -548,12 +556,12 @@ def main():
         float64 on the HOST.  One rank: ONE library call forms the rows and lands them in pinned host memory
         (lt_influence_rows_f64), one stream wait.  Several ranks: the step above (rows + all-gather), then the export launch."""
         bs = bs or base
-        if multi or not hasattr(bs, "influence_matrix_host"):
+        if (multi and probe_sharded) or not hasattr(bs, "influence_matrix_host"):
             full_ = step(mode, bs)
             drain()
             return engine.export_rows_f64(full_)
         bs.refresh(mode)
-        return bs.influence_matrix_host(probes, obs, delta, mode)
+        return bs.influence_matrix_host(obs if multi else probes, obs, delta, mode)
 
     def timed_host(mode, steps, warmup, blocks=1, bs=None):
         for _ in range(warmup):
@@ -568,6 +576,26 @@ def main():
             barrier()
             out.append(max_over_ranks(time.perf_counter() - t0))
         return out, m
+
+    local_all = torch.empty((a.n_test, a.n_test), dtype=torch.float32, device=dev) if multi else None
+    probe_choice = None
+    if multi:
+        def _sharded_once():
+            probe_sharded_set(True)
+            step(a.mode)
+            drain()
+
+        def _local_once():
+            probe_sharded_set(False)
+            step(a.mode)
+        key_ps = ("bench", a.n_test, a.mode)
+        probe_sharded = lt_dist.choose_probe_sharding(key_ps, _sharded_once, _local_once)
+        rep = lt_dist.probe_sharding_report(key_ps)
+        probe_choice = {"policy": lt_dist.shard_probes_policy(), "sharded": bool(probe_sharded),
+                        **({"ms_per_step_every_rank_all_rows": round(rep[1] * 1e3, 4), "ms_per_step_sharded_all_gather": round(rep[2] * 1e3, 4)}
+                           if rep else {})}
+    n_probe_local = (b1_ - b0) if (probe_sharded or not multi) else a.n_test
+    items_local = int(a_hat.tocsc()[:, test_nodes[b0:b1_] if (probe_sharded or not multi) else test_nodes].nnz)   # sum over this rank's probes of |R_v|
 
     if a.pmc_child:
         # the kernels of the value mode and of `full`, a few launches each, for the counter passes
@@ -932,7 +960,8 @@ def main():
                 ts.append(e0.elapsed_time(e1) * 1e3)
         return round(float(np.median(ts)), 2)
 
-    def sharded_build(bs, nodes_np, mode, steps, blocks=3, warm=2):
+    def sharded_build(bs, nodes_np, mode, steps, blocks=3, warm=2, strategy=None):
+        strategy = {} if strategy is None else strategy
         """(seconds per step, probes per rank): this rank's ceil(n / W) probes x all n observed nodes incl. the loop-invariant
         baseline of the mode, then the single all-gather -- barrier + synchronize around every block, MAX over ranks."""
         n_t = len(nodes_np)
@@ -950,6 +979,20 @@ def main():
             if work is not None:
                 pending.append(work)
             return full_
+        all_rows = torch.empty((n_t, n_t), dtype=torch.float32, device=dev)
+
+        def one_local():
+            bs.refresh(mode)
+            bs.influence_rows(ob, ob, delta, mode, out=all_rows)
+            return all_rows
+        key_ = ("bench", n_t, mode, id(bs))
+        use = lt_dist.choose_probe_sharding(key_, lambda: (one(), drain()), one_local, trials=3, warm=1) if multi else False
+        strategy.update({"sharded": bool(use), "policy": lt_dist.shard_probes_policy()})
+        rep_ = lt_dist.probe_sharding_report(key_)
+        if rep_:
+            strategy.update({"ms_per_step_every_rank_all_rows": round(rep_[1] * 1e3, 4), "ms_per_step_sharded_all_gather": round(rep_[2] * 1e3, 4)})
+        if multi and not use:
+            one, per_ = one_local, n_t
         for _ in range(warm):
             one()
         ts = []
@@ -977,14 +1020,17 @@ def main():
                                   "on one GPU = 4.9x before the collective; the 3 800 hub rows every rank's probes reach are 84 % of a rank's "
                                   "loop-invariant part and are replicated: DESIGN.md section 7 sizes sharding them)",
                    "mode": a.mode, "n_gpus": world}
-        scaling["configs[1]"] = {"workload": f"n_test={a.n_test} (the `value` workload)", "ms_per_step": round(ms_per_step, 4),
-                                 "pairs_per_s": round(value, 1), "probes_per_rank": per, "collective_us": collective_us(per, a.n_test)}
+        scaling["configs[1]"] = {"workload": f"n_test={a.n_test} (the `value` workload; ends on the host)", "ms_per_step": round(ms_per_step, 4),
+                                 "pairs_per_s": round(value, 1), "probes_per_rank": n_probe_local, "collective_us": collective_us(per, a.n_test),
+                                 "strategy": probe_choice}
         if n >= 2000:
             np.random.seed(42)
             nodes3 = np.random.choice(np.arange(n), 2000, replace=False)
-            t3, per3 = sharded_build(base, nodes3, a.mode, 10)
+            st3 = {}
+            t3, per3 = sharded_build(base, nodes3, a.mode, 10, strategy=st3)
             scaling["configs[2]"] = {"workload": "n_test=2000 on the same graph (BASELINE configs[2])", "ms_per_step": round(t3 * 1e3, 4),
-                                     "pairs_per_s": round(2000 ** 2 / t3, 1), "probes_per_rank": per3, "collective_us": collective_us(per3, 2000)}
+                                     "pairs_per_s": round(2000 ** 2 / t3, 1), "probes_per_rank": per3,
+                                     "collective_us": collective_us(lt_dist.shard_bounds(2000, rank, world)[2], 2000), "strategy": st3}
             base.refresh()
         if a.spmm_scale:
             big, gb, _ = rmat_problem(a.spmm_scale)
@@ -993,10 +1039,11 @@ def main():
                 bb.enable_fp64()
             lt_dist.choose_baseline_sharding(bb, mode=a.mode)
             nodes5 = np.random.RandomState(42).choice(big.shape[0], 4096, replace=False)
-            t5, per5 = sharded_build(bb, nodes5, a.mode, 3, blocks=3, warm=1)
+            st5 = {}
+            t5, per5 = sharded_build(bb, nodes5, a.mode, 3, blocks=3, warm=1, strategy=st5)
             scaling["configs[4]"] = {"workload": f"R-MAT scale {a.spmm_scale} (N={big.shape[0]}, nnz={big.nnz}) F=256 H={h} n_test=4096 (BASELINE configs[4])",
                                      "ms_per_step": round(t5 * 1e3, 3), "pairs_per_s": round(4096 ** 2 / t5, 1), "probes_per_rank": per5,
-                                     "collective_us": collective_us(per5, 4096)}
+                                     "collective_us": collective_us(lt_dist.shard_bounds(4096, rank, world)[2], 4096), "strategy": st5}
             del bb
         rmat_cache.clear()
 
@@ -1080,7 +1127,7 @@ def main():
         hp = (h + 3) // 4 * 4
         coll = 0
         if multi:
-            coll = world * per * a.n_test * 4
+            coll = world * per * a.n_test * 4 if probe_sharded else 0
             if baseline_sharded:
                 coll += world * lt_dist.shard_bounds(n, rank, world)[2] * hp * (8 if a.mode == "delta" else 4)
         out = {
@@ -1100,6 +1147,7 @@ def main():
                        "features": "standardised 0/1 indicators, Bernoulli(0.006) (two values per column, as the reference's twitch loader "
                                    "produces: utils/load.py:53-59 + StandardScaler)",
                        "mode": a.mode, "probes_per_rank": n_probe_local, "baseline_XW1": shard_note,
+                       "probe_sharding": probe_choice if multi else "one rank",
                        "fp64_product_route": {1: "feature rows as differences to a reference row (k_s1d_feature_rows)",
                                               2: "aggregate-first on the rows the probes reach (k_rows_tiled_xf64 + k_gemm_f64_rows)",
                                               0: "f64 matrix cores (k_gemm_f64acc_128)", -1: "not used"}[fp64_route],

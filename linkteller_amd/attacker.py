@@ -202,12 +202,15 @@ class Attacker:
         dev = self.features.device
         if dev.type != "cuda":
             return nodes[b:e], nodes            # (engine refuses CPU tensors with its own message)
-        key = (nodes.tobytes(), b, e, dev.index)
+        key = (nodes.tobytes(), dev.index)
         hit = getattr(self, "_node_cache", None)
         if hit is None or hit[0] != key:
             obs = engine._as_nodes(nodes, int(self.features.shape[0]), dev, "test_nodes")
-            hit = self._node_cache = (key, obs[b:e].contiguous(), obs)
-        return hit[1], hit[2]
+            hit = self._node_cache = (key, {}, obs)
+        sl = hit[1].get((b, e))
+        if sl is None:                          # (a contiguous slice of a 1-d tensor: a view, no copy)
+            sl = hit[1][(b, e)] = hit[2] if (b, e) == (0, len(nodes)) else hit[2][b:e]
+        return sl, hit[2]
 
     def baseline(self, mode=None, sd=None) -> engine.Baseline:
         """Loop-invariant model(features, adj) of attacker.py:106: built once per (features, adj, parameters) --
@@ -263,8 +266,19 @@ class Attacker:
                 base = self.baseline(m, sd)
                 if isinstance(base, engine.Baseline):
                     return base.influence_matrix_host(probes, observed, float(self.args.influence), m)
+        sharded = True
+        if lt_dist.collectives_on():
+            # several ranks: shard the probes + one all-gather, or -- when that measures slower than a rank doing every probe
+            # itself (LT_SHARD_PROBES=auto: a build that is mostly its loop-invariant baseline) -- no collective at all
+            all_p, _ = self._device_nodes(nodes, 0, len(nodes))
+            key = ("attack", id(self.adj), self.features.data_ptr(), len(nodes), nodes[:8].tobytes(), self._mode(mode))
+            sharded = lt_dist.choose_probe_sharding(
+                key, lambda: lt_dist.all_gather_rows(self._rows(probes, observed, mode), len(nodes)),
+                lambda: self._rows(all_p, observed, mode))
+            if not sharded:
+                probes = all_p
         local = self._rows(probes, observed, mode)
-        full = lt_dist.all_gather_rows(local, len(nodes))
+        full = lt_dist.all_gather_rows(local, len(nodes)) if sharded else local
         if full.is_cuda:
             # ONE launch widens the rows on the device and writes them into pinned host memory; one wait (the reference:
             # n_test**2 `.item()` round trips into np.zeros -> float64, attacker.py:216-229)

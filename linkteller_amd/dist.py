@@ -77,6 +77,60 @@ def all_gather_into(full: torch.Tensor, shard: torch.Tensor):
     dist.all_gather_into_tensor(full, shard)
 
 
+def shard_probes_policy() -> str:
+    """LT_SHARD_PROBES: '1' every call shards its probes over the ranks and all-gathers the row slabs, '0' every rank builds
+    the whole matrix itself (no collective), 'auto' (default) times both once per workload and keeps the faster -- the same
+    branch on every rank.  A build whose loop-invariant part dominates (n_test = 500 in `delta`: one pass over X + the
+    pre-activation, repeated by every rank whatever its share of the probes) gains less from a rank's shorter probe list
+    than the all-gather costs: sharded, it would be SLOWER than one GPU."""
+    v = os.environ.get("LT_SHARD_PROBES", "auto").lower()
+    return v if v in ("0", "1", "auto") else "auto"
+
+
+_probe_choice = {}
+
+
+def choose_probe_sharding(key, sharded, local, trials: int = 5, warm: int = 2, sync=None) -> bool:
+    """Whether the workload `key` shards its probes (True) or every rank builds all rows (False), by shard_probes_policy().
+    `sharded` / `local` run one build each way (the callers' real step: refresh + rows (+ all-gather)); 'auto' times
+    `trials` of each after `warm`, takes the MAX over the ranks (one all-reduce per strategy) and keeps the faster -- every
+    rank gets the same answer, remembered per key.  `sync`: drains the device (default torch.cuda.synchronize when CUDA is
+    initialised).  The pattern of _choose_baseline_sharding."""
+    import time
+    if not collectives_on():
+        return False
+    pol = shard_probes_policy()
+    if pol != "auto":
+        return pol == "1"
+    if key in _probe_choice:
+        return _probe_choice[key][0]
+    if sync is None:
+        sync = torch.cuda.synchronize if (torch.cuda.is_available() and torch.cuda.is_initialized()) else (lambda: None)
+    times = []
+    for fn in (local, sharded):
+        for _ in range(warm):
+            fn()
+        sync()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(trials):
+            fn()
+        sync()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if dist.get_backend() != "gloo":
+            t = t.to(torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        times.append(float(t.item()) / trials)
+    use = times[1] < times[0]
+    _probe_choice[key] = (use, times[0], times[1])
+    return use
+
+
+def probe_sharding_report(key):
+    """(sharded?, seconds per build local, seconds per build sharded) of a decided workload, or None."""
+    return _probe_choice.get(key)
+
+
 def shard_baseline_policy() -> str:
     """LT_SHARD_BASELINE: '0' replicate X W1 on every rank, '1' shard it + all-gather S1, 'auto' (default) time both
     at first use and keep the faster (the product is small at twitch size: whether the all-gather beats recomputing

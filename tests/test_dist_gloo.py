@@ -101,3 +101,55 @@ def test_cli_ranks_join_group_and_rank0_writes(tmp_path):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True, True), (1, True, False)]
+
+
+def _policy_worker(rank, ws, port, q):
+    """choose_probe_sharding under gloo: both ranks take the same branch (MAX over ranks of the measured times), the choice is
+    remembered per key, LT_SHARD_PROBES pins it."""
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    calls = {"s": 0, "l": 0}
+
+    def sharded():          # fast on rank 0, slow on rank 1: the MAX over ranks must decide
+        calls["s"] += 1
+        time.sleep(0.001 if rank == 0 else 0.02)
+
+    def local():
+        calls["l"] += 1
+        time.sleep(0.006)
+    os.environ.pop("LT_SHARD_PROBES", None)
+    a = lt_dist.choose_probe_sharding("w1", sharded, local, trials=3, warm=1)
+    n_after = dict(calls)
+    b = lt_dist.choose_probe_sharding("w1", sharded, local, trials=3, warm=1)      # remembered: no further timing
+    rep = lt_dist.probe_sharding_report("w1")
+    c = lt_dist.choose_probe_sharding("w2", lambda: time.sleep(0.001), lambda: time.sleep(0.01), trials=3, warm=1)
+    os.environ["LT_SHARD_PROBES"] = "1"
+    d = lt_dist.choose_probe_sharding("w1", sharded, local)
+    os.environ["LT_SHARD_PROBES"] = "0"
+    e = lt_dist.choose_probe_sharding("w2", sharded, local)
+    q.put((rank, a, b, c, d, e, n_after == calls, rep is not None and rep[1] < rep[2]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_probe_sharding_policy_two_ranks():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_policy_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # w1: sharded is slower on the slowest rank -> every rank builds all rows; w2: sharded faster; the pins override
+    assert res == [(0, False, False, True, True, False, True, True), (1, False, False, True, True, False, True, True)]
+
+
+def test_probe_sharding_policy_single_process():
+    assert lt_dist.choose_probe_sharding("x", lambda: 1 / 0, lambda: 1 / 0) is False      # no group: nothing is timed

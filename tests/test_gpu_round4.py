@@ -72,7 +72,9 @@ def test_bench_collectives_execute_under_rccl_at_world_size_1(gpu, tmp_path, mod
     common = ["--steps", "3", "--warmup", "1", "--blocks", "2", "--no-cpu-baseline", "--no-extras", "--no-pmc", "--mode", mode,
               "--n-test", "120", "--spmm-scale", "14"]
     plain = _bench(common, {"LT_BENCH_DUMP": str(tmp_path / "plain.npy"), **extra})
-    forced = _bench(common, {"LT_FORCE_COLLECTIVES": "1", "LT_BENCH_DUMP": str(tmp_path / "forced.npy"), **extra})
+    # (LT_SHARD_PROBES=1: the all-gather of row slabs on every step -- under the default `auto` a one-rank "group" would find
+    # that building all rows locally is faster and issue none; tests/test_gpu_round6.py covers that policy)
+    forced = _bench(common, {"LT_FORCE_COLLECTIVES": "1", "LT_SHARD_PROBES": "1", "LT_BENCH_DUMP": str(tmp_path / "forced.npy"), **extra})
     assert plain["collectives"]["backend"] is None and not plain["collectives"]["forced_at_world_size_1"]
     col = forced["collectives"]
     assert col["backend"] == "nccl" and col["forced_at_world_size_1"] and col["librccl_mapped"], col
@@ -121,6 +123,7 @@ def run():
     return out
 plain = run()
 os.environ["LT_FORCE_COLLECTIVES"] = "1"
+os.environ["LT_SHARD_PROBES"] = "1"
 os.environ["LT_SHARD_BASELINE"] = "1"
 assert lt_main.init_distributed() is True
 assert lt_dist.force_collectives() and lt_dist.collectives_on() and lt_dist.world() == (0, 1)

@@ -178,3 +178,23 @@ def test_influence_rows_f64_equals_rows_plus_export(gpu, graph_kind, mode):
     with pytest.raises(IndexError):
         base.influence_matrix_host(torch.tensor([0, n], dtype=torch.int32, device=gpu), obs, 1e-4, mode)
     engine.node_check()
+
+
+def test_probe_sharding_auto_never_slower_than_one_gpu(gpu, tmp_path):
+    """LT_SHARD_PROBES=auto (default) under LT_FORCE_COLLECTIVES=1: bench.py times 'shard + all-gather' against 'every rank builds
+    all rows' through the group's collectives (RCCL at world size 1) and takes the faster; on the n_test = 500-shaped `delta`
+    build -- whose step is its loop-invariant baseline -- that is the local build, the line says so, and the matrix equals the
+    plain run's bit for bit."""
+    from test_gpu_round4 import _bench
+    common = ["--steps", "5", "--warmup", "1", "--blocks", "3", "--no-cpu-baseline", "--no-extras", "--no-pmc", "--no-scaling-workloads",
+              "--no-api-wall", "--mode", "delta", "--n-test", "200"]
+    plain = _bench(common, {"LT_BENCH_DUMP": str(tmp_path / "plain.npy")})
+    auto = _bench(common, {"LT_FORCE_COLLECTIVES": "1", "LT_BENCH_DUMP": str(tmp_path / "auto.npy")})
+    ps = auto["config"]["probe_sharding"]
+    assert ps["policy"] == "auto" and ps["sharded"] is False, ps
+    assert ps["ms_per_step_every_rank_all_rows"] < ps["ms_per_step_sharded_all_gather"], ps
+    assert auto["config"]["collective_bytes_per_step"] == 0
+    assert np.array_equal(np.load(tmp_path / "plain.npy"), np.load(tmp_path / "auto.npy"))
+    print(f"plain {plain['ms_per_step']} ms, forced collectives + auto {auto['ms_per_step']} ms per step")
+    if os.environ.get("LT_ASSERT_TIMINGS"):
+        assert auto["ms_per_step"] <= 1.10 * plain["ms_per_step"]
