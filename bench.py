@@ -345,6 +345,35 @@ def main():
             shard[f"{m_}_ms"] = wall(lambda: bb.influence_rows(pb, ob, 1e-4, m_))
             shard[f"{m_}_incl_baseline_ms"] = wall(lambda: (bb.refresh(m_), bb.influence_rows(pb, ob, 1e-4, m_)))
         shard["pairs_per_s_delta_incl_baseline"] = round(512 * 4096 / (shard["delta_incl_baseline_ms"] * 1e-3), 1)
+        if bb.fp64_route() == 2:
+            # The same rank with the hub rows ALL 4096 probes reach split over 8 ranks (dist.SharedHubRows): this GPU plays rank 0
+            # -- it forms 1/8 of those rows and packs them; the all-gather is EXCLUDED (its output, the other ranks' rows, is
+            # prepared once outside the timed region); it adopts all of them, then runs its 512 probes.
+            rows_all = bb.reached_rows(ob, lt_dist.HUB_ROW_MIN_ENTRIES)
+            nh = int(rows_all.numel())
+            per8 = (nh + 7) // 8
+            hp = (hcols + 3) // 4 * 4
+            allbuf = torch.empty((max(nh, 1), hp), dtype=torch.float64, device=dev)
+            bb.refresh("delta")
+            bb.form_rows_fp64(rows_all)
+            bb.gather_rows_fp64(rows_all, allbuf)
+            mine = rows_all[:per8].contiguous()
+            send = torch.empty((max(per8, 1), hp), dtype=torch.float64, device=dev)
+
+            def hub_step():
+                bb.refresh("delta")
+                bb.form_rows_fp64(mine)
+                bb.gather_rows_fp64(mine, send)
+                bb.scatter_rows_fp64(rows_all, allbuf)
+                return bb.influence_rows(pb, ob, 1e-4, "delta")
+            plain = bb.influence_rows(pb, ob, 1e-4, "delta").clone()
+            shard["delta_incl_baseline_hub_rows_shared_ms"] = wall(hub_step)
+            shard["hub_rows_shared"] = {
+                "rows_all_ranks_reach": nh, "min_entries": lt_dist.HUB_ROW_MIN_ENTRIES, "rows_formed_by_this_rank": int(mine.numel()),
+                "all_gather_bytes": int(8 * per8 * hp * 8), "same_bits_as_the_unshared_build": bool(torch.equal(hub_step(), plain)),
+                "predicted_speedup_at_8_ranks_before_collectives": None,
+                "note": "one rank of 8 emulated on this GPU: 1/8 of the hub rows formed here, the other ranks' rows adopted from a buffer "
+                        "filled outside the timed region (the all-gather itself is not in the figure)"}
         return shard
 
     def tiled_route(gb_, hcols):
@@ -969,11 +998,18 @@ def main():
         pr = torch.from_numpy(nodes_np[q0:q1].astype(np.int32)).to(dev)
         ob = torch.from_numpy(nodes_np.astype(np.int32)).to(dev)
 
+        hub = None
+        if multi and mode == "delta" and bs.fp64_route() == 2 and os.environ.get("LT_SHARE_HUB_ROWS", "1") != "0":
+            hub = lt_dist.SharedHubRows(bs, ob)
+            strategy["hub_rows_shared"] = {"rows": hub.n_rows, "rows_per_rank": hub.per, "all_gather_bytes": hub.collective_bytes}
+
         def one():
             slab = torch.empty((per_, n_t), dtype=torch.float32, device=dev)
             if q1 - q0 < per_:
                 slab[q1 - q0:].zero_()
             bs.refresh(mode)
+            if hub is not None:
+                hub.exchange()
             bs.influence_rows(pr, ob, delta, mode, out=slab[: q1 - q0])
             full_, work = lt_dist.all_gather_rows(slab, n_t, async_op=True)
             if work is not None:

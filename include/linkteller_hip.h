@@ -29,8 +29,9 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 5   /* 5: lt_influence_rows_f64 (the probes' blocks write the float64 matrix themselves); every version-4 entry point is
-                            unchanged.  4: lt_export_rows_f64 (the matrix leaves the device once, as float64), node ids checked on the device
+#define LT_ABI_VERSION 5   /* 5: lt_influence_rows_f64 (the probes' blocks write the float64 matrix themselves), the on-demand pre-activation by
+                            row list (lt_baseline_form / gather / scatter_rows_fp64: hub rows shared between ranks); every version-4 entry
+                            point is unchanged.  4: lt_export_rows_f64 (the matrix leaves the device once, as float64), node ids checked on the device
                             (LT_ERR_INDEX, lt_node_check), lt_profile_calls; every version-3 entry point is unchanged.  2: lt_baseline_refresh launches nothing (lazy recomputation on the first reader's stream); fp64 shard entry points;
                             profile classes 9-11.  3: lt_influence_rows_vec + lt_wide_combine (layers wider than one pass of the fused
                             kernels), lt_spmm_gather_ceiling (measurement support); every version-2 entry point is unchanged */
@@ -141,6 +142,12 @@ int lt_graph_create(int32_t n, int64_t nnz, const int32_t *rowptr, const int32_t
                     const float *val, lt_graph **out);
 int lt_graph_destroy(lt_graph *g);
 int lt_graph_info(const lt_graph *g, int32_t *n, int64_t *nnz, int32_t *max_row_nnz);
+/* The rows of at least min_entries entries that the probe nodes reach in one hop ({r : A_hat[r, v] != 0 for a probe v}), each once,
+ * in no particular order: rows[0 .. *count) (device; capacity n), flags: device scratch of n int32 (overwritten).  What the ranks
+ * of a multi-GPU run agree on (every rank runs it on the WHOLE probe list and sorts the result) before they split the hub rows
+ * of the on-demand pre-activation between them (lt_baseline_form_rows_fp64 below). */
+int lt_graph_reached_rows(const lt_graph *g, const int32_t *probes, int32_t n_probe, int32_t min_entries, int32_t *flags,
+                          int32_t *rows, int32_t *count, void *stream);
 /* Host only (no device call): the incidence records lt_graph_create would build for this CSR -- what tests/test_records.py pins
  * against a plain restatement.  meta [4 n]: per node (offset into rec in 32-bit words, items, touched nodes, incidences);
  * rec (may be NULL: sizes only): per node its items (row r, A_hat[r, v] as bits), then the touched nodes (u, first entry |
@@ -222,6 +229,18 @@ int lt_baseline_refresh_rows(lt_baseline *b, int32_t row_begin, int32_t row_end,
 int lt_baseline_attach_s1d(lt_baseline *b, double *S1d, int64_t ld, void *stream);
 int lt_baseline_refresh_rows_fp64(lt_baseline *b, int32_t row_begin, int32_t row_end, double *dst, void *stream);
 int lt_baseline_fp64_route(const lt_baseline *b, int32_t *route);
+/* The on-demand route by ROW LIST (lt_baseline_fp64_route == 2; LT_ERR_UNSUPPORTED otherwise): a call of lt_influence_rows forms
+ * the fp64 pre-activation Z1d on the rows ITS probes reach.  On a heavy-tailed graph most of that work lies in hub rows every
+ * rank's probes reach (BASELINE configs[4], 8 ranks x 512 probes: ~3 800 rows of >= 1 024 entries hold 84 % of a rank's gathers,
+ * and they are the same rows on every rank).  Every rank knows the whole probe list (attacker.py:220: one list), so the ranks
+ * can split those rows: each forms its share (lt_baseline_form_rows_fp64: the listed rows now; rows valid since the last refresh
+ * are skipped), packs it (lt_baseline_gather_rows_fp64: dst[i, 0 .. Hp) = Z1d[rows[i]], the send buffer of ONE all-gather) and
+ * adopts everybody's (lt_baseline_scatter_rows_fp64: Z1d[rows[i]] = src[i, 0 .. Hp), marked valid).  The calls of
+ * lt_influence_rows that follow skip valid rows.  A row's bits do not depend on who formed it.  rows: device int32 lists (ids out
+ * of range are skipped); dst / src: device, [n_rows, Hp] doubles, 16-byte aligned; Hp = H rounded up to 4. */
+int lt_baseline_form_rows_fp64(lt_baseline *b, const int32_t *rows, int32_t n_rows, void *stream);
+int lt_baseline_gather_rows_fp64(lt_baseline *b, const int32_t *rows, int32_t n_rows, double *dst, void *stream);
+int lt_baseline_scatter_rows_fp64(lt_baseline *b, const int32_t *rows, int32_t n_rows, const double *src, void *stream);
 int lt_baseline_destroy(lt_baseline *b);
 /* copies the baseline logits OUT [n, C] (dense, ld = C) to a device buffer */
 int lt_baseline_logits(const lt_baseline *b, float *dst, void *stream);

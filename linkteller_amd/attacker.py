@@ -277,7 +277,21 @@ class Attacker:
                 lambda: self._rows(all_p, observed, mode))
             if not sharded:
                 probes = all_p
-        local = self._rows(probes, observed, mode)
+        local = None
+        if sharded and lt_dist.collectives_on() and self._walk()[0] == "gcn2" and self._mode(mode) == "delta":
+            # `delta` on the on-demand route (large graphs): the hub rows every rank's probes reach are formed once across the
+            # ranks and exchanged (dist.SharedHubRows) instead of by every rank
+            kind, sd = self._walk()
+            base = self.baseline("delta", sd)
+            if isinstance(base, engine.Baseline) and base.fp64_route() == 2:
+                hkey = (id(base), nodes.tobytes())
+                hub = getattr(self, "_hub_rows", None)
+                if hub is None or hub[0] != hkey:
+                    hub = self._hub_rows = (hkey, lt_dist.SharedHubRows(base, observed))
+                hub[1].exchange()
+                local = base.influence_rows(probes, observed, float(self.args.influence), "delta")
+        if local is None:
+            local = self._rows(probes, observed, mode)
         full = lt_dist.all_gather_rows(local, len(nodes)) if sharded else local
         if full.is_cuda:
             # ONE launch widens the rows on the device and writes them into pinned host memory; one wait (the reference:

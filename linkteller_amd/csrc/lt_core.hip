@@ -631,6 +631,41 @@ extern "C" int lt_graph_info(const lt_graph *g, int32_t *n, int64_t *nnz, int32_
     return LT_OK;
 }
 
+// ---- lt_graph_reached_rows: the rows of at least min_entries entries that a list of probe nodes reaches in one hop -----------
+// (R_v = {r : A_hat[r, v] != 0} over the probes' CSC columns.)  What the ranks of a multi-GPU run agree on before they split the
+// shared hub rows of the on-demand pre-activation (lt_baseline_form_rows_fp64): every rank runs this on the WHOLE probe list.
+// The list comes out in no particular order (a flag word per row, first arrival appends): sort it before use.
+static __global__ __launch_bounds__(256) void k_reached_rows(const int32_t *__restrict__ probes, int n_probe, int n,
+                                                             const int32_t *__restrict__ tptr, const int32_t *__restrict__ trow,
+                                                             const int32_t *__restrict__ rowptr, int min_entries,
+                                                             int32_t *__restrict__ flags, int32_t *__restrict__ rows,
+                                                             int32_t *__restrict__ count) {
+    // one wave per probe: its column's entries in strides of 64
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= n_probe) return;
+    const int v = probes[wave];
+    if ((unsigned)v >= (unsigned)n) return;
+    for (int e = tptr[v] + lane; e < tptr[v + 1]; e += 64) {
+        const int r = trow[e];
+        if (rowptr[r + 1] - rowptr[r] < min_entries) continue;
+        if (atomicExch(&flags[r], 1) == 0) rows[atomicAdd(count, 1)] = r;
+    }
+}
+extern "C" int lt_graph_reached_rows(const lt_graph *g, const int32_t *probes, int32_t n_probe, int32_t min_entries, int32_t *flags,
+                                     int32_t *rows, int32_t *count, void *stream) {
+    LT_REQUIRE(g != nullptr, "lt_graph_reached_rows: graph is NULL");
+    LT_REQUIRE(n_probe >= 0 && (n_probe == 0 || probes != nullptr), "lt_graph_reached_rows: bad probe list");
+    LT_REQUIRE(flags && rows && count, "lt_graph_reached_rows: NULL output / scratch pointer");
+    hipStream_t st = (hipStream_t)stream;
+    LT_HIP(hipMemsetAsync(flags, 0, (size_t)(g->n > 0 ? g->n : 1) * sizeof(int32_t), st));
+    LT_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), st));
+    if (n_probe == 0 || g->n == 0) return LT_OK;
+    hipLaunchKernelGGL(k_reached_rows, dim3((unsigned)((n_probe + 3) / 4)), dim3(256), 0, st, probes, n_probe, g->n, g->tptr, g->trow,
+                       g->rowptr, min_entries, flags, rows, count);
+    LT_CHECK_LAUNCH();
+    return LT_OK;
+}
+
 // ---- node ids out of range: the flag words the kernels raise (include/linkteller_hip.h, lt_node_check) -------------------------
 // Two words of mapped host memory per process (portable: every device writes through its own alias): [0] a probe list,
 // [1] an observed list held an id outside [0, n).

@@ -1265,14 +1265,11 @@ bool lt_fp64_agg_active(const lt_baseline *b) {
     return b->agg_default;
 }
 
-int lt_fp64_prepare_items(const lt_baseline *b, const int32_t *off, int nb, const int2 *item_pr, const int32_t *probes,
-                          double *Spd, hipStream_t st) {
+// the rows marked 2 (listed in zrows / zcount): (A_hat X)[r] by the tiled gathers, then Z1d[r] = Y[r] W1 + b1, zstate -> 1
+static int agg_form_marked(const lt_baseline *b, hipStream_t st) {
     const lt_graph *g = b->g;
     const int Hp = b->Hp, H = b->H, F = b->F, Fp = b->Fp;
     { lt_prof_scope prof_(LT_K_FP64_SPMM, st);
-    LT_HIP(hipMemsetAsync(b->zcount, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_z_mark, dim3(1024), dim3(256), 0, st, off, nb, item_pr, b->zstate, b->zrows, b->zcount);
-    LT_CHECK_LAUNCH();
     int rc = lt_launch_rows_tiled_xf64(g, b->X, b->ldx, F, b->Yd, Fp, b->seg_y, Fp, b->zstate, b->zitems, b->zicount, st);
     if (rc) return rc;
     if (g->p_n_long > 0) {
@@ -1286,6 +1283,19 @@ int lt_fp64_prepare_items(const lt_baseline *b, const int32_t *off, int nb, cons
     hipLaunchKernelGGL((k_gemm_f64_rows<double>), dim3(2048), dim3(256), 0, st, b->Yd, (long)Fp, b->zrows, b->zcount, 0, b->W1,
                        (long)H, H, F, b->b1, b->Z1d, (long)Hp, 1, b->zstate, 0);
     LT_CHECK_LAUNCH();
+    return LT_OK;
+}
+
+int lt_fp64_prepare_items(const lt_baseline *b, const int32_t *off, int nb, const int2 *item_pr, const int32_t *probes,
+                          double *Spd, hipStream_t st) {
+    const int Hp = b->Hp, H = b->H, F = b->F;
+    { lt_prof_scope prof_(LT_K_FP64_SPMM, st);
+    LT_HIP(hipMemsetAsync(b->zcount, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_z_mark, dim3(1024), dim3(256), 0, st, off, nb, item_pr, b->zstate, b->zrows, b->zcount);
+    LT_CHECK_LAUNCH(); }
+    { const int rc = agg_form_marked(b, st);
+      if (rc) return rc; }
+    lt_prof_scope prof_(LT_K_FP64_PRODUCT, st);
     if (Hp != H) LT_HIP(hipMemsetAsync(Spd, 0, (size_t)nb * Hp * sizeof(double), st));
     const int tiles = ((nb + GD_BM - 1) / GD_BM) * ((H + GD_BN - 1) / GD_BN);
     hipLaunchKernelGGL((k_gemm_f64_rows<float>), dim3((unsigned)(tiles < 2048 ? tiles : 2048)), dim3(256), 0, st, b->X, (long)b->ldx,
@@ -1698,6 +1708,74 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     rc = compute_s1d(b, st);
     b->fp64_fresh = rc == LT_OK;
     return rc;
+}
+
+// ---- the aggregate-first pre-activation by ROW LIST: what lets several ranks share the rows all of them reach -------------------
+// On the on-demand route (lt_baseline_fp64_route == 2) a call forms Z1d on the rows its own probes reach.  On a heavy-tailed
+// graph most of that work is in hub rows EVERY rank's probes reach (R-MAT scale 21, 8 x 512 probes: 84 % of a rank's gathers
+// are in ~3 800 rows of >= 1 024 entries common to all ranks).  With these three a caller splits such rows over the ranks:
+//   lt_baseline_form_rows_fp64    Z1d[r] for the listed rows now (rows already valid since the last refresh are skipped)
+//   lt_baseline_gather_rows_fp64  dst[i, 0 .. Hp) = Z1d[rows[i]]           (the rank's send buffer)
+//   lt_baseline_scatter_rows_fp64 Z1d[rows[i]] = src[i, 0 .. Hp), row valid (the all-gather's output, every rank's rows)
+// A row carries the same bits whichever rank formed it (its gathers and its product are a function of the row alone).
+static __global__ __launch_bounds__(256) void k_z_mark_rows(const int32_t *__restrict__ rows, int n_rows, int n,
+                                                            int32_t *__restrict__ zstate, int32_t *__restrict__ zrows,
+                                                            int32_t *__restrict__ zcount) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_rows; i += (long)gridDim.x * 256) {
+        const int r = rows[i];
+        if ((unsigned)r >= (unsigned)n || zstate[r] != 0) continue;
+        if (atomicCAS(&zstate[r], 0, 2) == 0) zrows[atomicAdd(zcount, 1)] = r;
+    }
+}
+static __global__ __launch_bounds__(256) void k_z_rows_copy(const int32_t *__restrict__ rows, int n_rows, int n, int Hp,
+                                                            double *__restrict__ Z1d, double *__restrict__ buf,
+                                                            int32_t *__restrict__ zstate, int scatter) {
+    // a lane group of Hp / 2 lanes (16-byte pieces) per row
+    const int per = Hp / 2;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < (long)n_rows * per; k += (long)gridDim.x * 256) {
+        const int i = (int)(k / per), c = (int)(k % per) * 2;
+        const int r = rows[i];
+        if ((unsigned)r >= (unsigned)n) continue;
+        double2 *z = reinterpret_cast<double2 *>(Z1d + (size_t)r * Hp + c), *q = reinterpret_cast<double2 *>(buf + (size_t)i * Hp + c);
+        if (scatter) { *z = *q; if (c == 0) zstate[r] = 1; }
+        else *q = *z;
+    }
+}
+static int agg_rows_check(const char *who, lt_baseline *b, const int32_t *rows, int32_t n_rows, hipStream_t st) {
+    LT_REQUIRE(b != nullptr, "%s: baseline is NULL", who);
+    LT_REQUIRE(n_rows >= 0 && (rows != nullptr || n_rows == 0), "%s: bad row list", who);
+    if (!lt_fp64_agg_active(b))
+        return lt_set_error(LT_ERR_UNSUPPORTED, "%s: the baseline is not on the aggregate-first route (lt_baseline_fp64_route != 2)", who);
+    return lt_baseline_ensure_layers(b, true, st, false);      // (a refresh since the last call: every row stale again)
+}
+extern "C" int lt_baseline_form_rows_fp64(lt_baseline *b, const int32_t *rows, int32_t n_rows, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    int rc = agg_rows_check("lt_baseline_form_rows_fp64", b, rows, n_rows, st);
+    if (rc || n_rows == 0) return rc;
+    { lt_prof_scope prof_(LT_K_FP64_SPMM, st);
+    LT_HIP(hipMemsetAsync(b->zcount, 0, sizeof(int32_t), st));
+    const int blocks = (n_rows + 255) / 256;
+    hipLaunchKernelGGL(k_z_mark_rows, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st, rows, n_rows, b->n, b->zstate,
+                       b->zrows, b->zcount);
+    LT_CHECK_LAUNCH(); }
+    return agg_form_marked(b, st);
+}
+static int agg_rows_copy(const char *who, lt_baseline *b, const int32_t *rows, int32_t n_rows, double *buf, hipStream_t st, int scatter) {
+    int rc = agg_rows_check(who, b, rows, n_rows, st);
+    if (rc || n_rows == 0) return rc;
+    LT_REQUIRE(buf != nullptr && ((uintptr_t)buf & 15) == 0, "%s: buffer is NULL or not 16-byte aligned", who);
+    const long total = (long)n_rows * (b->Hp / 2);
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_z_rows_copy, dim3((unsigned)blocks), dim3(256), 0, st, rows, n_rows, b->n, b->Hp, b->Z1d, buf, b->zstate, scatter);
+    LT_CHECK_LAUNCH();
+    return LT_OK;
+}
+extern "C" int lt_baseline_gather_rows_fp64(lt_baseline *b, const int32_t *rows, int32_t n_rows, double *dst, void *stream) {
+    return agg_rows_copy("lt_baseline_gather_rows_fp64", b, rows, n_rows, dst, (hipStream_t)stream, 0);
+}
+extern "C" int lt_baseline_scatter_rows_fp64(lt_baseline *b, const int32_t *rows, int32_t n_rows, const double *src, void *stream) {
+    return agg_rows_copy("lt_baseline_scatter_rows_fp64", b, rows, n_rows, const_cast<double *>(src), (hipStream_t)stream, 1);
 }
 
 extern "C" int lt_baseline_fp64_route(const lt_baseline *b, int32_t *route) {

@@ -131,6 +131,53 @@ def probe_sharding_report(key):
     return _probe_choice.get(key)
 
 
+HUB_ROW_MIN_ENTRIES = int(os.environ.get("LT_HUB_ROW_MIN_ENTRIES", "1024"))   # rows at least this long are worth an exchange (2 KB of fp64
+                                                                             # per row against >= 1 MB of gathers); the env is a test hook
+
+
+class SharedHubRows:
+    """The hub rows ALL ranks' probes reach, split over the ranks (BASELINE configs[4]: R-MAT, n_test = 4096 over 8 ranks).
+
+    On the on-demand route of `delta` (engine.Baseline.fp64_route() == 2) a rank forms the fp64 pre-activation on the rows its
+    own probes reach; on a heavy-tailed graph most of that work lies in hub rows every rank reaches (84 % of a rank's gathers
+    in ~3 800 rows at configs[4]) -- replicated W times.  Every rank holds the whole probe list (attacker.py:220: one list), so
+    all of them compute the same sorted list of reached rows of >= HUB_ROW_MIN_ENTRIES entries ONCE per node list (here), and
+    after every refresh (``exchange``) rank k forms rows [k per, (k + 1) per) of it, one all-gather moves the 2-KB rows, every
+    rank adopts all of them; the probe calls that follow skip valid rows.  A row's bits do not depend on the rank that formed it
+    (its gathers and its product are functions of the row alone), so the matrix equals the single-rank one bit for bit."""
+
+    def __init__(self, base, all_probe_nodes, min_entries: int = HUB_ROW_MIN_ENTRIES):
+        rank, ws = world()
+        self.base = base
+        self.rows = base.reached_rows(all_probe_nodes, min_entries)
+        n = self.rows.numel()
+        self.n_rows = n
+        self.b, self.e, self.per = shard_bounds(n, rank, ws)
+        dev = self.rows.device
+        hp = (base.h + 3) // 4 * 4
+        self.mine = self.rows[self.b:self.e].contiguous()
+        padded = torch.full((ws * self.per,), -1, dtype=torch.int32, device=dev)      # (ids out of range are skipped by the scatter)
+        padded[:n] = self.rows
+        self.padded = padded
+        self.send = torch.zeros((max(self.per, 1), hp), dtype=torch.float64, device=dev)
+        self.recv = torch.empty((max(ws * self.per, 1), hp), dtype=torch.float64, device=dev)
+
+    def exchange(self):
+        """After a refresh, before the probe call: form this rank's share, all-gather, adopt every rank's rows."""
+        if self.n_rows == 0:
+            return
+        if self.mine.numel():
+            self.base.form_rows_fp64(self.mine)
+            self.base.gather_rows_fp64(self.mine, self.send)
+        if collectives_on():
+            all_gather_into(self.recv, self.send)
+            self.base.scatter_rows_fp64(self.padded, self.recv)
+
+    @property
+    def collective_bytes(self):
+        return int(self.recv.numel() * 8)
+
+
 def shard_baseline_policy() -> str:
     """LT_SHARD_BASELINE: '0' replicate X W1 on every rank, '1' shard it + all-gather S1, 'auto' (default) time both
     at first use and keep the faster (the product is small at twitch size: whether the all-gather beats recomputing

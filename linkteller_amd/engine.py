@@ -170,6 +170,32 @@ class Baseline:
         _lib.check(_lib.lib().lt_baseline_fp64_route(self._h, C.byref(r)), "lt_baseline_fp64_route")
         return r.value
 
+    # ---- the on-demand pre-activation by row list (fp64_route() == 2): hub rows shared between ranks, dist.share_hub_rows ----
+    def reached_rows(self, probe_nodes, min_entries: int) -> torch.Tensor:
+        """Sorted int32 device list of the rows of >= min_entries entries that the probes reach in one hop (lt_graph_reached_rows;
+        one host sync for the count: call once per node list, not per step)."""
+        dev = self.x.device
+        probes = _as_nodes(probe_nodes, self.n, dev, "probe_nodes")
+        flags = torch.empty(max(self.n, 1), dtype=torch.int32, device=dev)
+        rows = torch.empty(max(self.n, 1), dtype=torch.int32, device=dev)
+        count = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().lt_graph_reached_rows(self.graph.handle, probes.data_ptr(), probes.numel(), int(min_entries),
+                                                    flags.data_ptr(), rows.data_ptr(), count.data_ptr(), _stream()),
+                   "lt_graph_reached_rows")
+        return torch.sort(rows[: int(count.item())]).values.contiguous()
+
+    def form_rows_fp64(self, rows: torch.Tensor):
+        self.enable_fp64()
+        _lib.check(_lib.lib().lt_baseline_form_rows_fp64(self._h, rows.data_ptr(), rows.numel(), _stream()), "lt_baseline_form_rows_fp64")
+
+    def gather_rows_fp64(self, rows: torch.Tensor, dst: torch.Tensor):
+        _lib.check(_lib.lib().lt_baseline_gather_rows_fp64(self._h, rows.data_ptr(), rows.numel(), dst.data_ptr(), _stream()),
+                   "lt_baseline_gather_rows_fp64")
+
+    def scatter_rows_fp64(self, rows: torch.Tensor, src: torch.Tensor):
+        _lib.check(_lib.lib().lt_baseline_scatter_rows_fp64(self._h, rows.data_ptr(), rows.numel(), src.data_ptr(), _stream()),
+                   "lt_baseline_scatter_rows_fp64")
+
     def shard_refresh_fp64(self, enable=True):
         """Multi-GPU: shard the fp64 product X W1 of `delta` over the ranks (rows of k_gemm_f64acc_128 + one all-gather
         of S1d) instead of recomputing it on every rank.  Bits are those of the replicated product."""

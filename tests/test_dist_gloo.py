@@ -153,3 +153,67 @@ def test_probe_sharding_policy_two_ranks():
 
 def test_probe_sharding_policy_single_process():
     assert lt_dist.choose_probe_sharding("x", lambda: 1 / 0, lambda: 1 / 0) is False      # no group: nothing is timed
+
+
+class _FakeBase:
+    """What dist.SharedHubRows needs of an engine.Baseline, on CPU tensors: Z[r] = r * (1, 2, ..., Hp) for a formed row."""
+    def __init__(self, n, h, reached):
+        self.n, self.h = n, h
+        self._reached = torch.tensor(sorted(reached), dtype=torch.int32)
+        self.z = torch.zeros((n, (h + 3) // 4 * 4), dtype=torch.float64)
+        self.valid = torch.zeros(n, dtype=torch.bool)
+        self.formed = []
+
+    def reached_rows(self, nodes, min_entries):
+        return self._reached.clone()
+
+    def form_rows_fp64(self, rows):
+        for r in rows.tolist():
+            self.z[r] = float(r) * torch.arange(1, self.z.shape[1] + 1, dtype=torch.float64)
+            self.valid[r] = True
+            self.formed.append(r)
+
+    def gather_rows_fp64(self, rows, dst):
+        dst[: rows.numel()] = self.z[rows.long()]
+
+    def scatter_rows_fp64(self, rows, src):
+        for i, r in enumerate(rows.tolist()):
+            if 0 <= r < self.n:
+                self.z[r] = src[i]
+                self.valid[r] = True
+
+
+def _hub_worker(rank, ws, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    ok = True
+    for reached in ([3, 17, 4, 90, 55, 21, 8], [5], list(range(10, 26)), []):
+        base = _FakeBase(100, 6, reached)
+        hub = lt_dist.SharedHubRows(base, None, min_entries=1)
+        hub.exchange()
+        want = torch.zeros_like(base.z)
+        for r in reached:
+            want[r] = float(r) * torch.arange(1, want.shape[1] + 1, dtype=torch.float64)
+        b, e, per = lt_dist.shard_bounds(len(reached), rank, ws)
+        ok = ok and torch.equal(base.z, want) and sorted(base.formed) == sorted(reached)[b:e]      # only its share was formed here
+        ok = ok and bool(base.valid[torch.tensor(sorted(reached), dtype=torch.long)].all()) and int(base.valid.sum()) == len(reached)
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shared_hub_rows_partition_two_ranks():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_hub_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]

@@ -198,3 +198,125 @@ def test_probe_sharding_auto_never_slower_than_one_gpu(gpu, tmp_path):
     print(f"plain {plain['ms_per_step']} ms, forced collectives + auto {auto['ms_per_step']} ms per step")
     if os.environ.get("LT_ASSERT_TIMINGS"):
         assert auto["ms_per_step"] <= 1.10 * plain["ms_per_step"]
+
+
+def test_on_demand_preactivation_by_row_list(gpu):
+    """lt_graph_reached_rows + lt_baseline_form / gather / scatter_rows_fp64 (the row-list form of the aggregate-first route): the hub
+    rows a probe list reaches, formed ahead of the probe call, packed, and adopted from a buffer -- the matrix keeps every bit
+    of the plain call's; rows stay valid until the next refresh (the call skips them); other routes refuse."""
+    import scipy.sparse as sp
+    from linkteller_amd import _lib, engine, graph, synth
+    n, f, h = 3000, 96, 64
+    adj = synth.powerlaw_graph(n, 20000, seed=5)
+    a_hat = graph.first_order_gcn(adj)
+    hg = graph.HipGraph(a_hat)
+    x = torch.from_numpy(synth.gaussian_features(n, f, seed=6)).to(gpu)
+    w = synth.gcn_weights(f, h, 2, seed=7)
+    rng = np.random.RandomState(8)
+    obs = rng.choice(n, 400, replace=False)
+    probes = obs[:100]
+    _lib.set_tuning("aggregate_first", 1)
+    try:
+        base = engine.Baseline(hg, x, *_params(w, gpu)).enable_fp64()
+        assert base.fp64_route() == 2
+        plain = base.influence_rows(probes, obs, 1e-4, "delta").clone()
+        # the reached rows against scipy
+        thr = 40
+        rows = base.reached_rows(obs, thr)
+        csc = sp.csc_matrix(a_hat)
+        reach = np.unique(np.concatenate([csc.indices[csc.indptr[v]:csc.indptr[v + 1]] for v in obs]))
+        lens = np.diff(sp.csr_matrix(a_hat).indptr)
+        want_rows = reach[lens[reach] >= thr]
+        assert len(want_rows) > 10 and np.array_equal(rows.cpu().numpy(), want_rows)
+        hp = (h + 3) // 4 * 4
+        buf = torch.full((rows.numel(), hp), float("nan"), dtype=torch.float64, device=gpu)
+        base.refresh("delta")
+        base.form_rows_fp64(rows)
+        base.gather_rows_fp64(rows, buf)
+        assert bool(torch.isfinite(buf).all())
+        a = base.influence_rows(probes, obs, 1e-4, "delta")          # (the hub rows are valid: only the others are formed)
+        assert torch.equal(a, plain)
+        # adopt the rows from the buffer instead of forming them (ids out of range in the list are skipped)
+        base.refresh("delta")
+        padded = torch.cat([rows, torch.tensor([-1, n, -5], dtype=torch.int32, device=gpu)])
+        bufp = torch.cat([buf, torch.full((3, hp), float("nan"), dtype=torch.float64, device=gpu)])
+        base.scatter_rows_fp64(padded, bufp)
+        b = base.influence_rows(probes, obs, 1e-4, "delta")
+        assert torch.equal(b, plain)
+        # a share formed here, the rest adopted: what dist.SharedHubRows does on one of several ranks
+        base.refresh("delta")
+        k = rows.numel() // 3
+        base.form_rows_fp64(rows[:k].contiguous())
+        base.scatter_rows_fp64(rows[k:].contiguous(), buf[k:].contiguous())
+        assert torch.equal(base.influence_rows(probes, obs, 1e-4, "delta"), plain)
+        # poisoned rows DO reach the result (the call really takes them from the buffer)
+        base.refresh("delta")
+        base.scatter_rows_fp64(rows, -buf)               # (the kink test reads the sign: a scaled row would change nothing)
+        assert not torch.equal(base.influence_rows(probes, obs, 1e-4, "delta"), plain)
+        base.refresh("delta")
+    finally:
+        _lib.set_tuning("aggregate_first", None)
+    _lib.set_tuning("aggregate_first", 0)
+    try:
+        base2 = engine.Baseline(hg, x, *_params(w, gpu)).enable_fp64()
+        assert base2.fp64_route() != 2
+        with pytest.raises(RuntimeError):
+            base2.form_rows_fp64(rows)
+    finally:
+        _lib.set_tuning("aggregate_first", None)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_hub_rows_shared_between_ranks_keep_every_bit(gpu, tmp_path, world):
+    """dist.SharedHubRows through the product path (Attacker.influence_matrix on the on-demand route, several ranks as processes on
+    one device over gloo): the ranks split the hub rows all probes reach, one all-gather moves them, and the matrix equals the
+    single-rank one bit for bit."""
+    import textwrap
+    from test_gpu_round2 import _run_ranks
+    from linkteller_amd import _lib, engine, graph, synth
+    code = textwrap.dedent('''
+        import argparse, os, types, numpy as np, torch
+        from linkteller_amd import graph, synth, main as lt_main, dist as lt_dist
+        from linkteller_amd.attacker import Attacker
+        from linkteller_amd.gcn import GCN
+        assert lt_main.init_distributed()
+        import torch.distributed as dist
+        n, f, h = 3000, 96, 64
+        adj = synth.powerlaw_graph(n, 20000, seed=5)
+        x = torch.from_numpy(synth.gaussian_features(n, f, seed=6)).cuda()
+        w = synth.gcn_weights(f, h, 2, seed=7)
+        model = GCN(f, h, 2, 0.5)
+        model.load_state_dict({"gc1.weight": torch.from_numpy(w["W1"]), "gc1.bias": torch.from_numpy(w["b1"]),
+                               "gc2.weight": torch.from_numpy(w["W2"]), "gc2.bias": torch.from_numpy(w["b2"])})
+        model.cuda().eval()
+        adj_t = graph.sparse_mx_to_torch_sparse_tensor(graph.first_order_gcn(adj)).cuda()
+        wk = types.SimpleNamespace(features_2=x, adj_2=adj_t, adj_ori=adj.tocsr(), n_nodes=n)
+        ns = argparse.Namespace(dataset="twitch/ES/RU", sample_type="unbalanced", n_test=301, sample_seed=42, influence=1e-4,
+                                mode="vanilla-clean", attack_mode="efficient", influence_mode="delta")
+        atk = Attacker(ns, model, wk)
+        atk.test_nodes = np.random.RandomState(8).choice(n, 301, replace=False)
+        m1 = atk.influence_matrix()
+        m2 = atk.influence_matrix()                      # (a second attack: the row list is cached, the rows are exchanged again)
+        hub = atk._hub_rows[1]
+        assert hub.n_rows > 10 and hub.per * dist.get_world_size() >= hub.n_rows
+        assert np.array_equal(m1, m2)
+        if dist.get_rank() == 0:
+            np.save(os.environ["LT_TEST_OUT"], m1)
+        dist.barrier(); dist.destroy_process_group()
+    ''')
+    n, f, h = 3000, 96, 64
+    adj = synth.powerlaw_graph(n, 20000, seed=5)
+    hg = graph.HipGraph(graph.first_order_gcn(adj))
+    x = torch.from_numpy(synth.gaussian_features(n, f, seed=6)).to(gpu)
+    w = synth.gcn_weights(f, h, 2, seed=7)
+    nodes = np.random.RandomState(8).choice(n, 301, replace=False)
+    _lib.set_tuning("aggregate_first", 1)
+    try:
+        base = engine.Baseline(hg, x, *_params(w, gpu)).enable_fp64()
+        assert base.fp64_route() == 2
+        single = base.influence_rows(nodes, nodes, 1e-4, "delta").cpu().numpy().astype(np.float64)
+    finally:
+        _lib.set_tuning("aggregate_first", None)
+    out = tmp_path / f"hub{world}.npy"
+    _run_ranks(code, world, {"LT_TEST_OUT": str(out), "LT_AGGREGATE_FIRST": "1", "LT_HUB_ROW_MIN_ENTRIES": "40", "LT_SHARD_PROBES": "1"})
+    assert np.array_equal(np.load(out), single)

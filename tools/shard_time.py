@@ -32,3 +32,26 @@ for m in modes:
     a = wall(lambda: bb.influence_rows(pb, ob, 1e-4, m, out=out))
     b = wall(lambda: (bb.refresh(m), bb.influence_rows(pb, ob, 1e-4, m, out=out)))
     print(f"{m}: {a} ms, incl. baseline {b} ms   (checksum {float(out.double().sum()):.6f}, nonzero {int((out > 0).sum())})")
+
+
+if "delta" in modes and bb.fp64_route() == 2:
+    # one rank of 8 with the hub rows all 4096 probes reach split over the ranks (dist.SharedHubRows): 1/8 formed here, the others'
+    # adopted from a buffer filled beforehand (the all-gather is not in the figure)
+    from linkteller_amd import dist as lt_dist
+    rows_all = bb.reached_rows(ob, lt_dist.HUB_ROW_MIN_ENTRIES)
+    nh = rows_all.numel()
+    per8 = (nh + 7) // 8
+    allbuf = torch.empty((nh, 256), dtype=torch.float64, device=dev)
+    bb.refresh("delta"); bb.form_rows_fp64(rows_all); bb.gather_rows_fp64(rows_all, allbuf)
+    mine = rows_all[:per8].contiguous()
+    send = torch.empty((per8, 256), dtype=torch.float64, device=dev)
+    plain = out.clone()
+
+    def hub_step():
+        bb.refresh("delta"); bb.form_rows_fp64(mine); bb.gather_rows_fp64(mine, send); bb.scatter_rows_fp64(rows_all, allbuf)
+        bb.influence_rows(pb, ob, 1e-4, "delta", out=out)
+    c = wall(hub_step)
+    parts = {"form my 1/8 of the hub rows": wall(lambda: (bb.refresh("delta"), bb.form_rows_fp64(mine))),
+             "pack": wall(lambda: bb.gather_rows_fp64(mine, send)), "adopt all": wall(lambda: bb.scatter_rows_fp64(rows_all, allbuf))}
+    print(f"delta, hub rows shared over 8 ranks: {nh} rows of >= {lt_dist.HUB_ROW_MIN_ENTRIES} entries, {per8} formed here, all-gather "
+          f"{8 * per8 * 256 * 8 / 1e6:.1f} MB: incl. baseline {c} ms  (same bits: {bool(torch.equal(out, plain))}); {parts}")
