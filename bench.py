@@ -952,6 +952,34 @@ def main():
                                     **{f"{m}_ms_per_step": round(res3[m] * 1e3, 4) for m in res3}}
             del out3
             base.refresh()
+        # the 3-layer model (gcn/models.py:28-46, --n-layer 3) at n_test = 500, and `balanced-full`'s chunk shape
+        # (attacker.py:250-284: every node a probe, all N observed; 1024 probes per chunk) on the 2-layer model
+        if not a.powerlaw:
+            rs5 = np.random.RandomState(7)
+
+            def u5(shape, fan_out):
+                s_ = 1.0 / np.sqrt(fan_out)
+                return torch.from_numpy(rs5.uniform(-s_, s_, size=shape).astype(np.float32)).to(dev)
+            h2_ = 64
+            b3 = engine.Baseline3(hg, x, u5((f, h), h), u5((h,), h), u5((h, h2_), h2_), u5((h2_,), h2_), u5((h2_, c), c), u5((c,), c))
+            out5 = torch.empty((a.n_test, a.n_test), dtype=torch.float32, device=dev)
+            g3 = {m: wall_median(lambda: (b3.refresh(), b3.influence_rows(obs, obs, delta, m, out=out5)), 10) for m in ("delta", "sparse")}
+            del b3
+            nb5 = min(1024, n)
+            pr5 = torch.from_numpy(np.random.RandomState(5).choice(n, nb5, replace=False).astype(np.int32)).to(dev)
+            ev5 = torch.arange(n, dtype=torch.int32, device=dev)
+            out5 = torch.empty((nb5, n), dtype=torch.float32, device=dev)
+            bf = {m: wall_median(lambda: (base.refresh(m), base.influence_rows(pr5, ev5, delta, m, out=out5)), 10) for m in ("delta", "sparse")}
+            extras["workload_5"] = {
+                "gcn3": {"workload": f"GCN3 {f}-{h}-{h2_}-{c} (--n-layer 3, gcn/models.py:28-46), n_test={a.n_test} on the headline graph",
+                         "value": round(a.n_test ** 2 / g3[a.mode if a.mode in g3 else "delta"], 1), "unit": "node-pairs/s",
+                         **{f"{m}_ms_per_step": round(g3[m] * 1e3, 4) for m in g3}},
+                "balanced_full_chunk": {"workload": f"balanced-full (attacker.py:250-284): one chunk of {nb5} probes x all {n} nodes observed, 2-layer model",
+                                        "value": round(nb5 * n / bf[a.mode if a.mode in bf else "delta"], 1), "unit": "node-pairs/s",
+                                        **{f"{m}_ms_per_step": round(bf[m] * 1e3, 4) for m in bf}},
+                "note": "step = loop-invariant baseline of the mode + the probes, device-resident (as workload_2 .. 4)"}
+            del out5
+            base.refresh()
         # standalone SpMM (lt_spmm_csr_f32) on this graph (cache-resident) and on the R-MAT graph of configs[4]
         def time_spmm(g_, s_, reps=20):
             for _ in range(3):
@@ -1112,7 +1140,7 @@ def main():
         ncpu = os.cpu_count() or 1
         best = (None, 1e30)
         calib = {}
-        for th in sorted({t for t in (1, 8, 16, 32, 64) if t <= ncpu}):
+        for th in sorted({t for t in (1, 8, 16, 32, 64, ncpu) if t <= ncpu}):      # (ncpu: BASELINE.md section 3's set_num_threads(os.cpu_count()))
             torch.set_num_threads(th)
             tc = time.perf_counter()
             O.influence_matrix(xt, adj_t, P, test_nodes, delta, probe_range=range(0, 1))
@@ -1136,7 +1164,13 @@ def main():
                          f"reference op sequence incl. per-probe baseline forward and per-pair .item(), {el:.1f} s",
                "host_cores": ncpu, "cpu_model": cpu_model(),
                "single_thread": {"value": round(a.n_test / calib[1], 1), "unit": "node-pairs/s", "cores": 1,
-                                 "sample": f"1 probe x {a.n_test} observed nodes, {calib[1]:.2f} s"}}
+                                 "sample": f"1 probe x {a.n_test} observed nodes, {calib[1]:.2f} s"},
+               "all_cores": {"value": round(a.n_test / calib[ncpu], 1), "unit": "node-pairs/s", "cores": ncpu,
+                             "sample": f"1 probe x {a.n_test} observed nodes at torch.set_num_threads(os.cpu_count()) as BASELINE.md section 3 "
+                                       f"words it, {calib[ncpu]:.2f} s"},
+               "threads_tried": {str(k_): round(a.n_test / v_, 1) for k_, v_ in sorted(calib.items())},
+               "cores_note": "`value` is the sample at the FASTEST thread count of the calibration (tiny ops do not scale to hundreds of host "
+                             "cores); the all-cores and single-thread figures stand next to it"}
         # ---- parity gate: the same reference path evaluated in fp64 on the first rows of the sample (untimed) ----
         kq = min(done, 8)
         P64 = {k_: v.double() for k_, v in P.items()}

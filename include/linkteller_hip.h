@@ -107,6 +107,8 @@ int lt_device_count(int *count);
  *                         they do and the matrix has at least "feature_ring_min_rows" rows.  fp64 summation order only (as with
  *                         the "feature_delta" knob); a probe chunk's record blocks then ride in the pre-activation's launch
  *   "feature_ring_min_rows"   see "feature_ring" (default 1024, >= 2)
+ *   "xf64_blocks"         aggregate-first route: blocks per XCD that walk the compacted work items of the rows a call reaches (default 96;
+ *                         1 .. 4096).  Bit-identical
  *   "feature_flags"       feature-difference route, one wave per row: 1 = a row's differing columns are found as flag bits (plain VALU)
  *                         and listed level by level, 0 = by a ballot per value as in round 5 (default: the two measure alike and
  *                         this one keeps round 5's bits).  Changes the order of a row's list: fp64 summation order only

@@ -172,6 +172,9 @@ struct lt_tuning {
                                  // (k_delta_probe_block), 0 the item kernels (LT_DELTA_FUSED)
     int records_early;           // DELTA fused route: 1 the first chunk's record blocks ride in the product rows' launch when it runs (default),
                                  // 0 in the pre-activation's launch as in round 4 (LT_RECORDS_EARLY)
+    int xf64_blocks;             // aggregate-first gathers (k_rows_tiled_xf64): blocks per XCD that walk the compacted work items (default 96:
+                                 // more gathers in flight than the L2s hold windows for cost more than idle CUs; tuned on BASELINE
+                                 // configs[4], profiles/r05_xf64_sweep.txt) (LT_XF64_BLOCKS)
     int feature_ring;            // feature-difference route: the persistent LDS-ring form of the rows kernel (lt_feature_ring.hip.h): 0 never
                                  // (default: it measured 25.6 us against 22.0 at twitch size, profiles/r06_ring_lab.txt), 1 whenever the shapes
                                  // allow, -1 when they do and there are >= feature_ring_min_rows rows (LT_FEATURE_RING)

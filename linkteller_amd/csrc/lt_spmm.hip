@@ -391,7 +391,7 @@ int lt_launch_rows_tiled_xf64(const lt_graph *g, const float *X, int64_t ldx, in
     // (how many blocks walk the list at once matters -- more gathers in flight than the L2s hold windows for cost more than idle
     // CUs do.  BASELINE configs[4], 190 K marked items, per call incl. the rest of the baseline and the 0.76 ms of the probes:
     // 32 blocks per XCD 4.43 ms, 48: 3.66, 64: 3.07, 96: 3.00, 128: 3.18, 512: 3.33; profiles/r05_xf64_sweep.txt)
-    static const long cap = [] { const char *e = getenv("LT_XF64_BLOCKS"); const long v = e ? atol(e) : 0; return v > 0 ? v : 96L; }();
+    const long cap = lt_tune().xf64_blocks;           // ("xf64_blocks", LT_XF64_BLOCKS: 96 per XCD)
     if (grid > 8 * cap) grid = 8 * cap;
     hipLaunchKernelGGL(k_rows_tiled_xf64, dim3((unsigned)grid), dim3(LT_BLOCK), 0, st, zitems, zicount, g->w_e0, g->w_cnt, g->w_dst,
                        g->n, g->col, g->val, X, (long)ldx, ncols, out, (long)ldo, seg_out, (long)ld_seg, ns, g->cv);
@@ -442,9 +442,10 @@ int lt_launch_rows_tiled(const lt_graph *g, const float *S, int64_t lds, int nco
     const long grid = 8 * ((chunks + xps - 1) / xps);
     LT_REQUIRE(grid < 2147483647L, "tiled SpMM: grid limit");
     const bool big = lt_tune().tiled_big != 0 || (unsigned long long)g->n * (unsigned long long)lds * 4ull >= (1ull << 32);
-    // LT_TILED_LDS (experiment hook): dynamic LDS nobody uses, to cap the blocks a CU holds at once (40 KB: 4, 53 KB: 3) -- does the
-    // SpMM, like the aggregate-first gathers, run better with fewer gathers in flight than the chip can hold?
-    static const unsigned occ_lds = [] { const char *e = getenv("LT_TILED_LDS"); const long v = e ? atol(e) : 0; return (unsigned)(v > 0 && v <= 65536 ? v : 0); }();
+    // (round 5 capped the blocks a CU holds with unused dynamic LDS -- "do fewer gathers in flight help here as they do the
+    // aggregate-first gathers?" -- 6 / 5 / 4 / 3 / 2 blocks per CU: 8.41 / 8.59 / 8.59 / 8.66 / 9.66 ms against 8.36: no, and the
+    // hook left the production launch in round 6; profiles/r05_tiled_occupancy.txt)
+    const unsigned occ_lds = 0u;
     if (big)
         hipLaunchKernelGGL(k_rows_tiled<true>, dim3((unsigned)grid), dim3(LT_BLOCK), occ_lds, st, g->w_n, g->w_e0, g->w_cnt, g->w_dst,
                            g->n, g->col, g->val, S, (long)lds, ncols, init, bias_after, relu, out, (long)ldo, seg_out,

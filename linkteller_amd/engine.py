@@ -331,7 +331,8 @@ class WideBaseline:
     order (include/linkteller_hip.h).  All three modes: `sparse` (= `full`: per slice the fp32 finite difference of the
     slice's own forward, exact zeros outside the 2-hop set) and `delta` (the exact propagation, fp64 kink test per slice).
     ~5 launches per (s, t) per matrix, independent of the number of probes (round 3 looped ~5 launches per PROBE and had
-    no `delta`).  Cost model: every (s, t) baseline forms its own X W1[:, s] -- the general route, not the fast one."""
+    no `delta`).  The fp32 product X W1[:, s] is formed once per hidden slice and shared by its class slices (round 6); the
+    fp64 parts of `delta` are per (s, t)."""
 
     supports_sharding = False       # dist.choose_baseline_sharding: replicated on every rank, no timing loop
     VEC_BUDGET_BYTES = 256 << 20    # difference vectors of one probe chunk, all hidden slices together
@@ -366,6 +367,29 @@ class WideBaseline:
                          self.w2[s0:s1, t0:t1].contiguous(), self.b2[t0:t1].contiguous())
                 subs[(si, ti)] = (Baseline(self.graph, self.x, *parts), parts)
         self._subs = subs
+        # ONE product X W1[:, s] per hidden slice, shared by the slice's class slices (a 121-class model has 16 of them): every
+        # (s, t) baseline reads S1 from the slice's torch-owned storage (lt_baseline_attach_s1), the first class slice's
+        # baseline forms it there (lt_baseline_refresh_rows over all rows), the others are told it is current
+        self._s1 = {}
+        for si, (s0, s1) in enumerate(self.h_slices):
+            hp = (s1 - s0 + 3) // 4 * 4
+            t = torch.zeros((self.n, hp), dtype=torch.float32, device=self.x.device)
+            self._s1[si] = t
+            for ti in range(len(self.c_slices)):
+                sub = subs[(si, ti)][0]
+                # (marked current first: attaching copies the baseline's own S1 over, and none has been formed yet)
+                _lib.check(_lib.lib().lt_baseline_refresh_rows(sub._h, 0, 0, t.data_ptr(), _stream()), "lt_baseline_refresh_rows")
+                _lib.check(_lib.lib().lt_baseline_attach_s1(sub._h, t.data_ptr(), hp, _stream()), "lt_baseline_attach_s1")
+                sub._s1_full = t
+        self._share_products()
+
+    def _share_products(self):
+        for si in range(len(self.h_slices)):
+            t = self._s1[si]
+            for ti in range(len(self.c_slices)):
+                sub = self._subs[(si, ti)][0]
+                _lib.check(_lib.lib().lt_baseline_refresh_rows(sub._h, 0, self.n if ti == 0 else 0, t.data_ptr(), _stream()),
+                           "lt_baseline_refresh_rows")
 
     def refresh(self, mode=None):
         """The borrowed inputs changed: the slices are re-cut from them, everything derived is recomputed on next use."""
@@ -376,7 +400,7 @@ class WideBaseline:
             (s0, s1), (t0, t1) = self.h_slices[si], self.c_slices[ti]
             w1s.copy_(self.w1[:, s0:s1]); b1s.copy_(self.b1[s0:s1])
             w2s.copy_(self.w2[s0:s1, t0:t1]); b2s.copy_(self.b2[t0:t1])
-            sub.refresh("sparse" if mode == "full" else mode)
+        self._share_products()          # (marks every slice's layers and fp64 parts stale as lt_baseline_refresh does)
 
     def shard_refresh(self, enable=True):
         return self

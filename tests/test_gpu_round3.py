@@ -536,6 +536,13 @@ def test_full_mode_on_a_hub_of_many_segments(gpu, long_par, p):
         assert o <= max(4.0 * t, 5.0 * rms_t), (i, o, t, rms_t)
     assert rms_o <= 2.0 * rms_t, (rms_o, rms_t)
     assert ours.max() <= 2.0 * theirs.max(), (ours.max(), theirs.max())
+    #  why 2x and not BASELINE.md's 1x here: the golden ref32 is ONE draw of the reference's own noise (this case's
+    # figure moves by 1.45x between two hosts for the reference itself), so 2x is the noise-class ceiling of conftest.noise_gate;
+    # the MEASURED ratios are recorded per (p, long_par) and gated at +10 % like every other fp32 case -- a drift from 1.3x
+    # towards 2x fails here first.  (Every summation order is fixed: the ratios reproduce to the last digit on every box.)
+    from conftest import noise_gate
+    noise_gate(f"hub_row.p{p}.lp{long_par}.rms", rms_o / rms_t)
+    noise_gate(f"hub_row.p{p}.lp{long_par}.max", ours.max() / theirs.max())
 
 
 @pytest.mark.gpu

@@ -320,3 +320,73 @@ def test_hub_rows_shared_between_ranks_keep_every_bit(gpu, tmp_path, world):
     out = tmp_path / f"hub{world}.npy"
     _run_ranks(code, world, {"LT_TEST_OUT": str(out), "LT_AGGREGATE_FIRST": "1", "LT_HUB_ROW_MIN_ENTRIES": "40", "LT_SHARD_PROBES": "1"})
     assert np.array_equal(np.load(out), single)
+
+
+def test_rmat_scale21_config5_per_rank_shape(gpu):
+    """BASELINE configs[4] at FULL size in the default set (the 150-s `slow` test was the only one at 2 M nodes):
+    R-MAT scale 21 (2 097 152 nodes, nnz(A_hat) ~ 77 M, a hub row of > 10^5 entries), F = H = 256, the per-rank shape of the
+    config (512 probes x 4096 observed, the three biggest hubs on both sides) in `delta` and `sparse`: 4 probe rows (the biggest
+    hub, a mid-degree probe, two random ones) against oracle.RestrictedOracle (pinned to the verbatim op sequence by
+    tests/test_oracle_golden.py), exact zeros off the 2-hop set, the two modes within the fp32 difference's noise of each other,
+    and the hub rows shared between ranks (dist.SharedHubRows' three calls) keeping every bit.  The verbatim-oracle rows stay
+    in the `slow` variant (tests/test_gpu_round2.py)."""
+    import time
+    import scipy.sparse as sp
+    from linkteller_amd import dist as lt_dist, engine, graph, synth
+    from oracle import linkteller_oracle as O
+    t0 = time.time()
+    adj = synth.rmat_graph(21, synth.rmat_draws(21), seed=42)
+    a_hat = graph.first_order_gcn(adj)
+    n = adj.shape[0]
+    deg = np.diff(a_hat.indptr)
+    assert n == 1 << 21 and a_hat.nnz > 70_000_000 and deg.max() > 50_000
+    x_np = synth.gaussian_features(n, 256, seed=1)
+    w = synth.gcn_weights(256, 256, 2, seed=42)
+    x = torch.from_numpy(x_np).to(gpu)
+    base = engine.Baseline(graph.HipGraph(a_hat), x, *_params(w, gpu))
+    t_build = time.time() - t0
+    rng = np.random.RandomState(3)
+    hubs = np.argsort(-deg)[:3].astype(np.int64)
+    rest = rng.choice(np.setdiff1d(np.arange(n), hubs), 4096 - len(hubs), replace=False)
+    observe = np.concatenate([hubs, rest])
+    probes = observe[:512]
+    t0 = time.time()
+    delta = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy()
+    assert base.fp64_route() == 2                                   # the on-demand route: what this size takes
+    sparse = base.influence_rows(probes, observe, 1e-4, "sparse").cpu().numpy()
+    t_gpu = time.time() - t0
+    assert np.isfinite(delta).all() and np.isfinite(sparse).all()
+    # exact zeros off the 2-hop set, both modes (the mask: pattern product restricted to the probes' columns and the observed rows)
+    pat = sp.csr_matrix((np.ones(a_hat.nnz, np.float32), a_hat.indices, a_hat.indptr), shape=a_hat.shape)
+    r1 = pat.T.tocsr()[probes]
+    mask = np.asarray((r1 @ pat[observe].T.tocsc()).todense()) > 0
+    assert np.all(delta[~mask] == 0) and np.all(sparse[~mask] == 0)
+    assert (delta[mask] > 0).mean() > 0.9
+    assert np.abs(sparse - delta).max() <= 0.05 * delta.max()
+    # the fp64 oracle on 4 rows
+    pdeg = deg[probes]
+    rows = np.unique(np.concatenate([[0, int(np.argsort(pdeg)[len(pdeg) // 2])], rng.choice(512, 2, replace=False)]))
+    t0 = time.time()
+    ro = O.RestrictedOracle(x_np, a_hat, w)
+    ref_rows = ro.rows(probes[rows], observe, 1e-4)
+    t_oracle = time.time() - t0
+    for k, i in enumerate(rows):
+        ref64 = ref_rows[k]
+        assert np.abs(delta[i] - ref64).max() <= 1e-5 * max(ref64.max(), 1e-3), (int(i), int(probes[i]))
+        assert np.all(delta[i][ref64 == 0] == 0) and np.all(sparse[i][ref64 == 0] == 0) and np.all(mask[i][ref64 > 0])
+    del ro
+    # the hub rows every rank's probes reach, split over 8 ranks: this GPU forms one share, adopts the rest -- same bits
+    t0 = time.time()
+    rows_all = base.reached_rows(observe, lt_dist.HUB_ROW_MIN_ENTRIES)
+    nh = rows_all.numel()
+    assert nh > 1000 and bool((torch.from_numpy(deg).to(gpu)[rows_all.long()] >= lt_dist.HUB_ROW_MIN_ENTRIES).all())
+    buf = torch.empty((nh, 256), dtype=torch.float64, device=gpu)
+    base.refresh("delta"); base.form_rows_fp64(rows_all); base.gather_rows_fp64(rows_all, buf)
+    per8 = (nh + 7) // 8
+    base.refresh("delta")
+    base.form_rows_fp64(rows_all[3 * per8:4 * per8].contiguous())      # (rank 3's share)
+    base.scatter_rows_fp64(rows_all, buf)
+    shared = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy()
+    assert np.array_equal(shared, delta)
+    print(f"scale 21: build {t_build:.1f} s, delta + sparse {t_gpu:.2f} s, restricted oracle on rows {rows.tolist()} {t_oracle:.1f} s, "
+          f"{nh} shared hub rows {time.time() - t0:.2f} s")
