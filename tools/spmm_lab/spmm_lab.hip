@@ -91,14 +91,17 @@ __global__ __launch_bounds__(256) void k_spmm_sliced(
     const int32_t *__restrict__ w_dst, const int32_t *__restrict__ rowptr, int n,
     const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ S, int lds, int ncols, float *__restrict__ out, int ldo,
-    float *__restrict__ partial, int ldp, int ns /* slices */) {
+    float *__restrict__ partial, int ldp, int ns /* slices */, int slice_fixed = -1) {
     constexpr int GPW = 64 / GL;            // groups per wave
     constexpr int IPB = 4 * GPW;            // items per block
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int j = lane & (GL - 1);
     int slice, chunk;
-    if (SEQ) {
+    if (slice_fixed >= 0) {                 // (round 6: one launch per slice -- the slices strictly one after the other)
+        slice = slice_fixed;
+        chunk = blockIdx.x;
+    } else if (SEQ) {
         const int bps = gridDim.x / ns;     // blocks per slice
         slice = blockIdx.x / bps;
         chunk = blockIdx.x % bps;
@@ -578,6 +581,25 @@ static void run_sliced(Ctx &c, hipStream_t st) {
 }
 
 
+// TEMPORAL slicing (round 6): the column slices one after the other with ALL XCDs on the same slice, so that a
+// pass's gather working set (n x 256 B = 537 MB at scale 21, n x 128 B = 268 MB) sits in front of the 256 MiB Infinity Cache
+// instead of all slices' at once; the index stream is re-read per pass.  One launch per slice (strictly sequential).
+template <int GL, int U, int ORDER = 2>
+static void run_temporal(Ctx &c, hipStream_t st) {
+    Work &W = ORDER == 2 ? c.work_half : (ORDER ? c.work_col : c.work);
+    const int ns = (c.H + 4 * GL - 1) / (4 * GL);
+    constexpr int IPB = 4 * (64 / GL);
+    const int chunks = (W.n_items + IPB - 1) / IPB;
+    for (int sl = 0; sl < ns; ++sl)
+        hipLaunchKernelGGL((k_spmm_sliced<GL, U, true, true, 0, false, true>), dim3(chunks), dim3(256), 0, st, W.n_items, W.e0, W.cnt,
+                           W.dst, c.rowptr, c.g->n, c.col, c.val, c.S, c.H, c.H, c.out, c.H, W.partial, c.H, ns, sl);
+    if (W.n_long > 0) {
+        const int tot = W.n_long * c.H;
+        hipLaunchKernelGGL(k_combine, dim3((tot + 255) / 256), dim3(256), 0, st, W.n_long, W.long_row, W.long_segptr, W.partial, c.H,
+                           c.H, c.out, c.H);
+    }
+}
+
 template <int U, int ORDER = 2>
 static void run_sliced8(Ctx &c, hipStream_t st) {
     Work &W = ORDER == 2 ? c.work_half : (ORDER ? c.work_col : c.work);
@@ -695,6 +717,11 @@ int main(int argc, char **argv) {
         {"g8_half_pf", run_sliced<8, 8, true, true, 0, false, 0, 2, true>},
         {"g8_col_pf", run_sliced<8, 8, true, true, 0, false, 0, 1, true>},
         {"g32_half_pf", run_sliced<32, 8, true, true, 0, false, 0, 2, true>},
+        {"seq4_half_pf", run_sliced<16, 8, true, true, 0, true, 0, 2, true>},      // one launch, blocks in slice order (4 x 256 B)
+        {"seq8_half_pf", run_sliced<8, 8, true, true, 0, true, 0, 2, true>},       // (8 x 128 B)
+        {"t4_half_pf", run_temporal<16, 8, 2>},                                    // one launch per slice: 4 passes of 256 B
+        {"t8_half_pf", run_temporal<8, 8, 2>},                                     // 8 passes of 128 B
+        {"t2_half_pf", run_temporal<32, 8, 2>},                                    // 2 passes of 512 B
         {"w8_half_u8", run_sliced8<8, 2>},
         {"w8_half_u16", run_sliced8<16, 2>},
         {"w8_col_u8", run_sliced8<8, 1>},
