@@ -107,11 +107,13 @@ int lt_device_count(int *count);
  *                         they do and the matrix has at least "feature_ring_min_rows" rows.  fp64 summation order only (as with
  *                         the "feature_delta" knob); a probe chunk's record blocks then ride in the pre-activation's launch
  *   "feature_ring_min_rows"   see "feature_ring" (default 1024, >= 2)
+ *   "feature_stagger"     feature-difference route, one wave per row: the row blocks start in (value & 255) groups, (value >> 8) x 10 ns
+ *                         apart, so that a group walks its lists while the next one's rows arrive; 0 = all together.  Bit-identical
  *   "xf64_blocks"         aggregate-first route: blocks per XCD that walk the compacted work items of the rows a call reaches (default 96;
  *                         1 .. 4096).  Bit-identical
  *   "feature_flags"       feature-difference route, one wave per row: 1 = a row's differing columns are found as flag bits (plain VALU)
- *                         and listed level by level, 0 = by a ballot per value as in round 5 (default: the two measure alike and
- *                         this one keeps round 5's bits).  Changes the order of a row's list: fp64 summation order only
+ *                         and listed level by level (default: the kernel is bound by the issue of its compare steps), 0 = by a
+ *                         ballot per value as in round 5.  Changes the order of a row's list: fp64 summation order only
  *   "defer_cref"          feature-difference route: 1 = the reference vector's product m W1 is formed by extra blocks of the rows'
  *                         launch and added by the readers of S1d (the fp64 SpMM, stage A) (default), 0 = formed first and added
  *                         by the rows kernel.  fp64 summation order only, like "feature_delta"

@@ -57,7 +57,8 @@ static lt_tuning tuning_defaults() {
     t.delta_fused = env_ll("LT_DELTA_FUSED", 1) != 0 ? 1 : 0;
     t.records_early = env_ll("LT_RECORDS_EARLY", 1) != 0 ? 1 : 0;
     t.feature_ring = env_ll("LT_FEATURE_RING", 0) != 0 ? (env_ll("LT_FEATURE_RING", 0) < 0 ? -1 : 1) : 0;
-    t.feature_flags = env_ll("LT_FEATURE_FLAGS", 0) != 0 ? 1 : 0;
+    t.feature_flags = env_ll("LT_FEATURE_FLAGS", 1) != 0 ? 1 : 0;
+    t.feature_stagger = (int)env_ll("LT_FEATURE_STAGGER", 0);
     const long long xb = env_ll("LT_XF64_BLOCKS", 96);
     t.xf64_blocks = xb > 0 && xb <= 4096 ? (int)xb : 96;
     const long long frm = env_ll("LT_FEATURE_RING_MIN_ROWS", 1024);
@@ -104,6 +105,10 @@ extern "C" int lt_set_tuning(const char *key, long long value) {
     else if (!strcmp(key, "feature_delta")) t.feature_delta = reset ? d.feature_delta : (value < 0 ? -1 : (value != 0));
     else if (!strcmp(key, "feature_ring")) t.feature_ring = reset ? d.feature_ring : (value < 0 ? -1 : (value != 0));
     else if (!strcmp(key, "feature_flags")) t.feature_flags = reset ? d.feature_flags : (value != 0);
+    else if (!strcmp(key, "feature_stagger")) {
+        LT_REQUIRE(reset || (value >= 0 && value < (1 << 24)), "lt_set_tuning: feature_stagger out of range");
+        t.feature_stagger = reset ? d.feature_stagger : (int)value;
+    }
     else if (!strcmp(key, "xf64_blocks")) {
         LT_REQUIRE(reset || (value >= 1 && value <= 4096), "lt_set_tuning: xf64_blocks must be in [1, 4096]");
         t.xf64_blocks = reset ? d.xf64_blocks : (int)value;

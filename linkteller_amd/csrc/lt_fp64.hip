@@ -656,7 +656,7 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     const float *__restrict__ W1, const double *__restrict__ cref, double *__restrict__ S1d, int hint_cap,
     int *__restrict__ dense_hint, int nslab, double *__restrict__ slabs, int32_t *__restrict__ zstate,
     float *__restrict__ S1x, unsigned *__restrict__ gate, double *__restrict__ cref_out, double *__restrict__ S1qs,
-    const lt_bits_job job = lt_bits_job{}, const int job_first = 0, const int flag_bits = 0) {
+    const lt_bits_job job = lt_bits_job{}, const int job_first = 0, const int flag_bits = 0, const int stagger = 0) {
     // job.nblocks > 0 (round 5): the blocks from job_first on -- BEHIND the rows in dispatch order, into the CU slots the rows leave
     // free -- are a probe chunk's record blocks or item-table blocks (lt_items.hip.h: nothing in them reads a layer).  They used to ride
     // in the launch that forms the pre-activation and cost it 1.5 us; this launch is seven times longer and bound by the pass over X.
@@ -673,6 +673,16 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
     if ((int)blockIdx.x < nslab) {
         fd_slab_block(fd_smem, nslab, F, H, Hp, ref, W1, slabs, gate, cref_out);
         return;
+    }
+    // stagger (round 6): the row blocks start in `stagger & 255` groups, group k (blocks in launch order) `stagger >> 8` ticks of the
+    // 100 MHz clock after group k - 1.  Every row of the launch is one generation of waves: started together, their rows all land
+    // at the end of the pass over X and the list walks of ALL rows (20 W1 rows per row of X: 1.6 x the bytes of X through the
+    // L1s) queue behind it; started in groups, group k walks while group k + 1's rows are still arriving.
+    if ((stagger & 255) > 1) {
+        const int nrb = (int)gridDim.x - nslab - (job.nblocks > 0 ? job.nblocks : 0);
+        const int grp = (int)(((long)((int)blockIdx.x - nslab) * (stagger & 255)) / (nrb > 0 ? nrb : 1));
+        const unsigned long long until = wall_clock64() + (unsigned long long)grp * (unsigned)(stagger >> 8);
+        while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
     }
     FD_STAMP(0);
     float *sref = reinterpret_cast<float *>(fd_smem);                              // [Fp] the reference vector
@@ -1383,7 +1393,7 @@ static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, b
 #define LT_FD_LAUNCH(V_, O_)                                                                                                  \
     hipLaunchKernelGGL((k_s1d_feature_rows<V_, O_>), dim3(blocks), dim3(64 * FD_WAVES), smem, st, n, F, H, Hp, b->X, (long)b->ldx, \
                        b->fd_ref, b->W1, cref, b->S1d, fd_hint_cap(F), b->fd_hint_dev, nslab, b->fd_slabs, zstate, s1x,           \
-                       defer ? (unsigned *)b->fd_gate : (unsigned *)nullptr, b->fd_cref, b->S1qs, jb, job_first, lt_tune().feature_flags)
+                       defer ? (unsigned *)b->fd_gate : (unsigned *)nullptr, b->fd_cref, b->S1qs, jb, job_first, lt_tune().feature_flags, lt_tune().feature_stagger)
     if (vec2 && one) LT_FD_LAUNCH(2, true);
     else if (vec2) LT_FD_LAUNCH(2, false);
     else if (one) LT_FD_LAUNCH(1, true);

@@ -178,8 +178,11 @@ struct lt_tuning {
     int feature_ring;            // feature-difference route: the persistent LDS-ring form of the rows kernel (lt_feature_ring.hip.h): 0 never
                                  // (default: it measured 25.6 us against 22.0 at twitch size, profiles/r06_ring_lab.txt), 1 whenever the shapes
                                  // allow, -1 when they do and there are >= feature_ring_min_rows rows (LT_FEATURE_RING)
-    int feature_flags;           // the row-per-wave kernel lists a row's differing columns from flag bits (1) or by a ballot per value (0, default:
-                                 // 22.4 against 22.5 us, and the ballot form keeps round 5's bits) (LT_FEATURE_FLAGS)
+    int feature_flags;           // the row-per-wave kernel lists a row's differing columns from flag bits (1, default: the kernel is bound by
+                                 // the issue of its 52 compare steps -- 24.8 against 25.4 us by events, profiles/r06_feat_lab_timeline.txt) or by
+                                 // a ballot per value (0: round 5's list order) (LT_FEATURE_FLAGS)
+    int feature_stagger;         // the row-per-wave kernel's blocks start in (value & 255) groups, (value >> 8) ticks of 10 ns apart; 0 = together
+                                 // (LT_FEATURE_STAGGER)
     int feature_ring_min_rows;   // (LT_FEATURE_RING_MIN_ROWS, default 1024: below it the CUs' waves have no row each)
     int profile_every;           // lt_profile_enable: bracket every N-th scope of an enabled class with events (1 = all; an event pair
                                  // costs ~5 us of stream time, so a timed region samples)

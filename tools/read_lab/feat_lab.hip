@@ -11,6 +11,7 @@
 #include <random>
 #include <vector>
 
+static int g_flags = 0, g_stagger = 0;
 template <int VEC>
 static void run(int n, int F, int H, const float *X, const float *ref, const float *W1, double *S1d, int *hint, double *slabs, int *zstate,
                 float *S1x, unsigned *gate, double *cref, double *S1qs, unsigned long long *trace, const char *name) {
@@ -26,7 +27,7 @@ static void run(int n, int F, int H, const float *X, const float *ref, const flo
         hipDeviceSynchronize();
         hipEventRecord(e0, 0);
         hipLaunchKernelGGL((k_s1d_feature_rows<VEC, true>), dim3(blocks), dim3(64 * FD_WAVES), smem, 0, n, F, H, H, X, (long)F, ref, W1,
-                           (const double *)nullptr, S1d, fd_hint_cap(F), hint, nslab, slabs, zstate, S1x, gate, cref, S1qs);
+                           (const double *)nullptr, S1d, fd_hint_cap(F), hint, nslab, slabs, zstate, S1x, gate, cref, S1qs, lt_bits_job{}, 0, g_flags, g_stagger);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms;
@@ -45,6 +46,24 @@ static void run(int n, int F, int H, const float *X, const float *ref, const flo
             for (int k = 0; k < 7; ++k) ph[k].push_back((h[w * 8 + k] - t0) * 0.01);
         }
         std::printf("%s: event time %.1f us; first row-wave entry -> last row stored %.1f us; %zu row waves\n", name, ms * 1e3, (t1 - t0) * 0.01, ph[0].size());
+        if ((g_stagger & 255) > 1) {       // per start group: when its waves enter, and how long a wave takes from entry to its store
+            const int G = g_stagger & 255;
+            const size_t nrb = blocks - nslab;
+            for (int gq = 0; gq < G; ++gq) {
+                std::vector<double> en, du;
+                for (size_t w = (size_t)nslab * FD_WAVES; w < nw; ++w) {
+                    if (!h[w * 8] || !h[w * 8 + 6]) continue;
+                    const size_t bk = w / FD_WAVES - nslab;
+                    if ((int)(bk * G / nrb) != gq) continue;
+                    en.push_back((h[w * 8] - t0) * 0.01);
+                    du.push_back((h[w * 8 + 6] - h[w * 8]) * 0.01);
+                }
+                std::sort(en.begin(), en.end()); std::sort(du.begin(), du.end());
+                if (!en.empty())
+                    std::printf("   group %d: entry p50 %.1f us; entry -> stored per wave p10 %.1f p50 %.1f p90 %.1f max %.1f us\n", gq, en[en.size() / 2],
+                                du[du.size() / 10], du[du.size() / 2], du[9 * du.size() / 10], du.back());
+            }
+        }
         const char *nm[7] = {"entry", "ref staged (barrier)", "compare step 0 done", "compare step UN/2 done", "last compare step done",
                              "list walked", "row stored"};
         for (int k = 0; k < 7; ++k) {
@@ -68,6 +87,8 @@ static void run(int n, int F, int H, const float *X, const float *ref, const flo
 
 int main(int argc, char **argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 4385, F = argc > 2 ? atoi(argv[2]) : 3170, H = argc > 3 ? atoi(argv[3]) : 256;
+    g_flags = argc > 4 ? atoi(argv[4]) : 0;
+    g_stagger = argc > 5 ? atoi(argv[5]) : 0;      // (gap in 10-ns ticks) << 8 | groups
     std::mt19937 rng(1);
     std::uniform_real_distribution<float> U(0.f, 1.f);
     std::vector<float> hx((size_t)n * F), href((size_t)F + FD_REF_PAD, 0.f), hw((size_t)F * H);

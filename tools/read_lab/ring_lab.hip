@@ -20,13 +20,13 @@ struct Bufs {
     unsigned *gate;
 };
 
-static int g_flags = 0;
+static int g_flags = 0, g_stagger = 0;
 static void launch_old(int n, int F, int H, const Bufs &b, bool defer) {
     const int nslab = defer ? (F + 63) / 64 : 0;
     const unsigned blocks = (unsigned)((n + FD_WAVES - 1) / FD_WAVES + nslab);
     hipLaunchKernelGGL((k_s1d_feature_rows<2, true>), dim3(blocks), dim3(64 * FD_WAVES), fd_smem_bytes(F), 0, n, F, H, H, b.X, (long)F, b.ref, b.W1,
                        defer ? (const double *)nullptr : b.cref, b.S1d, fd_hint_cap(F), b.hint, nslab, b.slabs, b.zstate, defer ? b.S1x : (float *)nullptr,
-                       defer ? b.gate : (unsigned *)nullptr, b.cref, b.S1qs, lt_bits_job{}, 0, g_flags);
+                       defer ? b.gate : (unsigned *)nullptr, b.cref, b.S1qs, lt_bits_job{}, 0, g_flags, g_stagger);
 }
 static int g_cus = 256;
 static int g_nsl = 0;
@@ -237,6 +237,19 @@ int main(int argc, char **argv) {
         cmp("rows kernel: flag bits - ballots", a1, a0);
         time_it("k_s1d_feature_rows<2> flag bits (deferred)", [&] { launch_old(n, F, H, b, true); });
         g_flags = 0;
+    }
+    {   // staggered start of the row blocks: groups x gap (us)
+        std::vector<double> a0, a1;
+        g_stagger = 0; launch_old(n, F, H, b, true); fetch(true, a0);
+        for (int groups : {2, 3, 4, 6, 8})
+            for (int gap_us10 : {10, 15, 20, 30, 40, 60}) {      // 0.1 us units
+                g_stagger = (gap_us10 * 10) << 8 | groups;
+                launch_old(n, F, H, b, true); fetch(true, a1);
+                char nm[96];
+                snprintf(nm, sizeof nm, "rows<2> stagger %d groups x %.1f us%s", groups, gap_us10 * 0.1, a1 == a0 ? "" : "  BITS DIFFER");
+                time_it(nm, [&] { launch_old(n, F, H, b, true); });
+            }
+        g_stagger = 0;
     }
     time_it("k_s1d_feature_ring    (deferred, fixed point)", [&] { launch_ring(n, F, H, b, true); });
     time_it("k_s1d_feature_rows<2> (cref in the rows, fp64)", [&] { launch_old(n, F, H, b, false); });
