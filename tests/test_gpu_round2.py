@@ -191,9 +191,11 @@ def _run_ranks(code, world, extra_env=None, timeout=900):
     port = _free_port()
     procs = []
     for r in range(world):
+        # (LT_SHARD_PROBES=1 unless the caller says otherwise: these tests are about the sharded path; under the default `auto` ranks
+        # that share ONE device would find the local build faster -- tests/test_gpu_round6.py covers the policy)
         env = dict(os.environ, PYTHONPATH=REPO + ":" + os.path.join(REPO, "tests"), RANK=str(r), WORLD_SIZE=str(world),
                    LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LT_DIST_BACKEND="gloo",
-                   LT_DIST_DEVICE="0", **(extra_env or {}))
+                   LT_DIST_DEVICE="0", **{"LT_SHARD_PROBES": "1", **(extra_env or {})})
         procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []

@@ -82,7 +82,7 @@ def test_bench_two_ranks_through_its_own_launcher(gpu, tmp_path, mode, extra):
     common = ["--steps", "3", "--warmup", "1", "--blocks", "2", "--no-cpu-baseline", "--no-extras", "--no-pmc", "--mode", mode,
               "--n-test", "120"]
     one = _bench(common, {"LT_BENCH_DUMP": str(tmp_path / "one.npy"), **extra})
-    two = _bench(common + ["--gpus", "2"], {"LT_BENCH_BACKEND": "gloo", "LT_BENCH_DEVICE": "0",
+    two = _bench(common + ["--gpus", "2"], {"LT_BENCH_BACKEND": "gloo", "LT_BENCH_DEVICE": "0", "LT_SHARD_PROBES": "1",
                                             "LT_BENCH_DUMP": str(tmp_path / "two.npy"), **extra})
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
     assert two["config"]["probes_per_rank"] == 60 and two["config"]["collective_bytes_per_step"] >= 120 * 120 * 4
