@@ -45,6 +45,7 @@ if "delta" in modes and bb.fp64_route() == 2:
     bb.refresh("delta"); bb.form_rows_fp64(rows_all); bb.gather_rows_fp64(rows_all, allbuf)
     mine = rows_all[:per8].contiguous()
     send = torch.empty((per8, 256), dtype=torch.float64, device=dev)
+    bb.refresh("delta"); bb.influence_rows(pb, ob, 1e-4, "delta", out=out)
     plain = out.clone()
 
     def hub_step():
