@@ -555,8 +555,13 @@ __device__ unsigned long long *g_fd_trace = nullptr;
 #endif
 #define FD_CAP 384
 #define FD_WAVES 4
+#ifndef FD_PU
 #define FD_PU 6          // W1 rows in flight per lane while a list is walked (FD_CAP is a multiple; 8 costs the fifth wave per SIMD: 110 VGPRs
                          // against 90 -- ~10 per row in flight, address pair + data + index -- and 12 the fourth: 138; round 5 re-measured)
+#endif
+#ifndef FD_MIN_WAVES      // (tools/read_lab/feat_lab builds with 5: its stamps would otherwise cost the kernel its fifth wave per SIMD)
+#define FD_MIN_WAVES 1
+#endif
 #define FD_REF_PAD (16 * 64 * FD_WAVES + 64)   // the staging loop of k_s1d_feature_rows reads the reference vector in whole passes
 #define FD_UN 26         // loads in flight per lane in the row pass (x 128 floats: F <= 3328 is one trip)
 // VEC: floats per lane and load, 2 when the rows of X are 8-byte aligned, else 1.  (Round 4 built VEC = 4 -- 13 loads of 16 bytes,
@@ -651,7 +656,7 @@ __device__ __forceinline__ void fd_slab_block(unsigned char *fd_smem, int nslab,
         return;
     }
 template <int VEC, bool ONE>
-__global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
+__global__ __launch_bounds__(64 * FD_WAVES, FD_MIN_WAVES) void k_s1d_feature_rows(
     int n, int F, int H, int Hp, const float *__restrict__ X, long ldx, const float *__restrict__ ref,
     const float *__restrict__ W1, const double *__restrict__ cref, double *__restrict__ S1d, int hint_cap,
     int *__restrict__ dense_hint, int nslab, double *__restrict__ slabs, int32_t *__restrict__ zstate,
@@ -777,6 +782,8 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
                 for (int k = 0; k < FD_PU; ++k)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) acc[t] = fma(d[k], (double)w[k][t], acc[t]);
+                // (round 6 re-measured the trip depth with __launch_bounds__(256, 5) holding the fifth wave: 6 / 8 / 12 rows in flight,
+                // the differences read when used: 22.6 / 22.4 / 22.5 us -- the walk's trips are not what bounds the launch)
             }
         } else if (own) {
             for (int e = 0; e < padded; ++e) {
@@ -812,6 +819,8 @@ __global__ __launch_bounds__(64 * FD_WAVES) void k_s1d_feature_rows(
                 }
             }
             unsigned long long flags = ((unsigned long long)(fl[2] | fl[3]) << 32) | (unsigned long long)(fl[0] | fl[1]);
+            FD_STAMP(2);
+            FD_STAMP(3);
             {
                 int jq[3];
                 float xq[3], rq[3];

@@ -2,7 +2,7 @@
 // stamps per row wave on the constant 100 MHz clock: entry, reference vector staged, first / middle / last compare step
 // done, list walked, row stored) and runs the twitch-RU shape (4385 x 3170 -> 256) in the production configuration
 // (deferred cref: 50 slab blocks in front, fixed-point rows) a few times.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -Iinclude -Ilinkteller_amd/csrc -c tools/read_lab/feat_lab.hip -o /tmp/feat_lab.o && \
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DFD_MIN_WAVES=5 -Iinclude -Ilinkteller_amd/csrc -c tools/read_lab/feat_lab.hip -o /tmp/feat_lab.o && \
 //   (cd linkteller_amd/csrc && hipcc --offload-arch=gfx950 /tmp/feat_lab.o lt_core.o lt_gemm.o lt_spmm.o lt_forward.o lt_influence.o lt_gcn3.o lt_dp.o -o ../../tools/read_lab/feat_lab)
 #define LT_FD_TRACE
 #include "../../linkteller_amd/csrc/lt_fp64.hip"
@@ -72,6 +72,25 @@ static void run(int n, int F, int H, const float *X, const float *ref, const flo
             const size_t m = v.size();
             std::printf("   %-26s us since the first entry: min %5.1f  p10 %5.1f  p50 %5.1f  p90 %5.1f  max %5.1f\n", nm[k], v[0], v[m / 10], v[m / 2],
                         v[9 * m / 10], v[m - 1]);
+        }
+        {   // the waves that are stored last (the slowest 5 %): where did THEY spend their time
+            std::vector<std::pair<double, size_t>> order;
+            for (size_t i = 0; i < ph[0].size(); ++i) order.push_back({ph[6][i], i});
+            std::sort(order.begin(), order.end());
+            const size_t m = order.size(), k0 = m - m / 20;
+            double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+            for (size_t q = k0; q < m; ++q)
+                for (int k = 0; k < 7; ++k) acc[k] += ph[k][order[q].second];
+            std::printf("   the last 5 %% of the waves (mean, us since the first entry):");
+            for (int k = 0; k < 7; ++k) std::printf("  %s %.1f", nm[k], acc[k] / (m - k0));
+            std::printf("\n");
+            double acc2[7] = {0, 0, 0, 0, 0, 0, 0};
+            const size_t k1 = m / 20;
+            for (size_t q = 0; q < k1; ++q)
+                for (int k = 0; k < 7; ++k) acc2[k] += ph[k][order[q].second];
+            std::printf("   the first 5 %% of the waves:");
+            for (int k = 0; k < 7; ++k) std::printf("  %s %.1f", nm[k], acc2[k] / k1);
+            std::printf("\n");
         }
         // per-wave phase lengths
         const char *pn[6] = {"staging", "-> first data compared", "-> half the row compared", "-> whole row compared", "walk", "convert + store"};
