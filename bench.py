@@ -589,8 +589,7 @@ def main():
             full_ = step(mode, bs)
             drain()
             return engine.export_rows_f64(full_)
-        bs.refresh(mode)
-        return bs.influence_matrix_host(obs if multi else probes, obs, delta, mode)
+        return bs.influence_matrix_host(obs if multi else probes, obs, delta, mode, refresh=True)
 
     def timed_host(mode, steps, warmup, blocks=1, bs=None):
         for _ in range(warmup):

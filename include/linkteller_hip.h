@@ -107,6 +107,16 @@ int lt_device_count(int *count);
  *                         they do and the matrix has at least "feature_ring_min_rows" rows.  fp64 summation order only (as with
  *                         the "feature_delta" knob); a probe chunk's record blocks then ride in the pre-activation's launch
  *   "feature_ring_min_rows"   see "feature_ring" (default 1024, >= 2)
+ *   "export_sparse"       lt_influence_rows_f64 on the fused LT_MODE_DELTA route, calls that find the baseline refreshed: 1 = the first
+ *                         rows of dst are zero-filled by a few waves riding in the launch that forms the fp64 product rows and in the
+ *                         pre-activation's (np.zeros of attacker.py:216 crossing PCIe under those launches) and their probes' blocks
+ *                         write the touched positions only; the other rows are widened whole by their blocks (default), 0 = all rows
+ *                         are.  Bit-identical; so are the four keys below
+ *   "export_zero_share"   per cent of dst's rows zero-filled under the product rows' launch (default 35; 0 .. 100)
+ *   "export_zero_share2"  per cent of dst's rows, the next ones, zero-filled under the pre-activation's launch (default 15; 0 .. 100)
+ *   "export_zero_blocks"  waves that zero-fill in each of the two launches (default 16; 1 .. 4096: more of them, or more stores in
+ *                         flight, and the writes queued for the link hold up the loads of the kernels beside them)
+ *   "export_zero_inflight"   1-KiB stores each such wave keeps in flight (default 4; 1 .. 64)
  *   "feature_stagger"     feature-difference route, one wave per row: the row blocks start in (value & 255) groups, (value >> 8) x 10 ns
  *                         apart, so that a group walks its lists while the next one's rows arrive; 0 = all together.  Bit-identical
  *   "xf64_blocks"         aggregate-first route: blocks per XCD that walk the compacted work items of the rows a call reaches (default 96;
@@ -284,8 +294,11 @@ int lt_export_rows_f64(const float *src, int64_t lds, int32_t rows, int32_t cols
 /* lt_influence_rows and lt_export_rows_f64 in ONE call: out ([n_probe, ldo] fp32, device) is written as by lt_influence_rows, and
  * dst[i * ldd + j] = (double)out[i * ldo + j] -- the reference's influence_val (attacker.py:216, 227-229) -- in device memory or
  * PINNED host memory (as lt_export_rows_f64).  On the fused LT_MODE_DELTA route (graphs with incidence records) every probe's
- * block widens its own finished row into dst, so the rows cross PCIe while the other probes still compute and no export launch
- * follows; every other route ends with the launch lt_export_rows_f64 makes.  Same values as the two calls, bit for bit. */
+ * block writes its own finished row into dst and no export launch follows; when the call also recomputes the baseline (it
+ * follows an lt_baseline_refresh) the first half of dst's rows is zero-filled by a few waves riding in the launches that form
+ * the fp64 product rows and the pre-activation -- np.zeros crossing PCIe under kernels that do not touch the link -- and the
+ * blocks of those rows send their touched positions only (tuning keys "export_sparse", "export_zero_*").  Every other route
+ * ends with the launch lt_export_rows_f64 makes.  Same values as the two calls, bit for bit. */
 int lt_influence_rows_f64(const lt_baseline *b, const int32_t *probe_nodes, int32_t n_probe,
                           const int32_t *observe_nodes, int32_t n_obs, float delta, int32_t mode,
                           float *out, int64_t ldo, double *dst, int64_t ldd, void *workspace, size_t workspace_bytes,

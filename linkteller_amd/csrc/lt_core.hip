@@ -58,6 +58,11 @@ static lt_tuning tuning_defaults() {
     t.records_early = env_ll("LT_RECORDS_EARLY", 1) != 0 ? 1 : 0;
     t.feature_ring = env_ll("LT_FEATURE_RING", 0) != 0 ? (env_ll("LT_FEATURE_RING", 0) < 0 ? -1 : 1) : 0;
     t.feature_flags = env_ll("LT_FEATURE_FLAGS", 1) != 0 ? 1 : 0;
+    t.export_sparse = env_ll("LT_EXPORT_SPARSE", 1) != 0 ? 1 : 0;
+    t.export_zero_blocks = (int)std::min<long long>(4096, std::max<long long>(1, env_ll("LT_EXPORT_ZERO_BLOCKS", 16)));
+    t.export_zero_inflight = (int)std::min<long long>(64, std::max<long long>(1, env_ll("LT_EXPORT_ZERO_INFLIGHT", 4)));
+    t.export_zero_share2 = (int)std::min<long long>(100, std::max<long long>(0, env_ll("LT_EXPORT_ZERO_SHARE2", 15)));
+    t.export_zero_share = (int)std::min<long long>(100, std::max<long long>(0, env_ll("LT_EXPORT_ZERO_SHARE", 35)));
     t.feature_stagger = (int)env_ll("LT_FEATURE_STAGGER", 0);
     const long long xb = env_ll("LT_XF64_BLOCKS", 96);
     t.xf64_blocks = xb > 0 && xb <= 4096 ? (int)xb : 96;
@@ -105,6 +110,11 @@ extern "C" int lt_set_tuning(const char *key, long long value) {
     else if (!strcmp(key, "feature_delta")) t.feature_delta = reset ? d.feature_delta : (value < 0 ? -1 : (value != 0));
     else if (!strcmp(key, "feature_ring")) t.feature_ring = reset ? d.feature_ring : (value < 0 ? -1 : (value != 0));
     else if (!strcmp(key, "feature_flags")) t.feature_flags = reset ? d.feature_flags : (value != 0);
+    else if (!strcmp(key, "export_sparse")) t.export_sparse = reset ? d.export_sparse : (value != 0);
+    else if (!strcmp(key, "export_zero_share2")) t.export_zero_share2 = reset ? d.export_zero_share2 : (int)std::min<long long>(100, std::max<long long>(0, value));
+    else if (!strcmp(key, "export_zero_share")) t.export_zero_share = reset ? d.export_zero_share : (int)std::min<long long>(100, std::max<long long>(0, value));
+    else if (!strcmp(key, "export_zero_inflight")) t.export_zero_inflight = reset ? d.export_zero_inflight : (int)std::min<long long>(64, std::max<long long>(1, value));
+    else if (!strcmp(key, "export_zero_blocks")) t.export_zero_blocks = reset ? d.export_zero_blocks : (int)std::min<long long>(4096, std::max<long long>(1, value));
     else if (!strcmp(key, "feature_stagger")) {
         LT_REQUIRE(reset || (value >= 0 && value < (1 << 24)), "lt_set_tuning: feature_stagger out of range");
         t.feature_stagger = reset ? d.feature_stagger : (int)value;

@@ -561,14 +561,12 @@ extern "C" int lt_baseline_create(const lt_graph *g, const float *X, int64_t ldx
     B_HIP(hipMalloc((void **)&b->OUT, nc));
     B_HIP(hipMalloc((void **)&b->b1p_buf, (size_t)b->Hp * sizeof(float)));
     B_HIP(hipMalloc((void **)&b->W2p_buf, (size_t)b->Hp * C * sizeof(float)));
-    if (g->p_n_seg > 0) {
-        B_HIP(hipMalloc((void **)&b->seg_part, (size_t)g->p_n_seg * b->Hp * sizeof(float)));
-        // hub rows of FULL stage A run on a side stream next to the plain rows (fork / join by events inside
-        // lt_influence_rows): created here so that the launch functions create nothing and stay capturable
-        B_HIP(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
-        B_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
-        B_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
-    }
+    if (g->p_n_seg > 0) B_HIP(hipMalloc((void **)&b->seg_part, (size_t)g->p_n_seg * b->Hp * sizeof(float)));
+    // hub rows of FULL stage A run on a side stream next to the plain rows (fork / join by events inside lt_influence_rows):
+    // created here so that the launch functions create nothing and stay capturable
+    B_HIP(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+    B_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+    B_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
     if (lt_gemm_splitk_slab_bytes(b->n, H, F, lt_gemm_pick_kslice(b->n, H, F)))
         B_HIP(hipMalloc((void **)&b->slabs, lt_gemm_splitk_slab_bytes(b->n, H, F, lt_gemm_pick_kslice(b->n, H, F))));
 #undef B_HIP

@@ -371,6 +371,11 @@ __global__ __launch_bounds__(256) void k_spmm_f64(int n, const int32_t *__restri
     // job_first < 0: the job's blocks are the FIRST of the grid instead (for a job whose blocks outlast a block of rows; the record
     // gather -- 4.5 us on its own -- is better off last: 11.1 against 11.5 us for the launch at twitch size)
     int bx = (int)blockIdx.x;
+    // job.zero_blocks > 0: the LAST blocks of the grid zero-fill rows of lt_influence_rows_f64's matrix (lt_items.hip.h zero_rows_wave)
+    if (job.zero_blocks > 0 && bx >= (int)gridDim.x - job.zero_blocks) {
+        zero_rows_wave(job, bx - ((int)gridDim.x - job.zero_blocks));
+        return;
+    }
     if (job.nblocks > 0) {
         extern __shared__ __attribute__((aligned(16))) unsigned char spmm_job_smem[];      // (job.smem_bytes: the record gather's list)
         if (job_first < 0) {
@@ -679,13 +684,20 @@ __global__ __launch_bounds__(64 * FD_WAVES, FD_MIN_WAVES) void k_s1d_feature_row
         fd_slab_block(fd_smem, nslab, F, H, Hp, ref, W1, slabs, gate, cref_out);
         return;
     }
+    // job.zero_blocks > 0 (lt_influence_rows_f64): the next blocks of the launch -- in front of the rows in dispatch order -- fill
+    // rows of the caller's float64 matrix with +0.0: np.zeros of attacker.py:216 crossing PCIe for as long as the rows take
+    const int nzero = job.zero_blocks;
+    if ((int)blockIdx.x < nslab + nzero) {
+        zero_rows_wave(job, (int)blockIdx.x - nslab);
+        return;
+    }
     // stagger (round 6): the row blocks start in `stagger & 255` groups, group k (blocks in launch order) `stagger >> 8` ticks of the
     // 100 MHz clock after group k - 1.  Every row of the launch is one generation of waves: started together, their rows all land
     // at the end of the pass over X and the list walks of ALL rows (20 W1 rows per row of X: 1.6 x the bytes of X through the
     // L1s) queue behind it; started in groups, group k walks while group k + 1's rows are still arriving.
     if ((stagger & 255) > 1) {
-        const int nrb = (int)gridDim.x - nslab - (job.nblocks > 0 ? job.nblocks : 0);
-        const int grp = (int)(((long)((int)blockIdx.x - nslab) * (stagger & 255)) / (nrb > 0 ? nrb : 1));
+        const int nrb = (int)gridDim.x - nslab - nzero - (job.nblocks > 0 ? job.nblocks : 0);
+        const int grp = (int)(((long)((int)blockIdx.x - nslab - nzero) * (stagger & 255)) / (nrb > 0 ? nrb : 1));
         const unsigned long long until = wall_clock64() + (unsigned long long)grp * (unsigned)(stagger >> 8);
         while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
     }
@@ -695,7 +707,7 @@ __global__ __launch_bounds__(64 * FD_WAVES, FD_MIN_WAVES) void k_s1d_feature_row
     double *ldv = reinterpret_cast<double *>(fd_smem + (((size_t)Fp * 4 + 15) & ~(size_t)15));   // [FD_WAVES][FD_CAP]
     int *lj = reinterpret_cast<int *>(ldv + FD_WAVES * FD_CAP);                    // [FD_WAVES][FD_CAP]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int i = ((int)blockIdx.x - nslab) * FD_WAVES + wid;
+    const int i = ((int)blockIdx.x - nslab - nzero) * FD_WAVES + wid;
     const bool live = i < n;                        // (waves past the last row still help staging and join the barrier)
     const float *xr = X + (long)(live ? i : 0) * ldx;
     constexpr int STEP = 64 * VEC;
@@ -1392,10 +1404,11 @@ static int launch_feature_s1d(lt_baseline *b, hipStream_t st, int n_rows = -1, b
     unsigned blocks = (unsigned)((n + FD_WAVES - 1) / FD_WAVES + nslab);
     const size_t smem = fd_smem_bytes(F);
     lt_bits_job jb = lt_bits_job{};
-    const int job_first = (int)blocks;
+    int job_first = (int)blocks;
     if (g_offered_job && n_rows < 0 && g_offered_job->nblocks > 0 && g_offered_job->smem_bytes <= smem && lt_tune().records_early != 0) {
         jb = *g_offered_job;
-        blocks += (unsigned)jb.nblocks;
+        job_first += jb.zero_blocks;          // (the zero-fill blocks sit between the slab blocks and the rows)
+        blocks += (unsigned)(jb.nblocks + jb.zero_blocks);
         g_offered_rode = true;
     }
     const bool vec2 = b->ldx % 2 == 0 && F % 2 == 0 && ((uintptr_t)b->X % 8) == 0, one = F <= 16 * 64 * FD_WAVES;
@@ -1488,15 +1501,16 @@ static int form_z1d(lt_baseline *b, int32_t *state, hipStream_t st, const lt_bit
     // the feature route with fp32 row storage, for LT_MODE_DELTA's stage A alone: the result in fp32 too
     float *zf = (allow_f32 && b->s1_f32 && b->Z1x && lt_tune().s1_f32 != 0) ? b->Z1x : nullptr;     // (on demand too: the same bits)
     b->z1x_valid = zf != nullptr;
-    const unsigned gj = jb.nblocks > 0 ? (unsigned)jb.nblocks : 0u;
-    if (job_done) *job_done = gj > 0;
+    const unsigned gz = jb.zero_blocks > 0 ? (unsigned)jb.zero_blocks : 0u;
+    const unsigned gj = (jb.nblocks > 0 ? (unsigned)jb.nblocks : 0u);
+    if (job_done) *job_done = gj + gz > 0;
     const size_t jsm = gj > 0 ? (size_t)jb.smem_bytes : 0;
     if (b->s1_f32) {
-        LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, float>), dim3(g2 + gs + gj), dim3(256), jsm, st, n, g->rowptr,
+        LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, float>), dim3(g2 + gs + gj + gz), dim3(256), jsm, st, n, g->rowptr,
                                                 g->col, g->val, b->S1x, Hp, b->b1p, b->Z1d, (int)gs, g->q_n_seg, g->q_seg_begin,
                                                 g->q_seg_long, g->q_long_row, b->seg_d, state, b->fd_rs, crefv, jb, (int)(g2 + gs), zf, b->S1qs));
     } else {
-        LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, double>), dim3(g2 + gs + gj), dim3(256), jsm, st, n, g->rowptr,
+        LT_DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_spmm_f64<LPR_, double>), dim3(g2 + gs + gj + gz), dim3(256), jsm, st, n, g->rowptr,
                                                 g->col, g->val, b->S1d, Hp, b->b1p, b->Z1d, (int)gs, g->q_n_seg, g->q_seg_begin,
                                                 g->q_seg_long, g->q_long_row, b->seg_d, state, b->fd_rs, crefv, jb, (int)(g2 + gs), zf));
     }

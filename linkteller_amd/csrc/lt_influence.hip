@@ -1524,7 +1524,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_finish(
     const double *__restrict__ crefv, const double *__restrict__ S1qs, const float *__restrict__ Z1x, int Hp,
     const float *__restrict__ W2p, int C, const int32_t *__restrict__ rec, int rec_words, int maxc,
     const int32_t *__restrict__ dl_src, int n_obs, float delta, float *__restrict__ out, long ldo,
-    double *__restrict__ out64 = nullptr, long ld64 = 0) {
+    double *__restrict__ out64 = nullptr, long ld64 = 0, int out64_sparse = 0) {      // (rows [0, out64_sparse) of out64 hold zeros already)
     extern __shared__ __attribute__((aligned(16))) unsigned char df_smem[];
     float *sS2 = reinterpret_cast<float *>(df_smem);             // [maxc][C] the items' layer-2 differences
     // (launched with 256, 128 or 64 threads: a call of more probes than the chip holds 4-wave blocks for -- ~ 90 VGPRs, 5 waves per
@@ -1547,6 +1547,13 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_finish(
     int2 ltp = gTp[max(n_obs - 1 - wid, 0)];
     float *orow = out + (long)b * ldo;
     for (int j = tid; j < n_obs; j += NT) orow[j] = 0.f;    // (the barrier below orders these before the positions' results)
+    // rows [0, out64_sparse) of out64 were zero-filled over PCIe by blocks of the launch that formed the product rows: their
+    // probes' blocks write the touched positions only -- 7 % of the row at twitch size
+    double *const srow = (out64 && b < out64_sparse) ? out64 + (long)b * ld64 : (double *)nullptr;
+    auto put = [&](int pos, float v) __attribute__((always_inline)) {
+        orow[pos] = v;
+        if (srow) srow[pos] = (double)v;
+    };
     const int cnt = hdr.x, n_short = hdr.y & 0xffff, n_long = (int)((unsigned)hdr.y >> 16), v = hdr.z;
     const lt_df_inc *ent = reinterpret_cast<const lt_df_inc *>(dl_src + hdr.w);
     // per touched position: up to 4 entries by one thread (a select per (entry, chain) pair, nothing but registers)
@@ -1627,7 +1634,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_finish(
             const float dd = oc / delta;
             ss = fmaf(dd, dd, ss);
         }
-        if (lane == 0) orow[lt_.x] = sqrtf(ss);
+        if (lane == 0) put(lt_.x, sqrtf(ss));
     };
     lt_df_inc te[TPR][4];
     lt_df_inc lmine = {0.f, 0};
@@ -1759,7 +1766,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_finish(
     // ---- the touched positions ----
 #pragma unroll
     for (int h = 0; h < TPR; ++h)
-        if (tid + h * NT < n_short) orow[tp[h].x] = short_answer(te[h], tp[h].y >> 16);
+        if (tid + h * NT < n_short) put(tp[h].x, short_answer(te[h], tp[h].y >> 16));
     DF_STAMP(3);
     if (wid < n_long) long_answer(ltp, lmine);
     DF_STAMP(4);
@@ -1770,7 +1777,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_finish(
         lt_df_inc e[4];
 #pragma unroll
         for (int y = 0; y < 4; ++y) e[y] = ent[st + min(y, c_ - 1)];
-        orow[t_.x] = short_answer(e, c_);
+        put(t_.x, short_answer(e, c_));
     }
     // The long positions beyond each wave's first (a clique of k nodes among the probes is k of them per member): 8 lanes per
     // position, 8 positions per wave side by side.  Lane q of a group holds entries q, q + 8, ... of a 64-entry stretch and the
@@ -1823,7 +1830,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_finish(
                     ss = fmaf(dd, dd, ss);
                 }
             }
-            if (have && q == 0) orow[t_.x] = sqrtf(ss);
+            if (have && q == 0) put(t_.x, sqrtf(ss));
         }
     }
     DF_STAMP(5);
@@ -1831,7 +1838,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_delta_probe_finish(
     // memory through its device-side alias: the rows cross PCIe while the other probes' blocks still compute, instead of in a
     // launch of their own behind this one (lt_export_rows_f64).  The barrier drains every wave's stores (hipcc emits vmcnt(0) in
     // front of it); the row is read back past this CU's L1 (an earlier call's export may have left lines of it there).
-    if (out64) {
+    if (out64 && !srow) {
         __syncthreads();
         double *drow = out64 + (long)b * ld64;
         const bool pair_ok = (reinterpret_cast<uintptr_t>(drow) & 15) == 0;
@@ -2440,6 +2447,7 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
     // the feature-rows route): nothing in them reads a layer, and that launch has CU slots to spare.
     lt_bits_job cj0 = {};
     bool recs_rode = false, items_rode = false;
+    int sparse_rows = 0;            // rows of dst64 zero-filled ahead of the probes' blocks
     {
         int32_t *const node_err0 = lt_node_err_dev();
         const bool offer = fused && dg.record_smem <= (size_t)16 * 1024;
@@ -2448,6 +2456,15 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
             cj0.probes = probe_nodes; cj0.nb = nb0; cj0.nblocks = nb0; cj0.dl_rec = w.dl_rec; cj0.dl_meta = g->dl_meta; cj0.dl_src = g->dl_rec;
             cj0.dl_maxc = dg.maxc; cj0.dl_rec_words = dg.rec_words; cj0.observe = observe_nodes; cj0.n_obs = n_obs;
             cj0.n = n; cj0.err = node_err0; cj0.smem_bytes = (unsigned)dg.record_smem;
+            // lt_influence_rows_f64: the first rows of the float64 matrix are zero-filled by blocks of that same launch -- np.zeros
+            // (attacker.py:216) crossing PCIe while the product rows are formed; their probes' blocks then send the touched positions
+            // only (7 % of a row at twitch size), the other probes' blocks widen their whole rows as before
+            if (dst64 != nullptr && lt_tune().export_sparse != 0 && n_obs > 0) {
+                cj0.zero_dst = dst64; cj0.zero_ld = (long)ldd; cj0.zero_cols = n_obs;
+                cj0.zero_rows = (int)(((long long)n_probe * lt_tune().export_zero_share + 99) / 100);
+                cj0.zero_blocks = cj0.zero_rows > 0 ? lt_tune().export_zero_blocks : 0;
+                cj0.zero_inflight = lt_tune().export_zero_inflight;
+            }
             lt_fp64_offer_job(&cj0);
         }
         // ... and the item route of a graph with per-probe bitmap rows its first chunk's item tables (k_item_bits' blocks), the same way
@@ -2466,6 +2483,7 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
         if (!rc) rc = mode == LT_MODE_FULL ? lt_baseline_ensure_s1(b, st) : lt_baseline_ensure_layers(b, mode == LT_MODE_DELTA, st, !delta64);
         if (offer) recs_rode = lt_fp64_offer_taken();
         else if (offer_items) items_rode = lt_fp64_offer_taken();
+        sparse_rows = recs_rode ? cj0.zero_rows : 0;
         if (rc) return rc;
     }
     // Node ids (lt_items.hip.h checked_node): DELTA calls without pair marks check their lists in the first blocks that read them
@@ -2626,8 +2644,19 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
                         cj.smem_bytes = (unsigned)dg.record_smem;
                         bool rode = p0 == 0 && recs_rode;      // (chunk 0's records went along with the product rows' launch)
                         if (p0 == 0 && recs_rode) {
-                            int rc = lt_fp64_prepare_rows(b, nullptr, 0, nullptr, n_probe, st, nullptr, nullptr);
+                            // (the next rows of lt_influence_rows_f64's matrix are zero-filled under this launch)
+                            lt_bits_job zj = {};
+                            bool z_rode = false;
+                            if (cj0.zero_blocks > 0 && lt_tune().export_zero_share2 > 0 && cj0.zero_rows < n_probe) {
+                                zj.zero_dst = cj0.zero_dst; zj.zero_ld = cj0.zero_ld; zj.zero_cols = cj0.zero_cols; zj.zero_row0 = cj0.zero_rows;
+                                const long long want = ((long long)n_probe * lt_tune().export_zero_share2 + 99) / 100;
+                                zj.zero_rows = (int)std::min<long long>(want, n_probe - cj0.zero_rows);
+                                zj.zero_blocks = cj0.zero_blocks; zj.zero_inflight = cj0.zero_inflight;
+                            }
+                            int rc = lt_fp64_prepare_rows(b, nullptr, 0, nullptr, n_probe, st, zj.zero_blocks > 0 ? &zj : nullptr,
+                                                          zj.zero_blocks > 0 ? &z_rode : nullptr);
                             if (rc) return rc;
+                            if (z_rode) sparse_rows += zj.zero_rows;
                         } else if (p0 == 0) {
                             // (a launch's dynamic LDS is given to ALL its blocks: beyond 16 KB of node list the records get a launch
                             // of their own rather than cost the row blocks their occupancy)
@@ -2652,7 +2681,7 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
         if (dg.finish_smem > (size_t)64 * 1024) { const int rc_ = df_allow_big_lds<LPR_, CP_, SX_, ZF_>(); if (rc_) return rc_; }    \
         hipLaunchKernelGGL((k_delta_probe_finish<LPR_, CP_, SX_, ZF_>), dim3((unsigned)nb), dim3(df_threads), dg.finish_smem, st,      \
                            b->Z1d, b->S1d, sxp, crp, b->S1qs, zxp, Hp, b->W2p, C, w.dl_rec, dg.rec_words, dg.maxc, g->dl_rec,        \
-                           n_obs, delta, orow, (long)ldo, drow64, (long)ldd)))
+                           n_obs, delta, orow, (long)ldo, drow64, (long)ldd, sparse_rows - p0)))
                     double *const drow64 = (dst64 && exported_rows == p0) ? dst64 + (int64_t)p0 * ldd : (double *)nullptr;
                     if (drow64) exported_rows = p0 + nb;
                     if (sxp && zxp) { LT_DF_LAUNCH(true, true); }

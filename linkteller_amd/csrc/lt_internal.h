@@ -181,6 +181,13 @@ struct lt_tuning {
     int feature_flags;           // the row-per-wave kernel lists a row's differing columns from flag bits (1, default: the kernel is bound by
                                  // the issue of its 52 compare steps -- 24.8 against 25.4 us by events, profiles/r06_feat_lab_timeline.txt) or by
                                  // a ballot per value (0: round 5's list order) (LT_FEATURE_FLAGS)
+    int export_sparse;           // lt_influence_rows_f64, fused route behind a refresh: 1 the first "export_zero_share" % rows of the float64
+                                 // matrix are zero-filled by blocks of the product rows' launch and their probes' blocks write the touched
+                                 // positions only (default), 0 every block widens its whole row (LT_EXPORT_SPARSE)
+    int export_zero_share;       // (LT_EXPORT_ZERO_SHARE, 0 .. 100)
+    int export_zero_share2;      // the next so many % of the rows, by blocks of the pre-activation's launch (LT_EXPORT_ZERO_SHARE2)
+    int export_zero_blocks;      // waves that zero-fill (LT_EXPORT_ZERO_BLOCKS)
+    int export_zero_inflight;    // stores each of them keeps in flight (LT_EXPORT_ZERO_INFLIGHT)
     int feature_stagger;         // the row-per-wave kernel's blocks start in (value & 255) groups, (value >> 8) ticks of 10 ns apart; 0 = together
                                  // (LT_FEATURE_STAGGER)
     int feature_ring_min_rows;   // (LT_FEATURE_RING_MIN_ROWS, default 1024: below it the CUs' waves have no row each)
@@ -299,6 +306,11 @@ struct lt_bits_job {
     // already checked).  n == 0: no check (the 3-layer path checks up front)
     int n;
     int32_t *err, *probes_s, *obs_s;
+    // zero_blocks > 0: that many more blocks of the carrying launch fill rows [zero_row0, zero_row0 + zero_rows) of zero_dst (float64,
+    // leading dimension zero_ld, columns [0, zero_cols)) with +0.0 -- rows of lt_influence_rows_f64's matrix, usually pinned host memory
+    double *zero_dst;
+    long zero_ld;
+    int zero_row0, zero_rows, zero_cols, zero_blocks, zero_inflight;
     unsigned smem_bytes;    // dynamic LDS the job's blocks need (the launch that carries them must be given it)
 };
 // job != NULL: *job_done says whether the job went along (it does when every row is formed by one plain launch; the on-demand

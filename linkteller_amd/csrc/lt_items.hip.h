@@ -231,6 +231,27 @@ static __global__ __launch_bounds__(256) void k_delta_records(const lt_bits_job 
     delta_record_block((int)blockIdx.x, job, dr_smem);
 }
 // the same block as part of another launch (256 threads per block)
+// lt_bits_job::zero_*: wave `w` of zero_blocks fills rows zero_row0 + w, + zero_blocks, ... of the caller's float64 matrix (pinned
+// host memory as a rule) with +0.0 -- whole rows, 1-KiB stores, a bounded number in flight.  One wave per carrying block (the
+// block's other waves leave at once).
+static __device__ __forceinline__ void zero_rows_wave(const lt_bits_job &j, const int w) {
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x, cols = j.zero_cols, cap = j.zero_inflight;
+    const bool pair_ok = (reinterpret_cast<uintptr_t>(j.zero_dst) & 15) == 0 && (j.zero_ld & 1) == 0;
+    for (int r = j.zero_row0 + w; r < j.zero_row0 + j.zero_rows; r += j.zero_blocks) {
+        double *row = j.zero_dst + (long)r * j.zero_ld;
+        for (int c = 2 * lane; c < cols; c += 128) {
+            if (c + 1 < cols && pair_ok) *reinterpret_cast<double2 *>(row + c) = make_double2(0.0, 0.0);
+            else { row[c] = 0.0; if (c + 1 < cols) row[c + 1] = 0.0; }
+            if (cap <= 2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else if (cap <= 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (cap <= 8) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else if (cap <= 16) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+            else asm volatile("" ::: "memory");
+        }
+    }
+}
+
 static __device__ __forceinline__ void item_bits_block(const int bid, const lt_bits_job &j, unsigned char *smem = nullptr) {
     if (j.dl_rec != nullptr) {      // (`smem`: the launch's dynamic LDS, j.smem_bytes)
         delta_record_block(bid, j, smem);

@@ -277,11 +277,13 @@ class Baseline:
                                                 ws.numel(), _stream()), "lt_influence_rows")
         return out
 
-    def influence_matrix_host(self, probe_nodes, observe_nodes, delta: float, mode="delta"):
+    def influence_matrix_host(self, probe_nodes, observe_nodes, delta: float, mode="delta", refresh=False):
         """[n_probe, n_obs] float64 on the HOST (the reference's ``influence_val``, attacker.py:216-229) by ONE library call:
         the rows are formed and land in pinned host memory (a block of torch's pinned-memory cache, owned by the returned
         array) without an export launch of their own where the route allows; one stream wait; then the device-side node-id
-        check (IndexError, as the reference raises)."""
+        check (IndexError, as the reference raises).  ``refresh``: mark the loop-invariant baseline stale first (``refresh(mode)``)
+        -- the call then recomputes it, and on the fused `delta` route the matrix's zeros cross PCIe under the launch that forms
+        the product rows while the probes' blocks send the touched positions only."""
         dev = self.x.device
         probes = _as_nodes(probe_nodes, self.n, dev, "probe_nodes")
         obs = _as_nodes(observe_nodes, self.n, dev, "observe_nodes")
@@ -292,6 +294,8 @@ class Baseline:
         if out is None:
             out = torch.empty((npb, nob), dtype=torch.float32, device=dev)
             self._host_scratch = {key: out}
+        if refresh:
+            self.refresh(mode)
         if npb and nob:
             self.influence_rows(probes, obs, delta, mode, out=out, host=host)
             torch.cuda.current_stream(dev).synchronize()

@@ -390,3 +390,71 @@ def test_rmat_scale21_config5_per_rank_shape(gpu):
     assert np.array_equal(shared, delta)
     print(f"scale 21: build {t_build:.1f} s, delta + sparse {t_gpu:.2f} s, restricted oracle on rows {rows.tolist()} {t_oracle:.1f} s, "
           f"{nh} shared hub rows {time.time() - t0:.2f} s")
+
+
+@pytest.mark.parametrize("share,share2", [(35, 15), (100, 0), (40, 60), (1, 1), (0, 50)])
+def test_host_matrix_with_zero_filled_head_equals_the_dense_export(gpu, share, share2):
+    """lt_influence_rows_f64 behind a refresh, fused `delta` route: the head of the float64 matrix is zero-filled by blocks riding in
+    the product rows' launch and in the pre-activation's, and its probes' blocks write the touched positions only
+    ("export_sparse"); same matrix as rows +
+    lt_export_rows_f64 -- row widths around the pair stores, a dirty pinned buffer used twice without a host-side wait, device
+    destinations, several probe chunks, the knob off."""
+    from linkteller_amd import _lib, engine, graph, synth
+    n, f, h = 1200, 96, 64
+    adj = synth.erdos_renyi_graph(n, 5000, seed=1)
+    hg = graph.HipGraph(graph.first_order_gcn(adj))
+    x = torch.from_numpy(synth.twitch_like_features(n, f, seed=2, density=0.05)).to(gpu)
+    w = synth.gcn_weights(f, h, 2, seed=3)
+    base = engine.Baseline(hg, x, *_params(w, gpu))
+    rng = np.random.RandomState(4)
+    _lib.set_tuning("export_zero_share", share)
+    _lib.set_tuning("export_zero_share2", share2)
+    try:
+        for nob in (1, 7, 64, 257, 1000):
+            obs = torch.from_numpy(rng.choice(n, nob, replace=False).astype(np.int32)).to(gpu)
+            probes = obs[: max(1, nob // 2)].contiguous()
+            npb = probes.numel()
+            base.refresh("delta")
+            want = engine.export_rows_f64(base.influence_rows(probes, obs, 1e-4, "delta"))
+            got = base.influence_matrix_host(probes, obs, 1e-4, "delta", refresh=True)
+            assert got.dtype == np.float64 and np.array_equal(got, want), nob
+            host = torch.full((npb, nob), 7.0, dtype=torch.float64).pin_memory()
+            out = torch.empty((npb, nob), dtype=torch.float32, device=gpu)
+            for _ in range(2):
+                base.refresh("delta")
+                base.influence_rows(probes, obs, 1e-4, "delta", out=out, host=host)
+            torch.cuda.synchronize()
+            assert np.array_equal(host.numpy(), want), (nob, "reused buffer")
+            dev64 = torch.full((npb, nob), -1.0, dtype=torch.float64, device=gpu)
+            base.refresh("delta")
+            base.influence_rows(probes, obs, 1e-4, "delta", out=out, host=dev64)
+            assert np.array_equal(dev64.cpu().numpy(), want), (nob, "device matrix")
+            # an odd leading dimension (8-byte stores)
+            wide = torch.full((npb, nob + 1), -1.0, dtype=torch.float64, device=gpu)
+            base.refresh("delta")
+            ws = base._ws[next(iter(base._ws))]
+            _lib.check(_lib.lib().lt_influence_rows_f64(base._h, probes.data_ptr(), npb, obs.data_ptr(), nob, 1e-4, _lib.MODE_DELTA,
+                                                        out.data_ptr(), nob, wide.data_ptr(), nob + 1, ws.data_ptr(), ws.numel(),
+                                                        engine._stream()), "lt_influence_rows_f64")
+            wide = wide.cpu().numpy()
+            assert np.array_equal(wide[:, :nob], want) and np.all(wide[:, nob] == -1.0), (nob, "ld = cols + 1")
+        # several probe chunks
+        obs = torch.from_numpy(rng.choice(n, 301, replace=False).astype(np.int32)).to(gpu)
+        probes = obs[:300].contiguous()
+        base.refresh("delta")
+        want = engine.export_rows_f64(base.influence_rows(probes, obs, 1e-4, "delta"))
+        _lib.set_tuning("chunk_budget_bytes", 1 << 20)
+        try:
+            got = base.influence_matrix_host(probes, obs, 1e-4, "delta", refresh=True)
+        finally:
+            _lib.set_tuning("chunk_budget_bytes", None)
+        assert np.array_equal(got, want)
+        _lib.set_tuning("export_sparse", 0)
+        try:
+            got = base.influence_matrix_host(probes, obs, 1e-4, "delta", refresh=True)
+        finally:
+            _lib.set_tuning("export_sparse", None)
+        assert np.array_equal(got, want)
+    finally:
+        _lib.set_tuning("export_zero_share", None)
+        _lib.set_tuning("export_zero_share2", None)
