@@ -507,10 +507,18 @@ __global__ void k_spmm_f64_long(int n_long, const int32_t *__restrict__ long_row
     if (i >= (long)n_long * ld) return;
     const int li = (int)(i / ld), c = (int)(i % ld);
     if (state && state[long_row[li]] != 2) return;
-    // (segment order; eight loads in flight -- as k_y_long: one dependent load per segment was most of this launch's 5 us)
+    // (segment order; eight loads in flight -- as k_y_long: one dependent load per segment was most of this launch's 5 us; sixteen while
+    // there are that many: a 1 749-entry row is 55 segments)
     const int s0 = long_segptr[li], s1 = long_segptr[li + 1];
     double acc = part[(size_t)s0 * ld + c];
     int sg = s0 + 1;
+    for (; sg + 16 <= s1; sg += 16) {
+        double v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = part[(size_t)(sg + t) * ld + c];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc += v[t];
+    }
     for (; sg + 8 <= s1; sg += 8) {
         double v[8];
 #pragma unroll

@@ -1,8 +1,8 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for f in 0 1; do
-  rm -rf /tmp/tr; LT_SPMM_LONG_FUSED=$f rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr -- python3 $R/bench.py --steps 20 --no-extras --powerlaw > /dev/null 2>&1
-  echo "== fused $f"
+for f in 1; do
+  rm -rf /tmp/tr; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr -- python3 $R/bench.py --steps 20 --no-extras --powerlaw > /dev/null 2>&1
+  echo "== power-law step"
   python3 - <<PY
 import csv,glob
 f=glob.glob('/tmp/tr/**/*kernel_stats.csv',recursive=True)[0]
