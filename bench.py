@@ -676,6 +676,17 @@ def main():
         if cnt:
             per_kernel[k] = {"launches_per_step": round(cnt / a.steps, 2), "us_per_step": round(tot / a.steps * 1e3, 2),
                              "share_of_step": round(tot / a.steps / (elapsed_i / a.steps * 1e3), 3)}
+    # the same table for the HOST-landed steps (`value`): the product rows' and the pre-activation's launches carry the zero-fill waves
+    # of the float64 matrix there, and the probes' launch its transfer
+    per_kernel_host = {}
+    if not (multi and probe_sharded) and hasattr(base, "influence_matrix_host"):
+        _lib.lib().lt_profile_enable(-1)
+        for _ in range(a.steps):
+            step_to_host(a.mode)
+        for k in classes:
+            tot, cnt = kernel_ms(k)
+            if cnt:
+                per_kernel_host[k] = {"launches_per_step": round(cnt / a.steps, 2), "us_per_step": round(tot / a.steps * 1e3, 2)}
     _lib.lib().lt_profile_enable(0)
     # what an empty event pair reads on this stream (median of 50): the overhead every HIP-event duration above carries
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
@@ -1204,7 +1215,10 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "value_note": "a step ends with influence_val on the HOST as float64 -- the region the reference times (attacker.py:213 -> 231, "
-                          "SURVEY 8(d)); inputs (graph, features, weights, node lists) resident in HBM",
+                          "SURVEY 8(d)); inputs (graph, features, weights, node lists) resident in HBM.  ONE library call per step "
+                          "(lt_influence_rows_f64): half of the matrix's rows are zero-filled over PCIe by a few waves riding in the "
+                          "product rows' and the pre-activation's launches and their probes' blocks send the touched positions only; the "
+                          "other rows are widened whole by their blocks (round 6: 0.106 -> 0.094 ms; profiles/r06_host_landed_lab.txt)",
             "value_device": round(value_dev, 1), "ms_per_step_device": round(ms_per_step_dev, 4),
             "value_device_note": "the same K steps ending with the fp32 matrix in HBM (what `value` was up to round 5)",
             "host_matrix_equals_device_matrix": host_equals_device,
@@ -1232,9 +1246,14 @@ def main():
                        "event_pair_note": "an EMPTY hipEventRecord pair on the kernels' stream reads this much: the per-class avg_launch_us "
                                           "figures (HIP events) sit that far above the rocprofv3 kernel durations in profiles/"},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "kernels": per_kernel,
-            "kernels_note": f"dominant class ({dom_name}) timed by HIP events inside the timed region (every {PROFILE_EVERY}th step: an event pair costs "
-                            f"~5 us of stream time); the other rows from an "
+            "kernels_note": f"dominant class ({dom_name}) timed by HIP events inside the device-resident timed region (`value_device`; every "
+                            f"{PROFILE_EVERY}th step: an event pair costs ~5 us of stream time); the other rows from an "
                             f"instrumented repeat of the same {a.steps} steps ({round(elapsed_i / a.steps * 1e3, 4)} ms/step)",
+            "kernels_host": per_kernel_host,
+            "kernels_host_note": "the same classes over an instrumented repeat of the HOST-landed steps (`value`): the product rows' launch "
+                                 "carries 35 % of the float64 matrix's zeros and the pre-activation's 15 % (a few waves each, over PCIe); "
+                                 "item_stageB (k_delta_probe_finish) holds the transfer of the rest -- the link, not the kernel's "
+                                 "arithmetic, is what it waits for",
         }
         if a.mode != "delta":
             out["parity_note"] = ("this mode is the reference's fp32 finite difference: its raw AUC can move by 1 / n_edges when a low-score "
