@@ -246,7 +246,9 @@ class Baseline:
 
     def influence_rows(self, probe_nodes, observe_nodes, delta: float, mode="full", out=None, host=None) -> torch.Tensor:
         """[n_probe, n_obs] fp32 on the device: ||(f(X + delta e_v x_v^T) - f(X))[u]||_2 / delta.  ``host``: a pinned (or
-        device) float64 [n_probe, n_obs] tensor that receives the same matrix widened (valid once the stream has drained)."""
+        device) float64 [n_probe, n_obs] tensor that receives the same matrix widened (valid once the stream has drained).
+        Node lists given as int32 CUDA tensors are checked on the device: call ``engine.node_check()`` after synchronising
+        (see ``_as_nodes``)."""
         dev = self.x.device
         probes = _as_nodes(probe_nodes, self.n, dev, "probe_nodes")
         obs = _as_nodes(observe_nodes, self.n, dev, "observe_nodes")
@@ -573,6 +575,11 @@ def node_check():
 
 
 def _as_nodes(nodes, n, device, name) -> torch.Tensor:
+    """Node list -> int32 device tensor.  Host lists are range-checked here (IndexError, as the reference's indexing raises).  An
+    int32 CUDA tensor is taken as it is -- no copy, no host round trip -- and its ids are checked by the KERNELS of the call that
+    reads it: an id outside [0, n) is replaced by node 0 there and raises a flag the caller collects with ``engine.node_check()``
+    AFTER synchronising (``influence_matrix_host`` / ``export_rows_f64`` do).  The flag is one per process (two words of mapped host
+    memory): a caller that never collects it gets LT_ERR_INDEX from the NEXT probe call of any baseline instead."""
     if isinstance(nodes, torch.Tensor) and nodes.is_cuda and nodes.dtype == torch.int32:
         return nodes.contiguous()          # fast path: the ids are checked on the device (lt_node_check / LT_ERR_INDEX)
     t = torch.as_tensor(nodes).to(torch.int64).reshape(-1).cpu()

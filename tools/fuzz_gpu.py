@@ -83,6 +83,19 @@ def main():
         finally:
             for k in knobs:
                 _lib.set_tuning(k, None)
+        # the float64 matrix on the host by ONE call behind a refresh (lt_influence_rows_f64; on the fused route the head of the matrix is
+        # zero-filled under the earlier launches, at random shares): the widened bits of the device matrix
+        shares = {"export_zero_share": int(rng.choice([0, 35, 100])), "export_zero_share2": int(rng.choice([0, 15, 60])),
+                  "export_zero_blocks": int(rng.choice([1, 16, 300]))}
+        for k, v in shares.items():
+            _lib.set_tuning(k, v)
+        try:
+            for m in ("delta", "sparse"):
+                hostm = base.influence_matrix_host(probes, observe, 1e-4, m, refresh=True)
+                assert hostm.dtype == np.float64 and np.array_equal(hostm, res[m]), (it, m, shares, "host matrix")
+        finally:
+            for k in shares:
+                _lib.set_tuning(k, None)
         # the other fp64 route of `delta` (aggregate-first <-> S1d; feature rows <-> matrix cores): fp64 summation order only
         route_knobs = (("aggregate_first", 0), ("feature_delta", int(rng.choice([0, 1]))), ("defer_cref", int(rng.choice([0, 1]))),
                        ("s1_f32", int(rng.choice([0, 1]))))
