@@ -458,3 +458,34 @@ def test_host_matrix_with_zero_filled_head_equals_the_dense_export(gpu, share, s
     finally:
         _lib.set_tuning("export_zero_share", None)
         _lib.set_tuning("export_zero_share2", None)
+
+
+def test_zero_filled_head_never_overtakes_the_values(gpu):
+    """The zeros of the host matrix's head are written by launches that END before the probes' launch begins, its values by that
+    launch: 3 000 host-landed builds at twitch-RU size into buffers that held 7.0 everywhere, alternating between two probe sets
+    (so a stale value of the previous build cannot pass for the present one) -- every matrix equals the widened device matrix."""
+    from linkteller_amd import engine, graph, synth
+    n, f, h = 4385, 3170, 256
+    hg = graph.HipGraph(graph.first_order_gcn(synth.erdos_renyi_graph(n, 37304, seed=42)))
+    x = torch.from_numpy(synth.twitch_like_features(n, f, seed=1)).to(gpu)
+    w = synth.gcn_weights(f, h, 2, seed=42)
+    base = engine.Baseline(hg, x, *_params(w, gpu))
+    rng = np.random.RandomState(7)
+    sets = []
+    for _ in range(2):
+        nodes = torch.from_numpy(rng.choice(n, 500, replace=False).astype(np.int32)).to(gpu)
+        base.refresh("delta")
+        sets.append((nodes, engine.export_rows_f64(base.influence_rows(nodes, nodes, 1e-4, "delta"))))
+    bufs = [torch.empty((500, 500), dtype=torch.float64).pin_memory() for _ in range(3)]
+    out = torch.empty((500, 500), dtype=torch.float32, device=gpu)
+    cur = torch.cuda.current_stream(gpu)
+    bad = 0
+    for it in range(3000):
+        nodes, want = sets[it & 1]
+        host = bufs[it % 3]
+        host.fill_(7.0)
+        base.refresh("delta")
+        base.influence_rows(nodes, nodes, 1e-4, "delta", out=out, host=host)
+        cur.synchronize()
+        bad += int(not np.array_equal(host.numpy(), want))
+    assert bad == 0, f"{bad} of 3000 host matrices differ"
