@@ -107,6 +107,9 @@ int lt_device_count(int *count);
  *                         they do and the matrix has at least "feature_ring_min_rows" rows.  fp64 summation order only (as with
  *                         the "feature_delta" knob); a probe chunk's record blocks then ride in the pre-activation's launch
  *   "feature_ring_min_rows"   see "feature_ring" (default 1024, >= 2)
+ *   "gcn3_product_gather" lt_influence3_rows, LT_MODE_DELTA: 1 = the probes' fp64 product rows X[v] W1 are read off the product the baseline
+ *                         already holds for every row (default), 0 = formed again on the f64 matrix cores (as on the aggregate-first
+ *                         route).  fp64 summation order / storage only: results agree to < 1e-6 of the largest score
  *   "export_sparse"       lt_influence_rows_f64 on the fused LT_MODE_DELTA route, calls that find the baseline refreshed: 1 = the first
  *                         rows of dst are zero-filled by a few waves riding in the launch that forms the fp64 product rows and in the
  *                         pre-activation's (np.zeros of attacker.py:216 crossing PCIe under those launches) and their probes' blocks
@@ -338,8 +341,9 @@ int lt_wide_combine(const float *const *vecs, int32_t n_vec, int64_t n_pairs, in
 
 /* ---- the same for the 3-layer model (GCN3, gcn/models.py:28-46; --n-layer 3, gcn_trainer.py:81-86) -------------
  *   logits = A (relu(A (relu(A (X W1) + b1) W2) + b2) W3) + b3,   H1, H2 <= 256, C <= 8.
- * lt_baseline3_create computes the unperturbed forward (owns S1, H1, S2, Z2, S3, OUT; borrows X and the six
- * parameter tensors; lt_baseline3_refresh recomputes everything from them).  lt_influence3_rows evaluates the
+ * lt_baseline3_create owns the unperturbed forward (S1, H1, S2, Z2, S3, OUT) and borrows X and the six parameter tensors;
+ * lt_baseline3_refresh marks everything stale and launches nothing: the next reader recomputes what IT reads on its own stream
+ * (a LT_MODE_DELTA build the fp64 pre-activations only, the fp32 modes and lt_baseline3_logits the fp32 forward).  lt_influence3_rows evaluates the
  * reference's fp32 finite difference (f(X + d e_v x_v^T) - f(X))[u] / d only where it can be non-zero: the rows a
  * probe reaches in 1, 2 and 3 hops, each recomputed with the arithmetic of the baseline forward, so unreachable
  * pairs are exactly 0.  The conventions of lt_influence_rows (enqueue only, no host synchronisation: the item

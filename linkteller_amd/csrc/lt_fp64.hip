@@ -1595,6 +1595,32 @@ int lt_launch_gemm_f64_dense(const double *A, long lda, int M, const float *B, l
     LT_CHECK_LAUNCH();
     return LT_OK;
 }
+// C[i, 0 .. Hp) = the fp64 product row S1[rows[i]] = X[rows[i]] W1 as the baseline holds it after lt_fp64_form_all -- fp64 rows, or the
+// 32-bit fixed-point rows times their scale, plus the reference vector's product where that is deferred: the expression the
+// 2-layer stage A reads a probe's row by (k_item_stageA_d2).  Returns 1 (nothing enqueued) when the baseline holds no product
+// rows (aggregate-first route): the caller forms them itself (lt_launch_gemm_f64_gather).
+static __global__ __launch_bounds__(256) void k_product_rows_gather(const int32_t *__restrict__ rows, int m, int Hp,
+                                                                     const double *__restrict__ S1d, const float *__restrict__ S1x,
+                                                                     const double *__restrict__ S1qs, const double *__restrict__ cref,
+                                                                     double *__restrict__ C, long ldc) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)m * Hp) return;
+    const int r = (int)(i / Hp), c = (int)(i % Hp), v = rows[r];
+    double s = S1x ? (double)__float_as_int(S1x[(size_t)v * Hp + c]) * S1qs[v] : S1d[(size_t)v * Hp + c];
+    if (cref) s += cref[c];
+    C[(size_t)r * ldc + c] = s;
+}
+int lt_fp64_product_rows_gather(const lt_baseline *b, const int32_t *rows, int m, double *C, long ldc, hipStream_t st) {
+    if (m <= 0) return LT_OK;
+    if (lt_fp64_agg_active(b) || !b->S1d || b->S1d_external) return 1;
+    const float *sx = b->s1_f32 ? b->S1x : (const float *)nullptr;
+    if (b->s1_f32 && (!b->S1x || !b->S1qs)) return 1;
+    const long tot = (long)m * b->Hp;
+    hipLaunchKernelGGL(k_product_rows_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, rows, m, b->Hp, b->S1d, sx, b->S1qs,
+                       b->cref_deferred ? b->fd_cref : (const double *)nullptr, C, ldc);
+    LT_CHECK_LAUNCH();
+    return LT_OK;
+}
 // C[i, 0..N) = A[rows[i], 0..K) * B, i < M, A fp32 (feature rows), fp64 accumulation
 int lt_launch_gemm_f64_gather(const float *A, long lda, const int32_t *rows, int M, const float *B, long ldb, int N, int K,
                               double *C, long ldc, hipStream_t st) {

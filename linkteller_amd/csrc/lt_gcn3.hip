@@ -46,6 +46,9 @@ struct lt_baseline3 {
     double *Z2d = nullptr;      // [n, Hp2]  A S2d + b2
     double *seg2d = nullptr;    // [lt_f64_seg_rows(g), Hp2]
     bool fp64_fresh = false;
+    // lt_baseline3_refresh launches nothing (round 6, as lt_baseline_refresh since ABI 2): the padded parameters and the fp32 forward
+    // are recomputed on the stream of the first call that reads them -- a LT_MODE_DELTA build reads no fp32 layer at all
+    bool pad_fresh = false, fp32_fresh = false;
 };
 
 // h[dst] = relu(A[r,:] S + bias): all rows (items == NULL), or the level-1 items of a probe chunk, whose row reads
@@ -370,21 +373,36 @@ static inline unsigned blocks_for(long n, int per_block) { return (unsigned)((n 
 
 extern "C" int lt_baseline3_refresh(lt_baseline3 *b, void *stream) {
     LT_REQUIRE(b != nullptr, "lt_baseline3_refresh: baseline is NULL");
-    hipStream_t st = (hipStream_t)stream;
-    const lt_graph *g = b->g;
-    const int n = b->n;
-    b->fp64_fresh = false;
+    b->fp64_fresh = b->pad_fresh = b->fp32_fresh = false;
     if (b->l1) (void)lt_baseline_refresh(b->l1, stream);
-    if (n == 0) return LT_OK;
+    return LT_OK;
+}
+
+// b1 / b2 / W3 zero-padded to the padded widths (read by the fp32 forward, the fp64 layer-2 pre-activation and the probes' kernels)
+static int ensure3_pad(const lt_baseline3 *cb, hipStream_t st) {
+    lt_baseline3 *b = const_cast<lt_baseline3 *>(cb);   // cache state only
+    if (b->pad_fresh || b->n == 0) return LT_OK;
     const int mx = (b->Hp1 > b->Hp2 * b->C ? b->Hp1 : b->Hp2 * b->C);
     hipLaunchKernelGGL(k3_pad, dim3((mx + 255) / 256), dim3(256), 0, st, b->b1, b->H1, b->Hp1, b->b2, b->H2, b->Hp2, b->W3,
                        b->C, b->b1p, b->b2p, b->W3p);
     LT_CHECK_LAUNCH();
+    b->pad_fresh = true;
+    return LT_OK;
+}
+
+// the unperturbed fp32 forward (the fp32 finite difference's baseline, lt_baseline3_logits)
+static int ensure3_fp32(const lt_baseline3 *cb, hipStream_t st) {
+    lt_baseline3 *b = const_cast<lt_baseline3 *>(cb);   // cache state only
+    if (b->fp32_fresh || b->n == 0) return LT_OK;
+    int rc = ensure3_pad(b, st);
+    if (rc) return rc;
+    const lt_graph *g = b->g;
+    const int n = b->n;
     // S1 = X W1 (pad columns zero)
     if (b->Hp1 != b->H1) LT_HIP(hipMemsetAsync(b->S1, 0, (size_t)n * b->Hp1 * sizeof(float), st));
-    int rc = b->slabs ? lt_launch_gemm_splitk(b->X, b->ldx, b->W1, b->H1, b->S1, b->Hp1, n, b->H1, b->F,
-                                              lt_gemm_pick_kslice(n, b->H1, b->F), b->slabs, st)
-                      : lt_launch_gemm(b->X, b->ldx, b->W1, b->H1, b->S1, b->Hp1, n, b->H1, b->F, st);
+    rc = b->slabs ? lt_launch_gemm_splitk(b->X, b->ldx, b->W1, b->H1, b->S1, b->Hp1, n, b->H1, b->F,
+                                          lt_gemm_pick_kslice(n, b->H1, b->F), b->slabs, st)
+                  : lt_launch_gemm(b->X, b->ldx, b->W1, b->H1, b->S1, b->Hp1, n, b->H1, b->F, st);
     if (rc) return rc;
     // H1 = relu(A S1 + b1)
     const int lpr1 = lt_lpr_for(b->Hp1);
@@ -400,7 +418,10 @@ extern "C" int lt_baseline3_refresh(lt_baseline3 *b, void *stream) {
     // S3 = relu(A S2 + b2) W3, OUT = A S3 + b3: the fused layer kernels of the 2-layer path
     rc = lt_launch_layer1(g, b->S2, b->Hp2, b->b2p, b->W3p, b->C, b->Z2, b->S3, st, b->seg_part);
     if (rc) return rc;
-    return lt_launch_layer2(g, b->S3, b->C, b->b3, b->OUT, st);
+    rc = lt_launch_layer2(g, b->S3, b->C, b->b3, b->OUT, st);
+    if (rc) return rc;
+    b->fp32_fresh = true;
+    return LT_OK;
 }
 
 extern "C" int lt_baseline3_create(const lt_graph *g, const float *X, int64_t ldx, int32_t F, const float *W1,
@@ -460,6 +481,7 @@ extern "C" int lt_baseline3_destroy(lt_baseline3 *b) {
 extern "C" int lt_baseline3_logits(const lt_baseline3 *b, float *dst, void *stream) {
     LT_REQUIRE(b != nullptr && dst != nullptr, "lt_baseline3_logits: NULL argument");
     if (b->n == 0) return LT_OK;
+    { const int rc = ensure3_fp32(b, (hipStream_t)stream); if (rc) return rc; }
     LT_HIP(hipMemcpyAsync(dst, b->OUT, (size_t)b->n * b->C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return LT_OK;
 }
@@ -496,7 +518,9 @@ extern "C" int lt_baseline3_enable_fp64(lt_baseline3 *b, void *stream) {
 static int ensure3_fp64(const lt_baseline3 *cb, hipStream_t st) {
     lt_baseline3 *b = const_cast<lt_baseline3 *>(cb);   // cache state only
     if (b->fp64_fresh || b->n == 0) return LT_OK;
-    int rc = lt_fp64_form_all(b->l1, st);               // Z1d, every row
+    int rc = ensure3_pad(b, st);                        // (b2p below)
+    if (rc) return rc;
+    rc = lt_fp64_form_all(b->l1, st);                   // Z1d, every row
     if (rc) return rc;
     rc = lt_launch_gemm_f64_dense(b->l1->Z1d, (long)b->Hp1, b->n, b->W2, (long)b->H2, b->H2, b->H1, nullptr, b->S2d, (long)b->Hp2, 1, st);
     if (rc) return rc;
@@ -603,8 +627,8 @@ extern "C" int lt_influence3_rows_mode(const lt_baseline3 *b, const int32_t *pro
     const int lpr1 = lt_lpr_for(Hp1), lpr2 = lt_lpr_for(Hp2);
     const int words = (n + 31) / 32;
     const long maxc = g->max_col_nnz > 0 ? g->max_col_nnz : 1;
-    if (exact) {
-        const int rc = ensure3_fp64(b, st);
+    {   // the baseline the mode reads: the fp64 pre-activations of the first two layers, or the fp32 forward
+        const int rc = exact ? ensure3_fp64(b, st) : ensure3_fp32(b, st);
         if (rc) return rc;
     }
     for (int p0 = 0; p0 < n_probe; p0 += w.chunk) {
@@ -623,9 +647,14 @@ extern "C" int lt_influence3_rows_mode(const lt_baseline3 *b, const int32_t *pro
                                        probes, delta);
             if (rc) return rc;
         } else {
-            // the probes' own product rows in fp64 (dS1[v] = d * S1[v])
-            if (Hp1 != b->H1) LT_HIP(hipMemsetAsync(w.Spd, 0, (size_t)nb * Hp1 * sizeof(double), st));
-            rc = lt_launch_gemm_f64_gather(b->X, (long)b->ldx, probes, nb, b->W1, (long)b->H1, b->H1, b->F, w.Spd, (long)Hp1, st);
+            // the probes' own product rows in fp64 (dS1[v] = d * S1[v]): read off the inner baseline's product where it holds one
+            // (ensure3_fp64 formed it for every row: the 2-layer stage A reads a probe's row the same way) -- X[probes] W1 over again
+            // on the f64 cores was 0.40 of the 0.87 ms this build took at twitch size (round 6); formed here on the aggregate-first route
+            rc = lt_tune().gcn3_product_gather != 0 ? lt_fp64_product_rows_gather(b->l1, probes, nb, w.Spd, (long)Hp1, st) : 1;
+            if (rc == 1) {
+                if (Hp1 != b->H1) LT_HIP(hipMemsetAsync(w.Spd, 0, (size_t)nb * Hp1 * sizeof(double), st));
+                rc = lt_launch_gemm_f64_gather(b->X, (long)b->ldx, probes, nb, b->W1, (long)b->H1, b->H1, b->F, w.Spd, (long)Hp1, st);
+            }
             if (rc) return rc;
         }
         hipLaunchKernelGGL(k_item_bits, dim3(nb), dim3(256), 0, st, g->tptr, g->trow, probes, nb, words, w.bits1, w.off, (int2 *)nullptr, (uint2 *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);

@@ -181,6 +181,8 @@ struct lt_tuning {
     int feature_flags;           // the row-per-wave kernel lists a row's differing columns from flag bits (1, default: the kernel is bound by
                                  // the issue of its 52 compare steps -- 24.8 against 25.4 us by events, profiles/r06_feat_lab_timeline.txt) or by
                                  // a ballot per value (0: round 5's list order) (LT_FEATURE_FLAGS)
+    int gcn3_product_gather;     // GCN3 `delta`: 1 the probes' fp64 product rows are read off the inner baseline's product (default), 0 formed again
+                                 // as X[probes] W1 on the f64 cores (LT_GCN3_PRODUCT_GATHER)
     int export_sparse;           // lt_influence_rows_f64, fused route behind a refresh: 1 the first "export_zero_share" % rows of the float64
                                  // matrix are zero-filled by blocks of the product rows' launch and their probes' blocks write the touched
                                  // positions only (default), 0 every block widens its whole row (LT_EXPORT_SPARSE)
@@ -276,6 +278,7 @@ bool lt_fp64_agg_active(const lt_baseline *b);
 int lt_fp64_form_all(lt_baseline *b, hipStream_t st);
 int lt_launch_gemm_f64_dense(const double *A, long lda, int M, const float *B, long ldb, int N, int K, const float *bias,
                              double *C, long ldc, int relu_a, hipStream_t st);
+int lt_fp64_product_rows_gather(const lt_baseline *b, const int32_t *rows, int m, double *C, long ldc, hipStream_t st);   // 1: no product rows held
 int lt_launch_gemm_f64_gather(const float *A, long lda, const int32_t *rows, int M, const float *B, long ldb, int N, int K,
                               double *C, long ldc, hipStream_t st);
 int lt_launch_spmm_f64(const lt_graph *g, const double *S, int ld, const float *biasp, double *out, double *seg_d, hipStream_t st);

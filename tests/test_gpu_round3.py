@@ -464,6 +464,17 @@ def test_gcn3_delta_mode_against_the_fp64_oracle(gpu, h1, h2, c, hub, features):
     assert np.array_equal(got[-1], got[-2])                         # duplicate probe -> identical rows
     sparse = base.influence_rows(probes, observe, 1e-4, "sparse").cpu().numpy().astype(np.float64)
     assert np.abs(sparse - got).max() <= 0.05 * scale + 0.05
+    # the probes' fp64 product rows read off the baseline's product (round 6, default) against X[probes] W1 formed again on the f64
+    # cores ("gcn3_product_gather" = 0): fp64 summation order / the fixed-point storage of the rows only
+    _lib.set_tuning("gcn3_product_gather", 0)
+    try:
+        base.refresh()
+        regemm = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
+    finally:
+        _lib.set_tuning("gcn3_product_gather", None)
+        base.refresh()
+    assert np.abs(regemm - ref64).max() / scale <= 1e-5 and np.abs(regemm - got).max() <= 1e-6 * scale
+    assert np.all(regemm[ref64 == 0] == 0)
     _lib.set_tuning("chunk_budget_bytes", 1 << 19)
     try:
         chunked = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
