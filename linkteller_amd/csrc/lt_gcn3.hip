@@ -86,13 +86,15 @@ __global__ __launch_bounds__(LT_BLOCK) void k3_rows_relu(
     }
 }
 
-// R2 of every probe: for each level-1 item (b, r) the rows r2 that read row r (CSC column r) are marked in the
-// probe's bitmap; the thread that flips a bit appends (b, r2) to the level-2 item list (order irrelevant: every item
-// is computed on its own and lands in S3x[b][r2])
+// R2 of every probe: for each level-1 item (b, r) the rows r2 that read row r (CSC column r) are marked in the probe's bitmap
+// (k3_mark2); k3_list2 then turns every probe's bitmap row into its level-2 items (b, r2) (order irrelevant: every item is
+// computed on its own and lands in S3x[b][r2]).
+// (Up to round 5 the thread that flipped a bit appended the item itself: one add per wave and trip on ONE word -- 9 K of them at
+// twitch size, which that word's L2 channel serves one after the other: 105 us of a 0.35 ms GCN3 build.  Now the marks are
+// fire-and-forget and the list costs one add per 256 bitmap words that hold anything.)
 __global__ __launch_bounds__(LT_BLOCK) void k3_mark2(
     const int32_t *__restrict__ tptr, const int32_t *__restrict__ trow, const int32_t *__restrict__ probes, int nb,
-    const int32_t *__restrict__ off, int words, uint32_t *__restrict__ bits2, int2 *__restrict__ items2,
-    int32_t *__restrict__ n_items2) {
+    const int32_t *__restrict__ off, int words, uint32_t *__restrict__ bits2) {
     const int lane = threadIdx.x & 63;
     const int total = off[nb];
     const int wave0 = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
@@ -103,10 +105,46 @@ __global__ __launch_bounds__(LT_BLOCK) void k3_mark2(
         const int r = trow[tptr[v] + (it - off[b])];
         for (int t = tptr[r] + lane; t < tptr[r + 1]; t += 64) {
             const int r2 = trow[t];
-            const unsigned bit = 1u << (r2 & 31);
-            const unsigned old = atomicOr(&bits2[(size_t)b * words + (r2 >> 5)], bit);
-            if (!(old & bit)) items2[atomicAdd(n_items2, 1)] = make_int2(b, r2);
+            atomicOr(&bits2[(size_t)b * words + (r2 >> 5)], 1u << (r2 & 31));
         }
+    }
+}
+// one block per probe: its bitmap row, 256 words at a time -> items2 (a place per set bit behind one add per stretch)
+__global__ __launch_bounds__(LT_BLOCK) void k3_list2(int words, const uint32_t *__restrict__ bits2, int2 *__restrict__ items2,
+                                                     int32_t *__restrict__ n_items2) {
+    __shared__ int s_wave[LT_BLOCK / 64];
+    __shared__ int s_base;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint32_t *row = bits2 + (size_t)b * words;
+    for (int w0 = 0; w0 < words; w0 += LT_BLOCK) {          // (block-uniform)
+        const int w = w0 + threadIdx.x;
+        uint32_t m = w < words ? row[w] : 0u;
+        const int cnt = __popc(m);
+        int incl = cnt;                                      // inclusive prefix over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) s_wave[wid] = incl;
+        __syncthreads();
+        int before = 0, all = 0;
+#pragma unroll
+        for (int k = 0; k < LT_BLOCK / 64; ++k) {
+            before += k < wid ? s_wave[k] : 0;
+            all += s_wave[k];
+        }
+        if (all > 0 && threadIdx.x == 0) s_base = atomicAdd(n_items2, all);
+        __syncthreads();
+        if (cnt > 0) {
+            int pos = s_base + before + incl - cnt;
+            while (m) {
+                const int bit = __ffs((int)m) - 1;
+                m &= m - 1u;
+                items2[pos++] = make_int2(b, w * 32 + bit);
+            }
+        }
+        __syncthreads();                                     // (s_wave / s_base are rewritten by the next stretch)
     }
 }
 
@@ -677,8 +715,9 @@ extern "C" int lt_influence3_rows_mode(const lt_baseline3 *b, const int32_t *pro
         // level 2: R2 and its items
         LT_HIP(hipMemsetAsync(w.bits2, 0, (size_t)nb * words * sizeof(uint32_t), st));
         LT_HIP(hipMemsetAsync(w.n_items2, 0, sizeof(int32_t), st));
-        hipLaunchKernelGGL(k3_mark2, dim3(LT3_GRID), dim3(LT_BLOCK), 0, st, g->tptr, g->trow, probes, nb, w.off, words, w.bits2,
-                           w.items2, w.n_items2);
+        hipLaunchKernelGGL(k3_mark2, dim3(LT3_GRID), dim3(LT_BLOCK), 0, st, g->tptr, g->trow, probes, nb, w.off, words, w.bits2);
+        LT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k3_list2, dim3((unsigned)nb), dim3(LT_BLOCK), 0, st, words, w.bits2, w.items2, w.n_items2);
         LT_CHECK_LAUNCH();
         const unsigned gridC = (unsigned)(((long)nb * n_obs * LT_L2_LANES + LT_BLOCK - 1) / LT_BLOCK);
         if (!exact) {
