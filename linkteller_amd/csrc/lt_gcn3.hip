@@ -317,14 +317,32 @@ __global__ __launch_bounds__(LT_BLOCK) void k3d_stageB(
         if (live) {
             const int2 w = items2[it];
             b = w.x; q = w.y;
-            if (active) {
-                const uint2 *mb = bits1 + (size_t)b * words;
-                const float *items = dS2x + (size_t)off[b] * Hp2;
-                f32x4 dz = {0.f, 0.f, 0.f, 0.f};
-                for (int e = rowptr[q]; e < rowptr[q + 1]; ++e) {        // members of R1 only, in entry order
-                    const int p = bits_pos(mb, col[e]);
-                    if (p >= 0) dz = fma4(val[e], ld4(items + (size_t)p * Hp2 + coff), dz);
+            const uint2 *mb = bits1 + (size_t)b * words;
+            const float *items = dS2x + (size_t)off[b] * Hp2;
+            f32x4 dz = {0.f, 0.f, 0.f, 0.f};
+            // (round 6) the group's lanes look up LPR entries of the row side by side (column, membership word: two trips for the
+            // stretch instead of two per entry -- the 18 dependent pairs of an average row were this launch's 94 us), then the members'
+            // items are added in entry order: the same chain
+            const int e_end = rowptr[q + 1], gbase = lane & ~(LPR - 1);
+            for (int e0 = rowptr[q]; e0 < e_end; e0 += LPR) {            // (group-uniform)
+                const int e = e0 + gl;
+                int p = -1;
+                float a = 0.f;
+                if (e < e_end) {
+                    p = bits_pos(mb, col[e]);
+                    a = val[e];
                 }
+                unsigned long long hits = __ballot(p >= 0) >> gbase;
+                if (LPR < 64) hits &= (1ull << LPR) - 1ull;
+                while (hits) {                                           // members of R1 only, in entry order (group-uniform)
+                    const int k = __ffsll((long long)hits) - 1;
+                    hits &= hits - 1ull;
+                    const int pk = __shfl(p, gbase + k, 64);
+                    const float ak = __shfl(a, gbase + k, 64);
+                    if (active) dz = fma4(ak, ld4(items + (size_t)pk * Hp2 + coff), dz);
+                }
+            }
+            if (active) {
                 const double *zp = Z2d + (size_t)q * Hp2 + coff;
                 float dh[4];
 #pragma unroll
