@@ -1219,7 +1219,10 @@ static __global__ void k_y_long(int n_long, const int32_t *__restrict__ long_row
 // C[row(i), 0..N) = A[rows[i], 0..K) * B[K, N] (+ bias), i < M, on v_mfma_f64_16x16x4_f64: 64 x 64 tiles, a fixed grid
 // walking the tiles (M may live on the device).  AT = double (the aggregated rows) or float (feature rows, widened).
 // scatter: 1 = row(i) = rows[i] (results land at the node's row), 0 = row(i) = i.  state != NULL: state[rows[i]] = 1.
-template <typename AT>
+// PF: k-steps whose global loads go out together (1: a step's loads, then its MFMAs -- every step pays a round trip; 4 for launches of
+// few tiles, where nothing else hides it: GCN3's S2d = relu(Z1d) W2 is 69 tiles on 256 CUs, 33.5 -> 27.7 us; a wave per row with W2 in
+// LDS and v_readlane broadcasts measured 48 us: instruction-bound).  Same accumulation order.
+template <typename AT, int PF = 1>
 __global__ __launch_bounds__(256) void k_gemm_f64_rows(const AT *__restrict__ A, long lda, const int32_t *__restrict__ rows,
                                                        const int32_t *__restrict__ m_dev, int m_host,
                                                        const float *__restrict__ B, long ldb, int N, int K,
@@ -1246,32 +1249,42 @@ __global__ __launch_bounds__(256) void k_gemm_f64_rows(const AT *__restrict__ A,
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
-        for (int k0 = 0; k0 < K; k0 += GD_BK) {
-            double ra[4] = {0.0, 0.0, 0.0, 0.0};
-            float rb[4] = {0.f, 0.f, 0.f, 0.f};
-            if (a_ok)
+        for (int k00 = 0; k00 < K; k00 += GD_BK * PF) {
+            double ra[PF][4];
+            float rb[PF][4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (k0 + a_col + j < K) { const double v = (double)ap[k0 + a_col + j]; ra[j] = (relu_a && v < 0.0) ? 0.0 : v; }
-            if (k0 + b_row < K)
+            for (int s_ = 0; s_ < PF; ++s_) {
+                const int k0 = k00 + s_ * GD_BK;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (n0 + b_col + j < N) rb[j] = B[(size_t)(k0 + b_row) * ldb + n0 + b_col + j];
-            __syncthreads();   // the previous k-step's fragment reads are done
+                for (int j = 0; j < 4; ++j) { ra[s_][j] = 0.0; rb[s_][j] = 0.f; }
+                if (a_ok)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                As[a_row * GD_LDA + a_col + j] = ra[j];
-                Bs[b_row * GD_LDB + b_col + j] = rb[j];
+                    for (int j = 0; j < 4; ++j)
+                        if (k0 + a_col + j < K) { const double v = (double)ap[k0 + a_col + j]; ra[s_][j] = (relu_a && v < 0.0) ? 0.0 : v; }
+                if (k0 + b_row < K)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (n0 + b_col + j < N) rb[s_][j] = B[(size_t)(k0 + b_row) * ldb + n0 + b_col + j];
             }
-            __syncthreads();
 #pragma unroll
-            for (int kk = 0; kk < GD_BK; kk += 4) {
-                const double a0 = As[a_frag + kk], a1 = As[a_frag + 16 * GD_LDA + kk];
-                const double b0 = (double)Bs[b_frag + kk * GD_LDB], b1 = (double)Bs[b_frag + kk * GD_LDB + 16];
-                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            for (int s_ = 0; s_ < PF; ++s_) {
+                if (k00 + s_ * GD_BK >= K) break;      // (block-uniform)
+                __syncthreads();   // the previous k-step's fragment reads are done
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    As[a_row * GD_LDA + a_col + j] = ra[s_][j];
+                    Bs[b_row * GD_LDB + b_col + j] = rb[s_][j];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int kk = 0; kk < GD_BK; kk += 4) {
+                    const double a0 = As[a_frag + kk], a1 = As[a_frag + 16 * GD_LDA + kk];
+                    const double b0 = (double)Bs[b_frag + kk * GD_LDB], b1 = (double)Bs[b_frag + kk * GD_LDB + 16];
+                    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+                }
             }
         }
         // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
@@ -1590,8 +1603,12 @@ int lt_launch_gemm_f64_dense(const double *A, long lda, int M, const float *B, l
                              double *C, long ldc, int relu_a, hipStream_t st) {
     if (M <= 0) return LT_OK;
     const long tiles = (long)((M + GD_BM - 1) / GD_BM) * ((N + GD_BN - 1) / GD_BN);
-    hipLaunchKernelGGL((k_gemm_f64_rows<double>), dim3((unsigned)(tiles < 4096 ? tiles : 4096)), dim3(256), 0, st, A, lda,
-                       (const int32_t *)nullptr, (const int32_t *)nullptr, M, B, ldb, N, K, bias, C, ldc, 0, (int32_t *)nullptr, relu_a);
+    if (tiles < 512)       // (less than two tiles per CU: nothing but the loads' own depth hides their round trips)
+        hipLaunchKernelGGL((k_gemm_f64_rows<double, 4>), dim3((unsigned)tiles), dim3(256), 0, st, A, lda,
+                           (const int32_t *)nullptr, (const int32_t *)nullptr, M, B, ldb, N, K, bias, C, ldc, 0, (int32_t *)nullptr, relu_a);
+    else
+        hipLaunchKernelGGL((k_gemm_f64_rows<double>), dim3((unsigned)(tiles < 4096 ? tiles : 4096)), dim3(256), 0, st, A, lda,
+                           (const int32_t *)nullptr, (const int32_t *)nullptr, M, B, ldb, N, K, bias, C, ldc, 0, (int32_t *)nullptr, relu_a);
     LT_CHECK_LAUNCH();
     return LT_OK;
 }
