@@ -1350,9 +1350,14 @@ int lt_fp64_prepare_items(const lt_baseline *b, const int32_t *off, int nb, cons
     lt_prof_scope prof_(LT_K_FP64_PRODUCT, st);
     if (Hp != H) LT_HIP(hipMemsetAsync(Spd, 0, (size_t)nb * Hp * sizeof(double), st));
     const int tiles = ((nb + GD_BM - 1) / GD_BM) * ((H + GD_BN - 1) / GD_BN);
-    hipLaunchKernelGGL((k_gemm_f64_rows<float>), dim3((unsigned)(tiles < 2048 ? tiles : 2048)), dim3(256), 0, st, b->X, (long)b->ldx,
-                       probes, (const int32_t *)nullptr, nb, b->W1, (long)H, H, F, (const float *)nullptr, Spd, (long)Hp, 0,
-                       (int32_t *)nullptr, 0);
+    if (tiles < 512)       // (few tiles: four k-steps' loads in flight, see k_gemm_f64_rows)
+        hipLaunchKernelGGL((k_gemm_f64_rows<float, 4>), dim3((unsigned)tiles), dim3(256), 0, st, b->X, (long)b->ldx,
+                           probes, (const int32_t *)nullptr, nb, b->W1, (long)H, H, F, (const float *)nullptr, Spd, (long)Hp, 0,
+                           (int32_t *)nullptr, 0);
+    else
+        hipLaunchKernelGGL((k_gemm_f64_rows<float>), dim3((unsigned)(tiles < 2048 ? tiles : 2048)), dim3(256), 0, st, b->X, (long)b->ldx,
+                           probes, (const int32_t *)nullptr, nb, b->W1, (long)H, H, F, (const float *)nullptr, Spd, (long)Hp, 0,
+                           (int32_t *)nullptr, 0);
     LT_CHECK_LAUNCH();
     return LT_OK;
 }
@@ -1643,8 +1648,12 @@ int lt_launch_gemm_f64_gather(const float *A, long lda, const int32_t *rows, int
                               double *C, long ldc, hipStream_t st) {
     if (M <= 0) return LT_OK;
     const long tiles = (long)((M + GD_BM - 1) / GD_BM) * ((N + GD_BN - 1) / GD_BN);
-    hipLaunchKernelGGL((k_gemm_f64_rows<float>), dim3((unsigned)(tiles < 4096 ? tiles : 4096)), dim3(256), 0, st, A, lda, rows,
-                       (const int32_t *)nullptr, M, B, ldb, N, K, (const float *)nullptr, C, ldc, 0, (int32_t *)nullptr, 0);
+    if (tiles < 512)
+        hipLaunchKernelGGL((k_gemm_f64_rows<float, 4>), dim3((unsigned)tiles), dim3(256), 0, st, A, lda, rows,
+                           (const int32_t *)nullptr, M, B, ldb, N, K, (const float *)nullptr, C, ldc, 0, (int32_t *)nullptr, 0);
+    else
+        hipLaunchKernelGGL((k_gemm_f64_rows<float>), dim3((unsigned)(tiles < 4096 ? tiles : 4096)), dim3(256), 0, st, A, lda, rows,
+                           (const int32_t *)nullptr, M, B, ldb, N, K, (const float *)nullptr, C, ldc, 0, (int32_t *)nullptr, 0);
     LT_CHECK_LAUNCH();
     return LT_OK;
 }
