@@ -307,6 +307,12 @@ __global__ __launch_bounds__(LT_BLOCK) void k3d_stageB(
     const int total = *n_items2;
     const int wave0 = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
     const int nwaves = gridDim.x * (LT_BLOCK / 64);
+    // (the lane's rows of W3 do not depend on the item: read once)
+    float w3r[4][CP];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < CP; ++c) w3r[k][c] = (active && c < C) ? W3p[(size_t)(coff + k) * C + c] : 0.f;
     for (int base = wave0 * RPW; base < total; base += nwaves * RPW) {
         const int it = base + lane / LPR;
         const bool live = it < total;   // group-uniform; dead groups still join the shuffles
@@ -320,6 +326,13 @@ __global__ __launch_bounds__(LT_BLOCK) void k3d_stageB(
             const uint2 *mb = bits1 + (size_t)b * words;
             const float *items = dS2x + (size_t)off[b] * Hp2;
             f32x4 dz = {0.f, 0.f, 0.f, 0.f};
+            // (the row's fp64 pre-activation goes out in front of the look-ups: nothing in them depends on it)
+            double zq[4] = {0.0, 0.0, 0.0, 0.0};
+            if (active) {
+                const double2 z01 = *reinterpret_cast<const double2 *>(Z2d + (size_t)q * Hp2 + coff);
+                const double2 z23 = *reinterpret_cast<const double2 *>(Z2d + (size_t)q * Hp2 + coff + 2);
+                zq[0] = z01.x; zq[1] = z01.y; zq[2] = z23.x; zq[3] = z23.y;
+            }
             // (round 6) the group's lanes look up LPR entries of the row side by side (column, membership word: two trips for the
             // stretch instead of two per entry -- the 18 dependent pairs of an average row were this launch's 94 us), then the members'
             // items are added in entry order: the same chain
@@ -343,18 +356,16 @@ __global__ __launch_bounds__(LT_BLOCK) void k3d_stageB(
                 }
             }
             if (active) {
-                const double *zp = Z2d + (size_t)q * Hp2 + coff;
                 float dh[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) dh[k] = relu_diff(zp[k], dz[k]);
-                const float *w3 = W3p + (size_t)coff * C;
+                for (int k = 0; k < 4; ++k) dh[k] = relu_diff(zq[k], dz[k]);
 #pragma unroll
                 for (int c = 0; c < CP; ++c)
                     if (c < C) {
-                        float pr = dh[0] * w3[c];
-                        pr = fmaf(dh[1], w3[C + c], pr);
-                        pr = fmaf(dh[2], w3[2 * C + c], pr);
-                        pr = fmaf(dh[3], w3[3 * C + c], pr);
+                        float pr = dh[0] * w3r[0][c];
+                        pr = fmaf(dh[1], w3r[1][c], pr);
+                        pr = fmaf(dh[2], w3r[2][c], pr);
+                        pr = fmaf(dh[3], w3r[3][c], pr);
                         part[c] = pr;
                     }
             }
