@@ -394,26 +394,19 @@ __global__ __launch_bounds__(LT_BLOCK) void k3d_stageC(
     const float *mine = dS3x + (size_t)b * n * C;
     const int e0 = rowptr[u], e1 = rowptr[u + 1];
     auto member = [&](int c) { return ((mb[c >> 5] >> (c & 31)) & 1u) != 0u; };
-    bool touch = false;
-    for (int e = e0 + q; e < e1; e += LT_L2_LANES) touch |= member(col[e]);
-    int t = touch ? 1 : 0;
+    // (round 6: no pass over the row in front that only asks whether any entry is a member -- three hops reach most pairs at twitch
+    // size, and a pair nothing reaches comes out of the sums as +0 all the same: 0 / delta, fma, sqrt)
+    float acc[CP];
+    row2_dot<CP>(col, val, e0, e1, q, C,
+                 [&](int c, int) { return member(c) ? mine + (size_t)c * C : (const float *)nullptr; }, acc);
+    float ss = 0.f;
 #pragma unroll
-    for (int m = LT_L2_LANES / 2; m >= 1; m >>= 1) t |= __shfl_xor(t, m, 64);
-    float res = 0.f;
-    if (t) {
-        float acc[CP];
-        row2_dot<CP>(col, val, e0, e1, q, C,
-                     [&](int c, int) { return member(c) ? mine + (size_t)c * C : (const float *)nullptr; }, acc);
-        float ss = 0.f;
-#pragma unroll
-        for (int c = 0; c < CP; ++c)
-            if (c < C) {
-                const float d = acc[c] / delta;
-                ss = fmaf(d, d, ss);
-            }
-        res = sqrtf(ss);
-    }
-    if (q == 0) out[(long)b * ldo + j] = res;
+    for (int c = 0; c < CP; ++c)
+        if (c < C) {
+            const float d = acc[c] / delta;
+            ss = fmaf(d, d, ss);
+        }
+    if (q == 0) out[(long)b * ldo + j] = sqrtf(ss);
 }
 
 __global__ void k3_pad(const float *__restrict__ b1, int H1, int Hp1, const float *__restrict__ b2, int H2, int Hp2,
