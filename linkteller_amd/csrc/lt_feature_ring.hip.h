@@ -46,24 +46,7 @@ template <int N> __device__ __forceinline__ void fr_wait() { asm volatile("s_wai
 
 typedef __attribute__((address_space(3))) void *fr_lds_ptr_t;
 
-// max over the wave's 64 lanes (DPP inside a row of 16, the four rows by v_readlane): ~12 VALU instead of six ds_bpermute round trips
-__device__ __forceinline__ unsigned fr_wave_max_u32(unsigned v) {
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));      // quad_perm [1,0,3,2]
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));      // quad_perm [2,3,0,1]
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));     // row_half_mirror
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true));     // row_mirror
-    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
-    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
-    return max(max(a, b), max(c, d));
-}
-// the largest of 64 non-negative finite doubles, exactly (their bit patterns order as integers: high words first, then the low
-// words of the lanes that hold the largest high word)
-__device__ __forceinline__ double fr_wave_max_nonneg(double v) {
-    const unsigned hi = (unsigned)__double2hiint(v), lo = (unsigned)__double2loint(v);
-    const unsigned mh = fr_wave_max_u32(hi);
-    const unsigned ml = fr_wave_max_u32(hi == mh ? lo : 0u);
-    return __hiloint2double((int)mh, (int)ml);
-}
+// (fr_wave_max_u32 / fr_wave_max_nonneg: lt_fp64.hip, in front of k_s1d_feature_rows, which takes its row maximum the same way)
 
 #define FR_SLOTS 6
 #ifdef LT_FR_TRACE      // tools/read_lab/ring_lab.hip: stamps of every wave's rows on the constant 100 MHz clock

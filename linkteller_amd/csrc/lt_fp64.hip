@@ -668,6 +668,24 @@ __device__ __forceinline__ void fd_slab_block(unsigned char *fd_smem, int nslab,
         if (threadIdx.x == 0) __hip_atomic_store(gate, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         return;
     }
+// max over the wave's 64 lanes (DPP inside a row of 16, the four rows by v_readlane): ~12 VALU instead of six ds_bpermute round trips
+__device__ __forceinline__ unsigned fr_wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));      // quad_perm [1,0,3,2]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));      // quad_perm [2,3,0,1]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));     // row_half_mirror
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true));     // row_mirror
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
+}
+// the largest of 64 non-negative finite doubles, exactly (their bit patterns order as integers: high words first, then the low
+// words of the lanes that hold the largest high word)
+__device__ __forceinline__ double fr_wave_max_nonneg(double v) {
+    const unsigned hi = (unsigned)__double2hiint(v), lo = (unsigned)__double2loint(v);
+    const unsigned mh = fr_wave_max_u32(hi);
+    const unsigned ml = fr_wave_max_u32(hi == mh ? lo : 0u);
+    return __hiloint2double((int)mh, (int)ml);
+}
 template <int VEC, bool ONE>
 __global__ __launch_bounds__(64 * FD_WAVES, FD_MIN_WAVES) void k_s1d_feature_rows(
     int n, int F, int H, int Hp, const float *__restrict__ X, long ldx, const float *__restrict__ ref,
@@ -926,9 +944,9 @@ __global__ __launch_bounds__(64 * FD_WAVES, FD_MIN_WAVES) void k_s1d_feature_row
         // against the row's largest value instead of fp32's 24 against each value, in the same 4 bytes.  What the readers sum is
         // A_hat[r, c] * value: an ABSOLUTE error per term is what reaches a pre-activation, and plain fp32 rows reached the result
         // as up to 7e-5 of the largest score where a hidden unit sat within dz of its kink (tools/fuzz_gpu.py 60 31337).
-        double mx = fmax(fmax(fabs(o[0]), fabs(o[1])), fmax(fabs(o[2]), fabs(o[3])));
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) mx = fmax(mx, __shfl_xor(mx, m, 64));
+        // (the wave's maximum by DPP on the two 32-bit halves, as the ring kernel takes it: six xor-shuffles of a double are twelve
+        // ds_bpermute round trips in every wave's tail)
+        const double mx = fr_wave_max_nonneg(fmax(fmax(fabs(o[0]), fabs(o[1])), fmax(fabs(o[2]), fabs(o[3]))));
         const double scale = mx > 0.0 ? mx * (1.0 / 2147483000.0) : 1.0;
         const double inv = 1.0 / scale;
         int q[4];
