@@ -107,6 +107,10 @@ int lt_device_count(int *count);
  *                         they do and the matrix has at least "feature_ring_min_rows" rows.  fp64 summation order only (as with
  *                         the "feature_delta" knob); a probe chunk's record blocks then ride in the pre-activation's launch
  *   "feature_ring_min_rows"   see "feature_ring" (default 1024, >= 2)
+ *   "pair_list"           SPARSE / DELTA stage B on calls that find their affected pairs by the join over the middle nodes ("pair_marks"): 1 = the
+ *                         marked pairs are compacted into a list, the result rows zero-filled, and the pair kernel walks the list (default;
+ *                         calls whose list would exceed 256 MiB keep the other form), 0 = every pair's lane group reads its own mark.
+ *                         Bit-identical
  *   "gcn3_product_gather" lt_influence3_rows, LT_MODE_DELTA: 1 = the probes' fp64 product rows X[v] W1 are read off the product the baseline
  *                         already holds for every row (default), 0 = formed again on the f64 matrix cores (as on the aggregate-first
  *                         route).  fp64 summation order / storage only: results agree to < 1e-6 of the largest score

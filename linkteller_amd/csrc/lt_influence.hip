@@ -1870,34 +1870,19 @@ static int df_allow_big_lds() {
     return LT_OK;
 }
 
-// SPARSE / DELTA stage B: 8 lanes per (probe, observed node).
+// one (probe, observed node) pair of SPARSE / DELTA stage B by its 8-lane group (k_item_stageB: gid from the grid; k_item_stageB_list:
+// from the list of marked pairs)
 template <int CP, bool DELTA>
-__global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
+__device__ __forceinline__ void item_stageB_pair(const long gid, const int q,
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const int32_t *__restrict__ tptr,
     const int32_t *__restrict__ trow, const float *__restrict__ S2, int C,
     const float *__restrict__ b2, const float *__restrict__ OUT,
     const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
     const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
-    float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words, int long_blocks, int skip_long,
+    float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words, int skip_long,
     const unsigned *__restrict__ marks, const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot,
-    int hub_short, const int32_t *__restrict__ hub_obs, float *__restrict__ vec) {
-    // long_blocks > 0 (the graph has hub rows): the first long_blocks blocks serve the observed hubs
-    // (stageB_long_block: most of them find a plain row and exit); skip_long: the pairs below leave those rows alone
-    // (SPARSE with the short-side search: k_item_stageB_hubs has them, long_blocks = 0 here)
-    // (DELTA: always k_item_stageB_hubs -- its hub block keeps 32 membership tests in flight per lane, 211 VGPRs, which as
-    // part of this kernel cost the pairs of a large call their occupancy: 0.88 -> 1.25 ms at BASELINE configs[4])
-    if constexpr (!DELTA) {
-        if ((int)blockIdx.x < long_blocks) {
-            stageB_long_block<CP, DELTA, false>((int)blockIdx.x, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off,
-                                                S2x, observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot, hub_obs,
-                                                long_blocks / ((nb + LT_BLOCK / LT_L2_LANES - 1) / (LT_BLOCK / LT_L2_LANES)), vec);
-            return;
-        }
-    }
-    const long gid = ((long)(blockIdx.x - long_blocks) * LT_BLOCK + threadIdx.x) / LT_L2_LANES;
-    const int q = threadIdx.x & (LT_L2_LANES - 1);
-    if (gid >= (long)nb * n_obs) return;
+    float *__restrict__ vec) {
     const int b = (int)(gid / n_obs), j = (int)(gid % n_obs);
     const int u = observe[j];
     const int v = probes[b];
@@ -1956,6 +1941,98 @@ __global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
         out[(long)b * ldo + j] = res;
         if (vec) store_diff_vec<CP>(vec, (long)b * ldo + j, C, acc, b2, DELTA ? (const float *)nullptr : OUT + (size_t)u * C, t != 0);
     }
+}
+
+
+// SPARSE / DELTA stage B: 8 lanes per (probe, observed node).
+template <int CP, bool DELTA>
+__global__ __launch_bounds__(LT_BLOCK) void k_item_stageB(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const int32_t *__restrict__ tptr,
+    const int32_t *__restrict__ trow, const float *__restrict__ S2, int C,
+    const float *__restrict__ b2, const float *__restrict__ OUT,
+    const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
+    const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
+    float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words, int long_blocks, int skip_long,
+    const unsigned *__restrict__ marks, const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot,
+    int hub_short, const int32_t *__restrict__ hub_obs, float *__restrict__ vec) {
+    // long_blocks > 0 (the graph has hub rows): the first long_blocks blocks serve the observed hubs
+    // (stageB_long_block: most of them find a plain row and exit); skip_long: the pairs below leave those rows alone
+    // (SPARSE with the short-side search: k_item_stageB_hubs has them, long_blocks = 0 here)
+    // (DELTA: always k_item_stageB_hubs -- its hub block keeps 32 membership tests in flight per lane, 211 VGPRs, which as
+    // part of this kernel cost the pairs of a large call their occupancy: 0.88 -> 1.25 ms at BASELINE configs[4])
+    if constexpr (!DELTA) {
+        if ((int)blockIdx.x < long_blocks) {
+            stageB_long_block<CP, DELTA, false>((int)blockIdx.x, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off,
+                                                S2x, observe, n_obs, delta, out, ldo, bits, words, big_bits, big_slot, hub_obs,
+                                                long_blocks / ((nb + LT_BLOCK / LT_L2_LANES - 1) / (LT_BLOCK / LT_L2_LANES)), vec);
+            return;
+        }
+    }
+    const long gid = ((long)(blockIdx.x - long_blocks) * LT_BLOCK + threadIdx.x) / LT_L2_LANES;
+    const int q = threadIdx.x & (LT_L2_LANES - 1);
+    if (gid >= (long)nb * n_obs) return;
+    item_stageB_pair<CP, DELTA>(gid, q, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off, S2x, observe, n_obs, delta, out, ldo,
+                                bits, words, skip_long, marks, big_bits, big_slot, vec);
+}
+
+// The same over a LIST of pairs (round 6): calls that find their affected pairs by the join over the middle nodes (pair marks) leave
+// 90+ % of their pairs unmarked, and a wave of k_item_stageB holds 8 pairs of which one marked pair makes the whole wave wait for its
+// chains -- 44 % of the waves of a `balanced-full` chunk, 342 us.  k_pm_compact turns the marks into the list of marked pairs, `out`
+// is zero-filled by a memset, and the marked pairs are walked 8 to a wave: the same per-pair code, the same bits.
+static __global__ __launch_bounds__(256) void k_pm_compact(const unsigned *__restrict__ marks, long n_words, int32_t *__restrict__ pairs,
+                                                           int32_t *__restrict__ n_pairs) {
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (long w0 = (long)blockIdx.x * 256; w0 < n_words; w0 += (long)gridDim.x * 256) {       // (block-uniform)
+        const long w = w0 + threadIdx.x;
+        unsigned m = w < n_words ? marks[w] : 0u;
+        const int cnt = __popc(m);
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) s_wave[wid] = incl;
+        __syncthreads();
+        int before = 0, all = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            before += k < wid ? s_wave[k] : 0;
+            all += s_wave[k];
+        }
+        if (all > 0 && threadIdx.x == 0) s_base = atomicAdd(n_pairs, all);
+        __syncthreads();
+        if (cnt > 0) {
+            int pos = s_base + before + incl - cnt;
+            while (m) {
+                const int bit = __ffs((int)m) - 1;
+                m &= m - 1u;
+                pairs[pos++] = (int32_t)(w * 32 + bit);
+            }
+        }
+        __syncthreads();
+    }
+}
+template <int CP, bool DELTA>
+__global__ __launch_bounds__(LT_BLOCK) void k_item_stageB_list(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const int32_t *__restrict__ tptr,
+    const int32_t *__restrict__ trow, const float *__restrict__ S2, int C,
+    const float *__restrict__ b2, const float *__restrict__ OUT,
+    const int32_t *__restrict__ probes, int nb, const int32_t *__restrict__ off,
+    const float *__restrict__ S2x, const int32_t *__restrict__ observe, int n_obs, float delta,
+    float *__restrict__ out, long ldo, const uint2 *__restrict__ bits, int words, int skip_long,
+    const unsigned *__restrict__ marks, const uint2 *__restrict__ big_bits, const int32_t *__restrict__ big_slot,
+    float *__restrict__ vec, const int32_t *__restrict__ pairs, const int32_t *__restrict__ n_pairs) {
+    const int total = *n_pairs;
+    const int q = threadIdx.x & (LT_L2_LANES - 1);
+    const int groups = (int)gridDim.x * (LT_BLOCK / LT_L2_LANES);
+    for (int idx = ((int)blockIdx.x * LT_BLOCK + threadIdx.x) / LT_L2_LANES; idx < total; idx += groups)
+        item_stageB_pair<CP, DELTA>((long)pairs[idx], q, rowptr, col, val, tptr, trow, S2, C, b2, OUT, probes, nb, off, S2x, observe, n_obs,
+                                    delta, out, ldo, bits, words, skip_long, marks, big_bits, big_slot, vec);
 }
 
 // SPARSE / DELTA stage B, calls with a bitmap row per probe (twitch size): one block per (observed node, slice of the
@@ -2261,6 +2338,7 @@ struct infl_ws {
     int2 *item_va;         // DELTA: (probe node, A_hat[row, probe node] as bits) of every item
     int32_t *pm_cnt, *pm_start, *pm_rank, *pm_list;   // SPARSE / DELTA pair marks: per-node lists of observed nodes (lt_items.hip.h)
     unsigned *pm_marks;    // SPARSE / DELTA: one bit per (probe of the chunk, observed node)
+    int32_t *pm_pairs, *pm_npairs;   // the marked pairs of a chunk as a list (k_pm_compact) + its length; NULL: beyond LT_PM_LIST_MAX_BYTES
     uint2 *big_bits;       // SPARSE / DELTA without `bits`: bitmap rows of the chunk's big probes [LT_BIG_SLOTS][ceil(n / 32)]
     int32_t *big_slot;     // [chunk + 1] slot of each probe (-1: none) + the slot counter
     uint2 *bits;           // SPARSE / DELTA: membership bitmap + positions of R_v per probe [chunk][ceil(n / 32)], or NULL (huge graphs)
@@ -2330,6 +2408,12 @@ static infl_ws carve_infl(void *base, const lt_baseline *b, int n_probe, int n_o
             w.pm_rank = (int32_t *)take(slots * sizeof(int32_t));
             w.pm_list = (int32_t *)take(slots * sizeof(int32_t));
             w.pm_marks = (unsigned *)take((chunk * (size_t)(n_obs > 0 ? n_obs : 1) + 31) / 32 * sizeof(unsigned));
+            // (the list of marked pairs, 4 bytes per pair of a chunk in the worst case: kept to calls where that stays modest)
+            const size_t pl = chunk * (size_t)(n_obs > 0 ? n_obs : 1) * sizeof(int32_t);
+            if (lt_tune().pair_list != 0 && pl <= ((size_t)256 << 20) && chunk * (size_t)(n_obs > 0 ? n_obs : 1) < 2147483647ull) {
+                w.pm_npairs = (int32_t *)take(sizeof(int32_t));
+                w.pm_pairs = (int32_t *)take(pl);
+            }
         }
     }
     w.bytes = offb;
@@ -2630,6 +2714,7 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
             // item offsets, the (probe, row) table of the items and the membership bitmap, one block per probe
             if (w.big_slot) LT_HIP(hipMemsetAsync(w.big_slot + w.chunk, 0, sizeof(int32_t), st));
             const unsigned *marks = nullptr;
+            bool pair_list = false;        // this chunk's marked pairs are a list (k_pm_compact)
             // DELTA on an S1d route whose pre-activation is still to be formed, all rows at once: the item tables ride in that
             // launch (lt_fp64_prepare_rows); otherwise -- and always in SPARSE -- a launch of their own
             {
@@ -2724,6 +2809,16 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
                                    w.pm_list, n_obs, w.pm_marks);
                 LT_CHECK_LAUNCH();
                 marks = w.pm_marks;
+                // the marked pairs as a list, `out` zero-filled: the pair kernel then walks the list (k_item_stageB_list)
+                pair_list = w.pm_pairs != nullptr && vrow == nullptr;
+                if (pair_list) {
+                    LT_HIP(hipMemsetAsync(w.pm_npairs, 0, sizeof(int32_t), st));
+                    const long n_words = (pairs + 31) / 32;
+                    hipLaunchKernelGGL(k_pm_compact, dim3((unsigned)std::min<long>((n_words + 255) / 256, 4096)), dim3(256), 0, st, marks,
+                                       n_words, w.pm_pairs, w.pm_npairs);
+                    LT_CHECK_LAUNCH();
+                    LT_HIP(hipMemset2DAsync(orow, (size_t)ldo * sizeof(float), 0, (size_t)n_obs * sizeof(float), (size_t)nb, st));
+                }
             } }
             if (mode == LT_MODE_SPARSE) {
                 { lt_prof_scope prof_(LT_K_ITEM_A, st);
@@ -2758,6 +2853,20 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
                                                            dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, b->S2, C, b->b2,
                                                            b->OUT, nb, w.off, w.S2x, observe_nodes, n_obs, delta, orow, (long)ldo,
                                                            w.bits, words, psplit));
+                } else if (pair_list) {
+                    if (inl > 0) {       // the observed hubs: the hub blocks of the pair kernel, launched without its pairs
+                        LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, false>), dim3(inl), dim3(LT_BLOCK), 0, st,
+                                                               g->rowptr, g->col, g->val, g->tptr, g->trow, b->S2, C, b->b2,
+                                                               b->OUT, probes, nb, w.off, w.S2x, observe_nodes, n_obs, delta,
+                                                               orow, (long)ldo, w.bits, words, (int)inl, 1, marks, w.big_bits,
+                                                               w.big_slot, 0, w.hub_obs, vrow));
+                        LT_CHECK_LAUNCH();
+                    }
+                    LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_list<CP_, false>), dim3(LT_ITEM_GRID), dim3(LT_BLOCK), 0, st,
+                                                           g->rowptr, g->col, g->val, g->tptr, g->trow, b->S2, C, b->b2, b->OUT,
+                                                           probes, nb, w.off, w.S2x, observe_nodes, n_obs, delta, orow, (long)ldo,
+                                                           w.bits, words, long_blocks > 0 ? 1 : 0, marks, w.big_bits, w.big_slot,
+                                                           vrow, w.pm_pairs, w.pm_npairs));
                 } else
                 LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, false>), dim3(gridB + inl),
                                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,
@@ -2827,6 +2936,12 @@ static int influence_rows_impl(const lt_baseline *b, const int32_t *probe_nodes,
                                                            dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val, b->S2, C, b->b2,
                                                            b->OUT, nb, w.off, w.S2x, observe_nodes, n_obs, delta, orow, (long)ldo,
                                                            w.bits, words, psplit, (int)hb, g->tptr, g->trow, probes, w.hub_obs));
+                } else if (pair_list) {
+                LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB_list<CP_, true>), dim3(LT_ITEM_GRID), dim3(LT_BLOCK), 0, st,
+                                                       g->rowptr, g->col, g->val, g->tptr, g->trow, b->S2, C, b->b2, b->OUT,
+                                                       probes, nb, w.off, w.S2x, observe_nodes, n_obs, delta, orow, (long)ldo,
+                                                       w.bits, words, long_blocks > 0 ? 1 : 0, marks, w.big_bits, w.big_slot, vrow,
+                                                       w.pm_pairs, w.pm_npairs));
                 } else
                 LT_DISPATCH_CP(cp, hipLaunchKernelGGL((k_item_stageB<CP_, true>), dim3(gridB),
                                                        dim3(LT_BLOCK), 0, st, g->rowptr, g->col, g->val,

@@ -181,6 +181,8 @@ struct lt_tuning {
     int feature_flags;           // the row-per-wave kernel lists a row's differing columns from flag bits (1, default: the kernel is bound by
                                  // the issue of its 52 compare steps -- 24.8 against 25.4 us by events, profiles/r06_feat_lab_timeline.txt) or by
                                  // a ballot per value (0: round 5's list order) (LT_FEATURE_FLAGS)
+    int pair_list;               // SPARSE / DELTA stage B with pair marks: 1 the marked pairs are compacted into a list and walked 8 to a wave (default),
+                                 // 0 every pair's group reads its mark (LT_PAIR_LIST)
     int gcn3_product_gather;     // GCN3 `delta`: 1 the probes' fp64 product rows are read off the inner baseline's product (default), 0 formed again
                                  // as X[probes] W1 on the f64 cores (LT_GCN3_PRODUCT_GATHER)
     int export_sparse;           // lt_influence_rows_f64, fused route behind a refresh: 1 the first "export_zero_share" % rows of the float64

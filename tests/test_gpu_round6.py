@@ -489,3 +489,52 @@ def test_zero_filled_head_never_overtakes_the_values(gpu):
         cur.synchronize()
         bad += int(not np.array_equal(host.numpy(), want))
     assert bad == 0, f"{bad} of 3000 host matrices differ"
+
+
+@pytest.mark.parametrize("mode", ["sparse", "delta"])
+def test_marked_pairs_as_a_list_give_the_per_pair_bits(gpu, mode):
+    """"pair_list": calls that find their affected pairs by the join over the middle nodes compact the marks into a list, zero-fill the
+    rows and walk the list 8 pairs to a wave -- the matrix of the form in which every pair's lane group reads its own mark, and of
+    the bitmap route; hub rows on both sides, several chunks, a leading dimension wider than the row."""
+    from linkteller_amd import _lib, engine, graph, synth
+    n, f, h = 3000, 128, 64
+    adj = synth.powerlaw_graph(n, 30000, seed=5)
+    hg = graph.HipGraph(graph.first_order_gcn(adj))
+    deg = np.diff(graph.first_order_gcn(adj).tocsr().indptr)
+    x = torch.from_numpy(synth.twitch_like_features(n, f, seed=2, density=0.05)).to(gpu)
+    w = synth.gcn_weights(f, h, 2, seed=3)
+    base = engine.Baseline(hg, x, *_params(w, gpu))
+    rng = np.random.RandomState(4)
+    hubs = np.argsort(-deg)[:5]
+    obs = np.unique(np.concatenate([hubs, rng.choice(n, 700, replace=False)])).astype(np.int32)
+    probes = np.concatenate([hubs[:2], rng.choice(n, 150, replace=False)]).astype(np.int32)
+
+    def run(**knobs):
+        for k, v in knobs.items():
+            _lib.set_tuning(k, v)
+        try:
+            base.refresh(mode)
+            return base.influence_rows(probes, obs, 1e-4, mode).cpu().numpy()
+        finally:
+            for k in knobs:
+                _lib.set_tuning(k, None)
+
+    want = run(pair_marks=-1)                                   # no marks: the bitmap route
+    for knobs in ({"pair_marks": 0, "pair_list": 0}, {"pair_marks": 0, "pair_list": 1}, {"pair_marks": 0, "pair_list": 1, "item_bits": 0},
+                  {"pair_marks": 0, "pair_list": 1, "chunk_budget_bytes": 1 << 16}):
+        assert np.array_equal(run(**knobs), want), knobs
+    assert (want > 0).any() and (want == 0).any()
+    # a result matrix wider than the row: the columns past n_obs are left alone
+    wide = torch.full((len(probes), len(obs) + 3), -1.0, dtype=torch.float32, device=gpu)
+    _lib.set_tuning("pair_marks", 0)
+    try:
+        base.refresh(mode)
+        pt = torch.from_numpy(probes).to(gpu)
+        ot = torch.from_numpy(obs).to(gpu)
+        ws = engine._workspace(_lib.lib().lt_influence_workspace_bytes(base._h, len(probes), len(obs), _lib.MODES[mode]), gpu)
+        _lib.check(_lib.lib().lt_influence_rows(base._h, pt.data_ptr(), len(probes), ot.data_ptr(), len(obs), 1e-4, _lib.MODES[mode],
+                                                wide.data_ptr(), len(obs) + 3, ws.data_ptr(), ws.numel(), engine._stream()), "lt_influence_rows")
+    finally:
+        _lib.set_tuning("pair_marks", None)
+    wide = wide.cpu().numpy()
+    assert np.array_equal(wide[:, :len(obs)], want) and np.all(wide[:, len(obs):] == -1.0)

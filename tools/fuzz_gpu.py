@@ -72,7 +72,7 @@ def main():
         knobs = {"pair_marks": int(rng.choice([-1, 0])), "bits_max_bytes": int(rng.choice([1, 1 << 27])),
                  "item_bits": int(rng.choice([0, 1, 1])), "hub_short_side": int(rng.choice([0, 1])), "tiled_min_bytes": int(rng.choice([0, 1 << 25])),
                  "chunk_budget_bytes": int(rng.choice([1 << 14, 1 << 30])), "stageb_rows": int(rng.choice([0, 1])),
-                 "z_on_demand": int(rng.choice([0, 1]))}
+                 "z_on_demand": int(rng.choice([0, 1])), "pair_list": int(rng.choice([0, 1, 1]))}
         for k, v in knobs.items():
             _lib.set_tuning(k, v)
         try:
