@@ -406,7 +406,14 @@ class WideBaseline:
             (s0, s1), (t0, t1) = self.h_slices[si], self.c_slices[ti]
             w1s.copy_(self.w1[:, s0:s1]); b1s.copy_(self.b1[s0:s1])
             w2s.copy_(self.w2[s0:s1, t0:t1]); b2s.copy_(self.b2[t0:t1])
-        self._share_products()          # (marks every slice's layers and fp64 parts stale as lt_baseline_refresh does)
+        m = _lib.MODES[mode] if isinstance(mode, str) else mode
+        if m == _lib.MODE_DELTA and all(sub._fp64 for sub, _ in self._subs.values()):
+            # `delta` reads the fp64 pre-activation only: no fp32 X W1[:, s] at all (75 us per hidden slice at twitch size, half of a
+            # 0.34 ms build with H = 512) -- every slice is marked stale, and an fp32 reader that comes later recomputes lazily
+            for sub, _ in self._subs.values():
+                _lib.check(_lib.lib().lt_baseline_refresh(sub._h, _stream()), "lt_baseline_refresh")
+        else:
+            self._share_products()      # (marks every slice's layers and fp64 parts stale as lt_baseline_refresh does)
 
     def shard_refresh(self, enable=True):
         return self

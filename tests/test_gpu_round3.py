@@ -151,6 +151,21 @@ def test_layers_wider_than_the_fused_kernels(gpu, h, c):
     w2_dev.copy_(keep)
     base.refresh()
     assert np.array_equal(base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64), res["delta"])
+    # (round 6) a refresh FOR `delta` forms no fp32 product; the fp32 modes behind it recompute what they read, W1 changed in place too
+    w1_dev = base.w1
+    keep1 = w1_dev.clone()
+    w1_dev.mul_(0.75)
+    base.refresh("delta")
+    d75 = base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64)
+    s75 = base.influence_rows(probes, observe, 1e-4, "sparse").cpu().numpy().astype(np.float64)
+    fresh = engine.baseline_for(hg, base.x, w1_dev, base.b1, base.w2, base.b2)
+    assert np.array_equal(s75, fresh.influence_rows(probes, observe, 1e-4, "sparse").cpu().numpy().astype(np.float64))
+    assert np.array_equal(d75, fresh.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64))
+    w1_dev.copy_(keep1)
+    base.refresh("delta")
+    assert np.array_equal(base.influence_rows(probes, observe, 1e-4, "delta").cpu().numpy().astype(np.float64), res["delta"])
+    base.refresh()
+    assert np.array_equal(base.influence_rows(probes, observe, 1e-4, "sparse").cpu().numpy().astype(np.float64), res["sparse"])
     P64 = {k: torch.from_numpy(w[k]).double() for k in w}
     ref_logits = O.gcn_forward(torch.from_numpy(x).double(), O.to_torch_sparse(a_hat).double(), P64).numpy()
     tol = 2e-5 * max(1.0, np.abs(ref_logits).max())
