@@ -28,6 +28,12 @@ def wall(fn, reps=5):
     return round(float(np.median(ts)) * 1e3, 3)
 
 
+if os.environ.get("LT_SHARD_TRACE"):      # rocprofv3: the build incl. the baseline alone, 10 times (tools/host_lab/shard_trace.sh)
+    for m in modes:
+        for _ in range(10):
+            bb.refresh(m); bb.influence_rows(pb, ob, 1e-4, m, out=out)
+        torch.cuda.synchronize()
+    sys.exit(0)
 for m in modes:
     a = wall(lambda: bb.influence_rows(pb, ob, 1e-4, m, out=out))
     b = wall(lambda: (bb.refresh(m), bb.influence_rows(pb, ob, 1e-4, m, out=out)))
