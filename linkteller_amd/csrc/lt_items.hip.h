@@ -310,11 +310,22 @@ static __global__ __launch_bounds__(256) void k_pm_lists(const int32_t *__restri
             const int t = __shfl_up(incl, m, 64);
             if (lane >= m) incl += t;
         }
-        const int total = __shfl(incl, 63, 64);
-        int base = 0;
-        if (lane == 63 && total > 0) base = atomicAdd(cursor, total);
-        base = __shfl(base, 63, 64);
-        if (claim) start[r] = base + incl - mine;
+        // (round 6: ... and a BLOCK asks once -- returning adds on one word are served one after the other by that word's L2 channel,
+        // ~6 ns each: the 8 K waves of a 4 096-node observed list still made this launch 51 us)
+        __shared__ int s_tot[4];
+        __shared__ int s_base;
+        const int wid = threadIdx.x >> 6;
+        if (lane == 63) s_tot[wid] = incl;
+        __syncthreads();
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            before += w < wid ? s_tot[w] : 0;
+            all += s_tot[w];
+        }
+        if (threadIdx.x == 0) s_base = all > 0 ? atomicAdd(cursor, all) : 0;
+        __syncthreads();
+        if (claim) start[r] = s_base + before + incl - mine;
     } else if (on) list[start[r] + rank[k]] = j;
 }
 
