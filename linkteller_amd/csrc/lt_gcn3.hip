@@ -94,8 +94,9 @@ __global__ __launch_bounds__(LT_BLOCK) void k3_rows_relu(
 // fire-and-forget and the list costs one add per 256 bitmap words that hold anything.)
 __global__ __launch_bounds__(LT_BLOCK) void k3_mark2(
     const int32_t *__restrict__ tptr, const int32_t *__restrict__ trow, const int32_t *__restrict__ probes, int nb,
-    const int32_t *__restrict__ off, int words, uint32_t *__restrict__ bits2) {
+    const int32_t *__restrict__ off, int words, uint32_t *__restrict__ bits2, int32_t *__restrict__ n_items2) {
     const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_items2 = 0;      // (k3_list2's cursor: cleared here instead of by a memset of its own)
     const int total = off[nb];
     const int wave0 = (blockIdx.x * LT_BLOCK + threadIdx.x) >> 6;
     const int nwaves = gridDim.x * (LT_BLOCK / 64);
@@ -736,8 +737,8 @@ extern "C" int lt_influence3_rows_mode(const lt_baseline3 *b, const int32_t *pro
         if (rc) return rc;
         // level 2: R2 and its items
         LT_HIP(hipMemsetAsync(w.bits2, 0, (size_t)nb * words * sizeof(uint32_t), st));
-        LT_HIP(hipMemsetAsync(w.n_items2, 0, sizeof(int32_t), st));
-        hipLaunchKernelGGL(k3_mark2, dim3(LT3_GRID), dim3(LT_BLOCK), 0, st, g->tptr, g->trow, probes, nb, w.off, words, w.bits2);
+        hipLaunchKernelGGL(k3_mark2, dim3(LT3_GRID), dim3(LT_BLOCK), 0, st, g->tptr, g->trow, probes, nb, w.off, words, w.bits2,
+                           w.n_items2);
         LT_CHECK_LAUNCH();
         hipLaunchKernelGGL(k3_list2, dim3((unsigned)nb), dim3(LT_BLOCK), 0, st, words, w.bits2, w.items2, w.n_items2);
         LT_CHECK_LAUNCH();
