@@ -111,6 +111,10 @@ int lt_device_count(int *count);
  *                         marked pairs are compacted into a list, the result rows zero-filled, and the pair kernel walks the list (default;
  *                         calls whose list would exceed 256 MiB keep the other form), 0 = every pair's lane group reads its own mark.
  *                         Bit-identical
+ *   "i8_split"            the fp64 product X*W1 of LT_MODE_DELTA on DENSE features (n >= 256, F >= 256, H a multiple of 64): 1 = as an
+ *                         error-free integer split on the int8 matrix cores (X five, W1 four signed base-256 digits, fourteen digit
+ *                         pairs, exact integer sums, one rounding per K slice: rows within 5e-10 of their largest value of the fp64
+ *                         product; default), 0 = on the f64 matrix cores.  Results agree to < 1e-6 of the largest score
  *   "gcn3_product_gather" lt_influence3_rows, LT_MODE_DELTA: 1 = the probes' fp64 product rows X[v] W1 are read off the product the baseline
  *                         already holds for every row (default), 0 = formed again on the f64 matrix cores (as on the aggregate-first
  *                         route).  fp64 summation order / storage only: results agree to < 1e-6 of the largest score

@@ -60,6 +60,7 @@ static lt_tuning tuning_defaults() {
     t.feature_flags = env_ll("LT_FEATURE_FLAGS", 1) != 0 ? 1 : 0;
     t.export_sparse = env_ll("LT_EXPORT_SPARSE", 1) != 0 ? 1 : 0;
     t.pair_list = env_ll("LT_PAIR_LIST", 1) != 0 ? 1 : 0;
+    t.i8_split = env_ll("LT_I8_SPLIT", 1) != 0 ? 1 : 0;
     t.gcn3_product_gather = env_ll("LT_GCN3_PRODUCT_GATHER", 1) != 0 ? 1 : 0;
     t.export_zero_blocks = (int)std::min<long long>(4096, std::max<long long>(1, env_ll("LT_EXPORT_ZERO_BLOCKS", 16)));
     t.export_zero_inflight = (int)std::min<long long>(64, std::max<long long>(1, env_ll("LT_EXPORT_ZERO_INFLIGHT", 4)));
@@ -113,6 +114,7 @@ extern "C" int lt_set_tuning(const char *key, long long value) {
     else if (!strcmp(key, "feature_ring")) t.feature_ring = reset ? d.feature_ring : (value < 0 ? -1 : (value != 0));
     else if (!strcmp(key, "feature_flags")) t.feature_flags = reset ? d.feature_flags : (value != 0);
     else if (!strcmp(key, "pair_list")) t.pair_list = reset ? d.pair_list : (value != 0);
+    else if (!strcmp(key, "i8_split")) t.i8_split = reset ? d.i8_split : (value != 0);
     else if (!strcmp(key, "gcn3_product_gather")) t.gcn3_product_gather = reset ? d.gcn3_product_gather : (value != 0);
     else if (!strcmp(key, "export_sparse")) t.export_sparse = reset ? d.export_sparse : (value != 0);
     else if (!strcmp(key, "export_zero_share2")) t.export_zero_share2 = reset ? d.export_zero_share2 : (int)std::min<long long>(100, std::max<long long>(0, value));

@@ -1156,19 +1156,40 @@ static int quant_rows(lt_baseline *b, const double *S, hipStream_t st) {
     LT_CHECK_LAUNCH();
     return LT_OK;
 }
+#include "lt_i8_split.hip.h"
+// "i8_split": the product on the int8 matrix cores as an error-free split (lt_i8_split.hip.h: X as five, W1 as four signed base-256
+// digits, the fourteen digit pairs of order >= 3, exact integer sums per order, one rounding per K slice) when the baseline holds
+// the digit buffers (shapes lt_i8_shapes_ok) -- rows within 5e-10 of the row's largest value of the fp64 product, the error of the
+// 32-bit fixed-point rows they are stored as
+static bool i8_route(const lt_baseline *b) {
+    return lt_tune().i8_split != 0 && b->i8_wd != nullptr && b->i8_ew != nullptr && lt_i8_shapes_ok(b->n, b->H, b->F);
+}
 static int launch_dense_s1d(lt_baseline *b, int r0, int r1, double *dst, long ldd_out, hipStream_t st, bool quant = false) {
     const int H = b->H, n = b->n, F = b->F, m = r1 - r0;
     if (m <= 0) return LT_OK;
     // the K slicing is that of the FULL product whatever the row range: a row has the same bits whichever rank computed it
     const int kslice = fp64_kslice(n, H, F);
-    const int splits = (F + kslice - 1) / kslice;
+    const bool i8 = i8_route(b) && b->slabs_d != nullptr;
+    const int splits = i8 ? lt_i8_slices(n, H, F) : (F + kslice - 1) / kslice;
     const bool big = fp64_big(n, H);
     dim3 grid(big ? (m + GE_BM - 1) / GE_BM : (m + GD_BM - 1) / GD_BM, big ? H / GE_BN : (H + GD_BN - 1) / GD_BN, splits);
-    double *out = splits > 1 ? b->slabs_d : dst;
+    double *out = (splits > 1 || i8) ? b->slabs_d : dst;
     const long ldd = splits > 1 ? (long)H : ldd_out;
     const long stride = splits > 1 ? (long)m * H : 0L;
     const float *A = b->X + (size_t)r0 * b->ldx;
-    if (big)
+    if (i8) {
+        // W1's digits (it may have changed since the last refresh), then this row range's slabs: one fp64 partial per K slice
+        int rc = lt_launch_i8_w_digits(b->W1, n, F, H, b->i8_wd, b->i8_ew, st);
+        if (rc) return rc;
+        rc = lt_launch_gemm_i8split<3>(A, (long)b->ldx, m, n, F, H, b->i8_wd, b->i8_ew, b->slabs_d, st);
+        if (rc) return rc;
+        if (splits == 1) {      // (one slice: the slab is the product; the sums below expect at least two)
+            const long tot = (long)m * H;
+            hipLaunchKernelGGL(k_sum_slabs_f64, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, b->slabs_d, tot, 1, tot, H, dst, ldd_out);
+            LT_CHECK_LAUNCH();
+            return quant ? quant_rows(b, dst, st) : LT_OK;
+        }
+    } else if (big)
         hipLaunchKernelGGL(k_gemm_f64acc_128, grid, dim3(256), 0, st, A, (long)b->ldx, b->W1, (long)H, out, ldd, m, H, F,
                            splits > 1 ? kslice : (F > 0 ? F : 1), stride);
     else
@@ -1769,13 +1790,19 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     float *fs1x = nullptr, *fz1x = nullptr;
     double *fs1q = nullptr;
     int *gate = nullptr;
+    int8_t *i8wd = nullptr;
+    unsigned *i8ew = nullptr;
     int32_t *zst = nullptr, *zrw = nullptr, *zct = nullptr, *zit = nullptr, *zic = nullptr;
     hipError_t e = hipMalloc((void **)&z1d, nh);
     if (e == hipSuccess) e = hipMemsetAsync(z1d, 0, nh, st);      // (pad columns stay zero on every route)
     if (alloc_s1d) {
         if (e == hipSuccess) e = hipMalloc((void **)&s1d, nh);
         if (e == hipSuccess && lt_f64_seg_rows(b->g) > 0) e = hipMalloc((void **)&segd, (size_t)lt_f64_seg_rows(b->g) * b->Hp * sizeof(double));
-        if (e == hipSuccess && splits > 1) e = hipMalloc((void **)&slabs, (size_t)splits * n1 * b->H * sizeof(double));
+        const bool i8_ok = lt_i8_shapes_ok(b->n, b->H, b->F);
+        const int slab_n = std::max(splits > 1 ? splits : 0, i8_ok ? lt_i8_slices(b->n, b->H, b->F) : 0);
+        if (e == hipSuccess && slab_n > 0) e = hipMalloc((void **)&slabs, (size_t)slab_n * n1 * b->H * sizeof(double));
+        if (e == hipSuccess && i8_ok) e = hipMalloc((void **)&i8wd, lt_i8_wd_bytes(b->H, b->F));
+        if (e == hipSuccess && i8_ok) e = hipMalloc((void **)&i8ew, lt_i8_ew_bytes(b->n, b->H, b->F));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&cref, (size_t)b->Hp * sizeof(double));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&fslabs, fd_slab_doubles(b->F, b->H) * sizeof(double));
         if (e == hipSuccess && fd_possible) e = hipMalloc((void **)&gate, FR_GATE_WORDS * sizeof(int));
@@ -1800,11 +1827,13 @@ extern "C" int lt_baseline_enable_fp64(lt_baseline *b, void *stream) {
     if (e != hipSuccess) {   // all or nothing: a retry starts from a clean state, nothing leaks
         (void)hipFree(s1d); (void)hipFree(z1d); (void)hipFree(slabs); (void)hipFree(segd);
         (void)hipFree(cref); (void)hipFree(fslabs); (void)hipFree(gate); (void)hipFree(fref); (void)hipFree(frs); (void)hipFree(fs1x); (void)hipFree(fz1x); (void)hipFree(fs1q);
+        (void)hipFree(i8wd); (void)hipFree(i8ew);
         (void)hipFree(yd); (void)hipFree(segy); (void)hipFree(zst); (void)hipFree(zrw); (void)hipFree(zct); (void)hipFree(zit); (void)hipFree(zic);
         if (hint_host) (void)hipHostFree(hint_host);
         return lt_set_error(LT_ERR_HIP, "lt_baseline_enable_fp64: hipMalloc failed: %s", hipGetErrorString(e));
     }
     b->S1d = s1d; b->Z1d = z1d; b->slabs_d = slabs; b->seg_d = segd;
+    b->i8_wd = i8wd; b->i8_ew = i8ew;
     b->fd_cref = cref; b->fd_slabs = fslabs; b->fd_gate = gate; b->fd_ref = fref; b->fd_rs = frs; b->S1x = fs1x; b->Z1x = fz1x; b->S1qs = fs1q;
     if (frs && b->n > 0) {
         hipLaunchKernelGGL(k_row_sums, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, st, b->n, b->g->rowptr, b->g->val, frs);
@@ -1956,6 +1985,8 @@ void lt_baseline_free_fp64(lt_baseline *b) {
     if (b->S1d_owned) (void)hipFree(b->S1d);
     (void)hipFree(b->Z1d);
     (void)hipFree(b->slabs_d);
+    (void)hipFree(b->i8_wd);
+    (void)hipFree(b->i8_ew);
     (void)hipFree(b->seg_d);
     (void)hipFree(b->fd_cref);
     (void)hipFree(b->fd_slabs);
@@ -1984,6 +2015,7 @@ void lt_baseline_free_fp64(lt_baseline *b) {
     (void)hipFree(b->zicount);
     b->zitems = b->zicount = nullptr;
     b->S1d = b->Z1d = b->slabs_d = b->seg_d = b->fd_cref = b->fd_slabs = b->Yd = b->seg_y = nullptr;
+    b->i8_wd = nullptr; b->i8_ew = nullptr;
     b->fd_gate = nullptr;
     b->zstate = b->zrows = b->zcount = nullptr;
     b->fp64_fresh = false;

@@ -1,7 +1,8 @@
-// LAB (not part of the library): the fp64-grade product S1d = X * W1 of dense features on the INT8 matrix cores of gfx950
+// The fp64-grade product S1d = X * W1 of dense features on the INT8 matrix cores of gfx950 (round 5: a lab; round 6: the product route
+// "i8_split" of lt_fp64.hip's launch_dense_s1d)
 // (v_mfma_i32_32x32x32_i8: 2x the bf16 rate, ~60x the f64 rate) -- the error-free-split form of the product LT_MODE_DELTA's kink
-// test needs (reference: gcn/layers.py:31, `support = torch.mm(input, self.weight)`; round-4 review item 5).  Results and the
-// reason it stayed a lab: profiles/r05_i8_split_lab.txt, NOTES.md (round 5).
+// test needs (reference: gcn/layers.py:31, `support = torch.mm(input, self.weight)`; round-4 review item 5).  Measurements:
+// profiles/r05_i8_split_lab.txt, NOTES.md (rounds 5 and 6).
 //
 //   * per (row, K slice) of X and per (column, K slice) of W1 one power-of-two scale; X becomes a 39-bit fixed-point integer
 //     (FIVE signed base-256 digits: an fp32 within 2^-15 of its row's largest value is represented exactly), W1 a 31-bit one (four);
@@ -466,7 +467,11 @@ __global__ __launch_bounds__(512) void k_gemm_i8split3(const float *__restrict__
 int lt_i8_steps(int F) { return (F + I8_KS - 1) / I8_KS; }
 int lt_i8_steps_per_slice(int n, int H, int F) {
     const int steps = lt_i8_steps(F);
+#ifdef LT_I8_LAB
     static const int forced = [] { const char *e = getenv("LT_I8_SLICES"); return e ? atoi(e) : 0; }();
+#else
+    const int forced = 0;
+#endif
     const long tiles = (long)((n + I8_BM - 1) / I8_BM) * ((lt_round_up(H, 64) + I8_BN - 1) / I8_BN);
     long want = forced > 0 ? forced : 512 / tiles;
     if (want < 1) want = 1;

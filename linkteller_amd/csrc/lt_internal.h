@@ -91,6 +91,8 @@ struct lt_baseline {
     double *S1d = nullptr;      // [n, Hp]
     double *Z1d = nullptr;      // [n, Hp]
     double *slabs_d = nullptr;  // split-K partials
+    int8_t *i8_wd = nullptr;    // W1's signed base-256 digits and ...
+    unsigned *i8_ew = nullptr;  // ... the exponents of its (column, K slice) scales: the int8 split of the dense fp64 product (lt_i8_split.hip.h)
     double *seg_d = nullptr;    // [g->p_n_seg, Hp] fp64 segment sums of the long rows
     bool S1d_owned = true;      // false after lt_baseline_attach_s1d: S1d is caller storage filled by the ranks' all-gather
     bool S1d_external = false;  // the fp64 product arrives from outside (lt_baseline_refresh_rows_fp64 + the caller's all-gather)
@@ -183,6 +185,7 @@ struct lt_tuning {
                                  // a ballot per value (0: round 5's list order) (LT_FEATURE_FLAGS)
     int pair_list;               // SPARSE / DELTA stage B with pair marks: 1 the marked pairs are compacted into a list and walked 8 to a wave (default),
                                  // 0 every pair's group reads its mark (LT_PAIR_LIST)
+    int i8_split;                // dense-feature fp64 product: 1 the error-free split on the int8 matrix cores (default), 0 the f64 cores (LT_I8_SPLIT)
     int gcn3_product_gather;     // GCN3 `delta`: 1 the probes' fp64 product rows are read off the inner baseline's product (default), 0 formed again
                                  // as X[probes] W1 on the f64 cores (LT_GCN3_PRODUCT_GATHER)
     int export_sparse;           // lt_influence_rows_f64, fused route behind a refresh: 1 the first "export_zero_share" % rows of the float64

@@ -538,3 +538,65 @@ def test_marked_pairs_as_a_list_give_the_per_pair_bits(gpu, mode):
         _lib.set_tuning("pair_marks", None)
     wide = wide.cpu().numpy()
     assert np.array_equal(wide[:, :len(obs)], want) and np.all(wide[:, len(obs):] == -1.0)
+
+
+@pytest.mark.parametrize("n,f,h,kind", [(700, 300, 64, "gaussian"), (1500, 1000, 256, "gaussian"), (1500, 1000, 128, "outliers")])
+def test_dense_product_on_the_int8_cores_against_the_f64_cores(gpu, n, f, h, kind):
+    """"i8_split": the fp64 product of dense features as an error-free integer split on the int8 matrix cores -- `delta` within 1e-6 of the
+    largest score of the f64 cores' matrix and within 1e-5 of the fp64 oracle (features with 60-sigma outliers included: they set
+    a row's scale), the same bits run to run and whichever row range of the product a launch forms (the sharded refresh)."""
+    from linkteller_amd import _lib, engine, graph, synth
+    from test_gpu_parity import _oracle_matrix
+    adj = synth.erdos_renyi_graph(n, 6 * n, seed=1)
+    a_hat = graph.first_order_gcn(adj)
+    hg = graph.HipGraph(a_hat)
+    x = synth.gaussian_features(n, f, seed=2)
+    if kind == "outliers":
+        rs = np.random.RandomState(3)
+        x[rs.randint(0, n, 200), rs.randint(0, f, 200)] = 60.0
+    w = synth.gcn_weights(f, h, 2, seed=3)
+    rng = np.random.RandomState(4)
+    obs = rng.choice(n, 120, replace=False)
+    probes = obs[:40]
+
+    def run(i8):
+        _lib.set_tuning("i8_split", i8)
+        _lib.set_tuning("aggregate_first", 0)
+        try:
+            base = engine.Baseline(hg, torch.from_numpy(x).to(gpu), *_params(w, gpu))
+            outs = [base.influence_rows(probes, obs, 1e-4, "delta").cpu().numpy().astype(np.float64)]
+            base.refresh("delta")
+            outs.append(base.influence_rows(probes, obs, 1e-4, "delta").cpu().numpy().astype(np.float64))
+            assert base.fp64_route() == 0 and np.array_equal(outs[0], outs[1])
+            return base, outs[0]
+        finally:
+            _lib.set_tuning("i8_split", None)
+            _lib.set_tuning("aggregate_first", None)
+
+    _, f64 = run(0)
+    base, i8 = run(1)
+    ref64 = _oracle_matrix(a_hat, x, w, probes, obs, 1e-4, torch.float64)
+    scale = ref64.max()
+    assert np.abs(i8 - f64).max() <= 1e-6 * scale, np.abs(i8 - f64).max() / scale
+    assert np.abs(i8 - ref64).max() <= 1e-5 * scale and np.abs(f64 - ref64).max() <= 1e-5 * scale
+    assert np.all(i8[ref64 == 0] == 0)
+    # the product formed in row ranges (what a rank of a sharded refresh does): the rows have the bits of the whole product's
+    _lib.set_tuning("i8_split", 1)
+    _lib.set_tuning("aggregate_first", 0)
+    try:
+        hp = (h + 3) // 4 * 4
+        whole = torch.empty((n, hp), dtype=torch.float64, device=gpu)
+        _lib.check(_lib.lib().lt_baseline_refresh_rows_fp64(base._h, 0, n, whole.data_ptr(), engine._stream()), "rows_fp64")
+        parts = torch.empty((n, hp), dtype=torch.float64, device=gpu)
+        cuts = [0, 77, 640, n]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            _lib.check(_lib.lib().lt_baseline_refresh_rows_fp64(base._h, a, b, parts[a:].data_ptr(), engine._stream()), "rows_fp64")
+        assert torch.equal(whole, parts)
+        host = x.astype(np.float64) @ w["W1"].astype(np.float64)
+        got = whole.cpu().numpy()[:, :h]
+        rowmax = np.abs(host).max(axis=1, keepdims=True)
+        assert (np.abs(got - host) / rowmax).max() <= 2e-9
+    finally:
+        _lib.set_tuning("i8_split", None)
+        _lib.set_tuning("aggregate_first", None)
+        base.refresh()

@@ -3,7 +3,7 @@
 // checks 256 rows against a host fp64 product and times the three launches.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DLT_I8_LAB -I tools/i8_lab tools/i8_lab/i8_lab.hip -o /tmp/i8_lab && /tmp/i8_lab
 #define LT_I8_LAB
-#include "i8_split.hip"
+#include "../../linkteller_amd/csrc/lt_i8_split.hip.h"
 #include <cmath>
 #include <random>
 #include <vector>
