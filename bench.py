@@ -49,6 +49,29 @@ FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 matrix peak
 # v_mfma_f64_16x16x4_f64 issues in 64 cycles (measured: tools/fold_test/mfma_peak.hip) = 32 FLOP/clk/SIMD, half the F32
 # row of the guide's matrix-core table: 32 x 4 SIMD x 256 CU x 2.4 GHz
 FP64_MFMA_PEAK_TFLOPS = 78.6
+INT8_MFMA_PEAK_TOPS = 5000.0   # MI355X_MICROARCH.md: I8 MFMA = 2x the BF16 rate per clock (BF16 ~2.5 PF dense)
+
+
+def dense_product_roofline(rows_x, f, h, n, us, traffic=None):
+    """Roofline object of the dense-feature fp64 product at `us` microseconds per refresh: on the int8 matrix cores as an error-free
+    split ("i8_split", default where the shapes allow -- 14 digit-pair products of 2*rows*F*H integer ops each) or on the f64 cores."""
+    sec = us * 1e-6 if us else None
+    flop = 2.0 * rows_x * f * h
+    i8 = os.environ.get("LT_I8_SPLIT", "1") != "0" and n >= 256 and 256 <= f < 32768 and h >= 64 and h % 64 == 0
+    if i8:
+        ops = 14.0 * flop
+        return {"kernel": "k_gemm_i8split (+ k_i8_w_max, k_i8_w_digits, k_sum_slabs_f64_q)", "bound": "mfma",
+                "achieved": round(ops / sec / 1e12, 1) if sec else None, "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s",
+                "frac": round(ops / sec / 1e12 / INT8_MFMA_PEAK_TOPS, 4) if sec else None, "traffic": traffic, "avg_launch_us": us,
+                "units_per_launch": f"X[{rows_x}x{f}] * W1[{f}x{h}] as 14 int8 digit-pair products (v_mfma_i32_32x32x32_i8), exact integer sums, "
+                                    f"one rounding per K slice; the time includes W1's digits and the slab sum",
+                "algorithmic_flop_per_launch": flop, "fp64_equivalent_TFLOPs": round(flop / sec / 1e12, 2) if sec else None,
+                "f64_mfma_peak_TFLOPs": FP64_MFMA_PEAK_TFLOPS}
+    return {"kernel": "k_gemm_f64acc_128 (+ k_sum_slabs_f64)", "bound": "mfma", "achieved": round(flop / sec / 1e12, 2) if sec else None,
+            "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if sec else None,
+            "traffic": traffic, "avg_launch_us": us,
+            "units_per_launch": f"X[{rows_x}x{f}] * W1[{f}x{h}], fp32 operands, fp64 accumulation (v_mfma_f64_16x16x4_f64)",
+            "algorithmic_flop_per_launch": flop}
 
 # kernel name (prefix) -> profile class, for the PMC passes
 KERNEL_CLASS = (("k_s1d_feature_rows", "fp64_product"), ("k_ref_product", "fp64_product"), ("k_ref_vector", "fp64_product"), ("k_gemm_f64", "fp64_product"),
@@ -734,11 +757,7 @@ def main():
                                         f"reference row); bytes = N*F*4 + F*H*4 + N*H*{out_b}"}
         if cls == "fp64_product":
             rows_x = (lt_dist.shard_bounds(n, rank, world)[1] - lt_dist.shard_bounds(n, rank, world)[0]) if baseline_sharded else n
-            flop = 2.0 * rows_x * f * h
-            return {"kernel": "k_gemm_f64acc_128 (+ k_sum_slabs_f64)", "bound": "mfma", "achieved": round(flop / sec / 1e12, 2),
-                    "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": tr,
-                    "avg_launch_us": us, "units_per_launch": f"X[{rows_x}x{f}] * W1[{f}x{h}], fp32 operands, fp64 accumulation (v_mfma_f64_16x16x4_f64)",
-                    "algorithmic_flop_per_launch": flop}
+            return dense_product_roofline(rows_x, f, h, n, us, tr)
         if cls in ("fp64_spmm", "layer1"):
             alg = spmm_bytes(n, nnz, hp, 8 if cls == "fp64_spmm" else 4)
             return {"kernel": "k_spmm_f64" if cls == "fp64_spmm" else "k_layer1", "bound": "hbm", "achieved": round(alg / sec / 1e9, 1), "peak": HBM_PEAK_GBS,
@@ -880,14 +899,12 @@ def main():
                 tot, cnt = kernel_ms("fp64_product")
                 _lib.lib().lt_profile_enable(0)
                 us = round(tot / cnt * 1e3, 2) if cnt else None
-                flop = 2.0 * n * f * h
                 extras["other_modes"]["delta_dense_features"] = {
                     "pairs_per_s": round(a.n_test ** 2 * a.steps / el, 1), "ms_per_step": round(el / a.steps * 1e3, 4),
                     "max_abs_diff_vs_value_mode": float((res - ref_value).abs().max().item()),
-                    "roofline": {"kernel": "k_gemm_f64acc_128 (+ k_sum_slabs_f64)", "bound": "mfma", "avg_launch_us": us,
-                                 "achieved": round(flop / (us * 1e-6) / 1e12, 2) if us else None, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": round(flop / (us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if us else None},
-                    "note": "feature_delta = 0: X*W1 in fp64 on the matrix cores, as for features that are not sparse differences"}
+                    "roofline": dense_product_roofline(n, f, h, n, us),
+                    "note": "feature_delta = 0: X*W1 at fp64 grade on the matrix cores (round 6: the error-free split on the int8 cores; 0.163 ms "
+                            "on the f64 cores, LT_I8_SPLIT=0), as for features that are not sparse differences"}
             finally:
                 _lib.set_tuning("feature_delta", None)
                 base.refresh()
