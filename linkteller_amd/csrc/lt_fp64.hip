@@ -269,9 +269,17 @@ __global__ void k_sum_slabs_f64(const double *__restrict__ slabs, long slab_stri
 // k_s1d_feature_rows: q = round(value / scale), scale = row max / 2^31): one wave per row, a lane per 4 columns (H <= 256).
 // Round 5: the matrix-core route stores its product rows like that too -- half the bytes the fp64 SpMM gathers and stage A reads.
 __global__ __launch_bounds__(256) void k_sum_slabs_f64_q(const double *__restrict__ slabs, long slab_stride, int splits, int M, int N,
-                                                         int Hp, float *__restrict__ S1x, double *__restrict__ S1qs) {
+                                                         int Hp, float *__restrict__ S1x, double *__restrict__ S1qs,
+                                                         int32_t *__restrict__ zstate = nullptr, unsigned *__restrict__ zero_words = nullptr,
+                                                         int n_zero = 0) {
+    // zstate != NULL: every row's pre-activation is marked stale here (saves the refresh a memset launch, as k_s1d_feature_rows does);
+    // zero_words: the int8 split's exponent words, cleared for the NEXT refresh's k_i8_w_max (the product kernel in front of this
+    // launch was their last reader) -- two ~3 us memsets of a 0.12 ms dense-feature build
+    if (zero_words && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < n_zero; i += 256) zero_words[i] = 0u;
     const int row = (int)(((long)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
+    if (zstate && lane == 0) zstate[row] = 0;
     const int c0 = 4 * lane;
     double o[4] = {0.0, 0.0, 0.0, 0.0};
     if (c0 < N) {       // (N % 4 == 0: 32-byte loads, every slab's in flight before the first add; slab order as k_sum_slabs_f64)
@@ -1164,7 +1172,8 @@ static int quant_rows(lt_baseline *b, const double *S, hipStream_t st) {
 static bool i8_route(const lt_baseline *b) {
     return lt_tune().i8_split != 0 && b->i8_wd != nullptr && b->i8_ew != nullptr && lt_i8_shapes_ok(b->n, b->H, b->F);
 }
-static int launch_dense_s1d(lt_baseline *b, int r0, int r1, double *dst, long ldd_out, hipStream_t st, bool quant = false) {
+static int launch_dense_s1d(lt_baseline *b, int r0, int r1, double *dst, long ldd_out, hipStream_t st, bool quant = false,
+                            int32_t *zstate_rows = nullptr) {      // zstate_rows: cleared by the slab sum (rows [r0, r1) = all rows)
     const int H = b->H, n = b->n, F = b->F, m = r1 - r0;
     if (m <= 0) return LT_OK;
     // the K slicing is that of the FULL product whatever the row range: a row has the same bits whichever rank computed it
@@ -1179,7 +1188,10 @@ static int launch_dense_s1d(lt_baseline *b, int r0, int r1, double *dst, long ld
     const float *A = b->X + (size_t)r0 * b->ldx;
     if (i8) {
         // W1's digits (it may have changed since the last refresh), then this row range's slabs: one fp64 partial per K slice
-        int rc = lt_launch_i8_w_digits(b->W1, n, F, H, b->i8_wd, b->i8_ew, st);
+        // (the exponent words are zero already when the last product's slab sum cleared them)
+        const bool clean = b->i8_ew_clean;
+        b->i8_ew_clean = false;
+        int rc = lt_launch_i8_w_digits(b->W1, n, F, H, b->i8_wd, b->i8_ew, st, !clean);
         if (rc) return rc;
         rc = lt_launch_gemm_i8split<3>(A, (long)b->ldx, m, n, F, H, b->i8_wd, b->i8_ew, b->slabs_d, st);
         if (rc) return rc;
@@ -1198,8 +1210,10 @@ static int launch_dense_s1d(lt_baseline *b, int r0, int r1, double *dst, long ld
     LT_CHECK_LAUNCH();
     if (splits > 1 && quant && b->slabs_d) {
         hipLaunchKernelGGL(k_sum_slabs_f64_q, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, b->slabs_d, (long)m * H, splits, m, H, b->Hp,
-                           b->S1x, b->S1qs);
+                           b->S1x, b->S1qs, zstate_rows, i8 ? b->i8_ew : (unsigned *)nullptr,
+                           i8 ? (int)(lt_i8_ew_bytes(n, H, F) / sizeof(unsigned)) : 0);
         LT_CHECK_LAUNCH();
+        if (i8) b->i8_ew_clean = true;
     } else if (splits > 1) {
         const long tot = (long)m * H;
         hipLaunchKernelGGL(k_sum_slabs_f64, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, b->slabs_d,
@@ -1502,7 +1516,13 @@ static int compute_s1d(lt_baseline *b, hipStream_t st) {
     b->z1x_valid = false;
     // every pre-activation row is stale from here on (the feature-rows kernel resets the words itself)
     const bool feat = !lt_fp64_agg_active(b) && b->S1d && !b->S1d_external && want_feature_rows(b);
-    if (!feat) LT_HIP(hipMemsetAsync(b->zstate, 0, (size_t)n * sizeof(int32_t), st));
+    // (the matrix-core product whose rows leave through k_sum_slabs_f64_q: that launch clears the words)
+    bool dense_resets = false;
+    if (!feat && !lt_fp64_agg_active(b) && b->S1d && !b->S1d_external && dense_quant_possible(b) && b->slabs_d) {
+        const int ks0 = fp64_kslice(n, H, b->F);
+        dense_resets = (i8_route(b) ? lt_i8_slices(n, H, b->F) : (b->F + ks0 - 1) / ks0) > 1;
+    }
+    if (!feat && !dense_resets) LT_HIP(hipMemsetAsync(b->zstate, 0, (size_t)n * sizeof(int32_t), st));
     if (lt_fp64_agg_active(b)) return LT_OK;
     if (!b->S1d)
         return lt_set_error(LT_ERR_UNSUPPORTED, "fp64 pre-activation: the S1d route was not allocated (set \"aggregate_first\" "
@@ -1531,7 +1551,7 @@ static int compute_s1d(lt_baseline *b, hipStream_t st) {
         const bool quant = dense_quant_possible(b);
         const int ks1 = fp64_kslice(n, H, b->F);
         if ((!quant || (b->F + ks1 - 1) / ks1 <= 1) && Hp != H) LT_HIP(hipMemsetAsync(b->S1d, 0, (size_t)n * Hp * sizeof(double), st));
-        int rc = launch_dense_s1d(b, 0, n, b->S1d, (long)Hp, st, quant);
+        int rc = launch_dense_s1d(b, 0, n, b->S1d, (long)Hp, st, quant, dense_resets ? b->zstate : (int32_t *)nullptr);
         if (rc) return rc;
         b->s1_f32 = quant;
     }

@@ -491,9 +491,9 @@ size_t lt_i8_wd_bytes(int H, int F) { return (size_t)lt_i8_steps(F) * I8_WD * lt
 size_t lt_i8_ew_bytes(int n, int H, int F) { return (size_t)lt_i8_slices(n, H, F) * lt_round_up(H, 64) * sizeof(unsigned); }
 
 // W1's digits (once per refresh), then rows [r0, r0 + m) of the product as lt_i8_slices(n, H, F) fp64 slabs of m * H
-int lt_launch_i8_w_digits(const float *W1, int n, int F, int H, int8_t *Wd, unsigned *ewb, hipStream_t st) {
+int lt_launch_i8_w_digits(const float *W1, int n, int F, int H, int8_t *Wd, unsigned *ewb, hipStream_t st, bool clear = true) {
     const int Hc = lt_round_up(H, 64), steps = lt_i8_steps(F), per = lt_i8_steps_per_slice(n, H, F);
-    LT_HIP(hipMemsetAsync(ewb, 0, lt_i8_ew_bytes(n, H, F), st));
+    if (clear) LT_HIP(hipMemsetAsync(ewb, 0, lt_i8_ew_bytes(n, H, F), st));      // (clear = false: the caller's last launch left the words zero)
     hipLaunchKernelGGL(k_i8_w_max, dim3((unsigned)steps, (unsigned)(Hc / 64)), dim3(256), 0, st, W1, F, H, Hc, per, ewb);
     LT_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_i8_w_digits, dim3((unsigned)steps, (unsigned)(Hc / 64)), dim3(256), 0, st, W1, F, H, Hc, per, ewb, Wd);

@@ -92,6 +92,7 @@ struct lt_baseline {
     double *Z1d = nullptr;      // [n, Hp]
     double *slabs_d = nullptr;  // split-K partials
     int8_t *i8_wd = nullptr;    // W1's signed base-256 digits and ...
+    bool i8_ew_clean = false;   // i8_ew holds zeros (the last product's slab sum cleared it)
     unsigned *i8_ew = nullptr;  // ... the exponents of its (column, K slice) scales: the int8 split of the dense fp64 product (lt_i8_split.hip.h)
     double *seg_d = nullptr;    // [g->p_n_seg, Hp] fp64 segment sums of the long rows
     bool S1d_owned = true;      // false after lt_baseline_attach_s1d: S1d is caller storage filled by the ranks' all-gather
