@@ -66,8 +66,9 @@ int lt_abi_version(void);
 int lt_device_count(int *count);
 
 /* ---- tuning knobs (no reference counterpart) ---------------------------------------------------
- * Every setting gives bit-identical results; the knobs choose between kernel routes and are what the
- * tests use to run each route on small inputs.  Defaults come from LT_* environment variables read once.
+ * Every setting gives bit-identical results unless its entry says otherwise (the entries that choose another fp64 summation order
+ * or storage form for LT_MODE_DELTA's product: results then agree to < 1e-6 of the largest score); the knobs choose between kernel
+ * routes and are what the tests use to run each route on small inputs.  Defaults come from LT_* environment variables read once.
  *   "tiled_min_bytes"     S of at least this many bytes takes the tiled SpMM / layer-1 route (default 32 MiB)
  *   "chunk_budget_bytes"  per-call scratch budget that decides the probe chunking (default 1 GiB)
  *   "full_p"              probes per wave of FULL stage A: 8 / 16 / 32, 0 = from the probe count
