@@ -600,3 +600,64 @@ def test_dense_product_on_the_int8_cores_against_the_f64_cores(gpu, n, f, h, kin
         _lib.set_tuning("i8_split", None)
         _lib.set_tuning("aggregate_first", None)
         base.refresh()
+
+
+def test_attacker_sees_every_kind_of_parameter_change(gpu):
+    """Attacker.influence_matrix() between attacks: an in-place update (the baseline's refresh reads the borrowed tensors), a
+    parameter's storage replaced (`p.data = ...`), a parameter object replaced, a submodule replaced, a load_state_dict -- every
+    one gives the matrix of a fresh Attacker on the same weights (the cached state_dict walk and the baseline key's fast path
+    must not outlive what they cached)."""
+    import argparse
+    import contextlib
+    import io
+    import types
+    from linkteller_amd import graph, synth
+    from linkteller_amd.attacker import Attacker
+    from linkteller_amd.gcn import GCN, GraphConvolution
+    n, f, h, c = 600, 80, 32, 3
+    adj = synth.erdos_renyi_graph(n, 2400, seed=1)
+    a_hat = graph.first_order_gcn(adj)
+    x = torch.from_numpy(synth.twitch_like_features(n, f, seed=2, density=0.05)).to(gpu)
+    adj_t = graph.sparse_mx_to_torch_sparse_tensor(a_hat).to(gpu)
+    wk = types.SimpleNamespace(features_2=x, adj_2=adj_t, adj_ori=adj.tocsr(), n_nodes=n)
+    args = argparse.Namespace(dataset="twitch/RU", sample_type="unbalanced", n_test=40, sample_seed=42, influence=1e-4,
+                              mode="vanilla-clean", attack_mode="efficient", influence_mode="delta")
+
+    def attacker(model):
+        atk = Attacker(args, model, wk)
+        with contextlib.redirect_stdout(io.StringIO()):
+            atk.prepare_test_data()
+        return atk
+
+    torch.manual_seed(0)
+    model = GCN(f, h, c, 0.5).to(gpu).eval()
+    atk = attacker(model)
+
+    def fresh():
+        twin = GCN(f, h, c, 0.5).to(gpu).eval()
+        twin.load_state_dict(model.state_dict())
+        return attacker(twin).influence_matrix()
+
+    m0 = atk.influence_matrix()
+    assert np.array_equal(m0, fresh()) and np.array_equal(m0, atk.influence_matrix())
+    steps = []
+    with torch.no_grad():
+        model.gc2.weight.mul_(0.5)                                          # in place
+    steps.append("in place")
+    m1 = atk.influence_matrix()
+    assert np.array_equal(m1, fresh()) and not np.array_equal(m1, m0)
+    model.gc1.weight.data = (model.gc1.weight.data * 1.25).clone()          # the parameter's storage replaced
+    m2 = atk.influence_matrix()
+    assert np.array_equal(m2, fresh()) and not np.array_equal(m2, m1)
+    model.gc2.weight = torch.nn.Parameter(torch.randn_like(model.gc2.weight) * 0.1)     # the parameter object replaced
+    m3 = atk.influence_matrix()
+    assert np.array_equal(m3, fresh()) and not np.array_equal(m3, m2)
+    new_gc1 = GraphConvolution(f, h).to(gpu)                                # a submodule replaced
+    model.gc1 = new_gc1
+    m4 = atk.influence_matrix()
+    assert np.array_equal(m4, fresh()) and not np.array_equal(m4, m3)
+    sd = {k: torch.randn_like(v) * 0.1 for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)                                               # load_state_dict (copies in place)
+    m5 = atk.influence_matrix()
+    assert np.array_equal(m5, fresh()) and not np.array_equal(m5, m4)
+    assert np.array_equal(m5, atk.influence_matrix())
