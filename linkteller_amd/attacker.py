@@ -74,8 +74,19 @@ class Attacker:
         c = getattr(self, "_walk_cache", None)
         if c is not None:
             try:
-                if c[0] is self.model and all(g(self.model) is p and p.data_ptr() == q for g, p, q in c[1]):
-                    return c[2], c[3]
+                if c[0] is self.model:
+                    ok = True
+                    for g, p, q, parent, child, owner, name in c[1]:
+                        # (two dict look-ups instead of nn.Module.__getattr__ twice: "gc1.weight" is model._modules["gc1"]._parameters["weight"])
+                        if owner is not None:
+                            if parent._modules.get(child) is not owner or owner._parameters.get(name) is not p or p.data_ptr() != q:
+                                ok = False
+                                break
+                        elif g(self.model) is not p or p.data_ptr() != q:
+                            ok = False
+                            break
+                    if ok:
+                        return c[2], c[3]
             except AttributeError:
                 pass
         sd = self.model.state_dict()
@@ -96,7 +107,12 @@ class Attacker:
                 prm = g(self.model)
                 if not isinstance(prm, torch.Tensor) or prm.data_ptr() != sd[k].data_ptr():
                     raise AttributeError(k)
-                trip.append((g, prm, prm.data_ptr()))
+                parts = k.split(".")
+                parent = child = owner = name = None
+                if len(parts) == 2 and self.model._modules.get(parts[0]) is not None and \
+                        self.model._modules[parts[0]]._parameters.get(parts[1]) is prm:
+                    parent, child, owner, name = self.model, parts[0], self.model._modules[parts[0]], parts[1]
+                trip.append((g, prm, prm.data_ptr(), parent, child, owner, name))
             self._walk_cache = (self.model, trip, kind, sd)
         except AttributeError:
             pass                   # (a model whose state_dict keys are not attribute paths: walk every time)
