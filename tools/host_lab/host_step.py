@@ -47,13 +47,10 @@ def wall(fn, reps=200):
 print("device-resident step:", wall(v_device), "us")
 for name, t in (("pinned host", pin),):
     print(f"{name}: + export launch {wall(lambda: v_export(t))} us")
-    for share, s2 in ((35, 15), (45, 15), (45, 20), (55, 20)):
+    for share in (0, 25, 30, 35, 40, 45):
         _lib.set_tuning("export_zero_share", share)
-        _lib.set_tuning("export_zero_share2", s2)
-        for zb in (8, 16, 32, 64, 256):
-            _lib.set_tuning("export_zero_blocks", zb)
-            row = [f"shares {share} + {s2} %, {zb} waves, stores in flight:"]
-            for cap in (4, 8, 16, 64):
-                _lib.set_tuning("export_zero_inflight", cap)
-                row.append(f"{cap}: {wall(lambda: v_onecall(t))} us")
-            print("   one call,", " ".join(row))
+        row = [f"share under the product rows {share} %, under the pre-activation:"]
+        for s2 in (0, 10, 15, 20, 25):
+            _lib.set_tuning("export_zero_share2", s2)
+            row.append(f"{s2} %: {wall(lambda: v_onecall(t))} us")
+        print("   one call,", " ".join(row))
